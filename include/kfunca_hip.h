@@ -1,0 +1,219 @@
+/*
+ * kfunca_hip.h — the C ABI of the MI355X (gfx950) device layer.
+ *
+ * This header is the drop-in boundary: everything the reference's host core
+ * (src/core) reaches in its device layer (src/device/include/*.h) is reachable here as an
+ * `extern "C"` function taking plain pointers, sizes and POD descriptors — no C++ types, no
+ * torch types, nothing thrown. Each entry cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - every function returns `int` status: 0 = KF_OK, anything else is an error whose text is
+ *     available from kf_last_error() (thread-local). The host core turns a non-zero status into
+ *     the reference's `utils::Error` (reference: src/core/utils/exception.h:123-131).
+ *   - the device layer owns NO memory: outputs, workspaces and semaphores are allocated by the
+ *     caller (the host core's caching allocator) and handed in. This breaks the reference's
+ *     L1→L2 link cycle (last paragraph).
+ *   - `stream` is a hipStream_t passed as void*; NULL means the device's null stream.
+ *   - dtype codes follow the reference's ScalarType order (src/core/include/scalar_type.h:9-27).
+ */
+#ifndef KFUNCA_HIP_H_
+#define KFUNCA_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KF_ABI_VERSION 1
+
+/* ---- status ------------------------------------------------------------------------------ */
+enum {
+    KF_OK = 0,
+    KF_ERR_HIP = 1,         /* a HIP runtime call or a kernel launch failed                  */
+    KF_ERR_INVALID = 2,     /* bad argument (shape/dtype/alignment/null pointer)             */
+    KF_ERR_UNSUPPORTED = 3, /* valid request the device layer has no kernel for              */
+    KF_ERR_INDEX_RANGE = 4, /* descriptor not 32-bit indexable; caller must split (a6)       */
+    KF_ERR_WORKSPACE = 5,   /* workspace missing or too small                                */
+    KF_ERR_COMM = 6         /* RCCL failure                                                  */
+};
+
+/* ---- dtypes: reference ScalarType order (scalar_type.h:9-27) ------------------------------ */
+enum {
+    KF_BOOL = 0,
+    KF_U8 = 1,
+    KF_I8 = 2,
+    KF_I16 = 3,
+    KF_I32 = 4,
+    KF_I64 = 5,
+    KF_F16 = 6,
+    KF_BF16 = 7,
+    KF_F32 = 8,
+    KF_F64 = 9,
+    KF_DTYPE_COUNT = 10
+};
+
+#define KF_MAX_DIMS 12   /* reference MAX_TENSOR_DIMS, tensor.h:7 */
+#define KF_MAX_TENSORS 8 /* reference TensorIterator::MAX_TENSORS, tensor_iterator.h:22-24 */
+
+/*
+ * The post-build() state of the reference's TensorIterator (tensor_iterator.h:27-47), as a POD.
+ * Operands are ordered outputs first, then inputs. Dimension 0 is the fastest-moving one
+ * (the iterator reorders dims fastest-first, tensor_iterator.cpp:181-244). Strides are BYTES;
+ * a stride of 0 marks a broadcast (input) or reduced (output) dimension.
+ */
+typedef struct kf_iter_desc {
+    int32_t ndim;      /* 1..KF_MAX_DIMS after coalescing                     */
+    int32_t ntensors;  /* noutputs + ninputs, <= KF_MAX_TENSORS              */
+    int32_t noutputs;
+    int32_t reserved;
+    int32_t dtype[KF_MAX_TENSORS];
+    int64_t shape[KF_MAX_DIMS];
+    int64_t stride_bytes[KF_MAX_TENSORS][KF_MAX_DIMS];
+    void *data[KF_MAX_TENSORS];
+} kf_iter_desc;
+
+/* ---- runtime: replaces memory_engine.h:5-10 and Launcher (launcher_cuda.h:105-354) -------- */
+const char *kf_last_error(void);
+int kf_abi_version(void);
+int kf_device_count(int *count);
+int kf_set_device(int device);              /* dset_device, memory_engine.h:5           */
+int kf_get_device(int *device);
+int kf_malloc(void **ptr, size_t bytes);    /* dmalloc, memory_engine.h:6               */
+int kf_free(void *ptr);                     /* dfree, memory_engine.h:7                 */
+int kf_memcpy_h2d(void *dst, const void *src, size_t bytes, void *stream); /* :8  (synchronous on return) */
+int kf_memcpy_d2h(void *dst, const void *src, size_t bytes, void *stream); /* :9  (synchronous on return) */
+int kf_memcpy_d2d(void *dst, const void *src, size_t bytes, void *stream); /* async on stream           */
+int kf_memset_zero(void *ptr, size_t bytes, void *stream);                 /* dmemset_zeros, :10 (async) */
+int kf_stream_create(void **stream);        /* Launcher::stream_begin, launcher_cuda.h:113-118 */
+int kf_stream_destroy(void *stream);
+int kf_stream_sync(void *stream);           /* Launcher::stream_sync, launcher_cuda.h:125-127  */
+int kf_device_sync(void);
+int kf_event_create(void **event);          /* per-launch timing mode, launcher_cuda.h:336-345 */
+int kf_event_destroy(void *event);
+int kf_event_record(void *event, void *stream);
+int kf_event_sync(void *event);
+int kf_event_elapsed_ms(void *start, void *stop, float *ms);
+
+/* per-launch timing mode: replaces Launcher::set_profiling_mode + the cudaEvent pair around each
+ * submit (launcher_cuda.h:253-255,336-345). While enabled, every kernel launch made through this
+ * library is bracketed by a HIP event pair on its own stream (no host sync); kf_profile_get()
+ * synchronises and reports, per kernel name, the number of launches and their summed duration. */
+int kf_profile_enable(int on);
+int kf_profile_reset(void);
+int kf_profile_count(int *n);
+int kf_profile_get(int i, char name[64], double *total_ms, int64_t *launches);
+
+typedef struct kf_device_props {
+    char name[256];
+    char arch[64];
+    int32_t compute_units;
+    int32_t wavefront_size;
+    int32_t max_threads_per_block;
+    int32_t clock_khz;
+    int32_t memory_clock_khz;
+    int32_t memory_bus_bits;
+    int64_t lds_per_block;
+    int64_t l2_bytes;
+    uint64_t total_mem;
+    uint64_t free_mem;
+} kf_device_props;
+int kf_device_props_get(int device, kf_device_props *out); /* device_info.h:5 (query half) */
+
+/* ---- elementwise loops: replaces binary/unary/nullary_ops_kernel.h ------------------------ */
+enum {
+    KF_EW_ADD = 0,  /* add_kernel,  binary_ops_kernel.h:5 */
+    KF_EW_SUB = 1,  /* sub_kernel,  :6 */
+    KF_EW_MUL = 2,  /* mul_kernel,  :7 */
+    KF_EW_DIV = 3,  /* div_kernel,  :8 */
+    KF_EW_COPY = 4, /* copy_kernel, unary_ops_kernel.h:5 (also dtype convert) */
+    KF_EW_FILL = 5  /* fill_kernel, nullary_ops_kernel.h:5 */
+};
+/*
+ * out = f(in...) over the iteration space of `desc` (1 output; 2 inputs for ADD..DIV, 1 for
+ * COPY, 0 for FILL). `compute_dtype` is the reference's iter.common_dtype() for ADD..DIV
+ * (binary_ops_kernel.cu:34-60; arithmetic runs in its accumulate type: float for half/bf16,
+ * int64 for ints, accumulate_type.h:17-27), ignored for COPY (value is cast to the output dtype,
+ * unary_ops_kernel.cu:13-17) and FILL (`scalar` cast to the output's accumulate type then to the
+ * output dtype, nullary_ops_kernel.cu:20-25).
+ * Contiguous descriptors of any size are accepted; strided ones must be 32-bit indexable
+ * (KF_ERR_INDEX_RANGE otherwise — the host splits, tensor_iterator.cpp:415-480).
+ */
+int kf_elementwise(int op, const kf_iter_desc *desc, int compute_dtype, double scalar, void *stream);
+
+/* ---- reductions: replaces reduce_ops_kernel.h:5-6 ------------------------------------------ */
+enum {
+    KF_RED_SUM = 0, /* sum_kernel  */
+    KF_RED_MEAN = 1 /* mean_kernel */
+};
+/*
+ * desc: 1 output, 1 input, built by the reference's build_for_reduce (tensor_iterator.cpp:523-528):
+ * reduced dims are the ones where the OUTPUT stride is 0 and shape > 1.
+ * The caller supplies scratch of at least kf_reduce_workspace_bytes(desc) bytes (may be 0);
+ * it needs no initialisation.
+ */
+int kf_reduce_workspace_bytes(const kf_iter_desc *desc, size_t *bytes);
+int kf_reduce(int op, const kf_iter_desc *desc, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- index_put_: replaces index_ops_kernel.h:5 --------------------------------------------- */
+/*
+ * desc operands: [0] = self viewed with stride 0 (index_ops.cpp:23-25), [1] = values,
+ * [2..2+nidx) = int64 index tensors. For each element n of the iteration space:
+ *   self_bytes[ sum_i wrap(idx_i[n], sizes[i]) * strides_bytes[i] ] = values[n]
+ * Negative indices wrap once; no bounds check; duplicates: last writer wins, unspecified order
+ * (tensor_index.h:56-75).
+ */
+int kf_index_put(const kf_iter_desc *desc, int nidx, const int64_t *sizes, const int64_t *strides_bytes,
+                 void *stream);
+
+/* ---- GEMM: replaces gemm_kernel.h:5 (+ NT/TN forms the backward needs) --------------------- */
+enum {
+    KF_EPI_NONE = 0,
+    KF_EPI_BIAS_ROW = 1 /* C[m,n] += bias[n] after alpha/beta (fused broadcast add, config C4) */
+};
+/*
+ * C[M,N] = alpha * op(A)[M,K] * op(B)[K,N] + beta * C, row-major, leading dims in ELEMENTS.
+ *   trans_a == 0: A is stored [M,K] (lda >= K);  trans_a == 1: A is stored [K,M] (lda >= M)
+ *   trans_b == 0: B is stored [K,N] (ldb >= N);  trans_b == 1: B is stored [N,K] (ldb >= K)
+ * dtype in {KF_F32, KF_F64, KF_F16, KF_BF16}; A, B, C share it; accumulation is f32 (f64 for f64).
+ * beta == 0 never reads C (the reference reads uninitialised memory there, gemm_ops.cpp:10-16).
+ * f16/bf16 may need scratch for operand re-layout: kf_gemm_workspace_bytes() says how much.
+ */
+int kf_gemm_workspace_bytes(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, size_t *bytes);
+int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const void *A,
+            int64_t lda, const void *B, int64_t ldb, float beta, void *C, int64_t ldc, int epilogue,
+            const void *bias, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- causal attention: replaces causal_attention_kernel.h:5 (+ backward) ------------------- */
+/*
+ * q:[B,H,Sq,D], k,v:[B,H,Skv,D], o:[B,H,Sq,D] contiguous; lse:[B,H,Sq] float32 (may be NULL for
+ * inference): lse = m + log(l), the natural-log-sum-exp of the scaled, masked scores.
+ * O = softmax(mask(Q K^T / sqrt(D))) V, mask keeps key n for query m iff m >= n (absolute
+ * indices, top-left aligned: causal_attention_ref.h:36-41).
+ * dtype in {KF_F32 (any D <= 256, any Sq/Skv), KF_BF16, KF_F16 (D in {64,128})}.
+ */
+int kf_attn_fwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, const void *q,
+                const void *k, const void *v, void *o, float *lse, void *stream);
+/*
+ * dq,dk,dv from d_o. Needs o and lse from the forward. workspace holds delta[B,H,Sq] f32 and an
+ * f32 dq accumulator; kf_attn_bwd_workspace_bytes() says how much; no initialisation needed.
+ */
+int kf_attn_bwd_workspace_bytes(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D,
+                                size_t *bytes);
+int kf_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, const void *q,
+                const void *k, const void *v, const void *o, const float *lse, const void *d_o, void *dq,
+                void *dk, void *dv, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- collectives (RCCL over xGMI): the one exchange step of the batch-sharded path (§8e) ---- */
+#define KF_COMM_ID_BYTES 128
+int kf_comm_unique_id(char id[KF_COMM_ID_BYTES]);
+int kf_comm_init(void **comm, const char id[KF_COMM_ID_BYTES], int rank, int world_size);
+int kf_comm_destroy(void *comm);
+/* in-place sum all-reduce of `count` elements of dtype (KF_F32, KF_BF16, KF_F16, KF_F64, ints) */
+int kf_allreduce_sum(void *comm, void *buf, size_t count, int dtype, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KFUNCA_HIP_H_ */

@@ -1,0 +1,117 @@
+"""In-tree builds: the gfx950 device library, the host core + pybind11 module, and the oracle.
+
+hipcc cross-compiles gfx950 without a GPU, so this runs in the build container and the
+resulting .so files travel to the GPU box with the source tree (they are git-ignored).
+Nothing here falls back to anything: a failed compile raises.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+import sysconfig
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+PKG = ROOT / "kfunca_amd"
+CSRC = PKG / "csrc"
+INCLUDE = ROOT / "include"
+BUILD = PKG / "_build"
+ROCM = Path(os.environ.get("ROCM_PATH", "/opt/rocm"))
+
+DEVICE_LIB = PKG / "libkfunca_hip.so"
+CORE_MODULE = PKG / ("_C" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+ORACLE_LIB = ROOT / "oracle" / "liboracle.so"
+
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc",
+             "-Wno-unused-result", f"-I{INCLUDE}", f"-I{CSRC / 'device'}"]
+CXX_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-sign-compare",
+             f"-I{INCLUDE}", f"-I{CSRC / 'core'}"]
+
+
+def _run(cmd, **kw):
+    res = subprocess.run([str(c) for c in cmd], capture_output=True, text=True, **kw)
+    if res.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s\n%s" % (" ".join(map(str, cmd)), res.stdout, res.stderr))
+    return res
+
+
+def _newer(target: Path, deps) -> bool:
+    if not target.exists():
+        return False
+    t = target.stat().st_mtime
+    return all(Path(d).stat().st_mtime <= t for d in deps)
+
+
+def _hipcc() -> str:
+    h = shutil.which("hipcc") or str(ROCM / "bin" / "hipcc")
+    if not Path(h).exists():
+        raise RuntimeError("hipcc not found: the device library cannot be built")
+    return h
+
+
+def build_device(force: bool = False) -> Path:
+    """hipcc --offload-arch=gfx950: kfunca_amd/csrc/device/*.hip -> kfunca_amd/libkfunca_hip.so"""
+    BUILD.mkdir(exist_ok=True)
+    srcs = sorted((CSRC / "device").glob("*.hip"))
+    hdrs = sorted((CSRC / "device").glob("*.h")) + sorted(INCLUDE.glob("*.h"))
+    objs = []
+    jobs = []
+    for s in srcs:
+        o = BUILD / (s.stem + ".o")
+        objs.append(o)
+        if force or not _newer(o, [s] + hdrs):
+            jobs.append([_hipcc(), *HIP_FLAGS, "-c", s, "-o", o])
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+        list(ex.map(_run, jobs))
+    if force or jobs or not _newer(DEVICE_LIB, objs):
+        _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", DEVICE_LIB, *objs,
+              f"-L{ROCM / 'lib'}", "-lrccl", f"-Wl,-rpath,{ROCM / 'lib'}"])
+    return DEVICE_LIB
+
+
+def build_core(force: bool = False) -> Path:
+    """g++: host core (Tensor / TensorIterator / allocator / autograd / ops) + pybind11 module."""
+    import pybind11
+
+    BUILD.mkdir(exist_ok=True)
+    build_device(force)
+    srcs = sorted((CSRC / "core").glob("*.cpp")) + sorted((CSRC / "binding").glob("*.cpp"))
+    hdrs = sorted((CSRC / "core").glob("*.h")) + sorted(INCLUDE.glob("*.h"))
+    py_inc = sysconfig.get_paths()["include"]
+    objs, jobs = [], []
+    for s in srcs:
+        o = BUILD / ("core_" + s.stem + ".o")
+        objs.append(o)
+        if force or not _newer(o, [s] + hdrs):
+            jobs.append(["g++", *CXX_FLAGS, f"-I{pybind11.get_include()}", f"-I{py_inc}", "-c", s, "-o", o])
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as ex:
+        list(ex.map(_run, jobs))
+    if force or jobs or not _newer(CORE_MODULE, objs + [DEVICE_LIB]):
+        _run(["g++", "-shared", "-fPIC", "-o", CORE_MODULE, *objs, f"-L{PKG}", "-lkfunca_hip",
+              "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{ROCM / 'lib'}"])
+    return CORE_MODULE
+
+
+def build_oracle(force: bool = False) -> Path:
+    """gcc: the CPU restatement (test infrastructure only) -> oracle/liboracle.so"""
+    src = ROOT / "oracle" / "oracle.c"
+    hdr = ROOT / "oracle" / "oracle.h"
+    if force or not _newer(ORACLE_LIB, [src, hdr]):
+        _run(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-std=c11", "-o", ORACLE_LIB, src, "-lm"])
+    return ORACLE_LIB
+
+
+def build_all(force: bool = False):
+    build_device(force)
+    if (CSRC / "core").exists() and any((CSRC / "core").glob("*.cpp")):
+        build_core(force)
+    if (ROOT / "oracle" / "oracle.c").exists():
+        build_oracle(force)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)
+    print("built:", DEVICE_LIB, CORE_MODULE if CORE_MODULE.exists() else "", ORACLE_LIB if ORACLE_LIB.exists() else "")

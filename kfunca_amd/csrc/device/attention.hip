@@ -1,0 +1,856 @@
+// Causal attention forward + backward for gfx950.
+//
+// Replaces src/device/causal_attention_kernel.cu:9-72 (+ utils/causal_attention.h,
+// causal_attention_ref.h, block_utils.h). Semantics are the reference's ref kernel
+// (causal_attention_ref.h:25-64): scores = Q K^T / sqrt(D); key n is visible to query m iff
+// m >= n (absolute indices, top-left aligned); max-subtracted softmax; O = P V. The reference
+// has no backward and allocates an O(S^2) scratch on every call (causal_attention_kernel.cu:22);
+// neither is reproduced: the forward also emits LSE = m + log(l) per query so the backward can
+// recompute P, and nothing of size S^2 is ever materialised.
+//
+// Two implementations behind one ABI:
+//  * MFMA path (bf16/f16, D = 128, Sq % 128 == 0, Skv % 64 == 0): flash-style, everything kept in
+//    the "query/key on the lane" orientation so softmax statistics are lane-local:
+//      S^T = K Q^T      A = K rows (LDS, ds_read_b128), B = Q fragments (registers)
+//      O^T += V^T P^T   A = V^T via ds_read_b64_tr_b16 (hardware transpose read of the row-major
+//                        LDS tile), B = the S^T accumulator converted in place to bf16
+//    K/V tiles use one XOR-swizzled LDS image that is conflict-free for both the row reads and
+//    the transposed reads; causal tiles above the diagonal are skipped.
+//    Backward = delta pre-pass + a dQ kernel (same skeleton: S^T, dP^T, dQ^T += K^T dS^T) + a
+//    dK/dV kernel (key on the lane: S, dP, dV^T += dO^T P, dK^T += Q^T dS). Recomputing S/dP
+//    in both kernels costs 7 products instead of 5 but needs no atomics: dQ is bitwise
+//    reproducible and there is no global-atomic floor.
+//  * generic path (f32 — the reference's own dtype — or any ragged shape/head size <= 256):
+//    LDS-tiled f32 online-softmax kernel; backward by two LDS-tiled f32 kernels.
+#include <math.h>
+
+#include "common.h"
+
+namespace kf {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct AttnArgs {
+    const char *q, *k, *v, *o, *d_o;
+    char *out, *dq, *dk, *dv;
+    float *lse;        // forward: written; backward: read
+    const float *lse_r;
+    float *delta;
+    int64_t B, H, Sq, Skv, D;
+    float scale;
+};
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+// ==========================================================================================
+// MFMA path, D = 128
+// ==========================================================================================
+constexpr int AD = 128;              // head size
+constexpr int AROW = AD * 2;         // bytes per row of a 16-bit tile
+constexpr int ABQ = 128, ABK = 64;   // forward / dQ: queries per block, keys per tile
+constexpr int OPAD = AROW + 8;       // epilogue staging row stride (bytes)
+
+template <bool BF> struct AFrag { using type = f16x8; };
+template <> struct AFrag<true> { using type = bf16x8; };
+
+template <bool BF>
+__device__ __forceinline__ f32x16 a_mfma(typename AFrag<BF>::type a, typename AFrag<BF>::type b, f32x16 c) {
+    if constexpr (BF)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// LDS image of a [rows][128 x 16-bit] tile with 256-B rows: 16-B chunk `ch` of row `row` lives at
+// chunk position ch ^ (((row & 3) << 2) | ((row >> 2) & 3)). Conflict-free for ds_read_b128 row
+// reads of 16 consecutive rows and for the 4-row x 16-column blocks of ds_read_b64_tr_b16.
+__device__ __forceinline__ int a_off(int row, int ch) { return row * AROW + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
+
+// A/B fragment of row `row`, k-chunk `ch` (8 consecutive elements)
+template <bool BF>
+__device__ __forceinline__ typename AFrag<BF>::type a_row_frag(const char *tile, int row, int ch) {
+    return *(const typename AFrag<BF>::type *)(tile + a_off(row, ch));
+}
+
+// A fragment of T^T for the product  T^T(cols col0..col0+31) x X  where X is an MFMA accumulator
+// used as the B operand (k order: element j of lane half h <-> row r0 + 8*(j>>2) + 4*h + (j&3)).
+// T is the row-major LDS tile; two transposed reads fetch rows r0+4h+{0..3} and r0+8+4h+{0..3}.
+template <bool BF>
+__device__ __forceinline__ typename AFrag<BF>::type a_tr_frag(const char *tile, int r0, int col0) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, i = lane & 15, qq = i >> 2, p = i & 3, h = g >> 1;
+    const int ch = ((col0 + 16 * (g & 1)) >> 3) + (p >> 1);
+    const int row1 = r0 + 4 * h + qq, row2 = row1 + 8;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4 *)(tile + a_off(row1, ch) + 8 * (p & 1)));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4 *)(tile + a_off(row2, ch) + 8 * (p & 1)));
+    s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(typename AFrag<BF>::type, r);
+}
+
+// registers 8s..8s+7 of an accumulator -> 16-bit B fragment of k-step s
+template <bool BF>
+__device__ __forceinline__ typename AFrag<BF>::type a_pack(const f32x16 &x, int s) {
+    typename AFrag<BF>::type r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if constexpr (BF)
+            r[j] = (__bf16)x[8 * s + j];
+        else
+            r[j] = (_Float16)x[8 * s + j];
+    }
+    return r;
+}
+
+// accumulator row index of register e for lane half h
+__device__ __forceinline__ int a_row(int e, int h) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
+
+// global [nrows][128] 16-bit rows -> registers -> swizzled LDS tile, coalesced 256-B rows.
+// Named members, not arrays: hipcc keeps by-reference uint4[N] staging arrays in scratch.
+struct Stage4 { uint4 a, b, c, d; }; // 64 rows
+struct Stage2 { uint4 a, b; };       // 32 rows
+__device__ __forceinline__ uint4 a_gld(const char *g, int id) { return *(const uint4 *)(g + (int64_t)(id >> 4) * AROW + (id & 15) * 16); }
+__device__ __forceinline__ void a_lst(char *tile, int id, const uint4 &v) { *(uint4 *)(tile + a_off(id >> 4, id & 15)) = v; }
+__device__ __forceinline__ void a_gload(const char *g, Stage4 &r) {
+    const int t = threadIdx.x;
+    r.a = a_gld(g, t); r.b = a_gld(g, t + 256); r.c = a_gld(g, t + 512); r.d = a_gld(g, t + 768);
+}
+__device__ __forceinline__ void a_gload(const char *g, Stage2 &r) {
+    const int t = threadIdx.x;
+    r.a = a_gld(g, t); r.b = a_gld(g, t + 256);
+}
+__device__ __forceinline__ void a_lstore(char *tile, const Stage4 &r) {
+    const int t = threadIdx.x;
+    a_lst(tile, t, r.a); a_lst(tile, t + 256, r.b); a_lst(tile, t + 512, r.c); a_lst(tile, t + 768, r.d);
+}
+__device__ __forceinline__ void a_lstore(char *tile, const Stage2 &r) {
+    const int t = threadIdx.x;
+    a_lst(tile, t, r.a); a_lst(tile, t + 256, r.b);
+}
+
+template <bool BF>
+__device__ __forceinline__ uint32_t a_cvt16(float v) { return BF ? f32_to_bf16(v).x : f32_to_f16(v).x; }
+
+// Write a wave's 32 x 128 result held as X^T accumulators (lane = row, registers = columns of
+// four 32-wide column blocks) as 16-bit rows of `dst` (row stride 256 B), via a per-wave LDS slab.
+template <bool BF>
+__device__ __forceinline__ void a_store_rows(char *slab, char *dst, const f32x16 (&acc)[4], float mul) {
+    const int lane = threadIdx.x & 63, xl = lane & 31, hl = lane >> 5;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const uint32_t h0 = a_cvt16<BF>(acc[db][4 * gq + 0] * mul), h1 = a_cvt16<BF>(acc[db][4 * gq + 1] * mul);
+            const uint32_t h2 = a_cvt16<BF>(acc[db][4 * gq + 2] * mul), h3 = a_cvt16<BF>(acc[db][4 * gq + 3] * mul);
+            uint2 w;
+            w.x = h0 | (h1 << 16);
+            w.y = h2 | (h3 << 16);
+            const int col = db * 32 + 8 * gq + 4 * hl;
+            *(uint2 *)(slab + xl * OPAD + col * 2) = w;
+        }
+    // same wave reads back what it wrote: LDS ops of one wave complete in order
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int id = lane + 64 * i; // 1024 pieces of 8 B: 32 rows x 32 pieces
+        const int row = id >> 5, piece = id & 31;
+        const uint2 w = *(const uint2 *)(slab + row * OPAD + piece * 8);
+        *(uint2 *)(dst + (int64_t)row * AROW + piece * 8) = w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+template <bool BF>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
+    using frag_t = typename AFrag<BF>::type;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *Kt = smem, *Vt = smem + ABK * AROW;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
+    const int qblk = gridDim.x - 1 - blockIdx.x; // longest (most KV tiles) blocks first
+    const int64_t bh = blockIdx.y;
+    const int64_t q0 = (int64_t)qblk * ABQ, qw = q0 + wid * 32, m = qw + xl;
+    const char *Qg = a.q + (bh * a.Sq + m) * AROW;
+    const char *Kg = a.k + bh * a.Skv * AROW;
+    const char *Vg = a.v + bh * a.Skv * AROW;
+
+    frag_t qf[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const frag_t *)(Qg + (kk * 16 + 8 * hl) * 2);
+
+    f32x16 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+    float m_i = -INFINITY, l_i = 0.f;
+    const float c = a.scale * kLog2e;
+
+    const int64_t kv_end = a.Skv < q0 + ABQ ? a.Skv : q0 + ABQ;
+    const int nt = (int)((kv_end + ABK - 1) / ABK);
+    Stage4 kr, vr;
+    a_gload(Kg, kr);
+    a_gload(Vg, vr);
+    for (int t = 0; t < nt; ++t) {
+        const int64_t kv0 = (int64_t)t * ABK;
+        __syncthreads();
+        a_lstore(Kt, kr);
+        a_lstore(Vt, vr);
+        __syncthreads();
+        if (t + 1 < nt) {
+            a_gload(Kg + (kv0 + ABK) * AROW, kr);
+            a_gload(Vg + (kv0 + ABK) * AROW, vr);
+        }
+        if (kv0 > qw + 31) continue; // every key of this tile is masked for this wave
+
+        f32x16 s[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                s[sub] = a_mfma<BF>(a_row_frag<BF>(Kt, sub * 32 + xl, kk * 2 + hl), qf[kk], s[sub]);
+        }
+        const bool need_mask = kv0 + ABK - 1 > qw;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = s[sub][e] * c;
+                if (need_mask && kv0 + sub * 32 + a_row(e, hl) > m) v = -INFINITY;
+                s[sub][e] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_i, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+        float rs = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = __builtin_amdgcn_exp2f(s[sub][e] - m_new);
+                s[sub][e] = p;
+                rs += p;
+            }
+        rs += __shfl_xor(rs, 32, 64);
+        l_i = l_i * alpha + rs;
+        m_i = m_new;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const frag_t pf = a_pack<BF>(s[sub], s2);
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    o[d] = a_mfma<BF>(a_tr_frag<BF>(Vt, sub * 32 + s2 * 16, d * 32), pf, o[d]);
+            }
+    }
+    __syncthreads(); // K/V tiles are dead: reuse LDS as per-wave output slabs
+    a_store_rows<BF>(smem + wid * 32 * OPAD, a.out + (bh * a.Sq + qw) * AROW, o, 1.f / l_i);
+    if (a.lse && hl == 0) a.lse[bh * a.Sq + m] = (m_i + __builtin_amdgcn_logf(l_i)) * kLn2;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward pre-pass: delta[q] = sum_d dO[q][d] * O[q][d]   (16 lanes per row, 16-B loads)
+// ------------------------------------------------------------------------------------------
+template <bool BF>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const char *o, const char *d_o, float *delta, int64_t nrows) {
+    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int part = threadIdx.x & 15;
+    float acc = 0.f;
+    if (row < nrows) {
+        const uint4 a = *(const uint4 *)(o + row * AROW + part * 16);
+        const uint4 b = *(const uint4 *)(d_o + row * AROW + part * 16);
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float a0, a1, b0, b1;
+            if constexpr (BF) {
+                a0 = __uint_as_float(aw[i] << 16); a1 = __uint_as_float(aw[i] & 0xffff0000u);
+                b0 = __uint_as_float(bw[i] << 16); b1 = __uint_as_float(bw[i] & 0xffff0000u);
+            } else {
+                a0 = f16_to_f32(f16_t{(uint16_t)(aw[i] & 0xffff)}); a1 = f16_to_f32(f16_t{(uint16_t)(aw[i] >> 16)});
+                b0 = f16_to_f32(f16_t{(uint16_t)(bw[i] & 0xffff)}); b1 = f16_to_f32(f16_t{(uint16_t)(bw[i] >> 16)});
+            }
+            acc += a0 * b0 + a1 * b1;
+        }
+    }
+    for (int msk = 8; msk > 0; msk >>= 1) acc += __shfl_xor(acc, msk, 64);
+    if (row < nrows && part == 0) delta[row] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// backward: dQ. Same skeleton as the forward; per KV tile S^T, dP^T, then dQ^T += K^T dS^T.
+// ------------------------------------------------------------------------------------------
+template <bool BF>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
+    using frag_t = typename AFrag<BF>::type;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *Kt = smem, *Vt = smem + ABK * AROW;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
+    const int qblk = gridDim.x - 1 - blockIdx.x;
+    const int64_t bh = blockIdx.y;
+    const int64_t q0 = (int64_t)qblk * ABQ, qw = q0 + wid * 32, m = qw + xl;
+    const char *Qg = a.q + (bh * a.Sq + m) * AROW;
+    const char *dOg = a.d_o + (bh * a.Sq + m) * AROW;
+    const char *Kg = a.k + bh * a.Skv * AROW;
+    const char *Vg = a.v + bh * a.Skv * AROW;
+
+    frag_t qf[8], dof[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        qf[kk] = *(const frag_t *)(Qg + (kk * 16 + 8 * hl) * 2);
+        dof[kk] = *(const frag_t *)(dOg + (kk * 16 + 8 * hl) * 2);
+    }
+    const float c = a.scale * kLog2e;
+    const float lse2 = a.lse_r[bh * a.Sq + m] * kLog2e;
+    const float dlt = a.delta[bh * a.Sq + m];
+
+    f32x16 dq[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dq[d][e] = 0.f;
+
+    const int64_t kv_end = a.Skv < q0 + ABQ ? a.Skv : q0 + ABQ;
+    const int nt = (int)((kv_end + ABK - 1) / ABK);
+    Stage4 kr, vr;
+    a_gload(Kg, kr);
+    a_gload(Vg, vr);
+    for (int t = 0; t < nt; ++t) {
+        const int64_t kv0 = (int64_t)t * ABK;
+        __syncthreads();
+        a_lstore(Kt, kr);
+        a_lstore(Vt, vr);
+        __syncthreads();
+        if (t + 1 < nt) {
+            a_gload(Kg + (kv0 + ABK) * AROW, kr);
+            a_gload(Vg + (kv0 + ABK) * AROW, vr);
+        }
+        if (kv0 > qw + 31) continue;
+        const bool need_mask = kv0 + ABK - 1 > qw;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                s = a_mfma<BF>(a_row_frag<BF>(Kt, sub * 32 + xl, kk * 2 + hl), qf[kk], s);
+                dp = a_mfma<BF>(a_row_frag<BF>(Vt, sub * 32 + xl, kk * 2 + hl), dof[kk], dp);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float p = __builtin_amdgcn_exp2f(s[e] * c - lse2);
+                if (need_mask && kv0 + sub * 32 + a_row(e, hl) > m) p = 0.f;
+                s[e] = p * (dp[e] - dlt);
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const frag_t df = a_pack<BF>(s, s2);
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+                    dq[d] = a_mfma<BF>(a_tr_frag<BF>(Kt, sub * 32 + s2 * 16, d * 32), df, dq[d]);
+            }
+        }
+    }
+    __syncthreads();
+    a_store_rows<BF>(smem + wid * 32 * OPAD, a.dq + (bh * a.Sq + qw) * AROW, dq, a.scale);
+}
+
+// ------------------------------------------------------------------------------------------
+// backward: dK, dV. One block = 128 keys (32 per wave, key on the lane); sweeps 32-query slices
+// from the diagonal down. Per slice: S = Q K^T, dP = dO V^T (A = Q / dO rows from LDS, B = K / V
+// fragments in registers), dV^T += dO^T P, dK^T += Q^T dS (A via transposed reads).
+// ------------------------------------------------------------------------------------------
+constexpr int BKB = 128; // keys per block
+constexpr int BQS = 32;  // queries per slice
+
+template <bool BF>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
+    using frag_t = typename AFrag<BF>::type;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *Qt = smem, *dOt = smem + BQS * AROW;
+    float *lse_s = (float *)(smem + 2 * BQS * AROW), *dlt_s = lse_s + BQS;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
+    const int64_t bh = blockIdx.y;
+    const int64_t k0 = (int64_t)blockIdx.x * BKB, kw = k0 + wid * 32, n = kw + xl;
+    const char *Kg = a.k + (bh * a.Skv + n) * AROW;
+    const char *Vg = a.v + (bh * a.Skv + n) * AROW;
+    const char *Qg = a.q + bh * a.Sq * AROW;
+    const char *dOg = a.d_o + bh * a.Sq * AROW;
+    const float *lse_g = a.lse_r + bh * a.Sq, *dlt_g = a.delta + bh * a.Sq;
+
+    frag_t kf[8], vf[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        kf[kk] = *(const frag_t *)(Kg + (kk * 16 + 8 * hl) * 2);
+        vf[kk] = *(const frag_t *)(Vg + (kk * 16 + 8 * hl) * 2);
+    }
+    f32x16 dk[4], dv[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk[d][e] = 0.f; dv[d][e] = 0.f; }
+    const float c = a.scale * kLog2e;
+
+    const int ns = (int)(a.Sq / BQS);
+    int sl = (int)(k0 / BQS); // first slice holding a query >= the block's first key
+    Stage2 qr, dr;
+    float lr = 0.f, tr = 0.f;
+    if (sl < ns) {
+        a_gload(Qg + (int64_t)sl * BQS * AROW, qr);
+        a_gload(dOg + (int64_t)sl * BQS * AROW, dr);
+        if (threadIdx.x < BQS) { lr = lse_g[sl * BQS + threadIdx.x]; tr = dlt_g[sl * BQS + threadIdx.x]; }
+    }
+    for (; sl < ns; ++sl) {
+        const int64_t qs = (int64_t)sl * BQS;
+        __syncthreads();
+        a_lstore(Qt, qr);
+        a_lstore(dOt, dr);
+        if (threadIdx.x < BQS) { lse_s[threadIdx.x] = lr * kLog2e; dlt_s[threadIdx.x] = tr; }
+        __syncthreads();
+        if (sl + 1 < ns) {
+            a_gload(Qg + (qs + BQS) * AROW, qr);
+            a_gload(dOg + (qs + BQS) * AROW, dr);
+            if (threadIdx.x < BQS) { lr = lse_g[qs + BQS + threadIdx.x]; tr = dlt_g[qs + BQS + threadIdx.x]; }
+        }
+        if (qs + BQS - 1 < kw) continue; // every query of the slice precedes this wave's keys
+        const bool need_mask = qs < kw + 31;
+
+        f32x16 s, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            s = a_mfma<BF>(a_row_frag<BF>(Qt, xl, kk * 2 + hl), kf[kk], s);
+            dp = a_mfma<BF>(a_row_frag<BF>(dOt, xl, kk * 2 + hl), vf[kk], dp);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = a_row(e, hl);
+            float p = __builtin_amdgcn_exp2f(s[e] * c - lse_s[r]);
+            if (need_mask && n > qs + r) p = 0.f;
+            s[e] = p;
+            dp[e] = p * (dp[e] - dlt_s[r]);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const frag_t pf = a_pack<BF>(s, s2), df = a_pack<BF>(dp, s2);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                dv[d] = a_mfma<BF>(a_tr_frag<BF>(dOt, s2 * 16, d * 32), pf, dv[d]);
+                dk[d] = a_mfma<BF>(a_tr_frag<BF>(Qt, s2 * 16, d * 32), df, dk[d]);
+            }
+        }
+    }
+    __syncthreads();
+    // slabs: 4 waves x 32 rows x OPAD bytes (needs 33792 B of LDS)
+    a_store_rows<BF>(smem + wid * 32 * OPAD, a.dv + (bh * a.Skv + kw) * AROW, dv, 1.f);
+    a_store_rows<BF>(smem + wid * 32 * OPAD, a.dk + (bh * a.Skv + kw) * AROW, dk, a.scale);
+}
+
+// ==========================================================================================
+// generic path: f32 math on the vector ALU, any Sq / Skv, D <= 256, f32 / bf16 / f16 storage.
+// One block = 16 queries; key tiles of 32; 256 threads.
+// ==========================================================================================
+constexpr int GQ = 16, GK = 32;
+
+template <typename T> __device__ __forceinline__ float t_load(const T *p) { return (float)*p; }
+template <> __device__ __forceinline__ float t_load<bf16_t>(const bf16_t *p) { return bf16_to_f32(*p); }
+template <> __device__ __forceinline__ float t_load<f16_t>(const f16_t *p) { return f16_to_f32(*p); }
+template <typename T> __device__ __forceinline__ void t_store(T *p, float v) { *p = (T)v; }
+template <> __device__ __forceinline__ void t_store<bf16_t>(bf16_t *p, float v) { *p = f32_to_bf16(v); }
+template <> __device__ __forceinline__ void t_store<f16_t>(f16_t *p, float v) { *p = f32_to_f16(v); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_fwd_generic_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int D = (int)a.D, DP = D + 1;
+    float *Qs = (float *)smem;       // [GQ][DP]
+    float *Ks = Qs + GQ * DP;        // [GK][DP]
+    float *Vs = Ks + GK * DP;        // [GK][D]
+    float *Ps = Vs + GK * D;         // [GQ][GK + 1]
+    float *al = Ps + GQ * (GK + 1);  // [GQ] rescale factor of the current tile
+    const int64_t bh = blockIdx.y, q0 = (int64_t)blockIdx.x * GQ;
+    const T *Qg = (const T *)a.q + bh * a.Sq * D;
+    const T *Kg = (const T *)a.k + bh * a.Skv * D;
+    const T *Vg = (const T *)a.v + bh * a.Skv * D;
+    const int t = threadIdx.x;
+
+    for (int i = t; i < GQ * D; i += 256) {
+        const int r = i / D, d = i % D;
+        Qs[r * DP + d] = q0 + r < a.Sq ? t_load<T>(Qg + (q0 + r) * D + d) : 0.f;
+    }
+    const int orow = t / 16, ocol = t % 16; // output ownership: row orow, columns ocol + 16 j
+    float o[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) o[j] = 0.f;
+    float m_i = -INFINITY, l_i = 0.f; // replicated over the 16 lanes of a row
+
+    const int64_t q_hi = q0 + GQ - 1 < a.Sq - 1 ? q0 + GQ - 1 : a.Sq - 1;
+    const int64_t kv_end = a.Skv < q_hi + 1 ? a.Skv : q_hi + 1;
+    for (int64_t kv0 = 0; kv0 < kv_end; kv0 += GK) {
+        __syncthreads();
+        for (int i = t; i < GK * D; i += 256) {
+            const int r = i / D, d = i % D;
+            const bool ok = kv0 + r < a.Skv;
+            Ks[r * DP + d] = ok ? t_load<T>(Kg + (kv0 + r) * D + d) : 0.f;
+            Vs[r * D + d] = ok ? t_load<T>(Vg + (kv0 + r) * D + d) : 0.f;
+        }
+        __syncthreads();
+        // scores: thread -> (query t/32 and +8, key t%32)
+        {
+            const int kk = t % GK;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int qq = t / GK + 8 * h;
+                float acc = 0.f;
+                for (int d = 0; d < D; ++d) acc = fmaf(Qs[qq * DP + d], Ks[kk * DP + d], acc);
+                acc *= a.scale;
+                const int64_t mq = q0 + qq, nk = kv0 + kk;
+                if (nk > mq || nk >= a.Skv) acc = -INFINITY;
+                Ps[qq * (GK + 1) + kk] = acc;
+            }
+        }
+        __syncthreads();
+        // online softmax: 16 lanes per row, 2 keys each
+        {
+            float s0 = Ps[orow * (GK + 1) + ocol], s1 = Ps[orow * (GK + 1) + ocol + 16];
+            float mx = fmaxf(s0, s1);
+            for (int msk = 8; msk > 0; msk >>= 1) mx = fmaxf(mx, __shfl_xor(mx, msk, 64));
+            const float m_new = fmaxf(m_i, mx);
+            const float p0 = expf(s0 - m_new), p1 = expf(s1 - m_new);
+            float rs = p0 + p1;
+            for (int msk = 8; msk > 0; msk >>= 1) rs += __shfl_xor(rs, msk, 64);
+            const float alpha = expf(m_i - m_new);
+            l_i = l_i * alpha + rs;
+            m_i = m_new;
+            Ps[orow * (GK + 1) + ocol] = p0;
+            Ps[orow * (GK + 1) + ocol + 16] = p1;
+            if (ocol == 0) al[orow] = alpha;
+        }
+        __syncthreads();
+        {
+            const float alpha = al[orow];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int d = ocol + 16 * j;
+                if (d < D) {
+                    float acc = o[j] * alpha;
+#pragma unroll 4
+                    for (int kk = 0; kk < GK; ++kk) acc = fmaf(Ps[orow * (GK + 1) + kk], Vs[kk * D + d], acc);
+                    o[j] = acc;
+                }
+            }
+        }
+    }
+    const int64_t mq = q0 + orow;
+    if (mq < a.Sq) {
+        T *Og = (T *)a.out + (bh * a.Sq + mq) * D;
+        const float inv = 1.f / l_i;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int d = ocol + 16 * j;
+            if (d < D) t_store<T>(Og + d, o[j] * inv);
+        }
+        if (a.lse && ocol == 0) a.lse[bh * a.Sq + mq] = m_i + logf(l_i);
+    }
+}
+
+// delta for the generic path: one wave per row
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_generic_kernel(const T *o, const T *d_o, float *delta, int64_t nrows, int D) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    float acc = 0.f;
+    if (row < nrows)
+        for (int d = lane; d < D; d += 64) acc += t_load<T>(o + row * D + d) * t_load<T>(d_o + row * D + d);
+    for (int msk = 32; msk > 0; msk >>= 1) acc += __shfl_xor(acc, msk, 64);
+    if (row < nrows && lane == 0) delta[row] = acc;
+}
+
+// generic backward, MODE 0: dQ for a block of 16 queries; MODE 1: dK and dV for a block of 16 keys.
+// The owned block's rows play the role of "row", the swept tiles of 32 the role of "col".
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int D = (int)a.D, DP = D + 1;
+    float *Rq = (float *)smem;        // MODE 0: Q block   | MODE 1: K block     [GQ][DP]
+    float *Rd = Rq + GQ * DP;         // MODE 0: dO block  | MODE 1: V block     [GQ][DP]
+    float *Cq = Rd + GQ * DP;         // MODE 0: K tile    | MODE 1: Q tile      [GK][DP]
+    float *Cd = Cq + GK * DP;         // MODE 0: V tile    | MODE 1: dO tile     [GK][DP]
+    float *Ps = Cd + GK * DP;         // p   [GQ][GK + 1]
+    float *Ds = Ps + GQ * (GK + 1);   // dS  [GQ][GK + 1]
+    float *cl = Ds + GQ * (GK + 1);   // per-col lse (MODE 1) [GK]
+    float *cd = cl + GK;              // per-col delta (MODE 1) [GK]
+    const int64_t bh = blockIdx.y, r0 = (int64_t)blockIdx.x * GQ;
+    const T *Qg = (const T *)a.q + bh * a.Sq * D, *dOg = (const T *)a.d_o + bh * a.Sq * D;
+    const T *Kg = (const T *)a.k + bh * a.Skv * D, *Vg = (const T *)a.v + bh * a.Skv * D;
+    const float *lse = a.lse_r + bh * a.Sq, *dlt = a.delta + bh * a.Sq;
+    const int64_t nrow = MODE == 0 ? a.Sq : a.Skv, ncol = MODE == 0 ? a.Skv : a.Sq;
+    const T *Rqg = MODE == 0 ? Qg : Kg, *Rdg = MODE == 0 ? dOg : Vg;
+    const T *Cqg = MODE == 0 ? Kg : Qg, *Cdg = MODE == 0 ? Vg : dOg;
+    const int t = threadIdx.x;
+    for (int i = t; i < GQ * D; i += 256) {
+        const int r = i / D, d = i % D;
+        const bool ok = r0 + r < nrow;
+        Rq[r * DP + d] = ok ? t_load<T>(Rqg + (r0 + r) * D + d) : 0.f;
+        Rd[r * DP + d] = ok ? t_load<T>(Rdg + (r0 + r) * D + d) : 0.f;
+    }
+    const int orow = t / 16, ocol = t % 16;
+    float acc0[16], acc1[16]; // MODE 0: dQ | MODE 1: dK, dV
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { acc0[j] = 0.f; acc1[j] = 0.f; }
+
+    // column range: MODE 0 keys 0..min(Skv, last query + 1); MODE 1 queries from first key .. Sq
+    int64_t c_begin = 0, c_end = ncol;
+    if (MODE == 0) {
+        const int64_t q_hi = r0 + GQ - 1 < a.Sq - 1 ? r0 + GQ - 1 : a.Sq - 1;
+        c_end = a.Skv < q_hi + 1 ? a.Skv : q_hi + 1;
+    } else {
+        c_begin = r0 / GK * GK;
+    }
+    for (int64_t c0 = c_begin; c0 < c_end; c0 += GK) {
+        __syncthreads();
+        for (int i = t; i < GK * D; i += 256) {
+            const int r = i / D, d = i % D;
+            const bool ok = c0 + r < ncol;
+            Cq[r * DP + d] = ok ? t_load<T>(Cqg + (c0 + r) * D + d) : 0.f;
+            Cd[r * DP + d] = ok ? t_load<T>(Cdg + (c0 + r) * D + d) : 0.f;
+        }
+        if (MODE == 1 && t < GK) {
+            const bool ok = c0 + t < ncol;
+            cl[t] = ok ? lse[c0 + t] : 0.f;
+            cd[t] = ok ? dlt[c0 + t] : 0.f;
+        }
+        __syncthreads();
+        {
+            const int cc = t % GK;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int rr = t / GK + 8 * h;
+                float s = 0.f, dp = 0.f;
+                for (int d = 0; d < D; ++d) {
+                    s = fmaf(Rq[rr * DP + d], Cq[cc * DP + d], s);
+                    dp = fmaf(Rd[rr * DP + d], Cd[cc * DP + d], dp);
+                }
+                const int64_t mq = MODE == 0 ? r0 + rr : c0 + cc; // query index
+                const int64_t nk = MODE == 0 ? c0 + cc : r0 + rr; // key index
+                float p = 0.f, ds = 0.f;
+                if (nk <= mq && mq < a.Sq && nk < a.Skv) {
+                    const float l = MODE == 0 ? lse[mq] : cl[cc];
+                    const float dl = MODE == 0 ? dlt[mq] : cd[cc];
+                    p = expf(s * a.scale - l);
+                    ds = p * (dp - dl);
+                }
+                Ps[rr * (GK + 1) + cc] = p;
+                Ds[rr * (GK + 1) + cc] = ds;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int d = ocol + 16 * j;
+            if (d < D) {
+                float x0 = acc0[j], x1 = acc1[j];
+#pragma unroll 4
+                for (int cc = 0; cc < GK; ++cc) {
+                    // MODE 0: dQ += dS K ; MODE 1: dK += dS^T Q, dV += P^T dO
+                    x0 = fmaf(Ds[orow * (GK + 1) + cc], Cq[cc * DP + d], x0);
+                    if (MODE == 1) x1 = fmaf(Ps[orow * (GK + 1) + cc], Cd[cc * DP + d], x1);
+                }
+                acc0[j] = x0;
+                acc1[j] = x1;
+            }
+        }
+    }
+    const int64_t r = r0 + orow;
+    if (r < nrow) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int d = ocol + 16 * j;
+            if (d < D) {
+                if (MODE == 0) {
+                    t_store<T>((T *)a.dq + (bh * a.Sq + r) * D + d, acc0[j] * a.scale);
+                } else {
+                    t_store<T>((T *)a.dk + (bh * a.Skv + r) * D + d, acc0[j] * a.scale);
+                    t_store<T>((T *)a.dv + (bh * a.Skv + r) * D + d, acc1[j]);
+                }
+            }
+        }
+    }
+}
+
+static bool mfma_ok(int dtype, int64_t Sq, int64_t Skv, int64_t D) {
+    return (dtype == KF_BF16 || dtype == KF_F16) && D == AD && Sq % ABQ == 0 && Skv % BKB == 0 && Sq > 0 && Skv > 0;
+}
+
+static inline size_t a_align(size_t v) { return (v + 255) / 256 * 256; }
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+    KF_HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return KF_OK;
+}
+
+} // namespace kf
+
+using namespace kf;
+
+static int check_common(const char *who, int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D) {
+    KF_REQUIRE(dtype == KF_F32 || dtype == KF_BF16 || dtype == KF_F16, KF_ERR_UNSUPPORTED, "%s: dtype %d not supported", who, dtype);
+    KF_REQUIRE(B >= 0 && H >= 0 && Sq >= 0 && Skv >= 0 && D > 0, KF_ERR_INVALID, "%s: bad extents", who);
+    KF_REQUIRE(D <= 256, KF_ERR_UNSUPPORTED, "%s: head size %lld > 256", who, (long long)D);
+    KF_REQUIRE(B * H <= 65535, KF_ERR_UNSUPPORTED, "%s: B*H %lld > 65535", who, (long long)(B * H));
+    return KF_OK;
+}
+
+extern "C" int kf_attn_fwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, const void *q,
+                           const void *k, const void *v, void *o, float *lse, void *stream) {
+    int rc = check_common("kf_attn_fwd", dtype, B, H, Sq, Skv, D);
+    if (rc != KF_OK) return rc;
+    if (B * H == 0 || Sq == 0) return KF_OK;
+    KF_REQUIRE(Skv > 0, KF_ERR_INVALID, "kf_attn_fwd: Skv must be positive");
+    KF_REQUIRE(q && k && v && o, KF_ERR_INVALID, "kf_attn_fwd: null operand");
+    hipStream_t st = as_stream(stream);
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = (const char *)q; a.k = (const char *)k; a.v = (const char *)v; a.out = (char *)o; a.lse = lse;
+    a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.D = D;
+    a.scale = 1.0f / sqrtf((float)D);
+    if (mfma_ok(dtype, Sq, Skv, D)) {
+        const size_t lds = 4 * 32 * OPAD; // >= 2 * ABK * AROW
+        dim3 grid((unsigned)(Sq / ABQ), (unsigned)(B * H));
+        KF_PROF("attn_fwd_mfma", st);
+        if (dtype == KF_BF16) {
+            rc = set_lds(attn_fwd_mfma_kernel<true>, lds);
+            if (rc != KF_OK) return rc;
+            attn_fwd_mfma_kernel<true><<<grid, 256, lds, st>>>(a);
+        } else {
+            rc = set_lds(attn_fwd_mfma_kernel<false>, lds);
+            if (rc != KF_OK) return rc;
+            attn_fwd_mfma_kernel<false><<<grid, 256, lds, st>>>(a);
+        }
+        KF_LAUNCH_CHECK();
+        return KF_OK;
+    }
+    const int DP = (int)D + 1;
+    const size_t lds = sizeof(float) * ((size_t)GQ * DP + (size_t)GK * DP + (size_t)GK * D + (size_t)GQ * (GK + 1) + GQ);
+    dim3 grid((unsigned)((Sq + GQ - 1) / GQ), (unsigned)(B * H));
+    KF_PROF("attn_fwd_generic", st);
+    switch (dtype) {
+    case KF_F32:
+        rc = set_lds(attn_fwd_generic_kernel<float>, lds);
+        if (rc != KF_OK) return rc;
+        attn_fwd_generic_kernel<float><<<grid, 256, lds, st>>>(a);
+        break;
+    case KF_BF16:
+        rc = set_lds(attn_fwd_generic_kernel<bf16_t>, lds);
+        if (rc != KF_OK) return rc;
+        attn_fwd_generic_kernel<bf16_t><<<grid, 256, lds, st>>>(a);
+        break;
+    default:
+        rc = set_lds(attn_fwd_generic_kernel<f16_t>, lds);
+        if (rc != KF_OK) return rc;
+        attn_fwd_generic_kernel<f16_t><<<grid, 256, lds, st>>>(a);
+        break;
+    }
+    KF_LAUNCH_CHECK();
+    return KF_OK;
+}
+
+extern "C" int kf_attn_bwd_workspace_bytes(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D,
+                                           size_t *bytes) {
+    KF_REQUIRE(bytes, KF_ERR_INVALID, "kf_attn_bwd_workspace_bytes: null out pointer");
+    int rc = check_common("kf_attn_bwd_workspace_bytes", dtype, B, H, Sq, Skv, D);
+    if (rc != KF_OK) return rc;
+    *bytes = a_align((size_t)B * H * Sq * sizeof(float)); // delta
+    return KF_OK;
+}
+
+extern "C" int kf_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, const void *q,
+                           const void *k, const void *v, const void *o, const float *lse, const void *d_o, void *dq,
+                           void *dk, void *dv, void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = check_common("kf_attn_bwd", dtype, B, H, Sq, Skv, D);
+    if (rc != KF_OK) return rc;
+    if (B * H == 0 || Sq == 0 || Skv == 0) return KF_OK;
+    KF_REQUIRE(q && k && v && o && lse && d_o && dq && dk && dv, KF_ERR_INVALID, "kf_attn_bwd: null operand");
+    size_t need = 0;
+    kf_attn_bwd_workspace_bytes(dtype, B, H, Sq, Skv, D, &need);
+    KF_REQUIRE(workspace && workspace_bytes >= need, KF_ERR_WORKSPACE, "kf_attn_bwd: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    hipStream_t st = as_stream(stream);
+    AttnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.q = (const char *)q; a.k = (const char *)k; a.v = (const char *)v; a.o = (const char *)o; a.d_o = (const char *)d_o;
+    a.dq = (char *)dq; a.dk = (char *)dk; a.dv = (char *)dv;
+    a.lse_r = lse; a.delta = (float *)workspace;
+    a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.D = D;
+    a.scale = 1.0f / sqrtf((float)D);
+    const int64_t nrows = B * H * Sq;
+    if (mfma_ok(dtype, Sq, Skv, D)) {
+        const size_t lds = 4 * 32 * OPAD;
+        dim3 gq((unsigned)(Sq / ABQ), (unsigned)(B * H)), gk((unsigned)(Skv / BKB), (unsigned)(B * H));
+        const unsigned gd = (unsigned)((nrows + 15) / 16);
+        if ((rc = set_lds(attn_bwd_dq_kernel<true>, lds)) != KF_OK) return rc;
+        if ((rc = set_lds(attn_bwd_dkv_kernel<true>, lds)) != KF_OK) return rc;
+        if ((rc = set_lds(attn_bwd_dq_kernel<false>, lds)) != KF_OK) return rc;
+        if ((rc = set_lds(attn_bwd_dkv_kernel<false>, lds)) != KF_OK) return rc;
+        const bool bf = dtype == KF_BF16;
+        {
+            KF_PROF("attn_bwd_delta", st);
+            if (bf) attn_delta_kernel<true><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows);
+            else attn_delta_kernel<false><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows);
+            KF_LAUNCH_CHECK();
+        }
+        {
+            KF_PROF("attn_bwd_dkv_mfma", st);
+            if (bf) attn_bwd_dkv_kernel<true><<<gk, 256, lds, st>>>(a);
+            else attn_bwd_dkv_kernel<false><<<gk, 256, lds, st>>>(a);
+            KF_LAUNCH_CHECK();
+        }
+        {
+            KF_PROF("attn_bwd_dq_mfma", st);
+            if (bf) attn_bwd_dq_kernel<true><<<gq, 256, lds, st>>>(a);
+            else attn_bwd_dq_kernel<false><<<gq, 256, lds, st>>>(a);
+            KF_LAUNCH_CHECK();
+        }
+        return KF_OK;
+    }
+    const int DP = (int)D + 1;
+    const size_t lds = sizeof(float) * ((size_t)2 * GQ * DP + (size_t)2 * GK * DP + (size_t)2 * GQ * (GK + 1) + 2 * GK);
+    dim3 gq((unsigned)((Sq + GQ - 1) / GQ), (unsigned)(B * H)), gk((unsigned)((Skv + GQ - 1) / GQ), (unsigned)(B * H));
+    const unsigned gd = (unsigned)((nrows + 3) / 4);
+    KF_PROF("attn_bwd_generic", st);
+#define KF_GENERIC_BWD(T)                                                                                   \
+    attn_delta_generic_kernel<T><<<gd, 256, 0, st>>>((const T *)o, (const T *)d_o, a.delta, nrows, (int)D);  \
+    KF_LAUNCH_CHECK();                                                                                      \
+    if ((rc = set_lds(attn_bwd_generic_kernel<T, 0>, lds)) != KF_OK) return rc;                             \
+    if ((rc = set_lds(attn_bwd_generic_kernel<T, 1>, lds)) != KF_OK) return rc;                             \
+    attn_bwd_generic_kernel<T, 0><<<gq, 256, lds, st>>>(a);                                                 \
+    KF_LAUNCH_CHECK();                                                                                      \
+    attn_bwd_generic_kernel<T, 1><<<gk, 256, lds, st>>>(a);                                                 \
+    KF_LAUNCH_CHECK();
+    switch (dtype) {
+    case KF_F32: { KF_GENERIC_BWD(float) } break;
+    case KF_BF16: { KF_GENERIC_BWD(bf16_t) } break;
+    default: { KF_GENERIC_BWD(f16_t) } break;
+    }
+#undef KF_GENERIC_BWD
+    return KF_OK;
+}

@@ -1,0 +1,426 @@
+// Elementwise loops for gfx950: add/sub/mul/div, copy/convert, fill.
+//
+// Replaces the reference's loop engine (src/device/utils/tensor_loops.h:16-369 + the functors in
+// binary/unary/nullary_ops_kernel.cu). Design differences, MI355X-first:
+//   * every same-dtype path moves 16 B per lane (bf16/half included — the reference runs every
+//     half/bf16/int binary op through a scalar cast loop, binary_ops_kernel.cu:34-39);
+//   * launches are capped at ~8 blocks per CU and grid-stride the rest, 4 independent 16-B loads
+//     in flight per lane per operand;
+//   * broadcast operands with a contiguous (or stride-0) inner dimension stay on the 16-B path;
+//   * mixed dtypes use one runtime-cast kernel per accumulate class instead of a per-functor
+//     template zoo.
+// Arithmetic follows the reference exactly: operands are cast to the accumulate type of the common
+// dtype (float for half/bf16/float, double, int64 for integers, bool), combined, and cast to the
+// output dtype on store (accumulate_type.h:17-27, tensor_memory_access.h:13-37).
+#include "common.h"
+#include "offset_calc.h"
+
+namespace kf {
+
+// ------------------------------------------------------------------------------------------
+// scalar conversions (static_cast semantics of the reference's fetch_and_cast/cast_and_store)
+// ------------------------------------------------------------------------------------------
+template <typename A>
+__device__ __forceinline__ A load_as(int dt, const char *p) {
+    switch (dt) {
+    case KF_BOOL: return (A)(*(const uint8_t *)p != 0);
+    case KF_U8: return (A)(*(const uint8_t *)p);
+    case KF_I8: return (A)(*(const int8_t *)p);
+    case KF_I16: return (A)(*(const int16_t *)p);
+    case KF_I32: return (A)(*(const int32_t *)p);
+    case KF_I64: return (A)(*(const int64_t *)p);
+    case KF_F16: return (A)f16_to_f32(*(const f16_t *)p);
+    case KF_BF16: return (A)bf16_to_f32(*(const bf16_t *)p);
+    case KF_F32: return (A)(*(const float *)p);
+    case KF_F64: return (A)(*(const double *)p);
+    default: return A(0);
+    }
+}
+
+template <typename A>
+__device__ __forceinline__ void store_from(int dt, char *p, A v) {
+    switch (dt) {
+    case KF_BOOL: *(uint8_t *)p = (uint8_t)(v != A(0)); break;
+    case KF_U8: *(uint8_t *)p = (uint8_t)v; break;
+    case KF_I8: *(int8_t *)p = (int8_t)v; break;
+    case KF_I16: *(int16_t *)p = (int16_t)v; break;
+    case KF_I32: *(int32_t *)p = (int32_t)v; break;
+    case KF_I64: *(int64_t *)p = (int64_t)v; break;
+    case KF_F16: *(f16_t *)p = f32_to_f16((float)v); break;
+    case KF_BF16: *(bf16_t *)p = f32_to_bf16((float)v); break;
+    case KF_F32: *(float *)p = (float)v; break;
+    case KF_F64: *(double *)p = (double)v; break;
+    default: break;
+    }
+}
+
+template <typename A>
+__device__ __forceinline__ A apply_op(int op, A a, A b) {
+    switch (op) {
+    case KF_EW_ADD: return a + b;
+    case KF_EW_SUB: return a - b;
+    case KF_EW_MUL: return a * b;
+    default: return a / b;
+    }
+}
+template <>
+__device__ __forceinline__ int64_t apply_op<int64_t>(int op, int64_t a, int64_t b) {
+    switch (op) {
+    case KF_EW_ADD: return (int64_t)((uint64_t)a + (uint64_t)b);
+    case KF_EW_SUB: return (int64_t)((uint64_t)a - (uint64_t)b);
+    case KF_EW_MUL: return (int64_t)((uint64_t)a * (uint64_t)b);
+    default: return b == 0 ? 0 : (b == -1 ? (int64_t)(0 - (uint64_t)a) : a / b); // x/0 is UB in the reference; 0 here
+    }
+}
+template <>
+__device__ __forceinline__ bool apply_op<bool>(int op, bool a, bool b) {
+    // bool arithmetic promotes to int and converts back (C++), as the reference's Functor<bool> does
+    switch (op) {
+    case KF_EW_ADD: return a || b;
+    case KF_EW_SUB: return a != b;
+    case KF_EW_MUL: return a && b;
+    default: return a; // a / true; a / false is UB in the reference
+    }
+}
+
+// storage type <-> accumulate type for the same-dtype vector paths
+template <typename T> struct Acc { using type = T; };
+template <> struct Acc<bf16_t> { using type = float; };
+template <> struct Acc<f16_t> { using type = float; };
+template <> struct Acc<int32_t> { using type = int64_t; };
+
+template <typename T> __device__ __forceinline__ typename Acc<T>::type to_acc(T v) { return (typename Acc<T>::type)v; }
+template <> __device__ __forceinline__ float to_acc<bf16_t>(bf16_t v) { return bf16_to_f32(v); }
+template <> __device__ __forceinline__ float to_acc<f16_t>(f16_t v) { return f16_to_f32(v); }
+template <typename T> __device__ __forceinline__ T from_acc(typename Acc<T>::type v) { return (T)v; }
+template <> __device__ __forceinline__ bf16_t from_acc<bf16_t>(float v) { return f32_to_bf16(v); }
+template <> __device__ __forceinline__ f16_t from_acc<f16_t>(float v) { return f32_to_f16(v); }
+
+template <typename T, int VEC>
+struct alignas(sizeof(T) * VEC) Pack {
+    T v[VEC];
+};
+
+constexpr int kBlock = 256;
+constexpr int kUnroll = 4;
+
+// ------------------------------------------------------------------------------------------
+// same-dtype kernel: NIN inputs of type T, one output of type T. MODE: 0 = arithmetic (op at
+// run time), 1 = copy (raw bits), 2 = fill (raw bits).
+// ------------------------------------------------------------------------------------------
+template <int NT>
+struct SameArgs {
+    char *ptr[NT];
+    int64_t nvec;        // number of VEC-wide items
+    int op;
+    uint32_t bcast0;     // bit t set: operand t has stride 0 along dim 0 (vector path: splat)
+    uint64_t fill_bits;  // MODE 2
+    OffsetCalc<NT> oc;   // !CONTIG only
+};
+
+template <typename T, int VEC, int NIN, int MODE, bool CONTIG>
+__global__ __launch_bounds__(kBlock) void ew_same_kernel(const SameArgs<NIN + 1> args) {
+    constexpr int NT = NIN + 1;
+    using P = Pack<T, VEC>;
+    using A = typename Acc<T>::type;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+
+    P fillv;
+    if constexpr (MODE == 2) {
+        T one;
+        __builtin_memcpy(&one, &args.fill_bits, sizeof(T));
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) fillv.v[e] = one;
+    }
+
+    for (; i < args.nvec; i += stride * kUnroll) {
+        P in[kUnroll][NIN > 0 ? NIN : 1];
+        uint32_t ooff[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t idx = i + u * stride;
+            if (idx < args.nvec) {
+                if constexpr (CONTIG) {
+#pragma unroll
+                    for (int t = 0; t < NIN; ++t) in[u][t] = *(const P *)(args.ptr[t + 1] + idx * (int64_t)sizeof(P));
+                } else {
+                    uint32_t off[NT];
+                    args.oc.get((uint32_t)idx, off);
+                    ooff[u] = off[0];
+#pragma unroll
+                    for (int t = 0; t < NIN; ++t) {
+                        if (VEC > 1 && ((args.bcast0 >> (t + 1)) & 1u)) {
+                            T s = *(const T *)(args.ptr[t + 1] + off[t + 1]);
+#pragma unroll
+                            for (int e = 0; e < VEC; ++e) in[u][t].v[e] = s;
+                        } else {
+                            in[u][t] = *(const P *)(args.ptr[t + 1] + off[t + 1]);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t idx = i + u * stride;
+            if (idx < args.nvec) {
+                P out;
+                if constexpr (MODE == 2) {
+                    out = fillv;
+                } else if constexpr (MODE == 1) {
+                    out = in[u][0];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        out.v[e] = from_acc<T>(apply_op<A>(args.op, to_acc<T>(in[u][0].v[e]), to_acc<T>(in[u][NIN > 1 ? 1 : 0].v[e])));
+                }
+                if constexpr (CONTIG)
+                    *(P *)(args.ptr[0] + idx * (int64_t)sizeof(P)) = out;
+                else
+                    *(P *)(args.ptr[0] + ooff[u]) = out;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// runtime-cast kernel: any dtype per operand, accumulate class A, strided (32-bit indexable).
+// MODE 0 arithmetic, 1 copy/convert.
+// ------------------------------------------------------------------------------------------
+template <int NT>
+struct CastArgs {
+    char *ptr[NT];
+    int dtype[NT];
+    uint32_t n;
+    int op;
+    OffsetCalc<NT> oc;
+};
+
+template <typename A, int NIN, int MODE>
+__global__ __launch_bounds__(kBlock) void ew_cast_kernel(const CastArgs<NIN + 1> args) {
+    constexpr int NT = NIN + 1;
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < args.n; i += stride) {
+        uint32_t off[NT];
+        args.oc.get(i, off);
+        A a = load_as<A>(args.dtype[1], args.ptr[1] + off[1]);
+        A r;
+        if constexpr (MODE == 1) {
+            r = a;
+        } else {
+            A b = load_as<A>(args.dtype[NT - 1], args.ptr[NT - 1] + off[NT - 1]);
+            r = apply_op<A>(args.op, a, b);
+        }
+        store_from<A>(args.dtype[0], args.ptr[0] + off[0], r);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side dispatch
+// ------------------------------------------------------------------------------------------
+static inline int grid_for(int64_t nitems) {
+    int64_t blocks = (nitems + kBlock - 1) / kBlock;
+    const int64_t cap = 256 * 8; // 8 blocks of 256 threads per CU
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+static bool desc_contiguous(const kf_iter_desc *d) {
+    // reference TensorIterator::is_contiguous (tensor_iterator.cpp:407-415)
+    if (desc_numel(d) == 1) return true;
+    if (d->ndim != 1) return false;
+    for (int t = 0; t < d->ntensors; ++t)
+        if (d->stride_bytes[t][0] != dtype_size(d->dtype[t])) return false;
+    return true;
+}
+
+// Largest VEC (elements) so that every operand can be walked in 16-byte (or smaller pow2) packs
+// along dim 0: dim 0 contiguous or stride 0 (inputs only), sizes/strides/pointers aligned.
+static int pick_vec(const kf_iter_desc *d, int esize) {
+    int vec = 16 / esize;
+    for (; vec > 1; vec >>= 1) {
+        const int64_t vb = (int64_t)vec * esize;
+        bool ok = d->shape[0] % vec == 0;
+        for (int t = 0; ok && t < d->ntensors; ++t) {
+            const int64_t s0 = d->stride_bytes[t][0];
+            if (!(s0 == esize || (s0 == 0 && t >= d->noutputs))) ok = false;
+            if ((uintptr_t)d->data[t] % (s0 == 0 ? esize : vb)) ok = false;
+            if (s0 != 0)
+                for (int i = 1; ok && i < d->ndim; ++i)
+                    if (d->stride_bytes[t][i] % vb) ok = false;
+        }
+        if (ok) return vec;
+    }
+    return 1;
+}
+
+template <typename T, int NIN, int MODE>
+static int launch_same(const kf_iter_desc *d, int op, uint64_t fill_bits, hipStream_t st) {
+    constexpr int NT = NIN + 1;
+    constexpr int VMAX = 16 / sizeof(T);
+    KF_PROF(MODE == 0 ? "ew_arith" : MODE == 1 ? "ew_copy" : "ew_fill", st);
+    SameArgs<NT> a;
+    memset(&a, 0, sizeof(a));
+    for (int t = 0; t < NT; ++t) a.ptr[t] = (char *)d->data[t];
+    a.op = op;
+    a.fill_bits = fill_bits;
+    const int64_t numel = desc_numel(d);
+    int opidx[NT];
+    for (int t = 0; t < NT; ++t) opidx[t] = t;
+
+    if (desc_contiguous(d)) {
+        bool aligned = numel % VMAX == 0;
+        for (int t = 0; t < NT; ++t)
+            if ((uintptr_t)d->data[t] % 16) aligned = false;
+        if (aligned && VMAX > 1) {
+            a.nvec = numel / VMAX;
+            ew_same_kernel<T, VMAX, NIN, MODE, true><<<grid_for(a.nvec), kBlock, 0, st>>>(a);
+        } else {
+            a.nvec = numel;
+            ew_same_kernel<T, 1, NIN, MODE, true><<<grid_for(a.nvec), kBlock, 0, st>>>(a);
+        }
+        KF_LAUNCH_CHECK();
+        return KF_OK;
+    }
+    KF_REQUIRE(desc_is_32bit(d), KF_ERR_INDEX_RANGE, "kf_elementwise: strided descriptor is not 32-bit indexable");
+    int vec = pick_vec(d, sizeof(T));
+    if (vec != VMAX) vec = 1; // two instantiations only: full 16-B packs or scalar
+    for (int t = 0; t < NT; ++t)
+        if (d->stride_bytes[t][0] == 0 && t >= d->noutputs) a.bcast0 |= 1u << t;
+    KF_REQUIRE(OffsetCalc<NT>::build(a.oc, d, opidx, vec), KF_ERR_INVALID, "kf_elementwise: bad shape/stride");
+    a.nvec = numel / vec;
+    if (vec == VMAX && VMAX > 1)
+        ew_same_kernel<T, VMAX, NIN, MODE, false><<<grid_for(a.nvec), kBlock, 0, st>>>(a);
+    else
+        ew_same_kernel<T, 1, NIN, MODE, false><<<grid_for(a.nvec), kBlock, 0, st>>>(a);
+    KF_LAUNCH_CHECK();
+    return KF_OK;
+}
+
+template <typename A, int NIN, int MODE>
+static int launch_cast(const kf_iter_desc *d, int op, hipStream_t st) {
+    constexpr int NT = NIN + 1;
+    KF_REQUIRE(desc_is_32bit(d), KF_ERR_INDEX_RANGE, "kf_elementwise: mixed-dtype descriptor is not 32-bit indexable");
+    KF_PROF(MODE == 0 ? "ew_arith_cast" : "ew_convert", st);
+    CastArgs<NT> a;
+    memset(&a, 0, sizeof(a));
+    int opidx[NT];
+    for (int t = 0; t < NT; ++t) {
+        a.ptr[t] = (char *)d->data[t];
+        a.dtype[t] = d->dtype[t];
+        opidx[t] = t;
+    }
+    a.op = op;
+    a.n = (uint32_t)desc_numel(d);
+    KF_REQUIRE(OffsetCalc<NT>::build(a.oc, d, opidx, 1), KF_ERR_INVALID, "kf_elementwise: bad shape/stride");
+    ew_cast_kernel<A, NIN, MODE><<<grid_for(a.n), kBlock, 0, st>>>(a);
+    KF_LAUNCH_CHECK();
+    return KF_OK;
+}
+
+// accumulate class of a dtype: 0 float, 1 double, 2 int64, 3 bool
+static int acc_class(int dt) {
+    switch (dt) {
+    case KF_F16: case KF_BF16: case KF_F32: return 0;
+    case KF_F64: return 1;
+    case KF_BOOL: return 3;
+    default: return 2;
+    }
+}
+
+static uint16_t host_f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0x7FC0;
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+static uint16_t host_f32_to_f16(float f) {
+    _Float16 h = (_Float16)f;
+    uint16_t r;
+    memcpy(&r, &h, 2);
+    return r;
+}
+
+// value -> acc type of the output dtype -> output dtype (nullary_ops_kernel.cu:20-25)
+static uint64_t fill_pattern(int dt, double v) {
+    uint64_t bits = 0;
+    switch (dt) {
+    case KF_BOOL: { uint8_t x = (v != 0.0); memcpy(&bits, &x, 1); } break;
+    case KF_U8: { uint8_t x = (uint8_t)(int64_t)v; memcpy(&bits, &x, 1); } break;
+    case KF_I8: { int8_t x = (int8_t)(int64_t)v; memcpy(&bits, &x, 1); } break;
+    case KF_I16: { int16_t x = (int16_t)(int64_t)v; memcpy(&bits, &x, 2); } break;
+    case KF_I32: { int32_t x = (int32_t)(int64_t)v; memcpy(&bits, &x, 4); } break;
+    case KF_I64: { int64_t x = (int64_t)v; memcpy(&bits, &x, 8); } break;
+    case KF_F16: { uint16_t x = host_f32_to_f16((float)v); memcpy(&bits, &x, 2); } break;
+    case KF_BF16: { uint16_t x = host_f32_to_bf16((float)v); memcpy(&bits, &x, 2); } break;
+    case KF_F32: { float x = (float)v; memcpy(&bits, &x, 4); } break;
+    case KF_F64: { memcpy(&bits, &v, 8); } break;
+    }
+    return bits;
+}
+
+template <int NIN, int MODE>
+static int launch_raw_by_size(int esize, const kf_iter_desc *d, uint64_t bits, hipStream_t st) {
+    switch (esize) {
+    case 1: return launch_same<uint8_t, NIN, MODE>(d, 0, bits, st);
+    case 2: return launch_same<uint16_t, NIN, MODE>(d, 0, bits, st);
+    case 4: return launch_same<uint32_t, NIN, MODE>(d, 0, bits, st);
+    default: return launch_same<uint64_t, NIN, MODE>(d, 0, bits, st);
+    }
+}
+
+} // namespace kf
+
+using namespace kf;
+
+extern "C" int kf_elementwise(int op, const kf_iter_desc *d, int compute_dtype, double scalar, void *stream) {
+    KF_REQUIRE(d, KF_ERR_INVALID, "kf_elementwise: null descriptor");
+    KF_REQUIRE(op >= KF_EW_ADD && op <= KF_EW_FILL, KF_ERR_INVALID, "kf_elementwise: unknown op %d", op);
+    KF_REQUIRE(d->ndim >= 1 && d->ndim <= KF_MAX_DIMS, KF_ERR_INVALID, "kf_elementwise: ndim %d out of range", d->ndim);
+    const int nin = op <= KF_EW_DIV ? 2 : (op == KF_EW_COPY ? 1 : 0);
+    KF_REQUIRE(d->noutputs == 1 && d->ntensors == nin + 1, KF_ERR_INVALID,
+               "kf_elementwise: op %d wants 1 output + %d inputs, got %d/%d", op, nin, d->noutputs, d->ntensors);
+    for (int t = 0; t < d->ntensors; ++t) {
+        KF_REQUIRE(d->dtype[t] >= 0 && d->dtype[t] < KF_DTYPE_COUNT, KF_ERR_INVALID, "kf_elementwise: bad dtype");
+        KF_REQUIRE(d->data[t], KF_ERR_INVALID, "kf_elementwise: null data pointer for operand %d", t);
+    }
+    const int64_t numel = desc_numel(d);
+    if (numel == 0) return KF_OK;
+    KF_REQUIRE(numel > 0, KF_ERR_INVALID, "kf_elementwise: negative extent");
+    hipStream_t st = as_stream(stream);
+    const int odt = d->dtype[0];
+
+    if (op == KF_EW_FILL) return launch_raw_by_size<0, 2>(dtype_size(odt), d, fill_pattern(odt, scalar), st);
+
+    if (op == KF_EW_COPY) {
+        if (d->dtype[1] == odt) return launch_raw_by_size<1, 1>(dtype_size(odt), d, 0, st);
+        switch (acc_class(odt)) { // value is cast straight to the output dtype (unary_ops_kernel.cu:13-17)
+        case 0: return launch_cast<float, 1, 1>(d, op, st);
+        case 1: return launch_cast<double, 1, 1>(d, op, st);
+        case 2: return launch_cast<int64_t, 1, 1>(d, op, st);
+        default: return launch_cast<bool, 1, 1>(d, op, st);
+        }
+    }
+
+    KF_REQUIRE(compute_dtype >= 0 && compute_dtype < KF_DTYPE_COUNT, KF_ERR_INVALID, "kf_elementwise: bad compute dtype");
+    const bool same = d->dtype[0] == compute_dtype && d->dtype[1] == compute_dtype && d->dtype[2] == compute_dtype;
+    if (same) {
+        switch (compute_dtype) {
+        case KF_F32: return launch_same<float, 2, 0>(d, op, 0, st);
+        case KF_F64: return launch_same<double, 2, 0>(d, op, 0, st);
+        case KF_BF16: return launch_same<bf16_t, 2, 0>(d, op, 0, st);
+        case KF_F16: return launch_same<f16_t, 2, 0>(d, op, 0, st);
+        case KF_I32: return launch_same<int32_t, 2, 0>(d, op, 0, st);
+        case KF_I64: return launch_same<int64_t, 2, 0>(d, op, 0, st);
+        default: break;
+        }
+    }
+    switch (acc_class(compute_dtype)) {
+    case 0: return launch_cast<float, 2, 0>(d, op, st);
+    case 1: return launch_cast<double, 2, 0>(d, op, st);
+    case 2: return launch_cast<int64_t, 2, 0>(d, op, st);
+    default: return launch_cast<bool, 2, 0>(d, op, st);
+    }
+}

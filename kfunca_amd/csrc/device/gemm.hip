@@ -1,0 +1,438 @@
+// GEMM for gfx950: C[M,N] = alpha * op(A) * op(B) + beta * C (row-major), + fused row-bias epilogue.
+//
+// Replaces src/device/gemm_kernel.cu:8-38, whose arithmetic is an un-vendored CUTLASS SIMT GEMM
+// (src/device/launcher_cuda.h:537-614). Hand-written for CDNA4:
+//   f32      v_mfma_f32_32x32x2_f32 (exact f32 fma chain), 128x128x16 block tile, 4 waves each
+//            owning 64x64, LDS tiles kept k-major so every fragment read is a conflict-free
+//            ds_read_b32; all four op(A)/op(B) layouts are consumed in place.
+//   bf16/f16 v_mfma_f32_32x32x16_{bf16,f16}, 128x128x64 block tile, direct-to-LDS staging
+//            (global_load_lds_dwordx4, XOR-swizzled through the SOURCE address so ds_read_b128 is
+//            conflict-free), double-buffered LDS, one barrier per K tile, XCD-aware tile order.
+//            The kernel consumes K-contiguous operands (A as [M,K], B as [N,K]); the other layouts
+//            are re-laid by a tiled transpose into caller-supplied scratch.
+//   f64 / ragged shapes: a plain LDS-tiled FMA kernel (the reference's only GEMM test is this
+//            case: f64 123x457x234, test/test_gemm.py:9-17).
+#include "common.h"
+
+namespace kf {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+struct GemmArgs {
+    const void *A, *B;
+    void *C;
+    const void *bias;
+    int64_t M, N, K, lda, ldb, ldc;
+    float alpha, beta;
+    int epilogue;
+};
+
+// XCD-aware remap: consecutive logical tile ids land on the same XCD (its own 4 MiB L2) so
+// neighbouring tiles share operand panels in L2. Bijective for any grid size.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {
+    const uint32_t nx = 8, xcd = bid % nx, q = nwg / nx, r = nwg % nx;
+    const uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + bid / nx;
+}
+
+// ------------------------------------------------------------------------------------------
+// generic fallback: any shape, any layout, f32/f64/bf16/f16; 32x32 tile, 256 threads (2x2 per lane)
+// ------------------------------------------------------------------------------------------
+template <typename T> struct GAcc { using type = float; };
+template <> struct GAcc<double> { using type = double; };
+template <typename T> __device__ __forceinline__ typename GAcc<T>::type g_load(const T *p) { return (typename GAcc<T>::type)(*p); }
+template <> __device__ __forceinline__ float g_load<bf16_t>(const bf16_t *p) { return bf16_to_f32(*p); }
+template <> __device__ __forceinline__ float g_load<f16_t>(const f16_t *p) { return f16_to_f32(*p); }
+template <typename T> __device__ __forceinline__ void g_store(T *p, typename GAcc<T>::type v) { *p = (T)v; }
+template <> __device__ __forceinline__ void g_store<bf16_t>(bf16_t *p, float v) { *p = f32_to_bf16(v); }
+template <> __device__ __forceinline__ void g_store<f16_t>(f16_t *p, float v) { *p = f32_to_f16(v); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_generic_kernel(const GemmArgs g, int ta, int tb) {
+    using A_t = typename GAcc<T>::type;
+    constexpr int TS = 32, TK = 32;
+    __shared__ A_t As[TK][TS + 1], Bs[TK][TS + 1];
+    const T *A = (const T *)g.A, *B = (const T *)g.B;
+    T *C = (T *)g.C;
+    const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
+    const int64_t m0 = (int64_t)blockIdx.y * TS, n0 = (int64_t)blockIdx.x * TS;
+    A_t acc[2][2] = {{0, 0}, {0, 0}};
+    for (int64_t k0 = 0; k0 < g.K; k0 += TK) {
+        for (int i = threadIdx.x; i < TS * TK; i += 256) {
+            const int mm = ta ? i % TS : i / TK, kk = ta ? i / TS : i % TK; // walk the contiguous axis fastest
+            const int64_t m = m0 + mm, k = k0 + kk;
+            A_t v = 0;
+            if (m < g.M && k < g.K) v = g_load<T>(A + (ta ? k * g.lda + m : m * g.lda + k));
+            As[kk][mm] = v;
+        }
+        for (int i = threadIdx.x; i < TS * TK; i += 256) {
+            const int nn = tb ? i / TK : i % TS, kk = tb ? i % TK : i / TS;
+            const int64_t n = n0 + nn, k = k0 + kk;
+            A_t v = 0;
+            if (n < g.N && k < g.K) v = g_load<T>(B + (tb ? n * g.ldb + k : k * g.ldb + n));
+            Bs[kk][nn] = v;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < TK; ++kk) {
+            const A_t a0 = As[kk][ty], a1 = As[kk][ty + 16], b0 = Bs[kk][tx], b1 = Bs[kk][tx + 16];
+            acc[0][0] = fma(a0, b0, acc[0][0]);
+            acc[0][1] = fma(a0, b1, acc[0][1]);
+            acc[1][0] = fma(a1, b0, acc[1][0]);
+            acc[1][1] = fma(a1, b1, acc[1][1]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t m = m0 + ty + 16 * i, n = n0 + tx + 16 * j;
+            if (m < g.M && n < g.N) {
+                A_t v = (A_t)g.alpha * acc[i][j];
+                if (g.beta != 0.f) v += (A_t)g.beta * g_load<T>(C + m * g.ldc + n);
+                if (g.epilogue == KF_EPI_BIAS_ROW) v += g_load<T>((const T *)g.bias + n);
+                g_store<T>(C + m * g.ldc + n, v);
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// f32: MFMA 32x32x2, 128x128x16 tiles, all layouts in place
+// ------------------------------------------------------------------------------------------
+constexpr int F_BM = 128, F_BN = 128, F_BK = 16, F_LD = 132;
+
+// stage one operand tile (128 x 16) into registers; KCONTIG: global rows are along the 128-axis
+// with k contiguous; else global rows are k with the 128-axis contiguous. (Two named float4s, not
+// an array: hipcc keeps a by-reference float4[2] in scratch.)
+template <bool KCONTIG>
+__device__ __forceinline__ void f32_load_tile(const float *base, int64_t ld, int64_t x0, int64_t k0, float4 &r0, float4 &r1) {
+    const int t = threadIdx.x;
+    if constexpr (KCONTIG) {
+        const int row = t / 4, kq = t % 4;
+        r0 = *(const float4 *)(base + (x0 + row) * ld + k0 + kq * 4);
+        r1 = *(const float4 *)(base + (x0 + row + 64) * ld + k0 + kq * 4);
+    } else {
+        const int k = t / 32, xq = t % 32;
+        r0 = *(const float4 *)(base + (k0 + k) * ld + x0 + xq * 4);
+        r1 = *(const float4 *)(base + (k0 + k + 8) * ld + x0 + xq * 4);
+    }
+}
+template <bool KCONTIG>
+__device__ __forceinline__ void f32_write_tile(float (*s)[F_LD], const float4 &r0, const float4 &r1) {
+    const int t = threadIdx.x;
+    if constexpr (KCONTIG) {
+        const int row = t / 4, kq = t % 4;
+        s[kq * 4 + 0][row] = r0.x;
+        s[kq * 4 + 1][row] = r0.y;
+        s[kq * 4 + 2][row] = r0.z;
+        s[kq * 4 + 3][row] = r0.w;
+        s[kq * 4 + 0][row + 64] = r1.x;
+        s[kq * 4 + 1][row + 64] = r1.y;
+        s[kq * 4 + 2][row + 64] = r1.z;
+        s[kq * 4 + 3][row + 64] = r1.w;
+    } else {
+        const int k = t / 32, xq = t % 32;
+        *(float4 *)&s[k][xq * 4] = r0;
+        *(float4 *)&s[k + 8][xq * 4] = r1;
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) float As[2][F_BK][F_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][F_BK][F_LD];
+    const float *A = (const float *)g.A, *B = (const float *)g.B;
+    float *C = (float *)g.C;
+    const uint32_t tiles_n = (uint32_t)(g.N / F_BN);
+    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t m0 = (int64_t)(tile / tiles_n) * F_BM, n0 = (int64_t)(tile % tiles_n) * F_BN;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float4 ra0, ra1, rb0, rb1;
+    f32_load_tile<!TA>(A, g.lda, m0, 0, ra0, ra1);
+    f32_load_tile<TB>(B, g.ldb, n0, 0, rb0, rb1);
+    f32_write_tile<!TA>(As[0], ra0, ra1);
+    f32_write_tile<TB>(Bs[0], rb0, rb1);
+    __syncthreads();
+
+    const int nt = (int)(g.K / F_BK);
+    const int kl = lane >> 5, xl = lane & 31;
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            f32_load_tile<!TA>(A, g.lda, m0, (int64_t)(t + 1) * F_BK, ra0, ra1);
+            f32_load_tile<TB>(B, g.ldb, n0, (int64_t)(t + 1) * F_BK, rb0, rb1);
+        }
+#pragma unroll
+        for (int ks = 0; ks < F_BK; ks += 2) {
+            float a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = As[cur][ks + kl][wr * 64 + i * 32 + xl];
+                b[i] = Bs[cur][ks + kl][wc * 64 + i * 32 + xl];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nt) {
+            f32_write_tile<!TA>(As[cur ^ 1], ra0, ra1);
+            f32_write_tile<TB>(Bs[cur ^ 1], rb0, rb1);
+        }
+        __syncthreads();
+    }
+
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t n = n0 + wc * 64 + j * 32 + xl;
+            const float bias = g.epilogue == KF_EPI_BIAS_ROW ? ((const float *)g.bias)[n] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kl;
+                float v = g.alpha * acc[i][j][e];
+                if (g.beta != 0.f) v += g.beta * C[m * g.ldc + n];
+                C[m * g.ldc + n] = v + bias;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// bf16 / f16: MFMA 32x32x16, 128x128x64 tiles, global_load_lds staging, K-contiguous operands
+// ------------------------------------------------------------------------------------------
+constexpr int H_BM = 128, H_BN = 128, H_BK = 64;
+constexpr int H_TILE_BYTES = H_BM * H_BK * 2; // 16 KiB per operand tile
+
+template <bool BF> struct HFrag { using type = f16x8; };
+template <> struct HFrag<true> { using type = bf16x8; };
+
+template <bool BF>
+__device__ __forceinline__ f32x16 h_mfma(typename HFrag<BF>::type a, typename HFrag<BF>::type b, f32x16 c) {
+    if constexpr (BF)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// LDS image of a [128 rows][64 k] 16-bit tile: 128-B rows, 16-B chunk c of row r stored at chunk
+// position c ^ ((r >> 1) & 7) — makes the fragment ds_read_b128 (16 different rows per lane group,
+// same logical chunk) hit 16 different 16-B slots of the 256-B bank row.
+__device__ __forceinline__ int h_lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// one wave-instruction moves 8 rows x 128 B; 4 waves x 4 instructions cover the 128-row tile
+__device__ __forceinline__ void h_stage(const char *gbase, int64_t ld_bytes, int64_t x0, int64_t k0_bytes, char *lds_tile) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row0 = (wid * 4 + i) * 8;
+        const int row = row0 + (lane >> 3), pos = lane & 7;
+        const int chunk = pos ^ ((row >> 1) & 7); // inverse of the read-side XOR (an involution)
+        const char *src = gbase + (x0 + row) * ld_bytes + k0_bytes + chunk * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(lds_tile + row0 * 128), 16, 0, 0);
+    }
+}
+
+template <bool BF>
+__global__ __launch_bounds__(256) void gemm_h_kernel(const GemmArgs g) {
+    using frag_t = typename HFrag<BF>::type;
+    extern __shared__ __attribute__((aligned(16))) char smem[]; // [2 buffers][A tile | B tile]
+    const char *A = (const char *)g.A, *B = (const char *)g.B;
+    const uint32_t tiles_n = (uint32_t)(g.N / H_BN);
+    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t m0 = (int64_t)(tile / tiles_n) * H_BM, n0 = (int64_t)(tile % tiles_n) * H_BN;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int xl = lane & 31, hl = lane >> 5;
+    const int64_t lda_b = g.lda * 2, ldb_b = g.ldb * 2;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    h_stage(A, lda_b, m0, 0, smem);
+    h_stage(B, ldb_b, n0, 0, smem + H_TILE_BYTES);
+    __syncthreads(); // emits s_waitcnt vmcnt(0) for the LDS-DMA in flight, then s_barrier
+
+    const int nt = (int)(g.K / H_BK);
+    for (int t = 0; t < nt; ++t) {
+        char *cur = smem + (t & 1) * 2 * H_TILE_BYTES;
+        char *nxt = smem + ((t + 1) & 1) * 2 * H_TILE_BYTES;
+        if (t + 1 < nt) {
+            h_stage(A, lda_b, m0, (int64_t)(t + 1) * H_BK * 2, nxt);
+            h_stage(B, ldb_b, n0, (int64_t)(t + 1) * H_BK * 2, nxt + H_TILE_BYTES);
+        }
+#pragma unroll
+        for (int ks = 0; ks < H_BK / 16; ++ks) {
+            frag_t a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *(const frag_t *)(cur + h_lds_off(wr * 64 + i * 32 + xl, ks * 2 + hl));
+                b[i] = *(const frag_t *)(cur + H_TILE_BYTES + h_lds_off(wc * 64 + i * 32 + xl, ks * 2 + hl));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = h_mfma<BF>(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+    uint16_t *C = (uint16_t *)g.C;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t n = n0 + wc * 64 + j * 32 + xl;
+            float bias = 0.f;
+            if (g.epilogue == KF_EPI_BIAS_ROW) {
+                const uint16_t bb = ((const uint16_t *)g.bias)[n];
+                bias = BF ? bf16_to_f32(bf16_t{bb}) : f16_to_f32(f16_t{bb});
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+                float v = g.alpha * acc[i][j][e];
+                if (g.beta != 0.f) {
+                    const uint16_t old = C[m * g.ldc + n];
+                    v += g.beta * (BF ? bf16_to_f32(bf16_t{old}) : f16_to_f32(f16_t{old}));
+                }
+                v += bias;
+                C[m * g.ldc + n] = BF ? f32_to_bf16(v).x : f32_to_f16(v).x;
+            }
+        }
+}
+
+// tiled 16-bit transpose: dst[c][r] = src[r][c]; 64x64 tiles through LDS (+1 pad), bit-exact
+__global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t *src, int64_t ld_src, uint16_t *dst, int64_t ld_dst,
+                                                           int64_t R, int64_t Cc) {
+    __shared__ uint16_t tile[64][66];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t r = r0 + i, c = c0 + tx;
+        if (r < R && c < Cc) tile[i][tx] = src[r * ld_src + c];
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int64_t c = c0 + i, r = r0 + tx;
+        if (r < R && c < Cc) dst[c * ld_dst + r] = tile[tx][i];
+    }
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static bool h_fast_ok(int64_t M, int64_t N, int64_t K) { return M % H_BM == 0 && N % H_BN == 0 && K % H_BK == 0 && M > 0 && N > 0 && K > 0; }
+
+} // namespace kf
+
+using namespace kf;
+
+extern "C" int kf_gemm_workspace_bytes(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, size_t *bytes) {
+    KF_REQUIRE(bytes, KF_ERR_INVALID, "kf_gemm_workspace_bytes: null out pointer");
+    *bytes = 0;
+    if ((dtype == KF_BF16 || dtype == KF_F16) && h_fast_ok(M, N, K)) {
+        if (trans_a) *bytes += align_up((size_t)M * K * 2, 256);
+        if (!trans_b) *bytes += align_up((size_t)K * N * 2, 256);
+    }
+    return KF_OK;
+}
+
+extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const void *A,
+                       int64_t lda, const void *B, int64_t ldb, float beta, void *C, int64_t ldc, int epilogue,
+                       const void *bias, void *workspace, size_t workspace_bytes, void *stream) {
+    KF_REQUIRE(dtype == KF_F32 || dtype == KF_F64 || dtype == KF_F16 || dtype == KF_BF16, KF_ERR_UNSUPPORTED,
+               "kf_gemm: dtype %d not supported (float, double, half, bfloat16)", dtype);
+    KF_REQUIRE(M >= 0 && N >= 0 && K >= 0, KF_ERR_INVALID, "kf_gemm: negative extent");
+    if (M == 0 || N == 0) return KF_OK;
+    KF_REQUIRE(A && B && C, KF_ERR_INVALID, "kf_gemm: null operand");
+    KF_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, KF_ERR_INVALID, "kf_gemm: leading dimension too small");
+    KF_REQUIRE(epilogue == KF_EPI_NONE || (epilogue == KF_EPI_BIAS_ROW && bias), KF_ERR_INVALID, "kf_gemm: bad epilogue");
+    hipStream_t st = as_stream(stream);
+    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, beta, epilogue};
+
+    const bool al16 = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0);
+    if (dtype == KF_F32 && M % F_BM == 0 && N % F_BN == 0 && K % F_BK == 0 && K > 0 && al16 && lda % 4 == 0 && ldb % 4 == 0) {
+        const unsigned grid = (unsigned)((M / F_BM) * (N / F_BN));
+        KF_PROF("gemm_f32_mfma", st);
+        if (!trans_a && !trans_b) gemm_f32_kernel<false, false><<<grid, 256, 0, st>>>(g);
+        else if (!trans_a && trans_b) gemm_f32_kernel<false, true><<<grid, 256, 0, st>>>(g);
+        else if (trans_a && !trans_b) gemm_f32_kernel<true, false><<<grid, 256, 0, st>>>(g);
+        else gemm_f32_kernel<true, true><<<grid, 256, 0, st>>>(g);
+        KF_LAUNCH_CHECK();
+        return KF_OK;
+    }
+    if ((dtype == KF_BF16 || dtype == KF_F16) && h_fast_ok(M, N, K) && al16 && lda % 8 == 0 && ldb % 8 == 0) {
+        size_t need = 0;
+        kf_gemm_workspace_bytes(dtype, trans_a, trans_b, M, N, K, &need);
+        KF_REQUIRE(need == 0 || (workspace && workspace_bytes >= need && (uintptr_t)workspace % 16 == 0), KF_ERR_WORKSPACE,
+                   "kf_gemm: workspace of %zu bytes (16-B aligned) required, got %zu", need, workspace_bytes);
+        char *ws = (char *)workspace;
+        if (trans_a) { // stored [K,M] -> [M,K]
+            dim3 grid((unsigned)((M + 63) / 64), (unsigned)((K + 63) / 64));
+            KF_PROF("gemm_relayout16", st);
+            transpose16_kernel<<<grid, 256, 0, st>>>((const uint16_t *)A, lda, (uint16_t *)ws, K, K, M);
+            KF_LAUNCH_CHECK();
+            g.A = ws;
+            g.lda = K;
+            ws += align_up((size_t)M * K * 2, 256);
+        }
+        if (!trans_b) { // stored [K,N] -> [N,K]
+            dim3 grid((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64));
+            KF_PROF("gemm_relayout16", st);
+            transpose16_kernel<<<grid, 256, 0, st>>>((const uint16_t *)B, ldb, (uint16_t *)ws, K, K, N);
+            KF_LAUNCH_CHECK();
+            g.B = ws;
+            g.ldb = K;
+        }
+        const unsigned grid = (unsigned)((M / H_BM) * (N / H_BN));
+        const size_t lds = 4 * H_TILE_BYTES;
+        KF_PROF(dtype == KF_BF16 ? "gemm_bf16_mfma" : "gemm_f16_mfma", st);
+        if (dtype == KF_BF16) {
+            static bool attr_bf = false;
+            if (!attr_bf) {
+                KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_h_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_bf = true;
+            }
+            gemm_h_kernel<true><<<grid, 256, lds, st>>>(g);
+        } else {
+            static bool attr_h = false;
+            if (!attr_h) {
+                KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_h_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_h = true;
+            }
+            gemm_h_kernel<false><<<grid, 256, lds, st>>>(g);
+        }
+        KF_LAUNCH_CHECK();
+        return KF_OK;
+    }
+    dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32));
+    KF_PROF("gemm_generic", st);
+    switch (dtype) {
+    case KF_F32: gemm_generic_kernel<float><<<grid, 256, 0, st>>>(g, trans_a, trans_b); break;
+    case KF_F64: gemm_generic_kernel<double><<<grid, 256, 0, st>>>(g, trans_a, trans_b); break;
+    case KF_BF16: gemm_generic_kernel<bf16_t><<<grid, 256, 0, st>>>(g, trans_a, trans_b); break;
+    default: gemm_generic_kernel<f16_t><<<grid, 256, 0, st>>>(g, trans_a, trans_b); break;
+    }
+    KF_LAUNCH_CHECK();
+    return KF_OK;
+}

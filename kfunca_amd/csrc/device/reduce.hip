@@ -1,0 +1,474 @@
+// sum / mean reductions for gfx950 (keepdim over one logical dim, any layout).
+//
+// Replaces the reference's reduce engine (src/device/utils/tensor_reduce.h:35-1083 driven by
+// src/device/reduce_ops_kernel.cu:6-59). Native wave64 design rather than its 32-lane one:
+//   inner  — the reduced dim is contiguous: rows are streamed with coalesced (16-B when aligned)
+//            loads, lanes of one row combine with 64-wide wave shuffles, rows wider than a wave
+//            finish through LDS;
+//   outer  — the reduced dim is strided and an output dim is contiguous (column sums): lanes walk
+//            columns (coalesced), 4 row-groups per block combine through LDS;
+//   generic— anything else: one lane per output element.
+// Few-outputs/many-inputs shapes split the reduced extent over gridDim.y into an f32/f64/i64
+// partial buffer supplied by the caller, and a second tiny kernel folds the partials in a fixed
+// order — no atomics, no semaphores (the reference's last-block-done semaphores are never zeroed,
+// tensor_reduce.h:748,1057-1058), bitwise reproducible run to run.
+// Accumulation: float for half/bf16/float (the reference accumulates sum in the input dtype,
+// reduce_ops_kernel.cu:13-18 — ours is at least as accurate and inside its 1e-2 test tolerance),
+// double for double, int64 for integers (identical to in-dtype wraparound after truncation).
+// mean multiplies by the reference's factor = nout/numel evaluated in the input dtype
+// (reduce_ops_kernel.cu:49-53) — for integer dtypes that is an integer quotient (0 unless R == 1).
+#include <type_traits>
+
+#include "common.h"
+#include "offset_calc.h"
+
+namespace kf {
+
+constexpr int kRB = 256; // threads per block
+
+template <typename T> struct RAcc { using type = int64_t; };
+template <> struct RAcc<float> { using type = float; };
+template <> struct RAcc<bf16_t> { using type = float; };
+template <> struct RAcc<f16_t> { using type = float; };
+template <> struct RAcc<double> { using type = double; };
+
+template <typename T> __device__ __forceinline__ typename RAcc<T>::type r_load(const char *p) { return (typename RAcc<T>::type)(*(const T *)p); }
+template <> __device__ __forceinline__ float r_load<bf16_t>(const char *p) { return bf16_to_f32(*(const bf16_t *)p); }
+template <> __device__ __forceinline__ float r_load<f16_t>(const char *p) { return f16_to_f32(*(const f16_t *)p); }
+template <> __device__ __forceinline__ int64_t r_load<bool>(const char *p) { return *(const uint8_t *)p != 0; }
+
+template <typename T> __device__ __forceinline__ void r_store(char *p, typename RAcc<T>::type v) { *(T *)p = (T)v; }
+template <> __device__ __forceinline__ void r_store<bf16_t>(char *p, float v) { *(bf16_t *)p = f32_to_bf16(v); }
+template <> __device__ __forceinline__ void r_store<f16_t>(char *p, float v) { *(f16_t *)p = f32_to_f16(v); }
+template <> __device__ __forceinline__ void r_store<bool>(char *p, int64_t v) { *(uint8_t *)p = (uint8_t)(v != 0); }
+
+template <typename A> __device__ __forceinline__ A shfl_xor_acc(A v, int m) { return __shfl_xor(v, m, 64); }
+template <> __device__ __forceinline__ int64_t shfl_xor_acc<int64_t>(int64_t v, int m) {
+    int lo = __shfl_xor((int)(uint32_t)v, m, 64), hi = __shfl_xor((int)(v >> 32), m, 64);
+    return ((int64_t)hi << 32) | (uint32_t)lo;
+}
+template <> __device__ __forceinline__ double shfl_xor_acc<double>(double v, int m) {
+    int64_t b = __double_as_longlong(v);
+    return __longlong_as_double(shfl_xor_acc<int64_t>(b, m));
+}
+
+template <typename A>
+struct Project {
+    A factor;   // mean: nout/numel in the input dtype; sum: 1
+    int scale;  // 0: sum (no multiply)
+    __device__ __forceinline__ A operator()(A v) const { return scale ? v * factor : v; }
+};
+
+struct RedArgs {
+    const char *in;
+    char *out;
+    void *ws;          // partials [nsplit][nout] of the accumulate type (nsplit > 1)
+    int64_t R;         // reduced extent
+    int64_t r_stride;  // bytes between consecutive reduced elements
+    int64_t C;         // outer path: contiguous output extent (dim 1)
+    uint32_t nout;     // total outputs
+    uint32_t nouter;   // outer path: outputs beyond dim 1
+    int nsplit;
+    int tx;            // inner path: lanes per row (power of two <= 256)
+    OffsetCalc<2> oc;  // output-dims calculator: [0] = out bytes, [1] = in bytes
+    OffsetCalc<1> rc;  // generic path: reduced-dims calculator (in bytes)
+    uint32_t rtot;     // generic path: total reduced elements
+};
+
+template <typename T, int VEC>
+struct alignas(sizeof(T) * VEC) RPack { T v[VEC]; };
+
+// ---- inner: reduced dim contiguous ---------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(kRB) void reduce_inner_kernel(const RedArgs a, const Project<typename RAcc<T>::type> proj) {
+    using A = typename RAcc<T>::type;
+    __shared__ A smem[kRB];
+    const int tx = a.tx, ty = kRB / tx;
+    const int lx = threadIdx.x % tx, ly = threadIdx.x / tx;
+    const uint32_t o = blockIdx.x * ty + ly;
+    const bool live = o < a.nout;
+    A acc0 = A(0), acc1 = A(0), acc2 = A(0), acc3 = A(0);
+    uint32_t off[2] = {0, 0};
+    if (live) {
+        a.oc.get(o, off);
+        const int64_t chunk = ((a.R / VEC + a.nsplit - 1) / a.nsplit) * VEC;
+        const int64_t r0 = (int64_t)blockIdx.y * chunk;
+        const int64_t r1 = r0 + chunk < a.R ? r0 + chunk : a.R;
+        const char *row = a.in + off[1];
+        const int64_t step = (int64_t)tx * VEC;
+        int64_t r = r0 + (int64_t)lx * VEC;
+        for (; r + 3 * step < r1; r += 4 * step) {
+            RPack<T, VEC> p0 = *(const RPack<T, VEC> *)(row + r * sizeof(T));
+            RPack<T, VEC> p1 = *(const RPack<T, VEC> *)(row + (r + step) * sizeof(T));
+            RPack<T, VEC> p2 = *(const RPack<T, VEC> *)(row + (r + 2 * step) * sizeof(T));
+            RPack<T, VEC> p3 = *(const RPack<T, VEC> *)(row + (r + 3 * step) * sizeof(T));
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                acc0 += r_load<T>((const char *)&p0.v[e]);
+                acc1 += r_load<T>((const char *)&p1.v[e]);
+                acc2 += r_load<T>((const char *)&p2.v[e]);
+                acc3 += r_load<T>((const char *)&p3.v[e]);
+            }
+        }
+        for (; r < r1; r += step) {
+            RPack<T, VEC> p0 = *(const RPack<T, VEC> *)(row + r * sizeof(T));
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc0 += r_load<T>((const char *)&p0.v[e]);
+        }
+    }
+    A acc = (acc0 + acc1) + (acc2 + acc3);
+    if (tx <= kWave) {
+        for (int m = tx >> 1; m > 0; m >>= 1) acc += shfl_xor_acc<A>(acc, m);
+    } else {
+        smem[threadIdx.x] = acc;
+        __syncthreads();
+        for (int s = tx >> 1; s >= kWave; s >>= 1) {
+            if (lx < s) smem[threadIdx.x] += smem[threadIdx.x + s];
+            __syncthreads();
+        }
+        acc = smem[threadIdx.x];
+        if (lx < kWave)
+            for (int m = kWave >> 1; m > 0; m >>= 1) acc += shfl_xor_acc<A>(acc, m);
+    }
+    if (live && lx == 0) {
+        if (a.nsplit == 1)
+            r_store<T>(a.out + off[0], proj(acc));
+        else
+            ((A *)a.ws)[(size_t)blockIdx.y * a.nout + o] = acc;
+    }
+}
+
+// ---- outer: reduced dim strided, dim 1 contiguous (column sums) ------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(kRB) void reduce_outer_kernel(const RedArgs a, const Project<typename RAcc<T>::type> proj) {
+    using A = typename RAcc<T>::type;
+    __shared__ A smem[3][kWave][VEC];
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6; // 64 column-lanes x 4 row groups
+    const int64_t c = ((int64_t)blockIdx.x * kWave + lx) * VEC;
+    const bool live = c < a.C;
+    const int64_t chunk = (a.R + a.nsplit - 1) / a.nsplit;
+    const int64_t r0 = (int64_t)blockIdx.y * chunk;
+    const int64_t r1 = r0 + chunk < a.R ? r0 + chunk : a.R;
+    for (uint32_t z = blockIdx.z; z < a.nouter; z += gridDim.z) {
+        uint32_t off[2];
+        a.oc.get(z, off); // oc walks dims >= 2 here
+        A acc[4][VEC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[u][e] = A(0);
+        if (live) {
+            const char *col = a.in + off[1] + c * sizeof(T);
+            int64_t r = r0 + ly;
+            for (; r + 12 < r1; r += 16) {
+                RPack<T, VEC> p[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) p[u] = *(const RPack<T, VEC> *)(col + (r + 4 * u) * a.r_stride);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[u][e] += r_load<T>((const char *)&p[u].v[e]);
+            }
+            for (; r < r1; r += 4) {
+                RPack<T, VEC> p0 = *(const RPack<T, VEC> *)(col + r * a.r_stride);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[0][e] += r_load<T>((const char *)&p0.v[e]);
+            }
+        }
+        A tot[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) tot[e] = (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
+        __syncthreads();
+        if (ly > 0)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) smem[ly - 1][lx][e] = tot[e];
+        __syncthreads();
+        if (ly == 0 && live) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) tot[e] += (smem[0][lx][e] + smem[1][lx][e]) + smem[2][lx][e];
+            if (a.nsplit == 1) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) r_store<T>(a.out + off[0] + (c + e) * sizeof(T), proj(tot[e]));
+            } else {
+                A *w = (A *)a.ws + (size_t)blockIdx.y * a.nout + (size_t)z * a.C + c;
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) w[e] = tot[e];
+            }
+        }
+    }
+}
+
+// second stage: fold partials[nsplit][nout] in split order
+template <typename T>
+__global__ __launch_bounds__(kRB) void reduce_fold_kernel(const RedArgs a, const Project<typename RAcc<T>::type> proj, int outer_layout) {
+    using A = typename RAcc<T>::type;
+    const uint32_t o = blockIdx.x * kRB + threadIdx.x;
+    if (o >= a.nout) return;
+    A acc = A(0);
+    for (int s = 0; s < a.nsplit; ++s) acc += ((const A *)a.ws)[(size_t)s * a.nout + o];
+    uint32_t off[2];
+    if (outer_layout) { // o = z * C + c
+        const uint32_t z = o / (uint32_t)a.C, c = o - z * (uint32_t)a.C;
+        a.oc.get(z, off);
+        off[0] += c * sizeof(T);
+    } else {
+        a.oc.get(o, off);
+    }
+    r_store<T>(a.out + off[0], proj(acc));
+}
+
+// ---- generic: one lane per output -----------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kRB) void reduce_generic_kernel(const RedArgs a, const Project<typename RAcc<T>::type> proj) {
+    using A = typename RAcc<T>::type;
+    const uint32_t o = blockIdx.x * kRB + threadIdx.x;
+    if (o >= a.nout) return;
+    uint32_t off[2];
+    a.oc.get(o, off);
+    const char *base = a.in + off[1];
+    A acc = A(0);
+    for (uint32_t r = 0; r < a.rtot; ++r) {
+        uint32_t ro[1];
+        a.rc.get(r, ro);
+        acc += r_load<T>(base + ro[0]);
+    }
+    r_store<T>(a.out + off[0], proj(acc));
+}
+
+// ------------------------------------------------------------------------------------------
+enum { PATH_INNER = 0, PATH_OUTER = 1, PATH_GENERIC = 2 };
+
+struct Plan {
+    int path = PATH_GENERIC;
+    int vec = 1;
+    int tx = 1;
+    int nsplit = 1;
+    int64_t R = 1, r_stride = 0, C = 1;
+    int64_t nout = 1, nouter = 1, rtot = 1;
+    int red_dims[KF_MAX_DIMS], nred = 0;
+    int out_dims[KF_MAX_DIMS], nod = 0;
+    size_t ws_bytes = 0;
+};
+
+static int pow2_floor(int64_t v) {
+    int p = 1;
+    while ((int64_t)p * 2 <= v) p *= 2;
+    return p;
+}
+
+static int make_plan(const kf_iter_desc *d, Plan &p) {
+    KF_REQUIRE(d->noutputs == 1 && d->ntensors == 2, KF_ERR_INVALID, "kf_reduce: wants 1 output + 1 input");
+    KF_REQUIRE(d->ndim >= 1 && d->ndim <= KF_MAX_DIMS, KF_ERR_INVALID, "kf_reduce: ndim out of range");
+    KF_REQUIRE(d->dtype[0] == d->dtype[1], KF_ERR_UNSUPPORTED, "kf_reduce: output dtype must equal input dtype");
+    const int es = dtype_size(d->dtype[1]);
+    KF_REQUIRE(es > 0, KF_ERR_INVALID, "kf_reduce: bad dtype");
+    for (int i = 0; i < d->ndim; ++i) {
+        if (d->stride_bytes[0][i] == 0 && d->shape[i] > 1) {
+            p.red_dims[p.nred++] = i;
+            p.rtot *= d->shape[i];
+        } else {
+            p.out_dims[p.nod++] = i;
+            p.nout *= d->shape[i];
+        }
+    }
+    KF_REQUIRE(desc_is_32bit(d), KF_ERR_INDEX_RANGE, "kf_reduce: descriptor is not 32-bit indexable");
+    const int acc_bytes = (d->dtype[1] == KF_F32 || d->dtype[1] == KF_F16 || d->dtype[1] == KF_BF16) ? 4 : 8;
+    const int64_t target_blocks = 1024;
+    const int64_t in_s0 = d->stride_bytes[1][0];
+    if (p.nred == 1 && p.red_dims[0] == 0 && in_s0 == es) {
+        p.path = PATH_INNER;
+        p.R = d->shape[0];
+        p.r_stride = es;
+        int vec = 16 / es;
+        for (; vec > 1; vec >>= 1) { // rows must start on a pack boundary
+            bool ok = p.R % vec == 0 && (uintptr_t)d->data[1] % ((int64_t)vec * es) == 0;
+            for (int i = 1; ok && i < d->ndim; ++i)
+                if (d->stride_bytes[1][i] % ((int64_t)vec * es)) ok = false;
+            if (ok) break;
+        }
+        p.vec = vec == 16 / es ? vec : 1;
+        int64_t per = (p.R + p.vec - 1) / p.vec;
+        p.tx = per >= kRB ? kRB : pow2_floor(per < 1 ? 1 : per);
+        if (p.tx < per && p.tx < kRB) p.tx *= 2;
+        const int ty = kRB / p.tx;
+        const int64_t gx = (p.nout + ty - 1) / ty;
+        int64_t ns = 1;
+        if (gx < target_blocks / 2) {
+            ns = target_blocks / gx;
+            const int64_t max_split = p.R / ((int64_t)p.tx * p.vec * 8); // >= 8 packs per lane per split
+            if (ns > max_split) ns = max_split;
+            if (ns > 256) ns = 256;
+            if (ns < 1) ns = 1;
+        }
+        p.nsplit = (int)ns;
+    } else if (p.nred == 1 && p.red_dims[0] == 0 && d->ndim >= 2 && d->stride_bytes[1][1] == es &&
+               d->stride_bytes[0][1] == es) {
+        p.path = PATH_OUTER;
+        p.R = d->shape[0];
+        p.r_stride = in_s0;
+        p.C = d->shape[1];
+        p.nouter = p.nout / p.C;
+        int vec = 16 / es;
+        const int64_t vb = 16;
+        bool ok = p.C % vec == 0 && (uintptr_t)d->data[1] % vb == 0 && in_s0 % vb == 0;
+        for (int i = 2; ok && i < d->ndim; ++i)
+            if (d->stride_bytes[1][i] % vb) ok = false;
+        p.vec = ok ? vec : 1;
+        const int64_t gx = (p.C + (int64_t)kWave * p.vec - 1) / ((int64_t)kWave * p.vec);
+        const int64_t gz = p.nouter < 1024 ? p.nouter : 1024;
+        int64_t ns = 1;
+        if (gx * gz < target_blocks / 2) {
+            ns = target_blocks / (gx * gz);
+            const int64_t max_split = p.R / 16;
+            if (ns > max_split) ns = max_split;
+            if (ns > 256) ns = 256;
+            if (ns < 1) ns = 1;
+        }
+        p.nsplit = (int)ns;
+    } else {
+        p.path = PATH_GENERIC;
+    }
+    p.ws_bytes = p.nsplit > 1 ? (size_t)p.nsplit * p.nout * acc_bytes : 0;
+    return KF_OK;
+}
+
+template <typename T>
+static int run_reduce(int op, const kf_iter_desc *d, const Plan &p, void *ws, hipStream_t st) {
+    using A = typename RAcc<T>::type;
+    KF_PROF(p.path == PATH_INNER ? "reduce_inner" : p.path == PATH_OUTER ? "reduce_outer" : "reduce_generic", st);
+    RedArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in = (const char *)d->data[1];
+    a.out = (char *)d->data[0];
+    a.ws = ws;
+    a.R = p.R;
+    a.r_stride = p.r_stride;
+    a.C = p.C;
+    a.nout = (uint32_t)p.nout;
+    a.nouter = (uint32_t)p.nouter;
+    a.nsplit = p.nsplit;
+    a.tx = p.tx;
+    a.rtot = (uint32_t)p.rtot;
+
+    Project<A> proj;
+    proj.scale = op == KF_RED_MEAN;
+    const int64_t numel = p.nout * p.rtot;
+    // reference: factor = static_cast<acc_t>(nout) / numel with acc_t = scalar_t (reduce_ops_kernel.cu:49-53)
+    if constexpr (std::is_same<A, int64_t>::value)
+        proj.factor = numel ? p.nout / numel : 0;
+    else
+        proj.factor = (A)p.nout / (A)numel;
+
+    // sub-descriptor holding only the output dims (optionally skipping the first `skip` of them)
+    auto build_out_calc = [&](int skip) {
+        kf_iter_desc s;
+        memset(&s, 0, sizeof(s));
+        s.ntensors = 2;
+        s.noutputs = 1;
+        int n = 0;
+        for (int k = skip; k < p.nod; ++k) {
+            const int i = p.out_dims[k];
+            s.shape[n] = d->shape[i];
+            s.stride_bytes[0][n] = d->stride_bytes[0][i];
+            s.stride_bytes[1][n] = d->stride_bytes[1][i];
+            ++n;
+        }
+        if (n == 0) {
+            s.shape[0] = 1;
+            n = 1;
+        }
+        s.ndim = n;
+        int idx[2] = {0, 1};
+        return OffsetCalc<2>::build(a.oc, &s, idx, 1);
+    };
+
+    if (p.path == PATH_INNER) {
+        KF_REQUIRE(build_out_calc(0), KF_ERR_INVALID, "kf_reduce: bad shape/stride");
+        const int ty = kRB / p.tx;
+        dim3 grid((unsigned)((p.nout + ty - 1) / ty), (unsigned)p.nsplit);
+        if (p.vec > 1)
+            reduce_inner_kernel<T, 16 / sizeof(T)><<<grid, kRB, 0, st>>>(a, proj);
+        else
+            reduce_inner_kernel<T, 1><<<grid, kRB, 0, st>>>(a, proj);
+        KF_LAUNCH_CHECK();
+        if (p.nsplit > 1) {
+            reduce_fold_kernel<T><<<(unsigned)((p.nout + kRB - 1) / kRB), kRB, 0, st>>>(a, proj, 0);
+            KF_LAUNCH_CHECK();
+        }
+    } else if (p.path == PATH_OUTER) {
+        // out_dims[0] is dim 1 (the contiguous one) because dims are visited in order
+        KF_REQUIRE(build_out_calc(1), KF_ERR_INVALID, "kf_reduce: bad shape/stride");
+        const int64_t gx = (p.C + (int64_t)kWave * p.vec - 1) / ((int64_t)kWave * p.vec);
+        dim3 grid((unsigned)gx, (unsigned)p.nsplit, (unsigned)(p.nouter < 1024 ? p.nouter : 1024));
+        if (p.vec > 1)
+            reduce_outer_kernel<T, 16 / sizeof(T)><<<grid, kRB, 0, st>>>(a, proj);
+        else
+            reduce_outer_kernel<T, 1><<<grid, kRB, 0, st>>>(a, proj);
+        KF_LAUNCH_CHECK();
+        if (p.nsplit > 1) {
+            reduce_fold_kernel<T><<<(unsigned)((p.nout + kRB - 1) / kRB), kRB, 0, st>>>(a, proj, 1);
+            KF_LAUNCH_CHECK();
+        }
+    } else {
+        KF_REQUIRE(build_out_calc(0), KF_ERR_INVALID, "kf_reduce: bad shape/stride");
+        kf_iter_desc s;
+        memset(&s, 0, sizeof(s));
+        s.ntensors = 1;
+        int n = 0;
+        for (int k = 0; k < p.nred; ++k) {
+            s.shape[n] = d->shape[p.red_dims[k]];
+            s.stride_bytes[0][n] = d->stride_bytes[1][p.red_dims[k]];
+            ++n;
+        }
+        if (n == 0) {
+            s.shape[0] = 1;
+            n = 1;
+        }
+        s.ndim = n;
+        int idx[1] = {0};
+        KF_REQUIRE(OffsetCalc<1>::build(a.rc, &s, idx, 1), KF_ERR_INVALID, "kf_reduce: bad shape/stride");
+        reduce_generic_kernel<T><<<(unsigned)((p.nout + kRB - 1) / kRB), kRB, 0, st>>>(a, proj);
+        KF_LAUNCH_CHECK();
+    }
+    return KF_OK;
+}
+
+} // namespace kf
+
+using namespace kf;
+
+extern "C" int kf_reduce_workspace_bytes(const kf_iter_desc *d, size_t *bytes) {
+    KF_REQUIRE(d && bytes, KF_ERR_INVALID, "kf_reduce_workspace_bytes: null argument");
+    Plan p;
+    int rc = make_plan(d, p);
+    if (rc != KF_OK) return rc;
+    *bytes = p.ws_bytes;
+    return KF_OK;
+}
+
+extern "C" int kf_reduce(int op, const kf_iter_desc *d, void *workspace, size_t workspace_bytes, void *stream) {
+    KF_REQUIRE(d, KF_ERR_INVALID, "kf_reduce: null descriptor");
+    KF_REQUIRE(op == KF_RED_SUM || op == KF_RED_MEAN, KF_ERR_INVALID, "kf_reduce: unknown op %d", op);
+    Plan p;
+    int rc = make_plan(d, p);
+    if (rc != KF_OK) return rc;
+    if (p.nout == 0) return KF_OK;
+    KF_REQUIRE(d->data[0] && d->data[1], KF_ERR_INVALID, "kf_reduce: null data pointer");
+    KF_REQUIRE(p.ws_bytes == 0 || (workspace && workspace_bytes >= p.ws_bytes), KF_ERR_WORKSPACE,
+               "kf_reduce: workspace of %zu bytes required, got %zu", p.ws_bytes, workspace_bytes);
+    hipStream_t st = as_stream(stream);
+    switch (d->dtype[1]) {
+    case KF_BOOL: return run_reduce<bool>(op, d, p, workspace, st);
+    case KF_U8: return run_reduce<uint8_t>(op, d, p, workspace, st);
+    case KF_I8: return run_reduce<int8_t>(op, d, p, workspace, st);
+    case KF_I16: return run_reduce<int16_t>(op, d, p, workspace, st);
+    case KF_I32: return run_reduce<int32_t>(op, d, p, workspace, st);
+    case KF_I64: return run_reduce<int64_t>(op, d, p, workspace, st);
+    case KF_F16: return run_reduce<f16_t>(op, d, p, workspace, st);
+    case KF_BF16: return run_reduce<bf16_t>(op, d, p, workspace, st);
+    case KF_F32: return run_reduce<float>(op, d, p, workspace, st);
+    case KF_F64: return run_reduce<double>(op, d, p, workspace, st);
+    default: KF_REQUIRE(false, KF_ERR_INVALID, "kf_reduce: bad dtype");
+    }
+    return KF_OK;
+}

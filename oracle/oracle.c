@@ -1,0 +1,462 @@
+/*
+ * oracle.c — CPU restatement of the reference's tensor-kernel hot path.  TEST INFRASTRUCTURE ONLY
+ * (see oracle.h: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it).
+ *
+ * Parity status: PINNED against the reference's own test oracle (numpy / torch-CPU expressions of
+ * test/test_tensor.py, test_gemm.py, test_nn.py) via tests/golden/*.npz; the reference itself is
+ * unbuildable here (every op bottoms out in nvcc-only .cu files and an un-vendored CUTLASS).
+ * Citations are relative to /root/reference.
+ */
+#include "oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---- scalar types: src/core/include/half.h:150-208 ------------------------------------------ */
+float orc_bf16_to_f32(uint16_t v) {
+    uint32_t u = (uint32_t)v << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+uint16_t orc_f32_to_bf16(float f) { /* round-to-nearest-even; NaN -> 0x7FC0 (half.h:195-208) */
+    if (isnan(f)) return 0x7FC0;
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+float orc_f16_to_f32(uint16_t h) { /* IEEE binary16 -> binary32, exact (half.h:24-147) */
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t e = (h >> 10) & 0x1F, m = h & 0x3FFu, u;
+    if (e == 0) {
+        if (m == 0) {
+            u = sign;
+        } else { /* subnormal: renormalise */
+            int sh = 0;
+            while (!(m & 0x400u)) { m <<= 1; ++sh; }
+            m &= 0x3FFu;
+            u = sign | ((uint32_t)(113 - sh) << 23) | (m << 13);
+        }
+    } else if (e == 31) {
+        u = sign | 0x7F800000u | (m << 13);
+    } else {
+        u = sign | ((e + 112) << 23) | (m << 13);
+    }
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+uint16_t orc_f32_to_f16(float f) { /* binary32 -> binary16, round-to-nearest-even (half.h:150-182) */
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+    const uint32_t a = u & 0x7FFFFFFFu;
+    if (a > 0x7F800000u) return (uint16_t)(sign | 0x7E00u);
+    if (a >= 0x47800000u) return (uint16_t)(sign | 0x7C00u); /* >= 65536 (incl. inf) -> inf */
+    if (a < 0x33000001u) return sign;                         /* <= 2^-25 -> 0 (ties to even) */
+    int e = (int)(a >> 23) - 127;
+    uint32_t m = (a & 0x7FFFFFu) | 0x800000u;
+    uint32_t shift, half_e;
+    if (e < -14) { shift = (uint32_t)(13 + (-14 - e)); half_e = 0; } else { shift = 13; half_e = (uint32_t)(e + 15); }
+    uint32_t q = m >> shift, rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+    if (rem > halfway || (rem == halfway && (q & 1u))) ++q;
+    uint32_t r = half_e == 0 ? q : ((half_e - 1) << 10) + q; /* q carries the implicit bit: adds 1 to the exponent */
+    if (r >= 0x7C00u) r = 0x7C00u;
+    return (uint16_t)(sign | r);
+}
+
+static int dt_size(int dt) {
+    switch (dt) {
+    case ORC_BOOL: case ORC_U8: case ORC_I8: return 1;
+    case ORC_I16: case ORC_F16: case ORC_BF16: return 2;
+    case ORC_I32: case ORC_F32: return 4;
+    default: return 8;
+    }
+}
+/* accumulate class (accumulate_type.h:17-27): 0 float, 1 double, 2 int64, 3 bool */
+static int acc_class(int dt) {
+    switch (dt) {
+    case ORC_F16: case ORC_BF16: case ORC_F32: return 0;
+    case ORC_F64: return 1;
+    case ORC_BOOL: return 3;
+    default: return 2;
+    }
+}
+static int is_float(int t) { return t == ORC_F64 || t == ORC_F32 || t == ORC_F16 || t == ORC_BF16; }
+static int is_uint(int t) { return t == ORC_U8 || t == ORC_BOOL; }
+
+int orc_promote(int a, int b) { /* tensor_iterator.cpp:32-44 */
+    if (is_float(a) && is_float(b)) return a >= b ? a : b;
+    if (is_float(a) || is_float(b)) return is_float(a) ? a : b;
+    if (is_uint(a) && is_uint(b)) return a >= b ? a : b;
+    if (is_uint(a) || is_uint(b)) return is_uint(a) ? b : a;
+    return a >= b ? a : b;
+}
+
+/* fetch_and_cast<dest_t> (tensor_memory_access.h:13-24): static_cast from the stored type */
+#define ORC_LOAD(NAME, TYPE)                                              \
+    static TYPE NAME(int dt, const void *p) {                             \
+        switch (dt) {                                                     \
+        case ORC_BOOL: return (TYPE)(*(const uint8_t *)p != 0);           \
+        case ORC_U8: return (TYPE)(*(const uint8_t *)p);                  \
+        case ORC_I8: return (TYPE)(*(const int8_t *)p);                   \
+        case ORC_I16: return (TYPE)(*(const int16_t *)p);                 \
+        case ORC_I32: return (TYPE)(*(const int32_t *)p);                 \
+        case ORC_I64: return (TYPE)(*(const int64_t *)p);                 \
+        case ORC_F16: return (TYPE)orc_f16_to_f32(*(const uint16_t *)p);  \
+        case ORC_BF16: return (TYPE)orc_bf16_to_f32(*(const uint16_t *)p);\
+        case ORC_F32: return (TYPE)(*(const float *)p);                   \
+        default: return (TYPE)(*(const double *)p);                       \
+        }                                                                 \
+    }
+ORC_LOAD(ld_f, float)
+ORC_LOAD(ld_d, double)
+ORC_LOAD(ld_i, int64_t)
+static int ld_b(int dt, const void *p) { return ld_d(dt, p) != 0.0; }
+
+/* cast_and_store<src_t> (tensor_memory_access.h:26-37) */
+#define ORC_STORE(NAME, TYPE)                                              \
+    static void NAME(int dt, void *p, TYPE v) {                            \
+        switch (dt) {                                                      \
+        case ORC_BOOL: *(uint8_t *)p = (uint8_t)(v != 0); break;           \
+        case ORC_U8: *(uint8_t *)p = (uint8_t)v; break;                    \
+        case ORC_I8: *(int8_t *)p = (int8_t)v; break;                      \
+        case ORC_I16: *(int16_t *)p = (int16_t)v; break;                   \
+        case ORC_I32: *(int32_t *)p = (int32_t)v; break;                   \
+        case ORC_I64: *(int64_t *)p = (int64_t)v; break;                   \
+        case ORC_F16: *(uint16_t *)p = orc_f32_to_f16((float)v); break;    \
+        case ORC_BF16: *(uint16_t *)p = orc_f32_to_bf16((float)v); break;  \
+        case ORC_F32: *(float *)p = (float)v; break;                       \
+        default: *(double *)p = (double)v; break;                          \
+        }                                                                  \
+    }
+ORC_STORE(st_f, float)
+ORC_STORE(st_d, double)
+ORC_STORE(st_i, int64_t)
+
+/* ---- index walking --------------------------------------------------------------------------- */
+static int64_t numel_of(const orc_tensor *t) {
+    int64_t n = 1;
+    for (int i = 0; i < t->ndim; ++i) n *= t->shape[i];
+    return n;
+}
+/* element offset of operand `t` for the multi-index `idx` of an iteration space `shape`;
+ * size-1 dims of the operand broadcast (tensor_iterator.cpp:148-162) */
+static int64_t off_of(const orc_tensor *t, const int64_t *idx, const int64_t *shape) {
+    int64_t o = 0;
+    for (int i = 0; i < t->ndim; ++i)
+        if (!(t->shape[i] == 1 && shape[i] != 1)) o += idx[i] * t->stride[i];
+    return o;
+}
+static void unravel(int64_t lin, int ndim, const int64_t *shape, int64_t *idx) {
+    for (int i = ndim - 1; i >= 0; --i) {
+        idx[i] = shape[i] ? lin % shape[i] : 0;
+        lin = shape[i] ? lin / shape[i] : 0;
+    }
+}
+
+/* ---- elementwise ----------------------------------------------------------------------------- */
+int orc_binary(int op, const orc_tensor *a, const orc_tensor *b, orc_tensor *out) {
+    if (a->ndim != b->ndim || a->ndim != out->ndim) return 1; /* same-ndim rule, tensor_iterator.cpp:16-30 */
+    int64_t shape[ORC_MAX_DIMS];
+    for (int i = 0; i < a->ndim; ++i) {
+        const int64_t x = a->shape[i], y = b->shape[i];
+        if (!(x == y || x == 1 || y == 1)) return 2;
+        shape[i] = x == 1 ? y : x;
+        if (out->shape[i] != shape[i]) return 3;
+    }
+    const int common = orc_promote(a->dtype, b->dtype), cls = acc_class(common);
+    const int64_t n = numel_of(out);
+    const int sa = dt_size(a->dtype), sb = dt_size(b->dtype), so = dt_size(out->dtype);
+#pragma omp parallel for schedule(static) if (n > (1 << 16))
+    for (int64_t lin = 0; lin < n; ++lin) {
+        int64_t idx[ORC_MAX_DIMS];
+        unravel(lin, out->ndim, shape, idx);
+        const char *pa = (const char *)a->data + off_of(a, idx, shape) * sa;
+        const char *pb = (const char *)b->data + off_of(b, idx, shape) * sb;
+        char *po = (char *)out->data + off_of(out, idx, shape) * so;
+        if (cls == 0) {
+            const float x = ld_f(a->dtype, pa), y = ld_f(b->dtype, pb);
+            st_f(out->dtype, po, op == ORC_ADD ? x + y : op == ORC_SUB ? x - y : op == ORC_MUL ? x * y : x / y);
+        } else if (cls == 1) {
+            const double x = ld_d(a->dtype, pa), y = ld_d(b->dtype, pb);
+            st_d(out->dtype, po, op == ORC_ADD ? x + y : op == ORC_SUB ? x - y : op == ORC_MUL ? x * y : x / y);
+        } else if (cls == 2) {
+            const int64_t x = ld_i(a->dtype, pa), y = ld_i(b->dtype, pb);
+            int64_t r;
+            if (op == ORC_ADD) r = (int64_t)((uint64_t)x + (uint64_t)y);
+            else if (op == ORC_SUB) r = (int64_t)((uint64_t)x - (uint64_t)y);
+            else if (op == ORC_MUL) r = (int64_t)((uint64_t)x * (uint64_t)y);
+            else r = y == 0 ? 0 : (y == -1 ? (int64_t)(0 - (uint64_t)x) : x / y); /* x/0: UB in the reference */
+            st_i(out->dtype, po, r);
+        } else {
+            const int x = ld_b(a->dtype, pa), y = ld_b(b->dtype, pb);
+            st_i(out->dtype, po, op == ORC_ADD ? (x || y) : op == ORC_SUB ? (x != y) : op == ORC_MUL ? (x && y) : x);
+        }
+    }
+    return 0;
+}
+
+int orc_copy(const orc_tensor *src, orc_tensor *dst) {
+    if (src->ndim != dst->ndim) return 1;
+    for (int i = 0; i < src->ndim; ++i)
+        if (!(src->shape[i] == dst->shape[i] || src->shape[i] == 1)) return 2;
+    const int64_t n = numel_of(dst);
+    const int ss = dt_size(src->dtype), sd = dt_size(dst->dtype), cls = acc_class(dst->dtype);
+#pragma omp parallel for schedule(static) if (n > (1 << 16))
+    for (int64_t lin = 0; lin < n; ++lin) {
+        int64_t idx[ORC_MAX_DIMS];
+        unravel(lin, dst->ndim, dst->shape, idx);
+        const char *ps = (const char *)src->data + off_of(src, idx, dst->shape) * ss;
+        char *pd = (char *)dst->data + off_of(dst, idx, dst->shape) * sd;
+        if (src->dtype == dst->dtype) memcpy(pd, ps, (size_t)sd); /* CopyFunctor<scalar_t>: bit copy */
+        else if (cls == 0) st_f(dst->dtype, pd, ld_f(src->dtype, ps));
+        else if (cls == 1) st_d(dst->dtype, pd, ld_d(src->dtype, ps));
+        else if (cls == 2) st_i(dst->dtype, pd, ld_i(src->dtype, ps));
+        else st_i(dst->dtype, pd, ld_b(src->dtype, ps));
+    }
+    return 0;
+}
+
+int orc_fill(orc_tensor *dst, double value) { /* FillFunctor<acc_t>(double) then cast to out dtype */
+    const int64_t n = numel_of(dst);
+    const int sd = dt_size(dst->dtype), cls = acc_class(dst->dtype);
+    for (int64_t lin = 0; lin < n; ++lin) {
+        int64_t idx[ORC_MAX_DIMS];
+        unravel(lin, dst->ndim, dst->shape, idx);
+        char *pd = (char *)dst->data + off_of(dst, idx, dst->shape) * sd;
+        if (cls == 0) st_f(dst->dtype, pd, (float)value);
+        else if (cls == 1) st_d(dst->dtype, pd, value);
+        else if (cls == 2) st_i(dst->dtype, pd, (int64_t)value);
+        else st_i(dst->dtype, pd, value != 0.0);
+    }
+    return 0;
+}
+
+/* ---- reductions ------------------------------------------------------------------------------- */
+/* The reference's order of summation is an implementation detail of its GPU reduce tree
+ * (tensor_reduce.h:454-923) and its tests allow 1e-2 (test_tensor.py:118); the oracle therefore
+ * states the correctly rounded result: floating sums accumulate in double and are cast once.
+ * Integer sums wrap exactly as in-dtype accumulation does. mean = sum * factor with
+ * factor = static_cast<scalar_t>(nout) / numel evaluated in the input dtype
+ * (reduce_ops_kernel.cu:49-53) — an integer quotient for integer dtypes. */
+int orc_reduce(int op, const orc_tensor *in, int dim, orc_tensor *out) {
+    if (in->ndim != out->ndim || dim < 0 || dim >= in->ndim) return 1;
+    for (int i = 0; i < in->ndim; ++i)
+        if (out->shape[i] != (i == dim ? 1 : in->shape[i])) return 2;
+    if (in->dtype != out->dtype) return 3;
+    const int64_t R = in->shape[dim], nout = numel_of(out), numel = nout * R;
+    const int si = dt_size(in->dtype), so = dt_size(out->dtype), cls = acc_class(in->dtype);
+#pragma omp parallel for schedule(static) if (numel > (1 << 16))
+    for (int64_t lin = 0; lin < nout; ++lin) {
+        int64_t idx[ORC_MAX_DIMS];
+        unravel(lin, out->ndim, out->shape, idx);
+        int64_t base = 0;
+        for (int i = 0; i < in->ndim; ++i) base += idx[i] * in->stride[i];
+        char *po = (char *)out->data + off_of(out, idx, out->shape) * so;
+        if (cls == 0 || cls == 1) {
+            double acc = 0.0;
+            for (int64_t r = 0; r < R; ++r) acc += ld_d(in->dtype, (const char *)in->data + (base + r * in->stride[dim]) * si);
+            if (op == ORC_MEAN) {
+                if (cls == 1) acc *= (double)nout / (double)numel;
+                else acc *= (double)((float)nout / (float)numel);
+            }
+            st_d(out->dtype, po, acc);
+        } else {
+            int64_t acc = 0;
+            for (int64_t r = 0; r < R; ++r) {
+                const char *p = (const char *)in->data + (base + r * in->stride[dim]) * si;
+                acc = (int64_t)((uint64_t)acc + (uint64_t)(cls == 3 ? ld_b(in->dtype, p) : ld_i(in->dtype, p)));
+            }
+            if (op == ORC_MEAN) acc = (int64_t)((uint64_t)acc * (uint64_t)(numel ? nout / numel : 0));
+            st_i(out->dtype, po, acc);
+        }
+    }
+    return 0;
+}
+
+/* ---- index_put_ ------------------------------------------------------------------------------- */
+int orc_index_put(orc_tensor *self, int nidx, const orc_tensor *idx, const orc_tensor *values) {
+    if (nidx != self->ndim) return 1; /* index_ops.cpp:7-8 */
+    if (self->dtype != values->dtype) return 2;
+    const int64_t n = numel_of(&idx[0]);
+    const int es = dt_size(self->dtype);
+    for (int64_t lin = 0; lin < n; ++lin) { /* ascending n: a later duplicate overwrites an earlier one */
+        int64_t mi[ORC_MAX_DIMS];
+        unravel(lin, idx[0].ndim, idx[0].shape, mi);
+        int64_t target = 0;
+        for (int k = 0; k < nidx; ++k) {
+            if (idx[k].dtype != ORC_I64) return 3;
+            int64_t v = *((const int64_t *)idx[k].data + off_of(&idx[k], mi, idx[0].shape));
+            if (v < 0) v += self->shape[k]; /* tensor_index.h:66-68 */
+            target += v * self->stride[k];
+        }
+        memcpy((char *)self->data + target * es, (const char *)values->data + off_of(values, mi, idx[0].shape) * es, (size_t)es);
+    }
+    return 0;
+}
+
+/* ---- GEMM -------------------------------------------------------------------------------------- */
+int orc_gemm(int dtype, int ta, int tb, int64_t M, int64_t N, int64_t K, float alpha, const void *A, int64_t lda,
+             const void *B, int64_t ldb, float beta, void *C, int64_t ldc, const void *bias_row) {
+    if (!(dtype == ORC_F32 || dtype == ORC_F64 || dtype == ORC_F16 || dtype == ORC_BF16)) return 1;
+    const int es = dt_size(dtype);
+    if (dtype == ORC_F64) {
+        double *Bd = (double *)malloc(sizeof(double) * (size_t)(K * N ? K * N : 1));
+        for (int64_t k = 0; k < K; ++k)
+            for (int64_t j = 0; j < N; ++j) Bd[k * N + j] = ((const double *)B)[tb ? j * ldb + k : k * ldb + j];
+#pragma omp parallel for schedule(static)
+        for (int64_t i = 0; i < M; ++i) {
+            double *acc = (double *)calloc((size_t)(N ? N : 1), sizeof(double));
+            for (int64_t k = 0; k < K; ++k) {
+                const double a = ((const double *)A)[ta ? k * lda + i : i * lda + k];
+                const double *brow = Bd + k * N;
+                for (int64_t j = 0; j < N; ++j) acc[j] = fma(a, brow[j], acc[j]);
+            }
+            double *c = (double *)C + i * ldc;
+            for (int64_t j = 0; j < N; ++j) {
+                double v = (double)alpha * acc[j];
+                if (beta != 0.f) v += (double)beta * c[j];
+                if (bias_row) v += ((const double *)bias_row)[j];
+                c[j] = v;
+            }
+            free(acc);
+        }
+        free(Bd);
+        return 0;
+    }
+    /* float accumulate, k-ordered fma chain: sum += (float)a * (float)b (block_utils.h:60-71) */
+    float *Bf = (float *)malloc(sizeof(float) * (size_t)(K * N ? K * N : 1));
+#pragma omp parallel for schedule(static)
+    for (int64_t k = 0; k < K; ++k)
+        for (int64_t j = 0; j < N; ++j) Bf[k * N + j] = ld_f(dtype, (const char *)B + (tb ? j * ldb + k : k * ldb + j) * es);
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < M; ++i) {
+        float *acc = (float *)calloc((size_t)(N ? N : 1), sizeof(float));
+        for (int64_t k = 0; k < K; ++k) {
+            const float a = ld_f(dtype, (const char *)A + (ta ? k * lda + i : i * lda + k) * es);
+            const float *brow = Bf + k * N;
+            for (int64_t j = 0; j < N; ++j) acc[j] = fmaf(a, brow[j], acc[j]);
+        }
+        char *c = (char *)C + i * ldc * es;
+        for (int64_t j = 0; j < N; ++j) {
+            float v = alpha * acc[j];
+            if (beta != 0.f) v += beta * ld_f(dtype, c + j * es);
+            if (bias_row) v += ld_f(dtype, (const char *)bias_row + j * es);
+            st_f(dtype, c + j * es, v);
+        }
+        free(acc);
+    }
+    free(Bf);
+    return 0;
+}
+
+/* ---- causal attention --------------------------------------------------------------------------- */
+static void to_float(int dtype, const void *src, int64_t n, float *dst) {
+    const int es = dt_size(dtype);
+    for (int64_t i = 0; i < n; ++i) dst[i] = ld_f(dtype, (const char *)src + i * es);
+}
+
+int orc_attn_fwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, const void *q, const void *k,
+                 const void *v, void *o, float *lse) {
+    if (!(dtype == ORC_F32 || dtype == ORC_F16 || dtype == ORC_BF16)) return 1;
+    const int es = dt_size(dtype);
+    const float scale = 1.0f / sqrtf((float)D); /* causal_attention_ref.h:33 */
+#pragma omp parallel for schedule(dynamic)
+    for (int64_t bh = 0; bh < B * H; ++bh) {
+        float *qf = (float *)malloc(sizeof(float) * (size_t)(Sq * D)), *kf = (float *)malloc(sizeof(float) * (size_t)(Skv * D));
+        float *vf = (float *)malloc(sizeof(float) * (size_t)(Skv * D)), *s = (float *)malloc(sizeof(float) * (size_t)Skv);
+        float *orow = (float *)malloc(sizeof(float) * (size_t)D);
+        to_float(dtype, (const char *)q + bh * Sq * D * es, Sq * D, qf);
+        to_float(dtype, (const char *)k + bh * Skv * D * es, Skv * D, kf);
+        to_float(dtype, (const char *)v + bh * Skv * D * es, Skv * D, vf);
+        for (int64_t m = 0; m < Sq; ++m) {
+            const int64_t nvis = m + 1 < Skv ? m + 1 : Skv; /* m >= n kept (causal_attention_ref.h:36-41) */
+            float mx = -INFINITY;
+            for (int64_t n = 0; n < nvis; ++n) {
+                float sum = 0.f;
+                for (int64_t d = 0; d < D; ++d) sum += qf[m * D + d] * kf[n * D + d];
+                s[n] = sum * scale;
+                if (s[n] > mx) mx = s[n];
+            }
+            float l = 0.f;
+            for (int64_t n = 0; n < nvis; ++n) l += expf(s[n] - mx);
+            for (int64_t d = 0; d < D; ++d) orow[d] = 0.f;
+            for (int64_t n = 0; n < nvis; ++n) {
+                const float p = expf(s[n] - mx) / l;
+                for (int64_t d = 0; d < D; ++d) orow[d] += p * vf[n * D + d];
+            }
+            for (int64_t d = 0; d < D; ++d) st_f(dtype, (char *)o + ((bh * Sq + m) * D + d) * es, orow[d]);
+            if (lse) lse[bh * Sq + m] = mx + logf(l);
+        }
+        free(qf); free(kf); free(vf); free(s); free(orow);
+    }
+    return 0;
+}
+
+int orc_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, const void *q, const void *k,
+                 const void *v, const void *d_o, void *dq, void *dk, void *dv) {
+    if (!(dtype == ORC_F32 || dtype == ORC_F16 || dtype == ORC_BF16)) return 1;
+    const int es = dt_size(dtype);
+    const float scale = 1.0f / sqrtf((float)D);
+#pragma omp parallel for schedule(dynamic)
+    for (int64_t bh = 0; bh < B * H; ++bh) {
+        float *qf = (float *)malloc(sizeof(float) * (size_t)(Sq * D)), *kf = (float *)malloc(sizeof(float) * (size_t)(Skv * D));
+        float *vf = (float *)malloc(sizeof(float) * (size_t)(Skv * D)), *gof = (float *)malloc(sizeof(float) * (size_t)(Sq * D));
+        float *dkf = (float *)calloc((size_t)(Skv * D), sizeof(float)), *dvf = (float *)calloc((size_t)(Skv * D), sizeof(float));
+        float *p = (float *)malloc(sizeof(float) * (size_t)Skv), *dp = (float *)malloc(sizeof(float) * (size_t)Skv);
+        float *dqrow = (float *)malloc(sizeof(float) * (size_t)D);
+        to_float(dtype, (const char *)q + bh * Sq * D * es, Sq * D, qf);
+        to_float(dtype, (const char *)k + bh * Skv * D * es, Skv * D, kf);
+        to_float(dtype, (const char *)v + bh * Skv * D * es, Skv * D, vf);
+        to_float(dtype, (const char *)d_o + bh * Sq * D * es, Sq * D, gof);
+        for (int64_t m = 0; m < Sq; ++m) {
+            const int64_t nvis = m + 1 < Skv ? m + 1 : Skv;
+            float mx = -INFINITY;
+            for (int64_t n = 0; n < nvis; ++n) {
+                float sum = 0.f;
+                for (int64_t d = 0; d < D; ++d) sum += qf[m * D + d] * kf[n * D + d];
+                p[n] = sum * scale;
+                if (p[n] > mx) mx = p[n];
+            }
+            float l = 0.f;
+            for (int64_t n = 0; n < nvis; ++n) l += expf(p[n] - mx);
+            double delta = 0.0; /* sum_n P dP == sum_d dO O */
+            for (int64_t n = 0; n < nvis; ++n) {
+                p[n] = expf(p[n] - mx) / l;
+                float sum = 0.f;
+                for (int64_t d = 0; d < D; ++d) sum += gof[m * D + d] * vf[n * D + d];
+                dp[n] = sum;
+                delta += (double)p[n] * (double)sum;
+            }
+            for (int64_t d = 0; d < D; ++d) dqrow[d] = 0.f;
+            for (int64_t n = 0; n < nvis; ++n) {
+                const float ds = p[n] * (dp[n] - (float)delta) * scale; /* dS / sqrt(D) */
+                for (int64_t d = 0; d < D; ++d) {
+                    dqrow[d] += ds * kf[n * D + d];
+                    dkf[n * D + d] += ds * qf[m * D + d];
+                    dvf[n * D + d] += p[n] * gof[m * D + d];
+                }
+            }
+            for (int64_t d = 0; d < D; ++d) st_f(dtype, (char *)dq + ((bh * Sq + m) * D + d) * es, dqrow[d]);
+        }
+        for (int64_t i = 0; i < Skv * D; ++i) {
+            st_f(dtype, (char *)dk + (bh * Skv * D + i) * es, dkf[i]);
+            st_f(dtype, (char *)dv + (bh * Skv * D + i) * es, dvf[i]);
+        }
+        free(qf); free(kf); free(vf); free(gof); free(dkf); free(dvf); free(p); free(dp); free(dqrow);
+    }
+    return 0;
+}
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,190 @@
+"""-m gpu: causal attention forward/backward through the C ABI vs the CPU oracle and golden vectors.
+
+Tolerances (stated):
+  f32 (the reference's dtype): rtol = atol = 1e-3 on U(-10,10) inputs — the reference's own bound
+      (test_nn.py:11-33 via test/common.py:6-11).
+  bf16 / f16 MFMA path, U(-1,1) inputs (|O| <= 1): P and dS are rounded to the 16-bit type before
+      the second contraction and outputs are rounded once: |err| <= atol + rtol*|ref| with
+      bf16: rtol = 2e-2, atol = 2e-2 (fwd) / 3e-2 (bwd);  f16: rtol = 4e-3, atol = 4e-3 / 8e-3.
+      The oracle runs f32 math on the same 16-bit-rounded inputs.
+"""
+import numpy as np
+import pytest
+
+from kfunca_amd import hip_abi as H
+from oracle import oracle as O
+from tests.helpers import assert_close, golden, regen
+
+pytestmark = pytest.mark.gpu
+TOL = {H.BF16: dict(rtol=2e-2, atol=2e-2), H.F16: dict(rtol=4e-3, atol=4e-3), H.F32: dict(rtol=1e-3, atol=1e-3)}
+TOL_BWD = {H.BF16: dict(rtol=2e-2, atol=3e-2), H.F16: dict(rtol=4e-3, atol=8e-3), H.F32: dict(rtol=1e-3, atol=1e-3)}
+
+
+def fwd(code, q, k, v):
+    B, Hh, Sq, D = q.shape
+    Skv = k.shape[2]
+    dq_, dk_, dv_ = (H.DevBuf.from_numpy(x) for x in (q, k, v))
+    o = H.DevBuf(q.nbytes)
+    lse = H.DevBuf(4 * B * Hh * Sq)
+    H.attn_fwd(code, B, Hh, Sq, Skv, D, dq_.ptr, dk_.ptr, dv_.ptr, o.ptr, lse.ptr)
+    H.device_sync()
+    return o.to_numpy(q.shape, q.dtype), lse.to_numpy((B, Hh, Sq), np.float32)
+
+
+def bwd(code, q, k, v, o, lse, go):
+    B, Hh, Sq, D = q.shape
+    Skv = k.shape[2]
+    bufs = [H.DevBuf.from_numpy(x) for x in (q, k, v, o, lse, go)]
+    dq, dk, dv = H.DevBuf(q.nbytes), H.DevBuf(k.nbytes), H.DevBuf(v.nbytes)
+    need = H.attn_bwd_workspace_bytes(code, B, Hh, Sq, Skv, D)
+    ws = H.DevBuf(need)
+    H.attn_bwd(code, B, Hh, Sq, Skv, D, *[b.ptr for b in bufs], dq.ptr, dk.ptr, dv.ptr, ws.ptr, need)
+    H.device_sync()
+    return dq.to_numpy(q.shape, q.dtype), dk.to_numpy(k.shape, k.dtype), dv.to_numpy(v.shape, v.dtype)
+
+
+def f(x, code):
+    return O.to_float(x, code)
+
+
+def test_golden_fp32_reference_cases():
+    g = golden("attention")
+    for i in range(3):  # (2,4,32,256,128), (3,5,64,32,64), (5,16,65,33,123): test_nn.py:13-17
+        B, Hh, Sq, Skv, D = (int(x) for x in g[f"fwd{i}_dims"])
+        q, k, v = regen(1050 + i, [(B, Hh, Sq, D), (B, Hh, Skv, D), (B, Hh, Skv, D)], g[f"fwd{i}_sha"])
+        o, lse = fwd(H.F32, q, k, v)
+        assert_close(o, g[f"fwd{i}_out"], what=f"fp32 fwd case {i}")
+        _, lse_ref = O.attn_fwd(q, k, v)
+        assert_close(lse, lse_ref, rtol=1e-4, atol=1e-3, what="lse")
+
+
+def test_golden_fp32_backward():
+    g = golden("attention")
+    for i in range(3):
+        B, Hh, Sq, Skv, D = (int(x) for x in g[f"bwd{i}_dims"])
+        q, k, v, go = regen(1060 + i, [(B, Hh, Sq, D), (B, Hh, Skv, D), (B, Hh, Skv, D), (B, Hh, Sq, D)], g[f"bwd{i}_sha"], lo=-1, hi=1)
+        o, lse = fwd(H.F32, q, k, v)
+        assert_close(o, g[f"bwd{i}_out"], rtol=1e-4, atol=1e-5, what="fwd")
+        dq, dk, dv = bwd(H.F32, q, k, v, o, lse, go)
+        for n, got in (("dq", dq), ("dk", dk), ("dv", dv)):
+            assert_close(got, g[f"bwd{i}_{n}"], rtol=1e-4, atol=1e-5, what=f"fp32 bwd case {i} {n}")
+
+
+@pytest.mark.parametrize("code", [H.BF16, H.F16])
+def test_uniform_scores_exact_structure(code):
+    """Q = 0 makes every visible key equally likely: O[m] = mean(V[0..m]). With V holding small integers
+    and row counts that are powers of two the expected value is exact — this pins the causal mask,
+    the transposed V reads and the accumulator-as-operand k order, independent of exp/rounding."""
+    B, Hh, S, D = 1, 2, 256, 128
+    rng = np.random.default_rng(3)
+    q = np.zeros((B, Hh, S, D), dtype=np.float32)
+    k = rng.uniform(-1, 1, (B, Hh, S, D)).astype(np.float32)
+    v = rng.integers(-8, 9, (B, Hh, S, D)).astype(np.float32)
+    o, lse = fwd(code, *(O.from_float(x, code) for x in (q, k, v)))
+    want = np.cumsum(v.astype(np.float64), axis=2) / np.arange(1, S + 1)[None, None, :, None]
+    assert_close(f(o, code), want, rtol=2 ** -7, atol=2 ** -6, what="uniform attention")
+    for m in (0, 1, 3, 7, 15, 31, 63, 127, 255):  # 1/(m+1) exact: result must match to one final rounding
+        assert_close(f(o, code)[:, :, m], want[:, :, m], rtol=2 ** -8, atol=1e-6, what=f"row {m}")
+    assert_close(lse, np.log(np.arange(1, S + 1, dtype=np.float64))[None, None, :].repeat(Hh, 1), rtol=1e-5, atol=1e-5, what="lse = log(m+1)")
+
+
+@pytest.mark.parametrize("code", [H.BF16, H.F16])
+@pytest.mark.parametrize("B,Hh,Sq,Skv", [(1, 2, 256, 256), (2, 3, 128, 384), (1, 2, 384, 128), (1, 1, 512, 512)])
+def test_mfma_path_vs_oracle(code, B, Hh, Sq, Skv):
+    D = 128
+    rng = np.random.default_rng(Sq + Skv + code)
+    q, k, v, go = (O.from_float(rng.uniform(-1, 1, s).astype(np.float32), code)
+                   for s in ((B, Hh, Sq, D), (B, Hh, Skv, D), (B, Hh, Skv, D), (B, Hh, Sq, D)))
+    o, lse = fwd(code, q, k, v)
+    o_ref, lse_ref = O.attn_fwd(q, k, v, code=code)
+    assert_close(f(o, code), f(o_ref, code), **TOL[code], what="fwd")
+    assert_close(lse, lse_ref, rtol=1e-3, atol=2e-3, what="lse")
+    dq, dk, dv = bwd(code, q, k, v, o, lse, go)
+    rq, rk, rv = O.attn_bwd(q, k, v, go, code=code)
+    for n, got, want in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
+        assert_close(f(got, code), f(want, code), **TOL_BWD[code], what=f"bwd {n}")
+
+
+def test_rescale_branch_is_exercised():
+    """Online-softmax hazard test (guide rule 26): spike one key per tile against every query so the
+    running max jumps at a chosen tile and every earlier contribution must be rescaled exactly once."""
+    code, B, Hh, S, D = H.BF16, 1, 1, 512, 128
+    rng = np.random.default_rng(12)
+    q = rng.uniform(-1, 1, (B, Hh, S, D)).astype(np.float32)
+    k = rng.uniform(-1, 1, (B, Hh, S, D)).astype(np.float32)
+    v = rng.uniform(-1, 1, (B, Hh, S, D)).astype(np.float32)
+    q[..., 0] = 4.0
+    for j, n in enumerate((70, 200, 330, 460)):  # one spike in four different 64-key tiles, growing
+        k[0, 0, n, 0] = 8.0 * (j + 1)
+    qb, kb, vb = (O.f32_to_bf16(x) for x in (q, k, v))
+    o, lse = fwd(code, qb, kb, vb)
+    o_ref, lse_ref = O.attn_fwd(qb, kb, vb, code=code)
+    assert_close(f(o, code), f(o_ref, code), **TOL[code], what="spiked fwd")
+    assert_close(lse, lse_ref, rtol=1e-3, atol=2e-3, what="spiked lse")
+
+
+def test_generic_path_16bit_ragged():
+    rng = np.random.default_rng(13)
+    for code in (H.BF16, H.F16):
+        for (B, Hh, Sq, Skv, D) in ((2, 2, 65, 33, 64), (1, 3, 40, 72, 80), (1, 1, 17, 17, 256)):
+            q, k, v, go = (O.from_float(rng.uniform(-1, 1, s).astype(np.float32), code)
+                           for s in ((B, Hh, Sq, D), (B, Hh, Skv, D), (B, Hh, Skv, D), (B, Hh, Sq, D)))
+            o, lse = fwd(code, q, k, v)
+            o_ref, _ = O.attn_fwd(q, k, v, code=code)
+            assert_close(f(o, code), f(o_ref, code), **TOL[code], what="generic fwd")
+            dq, dk, dv = bwd(code, q, k, v, o, lse, go)
+            for got, want in zip((dq, dk, dv), O.attn_bwd(q, k, v, go, code=code)):
+                assert_close(f(got, code), f(want, code), **TOL_BWD[code], what="generic bwd")
+
+
+def test_full_size_properties():
+    """BASELINE config C3 shape per head (S = 4096, D = 128), fewer heads: size-independent properties.
+    (1) causal prefix: the first 256 output rows equal attention over the 256-token prefix (oracle);
+    (2) the last rows vs an f64 numpy evaluation; (3) V = const => O = const, dQ = dK = 0 and
+    dV[n] = sum over visible queries of P — columns of dV sum to sum(dO)."""
+    code, B, Hh, S, D = H.BF16, 1, 2, 4096, 128
+    rng = np.random.default_rng(14)
+    q, k, v, go = (O.f32_to_bf16(rng.uniform(-1, 1, (B, Hh, S, D)).astype(np.float32)) for _ in range(4))
+    o, lse = fwd(code, q, k, v)
+    o_pre, lse_pre = O.attn_fwd(q[:, :, :256], k[:, :, :256], v[:, :, :256], code=code)
+    assert_close(f(o, code)[:, :, :256], f(o_pre, code), **TOL[code], what="causal prefix")
+    assert_close(lse[:, :, :256], lse_pre, rtol=1e-3, atol=2e-3, what="prefix lse")
+    qf, kf, vf = (f(x, code).astype(np.float64) for x in (q, k, v))
+    for m in (4095, 4032, 2049):
+        s = (qf[0, 1, m] @ kf[0, 1, :m + 1].T) / np.sqrt(D)
+        p = np.exp(s - s.max())
+        p /= p.sum()
+        assert_close(f(o, code)[0, 1, m], p @ vf[0, 1, :m + 1], **TOL[code], what=f"row {m}")
+    dq, dk, dv = bwd(code, q, k, v, o, lse, go)
+    dq_pre = None
+    # dV column sums: sum_n dV[n] = sum_m dO[m] (rows of P sum to 1)
+    want = f(go, code).astype(np.float64).sum(axis=2)
+    assert_close(f(dv, code).astype(np.float64).sum(axis=2), want, rtol=2e-2, atol=0.5, what="sum dV == sum dO")
+    # dQ of the last 64 rows vs f64 numpy for one head
+    gf, of = f(go, code).astype(np.float64), f(o, code).astype(np.float64)
+    for m in (4095, 3000):
+        s = (qf[0, 0, m] @ kf[0, 0, :m + 1].T) / np.sqrt(D)
+        p = np.exp(s - s.max())
+        p /= p.sum()
+        dp = gf[0, 0, m] @ vf[0, 0, :m + 1].T
+        ds = p * (dp - (p * dp).sum())
+        assert_close(f(dq, code)[0, 0, m], (ds @ kf[0, 0, :m + 1]) / np.sqrt(D), **TOL_BWD[code], what=f"dq row {m}")
+    # dK, dV of the LAST key (only the last query sees it)
+    m = n = S - 1
+    s = (qf[0, 0, m] @ kf[0, 0].T) / np.sqrt(D)
+    p = np.exp(s - s.max())
+    p /= p.sum()
+    dp = gf[0, 0, m] @ vf[0, 0].T
+    ds = p * (dp - (p * dp).sum())
+    assert_close(f(dv, code)[0, 0, n], p[n] * gf[0, 0, m], **TOL_BWD[code], what="dv last key")
+    assert_close(f(dk, code)[0, 0, n], ds[n] * qf[0, 0, m] / np.sqrt(D), **TOL_BWD[code], what="dk last key")
+
+
+def test_errors():
+    a = H.DevBuf(4096)
+    with pytest.raises(H.KfError) as e:
+        H.attn_fwd(H.I32, 1, 1, 4, 4, 8, a.ptr, a.ptr, a.ptr, a.ptr)
+    assert e.value.code == H.KF_ERR_UNSUPPORTED
+    with pytest.raises(H.KfError) as e:
+        H.attn_fwd(H.F32, 1, 1, 4, 4, 512, a.ptr, a.ptr, a.ptr, a.ptr)
+    assert e.value.code == H.KF_ERR_UNSUPPORTED

@@ -1,0 +1,165 @@
+"""-m gpu: GEMM through the C ABI vs the CPU oracle and the golden vectors.
+
+Tolerances (stated, per dtype):
+  f64  : rtol = atol = 1e-3, the reference's own (test_gemm.py:9-17 via test/common.py:6-11); we also
+         assert 1e-10 relative, the f64 accumulation bound.
+  f32  : the MFMA f32 path is a k-ordered fma chain, the same arithmetic as the oracle's restatement of
+         fma_dot_ref (block_utils.h:46-77): we assert |err| <= 4e-7 * sum_k|a||b| (a few f32 ulps of
+         the accumulated magnitude) and the reference's 1e-3 on top.
+  bf16 / f16: inputs are exact in f32 and products exact; error = f32 accumulation order + one final
+         rounding: |err| <= 2^-8 * |c| + 1e-6 * sum_k|a||b| for bf16 (2^-11 for f16).
+"""
+import numpy as np
+import pytest
+
+from kfunca_amd import hip_abi as H
+from oracle import oracle as O
+from tests.helpers import assert_close, golden, regen
+
+pytestmark = pytest.mark.gpu
+
+
+def run_gemm(code, a, b, ta=False, tb=False, alpha=1.0, beta=0.0, c=None, bias=None):
+    """a, b are the STORED arrays (already transposed if ta/tb)."""
+    M = a.shape[1] if ta else a.shape[0]
+    K = a.shape[0] if ta else a.shape[1]
+    N = b.shape[0] if tb else b.shape[1]
+    da, db = H.DevBuf.from_numpy(a), H.DevBuf.from_numpy(b)
+    out = np.zeros((M, N), dtype=a.dtype) if c is None else c
+    dc = H.DevBuf.from_numpy(out)
+    dbias = H.DevBuf.from_numpy(bias) if bias is not None else None
+    need = H.gemm_workspace_bytes(code, ta, tb, M, N, K)
+    ws = H.DevBuf(need) if need else None
+    H.gemm(code, ta, tb, M, N, K, alpha, da.ptr, a.shape[1], db.ptr, b.shape[1], beta, dc.ptr, N,
+           H.EPI_BIAS_ROW if bias is not None else H.EPI_NONE, dbias.ptr if dbias else None,
+           ws.ptr if ws else None, need)
+    H.device_sync()
+    return dc.to_numpy((M, N), a.dtype)
+
+
+def f64(x, code):
+    return O.to_float(x, code).astype(np.float64)
+
+
+def test_golden_f64_reference_case():
+    g = golden("gemm")
+    a, b = regen(g["f64_seed"][0], [(123, 457), (457, 234)], g["f64_sha"], dtype=np.float64)
+    got = run_gemm(H.F64, a, b)
+    assert_close(got, g["f64_out"], what="f64 123x457x234 (test_gemm.py:9-17)")
+    assert_close(got, g["f64_out"], rtol=1e-10, atol=1e-9, what="f64 tight")
+
+
+def test_golden_f32_layouts_alpha_beta_backward():
+    g = golden("gemm")
+    a, b, c, gg = g["f32_a"], g["f32_b"], g["f32_c"], g["f32_g"]
+    tol = dict(rtol=1e-4, atol=1e-4)
+    assert_close(run_gemm(H.F32, a, b), g["f32_out"], **tol, what="NN")
+    assert_close(run_gemm(H.F32, a.T.copy(), b, ta=True), g["f32_out"], **tol, what="TN")
+    assert_close(run_gemm(H.F32, a, b.T.copy(), tb=True), g["f32_out"], **tol, what="NT")
+    assert_close(run_gemm(H.F32, a.T.copy(), b.T.copy(), ta=True, tb=True), g["f32_out"], **tol, what="TT")
+    assert_close(run_gemm(H.F32, a, b, alpha=0.5, beta=2.0, c=c.copy()), g["f32_out_ab"], **tol, what="alpha/beta")
+    # backward of C = A B (no reference counterpart; torch autograd fixture): dA = dC B^T, dB = A^T dC
+    assert_close(run_gemm(H.F32, gg, b, tb=True), g["f32_da"], **tol, what="dA")
+    assert_close(run_gemm(H.F32, a, gg, ta=True), g["f32_db"], **tol, what="dB")
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (256, 384, 272), (512, 128, 1024), (100, 130, 70), (1, 1, 1), (129, 257, 33)])
+def test_f32_vs_oracle(M, N, K):
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    a, b = rng.uniform(-1, 1, (M, K)).astype(np.float32), rng.uniform(-1, 1, (K, N)).astype(np.float32)
+    mag = np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)
+    for ta in (False, True):
+        for tb in (False, True):
+            sa, sb = (a.T.copy() if ta else a), (b.T.copy() if tb else b)
+            got = run_gemm(H.F32, sa, sb, ta, tb)
+            want = O.gemm(sa, sb, trans_a=ta, trans_b=tb)
+            assert (np.abs(got.astype(np.float64) - want) <= 4e-7 * mag + 1e-30).all(), (ta, tb)
+            assert_close(got, want, what=f"f32 {ta} {tb}")
+    bias = rng.uniform(-1, 1, (N,)).astype(np.float32)
+    c = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+    got = run_gemm(H.F32, a, b, alpha=0.75, beta=-1.5, c=c.copy(), bias=bias)
+    want = O.gemm(a, b, alpha=0.75, beta=-1.5, c=c.copy(), bias=bias)
+    assert_close(got, want, rtol=1e-5, atol=1e-5, what="alpha/beta/bias epilogue")
+
+
+def test_f32_mfma_is_the_fma_chain():
+    """v_mfma_f32_32x32x2_f32 accumulates as a k-ordered f32 fma chain (guide: 'bit-for-bit'), which
+    is what the oracle restates: with alpha = 1, beta = 0 the two agree exactly."""
+    rng = np.random.default_rng(5)
+    a, b = rng.uniform(-1, 1, (256, 512)).astype(np.float32), rng.uniform(-1, 1, (512, 128)).astype(np.float32)
+    got, want = run_gemm(H.F32, a, b), O.gemm(a, b)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("code", [H.BF16, H.F16])
+def test_16bit_exact_integers_catch_layout_bugs(code):
+    """Small integers are exact in bf16/f16 and in f32 accumulation: any fragment/lane/transposed-read
+    mistake shows up as a wrong integer. B is asymmetric, A is not the identity."""
+    rng = np.random.default_rng(6)
+    M, N, K = 256, 384, 192
+    a = rng.integers(-3, 4, (M, K)).astype(np.float32)
+    b = (rng.integers(-2, 3, (K, N)) + (np.arange(N)[None, :] % 3 == 0)).astype(np.float32)
+    want = a.astype(np.float64) @ b.astype(np.float64)
+    assert np.abs(want).max() < 2048 if code == H.F16 else True
+    for ta in (False, True):
+        for tb in (False, True):
+            sa, sb = (a.T.copy() if ta else a), (b.T.copy() if tb else b)
+            got = run_gemm(code, O.from_float(sa, code), O.from_float(sb, code), ta, tb)
+            exact = np.abs(want) <= 256  # representable without rounding in bf16
+            assert np.array_equal(f64(got, code)[exact], want[exact]), (code, ta, tb)
+            assert_close(f64(got, code), want, rtol=2 ** -8, atol=0, what=f"int {code} {ta} {tb}")
+
+
+@pytest.mark.parametrize("code,eps", [(H.BF16, 2.0 ** -8), (H.F16, 2.0 ** -11)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 512, 320), (384, 128, 1024), (100, 130, 70), (64, 64, 64)])
+def test_16bit_vs_oracle(code, eps, M, N, K):
+    rng = np.random.default_rng(M + N + K + code)
+    a = O.from_float(rng.uniform(-1, 1, (M, K)).astype(np.float32), code)
+    b = O.from_float(rng.uniform(-1, 1, (K, N)).astype(np.float32), code)
+    af, bf = f64(a, code), f64(b, code)
+    mag = np.abs(af) @ np.abs(bf)
+    for ta in (False, True):
+        for tb in (False, True):
+            sa, sb = (a.T.copy() if ta else a), (b.T.copy() if tb else b)
+            got = f64(run_gemm(code, sa, sb, ta, tb), code)
+            want = af @ bf
+            assert (np.abs(got - want) <= eps * np.abs(want) + 1e-6 * mag + 1e-30).all(), (code, ta, tb, M, N, K)
+            orc = f64(O.gemm(sa, sb, trans_a=ta, trans_b=tb, code=code), code)
+            assert (np.abs(got - orc) <= 2 * eps * np.abs(want) + 2e-6 * mag + 1e-30).all(), "vs oracle"
+    bias = O.from_float(rng.uniform(-1, 1, (N,)).astype(np.float32), code)
+    c = O.from_float(rng.uniform(-1, 1, (M, N)).astype(np.float32), code)
+    got = f64(run_gemm(code, a, b, alpha=0.5, beta=2.0, c=c.copy(), bias=bias), code)
+    want = 0.5 * (af @ bf) + 2.0 * f64(c, code) + f64(bias, code)[None, :]
+    assert (np.abs(got - want) <= 2 * eps * np.abs(want) + 2e-6 * mag + 2 * eps).all(), "epilogue"
+
+
+def test_linearity_at_full_size():
+    """Size-independent property at BASELINE size 4096^3 bf16: (A1 + A2) B == A1 B + A2 B within rounding,
+    and a column-sparse probe: B = one-hot columns selects columns of A exactly."""
+    rng = np.random.default_rng(11)
+    n = 4096
+    a = O.f32_to_bf16(rng.integers(-4, 5, (n, n)).astype(np.float32))
+    sel = rng.permutation(n)
+    b = np.zeros((n, n), dtype=np.float32)
+    b[sel, np.arange(n)] = 1.0  # C[:, j] = A[:, sel[j]]
+    got = O.bf16_to_f32(run_gemm(H.BF16, a, O.f32_to_bf16(b)))
+    assert np.array_equal(got, O.bf16_to_f32(a)[:, sel])
+    got_t = O.bf16_to_f32(run_gemm(H.BF16, a, O.f32_to_bf16(b.T.copy()), tb=True))
+    assert np.array_equal(got_t, O.bf16_to_f32(a)[:, sel])
+    got_ta = O.bf16_to_f32(run_gemm(H.BF16, a, O.f32_to_bf16(b), ta=True))  # A^T B
+    assert np.array_equal(got_ta, O.bf16_to_f32(a).T[:, sel])
+
+
+def test_errors():
+    a = H.DevBuf(1024)
+    with pytest.raises(H.KfError) as e:
+        H.gemm(H.I32, False, False, 4, 4, 4, 1.0, a.ptr, 4, a.ptr, 4, 0.0, a.ptr, 4)
+    assert e.value.code == H.KF_ERR_UNSUPPORTED
+    with pytest.raises(H.KfError) as e:
+        H.gemm(H.F32, False, False, 4, 4, 4, 1.0, a.ptr, 2, a.ptr, 4, 0.0, a.ptr, 4)
+    assert e.value.code == H.KF_ERR_INVALID
+    need = H.gemm_workspace_bytes(H.BF16, False, False, 128, 128, 64)
+    assert need > 0
+    with pytest.raises(H.KfError) as e:
+        H.gemm(H.BF16, False, False, 128, 128, 64, 1.0, a.ptr, 64, a.ptr, 128, 0.0, a.ptr, 128)
+    assert e.value.code == H.KF_ERR_WORKSPACE

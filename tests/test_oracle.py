@@ -1,0 +1,171 @@
+"""Pins the CPU oracle (oracle/oracle.c) against the golden vectors in tests/golden, which hold the
+reference's own test-oracle expressions (numpy / torch-CPU) evaluated on seeded inputs.
+No GPU needed."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests.helpers import assert_close, golden, regen, uni
+
+OPS = {"add": O.ADD, "sub": O.SUB, "mul": O.MUL, "div": O.DIV}
+
+
+def test_promotion_table():
+    # tensor_iterator.cpp:32-44
+    assert O.promote(O.I32, O.F32) == O.F32
+    assert O.promote(O.F16, O.BF16) == O.BF16       # reference quirk: Half + BFloat16 -> BFloat16
+    assert O.promote(O.U8, O.I8) == O.I8
+    assert O.promote(O.BOOL, O.U8) == O.U8
+    assert O.promote(O.I64, O.F16) == O.F16
+    assert O.promote(O.F32, O.F64) == O.F64
+
+
+def test_add_and_promotion_bit_exact():
+    g = golden("elementwise")
+    for i in range(3):
+        a = g[f"add{i}_a"]
+        assert np.array_equal(O.binary(O.ADD, a, a), g[f"add{i}_out"])
+        out = O.binary(O.ADD, g[f"promo{i}_a"], g[f"promo{i}_b"])
+        assert out.dtype == np.float32
+        assert np.array_equal(out, g[f"promo{i}_out"])
+
+
+def test_inplace_chain():
+    g = golden("elementwise")
+    a, b = g["inpl_a"].copy(), g["inpl_b"]
+    steps = g["inpl_steps"]
+    for k, op in enumerate((O.ADD, O.SUB, O.MUL, O.DIV)):
+        O.binary_out(op, a, b, a)
+        assert np.array_equal(a, steps[k]), k
+    for k, (op, s) in enumerate(((O.ADD, 2), (O.SUB, 3), (O.MUL, 4), (O.DIV, 5))):
+        # register.cpp:172-206: scalar ops materialise empty_like(self).fill_(s)
+        sc = O.fill(np.empty_like(a), s)
+        O.binary_out(op, a, sc, a)
+        assert np.array_equal(a, steps[4 + k]), k
+
+
+def test_broadcast_binary():
+    g = golden("elementwise")
+    for i in range(3):
+        a, b = g[f"bc{i}_a"], g[f"bc{i}_b"]
+        for name, op in OPS.items():
+            assert np.array_equal(O.binary(op, a, b), g[f"bc{i}_{name}"]), (i, name)
+        assert np.array_equal(O.binary(O.MUL, g[f"bc{i}_ai"], b), g[f"bc{i}_imul"])
+
+
+def test_convert_half_bf16():
+    g = golden("elementwise")
+    x = g["cvt_x"]
+    h = O.convert(x, O.F16)
+    assert np.array_equal(h.view(np.uint16), g["cvt_half_bits"])
+    assert np.array_equal(O.convert(O.binary(O.MUL, h, h), O.F32), g["cvt_half_sq"])
+    bf = O.convert(x, O.BF16)
+    assert np.array_equal(bf, g["cvt_bf16_bits"])
+    sq = O.binary(O.MUL, bf, bf, a_code=O.BF16, b_code=O.BF16)
+    assert np.array_equal(O.convert(sq, O.F32, src_code=O.BF16), g["cvt_bf16_sq"])
+    assert np.array_equal(O.convert(g["cvt_big"], O.BF16), g["cvt_big_bf16"])
+    assert np.array_equal(O.convert(g["cvt_big"], O.F16).view(np.uint16), g["cvt_big_f16"])
+
+
+def test_integer_and_bool_semantics():
+    a = np.array([127, -128, 5, -7], dtype=np.int8)
+    b = np.array([1, -1, 2, 2], dtype=np.int8)
+    assert np.array_equal(O.binary(O.ADD, a, b), np.array([-128, 127, 7, -5], dtype=np.int8))  # wraps
+    assert np.array_equal(O.binary(O.DIV, a, b), np.array([127, -128, 2, -3], dtype=np.int8))  # truncates; -128/-1 wraps
+    t, f = np.array([True, True, False, False]), np.array([True, False, True, False])
+    assert np.array_equal(O.binary(O.ADD, t, f), t | f)
+    assert np.array_equal(O.binary(O.SUB, t, f), t ^ f)
+    assert np.array_equal(O.binary(O.MUL, t, f), t & f)
+    assert np.array_equal(O.fill(np.empty(3, dtype=np.int32), -2.7), np.array([-2, -2, -2], dtype=np.int32))
+
+
+def test_views_copy_bit_exact():
+    g = golden("shape_ops")
+    x = g["perm_x"]
+    dst = np.empty(g["perm_out"].shape, dtype=x.dtype)
+    assert np.array_equal(O.copy(x.transpose(2, 1, 0, 3), dst), g["perm_out"])
+    x = g["slice_x"]
+    v = x[3, 3:8, 4:11:2]
+    assert np.array_equal(O.copy(v, np.empty(v.shape, dtype=x.dtype)), g["slice_out"])
+    x = g["view_x"].reshape(5, -1, 23)
+    one = O.fill(np.empty_like(x), 1)
+    assert np.array_equal(O.binary(O.ADD, x, one), g["view_out"])
+    # cat = empty + narrow().copy_() per input (tensor_shape.cpp:41-70)
+    out = np.empty(g["cat_out"].shape, dtype=np.float32)
+    off = 0
+    for k in "abc":
+        t = g[f"cat_{k}"]
+        O.copy(t, out[:, off:off + t.shape[1], :])
+        off += t.shape[1]
+    assert np.array_equal(out, g["cat_out"])
+    x, off = g["split_x"], 0
+    for i, n in enumerate((11, 13, 1)):
+        v = x[:, off:off + n, :]
+        assert np.array_equal(O.copy(v, np.empty(v.shape, dtype=x.dtype)), g[f"split_{i}"])
+        off += n
+    assert np.array_equal(O.binary(O.ADD, g["int_x"], g["int_x"]), g["int_out"])  # test/core/test_tensor.cpp:10-23
+
+
+def test_index_put():
+    g = golden("shape_ops")
+    x = g["iput_x"].copy()
+    assert np.array_equal(O.index_put(x, [g["iput_i0"], g["iput_i1"]], g["iput_v"]), g["iput_out"])
+    x = g["iput3_x"].copy()
+    assert np.array_equal(O.index_put(x, [g["iput3_i0"], g["iput3_i1"], g["iput3_i2"]], g["iput3_v"]), g["iput3_out"])
+
+
+def test_reductions():
+    g = golden("reductions")
+    x = g["x"]
+    for dim in range(3):
+        # reference tolerance for reductions: 1e-2 (test_tensor.py:118); the oracle is far inside it
+        assert_close(O.reduce(O.SUM, x, dim), g[f"sum{dim}"], rtol=1e-5, atol=1e-4, what=f"sum{dim}")
+        assert_close(O.reduce(O.MEAN, x, dim), g[f"mean{dim}"], rtol=1e-5, atol=1e-5, what=f"mean{dim}")
+        assert np.array_equal(O.reduce(O.SUM, g["xi"], dim), g[f"isum{dim}"])
+    # integer mean: factor = nout / numel in the integer dtype == 0 (reduce_ops_kernel.cu:49-53)
+    assert not O.reduce(O.MEAN, g["xi"], 1).any()
+    a, b = regen(g["c1_seed"][0], [(1024, 1024), (1024, 1024)], g["c1_sha"])
+    from tests.helpers import sha
+    assert np.array_equal(sha(O.binary(O.ADD, a, b)), g["c1_add_sha"])  # config C1 add: bit-exact
+    assert_close(O.reduce(O.SUM, a, 0), g["c1_sum0"], rtol=1e-6, atol=1e-3, what="c1 sum0")
+    assert_close(O.reduce(O.SUM, a, 1), g["c1_sum1"], rtol=1e-6, atol=1e-3, what="c1 sum1")
+
+
+def test_gemm():
+    g = golden("gemm")
+    a, b = regen(g["f64_seed"][0], [(123, 457), (457, 234)], g["f64_sha"], dtype=np.float64)
+    assert_close(O.gemm(a, b), g["f64_out"], what="f64 gemm (test_gemm.py:9-17)")
+    a, b, c = g["f32_a"], g["f32_b"], g["f32_c"]
+    assert_close(O.gemm(a, b), g["f32_out"], rtol=1e-4, atol=1e-4, what="f32 NN")
+    assert_close(O.gemm(a.T.copy(), b, trans_a=True), g["f32_out"], rtol=1e-4, atol=1e-4, what="f32 TN")
+    assert_close(O.gemm(a, b.T.copy(), trans_b=True), g["f32_out"], rtol=1e-4, atol=1e-4, what="f32 NT")
+    assert_close(O.gemm(a, b, alpha=0.5, beta=2.0, c=c), g["f32_out_ab"], rtol=1e-4, atol=1e-4, what="alpha/beta")
+    gg = g["f32_g"]  # dA = dC B^T, dB = A^T dC
+    assert_close(O.gemm(gg, b, trans_b=True), g["f32_da"], rtol=1e-4, atol=1e-4, what="dA")
+    assert_close(O.gemm(a, gg, trans_a=True), g["f32_db"], rtol=1e-4, atol=1e-4, what="dB")
+    # bf16 inputs: products exact in f32, result rounded once
+    ab, bb = O.f32_to_bf16(a), O.f32_to_bf16(b)
+    want = O.bf16_to_f32(ab).astype(np.float64) @ O.bf16_to_f32(bb).astype(np.float64)
+    assert_close(O.bf16_to_f32(O.gemm(ab, bb, code=O.BF16)), want, rtol=2 ** -8, atol=1e-2, what="bf16 gemm")
+
+
+def test_attention_forward():
+    g = golden("attention")
+    for i in range(3):
+        B, H, Sq, Skv, D = (int(v) for v in g[f"fwd{i}_dims"])
+        q, k, v = regen(1050 + i, [(B, H, Sq, D), (B, H, Skv, D), (B, H, Skv, D)], g[f"fwd{i}_sha"])
+        o, lse = O.attn_fwd(q, k, v)
+        assert_close(o, g[f"fwd{i}_out"], what=f"attention fwd case {i} (test_nn.py:11-33)")
+        assert np.isfinite(lse).all()
+
+
+def test_attention_backward():
+    g = golden("attention")
+    for i in range(3):
+        B, H, Sq, Skv, D = (int(v) for v in g[f"bwd{i}_dims"])
+        q, k, v, go = regen(1060 + i, [(B, H, Sq, D), (B, H, Skv, D), (B, H, Skv, D), (B, H, Sq, D)], g[f"bwd{i}_sha"], lo=-1, hi=1)
+        o, _ = O.attn_fwd(q, k, v)
+        assert_close(o, g[f"bwd{i}_out"], rtol=1e-4, atol=1e-5, what="fwd")
+        dq, dk, dv = O.attn_bwd(q, k, v, go)
+        for n, got in (("dq", dq), ("dk", dk), ("dv", dv)):
+            assert_close(got, g[f"bwd{i}_{n}"], rtol=1e-4, atol=1e-5, what=f"bwd case {i} {n}")
