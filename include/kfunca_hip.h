@@ -89,6 +89,7 @@ int kf_memset_zero(void *ptr, size_t bytes, void *stream);                 /* dm
 int kf_stream_create(void **stream);        /* Launcher::stream_begin, launcher_cuda.h:113-118 */
 int kf_stream_destroy(void *stream);
 int kf_stream_sync(void *stream);           /* Launcher::stream_sync, launcher_cuda.h:125-127  */
+int kf_stream_wait_event(void *stream, void *event); /* cross-stream ordering without a host sync */
 int kf_device_sync(void);
 int kf_event_create(void **event);          /* per-launch timing mode, launcher_cuda.h:336-345 */
 int kf_event_destroy(void *event);

@@ -1,0 +1,81 @@
+// Caching device allocator on kf_malloc (hipMalloc).
+// Same contract as the reference's DeviceAllocator (src/core/include/device_allocator.h:42-82,
+// device_allocator.cpp:37-72): singleton, 1 KiB granularity, eight size classes bounded at
+// 4K/64K/256K/1M/4M/64M/256M/inf, best-fit reuse of a cached block of the same class, no splitting,
+// memory is never returned to the driver. Rebuilt for multi-GPU MI355X nodes: pools are keyed by
+// DEVICE (the reference's free lists ignore it — a block freed on device 0 can be handed to device 1,
+// device_allocator.h:30-40), all state sits behind a mutex, and zero-initialised scratch is available
+// for kernels that need it.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <unordered_map>
+#include <vector>
+
+namespace utils {
+namespace memory {
+
+// owning handle to a cached block; releasing it returns the block to the pool
+class DataPtr {
+public:
+    DataPtr() = default;
+    DataPtr(void *p, size_t bytes, int device) : p_(p), bytes_(bytes), device_(device) {}
+    DataPtr(const DataPtr &) = delete;
+    DataPtr &operator=(const DataPtr &) = delete;
+    DataPtr(DataPtr &&o) noexcept { steal(o); }
+    DataPtr &operator=(DataPtr &&o) noexcept {
+        if (this != &o) { clear(); steal(o); }
+        return *this;
+    }
+    ~DataPtr() { clear(); }
+    void *get() const { return p_; }
+    size_t capacity() const { return bytes_; }
+    int device() const { return device_; }
+    explicit operator bool() const { return p_ != nullptr; }
+    void clear();
+
+private:
+    void steal(DataPtr &o) { p_ = o.p_; bytes_ = o.bytes_; device_ = o.device_; o.p_ = nullptr; o.bytes_ = 0; }
+    void *p_ = nullptr;
+    size_t bytes_ = 0;
+    int device_ = -1;
+};
+
+class DeviceAllocator {
+public:
+    static constexpr size_t kAlignment = 1024;
+    static constexpr int kNumPools = 8;
+    static DeviceAllocator *GetInstance();
+
+    DataPtr allocate(size_t size_in_bytes, int device);
+    void free(void *ptr);
+    void print();
+
+    struct Stats { size_t active_blocks, cached_blocks, active_bytes, cached_bytes, driver_allocs; };
+    Stats stats(int device = -1);
+    static int pool_index(size_t size);
+
+private:
+    DeviceAllocator() = default;
+    struct Block { void *ptr; size_t size; int device; uint32_t id; bool in_use; };
+    struct BySizeThenPtr {
+        bool operator()(const Block *a, const Block *b) const {
+            if (a->size != b->size) return a->size < b->size;
+            return reinterpret_cast<uintptr_t>(a->ptr) < reinterpret_cast<uintptr_t>(b->ptr);
+        }
+    };
+    using Pool = std::set<Block *, BySizeThenPtr>;
+    std::mutex mu_;
+    std::map<int, std::vector<Pool>> free_;            // device -> size class -> cached blocks
+    std::unordered_map<void *, Block *> by_ptr_;       // every block ever allocated
+    uint32_t next_id_ = 0;
+    size_t driver_allocs_ = 0;
+};
+
+} // namespace memory
+} // namespace utils

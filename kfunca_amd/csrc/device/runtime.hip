@@ -172,6 +172,12 @@ int kf_stream_sync(void *stream) {
     return KF_OK;
 }
 
+int kf_stream_wait_event(void *stream, void *event) {
+    KF_REQUIRE(event, KF_ERR_INVALID, "kf_stream_wait_event: null event");
+    KF_HIP_TRY(hipStreamWaitEvent(as_stream(stream), reinterpret_cast<hipEvent_t>(event), 0));
+    return KF_OK;
+}
+
 int kf_device_sync(void) {
     KF_HIP_TRY(hipDeviceSynchronize());
     return KF_OK;

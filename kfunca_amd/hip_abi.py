@@ -34,7 +34,7 @@ CODE2NP = {BOOL: np.bool_, U8: np.uint8, I8: np.int8, I16: np.int16, I32: np.int
 EXPORTS = [
     "kf_last_error", "kf_abi_version", "kf_device_count", "kf_set_device", "kf_get_device", "kf_malloc", "kf_free",
     "kf_memcpy_h2d", "kf_memcpy_d2h", "kf_memcpy_d2d", "kf_memset_zero", "kf_stream_create", "kf_stream_destroy",
-    "kf_stream_sync", "kf_device_sync", "kf_event_create", "kf_event_destroy", "kf_event_record", "kf_event_sync",
+    "kf_stream_sync", "kf_stream_wait_event", "kf_device_sync", "kf_event_create", "kf_event_destroy", "kf_event_record", "kf_event_sync",
     "kf_event_elapsed_ms", "kf_profile_enable", "kf_profile_reset", "kf_profile_count", "kf_profile_get",
     "kf_device_props_get", "kf_elementwise", "kf_reduce_workspace_bytes", "kf_reduce",
     "kf_index_put", "kf_gemm_workspace_bytes", "kf_gemm", "kf_attn_fwd", "kf_attn_bwd_workspace_bytes",
@@ -83,6 +83,7 @@ def lib():
         _lib.kf_stream_create.argtypes = [C.POINTER(vp)]
         _lib.kf_stream_destroy.argtypes = [vp]
         _lib.kf_stream_sync.argtypes = [vp]
+        _lib.kf_stream_wait_event.argtypes = [vp, vp]
         _lib.kf_event_create.argtypes = [C.POINTER(vp)]
         _lib.kf_event_destroy.argtypes = [vp]
         _lib.kf_event_record.argtypes = [vp, vp]
@@ -340,6 +341,10 @@ def attn_bwd(dtype, B, H, Sq, Skv, D, q, k, v, o, lse, d_o, dq, dk, dv, workspac
 
 def device_sync():
     check(lib().kf_device_sync())
+
+
+def stream_wait_event(stream, event: "Event"):
+    check(lib().kf_stream_wait_event(stream, event.handle))
 
 
 def profile_enable(on: bool):

@@ -96,9 +96,9 @@ def test_workspace_contract():
 def test_golden_index_put():
     g = golden("shape_ops")
 
-    def run(x, idx, vals):
-        self_ = Dev(x.copy())
-        vd = Dev(vals)
+    def run(x, idx, vals, code=None):
+        self_ = Dev(x.copy(), code)
+        vd = Dev(vals, code)
         ids = [Dev(np.ascontiguousarray(i, dtype=np.int64)) for i in idx]
         # self viewed with stride 0 over the index shape (index_ops.cpp:23-25)
         sv = H.View(self_.buf.ptr, vals.shape, (0,) * vals.ndim, self_.code)
@@ -119,4 +119,4 @@ def test_golden_index_put():
         i0[::7] -= 300  # negative indices wrap once
         vals = rand_of(rng, (5000,), code)
         want = O.index_put(x.copy(), [i0, i1], vals, code=code)
-        assert np.array_equal(run(x, [i0, i1], vals), want), code
+        assert np.array_equal(run(x, [i0, i1], vals, code), want), code
