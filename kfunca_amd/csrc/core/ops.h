@@ -1,0 +1,55 @@
+// namespace gpu: the operator API (reference: src/core/include/*_ops.h, tensor_shape.h).
+// Each op builds a TensorIterator (or validates shapes), asks the allocator for outputs/scratch,
+// and crosses the C ABI exactly once per kernel.
+#pragma once
+
+#include <tuple>
+#include <vector>
+
+#include "tensor.h"
+
+namespace gpu {
+
+// binary_ops.h:5-18
+Tensor &add_out(Tensor &out, const Tensor &left, const Tensor &right);
+Tensor add(const Tensor &left, const Tensor &right);
+Tensor &add_(Tensor &self, const Tensor &other);
+Tensor &sub_out(Tensor &out, const Tensor &left, const Tensor &right);
+Tensor sub(const Tensor &left, const Tensor &right);
+Tensor &sub_(Tensor &self, const Tensor &other);
+Tensor &mul_out(Tensor &out, const Tensor &left, const Tensor &right);
+Tensor mul(const Tensor &left, const Tensor &right);
+Tensor &mul_(Tensor &self, const Tensor &other);
+Tensor &div_out(Tensor &out, const Tensor &left, const Tensor &right);
+Tensor div(const Tensor &left, const Tensor &right);
+Tensor &div_(Tensor &self, const Tensor &other);
+// unary_ops.h:5-9, nullary_ops.h:5-8
+Tensor clone(const Tensor &self);
+Tensor &copy_(Tensor &self, const Tensor &other);
+Tensor convert(const Tensor &self, ScalarType dtype);
+Tensor &fill_out(Tensor &out, const any_t &value);
+Tensor &fill_(Tensor &self, const any_t &value);
+// reduce_ops.h:5-9
+Tensor sum(const Tensor &self, int64_t reduce_dim);
+Tensor mean(const Tensor &self, int64_t reduce_dim);
+std::tuple<Tensor, Tensor> mean_var(const Tensor &self, int64_t reduce_dim, bool take_sqrt);
+// gemm_ops.h:5-8, nn_ops.h:5-7
+void gemm_out(Tensor &out, const Tensor &a, const Tensor &b, float alpha, float beta);
+Tensor gemm(const Tensor &a, const Tensor &b, float alpha, float beta);
+Tensor causal_attention(const Tensor &q, const Tensor &k, const Tensor &v);
+// index_ops.h:5-9, tensor_shape.h:5-10
+Tensor &index_put_(Tensor &self, const std::vector<Tensor> &indices, const Tensor &values);
+Tensor concat(const std::vector<Tensor> tensors, int64_t dim);
+std::vector<Tensor> tensor_split(const Tensor &self, std::vector<int64_t> indices, int64_t dim);
+// norm_ops.h, sort_ops.h: outside the hot-path scope — raise
+std::tuple<Tensor, Tensor> norm_stat(const Tensor &self, int64_t dim);
+std::tuple<Tensor, Tensor> sort(const Tensor &self, int64_t dim, bool descending);
+std::tuple<Tensor, Tensor> topk(const Tensor &self, int64_t k, int64_t dim, bool largest);
+
+// extensions used by the backward passes (no reference counterpart)
+Tensor gemm_ex(const Tensor &a, bool trans_a, const Tensor &b, bool trans_b, float alpha);
+std::tuple<Tensor, Tensor> causal_attention_fwd(const Tensor &q, const Tensor &k, const Tensor &v); // (out, lse)
+std::tuple<Tensor, Tensor, Tensor> causal_attention_bwd(const Tensor &q, const Tensor &k, const Tensor &v, const Tensor &out,
+                                                        const Tensor &lse, const Tensor &grad_out);
+
+} // namespace gpu
