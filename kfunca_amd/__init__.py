@@ -1,0 +1,40 @@
+"""kfunca_amd — MI355X-native (gfx950) implementation of kfunca's tensor-kernel hot path.
+
+    import kfunca_amd as kfunca        # same surface as the reference's `kfunca` module (src/register.cpp)
+
+Layers:
+    kfunca_amd._C            pybind11 module: Tensor / autograd / operator API (host C++, kfunca_amd/csrc/core)
+    libkfunca_hip.so         the C-ABI device library (include/kfunca_hip.h): hand-written HIP kernels + RCCL
+    kfunca_amd.hip_abi       ctypes binding of that C ABI (what a foreign host would bind)
+    kfunca_amd.parallel      batch sharding + gradient all-reduce for 1..8 GPUs of one node
+
+The native module is loaded on first use; if it has not been built the import fails loudly — there is
+no Python or CPU fallback for any operator.
+"""
+import importlib
+
+__all__ = ["device_info", "memstat", "dtype", "empty", "empty_like", "from_numpy", "to_numpy", "zeros",
+           "causal_attention", "gemm", "cat", "tensor"]
+
+_native = None
+
+
+def _load():
+    global _native
+    if _native is None:
+        try:
+            _native = importlib.import_module("kfunca_amd._C")
+        except ImportError as e:  # loud: no fallback
+            raise ImportError("kfunca_amd._C is not built (run `python -m kfunca_amd._build`); "
+                              "the operator API has no fallback path") from e
+    return _native
+
+
+def __getattr__(name):
+    if name.startswith("__"):
+        raise AttributeError(name)
+    return getattr(_load(), name)
+
+
+def __dir__():
+    return sorted(set(__all__) | set(dir(_load())))

@@ -1,0 +1,367 @@
+// namespace gpu: operator implementations over the C ABI.
+// Behavioural references: src/core/{binary,unary,nullary,reduce,gemm,nn,index}_ops.cpp,
+// src/core/tensor_shape.cpp and the argument checks of src/device/{gemm,causal_attention}_kernel.cu.
+#include "ops.h"
+
+#include <algorithm>
+
+#include "device_api.h"
+#include "tensor_iterator.h"
+
+using utils::memory::DataPtr;
+using utils::memory::DeviceAllocator;
+
+namespace gpu {
+
+namespace {
+
+int code(ScalarType t) { return static_cast<int>(t); }
+
+// elementwise launch: contiguous iteration spaces go down whole (the kernel indexes in 64 bits);
+// strided ones are cut into 32-bit-indexable pieces first (reference tensor_loops.h:357-369)
+void run_elementwise(TensorIterator &iter, int op, ScalarType compute, double scalar = 0.0) {
+    if (iter.numel() == 0) return;
+    void *stream = dev::stream(iter.device(0));
+    auto launch = [&](const IterGeometry &g) {
+        kf_iter_desc d;
+        g.to_desc(d);
+        DEV_CALL(kf_elementwise(op, &d, compute == ScalarType::Undefined ? 0 : code(compute), scalar, stream));
+    };
+    if (iter.geometry().is_contiguous()) launch(iter.geometry());
+    else iter.geometry().for_each_32bit(launch);
+}
+
+Tensor &binary_out(int op, Tensor &out, const Tensor &left, const Tensor &right) {
+    auto iter = TensorIterator().add_output(out).add_input(left).add_input(right).build_for_loops();
+    run_elementwise(iter, op, iter.common_dtype());
+    return out;
+}
+
+void run_reduce(TensorIterator &iter, int op) {
+    if (iter.num_output_elements() == 0) return;
+    CHECK_FAIL(iter.can_use_32bit_indexing(), "reduction over more than 2^31 bytes per operand is not supported yet");
+    kf_iter_desc d;
+    iter.geometry().to_desc(d);
+    size_t need = 0;
+    DEV_CALL(kf_reduce_workspace_bytes(&d, &need));
+    const int device = iter.device(0);
+    DataPtr scratch;
+    if (need) scratch = DeviceAllocator::GetInstance()->allocate(need, device);
+    DEV_CALL(kf_reduce(op, &d, scratch.get(), need, dev::stream(device)));
+    // scratch returns to the cache here; reuse is stream-ordered behind the kernel that reads it
+}
+
+[[noreturn]] void out_of_scope(const char *what) {
+    CHECK_FAIL(false, what, " is outside the tensor-kernel hot path this build covers (SURVEY.md §8f); not implemented");
+    std::abort();
+}
+
+} // namespace
+
+// ---- binary (binary_ops.cpp:6-91) ------------------------------------------------------------------
+Tensor &add_out(Tensor &out, const Tensor &l, const Tensor &r) { return binary_out(KF_EW_ADD, out, l, r); }
+Tensor &sub_out(Tensor &out, const Tensor &l, const Tensor &r) { return binary_out(KF_EW_SUB, out, l, r); }
+Tensor &mul_out(Tensor &out, const Tensor &l, const Tensor &r) { return binary_out(KF_EW_MUL, out, l, r); }
+Tensor &div_out(Tensor &out, const Tensor &l, const Tensor &r) { return binary_out(KF_EW_DIV, out, l, r); }
+Tensor &add_(Tensor &self, const Tensor &other) { return add_out(self, self, other); }
+Tensor &sub_(Tensor &self, const Tensor &other) { return sub_out(self, self, other); }
+Tensor &mul_(Tensor &self, const Tensor &other) { return mul_out(self, self, other); }
+Tensor &div_(Tensor &self, const Tensor &other) { return div_out(self, self, other); }
+
+namespace {
+// d(a+b) = (g, g): the reference's only GradFunction (binary_ops.cpp:16-33)
+class AddGradFunction : public GradFunction {
+public:
+    AddGradFunction(const Tensor &l, const Tensor &r) { inputs = {l, r}; }
+    std::vector<Tensor> backward(Tensor g) override {
+        std::vector<Tensor> out(2);
+        if (inputs[0].requires_grad()) out[0] = g;
+        if (inputs[1].requires_grad()) out[1] = g;
+        return out;
+    }
+};
+} // namespace
+
+Tensor add(const Tensor &left, const Tensor &right) {
+    Tensor out;
+    add_out(out, left, right);
+    out.set_requires_grad(left.requires_grad() || right.requires_grad());
+    if (out.requires_grad()) out.set_grad_fn(new AddGradFunction(left, right));
+    return out;
+}
+Tensor sub(const Tensor &l, const Tensor &r) { Tensor out; sub_out(out, l, r); return out; }
+Tensor mul(const Tensor &l, const Tensor &r) { Tensor out; mul_out(out, l, r); return out; }
+Tensor div(const Tensor &l, const Tensor &r) { Tensor out; div_out(out, l, r); return out; }
+
+// ---- unary / nullary (unary_ops.cpp:7-24, nullary_ops.cpp:6-14) --------------------------------------
+Tensor &copy_(Tensor &self, const Tensor &other) {
+    auto iter = TensorIterator().add_output(self).add_input(other).resize_outputs(false).check_mem_overlap(false).build_for_loops();
+    run_elementwise(iter, KF_EW_COPY, ScalarType::Undefined);
+    return self;
+}
+
+Tensor clone(const Tensor &self) {
+    Tensor out = empty_like(self);
+    copy_(out, self);
+    return out;
+}
+
+Tensor convert(const Tensor &self, ScalarType dtype) {
+    Tensor out = empty(self.sizes(), dtype, self.device());
+    auto iter = TensorIterator().add_output(out).add_input(self).build_for_loops();
+    run_elementwise(iter, KF_EW_COPY, ScalarType::Undefined);
+    return out;
+}
+
+Tensor &fill_out(Tensor &out, const any_t &value) {
+    auto iter = TensorIterator().add_output(out).resize_outputs(false).build();
+    run_elementwise(iter, KF_EW_FILL, ScalarType::Undefined, static_cast<double>(value));
+    return out;
+}
+Tensor &fill_(Tensor &self, const any_t &value) { return fill_out(self, value); }
+
+// ---- reductions (reduce_ops.cpp:8-28) ------------------------------------------------------------------
+Tensor sum(const Tensor &self, int64_t reduce_dim) {
+    Tensor out;
+    auto iter = TensorIterator().add_output(out).add_input(self).build_for_reduce(reduce_dim);
+    run_reduce(iter, KF_RED_SUM);
+    return out;
+}
+
+Tensor mean(const Tensor &self, int64_t reduce_dim) {
+    Tensor out;
+    auto iter = TensorIterator().add_output(out).add_input(self).build_for_reduce(reduce_dim);
+    run_reduce(iter, KF_RED_MEAN);
+    return out;
+}
+
+std::tuple<Tensor, Tensor> mean_var(const Tensor &, int64_t, bool) { out_of_scope("mean_var"); }
+std::tuple<Tensor, Tensor> norm_stat(const Tensor &, int64_t) { out_of_scope("norm_stat"); }
+std::tuple<Tensor, Tensor> sort(const Tensor &, int64_t, bool) { out_of_scope("sort"); }
+std::tuple<Tensor, Tensor> topk(const Tensor &, int64_t, int64_t, bool) { out_of_scope("topk"); }
+
+// ---- GEMM (gemm_ops.cpp:6-16 + the checks of gemm_kernel.cu:8-25) -----------------------------------------
+namespace {
+
+bool gemm_dtype_ok(ScalarType t) {
+    return t == ScalarType::Float || t == ScalarType::Double || t == ScalarType::Half || t == ScalarType::BFloat16;
+}
+
+// C[M,N] = alpha op(A) op(B) + beta C on raw 2-D geometry
+void launch_gemm(ScalarType dt, bool ta, bool tb, int64_t M, int64_t N, int64_t K, float alpha, const void *A, int64_t lda,
+                 const void *B, int64_t ldb, float beta, void *C, int64_t ldc, int device) {
+    size_t need = 0;
+    DEV_CALL(kf_gemm_workspace_bytes(code(dt), ta, tb, M, N, K, &need));
+    DataPtr scratch;
+    if (need) scratch = DeviceAllocator::GetInstance()->allocate(need, device);
+    DEV_CALL(kf_gemm(code(dt), ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, KF_EPI_NONE, nullptr, scratch.get(), need,
+                     dev::stream(device)));
+}
+
+// dA = alpha * dC B^T, dB = alpha * A^T dC with A flattened to [M,K] (no reference counterpart)
+class GemmGradFunction : public GradFunction {
+public:
+    GemmGradFunction(const Tensor &a, const Tensor &b, float alpha) : alpha_(alpha) { inputs = {a, b}; }
+    std::vector<Tensor> backward(Tensor g) override {
+        const Tensor &a = inputs[0], &b = inputs[1];
+        const int64_t K = b.shape(0), N = b.shape(1), M = a.numel() / K;
+        Tensor gc = g.contiguous();
+        std::vector<Tensor> out(2);
+        if (a.requires_grad()) {
+            out[0] = empty(a.sizes(), a.dtype(), a.device());
+            launch_gemm(a.dtype(), false, true, M, K, N, alpha_, gc.data_ptr(), N, b.data_ptr(), N, 0.f, out[0].data_ptr(), K, a.device());
+        }
+        if (b.requires_grad()) {
+            out[1] = empty(b.sizes(), b.dtype(), b.device());
+            launch_gemm(a.dtype(), true, false, K, N, M, alpha_, a.data_ptr(), K, gc.data_ptr(), N, 0.f, out[1].data_ptr(), N, b.device());
+        }
+        return out;
+    }
+
+private:
+    float alpha_;
+};
+
+} // namespace
+
+void gemm_out(Tensor &out, const Tensor &a, const Tensor &b, float alpha, float beta) {
+    CHECK_FAIL(out.is_contiguous() && a.is_contiguous() && b.is_contiguous());
+    CHECK_FAIL(a.dim() >= 1);
+    const int64_t k = a.shape(-1);
+    CHECK_FAIL(k > 0);
+    const int64_t m = a.numel() / k;
+    CHECK_FAIL(b.dim() == 2 && b.shape(0) == k);
+    CHECK_FAIL(a.dtype() == b.dtype());
+    CHECK_FAIL(out.dtype() == a.dtype());
+    const int64_t n = b.shape(-1);
+    CHECK_FAIL(out.shape(-1) == n);
+    CHECK_FAIL(n > 0 && out.numel() / n == m);
+    CHECK_FAIL(gemm_dtype_ok(a.dtype()), "Unsupported ScalarType ", a.dtype());
+    CHECK_FAIL(a.device() == b.device() && a.device() == out.device());
+    launch_gemm(a.dtype(), false, false, m, n, k, alpha, a.data_ptr(), k, b.data_ptr(), n, beta, out.data_ptr(), n, a.device());
+}
+
+Tensor gemm(const Tensor &a, const Tensor &b, float alpha, float beta) {
+    auto out_size = a.sizes();
+    CHECK_FAIL(!out_size.empty() && b.dim() >= 1);
+    out_size.back() = b.shape(-1);
+    Tensor out = empty(out_size, a.dtype(), a.device());
+    gemm_out(out, a, b, alpha, beta);
+    out.set_requires_grad(a.requires_grad() || b.requires_grad());
+    if (out.requires_grad()) {
+        CHECK_FAIL(beta == 0.f, "gemm(): autograd needs beta == 0 (the output operand is not an input)");
+        out.set_grad_fn(new GemmGradFunction(a, b, alpha));
+    }
+    return out;
+}
+
+Tensor gemm_ex(const Tensor &a, bool trans_a, const Tensor &b, bool trans_b, float alpha) {
+    CHECK_FAIL(a.dim() == 2 && b.dim() == 2 && a.is_contiguous() && b.is_contiguous());
+    CHECK_FAIL(a.dtype() == b.dtype() && gemm_dtype_ok(a.dtype()));
+    const int64_t M = trans_a ? a.shape(1) : a.shape(0), K = trans_a ? a.shape(0) : a.shape(1);
+    const int64_t Kb = trans_b ? b.shape(1) : b.shape(0), N = trans_b ? b.shape(0) : b.shape(1);
+    CHECK_FAIL(K == Kb);
+    Tensor out = empty({M, N}, a.dtype(), a.device());
+    launch_gemm(a.dtype(), trans_a, trans_b, M, N, K, alpha, a.data_ptr(), a.shape(1), b.data_ptr(), b.shape(1), 0.f, out.data_ptr(), N,
+                a.device());
+    return out;
+}
+
+// ---- causal attention (nn_ops.cpp:6-8 + the checks of causal_attention_kernel.cu:9-20) ---------------------
+namespace {
+
+void check_attention(const Tensor &q, const Tensor &k, const Tensor &v) {
+    CHECK_FAIL(q.dim() == 4 && k.dim() == 4 && v.dim() == 4);
+    CHECK_FAIL(k.shape(0) == q.shape(0) && k.shape(1) == q.shape(1) && k.shape(3) == q.shape(3));
+    CHECK_FAIL(k.sizes() == v.sizes());
+    CHECK_FAIL(q.dtype() == k.dtype() && q.dtype() == v.dtype());
+    CHECK_FAIL(q.dtype() == ScalarType::Float || q.dtype() == ScalarType::Half || q.dtype() == ScalarType::BFloat16,
+               "Unsupported ScalarType ", q.dtype());
+    CHECK_FAIL(q.is_contiguous() && k.is_contiguous() && v.is_contiguous());
+    CHECK_FAIL(q.device() == k.device() && q.device() == v.device());
+}
+
+class AttentionGradFunction : public GradFunction {
+public:
+    AttentionGradFunction(const Tensor &q, const Tensor &k, const Tensor &v, const Tensor &out, const Tensor &lse) : out_(out), lse_(lse) {
+        inputs = {q, k, v};
+    }
+    std::vector<Tensor> backward(Tensor g) override {
+        auto [dq, dk, dv] = causal_attention_bwd(inputs[0], inputs[1], inputs[2], out_, lse_, g);
+        return {dq, dk, dv};
+    }
+
+private:
+    Tensor out_, lse_;
+};
+
+} // namespace
+
+std::tuple<Tensor, Tensor> causal_attention_fwd(const Tensor &q, const Tensor &k, const Tensor &v) {
+    check_attention(q, k, v);
+    const int64_t B = q.shape(0), H = q.shape(1), Sq = q.shape(2), D = q.shape(3), Skv = k.shape(2);
+    Tensor out = empty_like(q);
+    Tensor lse = empty({B, H, Sq}, ScalarType::Float, q.device());
+    DEV_CALL(kf_attn_fwd(code(q.dtype()), B, H, Sq, Skv, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                         static_cast<float *>(lse.data_ptr()), dev::stream(q.device())));
+    return {out, lse};
+}
+
+std::tuple<Tensor, Tensor, Tensor> causal_attention_bwd(const Tensor &q, const Tensor &k, const Tensor &v, const Tensor &out,
+                                                        const Tensor &lse, const Tensor &grad_out) {
+    check_attention(q, k, v);
+    CHECK_FAIL(grad_out.sizes() == q.sizes() && grad_out.dtype() == q.dtype());
+    const int64_t B = q.shape(0), H = q.shape(1), Sq = q.shape(2), D = q.shape(3), Skv = k.shape(2);
+    Tensor go = grad_out.contiguous();
+    Tensor dq = empty_like(q), dk = empty_like(k), dv = empty_like(v);
+    size_t need = 0;
+    DEV_CALL(kf_attn_bwd_workspace_bytes(code(q.dtype()), B, H, Sq, Skv, D, &need));
+    DataPtr scratch = DeviceAllocator::GetInstance()->allocate(need, q.device());
+    DEV_CALL(kf_attn_bwd(code(q.dtype()), B, H, Sq, Skv, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
+                         static_cast<const float *>(lse.data_ptr()), go.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                         scratch.get(), need, dev::stream(q.device())));
+    return {dq, dk, dv};
+}
+
+Tensor causal_attention(const Tensor &q, const Tensor &k, const Tensor &v) {
+    auto [out, lse] = causal_attention_fwd(q, k, v);
+    out.set_requires_grad(q.requires_grad() || k.requires_grad() || v.requires_grad());
+    if (out.requires_grad()) out.set_grad_fn(new AttentionGradFunction(q, k, v, out, lse));
+    return out;
+}
+
+// ---- index_put_ (index_ops.cpp:6-38) ----------------------------------------------------------------------------
+Tensor &index_put_(Tensor &self, const std::vector<Tensor> &indices, const Tensor &values) {
+    CHECK_FAIL((int)indices.size() == self.dim(), "Number of indices must match the number of dimensions in the tensor.");
+    CHECK_FAIL(self.defined() && values.defined(), "Both self and values tensors must be defined.");
+    CHECK_FAIL(self.dtype() == values.dtype(), "Data types of self and values tensors must match.");
+    CHECK_FAIL(!indices.empty() && (int)indices.size() <= KF_MAX_TENSORS - 2, "index_put_ supports 1..", KF_MAX_TENSORS - 2, " indexed dims");
+    const int64_t es = self.element_size_in_bytes();
+    std::vector<int64_t> sizes, strides;
+    for (int d = 0; d < self.dim(); ++d) {
+        sizes.push_back(self.shape(d));
+        strides.push_back(self.stride(d) * es);
+        CHECK_FAIL(self.shape(d) != 0, "index is out of bounds for dimension with size 0");
+    }
+    // self, seen through the index shape with stride 0: the kernel adds the gathered byte offset
+    auto ishape = indices[0].sizes();
+    Tensor target = self.as_strided(ishape, std::vector<int64_t>(ishape.size(), 0), self.storage_offset());
+    TensorIterator iter;
+    iter.add_output(target).check_mem_overlap(false).resize_outputs(false);
+    iter.add_input(values);
+    for (auto &ix : indices) {
+        CHECK_FAIL(ix.defined() && ix.dtype() == ScalarType::Long, "Indices must be of type Long.");
+        iter.add_input(ix);
+    }
+    iter.build();
+    if (iter.numel() == 0) return self;
+    void *stream = dev::stream(self.device());
+    iter.geometry().for_each_32bit([&](const IterGeometry &g) {
+        kf_iter_desc d;
+        g.to_desc(d);
+        DEV_CALL(kf_index_put(&d, (int)sizes.size(), sizes.data(), strides.data(), stream));
+    });
+    return self;
+}
+
+// ---- shape ops (tensor_shape.cpp:41-89) ----------------------------------------------------------------------------
+Tensor concat(const std::vector<Tensor> tensors, int64_t dim) {
+    CHECK_FAIL(!tensors.empty(), "concat expects a non-empty list");
+    const Tensor &first = tensors[0];
+    const int d = maybe_wrap_dim((int)dim, first.dim());
+    int64_t total = 0;
+    for (size_t i = 0; i < tensors.size(); ++i) {
+        const Tensor &t = tensors[i];
+        CHECK_FAIL(t.device() == first.device());
+        CHECK_FAIL(t.dim() == first.dim(), "Tensors must have same number of dimensions: got ", first.dim(), " and ", t.dim());
+        for (int k = 0; k < first.dim(); ++k)
+            CHECK_FAIL(k == d || t.shape(k) == first.shape(k), "Sizes of tensors must match except in dimension ", d, ". Expected size ",
+                       first.shape(k), " but got size ", t.shape(k), " for tensor number ", i, " in the list.");
+        total += t.shape(d);
+    }
+    auto out_size = first.sizes();
+    out_size[d] = total;
+    Tensor result = empty(out_size, first.dtype(), first.device());
+    int64_t at = 0;
+    for (const Tensor &t : tensors) {
+        Tensor window = result.narrow(d, at, t.shape(d));
+        window.copy_(t);
+        at += t.shape(d);
+    }
+    return result;
+}
+
+std::vector<Tensor> tensor_split(const Tensor &self, std::vector<int64_t> indices, int64_t dim) {
+    CHECK_FAIL(self.dim() > 0, "tensor_split expected at least a 1-dimensional tensor, but got a tensor with ", self.dim(), " dims");
+    const int d = maybe_wrap_dim((int)dim, self.dim());
+    std::vector<Tensor> parts;
+    int64_t at = 0;
+    for (int64_t len : indices) {
+        parts.push_back(self.slice(d, at, at + len));
+        at += len;
+    }
+    CHECK_FAIL(at == self.shape(d));
+    return parts;
+}
+
+} // namespace gpu

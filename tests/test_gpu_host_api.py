@@ -1,0 +1,259 @@
+"""-m gpu: the Python operator API (`import kfunca_amd as kfunca`) — the cases of the reference's own
+test suite (test/test_tensor.py, test_gemm.py, test_nn.py), re-derived with fixed seeds and checked
+against the golden vectors / the CPU oracle, plus what the reference lacks (GEMM / attention backward)."""
+import copy
+
+import numpy as np
+import pytest
+
+import kfunca_amd as kfunca
+from oracle import oracle as O
+from tests.helpers import assert_close, golden, regen, uni
+
+pytestmark = pytest.mark.gpu
+
+
+def close(a, b, atol=1e-3, rtol=1e-3):  # test/common.py:6-11
+    a = a if isinstance(a, np.ndarray) else a.contiguous().numpy()
+    b = b if isinstance(b, np.ndarray) else b.contiguous().numpy()
+    assert_close(a, b, rtol=rtol, atol=atol)
+
+
+def test_tensor_impl_roundtrip():  # test_tensor.py:10-13
+    rng = np.random.default_rng(1)
+    for dt in (np.float64, np.float32, np.float16, np.int64, np.int32, np.int16, np.int8, np.uint8, np.bool_):
+        arr = (rng.uniform(-10, 10, size=(2, 3)) * 3).astype(dt)
+        t = kfunca.from_numpy(arr, 0)
+        assert t.sizes() == [2, 3] and np.array_equal(t.numpy(), arr)
+    nc = np.arange(24, dtype=np.float32).reshape(4, 6).T  # non-contiguous numpy input is honoured
+    assert np.array_equal(kfunca.from_numpy(nc, 0).numpy(), nc)
+
+
+def test_tensor_add_golden():  # test_tensor.py:15-27
+    g = golden("elementwise")
+    for i in range(3):
+        a = kfunca.from_numpy(g[f"add{i}_a"], 0)
+        assert np.array_equal((a + a).numpy(), g[f"add{i}_out"])
+        out = kfunca.from_numpy(g[f"promo{i}_a"], 0) + kfunca.from_numpy(g[f"promo{i}_b"], 0)
+        assert out.dtype() == kfunca.float and np.array_equal(out.numpy(), g[f"promo{i}_out"])
+    s = golden("shape_ops")
+    t = kfunca.from_numpy(s["int_x"], 0)
+    assert np.array_equal((t + t).numpy(), s["int_out"])  # test/core/test_tensor.cpp:10-23
+
+
+def test_inplace_op_golden():  # test_tensor.py:29-68
+    g = golden("elementwise")
+    a, b = kfunca.from_numpy(g["inpl_a"], 0), kfunca.from_numpy(g["inpl_b"], 0)
+    addr = a.data_ptr()
+    steps = g["inpl_steps"]
+    a += b; assert a.data_ptr() == addr and np.array_equal(a.numpy(), steps[0])
+    a -= b; assert a.data_ptr() == addr and np.array_equal(a.numpy(), steps[1])
+    a *= b; assert a.data_ptr() == addr and np.array_equal(a.numpy(), steps[2])
+    a /= b; assert a.data_ptr() == addr and np.array_equal(a.numpy(), steps[3])
+    a += 2; assert a.data_ptr() == addr and np.array_equal(a.numpy(), steps[4])
+    a -= 3; assert a.data_ptr() == addr and np.array_equal(a.numpy(), steps[5])
+    a *= 4; assert a.data_ptr() == addr and np.array_equal(a.numpy(), steps[6])
+    a /= 5; assert a.data_ptr() == addr and np.array_equal(a.numpy(), steps[7])
+
+
+def test_data_ptr_and_refcounts():  # test_tensor.py:70-84
+    arr = np.random.default_rng(2).uniform(-10, 10, size=(3, 4)).astype(np.float32)
+    x = kfunca.from_numpy(arr, 0)
+    x_ref = kfunca.from_numpy(arr, 0)
+    x_ref = x
+    x_deep = copy.deepcopy(x)
+    assert x.data_ptr() == x_ref.data_ptr() == x_deep.data_ptr()
+    assert x.storage_ref_count() == x_ref.storage_ref_count() == x_deep.storage_ref_count() == 1
+    assert x.impl_ref_count() == x_ref.impl_ref_count() == x_deep.impl_ref_count() == 2
+    del x
+    assert x_deep.impl_ref_count() == 2 and x_ref.impl_ref_count() == 2
+    del x_ref
+    assert x_deep.impl_ref_count() == 1
+    v = x_deep.permute(1, 0)  # a view shares the storage, not the impl
+    assert v.storage_ref_count() == 2 and v.impl_ref_count() == 1 and v.data_ptr() == x_deep.data_ptr()
+
+
+def test_broadcast_binary_golden():  # test_tensor.py:86-108 ('easy' shapes)
+    g = golden("elementwise")
+    for i in range(3):
+        a, b = kfunca.from_numpy(g[f"bc{i}_a"], 0), kfunca.from_numpy(g[f"bc{i}_b"], 0)
+        assert np.array_equal((a + b).numpy(), g[f"bc{i}_add"])
+        assert np.array_equal((a - b).numpy(), g[f"bc{i}_sub"])
+        assert np.array_equal((a * b).numpy(), g[f"bc{i}_mul"])
+        assert np.array_equal((a / b).numpy(), g[f"bc{i}_div"])
+        assert np.array_equal((kfunca.from_numpy(g[f"bc{i}_ai"], 0) * b).numpy(), g[f"bc{i}_imul"])
+
+
+@pytest.mark.slow
+def test_broadcast_binary_hard():  # test_tensor.py:91-92: 2^30 elements, forces the 32-bit split
+    rng = np.random.default_rng(3)
+    small = uni(rng, (2, 1024, 1, 512))
+    big = kfunca.empty([2, 1024, 1024, 512], kfunca.float, 0)
+    big.fill_(1.5)
+    out = big + kfunca.from_numpy(small, 0)
+    assert out.sizes() == [2, 1024, 1024, 512]
+    for (i, j) in ((0, 0), (0, 1023), (1, 512), (1, 1023)):  # windows on both sides of the 2^31-byte boundary
+        got = out[i, j].contiguous().numpy()
+        assert np.array_equal(got, np.broadcast_to(small[i, j] + np.float32(1.5), (1024, 512)))
+    same = big + big
+    assert np.array_equal(same[1, 1000, 17:19].contiguous().numpy(), np.full((2, 512), 3.0, dtype=np.float32))
+
+
+def test_reduce():  # test_tensor.py:110-118 at the reference's shape
+    g = golden("reductions")
+    x = kfunca.from_numpy(g["x"], 0)
+    for dim in range(3):
+        close(x.sum(dim), g[f"sum{dim}"], atol=1e-2, rtol=1e-2)
+        close(x.mean(dim), g[f"mean{dim}"], atol=1e-2, rtol=1e-2)
+        assert x.sum(dim).sizes() == list(g[f"sum{dim}"].shape)  # keepdim
+    rng = np.random.default_rng(4)
+    arr = uni(rng, (223, 23, 3213))
+    t = kfunca.from_numpy(arr, 0)
+    for dim in range(3):
+        close(t.sum(dim), np.sum(arr, axis=dim, keepdims=True), atol=1e-2, rtol=1e-2)
+        close(t.mean(dim), np.mean(arr, axis=dim, keepdims=True), atol=1e-2, rtol=1e-2)
+    a, _ = regen(g["c1_seed"][0], [(1024, 1024), (1024, 1024)], g["c1_sha"])  # BASELINE C1
+    ta = kfunca.from_numpy(a, 0)
+    close(ta.sum(0), g["c1_sum0"], atol=1e-2, rtol=1e-5)
+    close(ta.sum(1), g["c1_sum1"], atol=1e-2, rtol=1e-5)
+
+
+def test_convert():  # test_tensor.py:148-160
+    g = golden("elementwise")
+    t = kfunca.from_numpy(g["cvt_x"], 0)
+    h = t.half()
+    assert np.array_equal(h.numpy().view(np.uint16), g["cvt_half_bits"])
+    h *= h
+    assert np.array_equal(h.float().numpy(), g["cvt_half_sq"])
+    bf = t.bfloat16()
+    bf *= bf
+    assert np.array_equal(bf.float().numpy(), g["cvt_bf16_sq"])
+    t *= t
+    close(t, bf.float(), atol=1e-1, rtol=1e-1)
+
+
+def test_permute_slice_view_cat_split_golden():  # test_tensor.py:162-167, 233-271 — bit-exact
+    s = golden("shape_ops")
+    t = kfunca.from_numpy(s["perm_x"], 0)
+    p = t.permute(2, 1, 0, 3)
+    assert not p.is_contiguous() and p.data_ptr() == t.data_ptr()
+    assert np.array_equal(p.contiguous().numpy(), s["perm_out"])
+    t = kfunca.from_numpy(s["slice_x"], 0)
+    assert np.array_equal(t[3, 3:8, 4:11:2].contiguous().numpy(), s["slice_out"])
+    t = kfunca.from_numpy(s["view_x"], 0)
+    assert np.array_equal((t.view(5, -1, 23).contiguous() + 1).numpy(), s["view_out"])
+    parts = [kfunca.from_numpy(s[f"cat_{k}"], 0) for k in "abc"]
+    assert np.array_equal(kfunca.cat(parts, 1).numpy(), s["cat_out"])
+    t = kfunca.from_numpy(s["split_x"], 0)
+    for i, part in enumerate(t.split([11, 13, 1], 1)):
+        assert np.array_equal(part.contiguous().numpy(), s[f"split_{i}"])
+    with pytest.raises(RuntimeError):
+        t.split([11, 13], 1)  # sizes must cover the dim (tensor_shape.cpp:87)
+    with pytest.raises(RuntimeError):
+        t.permute(0, 0, 1)
+
+
+def test_index_put_golden():  # test_tensor.py:273-284
+    s = golden("shape_ops")
+    t = kfunca.from_numpy(s["iput_x"], 0)
+    idx = [kfunca.from_numpy(s["iput_i0"].astype("q"), 0), kfunca.from_numpy(s["iput_i1"].astype("q"), 0)]
+    t.index_put_(idx, kfunca.from_numpy(s["iput_v"], 0))
+    assert np.array_equal(t.numpy(), s["iput_out"])
+    t = kfunca.from_numpy(s["iput3_x"], 0)
+    idx = [kfunca.from_numpy(s[f"iput3_i{k}"], 0) for k in range(3)]
+    t.index_put_(idx, kfunca.from_numpy(s["iput3_v"], 0))
+    assert np.array_equal(t.numpy(), s["iput3_out"])
+    with pytest.raises(RuntimeError, match="Long"):
+        t.index_put_([kfunca.from_numpy(np.zeros((2, 2), dtype=np.int32), 0)] * 3, kfunca.from_numpy(s["iput3_v"], 0))
+
+
+def test_basic_backward_add_dag():  # test_tensor.py:286-309
+    s = golden("shape_ops")
+    rng = np.random.default_rng(5)
+    grad = kfunca.from_numpy(s["ag_grad"], 0)
+    a, b, c = (kfunca.from_numpy(uni(rng, (2, 3)), 0) for _ in range(3))
+    a.set_requires_grad(True)
+    b.set_requires_grad(True)
+    ca = c + a
+    ab = a + b
+    accb = ca + ab
+    accba = accb + a
+    accba.backward(grad)
+    close(a.grad(), s["ag_a_grad"])
+    close(b.grad(), s["ag_b_grad"])
+    assert not c.grad().defined()
+
+
+def test_gemm_golden_and_backward():  # test_gemm.py:9-17 + backward (no reference counterpart)
+    g = golden("gemm")
+    a, b = regen(g["f64_seed"][0], [(123, 457), (457, 234)], g["f64_sha"], dtype=np.float64)
+    out = kfunca.gemm(kfunca.from_numpy(a, 0), kfunca.from_numpy(b, 0), 1.0, 0.0)
+    close(out, g["f64_out"])
+    ta, tb = kfunca.from_numpy(g["f32_a"], 0), kfunca.from_numpy(g["f32_b"], 0)
+    ta.set_requires_grad(True)
+    tb.set_requires_grad(True)
+    c = kfunca.gemm(ta, tb, 1.0, 0.0)
+    close(c, g["f32_out"], atol=1e-4, rtol=1e-4)
+    c.backward(kfunca.from_numpy(g["f32_g"], 0))
+    close(ta.grad(), g["f32_da"], atol=1e-4, rtol=1e-4)
+    close(tb.grad(), g["f32_db"], atol=1e-4, rtol=1e-4)
+    # leading dims of A flatten into M (gemm_kernel.cu:10-15)
+    a3 = kfunca.from_numpy(g["f32_a"].reshape(4, 32, 64), 0)
+    c3 = kfunca.gemm(a3, tb, 1.0, 0.0)
+    assert c3.sizes() == [4, 32, 256]
+    close(c3, g["f32_out"].reshape(4, 32, 256), atol=1e-4, rtol=1e-4)
+    with pytest.raises(RuntimeError):
+        kfunca.gemm(ta, kfunca.from_numpy(g["f32_a"], 0), 1.0, 0.0)  # K mismatch
+    with pytest.raises(RuntimeError):
+        kfunca.gemm(ta.permute(1, 0), tb, 1.0, 0.0)  # operands must be contiguous
+
+
+def test_causal_attention_golden_and_backward():  # test_nn.py:11-33 + backward
+    g = golden("attention")
+    for i in range(3):
+        B, H, Sq, Skv, D = (int(x) for x in g[f"fwd{i}_dims"])
+        q, k, v = regen(1050 + i, [(B, H, Sq, D), (B, H, Skv, D), (B, H, Skv, D)], g[f"fwd{i}_sha"])
+        out = kfunca.causal_attention(*(kfunca.from_numpy(x, 0) for x in (q, k, v))).numpy()
+        close(out, g[f"fwd{i}_out"])
+    for i in range(3):
+        B, H, Sq, Skv, D = (int(x) for x in g[f"bwd{i}_dims"])
+        q, k, v, go = regen(1060 + i, [(B, H, Sq, D), (B, H, Skv, D), (B, H, Skv, D), (B, H, Sq, D)], g[f"bwd{i}_sha"], lo=-1, hi=1)
+        tq, tk, tv = (kfunca.from_numpy(x, 0) for x in (q, k, v))
+        for t in (tq, tk, tv):
+            t.set_requires_grad(True)
+        out = kfunca.causal_attention(tq, tk, tv)
+        out.backward(kfunca.from_numpy(go, 0))
+        close(tq.grad(), g[f"bwd{i}_dq"], atol=1e-5, rtol=1e-4)
+        close(tk.grad(), g[f"bwd{i}_dk"], atol=1e-5, rtol=1e-4)
+        close(tv.grad(), g[f"bwd{i}_dv"], atol=1e-5, rtol=1e-4)
+    # bf16 MFMA path through the operator API (tolerance: tests/test_gpu_attention.py header)
+    rng = np.random.default_rng(6)
+    q, k, v, go = (rng.uniform(-1, 1, (1, 2, 256, 128)).astype(np.float32) for _ in range(4))
+    tq, tk, tv = (kfunca.from_numpy(x, 0).bfloat16() for x in (q, k, v))
+    for t in (tq, tk, tv):
+        t.set_requires_grad(True)
+    out = kfunca.causal_attention(tq, tk, tv)
+    out.backward(kfunca.from_numpy(go, 0).bfloat16())
+    qb, kb, vb, gb = (O.f32_to_bf16(x) for x in (q, k, v, go))
+    o_ref, _ = O.attn_fwd(qb, kb, vb, code=O.BF16)
+    close(out.float(), O.bf16_to_f32(o_ref), atol=2e-2, rtol=2e-2)
+    for t, ref in zip((tq, tk, tv), O.attn_bwd(qb, kb, vb, gb, code=O.BF16)):
+        close(t.grad().float(), O.bf16_to_f32(ref), atol=3e-2, rtol=2e-2)
+
+
+def test_allocator_reuse_and_scope():
+    base = kfunca.memstat_dict(0)
+    t = kfunca.empty([1 << 20], kfunca.float, 0)
+    p = t.data_ptr()
+    del t
+    t2 = kfunca.empty([1 << 20], kfunca.float, 0)  # best-fit reuse of the cached 4 MiB block
+    assert t2.data_ptr() == p
+    st = kfunca.memstat_dict(0)
+    assert st["driver_allocs"] <= base["driver_allocs"] + 1
+    z = kfunca.zeros([7, 5], kfunca.int, 0)
+    assert not z.numpy().any()
+    for call in (lambda: z.sort(0, False), lambda: z.topk(1, 0, True), lambda: z.norm_stat(0), lambda: z.mean_var(0, False)):
+        with pytest.raises(RuntimeError, match="outside the tensor-kernel hot path"):
+            call()
+    assert "tensor(shape=[7,5]" in repr(z)
+    assert z.item([1, 2]) == 0
