@@ -23,6 +23,7 @@
 //  * generic path (f32 — the reference's own dtype — or any ragged shape/head size <= 256):
 //    LDS-tiled f32 online-softmax kernel; backward by two LDS-tiled f32 kernels.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -266,6 +267,173 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// forward, v2: 8 waves x 32 query rows (256-row Q block, two waves per SIMD so one wave's softmax
+// overlaps its partner's MFMAs), K/V tiles of 64 keys double-buffered in LDS with ONE barrier per
+// tile (register-staged: global loads of tile t+2 are in flight across PV(t) and QK/softmax(t+1),
+// the LDS write of tile t+1 sits between QK(t) and PV(t)), mask code only on the diagonal tile,
+// scale folded into the exponent's FMA, every LDS address a loop-invariant VGPR + immediate.
+// ------------------------------------------------------------------------------------------
+constexpr int FQ = 256;                 // queries per block
+constexpr int FNT = 512;                // threads per block
+constexpr int FTILE = ABK * AROW;       // bytes of one K or V tile (16 KiB)
+constexpr int FBUF = 2 * FTILE;         // one double-buffer half: K tile | V tile
+
+// per-lane byte offset (relative to the tile, for a 16-row-aligned r0) of the two transposed reads
+__device__ __forceinline__ int a_tr_lane_off(int col0, int second) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, i = lane & 15, qq = i >> 2, p = i & 3, h = g >> 1;
+    const int ch = ((col0 + 16 * (g & 1)) >> 3) + (p >> 1);
+    return a_off(4 * h + qq + 8 * second, ch) + 8 * (p & 1);
+}
+
+template <bool BF>
+__device__ __forceinline__ typename AFrag<BF>::type a_tr_frag2(const char *p0, const char *p1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p1);
+    s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(typename AFrag<BF>::type, r);
+}
+
+struct StageKV { uint4 k0, k1, v0, v1; };
+__device__ __forceinline__ void f_gload(const char *kg, const char *vg, StageKV &r) { // 512 threads x 2 chunks per operand
+    const int t = threadIdx.x;
+    r.k0 = a_gld(kg, t); r.k1 = a_gld(kg, t + FNT);
+    r.v0 = a_gld(vg, t); r.v1 = a_gld(vg, t + FNT);
+}
+__device__ __forceinline__ void f_lstore(char *buf, const StageKV &r) {
+    const int t = threadIdx.x;
+    a_lst(buf, t, r.k0); a_lst(buf, t + FNT, r.k1);
+    a_lst(buf + FTILE, t, r.v0); a_lst(buf + FTILE, t + FNT, r.v1);
+}
+
+template <bool BF, bool MASK>
+__device__ __forceinline__ void f_tile(const char *buf, const typename AFrag<BF>::type (&qf)[8], const int (&ko)[8], const int (&vo)[4][2],
+                                       f32x16 (&o)[4], float &m_i, float &l_i, float c, int64_t kv0, int64_t m, int hl) {
+    using frag_t = typename AFrag<BF>::type;
+    f32x16 s[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+            s[sub] = a_mfma<BF>(*(const frag_t *)(buf + sub * 32 * AROW + ko[kk]), qf[kk], s[sub]);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (MASK && kv0 + sub * 32 + a_row(e, hl) > m) s[sub][e] = -INFINITY;
+            mx = fmaxf(mx, s[sub][e]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_i, mx);
+    const float mc = m_new * c;
+    const float alpha = __builtin_amdgcn_exp2f(m_i * c - mc);
+    float rs = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][e], c, -mc));
+            s[sub][e] = p;
+            rs += p;
+        }
+    rs += __shfl_xor(rs, 32, 64);
+    l_i = l_i * alpha + rs;
+    m_i = m_new;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+    const char *vt = buf + FTILE;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const frag_t pf = a_pack<BF>(s[sub], s2);
+            const int roff = (sub * 32 + s2 * 16) * AROW;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(a_tr_frag2<BF>(vt + roff + vo[d][0], vt + roff + vo[d][1]), pf, o[d]);
+        }
+}
+
+template <bool BF>
+__global__ __launch_bounds__(FNT, 2) void attn_fwd_v2_kernel(const AttnArgs a) {
+    using frag_t = typename AFrag<BF>::type;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
+    const int qblk = gridDim.x - 1 - blockIdx.x; // longest blocks first
+    const int64_t bh = blockIdx.y;
+    const int64_t q0 = (int64_t)qblk * FQ, qw = q0 + wid * 32, m = qw + xl;
+    const bool active = qw < a.Sq; // the last block may be partial (Sq % 256 != 0): idle waves still stage and sync
+    const char *Kg = a.k + bh * a.Skv * AROW;
+    const char *Vg = a.v + bh * a.Skv * AROW;
+
+    frag_t qf[8];
+    if (active) {
+        const char *Qg = a.q + (bh * a.Sq + m) * AROW;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const frag_t *)(Qg + (kk * 16 + 8 * hl) * 2);
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[kk][j] = 0;
+    }
+    int ko[8], vo[4][2];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) ko[kk] = a_off(xl, kk * 2 + hl);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        vo[d][0] = a_tr_lane_off(d * 32, 0);
+        vo[d][1] = a_tr_lane_off(d * 32, 1);
+    }
+
+    f32x16 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+    float m_i = -INFINITY, l_i = 0.f;
+    const float c = a.scale * kLog2e;
+
+    const int64_t q_end = q0 + FQ < a.Sq ? q0 + FQ : a.Sq;
+    const int64_t kv_end = a.Skv < q_end ? a.Skv : q_end;
+    const int nt = (int)((kv_end + ABK - 1) / ABK);
+    StageKV st;
+    f_gload(Kg, Vg, st);
+    f_lstore(smem, st);
+    if (nt > 1) f_gload(Kg + (int64_t)ABK * AROW, Vg + (int64_t)ABK * AROW, st);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int64_t kv0 = (int64_t)t * ABK;
+        const char *cur = smem + (t & 1) * FBUF;
+        char *nxt = smem + ((t + 1) & 1) * FBUF;
+        // this wave's relation to the tile: entirely visible, on the diagonal, or entirely masked
+        const bool skip = !active || kv0 > qw + 31;
+        const bool diag = kv0 + ABK - 1 > qw;
+        if (!skip) {
+            if (diag) f_tile<BF, true>(cur, qf, ko, vo, o, m_i, l_i, c, kv0, m, hl);
+            else f_tile<BF, false>(cur, qf, ko, vo, o, m_i, l_i, c, kv0, m, hl);
+        }
+        if (t + 1 < nt) {
+            f_lstore(nxt, st); // tile t+1 (loaded one iteration ago) -> the buffer everyone finished reading at the last barrier
+            if (t + 2 < nt) f_gload(Kg + (kv0 + 2 * ABK) * AROW, Vg + (kv0 + 2 * ABK) * AROW, st);
+        }
+        __syncthreads();
+    }
+    // K/V buffers are dead: reuse LDS as per-wave output slabs (8 x 32 x OPAD bytes)
+    if (active) {
+        a_store_rows<BF>(smem + wid * 32 * OPAD, a.out + (bh * a.Sq + qw) * AROW, o, 1.f / l_i);
+        if (a.lse && hl == 0) a.lse[bh * a.Sq + m] = (m_i * c + __builtin_amdgcn_logf(l_i)) * kLn2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward pre-pass: delta[q] = sum_d dO[q][d] * O[q][d]   (16 lanes per row, 16-B loads)
 // ------------------------------------------------------------------------------------------
 template <bool BF>
@@ -371,6 +539,128 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
     }
     __syncthreads();
     a_store_rows<BF>(smem + wid * 32 * OPAD, a.dq + (bh * a.Sq + qw) * AROW, dq, a.scale);
+}
+
+// ------------------------------------------------------------------------------------------
+// backward: dQ, v2 — the forward-v2 skeleton (8 waves x 32 queries, two waves per SIMD, K/V tiles
+// double-buffered, one barrier per tile). Per 32-key sub-tile: S^T = K Q^T, dP^T = V dO^T,
+// dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T (K^T through transposed reads of the same K image).
+// ------------------------------------------------------------------------------------------
+template <bool BF, bool MASK>
+__device__ __forceinline__ void q_tile(const char *buf, const char *doslab, const typename AFrag<BF>::type (&qf)[8], const int (&ko)[8],
+                                       const int (&vo)[4][2], f32x16 (&dq)[4], float c, float lse2, float dlt, int64_t kv0, int64_t m, int hl) {
+    using frag_t = typename AFrag<BF>::type;
+    const char *vt = buf + FTILE;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+        // groups of four k-steps fenced for the scheduler: hoisting every fragment load of the tile to the
+        // top costs > 90 VGPRs and spills at two waves per SIMD; the partner wave hides the LDS latency instead
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+#pragma unroll
+            for (int kk = 4 * kg; kk < 4 * kg + 4; ++kk) s = a_mfma<BF>(*(const frag_t *)(buf + sub * 32 * AROW + ko[kk]), qf[kk], s);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+#pragma unroll
+            for (int kk = 4 * kg; kk < 4 * kg + 4; ++kk)
+                dp = a_mfma<BF>(*(const frag_t *)(vt + sub * 32 * AROW + ko[kk]), *(const frag_t *)(doslab + ko[kk]), dp);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], c, -lse2));
+            if (MASK && kv0 + sub * 32 + a_row(e, hl) > m) p = 0.f;
+            s[e] = p * (dp[e] - dlt);
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const frag_t df = a_pack<BF>(s, s2);
+            const int roff = (sub * 32 + s2 * 16) * AROW;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) dq[d] = a_mfma<BF>(a_tr_frag2<BF>(buf + roff + vo[d][0], buf + roff + vo[d][1]), df, dq[d]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+constexpr int QSLAB = 32 * AROW;                 // one wave's dO rows (8 KiB)
+constexpr int QLDS = 2 * FBUF + 8 * QSLAB;       // K/V double buffer + 8 dO slabs = 128 KiB
+
+template <bool BF>
+__global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a) {
+    using frag_t = typename AFrag<BF>::type;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
+    const int qblk = gridDim.x - 1 - blockIdx.x;
+    const int64_t bh = blockIdx.y;
+    const int64_t q0 = (int64_t)qblk * FQ, qw = q0 + wid * 32, m = qw + xl;
+    const bool active = qw < a.Sq;
+    const char *Kg = a.k + bh * a.Skv * AROW;
+    const char *Vg = a.v + bh * a.Skv * AROW;
+    char *doslab = smem + 2 * FBUF + wid * QSLAB; // this wave's dO rows, same swizzled image as a K tile (B operand of dP^T)
+
+    frag_t qf[8];
+    float lse2 = 0.f, dlt = 0.f;
+    if (active) {
+        const char *Qg = a.q + (bh * a.Sq + m) * AROW;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const frag_t *)(Qg + (kk * 16 + 8 * hl) * 2);
+        const char *dOw = a.d_o + (bh * a.Sq + qw) * AROW;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a_lst(doslab, lane + 64 * i, a_gld(dOw, lane + 64 * i));
+        lse2 = a.lse_r[bh * a.Sq + m] * kLog2e;
+        dlt = a.delta[bh * a.Sq + m];
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[kk][j] = 0;
+    }
+    int ko[8], vo[4][2];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) ko[kk] = a_off(xl, kk * 2 + hl);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        vo[d][0] = a_tr_lane_off(d * 32, 0);
+        vo[d][1] = a_tr_lane_off(d * 32, 1);
+    }
+    f32x16 dq[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dq[d][e] = 0.f;
+    const float c = a.scale * kLog2e;
+
+    const int64_t q_end = q0 + FQ < a.Sq ? q0 + FQ : a.Sq;
+    const int64_t kv_end = a.Skv < q_end ? a.Skv : q_end;
+    const int nt = (int)((kv_end + ABK - 1) / ABK);
+    StageKV st;
+    f_gload(Kg, Vg, st);
+    f_lstore(smem, st);
+    if (nt > 1) f_gload(Kg + (int64_t)ABK * AROW, Vg + (int64_t)ABK * AROW, st);
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int64_t kv0 = (int64_t)t * ABK;
+        const char *cur = smem + (t & 1) * FBUF;
+        char *nxt = smem + ((t + 1) & 1) * FBUF;
+        const bool skip = !active || kv0 > qw + 31;
+        const bool diag = kv0 + ABK - 1 > qw;
+        if (!skip) {
+            if (diag) q_tile<BF, true>(cur, doslab, qf, ko, vo, dq, c, lse2, dlt, kv0, m, hl);
+            else q_tile<BF, false>(cur, doslab, qf, ko, vo, dq, c, lse2, dlt, kv0, m, hl);
+        }
+        if (t + 1 < nt) {
+            f_lstore(nxt, st);
+            if (t + 2 < nt) f_gload(Kg + (kv0 + 2 * ABK) * AROW, Vg + (kv0 + 2 * ABK) * AROW, st);
+        }
+        __syncthreads();
+    }
+    if (active) a_store_rows<BF>(smem + wid * 32 * OPAD, a.dq + (bh * a.Sq + qw) * AROW, dq, a.scale);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -735,18 +1025,25 @@ extern "C" int kf_attn_fwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
     a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.D = D;
     a.scale = 1.0f / sqrtf((float)D);
     if (mfma_ok(dtype, Sq, Skv, D)) {
-        const size_t lds = 4 * 32 * OPAD; // >= 2 * ABK * AROW
-        dim3 grid((unsigned)(Sq / ABQ), (unsigned)(B * H));
-        KF_PROF("attn_fwd_mfma", st);
-        if (dtype == KF_BF16) {
-            rc = set_lds(attn_fwd_mfma_kernel<true>, lds);
-            if (rc != KF_OK) return rc;
-            attn_fwd_mfma_kernel<true><<<grid, 256, lds, st>>>(a);
-        } else {
-            rc = set_lds(attn_fwd_mfma_kernel<false>, lds);
-            if (rc != KF_OK) return rc;
-            attn_fwd_mfma_kernel<false><<<grid, 256, lds, st>>>(a);
+        const bool use_v1 = getenv("KF_ATTN_FWD_V1") != nullptr; // A/B switch for the first-generation kernel
+        if (use_v1) {
+            const size_t lds = 4 * 32 * OPAD; // >= 2 * ABK * AROW
+            dim3 grid((unsigned)(Sq / ABQ), (unsigned)(B * H));
+            KF_PROF("attn_fwd_mfma_v1", st);
+            if ((rc = set_lds(attn_fwd_mfma_kernel<true>, lds)) != KF_OK) return rc;
+            if ((rc = set_lds(attn_fwd_mfma_kernel<false>, lds)) != KF_OK) return rc;
+            if (dtype == KF_BF16) attn_fwd_mfma_kernel<true><<<grid, 256, lds, st>>>(a);
+            else attn_fwd_mfma_kernel<false><<<grid, 256, lds, st>>>(a);
+            KF_LAUNCH_CHECK();
+            return KF_OK;
         }
+        const size_t lds = 8 * 32 * OPAD; // >= 2 * FBUF
+        dim3 grid((unsigned)((Sq + FQ - 1) / FQ), (unsigned)(B * H));
+        KF_PROF("attn_fwd_mfma", st);
+        if ((rc = set_lds(attn_fwd_v2_kernel<true>, lds)) != KF_OK) return rc;
+        if ((rc = set_lds(attn_fwd_v2_kernel<false>, lds)) != KF_OK) return rc;
+        if (dtype == KF_BF16) attn_fwd_v2_kernel<true><<<grid, FNT, lds, st>>>(a);
+        else attn_fwd_v2_kernel<false><<<grid, FNT, lds, st>>>(a);
         KF_LAUNCH_CHECK();
         return KF_OK;
     }
@@ -824,10 +1121,19 @@ extern "C" int kf_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
             else attn_bwd_dkv_kernel<false><<<gk, 256, lds, st>>>(a);
             KF_LAUNCH_CHECK();
         }
-        {
-            KF_PROF("attn_bwd_dq_mfma", st);
+        if (getenv("KF_ATTN_DQ_V1")) { // A/B switch for the first-generation kernel
+            KF_PROF("attn_bwd_dq_mfma_v1", st);
             if (bf) attn_bwd_dq_kernel<true><<<gq, 256, lds, st>>>(a);
             else attn_bwd_dq_kernel<false><<<gq, 256, lds, st>>>(a);
+            KF_LAUNCH_CHECK();
+        } else {
+            const size_t lds2 = QLDS;
+            dim3 gq2((unsigned)((Sq + FQ - 1) / FQ), (unsigned)(B * H));
+            if ((rc = set_lds(attn_bwd_dq_v2_kernel<true>, lds2)) != KF_OK) return rc;
+            if ((rc = set_lds(attn_bwd_dq_v2_kernel<false>, lds2)) != KF_OK) return rc;
+            KF_PROF("attn_bwd_dq_mfma", st);
+            if (bf) attn_bwd_dq_v2_kernel<true><<<gq2, FNT, lds2, st>>>(a);
+            else attn_bwd_dq_v2_kernel<false><<<gq2, FNT, lds2, st>>>(a);
             KF_LAUNCH_CHECK();
         }
         return KF_OK;
