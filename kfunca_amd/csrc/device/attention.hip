@@ -308,6 +308,21 @@ __device__ __forceinline__ void f_lstore(char *buf, const StageKV &r) {
     a_lst(buf + FTILE, t, r.v0); a_lst(buf + FTILE, t + FNT, r.v1);
 }
 
+// LDS-DMA staging of one 64-key K tile and V tile (global_load_lds_dwordx4): 16 + 16 wave-instructions of
+// 1 KiB (4 rows), two of each per wave; the tile image's XOR swizzle goes on the per-lane SOURCE chunk.
+__device__ __forceinline__ void f_stage(const char *kg, const char *vg, char *buf) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row0 = (wid * 2 + i) * 4, row = row0 + (lane >> 4), pos = lane & 15;
+        const int chunk = pos ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kg + row * AROW + chunk * 16),
+                                         (__attribute__((address_space(3))) void *)(buf + row0 * AROW), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vg + row * AROW + chunk * 16),
+                                         (__attribute__((address_space(3))) void *)(buf + FTILE + row0 * AROW), 16, 0, 0);
+    }
+}
+
 template <bool BF, bool MASK>
 __device__ __forceinline__ void f_tile(const char *buf, const typename AFrag<BF>::type (&qf)[8], const int (&ko)[8], const int (&vo)[4][2],
                                        f32x16 (&o)[4], float &m_i, float &l_i, float c, int64_t kv0, int64_t m, int hl) {
@@ -404,25 +419,20 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v2_kernel(const AttnArgs a) {
     const int64_t q_end = q0 + FQ < a.Sq ? q0 + FQ : a.Sq;
     const int64_t kv_end = a.Skv < q_end ? a.Skv : q_end;
     const int nt = (int)((kv_end + ABK - 1) / ABK);
-    StageKV st;
-    f_gload(Kg, Vg, st);
-    f_lstore(smem, st);
-    if (nt > 1) f_gload(Kg + (int64_t)ABK * AROW, Vg + (int64_t)ABK * AROW, st);
-    __syncthreads();
+    f_stage(Kg, Vg, smem);
+    __syncthreads(); // s_waitcnt vmcnt(0) for the LDS-DMA in flight, then s_barrier
     for (int t = 0; t < nt; ++t) {
         const int64_t kv0 = (int64_t)t * ABK;
         const char *cur = smem + (t & 1) * FBUF;
         char *nxt = smem + ((t + 1) & 1) * FBUF;
+        // tile t+1 streams into the buffer everyone finished reading at the last barrier while tile t is consumed
+        if (t + 1 < nt) f_stage(Kg + (kv0 + ABK) * AROW, Vg + (kv0 + ABK) * AROW, nxt);
         // this wave's relation to the tile: entirely visible, on the diagonal, or entirely masked
         const bool skip = !active || kv0 > qw + 31;
         const bool diag = kv0 + ABK - 1 > qw;
         if (!skip) {
             if (diag) f_tile<BF, true>(cur, qf, ko, vo, o, m_i, l_i, c, kv0, m, hl);
             else f_tile<BF, false>(cur, qf, ko, vo, o, m_i, l_i, c, kv0, m, hl);
-        }
-        if (t + 1 < nt) {
-            f_lstore(nxt, st); // tile t+1 (loaded one iteration ago) -> the buffer everyone finished reading at the last barrier
-            if (t + 2 < nt) f_gload(Kg + (kv0 + 2 * ABK) * AROW, Vg + (kv0 + 2 * ABK) * AROW, st);
         }
         __syncthreads();
     }
@@ -639,24 +649,18 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a
     const int64_t q_end = q0 + FQ < a.Sq ? q0 + FQ : a.Sq;
     const int64_t kv_end = a.Skv < q_end ? a.Skv : q_end;
     const int nt = (int)((kv_end + ABK - 1) / ABK);
-    StageKV st;
-    f_gload(Kg, Vg, st);
-    f_lstore(smem, st);
-    if (nt > 1) f_gload(Kg + (int64_t)ABK * AROW, Vg + (int64_t)ABK * AROW, st);
+    f_stage(Kg, Vg, smem);
     __syncthreads();
     for (int t = 0; t < nt; ++t) {
         const int64_t kv0 = (int64_t)t * ABK;
         const char *cur = smem + (t & 1) * FBUF;
         char *nxt = smem + ((t + 1) & 1) * FBUF;
+        if (t + 1 < nt) f_stage(Kg + (kv0 + ABK) * AROW, Vg + (kv0 + ABK) * AROW, nxt);
         const bool skip = !active || kv0 > qw + 31;
         const bool diag = kv0 + ABK - 1 > qw;
         if (!skip) {
             if (diag) q_tile<BF, true>(cur, doslab, qf, ko, vo, dq, c, lse2, dlt, kv0, m, hl);
             else q_tile<BF, false>(cur, doslab, qf, ko, vo, dq, c, lse2, dlt, kv0, m, hl);
-        }
-        if (t + 1 < nt) {
-            f_lstore(nxt, st);
-            if (t + 2 < nt) f_gload(Kg + (kv0 + 2 * ABK) * AROW, Vg + (kv0 + 2 * ABK) * AROW, st);
         }
         __syncthreads();
     }
@@ -753,6 +757,151 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
     // slabs: 4 waves x 32 rows x OPAD bytes (needs 33792 B of LDS)
     a_store_rows<BF>(smem + wid * 32 * OPAD, a.dv + (bh * a.Skv + kw) * AROW, dv, 1.f);
     a_store_rows<BF>(smem + wid * 32 * OPAD, a.dk + (bh * a.Skv + kw) * AROW, dk, a.scale);
+}
+
+// ------------------------------------------------------------------------------------------
+// backward: dK, dV, v2 — 8 waves x 32 keys (256-key block), two waves per SIMD. Q / dO slices of 32
+// queries are double-buffered in LDS with one barrier per slice; K fragments live in registers, V
+// fragments in a per-wave LDS slab (the accumulators already take 128 registers); mask code only on
+// the diagonal slice; scheduler fences keep fragment prefetch from spilling.
+// ------------------------------------------------------------------------------------------
+constexpr int KVB = 256;                          // keys per block
+constexpr int KSL = 2 * BQS * AROW + 256;         // one slice buffer: Q tile | dO tile | lse2[32] | delta[32]
+constexpr int KLDS = 2 * KSL + 8 * QSLAB;         // + 8 per-wave V slabs
+static_assert(KLDS >= 8 * 32 * OPAD, "epilogue slabs must fit");
+
+template <bool BF, bool MASK>
+__device__ __forceinline__ void kv_slice(const char *buf, const char *vslab, const typename AFrag<BF>::type (&kf)[8], const int (&ko)[8],
+                                         const int (&vo)[4][2], f32x16 (&dk)[4], f32x16 (&dv)[4], float c, int64_t qs, int64_t n, int hl) {
+    using frag_t = typename AFrag<BF>::type;
+    const char *qt = buf, *dot = buf + BQS * AROW;
+    const float *lse_s = (const float *)(buf + 2 * BQS * AROW), *dlt_s = lse_s + BQS;
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) { // fenced pairs of k-steps: bounds the fragments in flight (register budget: 256 at 2 waves/SIMD)
+#pragma unroll
+        for (int kk = 2 * kg; kk < 2 * kg + 2; ++kk) s = a_mfma<BF>(*(const frag_t *)(qt + ko[kk]), kf[kk], s);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg) {
+#pragma unroll
+        for (int kk = 2 * kg; kk < 2 * kg + 2; ++kk) dp = a_mfma<BF>(*(const frag_t *)(dot + ko[kk]), *(const frag_t *)(vslab + ko[kk]), dp);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) { // accumulator rows 8*g4 + 4*hl + {0..3}: one float4 of lse / delta each
+        const float4 l4 = *(const float4 *)(lse_s + 8 * g4 + 4 * hl);
+        const float4 d4 = *(const float4 *)(dlt_s + 8 * g4 + 4 * hl);
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = 4 * g4 + j;
+            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], c, -lv[j] * kLog2e));
+            if (MASK && n > qs + 8 * g4 + 4 * hl + j) p = 0.f;
+            s[e] = p;
+            dp[e] = p * (dp[e] - dvv[j]);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const frag_t pf = a_pack<BF>(s, s2), df = a_pack<BF>(dp, s2);
+        const int roff = s2 * 16 * AROW;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) dv[d] = a_mfma<BF>(a_tr_frag2<BF>(dot + roff + vo[d][0], dot + roff + vo[d][1]), pf, dv[d]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) dk[d] = a_mfma<BF>(a_tr_frag2<BF>(qt + roff + vo[d][0], qt + roff + vo[d][1]), df, dk[d]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <bool BF>
+__global__ __launch_bounds__(FNT, 2) void attn_bwd_dkv_v2_kernel(const AttnArgs a) {
+    using frag_t = typename AFrag<BF>::type;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
+    const int64_t bh = blockIdx.y;
+    const int64_t k0 = (int64_t)blockIdx.x * KVB, kw = k0 + wid * 32, n = kw + xl;
+    const bool active = kw < a.Skv;
+    const char *Qg = a.q + bh * a.Sq * AROW;
+    const char *dOg = a.d_o + bh * a.Sq * AROW;
+    const float *lse_g = a.lse_r + bh * a.Sq, *dlt_g = a.delta + bh * a.Sq;
+    char *vslab = smem + 2 * KSL + wid * QSLAB;
+
+    frag_t kf[8];
+    if (active) {
+        const char *Kg = a.k + (bh * a.Skv + n) * AROW;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) kf[kk] = *(const frag_t *)(Kg + (kk * 16 + 8 * hl) * 2);
+        const char *Vw = a.v + (bh * a.Skv + kw) * AROW;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a_lst(vslab, lane + 64 * i, a_gld(Vw, lane + 64 * i));
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kf[kk][j] = 0;
+    }
+    int ko[8], vo[4][2];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) ko[kk] = a_off(xl, kk * 2 + hl);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        vo[d][0] = a_tr_lane_off(d * 32, 0);
+        vo[d][1] = a_tr_lane_off(d * 32, 1);
+    }
+    f32x16 dk[4], dv[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk[d][e] = 0.f; dv[d][e] = 0.f; }
+    const float c = a.scale * kLog2e;
+
+    // staging by LDS-DMA (global_load_lds, no staging registers): a slice is 32 rows x 256 B of Q and of
+    // dO = 8 + 8 wave-instructions of 1 KiB, one of each per wave. The LDS destination is lane-linear,
+    // so the XOR swizzle of the tile image is applied to the per-lane SOURCE chunk. Wave 0 also fetches
+    // lse[32] | delta[32] with one 4-byte-per-lane instruction.
+    const int srow = wid * 4 + (lane >> 4), spos = lane & 15;
+    const int schunk = spos ^ (((srow & 3) << 2) | ((srow >> 2) & 3));
+    auto stage = [&](int sl_, char *buf) {
+        const int64_t qs_ = (int64_t)sl_ * BQS;
+        const char *qsrc = Qg + (qs_ + srow) * AROW + schunk * 16;
+        const char *osrc = dOg + (qs_ + srow) * AROW + schunk * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)qsrc,
+                                         (__attribute__((address_space(3))) void *)(buf + wid * 4 * AROW), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)osrc,
+                                         (__attribute__((address_space(3))) void *)(buf + BQS * AROW + wid * 4 * AROW), 16, 0, 0);
+        if (wid == 0) {
+            const float *src = lane < BQS ? lse_g + qs_ + lane : dlt_g + qs_ + lane - BQS;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(buf + 2 * BQS * AROW), 4, 0, 0);
+        }
+    };
+    const int ns = (int)(a.Sq / BQS);
+    int sl = (int)(k0 / BQS); // first slice holding a query >= the block's first key
+    if (sl < ns) stage(sl, smem);
+    __syncthreads(); // waits for the LDS-DMA (vmcnt) and the V slab writes
+    for (int it = 0; sl < ns; ++sl, ++it) {
+        const int64_t qs = (int64_t)sl * BQS;
+        const char *cur = smem + (it & 1) * KSL;
+        char *nxt = smem + ((it + 1) & 1) * KSL;
+        if (sl + 1 < ns) stage(sl + 1, nxt); // the buffer every wave finished reading at the last barrier
+        const bool skip = !active || qs + BQS - 1 < kw; // every query of the slice precedes this wave's keys
+        const bool diag = qs < kw + 31;
+        if (!skip) {
+            if (diag) kv_slice<BF, true>(cur, vslab, kf, ko, vo, dk, dv, c, qs, n, hl);
+            else kv_slice<BF, false>(cur, vslab, kf, ko, vo, dk, dv, c, qs, n, hl);
+        }
+        __syncthreads();
+    }
+    if (active) {
+        a_store_rows<BF>(smem + wid * 32 * OPAD, a.dv + (bh * a.Skv + kw) * AROW, dv, 1.f);
+        a_store_rows<BF>(smem + wid * 32 * OPAD, a.dk + (bh * a.Skv + kw) * AROW, dk, a.scale);
+    }
 }
 
 // ==========================================================================================
@@ -1115,10 +1264,18 @@ extern "C" int kf_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
             else attn_delta_kernel<false><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows);
             KF_LAUNCH_CHECK();
         }
-        {
-            KF_PROF("attn_bwd_dkv_mfma", st);
+        if (getenv("KF_ATTN_DKV_V1")) { // A/B switch for the first-generation kernel
+            KF_PROF("attn_bwd_dkv_mfma_v1", st);
             if (bf) attn_bwd_dkv_kernel<true><<<gk, 256, lds, st>>>(a);
             else attn_bwd_dkv_kernel<false><<<gk, 256, lds, st>>>(a);
+            KF_LAUNCH_CHECK();
+        } else {
+            dim3 gk2((unsigned)((Skv + KVB - 1) / KVB), (unsigned)(B * H));
+            if ((rc = set_lds(attn_bwd_dkv_v2_kernel<true>, KLDS)) != KF_OK) return rc;
+            if ((rc = set_lds(attn_bwd_dkv_v2_kernel<false>, KLDS)) != KF_OK) return rc;
+            KF_PROF("attn_bwd_dkv_mfma", st);
+            if (bf) attn_bwd_dkv_v2_kernel<true><<<gk2, FNT, KLDS, st>>>(a);
+            else attn_bwd_dkv_v2_kernel<false><<<gk2, FNT, KLDS, st>>>(a);
             KF_LAUNCH_CHECK();
         }
         if (getenv("KF_ATTN_DQ_V1")) { // A/B switch for the first-generation kernel
