@@ -296,6 +296,45 @@ __device__ __forceinline__ typename AFrag<BF>::type a_tr_frag2(const char *p0, c
     return __builtin_bit_cast(typename AFrag<BF>::type, r);
 }
 
+// Transposed reads issued from inline asm (the ds_read_tr builtin carries no memory operand, so beside an
+// LDS-DMA in flight hipcc guards it with s_waitcnt vmcnt(0) and drains the ring). Form (ii) of guide §5.7:
+// tr4_issue starts the eight reads of four fragments (column blocks d = 0..3 of one 16-row k-step) and
+// returns at once; tr4_wait is the matching lgkmcnt(0), naming every destination so no consumer can be
+// scheduled above it. ROFF = (first row of the k-step) * 256, a literal.
+struct Tr4 { s16x4 lo[4], hi[4]; };
+template <int ROFF>
+__device__ __forceinline__ void tr4_issue(const char *tile, const int (&vo)[4][2], Tr4 &t) {
+    const unsigned base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)tile;
+    asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%c16\n\tds_read_b64_tr_b16 %1, %9 offset:%c16\n\t"
+                 "ds_read_b64_tr_b16 %2, %10 offset:%c16\n\tds_read_b64_tr_b16 %3, %11 offset:%c16\n\t"
+                 "ds_read_b64_tr_b16 %4, %12 offset:%c16\n\tds_read_b64_tr_b16 %5, %13 offset:%c16\n\t"
+                 "ds_read_b64_tr_b16 %6, %14 offset:%c16\n\tds_read_b64_tr_b16 %7, %15 offset:%c16"
+                 : "=&v"(t.lo[0]), "=&v"(t.hi[0]), "=&v"(t.lo[1]), "=&v"(t.hi[1]), "=&v"(t.lo[2]), "=&v"(t.hi[2]), "=&v"(t.lo[3]), "=&v"(t.hi[3])
+                 : "v"(base + vo[0][0]), "v"(base + vo[0][1]), "v"(base + vo[1][0]), "v"(base + vo[1][1]), "v"(base + vo[2][0]),
+                   "v"(base + vo[2][1]), "v"(base + vo[3][0]), "v"(base + vo[3][1]), "i"(ROFF)
+                 : "memory");
+}
+__device__ __forceinline__ void tr4_wait(Tr4 &a, Tr4 &b) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a.lo[0]), "+v"(a.hi[0]), "+v"(a.lo[1]), "+v"(a.hi[1]), "+v"(a.lo[2]), "+v"(a.hi[2]), "+v"(a.lo[3]), "+v"(a.hi[3]),
+                   "+v"(b.lo[0]), "+v"(b.hi[0]), "+v"(b.lo[1]), "+v"(b.hi[1]), "+v"(b.lo[2]), "+v"(b.hi[2]), "+v"(b.lo[3]), "+v"(b.hi[3])
+                 :
+                 : "memory");
+}
+__device__ __forceinline__ void tr4_wait1(Tr4 &a) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a.lo[0]), "+v"(a.hi[0]), "+v"(a.lo[1]), "+v"(a.hi[1]), "+v"(a.lo[2]), "+v"(a.hi[2]), "+v"(a.lo[3]), "+v"(a.hi[3])
+                 :
+                 : "memory");
+}
+template <bool BF>
+__device__ __forceinline__ typename AFrag<BF>::type tr4_frag(const Tr4 &t, int d) {
+    s16x8 r;
+    r[0] = t.lo[d][0]; r[1] = t.lo[d][1]; r[2] = t.lo[d][2]; r[3] = t.lo[d][3];
+    r[4] = t.hi[d][0]; r[5] = t.hi[d][1]; r[6] = t.hi[d][2]; r[7] = t.hi[d][3];
+    return __builtin_bit_cast(typename AFrag<BF>::type, r);
+}
+
 struct StageKV { uint4 k0, k1, v0, v1; };
 __device__ __forceinline__ void f_gload(const char *kg, const char *vg, StageKV &r) { // 512 threads x 2 chunks per operand
     const int t = threadIdx.x;
@@ -365,15 +404,27 @@ __device__ __forceinline__ void f_tile(const char *buf, const typename AFrag<BF>
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
     const char *vt = buf + FTILE;
+    Tr4 ta, tb; // V^T fragments of k-step i+1 fly under the four MFMAs of k-step i
+    tr4_issue<0>(vt, vo, ta);
+    tr4_wait1(ta);
+    tr4_issue<16 * AROW>(vt, vo, tb);
+    { const frag_t pf = a_pack<BF>(s[0], 0);
 #pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
+      for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(tr4_frag<BF>(ta, d), pf, o[d]); }
+    tr4_wait1(tb);
+    tr4_issue<32 * AROW>(vt, vo, ta);
+    { const frag_t pf = a_pack<BF>(s[0], 1);
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const frag_t pf = a_pack<BF>(s[sub], s2);
-            const int roff = (sub * 32 + s2 * 16) * AROW;
+      for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(tr4_frag<BF>(tb, d), pf, o[d]); }
+    tr4_wait1(ta);
+    tr4_issue<48 * AROW>(vt, vo, tb);
+    { const frag_t pf = a_pack<BF>(s[1], 0);
 #pragma unroll
-            for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(a_tr_frag2<BF>(vt + roff + vo[d][0], vt + roff + vo[d][1]), pf, o[d]);
-        }
+      for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(tr4_frag<BF>(ta, d), pf, o[d]); }
+    tr4_wait1(tb);
+    { const frag_t pf = a_pack<BF>(s[1], 1);
+#pragma unroll
+      for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(tr4_frag<BF>(tb, d), pf, o[d]); }
 }
 
 template <bool BF>
@@ -587,14 +638,18 @@ __device__ __forceinline__ void q_tile(const char *buf, const char *doslab, cons
             if (MASK && kv0 + sub * 32 + a_row(e, hl) > m) p = 0.f;
             s[e] = p * (dp[e] - dlt);
         }
+        Tr4 ta, tb;
+        if (sub == 0) tr4_issue<0>(buf, vo, ta); else tr4_issue<32 * AROW>(buf, vo, ta);
+        tr4_wait1(ta);
+        if (sub == 0) tr4_issue<16 * AROW>(buf, vo, tb); else tr4_issue<48 * AROW>(buf, vo, tb);
+        { const frag_t df = a_pack<BF>(s, 0);
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const frag_t df = a_pack<BF>(s, s2);
-            const int roff = (sub * 32 + s2 * 16) * AROW;
+          for (int d = 0; d < 4; ++d) dq[d] = a_mfma<BF>(tr4_frag<BF>(ta, d), df, dq[d]); }
+        tr4_wait1(tb);
+        { const frag_t df = a_pack<BF>(s, 1);
 #pragma unroll
-            for (int d = 0; d < 4; ++d) dq[d] = a_mfma<BF>(a_tr_frag2<BF>(buf + roff + vo[d][0], buf + roff + vo[d][1]), df, dq[d]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+          for (int d = 0; d < 4; ++d) dq[d] = a_mfma<BF>(tr4_frag<BF>(tb, d), df, dq[d]); }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -807,7 +862,7 @@ __device__ __forceinline__ void kv_slice(const char *buf, const char *vslab, con
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
+    for (int s2 = 0; s2 < 2; ++s2) { // builtin transposed reads here: the asm issue/wait form costs this kernel registers it does not have
         const frag_t pf = a_pack<BF>(s, s2), df = a_pack<BF>(dp, s2);
         const int roff = s2 * 16 * AROW;
 #pragma unroll
@@ -902,6 +957,162 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dkv_v2_kernel(const AttnArgs 
         a_store_rows<BF>(smem + wid * 32 * OPAD, a.dv + (bh * a.Skv + kw) * AROW, dv, 1.f);
         a_store_rows<BF>(smem + wid * 32 * OPAD, a.dk + (bh * a.Skv + kw) * AROW, dk, a.scale);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward: dK, dV, v3 — 4 waves x 32 keys, ONE wave per SIMD with the whole 512-register file:
+// dK^T/dV^T accumulators (128) and the K and V fragments (64) stay in registers and the scheduler is
+// free to keep a full phase of LDS fragment reads in flight. Q / dO slices stream through a 3-deep
+// LDS ring by LDS-DMA: two slices are in flight behind a COUNTED s_waitcnt vmcnt and a raw s_barrier
+// (one barrier per slice; __syncthreads() would drain the ring with vmcnt(0)).
+// ------------------------------------------------------------------------------------------
+constexpr int K3LDS = 3 * KSL;
+static_assert(K3LDS >= 4 * 32 * OPAD, "epilogue slabs must fit");
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// The per-row lse | delta block of a slice is written by LDS-DMA. A plain LDS read of it makes hipcc drain
+// the whole DMA ring (s_waitcnt vmcnt(0): it cannot disambiguate the read from the DMA in flight), so the
+// eight 16-byte reads are issued from ONE asm statement with their own lgkmcnt(0) (guide §5.7 form (i)).
+__device__ __forceinline__ void kv3_read_rows(const float *lse_s, int hl, f32x4 (&l)[4], f32x4 (&d)[4]) {
+    const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)lse_s + 16u * hl;
+    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:32\n\tds_read_b128 %2, %8 offset:64\n\tds_read_b128 %3, %8 offset:96\n\t"
+                 "ds_read_b128 %4, %8 offset:128\n\tds_read_b128 %5, %8 offset:160\n\tds_read_b128 %6, %8 offset:192\n\t"
+                 "ds_read_b128 %7, %8 offset:224\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(l[0]), "=&v"(l[1]), "=&v"(l[2]), "=&v"(l[3]), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+                 : "v"(addr)
+                 : "memory");
+}
+
+template <bool BF, bool MASK>
+__device__ __forceinline__ void kv3_slice(const char *buf, const typename AFrag<BF>::type (&kf)[8], const typename AFrag<BF>::type (&vf)[8],
+                                          const int (&ko)[8], const int (&vo)[4][2], f32x16 (&dk)[4], f32x16 (&dv)[4], float c, int64_t qs,
+                                          int64_t n, int hl) {
+    using frag_t = typename AFrag<BF>::type;
+    const char *qt = buf, *dot = buf + BQS * AROW;
+    const float *lse_s = (const float *)(buf + 2 * BQS * AROW);
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) s = a_mfma<BF>(*(const frag_t *)(qt + ko[kk]), kf[kk], s);
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) dp = a_mfma<BF>(*(const frag_t *)(dot + ko[kk]), vf[kk], dp);
+    f32x4 l4[4], d4[4]; // accumulator rows 8*g4 + 4*hl + {0..3}
+    kv3_read_rows(lse_s, hl, l4, d4);
+    Tr4 to0, tq0, to1, tq1;
+    tr4_issue<0>(dot, vo, to0); // first k-step's dO^T and Q^T fragments fly under the softmax arithmetic
+    tr4_issue<0>(qt, vo, tq0);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int e = 4 * g4 + j;
+            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], c, -l4[g4][j] * kLog2e));
+            if (MASK && n > qs + 8 * g4 + 4 * hl + j) p = 0.f;
+            s[e] = p;
+            dp[e] = p * (dp[e] - d4[g4][j]);
+        }
+    }
+    tr4_wait(to0, tq0);
+    tr4_issue<16 * AROW>(dot, vo, to1); // second k-step's fragments fly under the first k-step's 8 MFMAs
+    tr4_issue<16 * AROW>(qt, vo, tq1);
+    {
+        const frag_t pf = a_pack<BF>(s, 0), df = a_pack<BF>(dp, 0);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) dv[d] = a_mfma<BF>(tr4_frag<BF>(to0, d), pf, dv[d]);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) dk[d] = a_mfma<BF>(tr4_frag<BF>(tq0, d), df, dk[d]);
+    }
+    tr4_wait(to1, tq1);
+    {
+        const frag_t pf = a_pack<BF>(s, 1), df = a_pack<BF>(dp, 1);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) dv[d] = a_mfma<BF>(tr4_frag<BF>(to1, d), pf, dv[d]);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) dk[d] = a_mfma<BF>(tr4_frag<BF>(tq1, d), df, dk[d]);
+    }
+}
+
+template <bool BF>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_v3_kernel(const AttnArgs a) {
+    using frag_t = typename AFrag<BF>::type;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
+    const int64_t bh = blockIdx.y;
+    const int64_t k0 = (int64_t)blockIdx.x * BKB, kw = k0 + wid * 32, n = kw + xl;
+    const char *Kg = a.k + (bh * a.Skv + n) * AROW;
+    const char *Vg = a.v + (bh * a.Skv + n) * AROW;
+    const char *Qg = a.q + bh * a.Sq * AROW;
+    const char *dOg = a.d_o + bh * a.Sq * AROW;
+    const float *lse_g = a.lse_r + bh * a.Sq, *dlt_g = a.delta + bh * a.Sq;
+
+    frag_t kf[8], vf[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        kf[kk] = *(const frag_t *)(Kg + (kk * 16 + 8 * hl) * 2);
+        vf[kk] = *(const frag_t *)(Vg + (kk * 16 + 8 * hl) * 2);
+    }
+    int ko[8], vo[4][2];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) ko[kk] = a_off(xl, kk * 2 + hl);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        vo[d][0] = a_tr_lane_off(d * 32, 0);
+        vo[d][1] = a_tr_lane_off(d * 32, 1);
+    }
+    f32x16 dk[4], dv[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk[d][e] = 0.f; dv[d][e] = 0.f; }
+    const float c = a.scale * kLog2e;
+
+    // LDS-DMA of one slice: Q tile and dO tile are 8 wave-instructions each (2 + 2 per wave) plus one
+    // 4-byte-per-lane instruction for lse | delta — issued by EVERY wave (identical bytes) so that every
+    // wave has exactly 5 DMA operations per slice and one counted wait serves all.
+    const int ns = (int)(a.Sq / BQS);
+    auto stage = [&](int sl_, char *buf) {
+        sl_ = sl_ < ns ? sl_ : ns - 1; // past the end: re-fetch the last slice (keeps the counts uniform; never consumed)
+        const int64_t qs_ = (int64_t)sl_ * BQS;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row0 = (wid * 2 + i) * 4, row = row0 + (lane >> 4), pos = lane & 15;
+            const int chunk = pos ^ (((row & 3) << 2) | ((row >> 2) & 3));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Qg + (qs_ + row) * AROW + chunk * 16),
+                                             (__attribute__((address_space(3))) void *)(buf + row0 * AROW), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dOg + (qs_ + row) * AROW + chunk * 16),
+                                             (__attribute__((address_space(3))) void *)(buf + BQS * AROW + row0 * AROW), 16, 0, 0);
+        }
+        const float *src = lane < BQS ? lse_g + qs_ + lane : dlt_g + qs_ + lane - BQS;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(buf + 2 * BQS * AROW), 4, 0, 0);
+    };
+    int sl = (int)(k0 / BQS); // first slice holding a query >= the block's first key
+    if (sl < ns) {
+        stage(sl, smem);
+        stage(sl + 1, smem + KSL);
+    }
+    for (int it = 0; sl < ns; ++sl, ++it) {
+        const int64_t qs = (int64_t)sl * BQS;
+        // slice `sl` has landed once all but this wave's 5 youngest DMA operations (slice sl+1) are done ...
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        // ... for every wave, and every wave is past its reads of the buffer slice sl+2 will overwrite
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stage(sl + 2, smem + ((it + 2) % 3) * KSL);
+        const char *cur = smem + (it % 3) * KSL;
+        const bool skip = qs + BQS - 1 < kw; // every query of the slice precedes this wave's keys
+        const bool diag = qs < kw + 31;
+        if (!skip) {
+            if (diag) kv3_slice<BF, true>(cur, kf, vf, ko, vo, dk, dv, c, qs, n, hl);
+            else kv3_slice<BF, false>(cur, kf, vf, ko, vo, dk, dv, c, qs, n, hl);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // drain the ring before LDS is reused
+    __syncthreads();
+    a_store_rows<BF>(smem + wid * 32 * OPAD, a.dv + (bh * a.Skv + kw) * AROW, dv, 1.f);
+    a_store_rows<BF>(smem + wid * 32 * OPAD, a.dk + (bh * a.Skv + kw) * AROW, dk, a.scale);
 }
 
 // ==========================================================================================
@@ -1268,6 +1479,13 @@ extern "C" int kf_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
             KF_PROF("attn_bwd_dkv_mfma_v1", st);
             if (bf) attn_bwd_dkv_kernel<true><<<gk, 256, lds, st>>>(a);
             else attn_bwd_dkv_kernel<false><<<gk, 256, lds, st>>>(a);
+            KF_LAUNCH_CHECK();
+        } else if (getenv("KF_ATTN_DKV_V3")) {
+            if ((rc = set_lds(attn_bwd_dkv_v3_kernel<true>, K3LDS)) != KF_OK) return rc;
+            if ((rc = set_lds(attn_bwd_dkv_v3_kernel<false>, K3LDS)) != KF_OK) return rc;
+            KF_PROF("attn_bwd_dkv_mfma_v3", st);
+            if (bf) attn_bwd_dkv_v3_kernel<true><<<gk, 256, K3LDS, st>>>(a);
+            else attn_bwd_dkv_v3_kernel<false><<<gk, 256, K3LDS, st>>>(a);
             KF_LAUNCH_CHECK();
         } else {
             dim3 gk2((unsigned)((Skv + KVB - 1) / KVB), (unsigned)(B * H));
