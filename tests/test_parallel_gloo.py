@@ -1,0 +1,66 @@
+"""CPU-only, world_size 2 over gloo: the N > 1 path of the hot path is batch sharding with ONE exchange
+step, the sum all-reduce of the weight gradient. The per-rank math is done by the CPU oracle (this is a
+test: the oracle is the checker); what is under test is kfunca_amd.parallel — shard ranges, the flat
+gradient bucket and the all-reduce — against the single-process full-batch result."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from kfunca_amd import parallel
+from oracle import oracle as O
+
+
+def test_shard_range_partitions_exactly():
+    for n in (0, 1, 7, 8, 9, 64, 1000):
+        for world in (1, 2, 3, 4, 8):
+            spans = [parallel.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        parallel.shard_range(8, 2, 2)
+
+
+def test_bucket_layout():
+    b = parallel.GradBucket([(4096, 4096), (7,), (3, 5)], dtype=np.float32)
+    assert b.slots[0].offset == 0 and b.slots[1].offset == 4096 * 4096 and b.slots[2].offset == 4096 * 4096 + 64
+    assert b.numel % 64 == 0 and all(b.byte_offset(i) % 16 == 0 for i in range(3))
+    flat = np.arange(b.numel, dtype=np.float32)
+    assert b.view(flat, 2).shape == (3, 5) and b.view(flat, 2)[0, 0] == b.slots[2].offset
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    pg = parallel.ProcessGroup(backend="gloo")
+    rng = np.random.default_rng(77)           # identical on every rank: full batch + replicated weights
+    M, K, N = 48, 32, 40
+    A = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+    dC = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+    extra = rng.uniform(-1, 1, (M, 5)).astype(np.float32)
+    lo, hi = parallel.shard_range(M, rank, world)
+    bucket = parallel.GradBucket([(K, N), (K, 5)], dtype=np.float32)
+    flat = np.zeros(bucket.numel, dtype=np.float32)
+    # per-rank weight gradients of its batch shard: dW_r = A_r^T dC_r
+    bucket.view(flat, 0)[...] = O.gemm(A[lo:hi], dC[lo:hi], trans_a=True)
+    bucket.view(flat, 1)[...] = O.gemm(A[lo:hi], extra[lo:hi], trans_a=True)
+    pg.allreduce_sum_host(flat)
+    worst = pg.max_over_ranks(float(rank))
+    full0, full1 = O.gemm(A, dC, trans_a=True), O.gemm(A, extra, trans_a=True)
+    ok = (np.allclose(bucket.view(flat, 0), full0, rtol=1e-5, atol=1e-5) and np.allclose(bucket.view(flat, 1), full1, rtol=1e-5, atol=1e-5)
+          and worst == world - 1)
+    out[rank] = bool(ok)
+    pg.close()
+
+
+def test_gradient_allreduce_world2_matches_full_batch():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    assert dict(out) == {0: True, 1: True}
