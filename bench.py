@@ -147,13 +147,16 @@ def main():
     comm = None
     if world > 1:
         import torch.distributed as dist  # plumbing only: rendezvous, barrier, max-reduce of the timing
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo", rank=rank, world_size=world)
+    if world > 1 or os.environ.get("KF_BENCH_FORCE_COMM"):  # the env knob exercises the collective path on one GPU
         ident = [None]
         if rank == 0:
             buf = C.create_string_buffer(H.COMM_ID_BYTES)
             H.check(H.lib().kf_comm_unique_id(buf))
             ident[0] = buf.raw
-        dist.broadcast_object_list(ident, src=0)
+        if dist is not None:
+            dist.broadcast_object_list(ident, src=0)
         h = C.c_void_p()
         H.check(H.lib().kf_comm_init(C.byref(h), ident[0], rank, world))
         comm = h.value

@@ -43,7 +43,25 @@ struct AttnArgs {
     float *delta;
     int64_t B, H, Sq, Skv, D;
     float scale;
+    int xcd_map; // 1: nbh % 8 == 0, heads are pinned to XCDs (a_block_map)
+    int dbg; // KF_ATTN_DBG: timing-only ablation mask for the forward (results are wrong when non-zero)
 };
+
+// XCD-aware block order for the v2 kernels (1-D grid of nx * nbh blocks). Hardware deals block ids round-robin
+// over the 8 XCDs, each with a private 4 MiB L2. All nx blocks of one (batch, head) re-read that head's K/V
+// (or Q/dO): 2 MiB at S = 4096. Dealing a head's blocks to ONE XCD keeps those re-reads in its L2 instead of
+// fetching every head into every L2. Speed only: any placement is correct.
+__device__ __forceinline__ void a_block_map(int nx, int nbh, int xcd_map, int &x, int64_t &bh) {
+    const unsigned id = blockIdx.x;
+    if (xcd_map) { // nbh % 8 == 0
+        const unsigned xcd = id & 7u, slot = id >> 3;
+        x = (int)(slot % (unsigned)nx);
+        bh = (int64_t)(slot / (unsigned)nx) * 8 + xcd;
+    } else {
+        x = (int)(id % (unsigned)nx);
+        bh = id / (unsigned)nx;
+    }
+}
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
@@ -276,7 +294,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
 constexpr int FQ = 256;                 // queries per block
 constexpr int FNT = 512;                // threads per block
 constexpr int FTILE = ABK * AROW;       // bytes of one K or V tile (16 KiB)
-constexpr int FBUF = 2 * FTILE;         // one double-buffer half: K tile | V tile
+constexpr int FBUF = 2 * FTILE;         // one ring slot: K tile | V tile
+constexpr int FRING = 3;                // ring depth (tiles t, t+1, t+2)
 
 // per-lane byte offset (relative to the tile, for a 16-row-aligned r0) of the two transposed reads
 __device__ __forceinline__ int a_tr_lane_off(int col0, int second) {
@@ -362,7 +381,7 @@ __device__ __forceinline__ void f_stage(const char *kg, const char *vg, char *bu
     }
 }
 
-template <bool BF, bool MASK>
+template <bool BF, bool MASK, int dbg = 0>
 __device__ __forceinline__ void f_tile(const char *buf, const typename AFrag<BF>::type (&qf)[8], const int (&ko)[8], const int (&vo)[4][2],
                                        f32x16 (&o)[4], float &m_i, float &l_i, float c, int64_t kv0, int64_t m, int hl) {
     using frag_t = typename AFrag<BF>::type;
@@ -371,9 +390,27 @@ __device__ __forceinline__ void f_tile(const char *buf, const typename AFrag<BF>
     for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;
+        if (!(dbg & 1)) {
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk)
-            s[sub] = a_mfma<BF>(*(const frag_t *)(buf + sub * 32 * AROW + ko[kk]), qf[kk], s[sub]);
+            for (int kk = 0; kk < 8; ++kk)
+                s[sub] = a_mfma<BF>(*(const frag_t *)(buf + sub * 32 * AROW + ko[kk]), qf[kk], s[sub]);
+        }
+    }
+    if (dbg & 2) { // ablation: no softmax arithmetic
+        const frag_t p0 = a_pack<BF>(s[0], 0), p1 = a_pack<BF>(s[1], 1);
+        if (!(dbg & 4)) {
+            const char *vt2 = buf + FTILE;
+            Tr4 tz;
+            tr4_issue<0>(vt2, vo, tz);
+            tr4_wait1(tz);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(tr4_frag<BF>(tz, d), r & 1 ? p1 : p0, o[d]);
+        } else {
+            asm volatile("" ::"v"(p0), "v"(p1));
+        }
+        return;
     }
     float mx = -INFINITY;
 #pragma unroll
@@ -403,6 +440,10 @@ __device__ __forceinline__ void f_tile(const char *buf, const typename AFrag<BF>
     for (int d = 0; d < 4; ++d)
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+    if (dbg & 4) { // ablation: no PV
+        asm volatile("" ::"v"(s[0]), "v"(s[1]));
+        return;
+    }
     const char *vt = buf + FTILE;
     Tr4 ta, tb; // V^T fragments of k-step i+1 fly under the four MFMAs of k-step i
     tr4_issue<0>(vt, vo, ta);
@@ -427,15 +468,18 @@ __device__ __forceinline__ void f_tile(const char *buf, const typename AFrag<BF>
       for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(tr4_frag<BF>(tb, d), pf, o[d]); }
 }
 
-template <bool BF>
+template <bool BF, int DBG = 0>
 __global__ __launch_bounds__(FNT, 2) void attn_fwd_v2_kernel(const AttnArgs a) {
     using frag_t = typename AFrag<BF>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
-    const int qblk = gridDim.x - 1 - blockIdx.x; // longest blocks first
-    const int64_t bh = blockIdx.y;
+    int xb;
+    int64_t bh;
+    const int nxb = (int)((a.Sq + FQ - 1) / FQ);
+    a_block_map(nxb, (int)(a.B * a.H), a.xcd_map, xb, bh);
+    const int qblk = nxb - 1 - xb; // longest blocks first
     const int64_t q0 = (int64_t)qblk * FQ, qw = q0 + wid * 32, m = qw + xl;
-    const bool active = qw < a.Sq; // the last block may be partial (Sq % 256 != 0): idle waves still stage and sync
+    const bool active = qw < a.Sq && !((DBG & 32) && wid >= 4) && !((DBG & 64) && (wid & 1)); // partial last block; ablations 32 / 64 idle half the waves
     const char *Kg = a.k + bh * a.Skv * AROW;
     const char *Vg = a.v + bh * a.Skv * AROW;
 
@@ -470,24 +514,209 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v2_kernel(const AttnArgs a) {
     const int64_t q_end = q0 + FQ < a.Sq ? q0 + FQ : a.Sq;
     const int64_t kv_end = a.Skv < q_end ? a.Skv : q_end;
     const int nt = (int)((kv_end + ABK - 1) / ABK);
-    f_stage(Kg, Vg, smem);
-    __syncthreads(); // s_waitcnt vmcnt(0) for the LDS-DMA in flight, then s_barrier
+    // 3-deep LDS ring fed by LDS-DMA: tiles t+1 and t+2 are in flight while tile t is consumed. One DMA
+    // round trip (~1-2 us under load) is longer than one tile of compute, so a single tile of prefetch
+    // leaves the loop latency-bound. Every wave issues exactly 4 DMA operations per tile (tiles past the end
+    // re-fetch the last one) so a COUNTED s_waitcnt vmcnt(4) means "tile t has landed"; the raw s_barrier
+    // (a __syncthreads() would drain the ring with vmcnt(0)) publishes it and retires the buffer tile t+2
+    // overwrites.
+    auto stage = [&](int tile, char *buf) {
+        const int64_t kv = (int64_t)(tile < nt ? tile : nt - 1) * ABK;
+        f_stage(Kg + kv * AROW, Vg + kv * AROW, buf);
+    };
+    stage(0, smem);
+    stage(1, smem + FBUF);
     for (int t = 0; t < nt; ++t) {
         const int64_t kv0 = (int64_t)t * ABK;
-        const char *cur = smem + (t & 1) * FBUF;
-        char *nxt = smem + ((t + 1) & 1) * FBUF;
-        // tile t+1 streams into the buffer everyone finished reading at the last barrier while tile t is consumed
-        if (t + 1 < nt) f_stage(Kg + (kv0 + ABK) * AROW, Vg + (kv0 + ABK) * AROW, nxt);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (!(DBG & 16)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (!(DBG & 8)) stage(t + 2, smem + ((t + 2) % FRING) * FBUF);
+        else { stage(0, smem + 4 * FBUF); } // ablation: keep the DMA count, hit one hot tile, never read it
+        const char *cur = smem + (t % FRING) * FBUF;
         // this wave's relation to the tile: entirely visible, on the diagonal, or entirely masked
         const bool skip = !active || kv0 > qw + 31;
         const bool diag = kv0 + ABK - 1 > qw;
         if (!skip) {
-            if (diag) f_tile<BF, true>(cur, qf, ko, vo, o, m_i, l_i, c, kv0, m, hl);
-            else f_tile<BF, false>(cur, qf, ko, vo, o, m_i, l_i, c, kv0, m, hl);
+            if (diag) f_tile<BF, true, DBG>(cur, qf, ko, vo, o, m_i, l_i, c, kv0, m, hl);
+            else f_tile<BF, false, DBG>(cur, qf, ko, vo, o, m_i, l_i, c, kv0, m, hl);
         }
-        __syncthreads();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // drain the ring before LDS is reused
+    __syncthreads();
     // K/V buffers are dead: reuse LDS as per-wave output slabs (8 x 32 x OPAD bytes)
+    if (active) {
+        a_store_rows<BF>(smem + wid * 32 * OPAD, a.out + (bh * a.Sq + qw) * AROW, o, 1.f / l_i);
+        if (a.lse && hl == 0) a.lse[bh * a.Sq + m] = (m_i * c + __builtin_amdgcn_logf(l_i)) * kLn2;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward, v3 = v2 with the two waves of each SIMD STAGGERED. Ablation of v2 (KF_ATTN_DBG) shows its QK,
+// softmax and PV costs add up (0.37 + 0.55 + 0.47 ms of 1.96): all eight waves leave the tile barrier
+// together, so both waves of a SIMD sit in the same phase and the matrix pipe idles while both do
+// softmax arithmetic. Here waves 4-7 run one phase late: in tile interval t they do PV(t-1), QK(t),
+// softmax(t) while waves 0-3 do QK(t), softmax(t), PV(t) — two of the three phases pair matrix work
+// with vector work. Costs one more ring slot (V of tile t-1 must survive interval t).
+// ------------------------------------------------------------------------------------------
+constexpr int SRING = 4;
+
+template <bool BF, bool MASK>
+__device__ __forceinline__ void s_qk_sm(const char *buf, const typename AFrag<BF>::type (&qf)[8], const int (&ko)[8], f32x16 (&o)[4],
+                                        typename AFrag<BF>::type (&pf)[4], float &m_i, float &l_i, float c, int64_t kv0, int64_t m, int hl) {
+    using frag_t = typename AFrag<BF>::type;
+    f32x16 s[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+#pragma unroll
+            for (int kk = 4 * kg; kk < 4 * kg + 4; ++kk)
+                s[sub] = a_mfma<BF>(*(const frag_t *)(buf + sub * 32 * AROW + ko[kk]), qf[kk], s[sub]);
+            __builtin_amdgcn_sched_barrier(0); // bounds the K fragments in flight (register budget)
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (MASK && kv0 + sub * 32 + a_row(e, hl) > m) s[sub][e] = -INFINITY;
+            mx = fmaxf(mx, s[sub][e]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_i, mx);
+    const float mc = m_new * c;
+    const float alpha = __builtin_amdgcn_exp2f(m_i * c - mc);
+    float rs = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][e], c, -mc));
+            s[sub][e] = p;
+            rs += p;
+        }
+    rs += __shfl_xor(rs, 32, 64);
+    l_i = l_i * alpha + rs;
+    m_i = m_new;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+    pf[0] = a_pack<BF>(s[0], 0);
+    pf[1] = a_pack<BF>(s[0], 1);
+    pf[2] = a_pack<BF>(s[1], 0);
+    pf[3] = a_pack<BF>(s[1], 1);
+}
+
+template <bool BF>
+__device__ __forceinline__ void s_pv(const char *vt, const int (&vo)[4][2], const typename AFrag<BF>::type (&pf)[4], f32x16 (&o)[4]) {
+    Tr4 ta; // one group of transposed V fragments at a time: the partner wave (in its softmax phase) covers the latency
+    tr4_issue<0>(vt, vo, ta);
+    tr4_wait1(ta);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(tr4_frag<BF>(ta, d), pf[0], o[d]);
+    __builtin_amdgcn_sched_barrier(0);
+    tr4_issue<16 * AROW>(vt, vo, ta);
+    tr4_wait1(ta);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(tr4_frag<BF>(ta, d), pf[1], o[d]);
+    __builtin_amdgcn_sched_barrier(0);
+    tr4_issue<32 * AROW>(vt, vo, ta);
+    tr4_wait1(ta);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(tr4_frag<BF>(ta, d), pf[2], o[d]);
+    __builtin_amdgcn_sched_barrier(0);
+    tr4_issue<48 * AROW>(vt, vo, ta);
+    tr4_wait1(ta);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(tr4_frag<BF>(ta, d), pf[3], o[d]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool BF>
+__global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
+    using frag_t = typename AFrag<BF>::type;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
+    int xb;
+    int64_t bh;
+    const int nxb = (int)((a.Sq + FQ - 1) / FQ);
+    a_block_map(nxb, (int)(a.B * a.H), a.xcd_map, xb, bh);
+    const int qblk = nxb - 1 - xb; // longest blocks first
+    // query rows are dealt so that each SIMD's early wave (w) and late wave (w + 4) own ADJACENT 32-row groups:
+    // their causal work differs by at most one tile
+    const int rgrp = ((wid & 3) << 1) | (wid >> 2);
+    const int64_t q0 = (int64_t)qblk * FQ, qw = q0 + rgrp * 32, m = qw + xl;
+    const bool active = qw < a.Sq;
+    const bool late = __builtin_amdgcn_readfirstlane(wid) >= 4;
+    const char *Kg = a.k + bh * a.Skv * AROW;
+    const char *Vg = a.v + bh * a.Skv * AROW;
+
+    frag_t qf[8];
+    if (active) {
+        const char *Qg = a.q + (bh * a.Sq + m) * AROW;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const frag_t *)(Qg + (kk * 16 + 8 * hl) * 2);
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qf[kk][j] = 0;
+    }
+    int ko[8], vo[4][2];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) ko[kk] = a_off(xl, kk * 2 + hl);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        vo[d][0] = a_tr_lane_off(d * 32, 0);
+        vo[d][1] = a_tr_lane_off(d * 32, 1);
+    }
+    f32x16 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+    float m_i = -INFINITY, l_i = 0.f;
+    const float c = a.scale * kLog2e;
+    frag_t pf[4];
+    bool pending = false; // late waves: P of the previous tile still waits for its PV
+
+    const int64_t q_end = q0 + FQ < a.Sq ? q0 + FQ : a.Sq;
+    const int64_t kv_end = a.Skv < q_end ? a.Skv : q_end;
+    const int nt = (int)((kv_end + ABK - 1) / ABK);
+    auto stage = [&](int tile, char *buf) {
+        const int64_t kv = (int64_t)(tile < nt ? tile : nt - 1) * ABK;
+        f_stage(Kg + kv * AROW, Vg + kv * AROW, buf);
+    };
+    stage(0, smem);
+    stage(1, smem + FBUF);
+    for (int t = 0; t < nt; ++t) {
+        const int64_t kv0 = (int64_t)t * ABK;
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stage(t + 2, smem + ((t + 2) % SRING) * FBUF); // slot of tile t-2: nobody reads it any more
+        const char *cur = smem + (t % SRING) * FBUF;
+        const bool skip = !active || kv0 > qw + 31;
+        const bool diag = kv0 + ABK - 1 > qw;
+        // one copy of each phase in program order [PV(t-1) | QK+softmax(t) | PV(t)]: late waves take the first
+        // two, early waves the last two
+        if (late && pending) s_pv<BF>(smem + ((t + SRING - 1) % SRING) * FBUF + FTILE, vo, pf, o);
+        pending = false;
+        if (!skip) {
+            if (diag) s_qk_sm<BF, true>(cur, qf, ko, o, pf, m_i, l_i, c, kv0, m, hl);
+            else s_qk_sm<BF, false>(cur, qf, ko, o, pf, m_i, l_i, c, kv0, m, hl);
+            if (late) pending = true;
+            else s_pv<BF>(cur + FTILE, vo, pf, o);
+        }
+    }
+    if (late && pending) s_pv<BF>(smem + ((nt + SRING - 1) % SRING) * FBUF + FTILE, vo, pf, o);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (active) {
         a_store_rows<BF>(smem + wid * 32 * OPAD, a.out + (bh * a.Sq + qw) * AROW, o, 1.f / l_i);
         if (a.lse && hl == 0) a.lse[bh * a.Sq + m] = (m_i * c + __builtin_amdgcn_logf(l_i)) * kLn2;
@@ -638,36 +867,40 @@ __device__ __forceinline__ void q_tile(const char *buf, const char *doslab, cons
             if (MASK && kv0 + sub * 32 + a_row(e, hl) > m) p = 0.f;
             s[e] = p * (dp[e] - dlt);
         }
-        Tr4 ta, tb;
+        Tr4 ta; // one group of transposed K fragments at a time (register budget); the partner wave covers the LDS latency
         if (sub == 0) tr4_issue<0>(buf, vo, ta); else tr4_issue<32 * AROW>(buf, vo, ta);
         tr4_wait1(ta);
-        if (sub == 0) tr4_issue<16 * AROW>(buf, vo, tb); else tr4_issue<48 * AROW>(buf, vo, tb);
         { const frag_t df = a_pack<BF>(s, 0);
 #pragma unroll
           for (int d = 0; d < 4; ++d) dq[d] = a_mfma<BF>(tr4_frag<BF>(ta, d), df, dq[d]); }
-        tr4_wait1(tb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (sub == 0) tr4_issue<16 * AROW>(buf, vo, ta); else tr4_issue<48 * AROW>(buf, vo, ta);
+        tr4_wait1(ta);
         { const frag_t df = a_pack<BF>(s, 1);
 #pragma unroll
-          for (int d = 0; d < 4; ++d) dq[d] = a_mfma<BF>(tr4_frag<BF>(tb, d), df, dq[d]); }
+          for (int d = 0; d < 4; ++d) dq[d] = a_mfma<BF>(tr4_frag<BF>(ta, d), df, dq[d]); }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 constexpr int QSLAB = 32 * AROW;                 // one wave's dO rows (8 KiB)
-constexpr int QLDS = 2 * FBUF + 8 * QSLAB;       // K/V double buffer + 8 dO slabs = 128 KiB
+constexpr int QLDS = FRING * FBUF + 8 * QSLAB;   // K/V ring + 8 dO slabs = 160 KiB (the whole LDS of a CU)
 
 template <bool BF>
 __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a) {
     using frag_t = typename AFrag<BF>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
-    const int qblk = gridDim.x - 1 - blockIdx.x;
-    const int64_t bh = blockIdx.y;
+    int xb;
+    int64_t bh;
+    const int nxb = (int)((a.Sq + FQ - 1) / FQ);
+    a_block_map(nxb, (int)(a.B * a.H), a.xcd_map, xb, bh);
+    const int qblk = nxb - 1 - xb; // longest blocks first
     const int64_t q0 = (int64_t)qblk * FQ, qw = q0 + wid * 32, m = qw + xl;
     const bool active = qw < a.Sq;
     const char *Kg = a.k + bh * a.Skv * AROW;
     const char *Vg = a.v + bh * a.Skv * AROW;
-    char *doslab = smem + 2 * FBUF + wid * QSLAB; // this wave's dO rows, same swizzled image as a K tile (B operand of dP^T)
+    char *doslab = smem + FRING * FBUF + wid * QSLAB; // this wave's dO rows, same swizzled image as a K tile (B operand of dP^T)
 
     frag_t qf[8];
     float lse2 = 0.f, dlt = 0.f;
@@ -704,21 +937,29 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a
     const int64_t q_end = q0 + FQ < a.Sq ? q0 + FQ : a.Sq;
     const int64_t kv_end = a.Skv < q_end ? a.Skv : q_end;
     const int nt = (int)((kv_end + ABK - 1) / ABK);
-    f_stage(Kg, Vg, smem);
-    __syncthreads();
+    auto stage = [&](int tile, char *buf) { // 3-deep ring, counted vmcnt: see attn_fwd_v2_kernel
+        const int64_t kv = (int64_t)(tile < nt ? tile : nt - 1) * ABK;
+        f_stage(Kg + kv * AROW, Vg + kv * AROW, buf);
+    };
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // Q fragments + the dO slab writes are done
+    stage(0, smem);
+    stage(1, smem + FBUF);
     for (int t = 0; t < nt; ++t) {
         const int64_t kv0 = (int64_t)t * ABK;
-        const char *cur = smem + (t & 1) * FBUF;
-        char *nxt = smem + ((t + 1) & 1) * FBUF;
-        if (t + 1 < nt) f_stage(Kg + (kv0 + ABK) * AROW, Vg + (kv0 + ABK) * AROW, nxt);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        stage(t + 2, smem + ((t + 2) % FRING) * FBUF);
+        const char *cur = smem + (t % FRING) * FBUF;
         const bool skip = !active || kv0 > qw + 31;
         const bool diag = kv0 + ABK - 1 > qw;
         if (!skip) {
             if (diag) q_tile<BF, true>(cur, doslab, qf, ko, vo, dq, c, lse2, dlt, kv0, m, hl);
             else q_tile<BF, false>(cur, doslab, qf, ko, vo, dq, c, lse2, dlt, kv0, m, hl);
         }
-        __syncthreads();
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (active) a_store_rows<BF>(smem + wid * 32 * OPAD, a.dq + (bh * a.Sq + qw) * AROW, dq, a.scale);
 }
 
@@ -822,7 +1063,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
 // ------------------------------------------------------------------------------------------
 constexpr int KVB = 256;                          // keys per block
 constexpr int KSL = 2 * BQS * AROW + 256;         // one slice buffer: Q tile | dO tile | lse2[32] | delta[32]
-constexpr int KLDS = 2 * KSL + 8 * QSLAB;         // + 8 per-wave V slabs
+constexpr int KNS = 2;                            // slices consumed per barrier
+constexpr int KLDS = 2 * KNS * KSL + 8 * QSLAB;   // double-buffered slice groups + 8 per-wave V slabs
 static_assert(KLDS >= 8 * 32 * OPAD, "epilogue slabs must fit");
 
 template <bool BF, bool MASK>
@@ -879,13 +1121,15 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dkv_v2_kernel(const AttnArgs 
     using frag_t = typename AFrag<BF>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
-    const int64_t bh = blockIdx.y;
-    const int64_t k0 = (int64_t)blockIdx.x * KVB, kw = k0 + wid * 32, n = kw + xl;
+    int xb;
+    int64_t bh;
+    a_block_map((int)((a.Skv + KVB - 1) / KVB), (int)(a.B * a.H), a.xcd_map, xb, bh);
+    const int64_t k0 = (int64_t)xb * KVB, kw = k0 + wid * 32, n = kw + xl;
     const bool active = kw < a.Skv;
     const char *Qg = a.q + bh * a.Sq * AROW;
     const char *dOg = a.d_o + bh * a.Sq * AROW;
     const float *lse_g = a.lse_r + bh * a.Sq, *dlt_g = a.delta + bh * a.Sq;
-    char *vslab = smem + 2 * KSL + wid * QSLAB;
+    char *vslab = smem + 2 * KNS * KSL + wid * QSLAB;
 
     frag_t kf[8];
     if (active) {
@@ -922,34 +1166,43 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dkv_v2_kernel(const AttnArgs 
     // lse[32] | delta[32] with one 4-byte-per-lane instruction.
     const int srow = wid * 4 + (lane >> 4), spos = lane & 15;
     const int schunk = spos ^ (((srow & 3) << 2) | ((srow >> 2) & 3));
-    auto stage = [&](int sl_, char *buf) {
-        const int64_t qs_ = (int64_t)sl_ * BQS;
-        const char *qsrc = Qg + (qs_ + srow) * AROW + schunk * 16;
-        const char *osrc = dOg + (qs_ + srow) * AROW + schunk * 16;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)qsrc,
-                                         (__attribute__((address_space(3))) void *)(buf + wid * 4 * AROW), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)osrc,
-                                         (__attribute__((address_space(3))) void *)(buf + BQS * AROW + wid * 4 * AROW), 16, 0, 0);
-        if (wid == 0) {
-            const float *src = lane < BQS ? lse_g + qs_ + lane : dlt_g + qs_ + lane - BQS;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(buf + 2 * BQS * AROW), 4, 0, 0);
+    const int ns = (int)(a.Sq / BQS);
+    auto stage = [&](int sl_, char *group) { // KNS consecutive slices -> one buffer group
+#pragma unroll
+        for (int j = 0; j < KNS; ++j) {
+            if (sl_ + j >= ns) break;
+            char *buf = group + j * KSL;
+            const int64_t qs_ = (int64_t)(sl_ + j) * BQS;
+            const char *qsrc = Qg + (qs_ + srow) * AROW + schunk * 16;
+            const char *osrc = dOg + (qs_ + srow) * AROW + schunk * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)qsrc,
+                                             (__attribute__((address_space(3))) void *)(buf + wid * 4 * AROW), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)osrc,
+                                             (__attribute__((address_space(3))) void *)(buf + BQS * AROW + wid * 4 * AROW), 16, 0, 0);
+            if (wid == j) {
+                const float *src = lane < BQS ? lse_g + qs_ + lane : dlt_g + qs_ + lane - BQS;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(buf + 2 * BQS * AROW), 4, 0, 0);
+            }
         }
     };
-    const int ns = (int)(a.Sq / BQS);
     int sl = (int)(k0 / BQS); // first slice holding a query >= the block's first key
     if (sl < ns) stage(sl, smem);
     __syncthreads(); // waits for the LDS-DMA (vmcnt) and the V slab writes
-    for (int it = 0; sl < ns; ++sl, ++it) {
-        const int64_t qs = (int64_t)sl * BQS;
-        const char *cur = smem + (it & 1) * KSL;
-        char *nxt = smem + ((it + 1) & 1) * KSL;
-        if (sl + 1 < ns) stage(sl + 1, nxt); // the buffer every wave finished reading at the last barrier
-        const bool skip = !active || qs + BQS - 1 < kw; // every query of the slice precedes this wave's keys
-        const bool diag = qs < kw + 31;
-        if (!skip) {
-            if (diag) kv_slice<BF, true>(cur, vslab, kf, ko, vo, dk, dv, c, qs, n, hl);
-            else kv_slice<BF, false>(cur, vslab, kf, ko, vo, dk, dv, c, qs, n, hl);
+    for (int it = 0; sl < ns; sl += KNS, ++it) {
+        const char *cur = smem + (it & 1) * KNS * KSL;
+        char *nxt = smem + ((it + 1) & 1) * KNS * KSL;
+        if (sl + KNS < ns) stage(sl + KNS, nxt); // the group every wave finished reading at the last barrier
+#pragma unroll
+        for (int j = 0; j < KNS; ++j) {
+            if (sl + j >= ns) break;
+            const int64_t qs = (int64_t)(sl + j) * BQS;
+            const bool skip = !active || qs + BQS - 1 < kw; // every query of the slice precedes this wave's keys
+            const bool diag = qs < kw + 31;
+            if (!skip) {
+                if (diag) kv_slice<BF, true>(cur + j * KSL, vslab, kf, ko, vo, dk, dv, c, qs, n, hl);
+                else kv_slice<BF, false>(cur + j * KSL, vslab, kf, ko, vo, dk, dv, c, qs, n, hl);
+            }
         }
         __syncthreads();
     }
@@ -1384,6 +1637,8 @@ extern "C" int kf_attn_fwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
     a.q = (const char *)q; a.k = (const char *)k; a.v = (const char *)v; a.out = (char *)o; a.lse = lse;
     a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.D = D;
     a.scale = 1.0f / sqrtf((float)D);
+    { const char *e = getenv("KF_ATTN_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.xcd_map = ((B * H) % 8 == 0) && !getenv("KF_ATTN_NO_XCD");
     if (mfma_ok(dtype, Sq, Skv, D)) {
         const bool use_v1 = getenv("KF_ATTN_FWD_V1") != nullptr; // A/B switch for the first-generation kernel
         if (use_v1) {
@@ -1397,12 +1652,34 @@ extern "C" int kf_attn_fwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
             KF_LAUNCH_CHECK();
             return KF_OK;
         }
-        const size_t lds = 8 * 32 * OPAD; // >= 2 * FBUF
-        dim3 grid((unsigned)((Sq + FQ - 1) / FQ), (unsigned)(B * H));
-        KF_PROF("attn_fwd_mfma", st);
+        if (!getenv("KF_ATTN_FWD_V2") && !a.dbg) { // default: the staggered-waves kernel; v2 (with its ablation switches) stays for A/B
+            const size_t lds3 = SRING * FBUF;
+            dim3 grid3((unsigned)(((Sq + FQ - 1) / FQ) * B * H));
+            KF_PROF("attn_fwd_mfma", st);
+            if ((rc = set_lds(attn_fwd_v3_kernel<true>, lds3)) != KF_OK) return rc;
+            if ((rc = set_lds(attn_fwd_v3_kernel<false>, lds3)) != KF_OK) return rc;
+            if (dtype == KF_BF16) attn_fwd_v3_kernel<true><<<grid3, FNT, lds3, st>>>(a);
+            else attn_fwd_v3_kernel<false><<<grid3, FNT, lds3, st>>>(a);
+            KF_LAUNCH_CHECK();
+            return KF_OK;
+        }
+        const size_t lds = (a.dbg & 8) ? 5 * FBUF : FRING * FBUF; // 96 KiB ring; the epilogue's 8 x 32 x OPAD slabs fit inside
+        dim3 grid((unsigned)(((Sq + FQ - 1) / FQ) * B * H));
+        KF_PROF("attn_fwd_mfma_v2", st);
         if ((rc = set_lds(attn_fwd_v2_kernel<true>, lds)) != KF_OK) return rc;
         if ((rc = set_lds(attn_fwd_v2_kernel<false>, lds)) != KF_OK) return rc;
-        if (dtype == KF_BF16) attn_fwd_v2_kernel<true><<<grid, FNT, lds, st>>>(a);
+        if (a.dbg && dtype == KF_BF16) { // timing-only ablations (wrong results): KF_ATTN_DBG = 1 noQK, 2 no softmax, 4 no PV, 8 no new DMA, 16 no barrier
+#define KF_DBG_CASE(N)                                                                         \
+    case N:                                                                                    \
+        if ((rc = set_lds(attn_fwd_v2_kernel<true, N>, lds)) != KF_OK) return rc;              \
+        attn_fwd_v2_kernel<true, N><<<grid, FNT, lds, st>>>(a);                                \
+        break;
+            switch (a.dbg) {
+                KF_DBG_CASE(1) KF_DBG_CASE(2) KF_DBG_CASE(4) KF_DBG_CASE(6) KF_DBG_CASE(7) KF_DBG_CASE(8) KF_DBG_CASE(16) KF_DBG_CASE(24) KF_DBG_CASE(32) KF_DBG_CASE(64)
+            default: KF_REQUIRE(false, KF_ERR_INVALID, "KF_ATTN_DBG=%d has no instantiation", a.dbg);
+            }
+#undef KF_DBG_CASE
+        } else if (dtype == KF_BF16) attn_fwd_v2_kernel<true><<<grid, FNT, lds, st>>>(a);
         else attn_fwd_v2_kernel<false><<<grid, FNT, lds, st>>>(a);
         KF_LAUNCH_CHECK();
         return KF_OK;
@@ -1457,6 +1734,7 @@ extern "C" int kf_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
     a.q = (const char *)q; a.k = (const char *)k; a.v = (const char *)v; a.o = (const char *)o; a.d_o = (const char *)d_o;
     a.dq = (char *)dq; a.dk = (char *)dk; a.dv = (char *)dv;
     a.lse_r = lse; a.delta = (float *)workspace;
+    a.xcd_map = ((B * H) % 8 == 0) && !getenv("KF_ATTN_NO_XCD");
     a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.D = D;
     a.scale = 1.0f / sqrtf((float)D);
     const int64_t nrows = B * H * Sq;
@@ -1488,7 +1766,7 @@ extern "C" int kf_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
             else attn_bwd_dkv_v3_kernel<false><<<gk, 256, K3LDS, st>>>(a);
             KF_LAUNCH_CHECK();
         } else {
-            dim3 gk2((unsigned)((Skv + KVB - 1) / KVB), (unsigned)(B * H));
+            dim3 gk2((unsigned)(((Skv + KVB - 1) / KVB) * B * H));
             if ((rc = set_lds(attn_bwd_dkv_v2_kernel<true>, KLDS)) != KF_OK) return rc;
             if ((rc = set_lds(attn_bwd_dkv_v2_kernel<false>, KLDS)) != KF_OK) return rc;
             KF_PROF("attn_bwd_dkv_mfma", st);
@@ -1503,7 +1781,7 @@ extern "C" int kf_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
             KF_LAUNCH_CHECK();
         } else {
             const size_t lds2 = QLDS;
-            dim3 gq2((unsigned)((Sq + FQ - 1) / FQ), (unsigned)(B * H));
+            dim3 gq2((unsigned)(((Sq + FQ - 1) / FQ) * B * H));
             if ((rc = set_lds(attn_bwd_dq_v2_kernel<true>, lds2)) != KF_OK) return rc;
             if ((rc = set_lds(attn_bwd_dq_v2_kernel<false>, lds2)) != KF_OK) return rc;
             KF_PROF("attn_bwd_dq_mfma", st);

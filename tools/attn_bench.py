@@ -44,7 +44,7 @@ def main():
     need = H.attn_bwd_workspace_bytes(H.BF16, B, Hh, S, S, D)
     ws = H.DevBuf(need)
     pair = B * Hh * S * S * D / 2.0
-    flops = {"attn_fwd_mfma": 4 * pair, "attn_fwd_mfma_v1": 4 * pair, "attn_bwd_dkv_mfma": 8 * pair, "attn_bwd_dq_mfma": 6 * pair, "attn_bwd_dq_mfma_v1": 6 * pair, "attn_bwd_dkv_mfma_v1": 8 * pair, "attn_bwd_dkv_mfma_v3": 8 * pair}
+    flops = {"attn_fwd_mfma": 4 * pair, "attn_fwd_mfma_v2": 4 * pair, "attn_fwd_mfma_v1": 4 * pair, "attn_bwd_dkv_mfma": 8 * pair, "attn_bwd_dq_mfma": 6 * pair, "attn_bwd_dq_mfma_v1": 6 * pair, "attn_bwd_dkv_mfma_v1": 8 * pair, "attn_bwd_dkv_mfma_v3": 8 * pair}
     variants = args.variants.split(",")
     results = {v: {} for v in variants}
     for r in range(args.rounds + 1):
@@ -53,7 +53,8 @@ def main():
                 del os.environ[e]
             if v != "default":
                 for kv in v.split("+"):
-                    os.environ[kv] = "1"
+                    k, _, val = kv.partition("=")
+                    os.environ[k] = val or "1"
             H.profile_reset()
             H.profile_enable(True)
             H.attn_fwd(H.BF16, B, Hh, S, S, D, bufs["q"].ptr, bufs["k"].ptr, bufs["v"].ptr, bufs["o"].ptr, lse.ptr)
