@@ -12,6 +12,8 @@
 // Arithmetic follows the reference exactly: operands are cast to the accumulate type of the common
 // dtype (float for half/bf16/float, double, int64 for integers, bool), combined, and cast to the
 // output dtype on store (accumulate_type.h:17-27, tensor_memory_access.h:13-37).
+#include <stdlib.h>
+
 #include "common.h"
 #include "offset_calc.h"
 
@@ -217,11 +219,66 @@ __global__ __launch_bounds__(kBlock) void ew_cast_kernel(const CastArgs<NIN + 1>
 }
 
 // ------------------------------------------------------------------------------------------
+// tiled transpose copy: the output walks memory along dim 0, the input along some other dim `j`
+// (permute(...).contiguous() of a matrix-like view). A 64 x 64 element tile goes through LDS so that
+// BOTH sides move whole coalesced rows: read with lanes along the input-contiguous dim, write with
+// lanes along the output-contiguous dim. Remaining dims are a batch walked by the offset calculator.
+// ------------------------------------------------------------------------------------------
+struct TransArgs {
+    const char *in;
+    char *out;
+    uint32_t n0, n1;            // extent of dim 0 (output-contiguous) and of dim j (input-contiguous)
+    uint32_t in_s0, out_s1;     // byte stride of the input along dim 0 / of the output along dim j
+    uint32_t tiles0, tiles1, nbatch;
+    OffsetCalc<2> bc;           // batch dims: [0] = out bytes, [1] = in bytes
+};
+
+template <typename U>
+__global__ __launch_bounds__(kBlock) void ew_transpose_kernel(const TransArgs a) {
+    constexpr int TD = 64;
+    __shared__ U tile[TD][TD + (sizeof(U) >= 4 ? 1 : 2)];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (uint32_t blk = blockIdx.x; blk < a.tiles0 * a.tiles1 * a.nbatch; blk += gridDim.x) {
+        const uint32_t bt = blk / (a.tiles0 * a.tiles1), rem = blk - bt * (a.tiles0 * a.tiles1);
+        const uint32_t t1 = rem / a.tiles0, t0 = rem - t1 * a.tiles0;
+        uint32_t boff[2];
+        a.bc.get(bt, boff);
+        const uint32_t i0 = t0 * TD, j0 = t1 * TD;
+        __syncthreads();
+        for (int r = ty; r < TD; r += 4) { // row r of the tile = index along dim 0; lanes along dim j
+            const uint32_t i = i0 + r, j = j0 + tx;
+            if (i < a.n0 && j < a.n1) tile[r][tx] = *(const U *)(a.in + boff[1] + (size_t)i * a.in_s0 + (size_t)j * sizeof(U));
+        }
+        __syncthreads();
+        for (int r = ty; r < TD; r += 4) { // row r = index along dim j; lanes along dim 0
+            const uint32_t j = j0 + r, i = i0 + tx;
+            if (i < a.n0 && j < a.n1) *(U *)(a.out + boff[0] + (size_t)j * a.out_s1 + (size_t)i * sizeof(U)) = tile[tx][r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// contiguous float-family conversion (f32 <-> bf16 <-> f16: Tensor::half()/bfloat16()/float()),
+// 8 elements per lane: 16-B accesses on the 16-bit side, 2 x 16 B on the f32 side
+// ------------------------------------------------------------------------------------------
+template <typename S, typename D>
+__global__ __launch_bounds__(kBlock) void ew_convert8_kernel(const S *in, D *out, int64_t n8) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n8; i += stride) {
+        const Pack<S, 8> v = *(const Pack<S, 8> *)(in + i * 8);
+        Pack<D, 8> o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.v[e] = from_acc<D>(to_acc<S>(v.v[e]));
+        *(Pack<D, 8> *)(out + i * 8) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------
 static inline int grid_for(int64_t nitems) {
     int64_t blocks = (nitems + kBlock - 1) / kBlock;
-    const int64_t cap = 256 * 8; // 8 blocks of 256 threads per CU
+    const int64_t cap = 256 * 8; // 8 blocks of 256 threads per CU (1024..8192 measured within noise of each other)
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (int)blocks;
@@ -285,6 +342,50 @@ static int launch_same(const kf_iter_desc *d, int op, uint64_t fill_bits, hipStr
         return KF_OK;
     }
     KF_REQUIRE(desc_is_32bit(d), KF_ERR_INDEX_RANGE, "kf_elementwise: strided descriptor is not 32-bit indexable");
+    if constexpr (MODE == 1) { // permute(...).contiguous(): a transposed walk goes through the LDS-tiled kernel
+        const int64_t es = sizeof(T);
+        int j = -1;
+        if (d->ndim >= 2 && d->stride_bytes[0][0] == es && d->stride_bytes[1][0] != es && d->shape[0] >= 16)
+            for (int i = 1; i < d->ndim; ++i)
+                if (d->stride_bytes[1][i] == es && d->shape[i] >= 16) { j = i; break; }
+        if (j > 0) {
+            TransArgs t;
+            memset(&t, 0, sizeof(t));
+            t.in = (const char *)d->data[1];
+            t.out = (char *)d->data[0];
+            t.n0 = (uint32_t)d->shape[0];
+            t.n1 = (uint32_t)d->shape[j];
+            t.in_s0 = (uint32_t)d->stride_bytes[1][0];
+            t.out_s1 = (uint32_t)d->stride_bytes[0][j];
+            t.tiles0 = (t.n0 + 63) / 64;
+            t.tiles1 = (t.n1 + 63) / 64;
+            kf_iter_desc bd; // the remaining dims
+            memset(&bd, 0, sizeof(bd));
+            bd.ntensors = 2;
+            bd.noutputs = 1;
+            int nb = 0;
+            int64_t nbatch = 1;
+            for (int i = 1; i < d->ndim; ++i) {
+                if (i == j) continue;
+                bd.shape[nb] = d->shape[i];
+                bd.stride_bytes[0][nb] = d->stride_bytes[0][i];
+                bd.stride_bytes[1][nb] = d->stride_bytes[1][i];
+                nbatch *= d->shape[i];
+                ++nb;
+            }
+            if (nb == 0) { bd.shape[0] = 1; nb = 1; }
+            bd.ndim = nb;
+            int two[2] = {0, 1};
+            const int64_t total = (int64_t)t.tiles0 * t.tiles1 * nbatch;
+            if (OffsetCalc<2>::build(t.bc, &bd, two, 1) && total < 0x7fffffffLL) {
+                t.nbatch = (uint32_t)nbatch;
+                const int grid = (int)(total < 256 * 16 ? total : 256 * 16);
+                ew_transpose_kernel<T><<<grid, kBlock, 0, st>>>(t);
+                KF_LAUNCH_CHECK();
+                return KF_OK;
+            }
+        }
+    }
     int vec = pick_vec(d, sizeof(T));
     if (vec != VMAX) vec = 1; // two instantiations only: full 16-B packs or scalar
     for (int t = 0; t < NT; ++t)
@@ -396,6 +497,26 @@ extern "C" int kf_elementwise(int op, const kf_iter_desc *d, int compute_dtype, 
 
     if (op == KF_EW_COPY) {
         if (d->dtype[1] == odt) return launch_raw_by_size<1, 1>(dtype_size(odt), d, 0, st);
+        {
+            const int idt = d->dtype[1];
+            const bool fam = (idt == KF_F32 || idt == KF_F16 || idt == KF_BF16) && (odt == KF_F32 || odt == KF_F16 || odt == KF_BF16);
+            if (fam && desc_contiguous(d) && numel % 8 == 0 && (uintptr_t)d->data[0] % 32 == 0 && (uintptr_t)d->data[1] % 32 == 0) {
+                KF_PROF("ew_convert", st);
+                const int64_t n8 = numel / 8;
+                const int g = grid_for(n8);
+#define KF_CVT(SC, ST, DC, DT) \
+    if (idt == SC && odt == DC) ew_convert8_kernel<ST, DT><<<g, kBlock, 0, st>>>((const ST *)d->data[1], (DT *)d->data[0], n8);
+                KF_CVT(KF_F32, float, KF_BF16, bf16_t)
+                KF_CVT(KF_F32, float, KF_F16, f16_t)
+                KF_CVT(KF_BF16, bf16_t, KF_F32, float)
+                KF_CVT(KF_F16, f16_t, KF_F32, float)
+                KF_CVT(KF_BF16, bf16_t, KF_F16, f16_t)
+                KF_CVT(KF_F16, f16_t, KF_BF16, bf16_t)
+#undef KF_CVT
+                KF_LAUNCH_CHECK();
+                return KF_OK;
+            }
+        }
         switch (acc_class(odt)) { // value is cast straight to the output dtype (unary_ops_kernel.cu:13-17)
         case 0: return launch_cast<float, 1, 1>(d, op, st);
         case 1: return launch_cast<double, 1, 1>(d, op, st);

@@ -221,3 +221,25 @@ def test_contiguous_beyond_int32_bytes():
     got = np.empty(1024, dtype=np.float32)
     H.check(H.lib().kf_memcpy_d2h(got.ctypes.data, c.ptr + 4 * (1 << 28), got.nbytes, None))
     assert np.array_equal(got, np.full(1024, -2.25, dtype=np.float32))
+
+
+def test_tiled_transpose_and_vector_convert_paths():
+    """permute(...).contiguous() through the LDS-tiled transpose kernel (ragged tiles, batch dims, every element
+    size) and the 8-wide float-family convert kernel — both must stay bit-exact."""
+    rng = np.random.default_rng(11)
+    for code in (H.U8, H.I16, H.F32, H.F64, H.BF16):
+        for shape, perm in (((70, 130), (1, 0)), ((3, 65, 129), (0, 2, 1)), ((5, 33, 4, 70), (3, 1, 2, 0)), ((2, 256, 64), (2, 0, 1)),
+                            ((17, 16), (1, 0))):
+            x = rand_of(rng, shape, code)
+            v = x.transpose(perm)
+            got = gpu_copy(Dev(v, code, base=x), Dev.empty(v.shape, code)).get()
+            assert np.array_equal(bits(got), bits(np.ascontiguousarray(v))), (code, shape, perm)
+    x = rand_of(rng, (4096, 4096), H.F32)  # multi-tile, exact
+    got = gpu_copy(Dev(x.T, base=x), Dev.empty((4096, 4096), H.F32)).get()
+    assert np.array_equal(got, x.T)
+    for cs in (H.F32, H.F16, H.BF16):
+        for n in (8, 1 << 16, (1 << 16) + 8):
+            x = rand_of(rng, (n,), cs)
+            for cd in (H.F32, H.F16, H.BF16):
+                got = gpu_copy(Dev(x, cs), Dev.empty((n,), cd)).get()
+                assert np.array_equal(bits(got), bits(O.convert(x, cd, src_code=cs))), (cs, cd, n)
