@@ -12,6 +12,8 @@
 //            are re-laid by a tiled transpose into caller-supplied scratch.
 //   f64 / ragged shapes: a plain LDS-tiled FMA kernel (the reference's only GEMM test is this
 //            case: f64 123x457x234, test/test_gemm.py:9-17).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace kf {
@@ -322,6 +324,218 @@ __global__ __launch_bounds__(256) void gemm_h_kernel(const GemmArgs g) {
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16 / f16, large shapes: 256 x 256 x 64 block tile, 8 waves (2 x 4, 128 x 64 per wave), MFMA 16x16x32,
+// two waves per SIMD running HALF A PHASE APART: while one group of four waves is in a matrix segment
+// (16 MFMAs) the other is in its load segment (fragment ds_reads + one half-tile of LDS-DMA), swapping at
+// every raw s_barrier. A K tile is cut into four half-tiles of 128 rows x 64 k, chosen so that each is read
+// in exactly ONE phase by every wave:
+//     HA0 = rows {wr*128 + 0..63}   (A0 fragments, phase 0)      HB0 = cols {wc*64 + 0..31}  (B0, phase 0)
+//     HA1 = rows {wr*128 + 64..127} (A1 fragments, phase 1)      HB1 = cols {wc*64 + 32..63} (B1, phase 2)
+// Quadrant order (A0,B0) (A1,B0) (A1,B1) (A0,B1): all four fragment sets stay in registers, so a half-tile's
+// LDS region is free one phase after its single read and is re-staged 5-6 phases before its next read:
+//     phase 0: stage HA1(T+1)   phase 1: HB1(T+1)   phase 2: HA0(T+2)   phase 3: HB0(T+2)
+// Every wave issues 2 DMA operations per phase, so ONE counted wait per phase, s_waitcnt vmcnt(8) (the four
+// youngest half-tiles stay in flight), retires exactly what the next phase reads; the barrier publishes it.
+// LDS: 2 K tiles x 4 half-tiles x 16 KiB = 128 KiB. Operands must be K-contiguous (A [M,K], B [N,K]).
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+constexpr int G_BM = 256, G_BN = 256, G_BK = 64, G_NT = 512;
+constexpr int G_HALF = 128 * G_BK * 2;      // 16 KiB
+constexpr int G_TILE = 4 * G_HALF;          // HA0 | HB0 | HA1 | HB1
+constexpr int G_LDS = 2 * G_TILE;           // 128 KiB
+
+template <bool BF>
+__device__ __forceinline__ f32x4 g_mfma16(typename HFrag<BF>::type a, typename HFrag<BF>::type b, f32x4 c) {
+    if constexpr (BF)
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+template <bool BF>
+__global__ __launch_bounds__(G_NT, 2) void gemm_h256_kernel(const GemmArgs g) {
+    using frag_t = typename HFrag<BF>::type;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wr = __builtin_amdgcn_readfirstlane(wid) >> 2, wc = __builtin_amdgcn_readfirstlane(wid) & 3;
+    const uint32_t tiles_n = (uint32_t)(g.N / G_BN);
+    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t m0 = (int64_t)(tile / tiles_n) * G_BM, n0 = (int64_t)(tile % tiles_n) * G_BN;
+    const int nt = (int)(g.K / G_BK);
+
+    // ---- LDS-DMA source pointers: wave w moves rows (2w + i) * 8 .. + 7 (i = 0, 1) of every half-tile
+    const char *srcA[2][2], *srcB[2][2]; // [half 0/1][i]
+    int ldsoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int hr = (wid * 2 + i) * 8 + (lane >> 3), pos = lane & 7;
+        const int chunk = pos ^ ((hr >> 1) & 7);
+        ldsoff[i] = (wid * 2 + i) * 8 * 128;
+        const int64_t arow = m0 + (hr >> 6) * 128 + (hr & 63), brow = n0 + (hr >> 5) * 64 + (hr & 31);
+        srcA[0][i] = (const char *)g.A + arow * g.lda * 2 + chunk * 16;
+        srcA[1][i] = srcA[0][i] + 64 * g.lda * 2;
+        srcB[0][i] = (const char *)g.B + brow * g.ldb * 2 + chunk * 16;
+        srcB[1][i] = srcB[0][i] + 32 * g.ldb * 2;
+    }
+    // which: 0 HA0, 1 HB0, 2 HA1, 3 HB1 (also the slot inside a tile buffer)
+    auto stage = [&](int which, int kt) {
+        const int64_t koff = (int64_t)(kt < nt ? kt : nt - 1) * G_BK * 2; // past the end: re-fetch the last tile (never read)
+        char *dst = smem + (kt & 1) * G_TILE + which * G_HALF;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const char *src = (which & 1) ? srcB[which >> 1][i] : srcA[which >> 1][i];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + koff),
+                                             (__attribute__((address_space(3))) void *)(dst + ldsoff[i]), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets: row r of a 16-row tile, k-chunk (ks*4 + lane>>4), XOR swizzle on (row>>1)&7
+    const int fr = lane & 15, fg = lane >> 4;
+    const int sw = (fr >> 1) & 7;
+    const int offk0 = fr * 128 + (((0 + fg) ^ sw) << 4), offk1 = fr * 128 + (((4 + fg) ^ sw) << 4);
+    const int abase = wr * 64 * 128, bbase = wc * 32 * 128; // this wave's rows inside HA* / HB*
+
+    f32x4 acc[4][8]; // [n-tile 0..3][m-tile 0..7]: D = B_frag x A_frag, i.e. C^T tiles (rows = n on registers)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    frag_t a0[4][2], a1[4][2], b0[2][2], b1[2][2];
+
+    // ---- prologue: the issues of "phases -6 .. -1"
+    stage(0, 0); stage(1, 0); stage(2, 0); stage(3, 0); stage(0, 1); stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier(); // waves 4-7 run half a phase behind waves 0-3
+    asm volatile("" ::: "memory");
+
+#define G_SEG_END()                            \
+    asm volatile("" ::: "memory");             \
+    __builtin_amdgcn_sched_barrier(0);         \
+    __builtin_amdgcn_s_barrier();              \
+    __builtin_amdgcn_sched_barrier(0);         \
+    asm volatile("" ::: "memory");
+
+    for (int kt = 0; kt < nt; ++kt) {
+        const char *buf = smem + (kt & 1) * G_TILE;
+        const char *ha0 = buf + abase, *hb0 = buf + G_HALF + bbase, *ha1 = buf + 2 * G_HALF + abase, *hb1 = buf + 3 * G_HALF + bbase;
+        // ---------------- phase 0: (A0, B0) ----------------
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            b0[t][0] = *(const frag_t *)(hb0 + t * 2048 + offk0);
+            b0[t][1] = *(const frag_t *)(hb0 + t * 2048 + offk1);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a0[t][0] = *(const frag_t *)(ha0 + t * 2048 + offk0);
+            a0[t][1] = *(const frag_t *)(ha0 + t * 2048 + offk1);
+        }
+        stage(2, kt + 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        G_SEG_END()
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[n][m] = g_mfma16<BF>(b0[n][ks], a0[m][ks], acc[n][m]);
+        __builtin_amdgcn_s_setprio(0);
+        G_SEG_END()
+        // ---------------- phase 1: (A1, B0) ----------------
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            a1[t][0] = *(const frag_t *)(ha1 + t * 2048 + offk0);
+            a1[t][1] = *(const frag_t *)(ha1 + t * 2048 + offk1);
+        }
+        stage(3, kt + 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        G_SEG_END()
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[n][4 + m] = g_mfma16<BF>(b0[n][ks], a1[m][ks], acc[n][4 + m]);
+        __builtin_amdgcn_s_setprio(0);
+        G_SEG_END()
+        // ---------------- phase 2: (A1, B1) ----------------
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            b1[t][0] = *(const frag_t *)(hb1 + t * 2048 + offk0);
+            b1[t][1] = *(const frag_t *)(hb1 + t * 2048 + offk1);
+        }
+        stage(0, kt + 2);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        G_SEG_END()
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[2 + n][4 + m] = g_mfma16<BF>(b1[n][ks], a1[m][ks], acc[2 + n][4 + m]);
+        __builtin_amdgcn_s_setprio(0);
+        G_SEG_END()
+        // ---------------- phase 3: (A0, B1): no fragment reads ----------------
+        stage(1, kt + 2);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        G_SEG_END()
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[2 + n][m] = g_mfma16<BF>(b1[n][ks], a0[m][ks], acc[2 + n][m]);
+        __builtin_amdgcn_s_setprio(0);
+        G_SEG_END()
+    }
+#undef G_SEG_END
+    if (wr == 0) __builtin_amdgcn_s_barrier(); // pairs with the extra barrier of waves 4-7
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue. acc[n][m][e] = C[m0 + wr*128 + m*16 + (lane & 15)][n0 + wc*64 + n*16 + (lane >> 4)*4 + e]:
+    // four consecutive columns per lane -> one 8-byte store per accumulator tile
+    uint16_t *C = (uint16_t *)g.C;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int64_t col = n0 + wc * 64 + n * 16 + fg * 4;
+        float bias[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.epilogue == KF_EPI_BIAS_ROW) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint16_t bb = ((const uint16_t *)g.bias)[col + e];
+                bias[e] = BF ? bf16_to_f32(bf16_t{bb}) : f16_to_f32(f16_t{bb});
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int64_t row = m0 + wr * 128 + m * 16 + fr;
+            uint16_t *dst = C + row * g.ldc + col;
+            uint16_t h[4];
+            uint2 old = {0, 0};
+            if (g.beta != 0.f) old = *(const uint2 *)dst;
+            const uint16_t o16[4] = {(uint16_t)(old.x & 0xffff), (uint16_t)(old.x >> 16), (uint16_t)(old.y & 0xffff), (uint16_t)(old.y >> 16)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = g.alpha * acc[n][m][e];
+                if (g.beta != 0.f) v += g.beta * (BF ? bf16_to_f32(bf16_t{o16[e]}) : f16_to_f32(f16_t{o16[e]}));
+                v += bias[e];
+                h[e] = BF ? f32_to_bf16(v).x : f32_to_f16(v).x;
+            }
+            uint2 w;
+            w.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+            w.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+            *(uint2 *)dst = w;
+        }
+    }
+}
+
 // tiled 16-bit transpose: dst[c][r] = src[r][c]; 64x64 tiles through LDS (+1 pad), bit-exact
 __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t *src, int64_t ld_src, uint16_t *dst, int64_t ld_dst,
                                                            int64_t R, int64_t Cc) {
@@ -404,9 +618,19 @@ extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N
             g.B = ws;
             g.ldb = K;
         }
+        if (M % G_BM == 0 && N % G_BN == 0 && K >= G_BK && g.ldc % 4 == 0 && (uintptr_t)C % 8 == 0 && !getenv("KF_GEMM_128")) {
+            const unsigned grid2 = (unsigned)((M / G_BM) * (N / G_BN));
+            KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_h256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+            KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_h256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+            KF_PROF(dtype == KF_BF16 ? "gemm_bf16_mfma" : "gemm_f16_mfma", st);
+            if (dtype == KF_BF16) gemm_h256_kernel<true><<<grid2, G_NT, G_LDS, st>>>(g);
+            else gemm_h256_kernel<false><<<grid2, G_NT, G_LDS, st>>>(g);
+            KF_LAUNCH_CHECK();
+            return KF_OK;
+        }
         const unsigned grid = (unsigned)((M / H_BM) * (N / H_BN));
         const size_t lds = 4 * H_TILE_BYTES;
-        KF_PROF(dtype == KF_BF16 ? "gemm_bf16_mfma" : "gemm_f16_mfma", st);
+        KF_PROF(dtype == KF_BF16 ? "gemm_bf16_mfma_128" : "gemm_f16_mfma_128", st);
         if (dtype == KF_BF16) {
             static bool attr_bf = false;
             if (!attr_bf) {

@@ -96,7 +96,7 @@ def test_16bit_exact_integers_catch_layout_bugs(code):
     """Small integers are exact in bf16/f16 and in f32 accumulation: any fragment/lane/transposed-read
     mistake shows up as a wrong integer. B is asymmetric, A is not the identity."""
     rng = np.random.default_rng(6)
-    M, N, K = 256, 384, 192
+    M, N, K = (256, 384, 192) if code == H.F16 else (512, 768, 448)  # f16: 128-tile kernel; bf16: 256-tile phase-staggered kernel
     a = rng.integers(-3, 4, (M, K)).astype(np.float32)
     b = (rng.integers(-2, 3, (K, N)) + (np.arange(N)[None, :] % 3 == 0)).astype(np.float32)
     want = a.astype(np.float64) @ b.astype(np.float64)
@@ -111,7 +111,7 @@ def test_16bit_exact_integers_catch_layout_bugs(code):
 
 
 @pytest.mark.parametrize("code,eps", [(H.BF16, 2.0 ** -8), (H.F16, 2.0 ** -11)])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 512, 320), (384, 128, 1024), (100, 130, 70), (64, 64, 64)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 512, 320), (384, 128, 1024), (100, 130, 70), (64, 64, 64), (512, 256, 64), (256, 256, 128), (768, 512, 2048)])
 def test_16bit_vs_oracle(code, eps, M, N, K):
     rng = np.random.default_rng(M + N + K + code)
     a = O.from_float(rng.uniform(-1, 1, (M, K)).astype(np.float32), code)
