@@ -536,20 +536,45 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_h256_kernel(const GemmArgs g) {
     }
 }
 
-// tiled 16-bit transpose: dst[c][r] = src[r][c]; 64x64 tiles through LDS (+1 pad), bit-exact
+// tiled 16-bit transpose: dst[c][r] = src[r][c]; 64x64 tiles through LDS, bit-exact. Full tiles with 16-byte
+// aligned rows move 16 B per lane on both the read and the write side (the LDS tile is written transposed,
+// 2 bytes at a time, and read back along the new contiguous dim); ragged tiles fall back to 2-byte accesses.
 __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t *src, int64_t ld_src, uint16_t *dst, int64_t ld_dst,
                                                            int64_t R, int64_t Cc) {
-    __shared__ uint16_t tile[64][66];
+    __shared__ __attribute__((aligned(16))) uint16_t tile[64][72]; // [c][r], 144-B rows keep 16-B alignment
     const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int t = threadIdx.x;
+    const bool fast = r0 + 64 <= R && c0 + 64 <= Cc && ld_src % 8 == 0 && ld_dst % 8 == 0 && ((uintptr_t)src % 16 == 0) &&
+                      ((uintptr_t)dst % 16 == 0);
+    if (fast) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = t + 256 * i, r = id >> 3, cq = id & 7; // row r, columns 8*cq .. 8*cq+7
+            const uint4 v = *(const uint4 *)(src + (r0 + r) * ld_src + c0 + cq * 8);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                tile[cq * 8 + 2 * e][r] = (uint16_t)(w[e] & 0xffff);
+                tile[cq * 8 + 2 * e + 1][r] = (uint16_t)(w[e] >> 16);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = t + 256 * i, c = id >> 3, rq = id & 7;
+            *(uint4 *)(dst + (c0 + c) * ld_dst + r0 + rq * 8) = *(const uint4 *)&tile[c][rq * 8];
+        }
+        return;
+    }
+    const int tx = t & 63, ty = t >> 6;
     for (int i = ty; i < 64; i += 4) {
         const int64_t r = r0 + i, c = c0 + tx;
-        if (r < R && c < Cc) tile[i][tx] = src[r * ld_src + c];
+        if (r < R && c < Cc) tile[tx][i] = src[r * ld_src + c];
     }
     __syncthreads();
     for (int i = ty; i < 64; i += 4) {
         const int64_t c = c0 + i, r = r0 + tx;
-        if (r < R && c < Cc) dst[c * ld_dst + r] = tile[tx][i];
+        if (r < R && c < Cc) dst[c * ld_dst + r] = tile[i][tx];
     }
 }
 
