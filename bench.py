@@ -104,7 +104,7 @@ def cpu_baseline():
     from oracle import oracle as O
     cores = O.num_threads()
     rng = np.random.default_rng(1003)
-    heads, rows, n = max(1, min(cores, 64)), 512, GEMM_N  # ~10-20 s of CPU work on 8..256 cores
+    heads, rows, n = max(1, min(cores, 128)), 512, GEMM_N  # ~10-20 s of CPU work on 8..256 cores
     q, k, v, go = (bf16_random(rng, (1, heads, AS, AD)) for _ in range(4))
     t0 = time.perf_counter()
     O.attn_fwd(q, k, v, code=O.BF16)
