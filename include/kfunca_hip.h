@@ -157,6 +157,23 @@ enum {
 int kf_reduce_workspace_bytes(const kf_iter_desc *desc, size_t *bytes);
 int kf_reduce(int op, const kf_iter_desc *desc, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---- moments: replaces mean_var_kernel (reduce_ops_kernel.h:7, reduce_ops_kernel.cu:61-153) and
+ *      norm_stat_kernel (norm_ops_kernel.h, norm_ops_kernel.cu:6-61) ------------------------------------ */
+enum {
+    KF_MOM_VAR = 0,   /* out0 = M2 / max(n - correction, 0)            (mean_var, take_sqrt = false) */
+    KF_MOM_STD = 1,   /* out0 = sqrt(M2 / max(n - correction, 0))      (mean_var, take_sqrt = true)  */
+    KF_MOM_INVSTD = 2 /* out0 = 1 / sqrt(M2 / n + eps)                 (norm_stat, welford_norm.h:183) */
+};
+/*
+ * desc: 2 outputs + 1 input in the reference iterator's order (reduce_ops.cpp:24-25): [0] = the variance-like
+ * output, [1] = the mean, [2] = the input; both outputs reduce the same dims (stride 0 there).
+ * Floating dtypes only; the outputs have the input's dtype, or f32 for f16 / bf16 inputs.
+ * Scratch as for kf_reduce (query kf_reduce_moments_workspace_bytes).
+ */
+int kf_reduce_moments_workspace_bytes(const kf_iter_desc *desc, size_t *bytes);
+int kf_reduce_moments(int mode, const kf_iter_desc *desc, double correction, double eps, void *workspace,
+                      size_t workspace_bytes, void *stream);
+
 /* ---- index_put_: replaces index_ops_kernel.h:5 --------------------------------------------- */
 /*
  * desc operands: [0] = self viewed with stride 0 (index_ops.cpp:23-25), [1] = values,

@@ -51,6 +51,20 @@ void run_reduce(TensorIterator &iter, int op) {
     // scratch returns to the cache here; reuse is stream-ordered behind the kernel that reads it
 }
 
+// two-output statistics reduction: iterator outputs are (variance-like, mean) as in reduce_ops.cpp:24
+void run_moments(TensorIterator &iter, int mode, double correction, double eps) {
+    if (iter.num_output_elements() == 0) return;
+    CHECK_FAIL(iter.can_use_32bit_indexing(), "reduction over more than 2^31 bytes per operand is not supported yet");
+    kf_iter_desc d;
+    iter.geometry().to_desc(d);
+    size_t need = 0;
+    DEV_CALL(kf_reduce_moments_workspace_bytes(&d, &need));
+    const int device = iter.device(0);
+    DataPtr scratch;
+    if (need) scratch = DeviceAllocator::GetInstance()->allocate(need, device);
+    DEV_CALL(kf_reduce_moments(mode, &d, correction, eps, scratch.get(), need, dev::stream(device)));
+}
+
 [[noreturn]] void out_of_scope(const char *what) {
     CHECK_FAIL(false, what, " is outside the tensor-kernel hot path this build covers (SURVEY.md §8f); not implemented");
     std::abort();
@@ -135,8 +149,30 @@ Tensor mean(const Tensor &self, int64_t reduce_dim) {
     return out;
 }
 
-std::tuple<Tensor, Tensor> mean_var(const Tensor &, int64_t, bool) { out_of_scope("mean_var"); }
-std::tuple<Tensor, Tensor> norm_stat(const Tensor &, int64_t) { out_of_scope("norm_stat"); }
+// reduce_ops.cpp:22-28: returns (mean, var | std) with the unbiased divisor (correction = 1), keepdim, input dtype
+std::tuple<Tensor, Tensor> mean_var(const Tensor &self, int64_t reduce_dim, bool take_sqrt) {
+    CHECK_FAIL(self.defined());
+    CHECK_FAIL(is_floating_type(self.dtype()), "Unsupported ScalarType ", self.dtype()); // DISPATCH_FLOATING_TYPES, reduce_ops_kernel.cu:149-153
+    Tensor mean, var;
+    auto iter = TensorIterator().add_output(var).add_output(mean).add_input(self).build_for_reduce(reduce_dim);
+    run_moments(iter, take_sqrt ? KF_MOM_STD : KF_MOM_VAR, /*correction=*/1.0, 0.0);
+    return std::make_tuple(mean, var);
+}
+
+// norm_ops.cpp:8-10 / norm_ops_kernel.cu:6-61: (mean, 1/sqrt(biased var + 1e-12)) in the accumulate dtype.
+// The reference accepts only dim == 0 of a 2-D tensor (norm_ops_kernel.cu:8); any dim of any rank works here.
+std::tuple<Tensor, Tensor> norm_stat(const Tensor &self, int64_t dim) {
+    CHECK_FAIL(self.defined());
+    CHECK_FAIL(is_floating_type(self.dtype()), "Unsupported ScalarType ", self.dtype());
+    CHECK_FAIL(dim >= -self.dim() && dim < self.dim(), "dim ", dim, " out of range");
+    if (dim < 0) dim += self.dim();
+    const ScalarType acc = accumulate_type(self.dtype());
+    Tensor save_mean = empty_like_reduced(self, (int)dim, acc);
+    Tensor save_invstd = empty_like_reduced(self, (int)dim, acc);
+    auto iter = TensorIterator().add_output(save_invstd).add_output(save_mean).add_input(self).resize_outputs(false).build_for_reduce(dim);
+    run_moments(iter, KF_MOM_INVSTD, 0.0, /*eps=*/1e-12);
+    return std::make_tuple(save_mean, save_invstd);
+}
 std::tuple<Tensor, Tensor> sort(const Tensor &, int64_t, bool) { out_of_scope("sort"); }
 std::tuple<Tensor, Tensor> topk(const Tensor &, int64_t, int64_t, bool) { out_of_scope("topk"); }
 

@@ -1,4 +1,4 @@
-// sum / mean reductions for gfx950 (keepdim over one logical dim, any layout).
+// sum / mean / moment (mean + variance) reductions for gfx950 (keepdim over one logical dim, any layout).
 //
 // Replaces the reference's reduce engine (src/device/utils/tensor_reduce.h:35-1083 driven by
 // src/device/reduce_ops_kernel.cu:6-59). Native wave64 design rather than its 32-lane one:
@@ -17,6 +17,12 @@
 // double for double, int64 for integers (identical to in-dtype wraparound after truncation).
 // mean multiplies by the reference's factor = nout/numel evaluated in the input dtype
 // (reduce_ops_kernel.cu:49-53) — for integer dtypes that is an integer quotient (0 unless R == 1).
+// Moments (mean_var_kernel, reduce_ops_kernel.cu:61-153, and norm_stat_kernel, norm_ops_kernel.cu:6-61) run on
+// the same three paths with a (mean, M2, n) accumulator: a lane folds each 16-byte pack into its running
+// triple with Chan's pairwise update (one reciprocal per pack instead of the reference's one division per
+// element, WelfordOps::reduce), lanes / row groups / splits combine with the same formula
+// (WelfordOps::combine), and the projection writes two outputs: var | sqrt(var) | 1/sqrt(var_biased + eps),
+// and the mean.
 #include <type_traits>
 
 #include "common.h"
@@ -52,16 +58,10 @@ template <> __device__ __forceinline__ double shfl_xor_acc<double>(double v, int
     return __longlong_as_double(shfl_xor_acc<int64_t>(b, m));
 }
 
-template <typename A>
-struct Project {
-    A factor;   // mean: nout/numel in the input dtype; sum: 1
-    int scale;  // 0: sum (no multiply)
-    __device__ __forceinline__ A operator()(A v) const { return scale ? v * factor : v; }
-};
-
 struct RedArgs {
     const char *in;
     char *out;
+    char *out1;        // moments: the mean output (out = variance-like output)
     void *ws;          // partials [nsplit][nout] of the accumulate type (nsplit > 1)
     int64_t R;         // reduced extent
     int64_t r_stride;  // bytes between consecutive reduced elements
@@ -70,25 +70,109 @@ struct RedArgs {
     uint32_t nouter;   // outer path: outputs beyond dim 1
     int nsplit;
     int tx;            // inner path: lanes per row (power of two <= 256)
-    OffsetCalc<2> oc;  // output-dims calculator: [0] = out bytes, [1] = in bytes
+    OffsetCalc<3> oc;  // output-dims calculator: [0] = out bytes, [1] = in bytes, [2] = out1 bytes
     OffsetCalc<1> rc;  // generic path: reduced-dims calculator (in bytes)
     uint32_t rtot;     // generic path: total reduced elements
+};
+
+// ---- reduction policies ------------------------------------------------------------------------
+// Ops::A accumulator, Ops::add_pack folds VEC loaded elements, Ops::comb merges two accumulators (the
+// engine fixes the order, so results are reproducible), Ops::Fin is the projection + store.
+template <typename T>
+struct SumOps {
+    using X = typename RAcc<T>::type;
+    using A = X;
+    struct Fin {
+        A factor;   // mean: nout/numel in the input dtype; sum: 1
+        int scale;  // 0: sum (no multiply)
+        __device__ __forceinline__ void store(const RedArgs &a, uint32_t o0, uint32_t, uint32_t e, A v) const {
+            r_store<T>(a.out + o0 + e * sizeof(T), scale ? v * factor : v);
+        }
+    };
+    static __device__ __forceinline__ A zero() { return A(0); }
+    template <int VEC> static __device__ __forceinline__ void add_pack(A &a, const X (&x)[VEC]) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a += x[e];
+    }
+    static __device__ __forceinline__ A comb(A a, A b) { return a + b; }
+    static __device__ __forceinline__ A shfl(A a, int m) { return shfl_xor_acc<A>(a, m); }
+};
+
+template <typename S> __device__ __forceinline__ S fast_rcp(S v) { return S(1) / v; }
+template <> __device__ __forceinline__ float fast_rcp<float>(float v) { return __frcp_rn(v); }
+
+template <typename T>
+struct MomentOps {
+    using X = typename RAcc<T>::type; // float | double
+    struct A { X mean, m2, n; };
+    struct Fin {
+        X correction, eps;
+        int mode;      // KF_MOM_VAR | KF_MOM_STD | KF_MOM_INVSTD
+        int out_f32;   // 16-bit inputs may write f32 statistics (the reference's acc_type outputs, norm_ops_kernel.cu:13-15)
+        __device__ __forceinline__ void put(char *p, uint32_t e, X v) const {
+            if (out_f32) *(float *)(p + e * 4) = (float)v;
+            else r_store<T>(p + e * sizeof(T), v);
+        }
+        __device__ __forceinline__ void store(const RedArgs &a, uint32_t o0, uint32_t o1, uint32_t e, A v) const {
+            X r;
+            if (mode == KF_MOM_INVSTD) {
+                r = X(1) / sqrt(v.m2 / v.n + eps); // welford_norm.h:183
+            } else {
+                const X div = v.n > correction ? v.n - correction : X(0); // WelfordOps::project, reduce_ops_kernel.cu:122-128
+                r = v.m2 / div;
+                if (mode == KF_MOM_STD) r = sqrt(r);
+            }
+            put(a.out + o0, e, r);
+            put(a.out1 + o1, e, v.mean);
+        }
+    };
+    static __device__ __forceinline__ A zero() { return A{X(0), X(0), X(0)}; }
+    template <int VEC> static __device__ __forceinline__ void add_pack(A &a, const X (&x)[VEC]) {
+        X pm = x[0];
+#pragma unroll
+        for (int e = 1; e < VEC; ++e) pm += x[e];
+        pm *= X(1) / X(VEC);
+        X pm2 = X(0);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) pm2 += (x[e] - pm) * (x[e] - pm);
+        const X n1 = a.n + X(VEC), w = X(VEC) * fast_rcp<X>(n1), d = pm - a.mean;
+        a.mean += d * w;
+        a.m2 += pm2 + d * d * a.n * w;
+        a.n = n1;
+    }
+    static __device__ __forceinline__ A comb(A a, A b) { // WelfordOps::combine, reduce_ops_kernel.cu:104-121
+        const X n = a.n + b.n;
+        if (n == X(0)) return a;
+        const X w = b.n / n, d = b.mean - a.mean;
+        return A{a.mean + d * w, a.m2 + b.m2 + d * d * a.n * w, n};
+    }
+    static __device__ __forceinline__ A shfl(A a, int m) {
+        return A{shfl_xor_acc<X>(a.mean, m), shfl_xor_acc<X>(a.m2, m), shfl_xor_acc<X>(a.n, m)};
+    }
 };
 
 template <typename T, int VEC>
 struct alignas(sizeof(T) * VEC) RPack { T v[VEC]; };
 
+template <typename Ops, typename T, int VEC>
+__device__ __forceinline__ void fold_pack(typename Ops::A &acc, const RPack<T, VEC> &p) {
+    typename Ops::X x[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) x[e] = r_load<T>((const char *)&p.v[e]);
+    Ops::template add_pack<VEC>(acc, x);
+}
+
 // ---- inner: reduced dim contiguous ---------------------------------------------------------
-template <typename T, int VEC>
-__global__ __launch_bounds__(kRB) void reduce_inner_kernel(const RedArgs a, const Project<typename RAcc<T>::type> proj) {
-    using A = typename RAcc<T>::type;
+template <typename T, typename Ops, int VEC>
+__global__ __launch_bounds__(kRB) void reduce_inner_kernel(const RedArgs a, const typename Ops::Fin fin) {
+    using A = typename Ops::A;
     __shared__ A smem[kRB];
     const int tx = a.tx, ty = kRB / tx;
     const int lx = threadIdx.x % tx, ly = threadIdx.x / tx;
     const uint32_t o = blockIdx.x * ty + ly;
     const bool live = o < a.nout;
-    A acc0 = A(0), acc1 = A(0), acc2 = A(0), acc3 = A(0);
-    uint32_t off[2] = {0, 0};
+    A acc0 = Ops::zero(), acc1 = Ops::zero(), acc2 = Ops::zero(), acc3 = Ops::zero();
+    uint32_t off[3] = {0, 0, 0};
     if (live) {
         a.oc.get(o, off);
         const int64_t chunk = ((a.R / VEC + a.nsplit - 1) / a.nsplit) * VEC;
@@ -102,46 +186,43 @@ __global__ __launch_bounds__(kRB) void reduce_inner_kernel(const RedArgs a, cons
             RPack<T, VEC> p1 = *(const RPack<T, VEC> *)(row + (r + step) * sizeof(T));
             RPack<T, VEC> p2 = *(const RPack<T, VEC> *)(row + (r + 2 * step) * sizeof(T));
             RPack<T, VEC> p3 = *(const RPack<T, VEC> *)(row + (r + 3 * step) * sizeof(T));
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                acc0 += r_load<T>((const char *)&p0.v[e]);
-                acc1 += r_load<T>((const char *)&p1.v[e]);
-                acc2 += r_load<T>((const char *)&p2.v[e]);
-                acc3 += r_load<T>((const char *)&p3.v[e]);
-            }
+            fold_pack<Ops, T, VEC>(acc0, p0);
+            fold_pack<Ops, T, VEC>(acc1, p1);
+            fold_pack<Ops, T, VEC>(acc2, p2);
+            fold_pack<Ops, T, VEC>(acc3, p3);
         }
         for (; r < r1; r += step) {
             RPack<T, VEC> p0 = *(const RPack<T, VEC> *)(row + r * sizeof(T));
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) acc0 += r_load<T>((const char *)&p0.v[e]);
+            fold_pack<Ops, T, VEC>(acc0, p0);
         }
     }
-    A acc = (acc0 + acc1) + (acc2 + acc3);
+    A acc = Ops::comb(Ops::comb(acc0, acc1), Ops::comb(acc2, acc3));
     if (tx <= kWave) {
-        for (int m = tx >> 1; m > 0; m >>= 1) acc += shfl_xor_acc<A>(acc, m);
+        for (int m = tx >> 1; m > 0; m >>= 1) acc = Ops::comb(acc, Ops::shfl(acc, m));
     } else {
         smem[threadIdx.x] = acc;
         __syncthreads();
         for (int s = tx >> 1; s >= kWave; s >>= 1) {
-            if (lx < s) smem[threadIdx.x] += smem[threadIdx.x + s];
+            if (lx < s) smem[threadIdx.x] = Ops::comb(smem[threadIdx.x], smem[threadIdx.x + s]);
             __syncthreads();
         }
         acc = smem[threadIdx.x];
         if (lx < kWave)
-            for (int m = kWave >> 1; m > 0; m >>= 1) acc += shfl_xor_acc<A>(acc, m);
+            for (int m = kWave >> 1; m > 0; m >>= 1) acc = Ops::comb(acc, Ops::shfl(acc, m));
     }
     if (live && lx == 0) {
         if (a.nsplit == 1)
-            r_store<T>(a.out + off[0], proj(acc));
+            fin.store(a, off[0], off[2], 0, acc);
         else
             ((A *)a.ws)[(size_t)blockIdx.y * a.nout + o] = acc;
     }
 }
 
 // ---- outer: reduced dim strided, dim 1 contiguous (column sums) ------------------------------
-template <typename T, int VEC>
-__global__ __launch_bounds__(kRB) void reduce_outer_kernel(const RedArgs a, const Project<typename RAcc<T>::type> proj) {
-    using A = typename RAcc<T>::type;
+template <typename T, typename Ops, int VEC>
+__global__ __launch_bounds__(kRB) void reduce_outer_kernel(const RedArgs a, const typename Ops::Fin fin) {
+    using A = typename Ops::A;
+    using X = typename Ops::X;
     __shared__ A smem[3][kWave][VEC];
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6; // 64 column-lanes x 4 row groups
     const int64_t c = ((int64_t)blockIdx.x * kWave + lx) * VEC;
@@ -150,13 +231,13 @@ __global__ __launch_bounds__(kRB) void reduce_outer_kernel(const RedArgs a, cons
     const int64_t r0 = (int64_t)blockIdx.y * chunk;
     const int64_t r1 = r0 + chunk < a.R ? r0 + chunk : a.R;
     for (uint32_t z = blockIdx.z; z < a.nouter; z += gridDim.z) {
-        uint32_t off[2];
+        uint32_t off[3];
         a.oc.get(z, off); // oc walks dims >= 2 here
         A acc[4][VEC];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) acc[u][e] = A(0);
+            for (int e = 0; e < VEC; ++e) acc[u][e] = Ops::zero();
         if (live) {
             const char *col = a.in + off[1] + c * sizeof(T);
             int64_t r = r0 + ly;
@@ -167,17 +248,23 @@ __global__ __launch_bounds__(kRB) void reduce_outer_kernel(const RedArgs a, cons
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int e = 0; e < VEC; ++e) acc[u][e] += r_load<T>((const char *)&p[u].v[e]);
+                    for (int e = 0; e < VEC; ++e) {
+                        const X x[1] = {r_load<T>((const char *)&p[u].v[e])};
+                        Ops::template add_pack<1>(acc[u][e], x);
+                    }
             }
             for (; r < r1; r += 4) {
                 RPack<T, VEC> p0 = *(const RPack<T, VEC> *)(col + r * a.r_stride);
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) acc[0][e] += r_load<T>((const char *)&p0.v[e]);
+                for (int e = 0; e < VEC; ++e) {
+                    const X x[1] = {r_load<T>((const char *)&p0.v[e])};
+                    Ops::template add_pack<1>(acc[0][e], x);
+                }
             }
         }
         A tot[VEC];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) tot[e] = (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
+        for (int e = 0; e < VEC; ++e) tot[e] = Ops::comb(Ops::comb(acc[0][e], acc[1][e]), Ops::comb(acc[2][e], acc[3][e]));
         __syncthreads();
         if (ly > 0)
 #pragma unroll
@@ -185,10 +272,10 @@ __global__ __launch_bounds__(kRB) void reduce_outer_kernel(const RedArgs a, cons
         __syncthreads();
         if (ly == 0 && live) {
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) tot[e] += (smem[0][lx][e] + smem[1][lx][e]) + smem[2][lx][e];
+            for (int e = 0; e < VEC; ++e) tot[e] = Ops::comb(tot[e], Ops::comb(Ops::comb(smem[0][lx][e], smem[1][lx][e]), smem[2][lx][e]));
             if (a.nsplit == 1) {
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) r_store<T>(a.out + off[0] + (c + e) * sizeof(T), proj(tot[e]));
+                for (int e = 0; e < VEC; ++e) fin.store(a, off[0], off[2], (uint32_t)(c + e), tot[e]);
             } else {
                 A *w = (A *)a.ws + (size_t)blockIdx.y * a.nout + (size_t)z * a.C + c;
 #pragma unroll
@@ -199,40 +286,43 @@ __global__ __launch_bounds__(kRB) void reduce_outer_kernel(const RedArgs a, cons
 }
 
 // second stage: fold partials[nsplit][nout] in split order
-template <typename T>
-__global__ __launch_bounds__(kRB) void reduce_fold_kernel(const RedArgs a, const Project<typename RAcc<T>::type> proj, int outer_layout) {
-    using A = typename RAcc<T>::type;
+template <typename T, typename Ops>
+__global__ __launch_bounds__(kRB) void reduce_fold_kernel(const RedArgs a, const typename Ops::Fin fin, int outer_layout) {
+    using A = typename Ops::A;
     const uint32_t o = blockIdx.x * kRB + threadIdx.x;
     if (o >= a.nout) return;
-    A acc = A(0);
-    for (int s = 0; s < a.nsplit; ++s) acc += ((const A *)a.ws)[(size_t)s * a.nout + o];
-    uint32_t off[2];
+    A acc = ((const A *)a.ws)[o];
+    for (int s = 1; s < a.nsplit; ++s) acc = Ops::comb(acc, ((const A *)a.ws)[(size_t)s * a.nout + o]);
+    uint32_t off[3];
+    uint32_t c = 0;
     if (outer_layout) { // o = z * C + c
-        const uint32_t z = o / (uint32_t)a.C, c = o - z * (uint32_t)a.C;
+        const uint32_t z = o / (uint32_t)a.C;
+        c = o - z * (uint32_t)a.C;
         a.oc.get(z, off);
-        off[0] += c * sizeof(T);
     } else {
         a.oc.get(o, off);
     }
-    r_store<T>(a.out + off[0], proj(acc));
+    fin.store(a, off[0], off[2], c, acc);
 }
 
 // ---- generic: one lane per output -----------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(kRB) void reduce_generic_kernel(const RedArgs a, const Project<typename RAcc<T>::type> proj) {
-    using A = typename RAcc<T>::type;
+template <typename T, typename Ops>
+__global__ __launch_bounds__(kRB) void reduce_generic_kernel(const RedArgs a, const typename Ops::Fin fin) {
+    using A = typename Ops::A;
+    using X = typename Ops::X;
     const uint32_t o = blockIdx.x * kRB + threadIdx.x;
     if (o >= a.nout) return;
-    uint32_t off[2];
+    uint32_t off[3];
     a.oc.get(o, off);
     const char *base = a.in + off[1];
-    A acc = A(0);
+    A acc = Ops::zero();
     for (uint32_t r = 0; r < a.rtot; ++r) {
         uint32_t ro[1];
         a.rc.get(r, ro);
-        acc += r_load<T>(base + ro[0]);
+        const X x[1] = {r_load<T>(base + ro[0])};
+        Ops::template add_pack<1>(acc, x);
     }
-    r_store<T>(a.out + off[0], proj(acc));
+    fin.store(a, off[0], off[2], 0, acc);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -256,11 +346,26 @@ static int pow2_floor(int64_t v) {
     return p;
 }
 
-static int make_plan(const kf_iter_desc *d, Plan &p) {
-    KF_REQUIRE(d->noutputs == 1 && d->ntensors == 2, KF_ERR_INVALID, "kf_reduce: wants 1 output + 1 input");
+// `moments`: 2 outputs (variance-like, mean) + 1 input, in the iterator's order (reduce_ops.cpp:24-25)
+static int make_plan(const kf_iter_desc *d, Plan &p, bool moments = false) {
+    const int in = moments ? 2 : 1;
+    if (moments) {
+        KF_REQUIRE(d->noutputs == 2 && d->ntensors == 3, KF_ERR_INVALID, "kf_reduce_moments: wants 2 outputs + 1 input");
+        const int dt = d->dtype[2];
+        KF_REQUIRE(dt == KF_F32 || dt == KF_F64 || dt == KF_F16 || dt == KF_BF16, KF_ERR_UNSUPPORTED,
+                   "kf_reduce_moments: floating dtypes only (mean_var_kernel dispatches on floating types, reduce_ops_kernel.cu:149-153)");
+        KF_REQUIRE(d->dtype[0] == d->dtype[1] && (d->dtype[0] == dt || (d->dtype[0] == KF_F32 && (dt == KF_F16 || dt == KF_BF16))),
+                   KF_ERR_UNSUPPORTED, "kf_reduce_moments: outputs must have the input dtype (or f32 for 16-bit inputs)");
+        for (int i = 0; i < d->ndim; ++i)
+            KF_REQUIRE((d->stride_bytes[0][i] == 0) == (d->stride_bytes[1][i] == 0) || d->shape[i] == 1, KF_ERR_INVALID,
+                       "kf_reduce_moments: the two outputs must reduce the same dims");
+    } else {
+        KF_REQUIRE(d->noutputs == 1 && d->ntensors == 2, KF_ERR_INVALID, "kf_reduce: wants 1 output + 1 input");
+        KF_REQUIRE(d->dtype[0] == d->dtype[1], KF_ERR_UNSUPPORTED, "kf_reduce: output dtype must equal input dtype");
+    }
     KF_REQUIRE(d->ndim >= 1 && d->ndim <= KF_MAX_DIMS, KF_ERR_INVALID, "kf_reduce: ndim out of range");
-    KF_REQUIRE(d->dtype[0] == d->dtype[1], KF_ERR_UNSUPPORTED, "kf_reduce: output dtype must equal input dtype");
-    const int es = dtype_size(d->dtype[1]);
+    const int es = dtype_size(d->dtype[in]);
+    const int eso = dtype_size(d->dtype[0]);
     KF_REQUIRE(es > 0, KF_ERR_INVALID, "kf_reduce: bad dtype");
     for (int i = 0; i < d->ndim; ++i) {
         if (d->stride_bytes[0][i] == 0 && d->shape[i] > 1) {
@@ -272,18 +377,18 @@ static int make_plan(const kf_iter_desc *d, Plan &p) {
         }
     }
     KF_REQUIRE(desc_is_32bit(d), KF_ERR_INDEX_RANGE, "kf_reduce: descriptor is not 32-bit indexable");
-    const int acc_bytes = (d->dtype[1] == KF_F32 || d->dtype[1] == KF_F16 || d->dtype[1] == KF_BF16) ? 4 : 8;
+    const int acc_bytes = ((d->dtype[in] == KF_F32 || d->dtype[in] == KF_F16 || d->dtype[in] == KF_BF16) ? 4 : 8) * (moments ? 3 : 1);
     const int64_t target_blocks = 1024;
-    const int64_t in_s0 = d->stride_bytes[1][0];
+    const int64_t in_s0 = d->stride_bytes[in][0];
     if (p.nred == 1 && p.red_dims[0] == 0 && in_s0 == es) {
         p.path = PATH_INNER;
         p.R = d->shape[0];
         p.r_stride = es;
         int vec = 16 / es;
         for (; vec > 1; vec >>= 1) { // rows must start on a pack boundary
-            bool ok = p.R % vec == 0 && (uintptr_t)d->data[1] % ((int64_t)vec * es) == 0;
+            bool ok = p.R % vec == 0 && (uintptr_t)d->data[in] % ((int64_t)vec * es) == 0;
             for (int i = 1; ok && i < d->ndim; ++i)
-                if (d->stride_bytes[1][i] % ((int64_t)vec * es)) ok = false;
+                if (d->stride_bytes[in][i] % ((int64_t)vec * es)) ok = false;
             if (ok) break;
         }
         p.vec = vec == 16 / es ? vec : 1;
@@ -301,8 +406,8 @@ static int make_plan(const kf_iter_desc *d, Plan &p) {
             if (ns < 1) ns = 1;
         }
         p.nsplit = (int)ns;
-    } else if (p.nred == 1 && p.red_dims[0] == 0 && d->ndim >= 2 && d->stride_bytes[1][1] == es &&
-               d->stride_bytes[0][1] == es) {
+    } else if (p.nred == 1 && p.red_dims[0] == 0 && d->ndim >= 2 && d->stride_bytes[in][1] == es &&
+               d->stride_bytes[0][1] == eso && (!moments || d->stride_bytes[1][1] == eso)) {
         p.path = PATH_OUTER;
         p.R = d->shape[0];
         p.r_stride = in_s0;
@@ -310,9 +415,9 @@ static int make_plan(const kf_iter_desc *d, Plan &p) {
         p.nouter = p.nout / p.C;
         int vec = 16 / es;
         const int64_t vb = 16;
-        bool ok = p.C % vec == 0 && (uintptr_t)d->data[1] % vb == 0 && in_s0 % vb == 0;
+        bool ok = p.C % vec == 0 && (uintptr_t)d->data[in] % vb == 0 && in_s0 % vb == 0;
         for (int i = 2; ok && i < d->ndim; ++i)
-            if (d->stride_bytes[1][i] % vb) ok = false;
+            if (d->stride_bytes[in][i] % vb) ok = false;
         p.vec = ok ? vec : 1;
         const int64_t gx = (p.C + (int64_t)kWave * p.vec - 1) / ((int64_t)kWave * p.vec);
         const int64_t gz = p.nouter < 1024 ? p.nouter : 1024;
@@ -332,14 +437,18 @@ static int make_plan(const kf_iter_desc *d, Plan &p) {
     return KF_OK;
 }
 
-template <typename T>
-static int run_reduce(int op, const kf_iter_desc *d, const Plan &p, void *ws, hipStream_t st) {
-    using A = typename RAcc<T>::type;
-    KF_PROF(p.path == PATH_INNER ? "reduce_inner" : p.path == PATH_OUTER ? "reduce_outer" : "reduce_generic", st);
+template <typename T, typename Ops>
+static int run_reduce(const char *what, const kf_iter_desc *d, const Plan &p, const typename Ops::Fin &fin, void *ws, hipStream_t st) {
+    const bool moments = d->noutputs == 2;
+    const int in = moments ? 2 : 1;
+    KF_PROF(moments ? (p.path == PATH_INNER ? "moments_inner" : p.path == PATH_OUTER ? "moments_outer" : "moments_generic")
+                    : (p.path == PATH_INNER ? "reduce_inner" : p.path == PATH_OUTER ? "reduce_outer" : "reduce_generic"), st);
+    (void)what;
     RedArgs a;
     memset(&a, 0, sizeof(a));
-    a.in = (const char *)d->data[1];
+    a.in = (const char *)d->data[in];
     a.out = (char *)d->data[0];
+    a.out1 = moments ? (char *)d->data[1] : nullptr;
     a.ws = ws;
     a.R = p.R;
     a.r_stride = p.r_stride;
@@ -350,27 +459,19 @@ static int run_reduce(int op, const kf_iter_desc *d, const Plan &p, void *ws, hi
     a.tx = p.tx;
     a.rtot = (uint32_t)p.rtot;
 
-    Project<A> proj;
-    proj.scale = op == KF_RED_MEAN;
-    const int64_t numel = p.nout * p.rtot;
-    // reference: factor = static_cast<acc_t>(nout) / numel with acc_t = scalar_t (reduce_ops_kernel.cu:49-53)
-    if constexpr (std::is_same<A, int64_t>::value)
-        proj.factor = numel ? p.nout / numel : 0;
-    else
-        proj.factor = (A)p.nout / (A)numel;
-
     // sub-descriptor holding only the output dims (optionally skipping the first `skip` of them)
     auto build_out_calc = [&](int skip) {
         kf_iter_desc s;
         memset(&s, 0, sizeof(s));
-        s.ntensors = 2;
+        s.ntensors = 3;
         s.noutputs = 1;
         int n = 0;
         for (int k = skip; k < p.nod; ++k) {
             const int i = p.out_dims[k];
             s.shape[n] = d->shape[i];
             s.stride_bytes[0][n] = d->stride_bytes[0][i];
-            s.stride_bytes[1][n] = d->stride_bytes[1][i];
+            s.stride_bytes[1][n] = d->stride_bytes[in][i];
+            s.stride_bytes[2][n] = moments ? d->stride_bytes[1][i] : 0;
             ++n;
         }
         if (n == 0) {
@@ -378,8 +479,8 @@ static int run_reduce(int op, const kf_iter_desc *d, const Plan &p, void *ws, hi
             n = 1;
         }
         s.ndim = n;
-        int idx[2] = {0, 1};
-        return OffsetCalc<2>::build(a.oc, &s, idx, 1);
+        int idx[3] = {0, 1, 2};
+        return OffsetCalc<3>::build(a.oc, &s, idx, 1);
     };
 
     if (p.path == PATH_INNER) {
@@ -387,12 +488,12 @@ static int run_reduce(int op, const kf_iter_desc *d, const Plan &p, void *ws, hi
         const int ty = kRB / p.tx;
         dim3 grid((unsigned)((p.nout + ty - 1) / ty), (unsigned)p.nsplit);
         if (p.vec > 1)
-            reduce_inner_kernel<T, 16 / sizeof(T)><<<grid, kRB, 0, st>>>(a, proj);
+            reduce_inner_kernel<T, Ops, 16 / sizeof(T)><<<grid, kRB, 0, st>>>(a, fin);
         else
-            reduce_inner_kernel<T, 1><<<grid, kRB, 0, st>>>(a, proj);
+            reduce_inner_kernel<T, Ops, 1><<<grid, kRB, 0, st>>>(a, fin);
         KF_LAUNCH_CHECK();
         if (p.nsplit > 1) {
-            reduce_fold_kernel<T><<<(unsigned)((p.nout + kRB - 1) / kRB), kRB, 0, st>>>(a, proj, 0);
+            reduce_fold_kernel<T, Ops><<<(unsigned)((p.nout + kRB - 1) / kRB), kRB, 0, st>>>(a, fin, 0);
             KF_LAUNCH_CHECK();
         }
     } else if (p.path == PATH_OUTER) {
@@ -401,12 +502,12 @@ static int run_reduce(int op, const kf_iter_desc *d, const Plan &p, void *ws, hi
         const int64_t gx = (p.C + (int64_t)kWave * p.vec - 1) / ((int64_t)kWave * p.vec);
         dim3 grid((unsigned)gx, (unsigned)p.nsplit, (unsigned)(p.nouter < 1024 ? p.nouter : 1024));
         if (p.vec > 1)
-            reduce_outer_kernel<T, 16 / sizeof(T)><<<grid, kRB, 0, st>>>(a, proj);
+            reduce_outer_kernel<T, Ops, 16 / sizeof(T)><<<grid, kRB, 0, st>>>(a, fin);
         else
-            reduce_outer_kernel<T, 1><<<grid, kRB, 0, st>>>(a, proj);
+            reduce_outer_kernel<T, Ops, 1><<<grid, kRB, 0, st>>>(a, fin);
         KF_LAUNCH_CHECK();
         if (p.nsplit > 1) {
-            reduce_fold_kernel<T><<<(unsigned)((p.nout + kRB - 1) / kRB), kRB, 0, st>>>(a, proj, 1);
+            reduce_fold_kernel<T, Ops><<<(unsigned)((p.nout + kRB - 1) / kRB), kRB, 0, st>>>(a, fin, 1);
             KF_LAUNCH_CHECK();
         }
     } else {
@@ -417,7 +518,7 @@ static int run_reduce(int op, const kf_iter_desc *d, const Plan &p, void *ws, hi
         int n = 0;
         for (int k = 0; k < p.nred; ++k) {
             s.shape[n] = d->shape[p.red_dims[k]];
-            s.stride_bytes[0][n] = d->stride_bytes[1][p.red_dims[k]];
+            s.stride_bytes[0][n] = d->stride_bytes[in][p.red_dims[k]];
             ++n;
         }
         if (n == 0) {
@@ -427,10 +528,35 @@ static int run_reduce(int op, const kf_iter_desc *d, const Plan &p, void *ws, hi
         s.ndim = n;
         int idx[1] = {0};
         KF_REQUIRE(OffsetCalc<1>::build(a.rc, &s, idx, 1), KF_ERR_INVALID, "kf_reduce: bad shape/stride");
-        reduce_generic_kernel<T><<<(unsigned)((p.nout + kRB - 1) / kRB), kRB, 0, st>>>(a, proj);
+        reduce_generic_kernel<T, Ops><<<(unsigned)((p.nout + kRB - 1) / kRB), kRB, 0, st>>>(a, fin);
         KF_LAUNCH_CHECK();
     }
     return KF_OK;
+}
+
+template <typename T>
+static int run_sum(int op, const kf_iter_desc *d, const Plan &p, void *ws, hipStream_t st) {
+    using A = typename RAcc<T>::type;
+    typename SumOps<T>::Fin fin;
+    fin.scale = op == KF_RED_MEAN;
+    const int64_t numel = p.nout * p.rtot;
+    // reference: factor = static_cast<acc_t>(nout) / numel with acc_t = scalar_t (reduce_ops_kernel.cu:49-53)
+    if constexpr (std::is_same<A, int64_t>::value)
+        fin.factor = numel ? p.nout / numel : 0;
+    else
+        fin.factor = (A)p.nout / (A)numel;
+    return run_reduce<T, SumOps<T>>("kf_reduce", d, p, fin, ws, st);
+}
+
+template <typename T>
+static int run_moments(int mode, const kf_iter_desc *d, const Plan &p, double correction, double eps, void *ws, hipStream_t st) {
+    using X = typename RAcc<T>::type;
+    typename MomentOps<T>::Fin fin;
+    fin.correction = (X)correction;
+    fin.eps = (X)eps;
+    fin.mode = mode;
+    fin.out_f32 = d->dtype[0] == KF_F32 && d->dtype[2] != KF_F32;
+    return run_reduce<T, MomentOps<T>>("kf_reduce_moments", d, p, fin, ws, st);
 }
 
 } // namespace kf
@@ -458,17 +584,48 @@ extern "C" int kf_reduce(int op, const kf_iter_desc *d, void *workspace, size_t 
                "kf_reduce: workspace of %zu bytes required, got %zu", p.ws_bytes, workspace_bytes);
     hipStream_t st = as_stream(stream);
     switch (d->dtype[1]) {
-    case KF_BOOL: return run_reduce<bool>(op, d, p, workspace, st);
-    case KF_U8: return run_reduce<uint8_t>(op, d, p, workspace, st);
-    case KF_I8: return run_reduce<int8_t>(op, d, p, workspace, st);
-    case KF_I16: return run_reduce<int16_t>(op, d, p, workspace, st);
-    case KF_I32: return run_reduce<int32_t>(op, d, p, workspace, st);
-    case KF_I64: return run_reduce<int64_t>(op, d, p, workspace, st);
-    case KF_F16: return run_reduce<f16_t>(op, d, p, workspace, st);
-    case KF_BF16: return run_reduce<bf16_t>(op, d, p, workspace, st);
-    case KF_F32: return run_reduce<float>(op, d, p, workspace, st);
-    case KF_F64: return run_reduce<double>(op, d, p, workspace, st);
+    case KF_BOOL: return run_sum<bool>(op, d, p, workspace, st);
+    case KF_U8: return run_sum<uint8_t>(op, d, p, workspace, st);
+    case KF_I8: return run_sum<int8_t>(op, d, p, workspace, st);
+    case KF_I16: return run_sum<int16_t>(op, d, p, workspace, st);
+    case KF_I32: return run_sum<int32_t>(op, d, p, workspace, st);
+    case KF_I64: return run_sum<int64_t>(op, d, p, workspace, st);
+    case KF_F16: return run_sum<f16_t>(op, d, p, workspace, st);
+    case KF_BF16: return run_sum<bf16_t>(op, d, p, workspace, st);
+    case KF_F32: return run_sum<float>(op, d, p, workspace, st);
+    case KF_F64: return run_sum<double>(op, d, p, workspace, st);
     default: KF_REQUIRE(false, KF_ERR_INVALID, "kf_reduce: bad dtype");
+    }
+    return KF_OK;
+}
+
+extern "C" int kf_reduce_moments_workspace_bytes(const kf_iter_desc *d, size_t *bytes) {
+    KF_REQUIRE(d && bytes, KF_ERR_INVALID, "kf_reduce_moments_workspace_bytes: null argument");
+    Plan p;
+    int rc = make_plan(d, p, true);
+    if (rc != KF_OK) return rc;
+    *bytes = p.ws_bytes;
+    return KF_OK;
+}
+
+extern "C" int kf_reduce_moments(int mode, const kf_iter_desc *d, double correction, double eps, void *workspace,
+                                 size_t workspace_bytes, void *stream) {
+    KF_REQUIRE(d, KF_ERR_INVALID, "kf_reduce_moments: null descriptor");
+    KF_REQUIRE(mode == KF_MOM_VAR || mode == KF_MOM_STD || mode == KF_MOM_INVSTD, KF_ERR_INVALID, "kf_reduce_moments: unknown mode %d", mode);
+    Plan p;
+    int rc = make_plan(d, p, true);
+    if (rc != KF_OK) return rc;
+    if (p.nout == 0) return KF_OK;
+    KF_REQUIRE(d->data[0] && d->data[1] && d->data[2], KF_ERR_INVALID, "kf_reduce_moments: null data pointer");
+    KF_REQUIRE(p.ws_bytes == 0 || (workspace && workspace_bytes >= p.ws_bytes), KF_ERR_WORKSPACE,
+               "kf_reduce_moments: workspace of %zu bytes required, got %zu", p.ws_bytes, workspace_bytes);
+    hipStream_t st = as_stream(stream);
+    switch (d->dtype[2]) {
+    case KF_F16: return run_moments<f16_t>(mode, d, p, correction, eps, workspace, st);
+    case KF_BF16: return run_moments<bf16_t>(mode, d, p, correction, eps, workspace, st);
+    case KF_F32: return run_moments<float>(mode, d, p, correction, eps, workspace, st);
+    case KF_F64: return run_moments<double>(mode, d, p, correction, eps, workspace, st);
+    default: KF_REQUIRE(false, KF_ERR_UNSUPPORTED, "kf_reduce_moments: bad dtype");
     }
     return KF_OK;
 }

@@ -20,6 +20,7 @@ BOOL, U8, I8, I16, I32, I64, F16, BF16, F32, F64 = range(10)
 DTYPE_SIZE = {BOOL: 1, U8: 1, I8: 1, I16: 2, I32: 4, I64: 8, F16: 2, BF16: 2, F32: 4, F64: 8}
 EW_ADD, EW_SUB, EW_MUL, EW_DIV, EW_COPY, EW_FILL = range(6)
 RED_SUM, RED_MEAN = range(2)
+MOM_VAR, MOM_STD, MOM_INVSTD = range(3)
 EPI_NONE, EPI_BIAS_ROW = range(2)
 MAX_DIMS, MAX_TENSORS = 12, 8
 KF_OK, KF_ERR_HIP, KF_ERR_INVALID, KF_ERR_UNSUPPORTED, KF_ERR_INDEX_RANGE, KF_ERR_WORKSPACE, KF_ERR_COMM = range(7)
@@ -37,6 +38,7 @@ EXPORTS = [
     "kf_stream_sync", "kf_stream_wait_event", "kf_device_sync", "kf_event_create", "kf_event_destroy", "kf_event_record", "kf_event_sync",
     "kf_event_elapsed_ms", "kf_profile_enable", "kf_profile_reset", "kf_profile_count", "kf_profile_get",
     "kf_device_props_get", "kf_elementwise", "kf_reduce_workspace_bytes", "kf_reduce",
+    "kf_reduce_moments_workspace_bytes", "kf_reduce_moments",
     "kf_index_put", "kf_gemm_workspace_bytes", "kf_gemm", "kf_attn_fwd", "kf_attn_bwd_workspace_bytes",
     "kf_attn_bwd", "kf_comm_unique_id", "kf_comm_init", "kf_comm_destroy", "kf_allreduce_sum",
 ]
@@ -93,6 +95,8 @@ def lib():
         _lib.kf_elementwise.argtypes = [C.c_int, C.POINTER(IterDesc), C.c_int, C.c_double, vp]
         _lib.kf_reduce_workspace_bytes.argtypes = [C.POINTER(IterDesc), C.POINTER(sz)]
         _lib.kf_reduce.argtypes = [C.c_int, C.POINTER(IterDesc), vp, sz, vp]
+        _lib.kf_reduce_moments_workspace_bytes.argtypes = [C.POINTER(IterDesc), C.POINTER(sz)]
+        _lib.kf_reduce_moments.argtypes = [C.c_int, C.POINTER(IterDesc), C.c_double, C.c_double, vp, sz, vp]
         _lib.kf_index_put.argtypes = [C.POINTER(IterDesc), C.c_int, C.POINTER(i64), C.POINTER(i64), vp]
         _lib.kf_gemm_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, i64, i64, i64, C.POINTER(sz)]
         _lib.kf_gemm.argtypes = [C.c_int, C.c_int, C.c_int, i64, i64, i64, C.c_float, vp, i64, vp, i64, C.c_float,
@@ -291,6 +295,30 @@ def make_reduce_desc(out: View, inp: View, dim: int) -> IterDesc:
         d.stride_bytes[0][i] = o_st
         d.stride_bytes[1][i] = i_st
     return d
+
+
+def make_moments_desc(out0: View, out1: View, inp: View, dim: int) -> IterDesc:
+    """Two-output form of make_reduce_desc (reduce_ops.cpp:24-25: outputs var, mean, then the input)."""
+    d1 = make_reduce_desc(out0, inp, dim)
+    d2 = make_reduce_desc(out1, inp, dim)
+    d = IterDesc()
+    d.ndim, d.ntensors, d.noutputs = d1.ndim, 3, 2
+    d.dtype[0], d.dtype[1], d.dtype[2] = out0.code, out1.code, inp.code
+    d.data[0], d.data[1], d.data[2] = out0.ptr, out1.ptr, inp.ptr
+    for i in range(d1.ndim):
+        d.shape[i] = d1.shape[i]
+        d.stride_bytes[0][i] = d1.stride_bytes[0][i]
+        d.stride_bytes[1][i] = d2.stride_bytes[0][i]
+        d.stride_bytes[2][i] = d1.stride_bytes[1][i]
+    return d
+
+
+def reduce_moments(mode, desc: IterDesc, correction=1.0, eps=0.0, stream=None):
+    need = C.c_size_t(0)
+    check(lib().kf_reduce_moments_workspace_bytes(C.byref(desc), C.byref(need)))
+    ws = DevBuf(need.value) if need.value else None
+    check(lib().kf_reduce_moments(int(mode), C.byref(desc), float(correction), float(eps), ws.ptr if ws else None, need.value, stream))
+    return ws  # keep alive until the stream is synchronised
 
 
 def elementwise(op, desc: IterDesc, compute_dtype=0, scalar=0.0, stream=None):

@@ -279,6 +279,49 @@ int orc_reduce(int op, const orc_tensor *in, int dim, orc_tensor *out) {
     return 0;
 }
 
+/* ---- moments: mean_var (reduce_ops.cpp:22-28, reduce_ops_kernel.cu:61-153) and norm_stat
+ *      (norm_ops_kernel.cu:6-61, welford_norm.h:170-187) ---------------------------------------------
+ * The reference's Welford recurrences compute, up to rounding, mean = sum(x)/n and M2 = sum((x-mean)^2);
+ * the oracle states exactly that with a two-pass double accumulation and one final cast.
+ *   mode 0: var = M2 / max(n - correction, 0)   (WelfordOps::project, correction = 1 from reduce_ops.cpp:26)
+ *   mode 1: sqrt of mode 0                      (take_sqrt)
+ *   mode 2: 1 / sqrt(M2 / n + eps)              (welford_norm.h:183, eps = 1e-12 from norm_ops_kernel.cu:40)
+ * out0 = the variance-like value, out1 = the mean (the iterator's output order, reduce_ops.cpp:24). */
+int orc_moments(int mode, const orc_tensor *in, int dim, double correction, double eps, orc_tensor *out0, orc_tensor *out1) {
+    if (in->ndim != out0->ndim || in->ndim != out1->ndim || dim < 0 || dim >= in->ndim) return 1;
+    for (int i = 0; i < in->ndim; ++i)
+        if (out0->shape[i] != (i == dim ? 1 : in->shape[i]) || out1->shape[i] != out0->shape[i]) return 2;
+    if (out0->dtype != out1->dtype) return 3;
+    if (acc_class(in->dtype) > 1) return 4; /* DISPATCH_FLOATING_TYPES */
+    const int64_t R = in->shape[dim], nout = numel_of(out0);
+    const int si = dt_size(in->dtype), so = dt_size(out0->dtype);
+#pragma omp parallel for schedule(static) if (nout * R > (1 << 16))
+    for (int64_t lin = 0; lin < nout; ++lin) {
+        int64_t idx[ORC_MAX_DIMS];
+        unravel(lin, out0->ndim, out0->shape, idx);
+        int64_t base = 0;
+        for (int i = 0; i < in->ndim; ++i) base += idx[i] * in->stride[i];
+        double sum = 0.0, m2 = 0.0;
+        for (int64_t r = 0; r < R; ++r) sum += ld_d(in->dtype, (const char *)in->data + (base + r * in->stride[dim]) * si);
+        const double mean = R ? sum / (double)R : 0.0;
+        for (int64_t r = 0; r < R; ++r) {
+            const double x = ld_d(in->dtype, (const char *)in->data + (base + r * in->stride[dim]) * si) - mean;
+            m2 += x * x;
+        }
+        double v;
+        if (mode == 2) {
+            v = 1.0 / sqrt(m2 / (double)R + eps);
+        } else {
+            const double div = (double)R > correction ? (double)R - correction : 0.0;
+            v = m2 / div;
+            if (mode == 1) v = sqrt(v);
+        }
+        st_d(out0->dtype, (char *)out0->data + off_of(out0, idx, out0->shape) * so, v);
+        st_d(out1->dtype, (char *)out1->data + off_of(out1, idx, out1->shape) * so, mean);
+    }
+    return 0;
+}
+
 /* ---- index_put_ ------------------------------------------------------------------------------- */
 int orc_index_put(orc_tensor *self, int nidx, const orc_tensor *idx, const orc_tensor *values) {
     if (nidx != self->ndim) return 1; /* index_ops.cpp:7-8 */

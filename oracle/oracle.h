@@ -45,6 +45,7 @@ int orc_fill(orc_tensor *dst, double value);
 /* reduce_ops.cpp:8-20 + reduce_ops_kernel.cu:6-59; out has shape[dim] == 1 (keepdim) */
 int orc_reduce(int op, const orc_tensor *in, int dim, orc_tensor *out);
 /* index_ops.cpp:6-38 + tensor_index.h:56-75; idx[i] are int64 tensors of identical shape; values same shape */
+int orc_moments(int mode, const orc_tensor *in, int dim, double correction, double eps, orc_tensor *out0, orc_tensor *out1);
 int orc_index_put(orc_tensor *self, int nidx, const orc_tensor *idx, const orc_tensor *values);
 /* gemm_kernel.cu:8-38 with the in-tree statement of the arithmetic, block_utils.h:46-77 (fma_dot_ref):
  * C = alpha * op(A) op(B) + beta * C, row-major, k-ordered fma chain per output element */

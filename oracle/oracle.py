@@ -150,6 +150,20 @@ def reduce(op, x, dim, code=None):
     return out
 
 
+def moments(mode, x, dim, correction=1.0, eps=0.0, code=None, out_code=None):
+    """(variance-like, mean) of x along dim, keepdim; mode 0 var, 1 std, 2 invstd (orc_moments)."""
+    c = code_of(x, code)
+    oc = c if out_code is None else out_code
+    shape = list(x.shape)
+    shape[dim] = 1
+    o0, o1 = np.empty(shape, dtype=CODE2NP[oc]), np.empty(shape, dtype=CODE2NP[oc])
+    ti, t0, t1 = _t(x, c), _t(o0, oc), _t(o1, oc)
+    f = lib().orc_moments
+    f.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+    _check(f(int(mode), C.byref(ti), int(dim), float(correction), float(eps), C.byref(t0), C.byref(t1)), "moments")
+    return o0, o1
+
+
 def index_put(self_arr, indices, values, code=None):
     c = code_of(self_arr, code)
     idx = (_Tensor * len(indices))(*[_t(np.ascontiguousarray(i, dtype=np.int64)) for i in indices])

@@ -151,6 +151,28 @@ def reductions():
     np.savez_compressed(OUT / "reductions.npz", **d)
 
 
+def moments():
+    d = {}
+    # test_tensor.py:120-132 test_mean_std: f64 (13, 325, 127), dim 1, unbiased variance from the test's expression
+    shape, dim = (13, 325, 127), 1
+    rng = np.random.default_rng(106)
+    arr = rng.uniform(-10, 10, size=shape)
+    d["ms_seed"], d["ms_sha"] = np.array([106]), sha(arr)
+    mean = np.mean(arr, axis=dim, keepdims=True)
+    d["ms_mean"] = mean
+    d["ms_var"] = ((arr - mean) * (arr - mean)).sum(axis=dim, keepdims=True) / (shape[dim] - 1)
+    # test_tensor.py:134-146 test_norm_stat: f32 [n, m], dim 0, invstd = 1 / sqrt(biased var)
+    for i, shp in enumerate(([64, 64], [1024, 2048], [4096, 4096], [4096 * 4 + 3, 4096 * 4 + 3])):
+        rng = np.random.default_rng(107 + i)
+        arr = uni(rng, shp)
+        d[f"ns{i}_seed"], d[f"ns{i}_sha"], d[f"ns{i}_shape"] = np.array([107 + i]), sha(arr), np.array(shp)
+        mean = np.mean(arr, axis=0, keepdims=True, dtype=np.float64)  # the test's f32 pairwise mean, stated exactly
+        var = np.sum((arr - mean) * (arr - mean), axis=0, keepdims=True)
+        d[f"ns{i}_mean"] = mean
+        d[f"ns{i}_invstd"] = 1.0 / np.sqrt(var / shp[0])
+    np.savez_compressed(OUT / "moments.npz", **d)
+
+
 def gemm():
     d = {}
     rng = np.random.default_rng(104)
@@ -199,7 +221,9 @@ def attention():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
-    for f in (elementwise, shape_ops, reductions, gemm, attention):
+    for f in (elementwise, shape_ops, reductions, moments, gemm, attention):
+        if len(sys.argv) > 1 and f.__name__ not in sys.argv[1:]:
+            continue
         f()
         print("wrote", f.__name__)
     sys.exit(0)

@@ -76,3 +76,16 @@ def rand_of(rng, shape, code):
     if code == H.BF16:
         return O.f32_to_bf16(x.astype(np.float32))
     return x.astype(H.CODE2NP[code])
+
+
+def gpu_moments(mode, x: Dev, dim, correction=1.0, eps=0.0, out_code=None):
+    """(variance-like, mean) through kf_reduce_moments; outputs in x's dtype unless out_code is given."""
+    shape = list(x.arr.shape)
+    shape[dim] = 1
+    oc = x.code if out_code is None else out_code
+    o0, o1 = Dev.empty(shape, oc), Dev.empty(shape, oc)
+    d = H.make_moments_desc(o0.view, o1.view, x.view, dim)
+    keep = H.reduce_moments(mode, d, correction, eps)
+    H.device_sync()
+    del keep
+    return o0, o1

@@ -118,6 +118,43 @@ def test_reduce():  # test_tensor.py:110-118 at the reference's shape
     close(ta.sum(1), g["c1_sum1"], atol=1e-2, rtol=1e-5)
 
 
+def test_mean_std():  # test_tensor.py:120-132, the same expressions on the GPU tensors, plus the golden values
+    g = golden("moments")
+    shape, dim = (13, 325, 127), 1
+    (arr,) = regen(g["ms_seed"][0], [shape], g["ms_sha"], dtype=np.float64)
+    arr_ = kfunca.from_numpy(arr, 0)
+    divisor = shape[dim] - 1
+    mean = arr_.mean(dim)
+    var = ((arr_ - mean) * (arr_ - mean)).sum(dim)
+    var = var / divisor
+    mean_var = arr_.mean_var(dim, False)
+    close(mean, mean_var[0], atol=1e-2, rtol=1e-2)
+    close(var, mean_var[1], atol=1e-2, rtol=1e-2)
+    close(mean_var[0], g["ms_mean"], atol=1e-12, rtol=1e-11)
+    close(mean_var[1], g["ms_var"], atol=0, rtol=1e-11)
+    assert mean_var[0].sizes() == [13, 1, 127] and mean_var[1].dtype() == kfunca.double
+    close(arr_.mean_var(dim, True)[1], np.sqrt(g["ms_var"]), atol=0, rtol=1e-11)
+    kfunca.memstat()
+
+
+def test_norm_stat():  # test_tensor.py:134-146
+    g = golden("moments")
+    for i in range(4):
+        shape = [int(v) for v in g[f"ns{i}_shape"]]
+        (arr,) = regen(g[f"ns{i}_seed"][0], [tuple(shape)], g[f"ns{i}_sha"])
+        arr_ = kfunca.from_numpy(arr, 0)
+        mean_invstd = arr_.norm_stat(0)
+        close(g[f"ns{i}_mean"], mean_invstd[0])
+        close(g[f"ns{i}_invstd"], mean_invstd[1])
+        assert mean_invstd[0].sizes() == [1, shape[1]] and mean_invstd[0].dtype() == kfunca.float
+    h = kfunca.from_numpy(uni(np.random.default_rng(5), (512, 384)), 0).bfloat16()  # 16-bit input: f32 statistics
+    m, inv = h.norm_stat(1)
+    ref = h.float().numpy().astype(np.float64)
+    assert m.dtype() == kfunca.float and m.sizes() == [512, 1]
+    close(m, ref.mean(axis=1, keepdims=True), atol=1e-5, rtol=1e-5)
+    close(inv, 1.0 / np.sqrt(ref.var(axis=1, keepdims=True)), atol=0, rtol=1e-4)
+
+
 def test_convert():  # test_tensor.py:148-160
     g = golden("elementwise")
     t = kfunca.from_numpy(g["cvt_x"], 0)
@@ -252,8 +289,11 @@ def test_allocator_reuse_and_scope():
     assert st["driver_allocs"] <= base["driver_allocs"] + 1
     z = kfunca.zeros([7, 5], kfunca.int, 0)
     assert not z.numpy().any()
-    for call in (lambda: z.sort(0, False), lambda: z.topk(1, 0, True), lambda: z.norm_stat(0), lambda: z.mean_var(0, False)):
+    for call in (lambda: z.sort(0, False), lambda: z.topk(1, 0, True)):
         with pytest.raises(RuntimeError, match="outside the tensor-kernel hot path"):
+            call()
+    for call in (lambda: z.norm_stat(0), lambda: z.mean_var(0, False)):  # floating dtypes only, as the reference's dispatch
+        with pytest.raises(RuntimeError, match="Unsupported ScalarType"):
             call()
     assert "tensor(shape=[7,5]" in repr(z)
     assert z.item([1, 2]) == 0

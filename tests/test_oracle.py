@@ -131,6 +131,25 @@ def test_reductions():
     assert_close(O.reduce(O.SUM, a, 1), g["c1_sum1"], rtol=1e-6, atol=1e-3, what="c1 sum1")
 
 
+def test_moments():
+    """orc_moments vs the reference tests' expressions: test_mean_std (test_tensor.py:120-132, f64, unbiased) and
+    test_norm_stat (test_tensor.py:134-146, f32, invstd of the biased variance)."""
+    g = golden("moments")
+    (arr,) = regen(g["ms_seed"][0], [(13, 325, 127)], g["ms_sha"], dtype=np.float64)
+    var, mean = O.moments(0, arr, 1)
+    assert_close(mean, g["ms_mean"], rtol=1e-12, atol=1e-13, what="mean")
+    assert_close(var, g["ms_var"], rtol=1e-12, atol=0, what="var")
+    std, _ = O.moments(1, arr, 1)
+    assert_close(std, np.sqrt(g["ms_var"]), rtol=1e-12, atol=0, what="std")
+    for i in range(3):  # the 16387^2 case is regenerated in the -m gpu suite only (1 GiB)
+        shp = tuple(int(v) for v in g[f"ns{i}_shape"])
+        (x,) = regen(g[f"ns{i}_seed"][0], [shp], g[f"ns{i}_sha"])
+        inv, mean = O.moments(2, x, 0, eps=1e-12)
+        assert mean.dtype == np.float32 and mean.shape == (1, shp[1])
+        assert_close(mean, g[f"ns{i}_mean"], rtol=1e-6, atol=1e-6, what="norm_stat mean")
+        assert_close(inv, g[f"ns{i}_invstd"], rtol=1e-5, atol=0, what="norm_stat invstd")
+
+
 def test_gemm():
     g = golden("gemm")
     a, b = regen(g["f64_seed"][0], [(123, 457), (457, 234)], g["f64_sha"], dtype=np.float64)

@@ -99,6 +99,20 @@ def main():
         keep = []
         ms, k = timed(tag, lambda: keep.append(H.reduce(H.RED_SUM, d)), args.rounds)
         record(tag, ms, 4 * rows * cols + 4 * (rows * cols // (cols if dim == 1 else rows)), k)
+    # statistics (mean_var / norm_stat): same traffic as sum, two small outputs
+    for (rows, cols, dim, code, tag) in ((R, R, 1, H.F32, "mean_var(1) f32 16384^2"), (R, R, 0, H.F32, "norm_stat(0) f32 16384^2"),
+                                         (1 << 16, 8192, 1, H.BF16, "row statistics bf16 [65536, 8192] (f32 outputs)")):
+        shape_o = [rows, cols]
+        shape_o[dim] = 1
+        es = 2 if code == H.BF16 else 4
+        vi = view(a, (rows, cols), code)
+        nout = rows * cols // shape_o[1 - dim] if False else (rows if dim == 1 else cols)
+        o0 = H.View(c.ptr, tuple(shape_o), (shape_o[1], 1), H.F32)
+        o1 = H.View(c.ptr + 4 * nout, tuple(shape_o), (shape_o[1], 1), H.F32)
+        d = H.make_moments_desc(o0, o1, vi, dim)
+        keep = []
+        ms, k = timed(tag, lambda: keep.append(H.reduce_moments(H.MOM_INVSTD if dim == 0 else H.MOM_VAR, d, 1.0, 1e-12)), args.rounds)
+        record(tag, ms, es * rows * cols + 8 * nout, k)
     # index_put_: 16 Mi scattered 4-byte values into a 256 Mi-element tensor (2 int64 indices each)
     m = 1 << 24
     rng = np.random.default_rng(0)
