@@ -129,11 +129,19 @@ enum {
     KF_EW_MUL = 2,  /* mul_kernel,  :7 */
     KF_EW_DIV = 3,  /* div_kernel,  :8 */
     KF_EW_COPY = 4, /* copy_kernel, unary_ops_kernel.h:5 (also dtype convert) */
-    KF_EW_FILL = 5  /* fill_kernel, nullary_ops_kernel.h:5 */
+    KF_EW_FILL = 5, /* fill_kernel, nullary_ops_kernel.h:5 */
+    /* out = in (op) scalar: what `tensor + 2.0` computes in the reference through a filled temporary
+     * (register.cpp:172-206: empty_like(self).fill_(s), then the binary kernel) without the temporary */
+    KF_EW_ADD_SCALAR = 6,
+    KF_EW_SUB_SCALAR = 7,
+    KF_EW_MUL_SCALAR = 8,
+    KF_EW_DIV_SCALAR = 9
 };
 /*
  * out = f(in...) over the iteration space of `desc` (1 output; 2 inputs for ADD..DIV, 1 for
- * COPY, 0 for FILL). `compute_dtype` is the reference's iter.common_dtype() for ADD..DIV
+ * COPY and the *_SCALAR ops, 0 for FILL). *_SCALAR: input and output share one dtype (f32, f64, bf16,
+ * f16, i32, i64); `scalar` is first rounded to that dtype exactly as FILL would, then the op runs in
+ * its accumulate type — bit-identical to the reference's fill-then-op sequence. `compute_dtype` is the reference's iter.common_dtype() for ADD..DIV
  * (binary_ops_kernel.cu:34-60; arithmetic runs in its accumulate type: float for half/bf16,
  * int64 for ints, accumulate_type.h:17-27), ignored for COPY (value is cast to the output dtype,
  * unary_ops_kernel.cu:13-17) and FILL (`scalar` cast to the output's accumulate type then to the

@@ -66,12 +66,6 @@ std::vector<int64_t> args_to_dims(const py::args &args) {
     return dims;
 }
 
-Tensor filled_like(const Tensor &self, double scalar) { // register.cpp:172-206: scalar ops materialise a filled tensor
-    Tensor t = empty_like(self);
-    t.fill_(any_t{scalar});
-    return t;
-}
-
 Tensor get_item(Tensor &self, py::object key) {
     Tensor out = self;
     auto apply = [&](py::handle item, int &dim) {
@@ -269,21 +263,21 @@ PYBIND11_MODULE(_C, m) {
         .def("topk", &Tensor::topk)
         .def("__getitem__", &get_item)
         .def("__add__", &Tensor::operator+)
-        .def("__add__", [](const Tensor &self, double s) { return self + filled_like(self, s); })
+        .def("__add__", [](const Tensor &self, double s) { return gpu::add(self, s); })
         .def("__iadd__", &Tensor::operator+=)
-        .def("__iadd__", [](Tensor &self, double s) { self += filled_like(self, s); return self; })
+        .def("__iadd__", [](Tensor &self, double s) { gpu::add_(self, s); return self; })
         .def("__sub__", &Tensor::operator-)
-        .def("__sub__", [](const Tensor &self, double s) { return self - filled_like(self, s); })
+        .def("__sub__", [](const Tensor &self, double s) { return gpu::sub(self, s); })
         .def("__isub__", &Tensor::operator-=)
-        .def("__isub__", [](Tensor &self, double s) { self -= filled_like(self, s); return self; })
+        .def("__isub__", [](Tensor &self, double s) { gpu::sub_(self, s); return self; })
         .def("__mul__", &Tensor::operator*)
-        .def("__mul__", [](const Tensor &self, double s) { return self * filled_like(self, s); })
+        .def("__mul__", [](const Tensor &self, double s) { return gpu::mul(self, s); })
         .def("__imul__", &Tensor::operator*=)
-        .def("__imul__", [](Tensor &self, double s) { self *= filled_like(self, s); return self; })
+        .def("__imul__", [](Tensor &self, double s) { gpu::mul_(self, s); return self; })
         .def("__truediv__", &Tensor::operator/)
-        .def("__truediv__", [](const Tensor &self, double s) { return self / filled_like(self, s); })
+        .def("__truediv__", [](const Tensor &self, double s) { return gpu::div(self, s); })
         .def("__itruediv__", &Tensor::operator/=)
-        .def("__itruediv__", [](Tensor &self, double s) { self /= filled_like(self, s); return self; })
+        .def("__itruediv__", [](Tensor &self, double s) { gpu::div_(self, s); return self; })
         .def("sum", &Tensor::sum)
         .def("mean", &Tensor::mean)
         .def("mean_var", &Tensor::mean_var)

@@ -103,6 +103,51 @@ Tensor add(const Tensor &left, const Tensor &right) {
     if (out.requires_grad()) out.set_grad_fn(new AddGradFunction(left, right));
     return out;
 }
+
+// ---- tensor (op) scalar (register.cpp:172-206) ---------------------------------------------------------
+// The reference materialises `empty_like(self).fill_(s)` and runs the binary kernel on it: one full-size write plus
+// one full-size read more than needed. Here the scalar rides in the launch (KF_EW_*_SCALAR, rounded to self's dtype
+// first exactly as fill_ would); dtypes the scalar kernel does not cover broadcast a 1-element tensor instead.
+namespace {
+class AddScalarGradFunction : public GradFunction { // d(a + c) = g
+public:
+    explicit AddScalarGradFunction(const Tensor &a) { inputs = {a}; }
+    std::vector<Tensor> backward(Tensor g) override { return {g}; }
+};
+bool scalar_kernel_covers(ScalarType t) {
+    switch (t) {
+    case ScalarType::Float: case ScalarType::Double: case ScalarType::BFloat16: case ScalarType::Half:
+    case ScalarType::Int: case ScalarType::Long: return true;
+    default: return false;
+    }
+}
+Tensor &binary_scalar_out(int op, Tensor &out, const Tensor &self, double value) {
+    CHECK_FAIL(self.defined());
+    if (!scalar_kernel_covers(self.dtype()) || (out.defined() && out.dtype() != self.dtype())) {
+        Tensor one = empty(std::vector<int64_t>(self.dim() > 0 ? self.dim() : 1, 1), self.dtype(), self.device());
+        one.fill_(any_t{value});
+        return binary_out(op, out, self, one);
+    }
+    auto iter = TensorIterator().add_output(out).add_input(self).build_for_loops();
+    run_elementwise(iter, op + (KF_EW_ADD_SCALAR - KF_EW_ADD), ScalarType::Undefined, value);
+    return out;
+}
+} // namespace
+Tensor add(const Tensor &self, double s) {
+    Tensor out;
+    binary_scalar_out(KF_EW_ADD, out, self, s);
+    out.set_requires_grad(self.requires_grad());
+    if (out.requires_grad()) out.set_grad_fn(new AddScalarGradFunction(self));
+    return out;
+}
+Tensor sub(const Tensor &self, double s) { Tensor out; binary_scalar_out(KF_EW_SUB, out, self, s); return out; }
+Tensor mul(const Tensor &self, double s) { Tensor out; binary_scalar_out(KF_EW_MUL, out, self, s); return out; }
+Tensor div(const Tensor &self, double s) { Tensor out; binary_scalar_out(KF_EW_DIV, out, self, s); return out; }
+Tensor &add_(Tensor &self, double s) { return binary_scalar_out(KF_EW_ADD, self, self, s); }
+Tensor &sub_(Tensor &self, double s) { return binary_scalar_out(KF_EW_SUB, self, self, s); }
+Tensor &mul_(Tensor &self, double s) { return binary_scalar_out(KF_EW_MUL, self, self, s); }
+Tensor &div_(Tensor &self, double s) { return binary_scalar_out(KF_EW_DIV, self, self, s); }
+
 Tensor sub(const Tensor &l, const Tensor &r) { Tensor out; sub_out(out, l, r); return out; }
 Tensor mul(const Tensor &l, const Tensor &r) { Tensor out; mul_out(out, l, r); return out; }
 Tensor div(const Tensor &l, const Tensor &r) { Tensor out; div_out(out, l, r); return out; }

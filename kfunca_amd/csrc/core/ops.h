@@ -23,6 +23,15 @@ Tensor &mul_(Tensor &self, const Tensor &other);
 Tensor &div_out(Tensor &out, const Tensor &left, const Tensor &right);
 Tensor div(const Tensor &left, const Tensor &right);
 Tensor &div_(Tensor &self, const Tensor &other);
+// tensor (op) python-float, register.cpp:172-206 — same results as the reference's fill-then-op, no temporary
+Tensor add(const Tensor &self, double s);
+Tensor sub(const Tensor &self, double s);
+Tensor mul(const Tensor &self, double s);
+Tensor div(const Tensor &self, double s);
+Tensor &add_(Tensor &self, double s);
+Tensor &sub_(Tensor &self, double s);
+Tensor &mul_(Tensor &self, double s);
+Tensor &div_(Tensor &self, double s);
 // unary_ops.h:5-9, nullary_ops.h:5-8
 Tensor clone(const Tensor &self);
 Tensor &copy_(Tensor &self, const Tensor &other);

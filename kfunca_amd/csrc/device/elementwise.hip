@@ -108,7 +108,8 @@ constexpr int kUnroll = 4;
 
 // ------------------------------------------------------------------------------------------
 // same-dtype kernel: NIN inputs of type T, one output of type T. MODE: 0 = arithmetic (op at
-// run time), 1 = copy (raw bits), 2 = fill (raw bits).
+// run time), 1 = copy (raw bits), 2 = fill (raw bits), 3 = arithmetic with a scalar right operand
+// (the value the reference would have filled a whole tensor with, register.cpp:172-206).
 // ------------------------------------------------------------------------------------------
 template <int NT>
 struct SameArgs {
@@ -116,7 +117,7 @@ struct SameArgs {
     int64_t nvec;        // number of VEC-wide items
     int op;
     uint32_t bcast0;     // bit t set: operand t has stride 0 along dim 0 (vector path: splat)
-    uint64_t fill_bits;  // MODE 2
+    uint64_t fill_bits;  // MODE 2 and 3: the scalar, already rounded to T
     OffsetCalc<NT> oc;   // !CONTIG only
 };
 
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(kBlock) void ew_same_kernel(const SameArgs<NIN + 1>
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
 
     P fillv;
-    if constexpr (MODE == 2) {
+    if constexpr (MODE == 2 || MODE == 3) {
         T one;
         __builtin_memcpy(&one, &args.fill_bits, sizeof(T));
 #pragma unroll
@@ -172,6 +173,10 @@ __global__ __launch_bounds__(kBlock) void ew_same_kernel(const SameArgs<NIN + 1>
                     out = fillv;
                 } else if constexpr (MODE == 1) {
                     out = in[u][0];
+                } else if constexpr (MODE == 3) {
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e)
+                        out.v[e] = from_acc<T>(apply_op<A>(args.op, to_acc<T>(in[u][0].v[e]), to_acc<T>(fillv.v[e])));
                 } else {
 #pragma unroll
                     for (int e = 0; e < VEC; ++e)
@@ -317,7 +322,7 @@ template <typename T, int NIN, int MODE>
 static int launch_same(const kf_iter_desc *d, int op, uint64_t fill_bits, hipStream_t st) {
     constexpr int NT = NIN + 1;
     constexpr int VMAX = 16 / sizeof(T);
-    KF_PROF(MODE == 0 ? "ew_arith" : MODE == 1 ? "ew_copy" : "ew_fill", st);
+    KF_PROF(MODE == 0 ? "ew_arith" : MODE == 1 ? "ew_copy" : MODE == 2 ? "ew_fill" : "ew_arith_scalar", st);
     SameArgs<NT> a;
     memset(&a, 0, sizeof(a));
     for (int t = 0; t < NT; ++t) a.ptr[t] = (char *)d->data[t];
@@ -478,9 +483,9 @@ using namespace kf;
 
 extern "C" int kf_elementwise(int op, const kf_iter_desc *d, int compute_dtype, double scalar, void *stream) {
     KF_REQUIRE(d, KF_ERR_INVALID, "kf_elementwise: null descriptor");
-    KF_REQUIRE(op >= KF_EW_ADD && op <= KF_EW_FILL, KF_ERR_INVALID, "kf_elementwise: unknown op %d", op);
+    KF_REQUIRE(op >= KF_EW_ADD && op <= KF_EW_DIV_SCALAR, KF_ERR_INVALID, "kf_elementwise: unknown op %d", op);
     KF_REQUIRE(d->ndim >= 1 && d->ndim <= KF_MAX_DIMS, KF_ERR_INVALID, "kf_elementwise: ndim %d out of range", d->ndim);
-    const int nin = op <= KF_EW_DIV ? 2 : (op == KF_EW_COPY ? 1 : 0);
+    const int nin = op <= KF_EW_DIV ? 2 : (op == KF_EW_FILL ? 0 : 1);
     KF_REQUIRE(d->noutputs == 1 && d->ntensors == nin + 1, KF_ERR_INVALID,
                "kf_elementwise: op %d wants 1 output + %d inputs, got %d/%d", op, nin, d->noutputs, d->ntensors);
     for (int t = 0; t < d->ntensors; ++t) {
@@ -494,6 +499,21 @@ extern "C" int kf_elementwise(int op, const kf_iter_desc *d, int compute_dtype, 
     const int odt = d->dtype[0];
 
     if (op == KF_EW_FILL) return launch_raw_by_size<0, 2>(dtype_size(odt), d, fill_pattern(odt, scalar), st);
+
+    if (op >= KF_EW_ADD_SCALAR) { // out = in (op) scalar, all in one dtype; the scalar is rounded to it first, as fill_ would
+        KF_REQUIRE(d->dtype[1] == odt, KF_ERR_UNSUPPORTED, "kf_elementwise: scalar ops want input dtype == output dtype");
+        const uint64_t bits = fill_pattern(odt, scalar);
+        const int aop = op - KF_EW_ADD_SCALAR;
+        switch (odt) {
+        case KF_F32: return launch_same<float, 1, 3>(d, aop, bits, st);
+        case KF_F64: return launch_same<double, 1, 3>(d, aop, bits, st);
+        case KF_BF16: return launch_same<bf16_t, 1, 3>(d, aop, bits, st);
+        case KF_F16: return launch_same<f16_t, 1, 3>(d, aop, bits, st);
+        case KF_I32: return launch_same<int32_t, 1, 3>(d, aop, bits, st);
+        case KF_I64: return launch_same<int64_t, 1, 3>(d, aop, bits, st);
+        default: KF_REQUIRE(false, KF_ERR_UNSUPPORTED, "kf_elementwise: scalar ops cover f32/f64/bf16/f16/i32/i64 (broadcast a 1-element tensor for the rest)");
+        }
+    }
 
     if (op == KF_EW_COPY) {
         if (d->dtype[1] == odt) return launch_raw_by_size<1, 1>(dtype_size(odt), d, 0, st);

@@ -18,7 +18,7 @@ LIB_PATH = PKG / "libkfunca_hip.so"
 # dtype codes == reference ScalarType order (src/core/include/scalar_type.h:9-27)
 BOOL, U8, I8, I16, I32, I64, F16, BF16, F32, F64 = range(10)
 DTYPE_SIZE = {BOOL: 1, U8: 1, I8: 1, I16: 2, I32: 4, I64: 8, F16: 2, BF16: 2, F32: 4, F64: 8}
-EW_ADD, EW_SUB, EW_MUL, EW_DIV, EW_COPY, EW_FILL = range(6)
+EW_ADD, EW_SUB, EW_MUL, EW_DIV, EW_COPY, EW_FILL, EW_ADD_SCALAR, EW_SUB_SCALAR, EW_MUL_SCALAR, EW_DIV_SCALAR = range(10)
 RED_SUM, RED_MEAN = range(2)
 MOM_VAR, MOM_STD, MOM_INVSTD = range(3)
 EPI_NONE, EPI_BIAS_ROW = range(2)

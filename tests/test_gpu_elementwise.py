@@ -243,3 +243,38 @@ def test_tiled_transpose_and_vector_convert_paths():
             for cd in (H.F32, H.F16, H.BF16):
                 got = gpu_copy(Dev(x, cs), Dev.empty((n,), cd)).get()
                 assert np.array_equal(bits(got), bits(O.convert(x, cd, src_code=cs))), (cs, cd, n)
+
+
+@pytest.mark.parametrize("code", [H.F32, H.F64, H.BF16, H.F16, H.I32, H.I64])
+def test_scalar_operand_equals_fill_then_op(code):
+    """`tensor (op) python-float` (register.cpp:172-206): the reference fills a same-dtype tensor with the scalar and runs
+    the binary kernel; KF_EW_*_SCALAR must give the same bits without the temporary — contiguous, ragged, strided, in place."""
+    rng = np.random.default_rng(300 + code)
+    scal = {"add": H.EW_ADD_SCALAR, "sub": H.EW_SUB_SCALAR, "mul": H.EW_MUL_SCALAR, "div": H.EW_DIV_SCALAR}
+    for shape in ((1,), (1000,), (64, 257), (7, 33, 64)):
+        a = rand_of(rng, shape, code)
+        for s in (2.0, -3.0, 0.3, 1e-3, 7.75):
+            if code in (H.I32, H.I64) and int(s) == 0:
+                continue  # x / 0
+            filled = O.fill(np.empty(shape, dtype=a.dtype), s, dst_code=code)
+            for name, (_, oop) in OPS.items():
+                want = O.binary(oop, a, filled, a_code=code, b_code=code)
+                da, out = Dev(a, code), Dev.empty(shape, code)
+                H.elementwise(scal[name], H.make_desc([out.view], [da.view]), 0, s)
+                H.device_sync()
+                assert np.array_equal(bits(out.get()), bits(want)), (code, shape, s, name)
+                H.elementwise(scal[name], H.make_desc([da.view], [da.view]), 0, s)  # in place
+                H.device_sync()
+                assert np.array_equal(bits(da.get()), bits(want)), (code, shape, s, name, "in place")
+    base = rand_of(rng, (12, 20, 36), code)
+    for view in (base.transpose(2, 0, 1), base[:, ::2, 1:30:3]):
+        filled = O.fill(np.empty(view.shape, dtype=base.dtype), 1.5, dst_code=code)
+        want = O.binary(O.MUL, np.ascontiguousarray(view), filled, a_code=code, b_code=code)
+        out = Dev.empty(view.shape, code)
+        H.elementwise(H.EW_MUL_SCALAR, H.make_desc([out.view], [Dev(view, code, base=base).view]), 0, 1.5)
+        H.device_sync()
+        assert np.array_equal(bits(out.get()), bits(want)), (code, view.shape)
+    with pytest.raises(H.KfError) as e:  # not covered: the host broadcasts a 1-element tensor instead
+        x = Dev(np.zeros(8, dtype=np.int8))
+        H.elementwise(H.EW_ADD_SCALAR, H.make_desc([x.view], [x.view]), 0, 1.0)
+    assert e.value.code == H.KF_ERR_UNSUPPORTED

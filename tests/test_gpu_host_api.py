@@ -56,6 +56,26 @@ def test_inplace_op_golden():  # test_tensor.py:29-68
     a /= 5; assert a.data_ptr() == addr and np.array_equal(a.numpy(), steps[7])
 
 
+def test_scalar_operands_no_temporary_and_small_dtypes():  # register.cpp:172-206 semantics on every path
+    rng = np.random.default_rng(9)
+    a = uni(rng, (33, 65))
+    t = kfunca.from_numpy(a, 0)
+    before = kfunca.memstat_dict(0)["driver_allocs"]
+    r = ((t + 2.0) * 0.5 - 1.0) / 4.0
+    assert np.array_equal(r.numpy(), ((a + np.float32(2.0)) * np.float32(0.5) - np.float32(1.0)) / np.float32(4.0))
+    i8 = kfunca.from_numpy(np.arange(-20, 20, dtype=np.int8).reshape(4, 10), 0)  # small ints: 1-element broadcast operand
+    assert np.array_equal((i8 * 3.0).numpy(), (np.arange(-20, 20).reshape(4, 10) * 3).astype(np.int8))
+    h = t.bfloat16()
+    want = O.binary(O.ADD, O.f32_to_bf16(a), O.fill(np.empty(a.shape, dtype=np.uint16), 0.3, dst_code=7), a_code=7, b_code=7)
+    assert np.array_equal((h + 0.3).float().numpy(), O.bf16_to_f32(want))
+    x = kfunca.from_numpy(a, 0)
+    x.set_requires_grad(True)
+    y = (x + 1.0) + x  # d/dx = 2
+    y.backward(kfunca.from_numpy(np.ones_like(a), 0))
+    assert np.array_equal(x.grad().numpy(), np.full_like(a, 2.0))
+    assert before <= kfunca.memstat_dict(0)["driver_allocs"]
+
+
 def test_data_ptr_and_refcounts():  # test_tensor.py:70-84
     arr = np.random.default_rng(2).uniform(-10, 10, size=(3, 4)).astype(np.float32)
     x = kfunca.from_numpy(arr, 0)
