@@ -337,13 +337,38 @@ __global__ __launch_bounds__(256) void gemm_h_kernel(const GemmArgs g) {
 //     phase 0: stage HA1(T+1)   phase 1: HB1(T+1)   phase 2: HA0(T+2)   phase 3: HB0(T+2)
 // Every wave issues 2 DMA operations per phase, so ONE counted wait per phase, s_waitcnt vmcnt(8) (the four
 // youngest half-tiles stay in flight), retires exactly what the next phase reads; the barrier publishes it.
-// LDS: 2 K tiles x 4 half-tiles x 16 KiB = 128 KiB. Operands must be K-contiguous (A [M,K], B [N,K]).
+// LDS: 2 K tiles x 4 half-tiles x (16 KiB + 256 B) = 130 KiB.
+// Operand layouts (TRA / TRB): a K-contiguous operand (A [M,K], B stored [N,K]) is staged as a [128 rows][128 B]
+// image and its 16 x 32 fragments are one ds_read_b128 each. An operand whose contraction dim is the STRIDED one
+// (A stored [K,M] for A^T B, B stored [K,N] for plain A B) is staged as it lies in memory, a [64 k][256 B] image of the
+// same 128 rows / columns, and its fragments are read with two ds_read_b64_tr_b16 (the hardware transposes 4 k x 16
+// lanes), so no operand is ever re-laid out in HBM. That image keeps the reads conflict-free with an XOR of the 16-B
+// chunk index by (k & 3) << 2 applied on the DMA source, plus 32 B of padding after every PAIR of 4-row groups
+// (a DMA instruction's 1 KiB lands contiguously, so padding can only sit between instructions); the k-step and
+// the lo / hi row quad of a fragment are then immediates (8192 + 128, 1024) off one per-tile address.
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 constexpr int G_BM = 256, G_BN = 256, G_BK = 64, G_NT = 512;
-constexpr int G_HALF = 128 * G_BK * 2;      // 16 KiB
+constexpr int G_HALF = 128 * G_BK * 2 + 256; // 16 KiB + the transposed image's padding (32 B x 7, rounded up)
 constexpr int G_TILE = 4 * G_HALF;          // HA0 | HB0 | HA1 | HB1
-constexpr int G_LDS = 2 * G_TILE;           // 128 KiB
+constexpr int G_LDS = 2 * G_TILE;           // 130 KiB
+
+typedef __attribute__((ext_vector_type(4))) short g_s16x4;
+typedef __attribute__((ext_vector_type(8))) short g_s16x8;
+
+// one 16 (m or n) x 32 (k) fragment out of a [k][256 B] image: rows 8*(lane>>4) + {0..3} and + {4..7} of the k-step
+template <bool BF, int OFF>
+__device__ __forceinline__ typename HFrag<BF>::type g_tr_frag(unsigned addr) {
+    g_s16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%c3\n\tds_read_b64_tr_b16 %1, %2 offset:%c4"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(addr), "n"(OFF), "n"(OFF + 1024)
+                 : "memory");
+    g_s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(typename HFrag<BF>::type, r);
+}
 
 template <bool BF>
 __device__ __forceinline__ f32x4 g_mfma16(typename HFrag<BF>::type a, typename HFrag<BF>::type b, f32x4 c) {
@@ -353,7 +378,7 @@ __device__ __forceinline__ f32x4 g_mfma16(typename HFrag<BF>::type a, typename H
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 
-template <bool BF>
+template <bool BF, bool TRA, bool TRB>
 __global__ __launch_bounds__(G_NT, 2) void gemm_h256_kernel(const GemmArgs g) {
     using frag_t = typename HFrag<BF>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -364,29 +389,48 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_h256_kernel(const GemmArgs g) {
     const int64_t m0 = (int64_t)(tile / tiles_n) * G_BM, n0 = (int64_t)(tile % tiles_n) * G_BN;
     const int nt = (int)(g.K / G_BK);
 
-    // ---- LDS-DMA source pointers: wave w moves rows (2w + i) * 8 .. + 7 (i = 0, 1) of every half-tile
+    // ---- LDS-DMA source pointers. K-contiguous operand: wave w moves rows (2w + i) * 8 .. + 7 (i = 0, 1) of every
+    // half-tile. Transposed-read operand: wave w moves k rows (2w + i) * 4 .. + 3, 256 B (128 rows / columns) each.
     const char *srcA[2][2], *srcB[2][2]; // [half 0/1][i]
-    int ldsoff[2];
+    int ldsoffA[2], ldsoffB[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int hr = (wid * 2 + i) * 8 + (lane >> 3), pos = lane & 7;
         const int chunk = pos ^ ((hr >> 1) & 7);
-        ldsoff[i] = (wid * 2 + i) * 8 * 128;
-        const int64_t arow = m0 + (hr >> 6) * 128 + (hr & 63), brow = n0 + (hr >> 5) * 64 + (hr & 31);
-        srcA[0][i] = (const char *)g.A + arow * g.lda * 2 + chunk * 16;
-        srcA[1][i] = srcA[0][i] + 64 * g.lda * 2;
-        srcB[0][i] = (const char *)g.B + brow * g.ldb * 2 + chunk * 16;
-        srcB[1][i] = srcB[0][i] + 32 * g.ldb * 2;
+        const int kr = (wid * 2 + i) * 4 + (lane >> 4);                // transposed image: k row of this lane
+        const int j0 = ((lane & 15) ^ ((kr & 3) << 2)) * 8;            // ... and the first of its 8 rows / columns
+        if constexpr (TRA) {
+            ldsoffA[i] = (wid * 2 + i) * 1024 + 32 * wid;
+            srcA[0][i] = (const char *)g.A + ((int64_t)kr * g.lda + m0 + j0) * 2; // HA0 = rows 0..127: whole 256-B lines per k
+            srcA[1][i] = srcA[0][i] + 128 * 2;
+        } else {
+            ldsoffA[i] = (wid * 2 + i) * 8 * 128;
+            const int64_t arow = m0 + (hr >> 6) * 128 + (hr & 63);
+            srcA[0][i] = (const char *)g.A + arow * g.lda * 2 + chunk * 16;
+            srcA[1][i] = srcA[0][i] + 64 * g.lda * 2;
+        }
+        if constexpr (TRB) {
+            ldsoffB[i] = (wid * 2 + i) * 1024 + 32 * wid;
+            srcB[0][i] = (const char *)g.B + ((int64_t)kr * g.ldb + n0 + j0) * 2; // HB0 = columns 0..127
+            srcB[1][i] = srcB[0][i] + 128 * 2;
+        } else {
+            ldsoffB[i] = (wid * 2 + i) * 8 * 128;
+            const int64_t brow = n0 + (hr >> 5) * 64 + (hr & 31);
+            srcB[0][i] = (const char *)g.B + brow * g.ldb * 2 + chunk * 16;
+            srcB[1][i] = srcB[0][i] + 32 * g.ldb * 2;
+        }
     }
+    const int64_t kstepA = TRA ? (int64_t)G_BK * g.lda * 2 : (int64_t)G_BK * 2;
+    const int64_t kstepB = TRB ? (int64_t)G_BK * g.ldb * 2 : (int64_t)G_BK * 2;
     // which: 0 HA0, 1 HB0, 2 HA1, 3 HB1 (also the slot inside a tile buffer)
     auto stage = [&](int which, int kt) {
-        const int64_t koff = (int64_t)(kt < nt ? kt : nt - 1) * G_BK * 2; // past the end: re-fetch the last tile (never read)
+        const int64_t ktc = kt < nt ? kt : nt - 1; // past the end: re-fetch the last tile (never read)
         char *dst = smem + (kt & 1) * G_TILE + which * G_HALF;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const char *src = (which & 1) ? srcB[which >> 1][i] : srcA[which >> 1][i];
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + koff),
-                                             (__attribute__((address_space(3))) void *)(dst + ldsoff[i]), 16, 0, 0);
+            const char *src = (which & 1) ? srcB[which >> 1][i] + ktc * kstepB : srcA[which >> 1][i] + ktc * kstepA;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                             (__attribute__((address_space(3))) void *)(dst + ((which & 1) ? ldsoffB[i] : ldsoffA[i])), 16, 0, 0);
         }
     };
 
@@ -394,7 +438,13 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_h256_kernel(const GemmArgs g) {
     const int fr = lane & 15, fg = lane >> 4;
     const int sw = (fr >> 1) & 7;
     const int offk0 = fr * 128 + (((0 + fg) ^ sw) << 4), offk1 = fr * 128 + (((4 + fg) ^ sw) << 4);
-    const int abase = wr * 64 * 128, bbase = wc * 32 * 128; // this wave's rows inside HA* / HB*
+    const int abase = TRA ? 0 : wr * 64 * 128, bbase = TRB ? 0 : wc * 32 * 128; // this wave's rows inside HA* / HB*
+    // transposed image: per-lane address of tile 0's low row quad; tile t is this XOR (16-B chunk index ^ 2 t), see above
+    const int tq = fr >> 2;
+    const int lbT = fg * 2048 + tq * 256 + (((((fr & 3) >> 1)) ^ (tq << 2)) << 4) + 8 * (fr & 1);
+    const int pbT = 32 * fg;
+    const unsigned smem_u = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)smem;
+    const int ecA = wr * 128, ecB = wc * 64; // (first chunk of this wave's columns) << 4
 
     f32x4 acc[4][8]; // [n-tile 0..3][m-tile 0..7]: D = B_frag x A_frag, i.e. C^T tiles (rows = n on registers)
 #pragma unroll
@@ -419,66 +469,78 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_h256_kernel(const GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);         \
     asm volatile("" ::: "memory");
 
+    // fragment loads of one half-tile, NTL tiles of 16 rows / columns. PART 0 runs in the load segment: both k-steps
+    // of a ds_read_b128 operand, k-step 0 of a transposed-read operand; PART 1 (transposed-read operands only) issues
+    // k-step 1; PART 2 both. The transposed A operand (16 + 16 read instructions per half-tile) is split: k-step 1 is
+    // issued at the top of the wave's own matrix segment, under the k-step-0 MFMAs, which keeps the load segment as
+    // short as the other group's matrix segment; the B operand (8 + 8) loads whole in the load segment.
+#define G_LOAD(FR, NTL, HB, TR, EC, PART)                                                             \
+    _Pragma("unroll") for (int t = 0; t < NTL; ++t) {                                                 \
+        if constexpr (TR) {                                                                           \
+            const unsigned x = (unsigned)((lbT ^ ((EC) + t * 32)) + pbT) + smem_u + (unsigned)((HB) - smem); \
+            if constexpr (PART == 0 || PART == 2) FR[t][0] = g_tr_frag<BF, 0>(x);                     \
+            if constexpr (PART == 1 || PART == 2) FR[t][1] = g_tr_frag<BF, 8192 + 128>(x);            \
+        } else if constexpr (PART == 0 || PART == 2) {                                                \
+            FR[t][0] = *(const frag_t *)((HB) + t * 2048 + offk0);                                    \
+            FR[t][1] = *(const frag_t *)((HB) + t * 2048 + offk1);                                    \
+        }                                                                                             \
+    }
+// the asm-issued transposed reads are invisible to the compiler's wait insertion: counted lgkmcnt waits by hand,
+// placed AFTER the barrier (the reads' latency overlaps the barrier wait, as the compiler arranges for ds_read_b128)
+#define G_LGKM(N)                                                        \
+    asm volatile("s_waitcnt lgkmcnt(%c0)" ::"n"(N) : "memory");          \
+    __builtin_amdgcn_sched_barrier(0);
+#define G_MFMA(KS, ACC, NOFF, MOFF, BF_, AF_)                                                           \
+    _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                     \
+        _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                 \
+            ACC[NOFF + n][MOFF + m] = g_mfma16<BF>(BF_[n][KS], AF_[m][KS], ACC[NOFF + n][MOFF + m]);
+    constexpr int NLA = 8; // k-step-1 read instructions of a transposed A half-tile (4 tiles x lo, hi)
+
     for (int kt = 0; kt < nt; ++kt) {
         const char *buf = smem + (kt & 1) * G_TILE;
         const char *ha0 = buf + abase, *hb0 = buf + G_HALF + bbase, *ha1 = buf + 2 * G_HALF + abase, *hb1 = buf + 3 * G_HALF + bbase;
         // ---------------- phase 0: (A0, B0) ----------------
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            b0[t][0] = *(const frag_t *)(hb0 + t * 2048 + offk0);
-            b0[t][1] = *(const frag_t *)(hb0 + t * 2048 + offk1);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            a0[t][0] = *(const frag_t *)(ha0 + t * 2048 + offk0);
-            a0[t][1] = *(const frag_t *)(ha0 + t * 2048 + offk1);
-        }
+        G_LOAD(b0, 2, hb0, TRB, ecB, 2)
+        G_LOAD(a0, 4, ha0, TRA, ecA, 0)
         stage(2, kt + 1);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         G_SEG_END()
+        if constexpr (TRA) {
+            G_LOAD(a0, 4, ha0, TRA, ecA, 1)
+            G_LGKM(NLA)
+        } else if constexpr (TRB) {
+            G_LGKM(0)
+        }
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) acc[n][m] = g_mfma16<BF>(b0[n][ks], a0[m][ks], acc[n][m]);
+        G_MFMA(0, acc, 0, 0, b0, a0)
+        if constexpr (TRA) { G_LGKM(0) }
+        G_MFMA(1, acc, 0, 0, b0, a0)
         __builtin_amdgcn_s_setprio(0);
         G_SEG_END()
         // ---------------- phase 1: (A1, B0) ----------------
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            a1[t][0] = *(const frag_t *)(ha1 + t * 2048 + offk0);
-            a1[t][1] = *(const frag_t *)(ha1 + t * 2048 + offk1);
-        }
+        G_LOAD(a1, 4, ha1, TRA, ecA, 0)
         stage(3, kt + 1);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         G_SEG_END()
+        if constexpr (TRA) {
+            G_LOAD(a1, 4, ha1, TRA, ecA, 1)
+            G_LGKM(NLA)
+        }
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) acc[n][4 + m] = g_mfma16<BF>(b0[n][ks], a1[m][ks], acc[n][4 + m]);
+        G_MFMA(0, acc, 0, 4, b0, a1)
+        if constexpr (TRA) { G_LGKM(0) }
+        G_MFMA(1, acc, 0, 4, b0, a1)
         __builtin_amdgcn_s_setprio(0);
         G_SEG_END()
         // ---------------- phase 2: (A1, B1) ----------------
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            b1[t][0] = *(const frag_t *)(hb1 + t * 2048 + offk0);
-            b1[t][1] = *(const frag_t *)(hb1 + t * 2048 + offk1);
-        }
+        G_LOAD(b1, 2, hb1, TRB, ecB, 2)
         stage(0, kt + 2);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         G_SEG_END()
+        if constexpr (TRB) { G_LGKM(0) }
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) acc[2 + n][4 + m] = g_mfma16<BF>(b1[n][ks], a1[m][ks], acc[2 + n][4 + m]);
+        G_MFMA(0, acc, 2, 4, b1, a1)
+        G_MFMA(1, acc, 2, 4, b1, a1)
         __builtin_amdgcn_s_setprio(0);
         G_SEG_END()
         // ---------------- phase 3: (A0, B1): no fragment reads ----------------
@@ -486,25 +548,26 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_h256_kernel(const GemmArgs g) {
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         G_SEG_END()
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) acc[2 + n][m] = g_mfma16<BF>(b1[n][ks], a0[m][ks], acc[2 + n][m]);
+        G_MFMA(0, acc, 2, 0, b1, a0)
+        G_MFMA(1, acc, 2, 0, b1, a0)
         __builtin_amdgcn_s_setprio(0);
         G_SEG_END()
     }
+#undef G_MFMA
 #undef G_SEG_END
+#undef G_LOAD
+#undef G_LGKM
     if (wr == 0) __builtin_amdgcn_s_barrier(); // pairs with the extra barrier of waves 4-7
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue. acc[n][m][e] = C[m0 + wr*128 + m*16 + (lane & 15)][n0 + wc*64 + n*16 + (lane >> 4)*4 + e]:
-    // four consecutive columns per lane -> one 8-byte store per accumulator tile
+    // four consecutive columns per lane -> one 8-byte store per accumulator tile. A transposed-read operand splits
+    // its 256 rows / columns into halves 0..127 | 128..255 instead (whole 256-B lines per DMA row), so a wave's
+    // tiles are then {half*128 + wr*64 + ..} / {half*128 + wc*32 + ..}.
     uint16_t *C = (uint16_t *)g.C;
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-        const int64_t col = n0 + wc * 64 + n * 16 + fg * 4;
+        const int64_t col = n0 + (TRB ? (n >> 1) * 128 + wc * 32 + (n & 1) * 16 : wc * 64 + n * 16) + fg * 4;
         float bias[4] = {0.f, 0.f, 0.f, 0.f};
         if (g.epilogue == KF_EPI_BIAS_ROW) {
 #pragma unroll
@@ -515,7 +578,7 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_h256_kernel(const GemmArgs g) {
         }
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
-            const int64_t row = m0 + wr * 128 + m * 16 + fr;
+            const int64_t row = m0 + (TRA ? (m >> 2) * 128 + wr * 64 + (m & 3) * 16 : wr * 128 + m * 16) + fr;
             uint16_t *dst = C + row * g.ldc + col;
             uint16_t h[4];
             uint2 old = {0, 0};
@@ -586,13 +649,39 @@ static bool h_fast_ok(int64_t M, int64_t N, int64_t K) { return M % H_BM == 0 &&
 
 using namespace kf;
 
+static bool h256_ok(int64_t M, int64_t N, int64_t K) {
+    return M % G_BM == 0 && N % G_BN == 0 && K % G_BK == 0 && M > 0 && N > 0 && K > 0 && !getenv("KF_GEMM_128");
+}
+
 extern "C" int kf_gemm_workspace_bytes(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, size_t *bytes) {
     KF_REQUIRE(bytes, KF_ERR_INVALID, "kf_gemm_workspace_bytes: null out pointer");
     *bytes = 0;
-    if ((dtype == KF_BF16 || dtype == KF_F16) && h_fast_ok(M, N, K)) {
+    // the 256-tile kernel reads every layout in place; the 128-tile one wants K-contiguous operands and re-lays the others
+    if ((dtype == KF_BF16 || dtype == KF_F16) && h_fast_ok(M, N, K) && !h256_ok(M, N, K)) {
         if (trans_a) *bytes += align_up((size_t)M * K * 2, 256);
         if (!trans_b) *bytes += align_up((size_t)K * N * 2, 256);
     }
+    return KF_OK;
+}
+
+template <bool BF>
+static int launch_h256(const GemmArgs &g, bool tra, bool trb, hipStream_t st) {
+    const unsigned grid = (unsigned)((g.M / G_BM) * (g.N / G_BN));
+#define KF_H256(TA, TB)                                                                                                   \
+    {                                                                                                                     \
+        static bool attr = false;                                                                                         \
+        if (!attr) {                                                                                                      \
+            KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_h256_kernel<BF, TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS)); \
+            attr = true;                                                                                                  \
+        }                                                                                                                 \
+        gemm_h256_kernel<BF, TA, TB><<<grid, G_NT, G_LDS, st>>>(g);                                                       \
+    }
+    if (!tra && !trb) KF_H256(false, false)
+    else if (!tra && trb) KF_H256(false, true)
+    else if (tra && !trb) KF_H256(true, false)
+    else KF_H256(true, true)
+#undef KF_H256
+    KF_LAUNCH_CHECK();
     return KF_OK;
 }
 
@@ -621,8 +710,13 @@ extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N
         return KF_OK;
     }
     if ((dtype == KF_BF16 || dtype == KF_F16) && h_fast_ok(M, N, K) && al16 && lda % 8 == 0 && ldb % 8 == 0) {
+        if (h256_ok(M, N, K) && g.ldc % 4 == 0 && (uintptr_t)C % 8 == 0) { // every operand layout is consumed in place
+            KF_PROF(dtype == KF_BF16 ? "gemm_bf16_mfma" : "gemm_f16_mfma", st);
+            return dtype == KF_BF16 ? launch_h256<true>(g, trans_a != 0, !trans_b, st) : launch_h256<false>(g, trans_a != 0, !trans_b, st);
+        }
         size_t need = 0;
-        kf_gemm_workspace_bytes(dtype, trans_a, trans_b, M, N, K, &need);
+        if (trans_a) need += align_up((size_t)M * K * 2, 256);
+        if (!trans_b) need += align_up((size_t)K * N * 2, 256);
         KF_REQUIRE(need == 0 || (workspace && workspace_bytes >= need && (uintptr_t)workspace % 16 == 0), KF_ERR_WORKSPACE,
                    "kf_gemm: workspace of %zu bytes (16-B aligned) required, got %zu", need, workspace_bytes);
         char *ws = (char *)workspace;
@@ -642,16 +736,6 @@ extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N
             KF_LAUNCH_CHECK();
             g.B = ws;
             g.ldb = K;
-        }
-        if (M % G_BM == 0 && N % G_BN == 0 && K >= G_BK && g.ldc % 4 == 0 && (uintptr_t)C % 8 == 0 && !getenv("KF_GEMM_128")) {
-            const unsigned grid2 = (unsigned)((M / G_BM) * (N / G_BN));
-            KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_h256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
-            KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_h256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
-            KF_PROF(dtype == KF_BF16 ? "gemm_bf16_mfma" : "gemm_f16_mfma", st);
-            if (dtype == KF_BF16) gemm_h256_kernel<true><<<grid2, G_NT, G_LDS, st>>>(g);
-            else gemm_h256_kernel<false><<<grid2, G_NT, G_LDS, st>>>(g);
-            KF_LAUNCH_CHECK();
-            return KF_OK;
         }
         const unsigned grid = (unsigned)((M / H_BM) * (N / H_BN));
         const size_t lds = 4 * H_TILE_BYTES;

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Timing of the non-MFMA attention paths (f32 — the reference's dtype — and 16-bit shapes the MFMA kernels do not
+cover) through the C ABI; HIP-event times from the library's profiling mode."""
+import argparse
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from kfunca_amd import hip_abi as H  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=3)
+    args = ap.parse_args()
+    H.set_device(0)
+    rng = np.random.default_rng(0)
+    for (code, B, Hh, S, D) in ((H.F32, 2, 8, 4096, 128), (H.F32, 2, 8, 4096, 64), (H.BF16, 2, 8, 4096, 64), (H.BF16, 2, 8, 4000, 128)):
+        es = 4 if code == H.F32 else 2
+        n = B * Hh * S * D
+        host = rng.uniform(-1, 1, n).astype(np.float32)
+        if code == H.BF16:
+            host = (host.view(np.uint32) >> 16).astype(np.uint16)
+        bufs = {k: H.DevBuf.from_numpy(host) for k in ("q", "k", "v", "do")}
+        for k in ("o", "dq", "dk", "dv"):
+            bufs[k] = H.DevBuf(n * es)
+        lse = H.DevBuf(4 * B * Hh * S)
+        need = H.attn_bwd_workspace_bytes(code, B, Hh, S, S, D)
+        ws = H.DevBuf(max(need, 16))
+        res = {}
+        for r in range(args.rounds + 1):
+            H.profile_reset()
+            H.profile_enable(True)
+            H.attn_fwd(code, B, Hh, S, S, D, bufs["q"].ptr, bufs["k"].ptr, bufs["v"].ptr, bufs["o"].ptr, lse.ptr)
+            H.attn_bwd(code, B, Hh, S, S, D, bufs["q"].ptr, bufs["k"].ptr, bufs["v"].ptr, bufs["o"].ptr, lse.ptr, bufs["do"].ptr,
+                       bufs["dq"].ptr, bufs["dk"].ptr, bufs["dv"].ptr, ws.ptr, need)
+            H.device_sync()
+            H.profile_enable(False)
+            if r:
+                for k, (ms, cnt) in H.profile_results().items():
+                    res.setdefault(k, []).append(ms / cnt)
+        pair = B * Hh * S * S * D / 2.0
+        print(f"== dtype {code} B={B} H={Hh} S={S} D={D}")
+        for k, xs in res.items():
+            med = float(np.median(xs))
+            fl = 4 * pair if "fwd" in k else 10 * pair
+            print(f"  {k:24s} {med:9.3f} ms   {fl / (med * 1e-3) / 1e12:7.1f} TF/s (algorithmic; bwd = whole backward's 10 units)")
+
+
+if __name__ == "__main__":
+    main()

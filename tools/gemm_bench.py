@@ -23,14 +23,17 @@ def main():
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--rounds", type=int, default=10)
     ap.add_argument("--variants", default="default")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     args = ap.parse_args()
     n = args.n
     H.set_device(0)
     rng = np.random.default_rng(0)
-    A, W, G = (H.DevBuf.from_numpy(bf16(rng, (n, n))) for _ in range(3))
-    out = H.DevBuf(2 * n * n)
-    need = max(H.gemm_workspace_bytes(H.BF16, ta, tb, n, n, n) for ta, tb in ((0, 0), (0, 1), (1, 0)))
-    ws = H.DevBuf(need)
+    DT = H.BF16 if args.dtype == "bf16" else H.F32
+    mk = (lambda: bf16(rng, (n, n))) if DT == H.BF16 else (lambda: rng.uniform(-1, 1, size=(n, n)).astype(np.float32))
+    A, W, G = (H.DevBuf.from_numpy(mk()) for _ in range(3))
+    out = H.DevBuf(4 * n * n)
+    need = max(H.gemm_workspace_bytes(DT, ta, tb, n, n, n) for ta, tb in ((0, 0), (0, 1), (1, 0)))
+    ws = H.DevBuf(max(need, 16))
     res = {}
     for r in range(args.rounds + 1):
         for v in args.variants.split(","):
@@ -38,16 +41,15 @@ def main():
                 del os.environ[e]
             if v != "default":
                 os.environ[v] = "1"
-            H.profile_reset()
-            H.profile_enable(True)
-            H.gemm(H.BF16, 0, 0, n, n, n, 1.0, A.ptr, n, W.ptr, n, 0.0, out.ptr, n, 0, None, ws.ptr, need)
-            H.gemm(H.BF16, 0, 1, n, n, n, 1.0, G.ptr, n, W.ptr, n, 0.0, out.ptr, n, 0, None, ws.ptr, need)
-            H.gemm(H.BF16, 1, 0, n, n, n, 1.0, A.ptr, n, G.ptr, n, 0.0, out.ptr, n, 0, None, ws.ptr, need)
-            H.device_sync()
-            H.profile_enable(False)
-            if r:
-                for k, (ms, cnt) in H.profile_results().items():
-                    res.setdefault(v, {}).setdefault(k, []).append((ms, cnt))
+            for tag, ta, tb, X, Y in (("NN fwd", 0, 0, A, W), ("NT dA", 0, 1, G, W), ("TN dB", 1, 0, A, G)):
+                H.profile_reset()
+                H.profile_enable(True)
+                H.gemm(DT, ta, tb, n, n, n, 1.0, X.ptr, n, Y.ptr, n, 0.0, out.ptr, n, 0, None, ws.ptr, need)
+                H.device_sync()
+                H.profile_enable(False)
+                if r:
+                    for k, (ms, cnt) in H.profile_results().items():
+                        res.setdefault(v, {}).setdefault(f"{k} [{tag}]", []).append((ms, cnt))
     for v, d in res.items():
         print(f"== {v} n={n}")
         tot = 0.0
@@ -55,7 +57,7 @@ def main():
             ms = float(np.median([m for m, _ in xs]))
             cnt = xs[0][1]
             tot += ms
-            tf = f"{2.0 * n ** 3 * cnt / (ms * 1e-3) / 1e12:8.1f} TF/s" if "mfma" in k else ""
+            tf = f"{2.0 * n ** 3 * cnt / (ms * 1e-3) / 1e12:8.1f} TF/s" if ("mfma" in k or "f32" in k) else ""
             print(f"  {k:22s} {ms / cnt:8.4f} ms x {cnt}  {tf}")
         print(f"  fwd+bwd total {tot:.4f} ms -> {6.0 * n ** 3 / (tot * 1e-3) / 1e12:.1f} TF/s")
 
