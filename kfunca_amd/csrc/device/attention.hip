@@ -25,6 +25,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace kf {
@@ -41,6 +43,7 @@ struct AttnArgs {
     float *lse;        // forward: written; backward: read
     const float *lse_r;
     float *delta;
+    float *nlse, *ndelta; // backward, dK/dV v4: -lse * sqrt(D) and -delta (initial accumulators of S and dP)
     int64_t B, H, Sq, Skv, D;
     float scale;
     int xcd_map; // 1: nbh % 8 == 0, heads are pinned to XCDs (a_block_map)
@@ -727,7 +730,8 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
 // backward pre-pass: delta[q] = sum_d dO[q][d] * O[q][d]   (16 lanes per row, 16-B loads)
 // ------------------------------------------------------------------------------------------
 template <bool BF>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const char *o, const char *d_o, float *delta, int64_t nrows) {
+__global__ __launch_bounds__(256) void attn_delta_kernel(const char *o, const char *d_o, float *delta, int64_t nrows, const float *lse = nullptr,
+                                                         float *nlse = nullptr, float *ndelta = nullptr, float rscale = 0.f) {
     const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int part = threadIdx.x & 15;
     float acc = 0.f;
@@ -749,7 +753,13 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const char *o, const ch
         }
     }
     for (int msk = 8; msk > 0; msk >>= 1) acc += __shfl_xor(acc, msk, 64);
-    if (row < nrows && part == 0) delta[row] = acc;
+    if (row < nrows && part == 0) {
+        delta[row] = acc;
+        if (nlse) { // row constants of the dK/dV kernel: S' = Q K^T - lse sqrt(D) and dP' = dO V^T - delta come out of the MFMA chains ready
+            nlse[row] = -lse[row] * rscale;
+            ndelta[row] = -acc;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1369,6 +1379,355 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v3_kernel(const AttnArgs a) 
 }
 
 // ==========================================================================================
+// backward: dK, dV, v4 - 4 waves x 32 keys, ONE wave per SIMD and the 512-register budget that goes with it.
+// The two-waves-per-SIMD kernel above cannot keep enough LDS reads in flight (256 registers, 128 of them
+// accumulators): its waves sit in s_waitcnt two thirds of the time. Here a wave walks a slice as eight quarter-phases
+// of 4 MFMAs (S, S, dP, dP, dV, dV, dK, dK), every quarter-phase's LDS fragments requested two quarter-phases ahead
+// (inline-asm reads, counted lgkmcnt waits that name their destinations). The arithmetic hides under MFMAs of the
+// SAME slice: p = exp2(c S') needs only S, so it runs under the dP chain; dV needs only p, so dS = p dP' runs under
+// the dV MFMAs. K and V fragments stay in registers (B operands of S and dP).
+// Row constants as initial accumulators: the pre-pass stores -lse sqrt(D) and -delta, a slice's 2 x 32 of them come
+// into LDS with its tiles and are read straight into the S and dP accumulators, so p = exp2(c S') and dS = p dP'.
+// LDS image of a 32-row tile: 8-row x 32-column subtiles of 512 B with the chunk XOR inside a subtile (guide T10,
+// image (a)) - two base VGPRs serve the 8 row reads of a tile and two the 16 transposed reads, the rest are
+// immediates. Q / dO slices stream through a ring of four slice PAIRS by LDS-DMA, one DMA operation per quarter-phase;
+// one barrier per pair, placed two quarter-phases before the pair ends so the next pair's first fragments are already
+// in flight at the loop edge.
+// ==========================================================================================
+constexpr int K4B = 128;                        // keys per block
+constexpr int K4SL = 2 * BQS * AROW + 256;      // slice buffer: Q tile | dO tile | nlse[32] | ndelta[32]
+constexpr int K4PAIR = 2 * K4SL;
+constexpr int K4LDS = 4 * K4PAIR;               // ring of four slice pairs, 130 KiB
+constexpr bool K4_SPREAD = false;
+static_assert(K4LDS >= 4 * 32 * OPAD, "epilogue slabs must fit");
+
+template <int OFF>
+__device__ __forceinline__ void k4_rows4(unsigned e, unsigned o, s16x8 (&f)[4]) { // four consecutive k-steps of one tile: even off e, odd off o
+    asm volatile("ds_read_b128 %0, %4 offset:%c6\n\tds_read_b128 %1, %5 offset:%c6\n\t"
+                 "ds_read_b128 %2, %4 offset:%c7\n\tds_read_b128 %3, %5 offset:%c7"
+                 : "=&v"(f[0]), "=&v"(f[1]), "=&v"(f[2]), "=&v"(f[3])
+                 : "v"(e), "v"(o), "n"(OFF), "n"(OFF + 512)
+                 : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void k4_rowc(unsigned lr, f32x4 (&c)[4]) { // 16 row constants: rows 8 g + 4 hl + {0..3}
+    asm volatile("ds_read_b128 %0, %4 offset:%c5\n\tds_read_b128 %1, %4 offset:%c6\n\t"
+                 "ds_read_b128 %2, %4 offset:%c7\n\tds_read_b128 %3, %4 offset:%c8"
+                 : "=&a"(c[0]), "=&a"(c[1]), "=&a"(c[2]), "=&a"(c[3]) // straight into accumulator registers
+                 : "v"(lr), "n"(OFF), "n"(OFF + 32), "n"(OFF + 64), "n"(OFF + 96)
+                 : "memory");
+}
+struct K4Tr { s16x4 lo[4], hi[4]; };
+template <int OFF>
+__device__ __forceinline__ void k4_tr4(unsigned t0, unsigned t1, K4Tr &t) { // column blocks d = 0..3 of one 16-row k-step
+    asm volatile("ds_read_b64_tr_b16 %0, %8 offset:%c10\n\tds_read_b64_tr_b16 %1, %9 offset:%c10\n\t"
+                 "ds_read_b64_tr_b16 %2, %8 offset:%c11\n\tds_read_b64_tr_b16 %3, %9 offset:%c11\n\t"
+                 "ds_read_b64_tr_b16 %4, %8 offset:%c12\n\tds_read_b64_tr_b16 %5, %9 offset:%c12\n\t"
+                 "ds_read_b64_tr_b16 %6, %8 offset:%c13\n\tds_read_b64_tr_b16 %7, %9 offset:%c13"
+                 : "=&v"(t.lo[0]), "=&v"(t.hi[0]), "=&v"(t.lo[1]), "=&v"(t.hi[1]), "=&v"(t.lo[2]), "=&v"(t.hi[2]), "=&v"(t.lo[3]), "=&v"(t.hi[3])
+                 : "v"(t0), "v"(t1), "n"(OFF), "n"(OFF + 512), "n"(OFF + 1024), "n"(OFF + 1536)
+                 : "memory");
+}
+// counted waits: N = LDS operations issued after the ones being waited for; the destinations are named so that no
+// consumer can be scheduled above the wait
+template <int N>
+__device__ __forceinline__ void k4_wait4(s16x8 (&f)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%c4)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void k4_wait4c(s16x8 (&f)[4], f32x4 (&c)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%c8)"
+                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+a"(c[0]), "+a"(c[1]), "+a"(c[2]), "+a"(c[3])
+                 : "n"(N)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void k4_wait_tr(K4Tr &a) {
+    asm volatile("s_waitcnt lgkmcnt(%c8)"
+                 : "+v"(a.lo[0]), "+v"(a.hi[0]), "+v"(a.lo[1]), "+v"(a.hi[1]), "+v"(a.lo[2]), "+v"(a.hi[2]), "+v"(a.lo[3]), "+v"(a.hi[3])
+                 : "n"(N)
+                 : "memory");
+}
+template <bool BF>
+__device__ __forceinline__ typename AFrag<BF>::type k4_frag(const K4Tr &t, int d) {
+    s16x8 r;
+    r[0] = t.lo[d][0]; r[1] = t.lo[d][1]; r[2] = t.lo[d][2]; r[3] = t.lo[d][3];
+    r[4] = t.hi[d][0]; r[5] = t.hi[d][1]; r[6] = t.hi[d][2]; r[7] = t.hi[d][3];
+    return __builtin_bit_cast(typename AFrag<BF>::type, r);
+}
+__device__ __forceinline__ f32x16 k4_acc(const f32x4 (&c)[4]) {
+    f32x16 r;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[4 * g + j] = c[g][j];
+    return r;
+}
+// p = exp2(c S'), dS = p dP' on one slice; S' and dP' arrive with their row constants folded in
+template <bool BF, bool MASK>
+__device__ __forceinline__ void k4_softmax(f32x16 &s, f32x16 &dp, float c, int64_t qs, int64_t n, int hl, typename AFrag<BF>::type (&pf)[2],
+                                           typename AFrag<BF>::type (&df)[2]) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        float p = __builtin_amdgcn_exp2f(s[e] * c);
+        if (MASK && n > qs + a_row(e, hl)) p = 0.f;
+        s[e] = p;
+        dp[e] = p * dp[e];
+    }
+    pf[0] = a_pack<BF>(s, 0); pf[1] = a_pack<BF>(s, 1);
+    df[0] = a_pack<BF>(dp, 0); df[1] = a_pack<BF>(dp, 1);
+}
+
+template <bool BF>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) {
+    using frag_t = typename AFrag<BF>::type;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), xl = lane & 31, hl = lane >> 5;
+    int xb;
+    int64_t bh;
+    a_block_map((int)(a.Skv / K4B), (int)(a.B * a.H), a.xcd_map, xb, bh);
+    const int64_t k0 = (int64_t)xb * K4B, kw = k0 + wid * 32, n = kw + xl;
+    const char *Qg = a.q + bh * a.Sq * AROW;
+    const char *dOg = a.d_o + bh * a.Sq * AROW;
+
+    frag_t kf[8], vf[8]; // this wave's 32 keys: B operands of S = Q K^T and dP = dO V^T
+    {
+        const char *Kg = a.k + (bh * a.Skv + n) * AROW;
+        const char *Vg = a.v + (bh * a.Skv + n) * AROW;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            kf[kk] = *(const frag_t *)(Kg + (kk * 16 + 8 * hl) * 2);
+            vf[kk] = *(const frag_t *)(Vg + (kk * 16 + 8 * hl) * 2);
+        }
+    }
+    f32x16 dk[4], dv[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk[d][e] = 0.f; dv[d][e] = 0.f; }
+    const float c = a.scale * kLog2e;
+
+    // ---- per-lane LDS read addresses inside a slice buffer (tile image (a): off(row, ch) =
+    //      2048 (row >> 3) + 512 (ch >> 2) + 64 (row & 7) + 16 ((ch & 3) ^ ((row >> 2) & 3)))
+    const unsigned smem_u = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)smem;
+    const int rsw = (xl >> 2) & 3;
+    const unsigned rb_e = smem_u + 2048 * (xl >> 3) + 64 * (xl & 7) + 16 * ((0 + hl) ^ rsw); // row xl, chunk 2 kk + hl, kk even
+    const unsigned rb_o = smem_u + 2048 * (xl >> 3) + 64 * (xl & 7) + 16 * ((2 + hl) ^ rsw); // kk odd
+    const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3, h = g >> 1;
+    const int tslot = 2 * (g & 1) + (pp >> 1);
+    const unsigned tb_0 = smem_u + 64 * (4 * h + qq) + 16 * (tslot ^ h) + 8 * (pp & 1);              // rows 16 ks + 4 h + qq
+    const unsigned tb_1 = smem_u + 2048 + 64 * (4 * h + qq) + 16 * (tslot ^ (h + 2)) + 8 * (pp & 1); // ... + 8
+    const unsigned lr = smem_u + 2 * BQS * AROW + 16 * hl;                                           // row constants 8 g4 + 4 hl
+
+    // ---- LDS-DMA: a 32-row tile is 8 wave-instructions of 1 KiB (8 rows x 128 B each); wave w moves rows 8 w .. 8 w + 7
+    // of the Q tile and of the dO tile, and every wave fetches the 64 row constants (identical bytes: uniform counts).
+    int soff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int sub = 2 * i + (lane >> 5), r = (lane >> 2) & 7, slot = lane & 3, row = 8 * wid + r;
+        soff[i] = row * AROW + (4 * sub + (slot ^ ((row >> 2) & 3))) * 16;
+    }
+    const float *rcg = lane < BQS ? a.nlse + bh * a.Sq + lane : a.ndelta + bh * a.Sq + lane - BQS;
+    const int ns = (int)(a.Sq / BQS), np = ns / 2;
+    // a pair is 10 DMA operations per wave (ids 0..9: slice id / 5; Q rows i, dO rows i for i = 0, 1, then the row
+    // constants); they are issued ONE per quarter-phase (an LDS-DMA instruction holds the wave's issue for 60-180 cycles,
+    // which a lone wave per SIMD can only hide under MFMAs already queued)
+    auto stage_piece = [&](auto id_c, int pr_, int slot4) __attribute__((always_inline)) {
+        constexpr int ID = decltype(id_c)::value, SL = ID / 5, K = ID % 5;
+        const int prc = pr_ < np ? pr_ : np - 1; // past the end: re-fetch the last pair (keeps the counts uniform; never consumed)
+        const int64_t qs_ = ((int64_t)prc * 2 + SL) * BQS;
+        char *buf = smem + slot4 * K4PAIR + SL * K4SL;
+        if constexpr (K == 4) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rcg + qs_),
+                                             (__attribute__((address_space(3))) void *)(buf + 2 * BQS * AROW), 4, 0, 0);
+        } else {
+            constexpr int i = K >> 1;
+            const char *src = (K & 1) ? dOg : Qg;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + qs_ * AROW + soff[i]),
+                                             (__attribute__((address_space(3))) void *)(buf + (K & 1) * BQS * AROW + 1024 * (2 * wid + i)), 16, 0, 0);
+        }
+    };
+    auto stage_pair = [&](int pr_, int slot4) __attribute__((always_inline)) {
+        stage_piece(std::integral_constant<int, 0>{}, pr_, slot4); stage_piece(std::integral_constant<int, 1>{}, pr_, slot4);
+        stage_piece(std::integral_constant<int, 2>{}, pr_, slot4); stage_piece(std::integral_constant<int, 3>{}, pr_, slot4);
+        stage_piece(std::integral_constant<int, 4>{}, pr_, slot4); stage_piece(std::integral_constant<int, 5>{}, pr_, slot4);
+        stage_piece(std::integral_constant<int, 6>{}, pr_, slot4); stage_piece(std::integral_constant<int, 7>{}, pr_, slot4);
+        stage_piece(std::integral_constant<int, 8>{}, pr_, slot4); stage_piece(std::integral_constant<int, 9>{}, pr_, slot4);
+    };
+
+    const int p0 = (int)(k0 / (2 * BQS)); // first pair holding a query >= the block's first key
+    stage_pair(p0, 0);
+    stage_pair(p0 + 1, 1);
+    if constexpr (K4_SPREAD) {
+        stage_piece(std::integral_constant<int, 0>{}, p0 + 2, 2); // what the last two quarter-phases of a pair "p0 - 1" would issue
+        stage_piece(std::integral_constant<int, 1>{}, p0 + 2, 2);
+    } else {
+        stage_pair(p0 + 2, 2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // pair p0 has landed (this wave's part) ...
+    __builtin_amdgcn_s_barrier();                      // ... and everyone else's
+    asm volatile("" ::: "memory");
+
+    // One slice = eight quarter-phases of 4 MFMAs, each with its own LDS read group requested TWO quarter-phases ahead:
+    //   q0 S k0..3 [Q 0..3 + row constants]  q1 S k4..7 [Q 4..7]  q2 dP k0..3 [dO 0..3 + constants]  q3 dP k4..7 [dO 4..7]
+    //   q4 dV k-step 0 [dO^T]  q5 dV k-step 1 [dO^T]  q6 dK k-step 0 [Q^T]  q7 dK k-step 1 [Q^T]
+    // (instruction counts 8 4 8 4 8 8 8 8; a wait leaves the two younger groups in flight, lgkmcnt saturates at 15).
+    // p = exp2(c S') and its conversion run under the dP chain (q2, q3); dS = p dP' and its conversion under the dV
+    // MFMAs (q4, q5), which need only p. q6 / q7 of a slice request the next slice's first two groups.
+    s16x8 g0[4], g1[4];
+    f32x4 cs[4];
+    k4_rows4<0>(rb_e, rb_o, g0);
+    k4_rowc<0>(lr, cs);
+    k4_rows4<1024>(rb_e, rb_o, g1);
+
+#define K4_MFMA4(ACC, FR, BOP, K0)                                                                                   \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) ACC = a_mfma<BF>(__builtin_bit_cast(frag_t, FR[kk]), BOP[K0 + kk], ACC);
+#define K4_MFMA_T(ACC, TR, PF)                                                                                       \
+    _Pragma("unroll") for (int d = 0; d < 4; ++d) ACC[d] = a_mfma<BF>(k4_frag<BF>(TR, d), PF, ACC[d]);
+
+    // SOFF: this slice's offset inside its pair buffer (bases e, o, t0, t1, l); the next slice's first groups are read off
+    // (en, on, ln) + NOFF; LAST: the slice that ends a pair (barrier + DMA of the pair after next before its q6)
+    auto slice_body = [&](auto mask_c, auto soff_c, auto noff_c, auto last_c, unsigned e, unsigned o, unsigned t0, unsigned t1, unsigned l,
+                          unsigned en, unsigned on, unsigned ln, int64_t qs, int pr, int it) __attribute__((always_inline)) {
+        constexpr bool MASK = decltype(mask_c)::value, LAST = decltype(last_c)::value;
+        constexpr int SOFF = decltype(soff_c)::value, NOFF = decltype(noff_c)::value, DO = SOFF + BQS * AROW;
+        f32x16 sv, dpv;
+        s16x8 g2[4], g3[4];
+        f32x4 cp[4];
+        K4Tr t4, t5, t6, t7;
+        frag_t pf[2], df[2];
+        // DMA schedule: after the barrier of pair pr (q6 of its second slice) come pieces 0, 1 of pair pr + 3; the first
+        // slice of pair pr + 1 then issues pieces 2..9 of that same pair, one per quarter-phase
+#define K4_PIECE(Q) if constexpr (!LAST && K4_SPREAD) stage_piece(std::integral_constant<int, 2 + Q>{}, pr + 2, (it + 2) & 3);
+        // q0
+        K4_PIECE(0)
+        k4_rows4<DO>(e, o, g2); k4_rowc<SOFF + 128>(l, cp);
+        k4_wait4c<12>(g0, cs);
+        sv = k4_acc(cs);
+        K4_MFMA4(sv, g0, kf, 0)
+        // q1
+        K4_PIECE(1)
+        k4_rows4<DO + 1024>(e, o, g3);
+        k4_wait4<12>(g1);
+        K4_MFMA4(sv, g1, kf, 4)
+        // q2
+        K4_PIECE(2)
+        k4_tr4<DO>(t0, t1, t4);
+        k4_wait4c<12>(g2, cp);
+        dpv = k4_acc(cp);
+        // the order below is pinned: left alone the scheduler puts the whole exp block in front of the dP chain and the
+        // whole dS block behind the dV MFMAs, and a lone wave then leaves the matrix pipe idle meanwhile. MFMA and VALU
+        // intrinsics are pure values (sched_barrier does not order them), so empty volatile asm statements that "redefine"
+        // the accumulator and the values in flight supply the dependencies: MFMA -> mark -> two elements -> mark -> MFMA.
+        // One dP MFMA (32 cycles in the pipe) covers two elements of p = exp2(c S').
+        float pe[16];
+#define K4_EXP2(E)                                                                      \
+    _Pragma("unroll") for (int e_ = (E); e_ < (E) + 2; ++e_) {                          \
+        float pv = __builtin_amdgcn_exp2f(sv[e_] * c);                                  \
+        if (MASK && n > qs + a_row(e_, hl)) pv = 0.f;                                   \
+        pe[e_] = pv;                                                                    \
+    }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            dpv = a_mfma<BF>(__builtin_bit_cast(frag_t, g2[kk]), vf[kk], dpv);
+            asm volatile("" : "+a"(dpv), "+a"(sv));
+            K4_EXP2(2 * kk)
+            asm volatile("" : "+a"(dpv), "+v"(pe[2 * kk]), "+v"(pe[2 * kk + 1]));
+        }
+        // q3
+        K4_PIECE(3)
+        k4_tr4<DO + 4096>(t0, t1, t5);
+        k4_wait4<15>(g3);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            dpv = a_mfma<BF>(__builtin_bit_cast(frag_t, g3[kk]), vf[4 + kk], dpv);
+            asm volatile("" : "+a"(dpv), "+a"(sv));
+            K4_EXP2(8 + 2 * kk)
+            asm volatile("" : "+a"(dpv), "+v"(pe[8 + 2 * kk]), "+v"(pe[9 + 2 * kk]));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (BF) { pf[0][j] = (__bf16)pe[j]; pf[1][j] = (__bf16)pe[8 + j]; }
+            else { pf[0][j] = (_Float16)pe[j]; pf[1][j] = (_Float16)pe[8 + j]; }
+        }
+        // q4: one dV MFMA covers two elements of dS = p dP'
+        K4_PIECE(4)
+        k4_tr4<SOFF>(t0, t1, t6);
+        k4_wait_tr<15>(t4);
+        float de[16];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            dv[d] = a_mfma<BF>(k4_frag<BF>(t4, d), pf[0], dv[d]);
+            asm volatile("" : "+a"(dv[d]), "+a"(dpv));
+            de[2 * d] = pe[2 * d] * dpv[2 * d]; de[2 * d + 1] = pe[2 * d + 1] * dpv[2 * d + 1];
+            asm volatile("" : "+a"(dv[(d + 1) & 3]), "+v"(de[2 * d]), "+v"(de[2 * d + 1]));
+        }
+        // q5
+        K4_PIECE(5)
+        k4_tr4<SOFF + 4096>(t0, t1, t7);
+        k4_wait_tr<15>(t5);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            dv[d] = a_mfma<BF>(k4_frag<BF>(t5, d), pf[1], dv[d]);
+            asm volatile("" : "+a"(dv[d]), "+a"(dpv));
+            de[8 + 2 * d] = pe[8 + 2 * d] * dpv[8 + 2 * d]; de[9 + 2 * d] = pe[9 + 2 * d] * dpv[9 + 2 * d];
+            asm volatile("" : "+a"(dv[(d + 1) & 3]), "+v"(de[8 + 2 * d]), "+v"(de[9 + 2 * d]));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (BF) { df[0][j] = (__bf16)de[j]; df[1][j] = (__bf16)de[8 + j]; }
+            else { df[0][j] = (_Float16)de[j]; df[1][j] = (_Float16)de[8 + j]; }
+        }
+#undef K4_EXP2
+        // q6
+        if constexpr (LAST) {
+            // the next pair has landed - this wave's part, then everyone's - and every wave is past its reads of the
+            // previous pair, whose buffer takes pair pr + 3. vmcnt(0), not a counted wait: register spills are VMEM
+            // operations too and would be counted among "the youngest"; the pair after next was issued a slice ago.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if constexpr (K4_SPREAD) stage_piece(std::integral_constant<int, 0>{}, pr + 3, (it + 3) & 3);
+            else stage_pair(pr + 3, (it + 3) & 3);
+        } else {
+            K4_PIECE(6)
+        }
+        k4_rows4<NOFF>(en, on, g0); k4_rowc<NOFF>(ln, cs);
+        k4_wait_tr<15>(t6);
+        K4_MFMA_T(dk, t6, df[0])
+        // q7
+        if constexpr (LAST && K4_SPREAD) stage_piece(std::integral_constant<int, 1>{}, pr + 3, (it + 3) & 3);
+        else { K4_PIECE(7) }
+        k4_rows4<NOFF + 1024>(en, on, g1);
+        k4_wait_tr<12>(t7);
+        K4_MFMA_T(dk, t7, df[1])
+#undef K4_PIECE
+    };
+
+    using I0 = std::integral_constant<int, 0>;
+    using IS = std::integral_constant<int, K4SL>;
+    auto pair_body = [&](auto mask_c, int pr, int it) __attribute__((always_inline)) {
+        const unsigned bo = (unsigned)((it & 3) * K4PAIR);           // this pair's buffer
+        const unsigned bn = (unsigned)(((it + 1) & 3) * K4PAIR);     // the next pair's
+        const int64_t qa = (int64_t)pr * 2 * BQS, qb = qa + BQS;
+        const unsigned e = rb_e + bo, o = rb_o + bo, t0 = tb_0 + bo, t1 = tb_1 + bo, l = lr + bo;
+        slice_body(mask_c, I0{}, IS{}, std::false_type{}, e, o, t0, t1, l, e, o, l, qa, pr, it);
+        slice_body(mask_c, IS{}, I0{}, std::true_type{}, e, o, t0, t1, l, rb_e + bn, rb_o + bn, lr + bn, qb, pr, it);
+    };
+    // two loops, one body each (a loop that switches between the masked and the plain body makes the allocator shuttle
+    // the dK / dV accumulators between the two register files at every iteration)
+    int pr = p0, it = 0;
+    for (; pr < np && (int64_t)pr * 2 * BQS < kw + 31; ++pr, ++it) pair_body(std::true_type{}, pr, it);
+    for (; pr < np; ++pr, ++it) pair_body(std::false_type{}, pr, it);
+#undef K4_MFMA4
+#undef K4_MFMA_T
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // drain the ring and the last prefetch before LDS is reused
+    __syncthreads();
+    a_store_rows<BF>(smem + wid * 32 * OPAD, a.dv + (bh * a.Skv + kw) * AROW, dv, 1.f);
+    a_store_rows<BF>(smem + wid * 32 * OPAD, a.dk + (bh * a.Skv + kw) * AROW, dk, a.scale);
+}
+
+// ==========================================================================================
 // generic path: f32 math on the vector ALU, any Sq / Skv, D <= 256, f32 / bf16 / f16 storage.
 // One block = 16 queries; key tiles of 32; 256 threads.
 // ==========================================================================================
@@ -1714,7 +2073,7 @@ extern "C" int kf_attn_bwd_workspace_bytes(int dtype, int64_t B, int64_t H, int6
     KF_REQUIRE(bytes, KF_ERR_INVALID, "kf_attn_bwd_workspace_bytes: null out pointer");
     int rc = check_common("kf_attn_bwd_workspace_bytes", dtype, B, H, Sq, Skv, D);
     if (rc != KF_OK) return rc;
-    *bytes = a_align((size_t)B * H * Sq * sizeof(float)); // delta
+    *bytes = 3 * a_align((size_t)B * H * Sq * sizeof(float)); // delta | -lse sqrt(D) | -delta
     return KF_OK;
 }
 
@@ -1734,6 +2093,8 @@ extern "C" int kf_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
     a.q = (const char *)q; a.k = (const char *)k; a.v = (const char *)v; a.o = (const char *)o; a.d_o = (const char *)d_o;
     a.dq = (char *)dq; a.dk = (char *)dk; a.dv = (char *)dv;
     a.lse_r = lse; a.delta = (float *)workspace;
+    a.nlse = (float *)((char *)workspace + a_align((size_t)B * H * Sq * sizeof(float)));
+    a.ndelta = (float *)((char *)workspace + 2 * a_align((size_t)B * H * Sq * sizeof(float)));
     a.xcd_map = ((B * H) % 8 == 0) && !getenv("KF_ATTN_NO_XCD");
     a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.D = D;
     a.scale = 1.0f / sqrtf((float)D);
@@ -1749,14 +2110,22 @@ extern "C" int kf_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
         const bool bf = dtype == KF_BF16;
         {
             KF_PROF("attn_bwd_delta", st);
-            if (bf) attn_delta_kernel<true><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows);
-            else attn_delta_kernel<false><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows);
+            if (bf) attn_delta_kernel<true><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, sqrtf((float)D));
+            else attn_delta_kernel<false><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, sqrtf((float)D));
             KF_LAUNCH_CHECK();
         }
         if (getenv("KF_ATTN_DKV_V1")) { // A/B switch for the first-generation kernel
             KF_PROF("attn_bwd_dkv_mfma_v1", st);
             if (bf) attn_bwd_dkv_kernel<true><<<gk, 256, lds, st>>>(a);
             else attn_bwd_dkv_kernel<false><<<gk, 256, lds, st>>>(a);
+            KF_LAUNCH_CHECK();
+        } else if (getenv("KF_ATTN_DKV_V4")) {
+            dim3 gk4((unsigned)((Skv / K4B) * B * H));
+            if ((rc = set_lds(attn_bwd_dkv_v4_kernel<true>, K4LDS)) != KF_OK) return rc;
+            if ((rc = set_lds(attn_bwd_dkv_v4_kernel<false>, K4LDS)) != KF_OK) return rc;
+            KF_PROF("attn_bwd_dkv_mfma_v4", st);
+            if (bf) attn_bwd_dkv_v4_kernel<true><<<gk4, 256, K4LDS, st>>>(a);
+            else attn_bwd_dkv_v4_kernel<false><<<gk4, 256, K4LDS, st>>>(a);
             KF_LAUNCH_CHECK();
         } else if (getenv("KF_ATTN_DKV_V3")) {
             if ((rc = set_lds(attn_bwd_dkv_v3_kernel<true>, K3LDS)) != KF_OK) return rc;
