@@ -1568,22 +1568,33 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     __builtin_amdgcn_s_barrier();                      // ... and everyone else's
     asm volatile("" ::: "memory");
 
-    // One slice = eight quarter-phases of 4 MFMAs, each with its own LDS read group requested TWO quarter-phases ahead:
-    //   q0 S k0..3 [Q 0..3 + row constants]  q1 S k4..7 [Q 4..7]  q2 dP k0..3 [dO 0..3 + constants]  q3 dP k4..7 [dO 4..7]
+    // One slice = eight quarter-phases of 4 MFMAs, each with its own LDS read group requested two quarter-phases ahead:
+    //   q0 S k0..3 [Q 0..3]   q1 S k4..7 [Q 4..7]   q2 dP k0..3 [dO 0..3]   q3 dP k4..7 [dO 4..7]
     //   q4 dV k-step 0 [dO^T]  q5 dV k-step 1 [dO^T]  q6 dK k-step 0 [Q^T]  q7 dK k-step 1 [Q^T]
-    // (instruction counts 8 4 8 4 8 8 8 8; a wait leaves the two younger groups in flight, lgkmcnt saturates at 15).
-    // p = exp2(c S') and its conversion run under the dP chain (q2, q3); dS = p dP' and its conversion under the dV
-    // MFMAs (q4, q5), which need only p. q6 / q7 of a slice request the next slice's first two groups.
+    // in issue order  q5: dO^T k1 + next slice's S constants (12) | q6: next Q 0..3 (4) | q7: next Q 4..7 + next dP constants
+    // (8) | q0: dO 0..3 (4) | q1: dO 4..7 (4) | q2: dO^T k0 (8) | q3: dO^T... (8) | q4: Q^T k0 (8); a wait leaves the two
+    // younger groups in flight (lgkmcnt saturates at 15).
+    // Every VALU instruction of the slice rides behind an MFMA of the same wave, in an order pinned by empty volatile asm
+    // statements (MFMA and VALU intrinsics are pure values, sched_barrier does not order them; left alone the scheduler
+    // lumps the arithmetic between the MFMA groups and a lone wave then leaves the matrix pipe idle meanwhile):
+    //   q1  the dP accumulator takes its row constants        q2, q3  p = exp2(c S'), two elements per MFMA; pack p (k0)
+    //   q4  dS = p dP' (k0 elements); pack p (k1)               q5  dS (k1 elements); pack dS (k0)
+    //   q6  pack dS (k1)                                        q7  the next slice's S accumulator takes its row constants
     s16x8 g0[4], g1[4];
-    f32x4 cs[4];
-    k4_rows4<0>(rb_e, rb_o, g0);
+    f32x4 cs[4], cp[4];
+    f32x16 sv;
     k4_rowc<0>(lr, cs);
+    k4_rows4<0>(rb_e, rb_o, g0);
     k4_rows4<1024>(rb_e, rb_o, g1);
+    k4_rowc<128>(lr, cp);
+    asm volatile("s_waitcnt lgkmcnt(12)" : "+a"(cs[0]), "+a"(cs[1]), "+a"(cs[2]), "+a"(cs[3]) : : "memory");
+    sv = k4_acc(cs);
 
 #define K4_MFMA4(ACC, FR, BOP, K0)                                                                                   \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) ACC = a_mfma<BF>(__builtin_bit_cast(frag_t, FR[kk]), BOP[K0 + kk], ACC);
-#define K4_MFMA_T(ACC, TR, PF)                                                                                       \
-    _Pragma("unroll") for (int d = 0; d < 4; ++d) ACC[d] = a_mfma<BF>(k4_frag<BF>(TR, d), PF, ACC[d]);
+#define K4_CVT2(DST, J, A, B)                                              \
+    if constexpr (BF) { DST[J] = (__bf16)(A); DST[(J) + 1] = (__bf16)(B); } \
+    else { DST[J] = (_Float16)(A); DST[(J) + 1] = (_Float16)(B); }
 
     // SOFF: this slice's offset inside its pair buffer (bases e, o, t0, t1, l); the next slice's first groups are read off
     // (en, on, ln) + NOFF; LAST: the slice that ends a pair (barrier + DMA of the pair after next before its q6)
@@ -1591,36 +1602,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
                           unsigned en, unsigned on, unsigned ln, int64_t qs, int pr, int it) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(mask_c)::value, LAST = decltype(last_c)::value;
         constexpr int SOFF = decltype(soff_c)::value, NOFF = decltype(noff_c)::value, DO = SOFF + BQS * AROW;
-        f32x16 sv, dpv;
+        f32x16 dpv, svn;
         s16x8 g2[4], g3[4];
-        f32x4 cp[4];
         K4Tr t4, t5, t6, t7;
         frag_t pf[2], df[2];
-        // DMA schedule: after the barrier of pair pr (q6 of its second slice) come pieces 0, 1 of pair pr + 3; the first
-        // slice of pair pr + 1 then issues pieces 2..9 of that same pair, one per quarter-phase
-#define K4_PIECE(Q) if constexpr (!LAST && K4_SPREAD) stage_piece(std::integral_constant<int, 2 + Q>{}, pr + 2, (it + 2) & 3);
-        // q0
-        K4_PIECE(0)
-        k4_rows4<DO>(e, o, g2); k4_rowc<SOFF + 128>(l, cp);
-        k4_wait4c<12>(g0, cs);
-        sv = k4_acc(cs);
+        float pe[16], de[16];
+        // q0: S k-steps 0..3
+        k4_rows4<DO>(e, o, g2);
+        k4_wait4<12>(g0);
         K4_MFMA4(sv, g0, kf, 0)
-        // q1
-        K4_PIECE(1)
+        // q1: S k-steps 4..7; the dP accumulator takes its row constants (- delta)
         k4_rows4<DO + 1024>(e, o, g3);
-        k4_wait4<12>(g1);
-        K4_MFMA4(sv, g1, kf, 4)
-        // q2
-        K4_PIECE(2)
+        k4_wait4c<8>(g1, cp);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            sv = a_mfma<BF>(__builtin_bit_cast(frag_t, g1[kk]), kf[4 + kk], sv);
+            asm volatile("" : "+a"(sv), "+a"(cp[kk]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dpv[4 * kk + j] = cp[kk][j];
+            asm volatile("" : "+a"(sv), "+a"(dpv));
+        }
+        // q2: dP k-steps 0..3; p = exp2(c S') for elements 0..7
         k4_tr4<DO>(t0, t1, t4);
-        k4_wait4c<12>(g2, cp);
-        dpv = k4_acc(cp);
-        // the order below is pinned: left alone the scheduler puts the whole exp block in front of the dP chain and the
-        // whole dS block behind the dV MFMAs, and a lone wave then leaves the matrix pipe idle meanwhile. MFMA and VALU
-        // intrinsics are pure values (sched_barrier does not order them), so empty volatile asm statements that "redefine"
-        // the accumulator and the values in flight supply the dependencies: MFMA -> mark -> two elements -> mark -> MFMA.
-        // One dP MFMA (32 cycles in the pipe) covers two elements of p = exp2(c S').
-        float pe[16];
+        k4_wait4<12>(g2);
 #define K4_EXP2(E)                                                                      \
     _Pragma("unroll") for (int e_ = (E); e_ < (E) + 2; ++e_) {                          \
         float pv = __builtin_amdgcn_exp2f(sv[e_] * c);                                  \
@@ -1634,74 +1638,80 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
             K4_EXP2(2 * kk)
             asm volatile("" : "+a"(dpv), "+v"(pe[2 * kk]), "+v"(pe[2 * kk + 1]));
         }
-        // q3
-        K4_PIECE(3)
+        // q3: dP k-steps 4..7; elements 8..15; pack p of k-step 0
         k4_tr4<DO + 4096>(t0, t1, t5);
         k4_wait4<15>(g3);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             dpv = a_mfma<BF>(__builtin_bit_cast(frag_t, g3[kk]), vf[4 + kk], dpv);
-            asm volatile("" : "+a"(dpv), "+a"(sv));
+            asm volatile("" : "+a"(dpv), "+a"(sv), "+v"(pe[2 * kk]), "+v"(pe[2 * kk + 1]));
             K4_EXP2(8 + 2 * kk)
-            asm volatile("" : "+a"(dpv), "+v"(pe[8 + 2 * kk]), "+v"(pe[9 + 2 * kk]));
+            K4_CVT2(pf[0], 2 * kk, pe[2 * kk], pe[2 * kk + 1])
+            asm volatile("" : "+a"(dpv), "+v"(pe[8 + 2 * kk]), "+v"(pe[9 + 2 * kk]), "+v"(pf[0]));
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if constexpr (BF) { pf[0][j] = (__bf16)pe[j]; pf[1][j] = (__bf16)pe[8 + j]; }
-            else { pf[0][j] = (_Float16)pe[j]; pf[1][j] = (_Float16)pe[8 + j]; }
-        }
-        // q4: one dV MFMA covers two elements of dS = p dP'
-        K4_PIECE(4)
+#undef K4_EXP2
+        // q4: dV k-step 0; dS = p dP' for elements 0..7; pack p of k-step 1
         k4_tr4<SOFF>(t0, t1, t6);
         k4_wait_tr<15>(t4);
-        float de[16];
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             dv[d] = a_mfma<BF>(k4_frag<BF>(t4, d), pf[0], dv[d]);
-            asm volatile("" : "+a"(dv[d]), "+a"(dpv));
+            asm volatile("" : "+a"(dv[d]), "+a"(dpv), "+v"(pe[8 + 2 * d]), "+v"(pe[9 + 2 * d]));
             de[2 * d] = pe[2 * d] * dpv[2 * d]; de[2 * d + 1] = pe[2 * d + 1] * dpv[2 * d + 1];
-            asm volatile("" : "+a"(dv[(d + 1) & 3]), "+v"(de[2 * d]), "+v"(de[2 * d + 1]));
+            K4_CVT2(pf[1], 2 * d, pe[8 + 2 * d], pe[9 + 2 * d])
+            asm volatile("" : "+a"(dv[(d + 1) & 3]), "+v"(de[2 * d]), "+v"(de[2 * d + 1]), "+v"(pf[1]));
         }
-        // q5
-        K4_PIECE(5)
+        // q5: dV k-step 1; dS for elements 8..15; pack dS of k-step 0
         k4_tr4<SOFF + 4096>(t0, t1, t7);
+        k4_rowc<NOFF>(ln, cs); // the next slice's S constants (q7 moves them into its accumulator)
         k4_wait_tr<15>(t5);
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             dv[d] = a_mfma<BF>(k4_frag<BF>(t5, d), pf[1], dv[d]);
-            asm volatile("" : "+a"(dv[d]), "+a"(dpv));
+            asm volatile("" : "+a"(dv[d]), "+a"(dpv), "+v"(de[2 * d]), "+v"(de[2 * d + 1]));
             de[8 + 2 * d] = pe[8 + 2 * d] * dpv[8 + 2 * d]; de[9 + 2 * d] = pe[9 + 2 * d] * dpv[9 + 2 * d];
-            asm volatile("" : "+a"(dv[(d + 1) & 3]), "+v"(de[8 + 2 * d]), "+v"(de[9 + 2 * d]));
+            K4_CVT2(df[0], 2 * d, de[2 * d], de[2 * d + 1])
+            asm volatile("" : "+a"(dv[(d + 1) & 3]), "+v"(de[8 + 2 * d]), "+v"(de[9 + 2 * d]), "+v"(df[0]));
         }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if constexpr (BF) { df[0][j] = (__bf16)de[j]; df[1][j] = (__bf16)de[8 + j]; }
-            else { df[0][j] = (_Float16)de[j]; df[1][j] = (_Float16)de[8 + j]; }
-        }
-#undef K4_EXP2
-        // q6
+        // q6: dK k-step 0; pack dS of k-step 1
         if constexpr (LAST) {
             // the next pair has landed - this wave's part, then everyone's - and every wave is past its reads of the
             // previous pair, whose buffer takes pair pr + 3. vmcnt(0), not a counted wait: register spills are VMEM
-            // operations too and would be counted among "the youngest"; the pair after next was issued a slice ago.
+            // operations too and would be counted among "the youngest"; the pair after next was issued a pair ago.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if constexpr (K4_SPREAD) stage_piece(std::integral_constant<int, 0>{}, pr + 3, (it + 3) & 3);
-            else stage_pair(pr + 3, (it + 3) & 3);
-        } else {
-            K4_PIECE(6)
+            stage_pair(pr + 3, (it + 3) & 3);
         }
-        k4_rows4<NOFF>(en, on, g0); k4_rowc<NOFF>(ln, cs);
+        k4_rows4<NOFF>(en, on, g0);
         k4_wait_tr<15>(t6);
-        K4_MFMA_T(dk, t6, df[0])
-        // q7
-        if constexpr (LAST && K4_SPREAD) stage_piece(std::integral_constant<int, 1>{}, pr + 3, (it + 3) & 3);
-        else { K4_PIECE(7) }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            dk[d] = a_mfma<BF>(k4_frag<BF>(t6, d), df[0], dk[d]);
+            asm volatile("" : "+a"(dk[d]), "+v"(de[8 + 2 * d]), "+v"(de[9 + 2 * d]));
+            K4_CVT2(df[1], 2 * d, de[8 + 2 * d], de[9 + 2 * d])
+            asm volatile("" : "+a"(dk[(d + 1) & 3]), "+v"(df[1]));
+        }
+        // q7: dK k-step 1; the next slice's S accumulator takes its row constants (- lse sqrt(D))
         k4_rows4<NOFF + 1024>(en, on, g1);
-        k4_wait_tr<12>(t7);
-        K4_MFMA_T(dk, t7, df[1])
-#undef K4_PIECE
+        k4_rowc<NOFF + 128>(ln, cp);
+        {
+            K4Tr &t = t7;
+            asm volatile("s_waitcnt lgkmcnt(12)"
+                         : "+v"(t.lo[0]), "+v"(t.hi[0]), "+v"(t.lo[1]), "+v"(t.hi[1]), "+v"(t.lo[2]), "+v"(t.hi[2]), "+v"(t.lo[3]), "+v"(t.hi[3]),
+                           "+a"(cs[0]), "+a"(cs[1]), "+a"(cs[2]), "+a"(cs[3])
+                         :
+                         : "memory");
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            dk[d] = a_mfma<BF>(k4_frag<BF>(t7, d), df[1], dk[d]);
+            asm volatile("" : "+a"(dk[d]), "+a"(cs[d]));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) svn[4 * d + j] = cs[d][j];
+            asm volatile("" : "+a"(dk[(d + 1) & 3]), "+a"(svn));
+        }
+        sv = svn;
     };
 
     using I0 = std::integral_constant<int, 0>;
@@ -1720,7 +1730,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     for (; pr < np && (int64_t)pr * 2 * BQS < kw + 31; ++pr, ++it) pair_body(std::true_type{}, pr, it);
     for (; pr < np; ++pr, ++it) pair_body(std::false_type{}, pr, it);
 #undef K4_MFMA4
-#undef K4_MFMA_T
+#undef K4_CVT2
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // drain the ring and the last prefetch before LDS is reused
     __syncthreads();
     a_store_rows<BF>(smem + wid * 32 * OPAD, a.dv + (bh * a.Skv + kw) * AROW, dv, 1.f);
