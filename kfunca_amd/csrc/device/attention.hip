@@ -1398,7 +1398,7 @@ constexpr int K4B = 128;                        // keys per block
 constexpr int K4SL = 2 * BQS * AROW + 256;      // slice buffer: Q tile | dO tile | nlse[32] | ndelta[32]
 constexpr int K4PAIR = 2 * K4SL;
 constexpr int K4LDS = 4 * K4PAIR;               // ring of four slice pairs, 130 KiB
-constexpr bool K4_SPREAD = false;
+constexpr bool K4_SPREAD = true; // DMA operations one per MFMA behind the barrier (false: all ten at once)
 static_assert(K4LDS >= 4 * 32 * OPAD, "epilogue slabs must fit");
 
 template <int OFF>
@@ -1558,12 +1558,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     const int p0 = (int)(k0 / (2 * BQS)); // first pair holding a query >= the block's first key
     stage_pair(p0, 0);
     stage_pair(p0 + 1, 1);
-    if constexpr (K4_SPREAD) {
-        stage_piece(std::integral_constant<int, 0>{}, p0 + 2, 2); // what the last two quarter-phases of a pair "p0 - 1" would issue
-        stage_piece(std::integral_constant<int, 1>{}, p0 + 2, 2);
-    } else {
-        stage_pair(p0 + 2, 2);
-    }
+    stage_pair(p0 + 2, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // pair p0 has landed (this wave's part) ...
     __builtin_amdgcn_s_barrier();                      // ... and everyone else's
     asm volatile("" ::: "memory");
@@ -1681,7 +1676,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            stage_pair(pr + 3, (it + 3) & 3);
+            if constexpr (!K4_SPREAD) stage_pair(pr + 3, (it + 3) & 3);
         }
         k4_rows4<NOFF>(en, on, g0);
         k4_wait_tr<15>(t6);
@@ -1690,7 +1685,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
             dk[d] = a_mfma<BF>(k4_frag<BF>(t6, d), df[0], dk[d]);
             asm volatile("" : "+a"(dk[d]), "+v"(de[8 + 2 * d]), "+v"(de[9 + 2 * d]));
             K4_CVT2(df[1], 2 * d, de[8 + 2 * d], de[9 + 2 * d])
-            asm volatile("" : "+a"(dk[(d + 1) & 3]), "+v"(df[1]));
+            if constexpr (LAST && K4_SPREAD) { // one DMA operation behind each MFMA: its issue (60-180 cycles) hides in the pipe time
+                if (d == 0) stage_piece(std::integral_constant<int, 0>{}, pr + 3, (it + 3) & 3);
+                if (d == 1) stage_piece(std::integral_constant<int, 1>{}, pr + 3, (it + 3) & 3);
+                if (d == 2) stage_piece(std::integral_constant<int, 2>{}, pr + 3, (it + 3) & 3);
+                if (d == 3) stage_piece(std::integral_constant<int, 3>{}, pr + 3, (it + 3) & 3);
+            }
+            asm volatile("" : "+a"(dk[(d + 1) & 3]), "+v"(df[1]) : : "memory");
         }
         // q7: dK k-step 1; the next slice's S accumulator takes its row constants (- lse sqrt(D))
         k4_rows4<NOFF + 1024>(en, on, g1);
@@ -1709,7 +1710,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
             asm volatile("" : "+a"(dk[d]), "+a"(cs[d]));
 #pragma unroll
             for (int j = 0; j < 4; ++j) svn[4 * d + j] = cs[d][j];
-            asm volatile("" : "+a"(dk[(d + 1) & 3]), "+a"(svn));
+            if constexpr (LAST && K4_SPREAD) {
+                if (d == 0) stage_piece(std::integral_constant<int, 4>{}, pr + 3, (it + 3) & 3);
+                if (d == 1) stage_piece(std::integral_constant<int, 5>{}, pr + 3, (it + 3) & 3);
+                if (d == 2) stage_piece(std::integral_constant<int, 6>{}, pr + 3, (it + 3) & 3);
+                if (d == 3) stage_piece(std::integral_constant<int, 7>{}, pr + 3, (it + 3) & 3);
+            }
+            asm volatile("" : "+a"(dk[(d + 1) & 3]), "+a"(svn) : : "memory");
+        }
+        if constexpr (LAST && K4_SPREAD) {
+            stage_piece(std::integral_constant<int, 8>{}, pr + 3, (it + 3) & 3);
+            stage_piece(std::integral_constant<int, 9>{}, pr + 3, (it + 3) & 3);
         }
         sv = svn;
     };
