@@ -2140,11 +2140,11 @@ extern "C" int kf_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
             if (bf) attn_bwd_dkv_kernel<true><<<gk, 256, lds, st>>>(a);
             else attn_bwd_dkv_kernel<false><<<gk, 256, lds, st>>>(a);
             KF_LAUNCH_CHECK();
-        } else if (getenv("KF_ATTN_DKV_V4")) {
+        } else if (!getenv("KF_ATTN_DKV_V2") && !getenv("KF_ATTN_DKV_V3")) { // default: one wave per SIMD, pinned MFMA / VALU interleave
             dim3 gk4((unsigned)((Skv / K4B) * B * H));
             if ((rc = set_lds(attn_bwd_dkv_v4_kernel<true>, K4LDS)) != KF_OK) return rc;
             if ((rc = set_lds(attn_bwd_dkv_v4_kernel<false>, K4LDS)) != KF_OK) return rc;
-            KF_PROF("attn_bwd_dkv_mfma_v4", st);
+            KF_PROF("attn_bwd_dkv_mfma", st);
             if (bf) attn_bwd_dkv_v4_kernel<true><<<gk4, 256, K4LDS, st>>>(a);
             else attn_bwd_dkv_v4_kernel<false><<<gk4, 256, K4LDS, st>>>(a);
             KF_LAUNCH_CHECK();
@@ -2159,7 +2159,7 @@ extern "C" int kf_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
             dim3 gk2((unsigned)(((Skv + KVB - 1) / KVB) * B * H));
             if ((rc = set_lds(attn_bwd_dkv_v2_kernel<true>, KLDS)) != KF_OK) return rc;
             if ((rc = set_lds(attn_bwd_dkv_v2_kernel<false>, KLDS)) != KF_OK) return rc;
-            KF_PROF("attn_bwd_dkv_mfma", st);
+            KF_PROF("attn_bwd_dkv_mfma_v2", st);
             if (bf) attn_bwd_dkv_v2_kernel<true><<<gk2, FNT, KLDS, st>>>(a);
             else attn_bwd_dkv_v2_kernel<false><<<gk2, FNT, KLDS, st>>>(a);
             KF_LAUNCH_CHECK();
