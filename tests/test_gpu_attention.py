@@ -188,3 +188,22 @@ def test_errors():
     with pytest.raises(H.KfError) as e:
         H.attn_fwd(H.F32, 1, 1, 4, 4, 512, a.ptr, a.ptr, a.ptr, a.ptr)
     assert e.value.code == H.KF_ERR_UNSUPPORTED
+
+
+def test_backward_is_bitwise_reproducible():
+    """No atomics anywhere in the backward: dQ, dK, dV must come out bit-identical run after run (this also catches
+    LDS-ring races and too-weak counted waits, which show up as run-to-run differences or NaNs in whole waves)."""
+    for code in (H.BF16, H.F16):
+        for (B, Hh, Sq, Skv) in ((2, 4, 1024, 1024), (1, 2, 384, 128), (2, 3, 128, 384)):
+            rng = np.random.default_rng(77 + Sq + code)
+            q, k, v, go = (O.from_float(rng.uniform(-1, 1, s).astype(np.float32), code)
+                           for s in ((B, Hh, Sq, 128), (B, Hh, Skv, 128), (B, Hh, Skv, 128), (B, Hh, Sq, 128)))
+            o, lse = fwd(code, q, k, v)
+            first = bwd(code, q, k, v, o, lse, go)
+            assert all(np.isfinite(f(x, code)).all() for x in first)
+            for rep in range(6):
+                junk = H.DevBuf(1 << (16 + rep))  # perturb the allocator / timing a little
+                again = bwd(code, q, k, v, o, lse, go)
+                for nme, a0, a1 in zip(("dq", "dk", "dv"), first, again):
+                    assert np.array_equal(a0.view(np.uint16), a1.view(np.uint16)), (code, Sq, Skv, rep, nme)
+                del junk
