@@ -36,6 +36,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 struct AttnArgs {
     const char *q, *k, *v, *o, *d_o;
@@ -47,7 +48,6 @@ struct AttnArgs {
     int64_t B, H, Sq, Skv, D;
     float scale;
     int xcd_map; // 1: nbh % 8 == 0, heads are pinned to XCDs (a_block_map)
-    int dbg; // KF_ATTN_DBG: timing-only ablation mask for the forward (results are wrong when non-zero)
 };
 
 // XCD-aware block order for the v2 kernels (1-D grid of nx * nbh blocks). Hardware deals block ids round-robin
@@ -94,29 +94,10 @@ __device__ __forceinline__ f32x16 a_mfma(typename AFrag<BF>::type a, typename AF
 __device__ __forceinline__ int a_off(int row, int ch) { return row * AROW + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
 
 // A/B fragment of row `row`, k-chunk `ch` (8 consecutive elements)
-template <bool BF>
-__device__ __forceinline__ typename AFrag<BF>::type a_row_frag(const char *tile, int row, int ch) {
-    return *(const typename AFrag<BF>::type *)(tile + a_off(row, ch));
-}
 
 // A fragment of T^T for the product  T^T(cols col0..col0+31) x X  where X is an MFMA accumulator
 // used as the B operand (k order: element j of lane half h <-> row r0 + 8*(j>>2) + 4*h + (j&3)).
 // T is the row-major LDS tile; two transposed reads fetch rows r0+4h+{0..3} and r0+8+4h+{0..3}.
-template <bool BF>
-__device__ __forceinline__ typename AFrag<BF>::type a_tr_frag(const char *tile, int r0, int col0) {
-    const int lane = threadIdx.x & 63;
-    const int g = lane >> 4, i = lane & 15, qq = i >> 2, p = i & 3, h = g >> 1;
-    const int ch = ((col0 + 16 * (g & 1)) >> 3) + (p >> 1);
-    const int row1 = r0 + 4 * h + qq, row2 = row1 + 8;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4 *)(tile + a_off(row1, ch) + 8 * (p & 1)));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4 *)(tile + a_off(row2, ch) + 8 * (p & 1)));
-    s16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return __builtin_bit_cast(typename AFrag<BF>::type, r);
-}
 
 // registers 8s..8s+7 of an accumulator -> 16-bit B fragment of k-step s
 template <bool BF>
@@ -139,24 +120,9 @@ __device__ __forceinline__ int a_row(int e, int h) { return (e & 3) + 8 * (e >> 
 // Named members, not arrays: hipcc keeps by-reference uint4[N] staging arrays in scratch.
 struct Stage4 { uint4 a, b, c, d; }; // 64 rows
 struct Stage2 { uint4 a, b; };       // 32 rows
+// global [nrows][128] 16-bit rows -> swizzled LDS tile, 16 bytes per call
 __device__ __forceinline__ uint4 a_gld(const char *g, int id) { return *(const uint4 *)(g + (int64_t)(id >> 4) * AROW + (id & 15) * 16); }
 __device__ __forceinline__ void a_lst(char *tile, int id, const uint4 &v) { *(uint4 *)(tile + a_off(id >> 4, id & 15)) = v; }
-__device__ __forceinline__ void a_gload(const char *g, Stage4 &r) {
-    const int t = threadIdx.x;
-    r.a = a_gld(g, t); r.b = a_gld(g, t + 256); r.c = a_gld(g, t + 512); r.d = a_gld(g, t + 768);
-}
-__device__ __forceinline__ void a_gload(const char *g, Stage2 &r) {
-    const int t = threadIdx.x;
-    r.a = a_gld(g, t); r.b = a_gld(g, t + 256);
-}
-__device__ __forceinline__ void a_lstore(char *tile, const Stage4 &r) {
-    const int t = threadIdx.x;
-    a_lst(tile, t, r.a); a_lst(tile, t + 256, r.b); a_lst(tile, t + 512, r.c); a_lst(tile, t + 768, r.d);
-}
-__device__ __forceinline__ void a_lstore(char *tile, const Stage2 &r) {
-    const int t = threadIdx.x;
-    a_lst(tile, t, r.a); a_lst(tile, t + 256, r.b);
-}
 
 template <bool BF>
 __device__ __forceinline__ uint32_t a_cvt16(float v) { return BF ? f32_to_bf16(v).x : f32_to_f16(v).x; }
@@ -189,110 +155,9 @@ __device__ __forceinline__ void a_store_rows(char *slab, char *dst, const f32x16
 }
 
 // ------------------------------------------------------------------------------------------
-// forward
-// ------------------------------------------------------------------------------------------
-template <bool BF>
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
-    using frag_t = typename AFrag<BF>::type;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *Kt = smem, *Vt = smem + ABK * AROW;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
-    const int qblk = gridDim.x - 1 - blockIdx.x; // longest (most KV tiles) blocks first
-    const int64_t bh = blockIdx.y;
-    const int64_t q0 = (int64_t)qblk * ABQ, qw = q0 + wid * 32, m = qw + xl;
-    const char *Qg = a.q + (bh * a.Sq + m) * AROW;
-    const char *Kg = a.k + bh * a.Skv * AROW;
-    const char *Vg = a.v + bh * a.Skv * AROW;
-
-    frag_t qf[8];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const frag_t *)(Qg + (kk * 16 + 8 * hl) * 2);
-
-    f32x16 o[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
-    float m_i = -INFINITY, l_i = 0.f;
-    const float c = a.scale * kLog2e;
-
-    const int64_t kv_end = a.Skv < q0 + ABQ ? a.Skv : q0 + ABQ;
-    const int nt = (int)((kv_end + ABK - 1) / ABK);
-    Stage4 kr, vr;
-    a_gload(Kg, kr);
-    a_gload(Vg, vr);
-    for (int t = 0; t < nt; ++t) {
-        const int64_t kv0 = (int64_t)t * ABK;
-        __syncthreads();
-        a_lstore(Kt, kr);
-        a_lstore(Vt, vr);
-        __syncthreads();
-        if (t + 1 < nt) {
-            a_gload(Kg + (kv0 + ABK) * AROW, kr);
-            a_gload(Vg + (kv0 + ABK) * AROW, vr);
-        }
-        if (kv0 > qw + 31) continue; // every key of this tile is masked for this wave
-
-        f32x16 s[2];
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
-                s[sub] = a_mfma<BF>(a_row_frag<BF>(Kt, sub * 32 + xl, kk * 2 + hl), qf[kk], s[sub]);
-        }
-        const bool need_mask = kv0 + ABK - 1 > qw;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float v = s[sub][e] * c;
-                if (need_mask && kv0 + sub * 32 + a_row(e, hl) > m) v = -INFINITY;
-                s[sub][e] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_i, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
-        float rs = 0.f;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float p = __builtin_amdgcn_exp2f(s[sub][e] - m_new);
-                s[sub][e] = p;
-                rs += p;
-            }
-        rs += __shfl_xor(rs, 32, 64);
-        l_i = l_i * alpha + rs;
-        m_i = m_new;
-#pragma unroll
-        for (int d = 0; d < 4; ++d)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const frag_t pf = a_pack<BF>(s[sub], s2);
-#pragma unroll
-                for (int d = 0; d < 4; ++d)
-                    o[d] = a_mfma<BF>(a_tr_frag<BF>(Vt, sub * 32 + s2 * 16, d * 32), pf, o[d]);
-            }
-    }
-    __syncthreads(); // K/V tiles are dead: reuse LDS as per-wave output slabs
-    a_store_rows<BF>(smem + wid * 32 * OPAD, a.out + (bh * a.Sq + qw) * AROW, o, 1.f / l_i);
-    if (a.lse && hl == 0) a.lse[bh * a.Sq + m] = (m_i + __builtin_amdgcn_logf(l_i)) * kLn2;
-}
-
-// ------------------------------------------------------------------------------------------
-// forward, v2: 8 waves x 32 query rows (256-row Q block, two waves per SIMD so one wave's softmax
-// overlaps its partner's MFMAs), K/V tiles of 64 keys double-buffered in LDS with ONE barrier per
-// tile (register-staged: global loads of tile t+2 are in flight across PV(t) and QK/softmax(t+1),
-// the LDS write of tile t+1 sits between QK(t) and PV(t)), mask code only on the diagonal tile,
-// scale folded into the exponent's FMA, every LDS address a loop-invariant VGPR + immediate.
+// forward / dQ skeleton: 8 waves x 32 query rows (256-row Q block, two waves per SIMD), K/V tiles of 64 keys in an
+// LDS ring filled by LDS-DMA, mask code only on the diagonal tile, scale folded into the exponent's FMA, every LDS
+// address a loop-invariant VGPR + immediate.
 // ------------------------------------------------------------------------------------------
 constexpr int FQ = 256;                 // queries per block
 constexpr int FNT = 512;                // threads per block
@@ -336,13 +201,6 @@ __device__ __forceinline__ void tr4_issue(const char *tile, const int (&vo)[4][2
                    "v"(base + vo[2][1]), "v"(base + vo[3][0]), "v"(base + vo[3][1]), "i"(ROFF)
                  : "memory");
 }
-__device__ __forceinline__ void tr4_wait(Tr4 &a, Tr4 &b) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a.lo[0]), "+v"(a.hi[0]), "+v"(a.lo[1]), "+v"(a.hi[1]), "+v"(a.lo[2]), "+v"(a.hi[2]), "+v"(a.lo[3]), "+v"(a.hi[3]),
-                   "+v"(b.lo[0]), "+v"(b.hi[0]), "+v"(b.lo[1]), "+v"(b.hi[1]), "+v"(b.lo[2]), "+v"(b.hi[2]), "+v"(b.lo[3]), "+v"(b.hi[3])
-                 :
-                 : "memory");
-}
 __device__ __forceinline__ void tr4_wait1(Tr4 &a) {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(a.lo[0]), "+v"(a.hi[0]), "+v"(a.lo[1]), "+v"(a.hi[1]), "+v"(a.lo[2]), "+v"(a.hi[2]), "+v"(a.lo[3]), "+v"(a.hi[3])
@@ -357,17 +215,6 @@ __device__ __forceinline__ typename AFrag<BF>::type tr4_frag(const Tr4 &t, int d
     return __builtin_bit_cast(typename AFrag<BF>::type, r);
 }
 
-struct StageKV { uint4 k0, k1, v0, v1; };
-__device__ __forceinline__ void f_gload(const char *kg, const char *vg, StageKV &r) { // 512 threads x 2 chunks per operand
-    const int t = threadIdx.x;
-    r.k0 = a_gld(kg, t); r.k1 = a_gld(kg, t + FNT);
-    r.v0 = a_gld(vg, t); r.v1 = a_gld(vg, t + FNT);
-}
-__device__ __forceinline__ void f_lstore(char *buf, const StageKV &r) {
-    const int t = threadIdx.x;
-    a_lst(buf, t, r.k0); a_lst(buf, t + FNT, r.k1);
-    a_lst(buf + FTILE, t, r.v0); a_lst(buf + FTILE, t + FNT, r.v1);
-}
 
 // LDS-DMA staging of one 64-key K tile and V tile (global_load_lds_dwordx4): 16 + 16 wave-instructions of
 // 1 KiB (4 rows), two of each per wave; the tile image's XOR swizzle goes on the per-lane SOURCE chunk.
@@ -384,179 +231,10 @@ __device__ __forceinline__ void f_stage(const char *kg, const char *vg, char *bu
     }
 }
 
-template <bool BF, bool MASK, int dbg = 0>
-__device__ __forceinline__ void f_tile(const char *buf, const typename AFrag<BF>::type (&qf)[8], const int (&ko)[8], const int (&vo)[4][2],
-                                       f32x16 (&o)[4], float &m_i, float &l_i, float c, int64_t kv0, int64_t m, int hl) {
-    using frag_t = typename AFrag<BF>::type;
-    f32x16 s[2];
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;
-        if (!(dbg & 1)) {
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
-                s[sub] = a_mfma<BF>(*(const frag_t *)(buf + sub * 32 * AROW + ko[kk]), qf[kk], s[sub]);
-        }
-    }
-    if (dbg & 2) { // ablation: no softmax arithmetic
-        const frag_t p0 = a_pack<BF>(s[0], 0), p1 = a_pack<BF>(s[1], 1);
-        if (!(dbg & 4)) {
-            const char *vt2 = buf + FTILE;
-            Tr4 tz;
-            tr4_issue<0>(vt2, vo, tz);
-            tr4_wait1(tz);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(tr4_frag<BF>(tz, d), r & 1 ? p1 : p0, o[d]);
-        } else {
-            asm volatile("" ::"v"(p0), "v"(p1));
-        }
-        return;
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if (MASK && kv0 + sub * 32 + a_row(e, hl) > m) s[sub][e] = -INFINITY;
-            mx = fmaxf(mx, s[sub][e]);
-        }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_i, mx);
-    const float mc = m_new * c;
-    const float alpha = __builtin_amdgcn_exp2f(m_i * c - mc);
-    float rs = 0.f;
-#pragma unroll
-    for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[sub][e], c, -mc));
-            s[sub][e] = p;
-            rs += p;
-        }
-    rs += __shfl_xor(rs, 32, 64);
-    l_i = l_i * alpha + rs;
-    m_i = m_new;
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
-    if (dbg & 4) { // ablation: no PV
-        asm volatile("" ::"v"(s[0]), "v"(s[1]));
-        return;
-    }
-    const char *vt = buf + FTILE;
-    Tr4 ta, tb; // V^T fragments of k-step i+1 fly under the four MFMAs of k-step i
-    tr4_issue<0>(vt, vo, ta);
-    tr4_wait1(ta);
-    tr4_issue<16 * AROW>(vt, vo, tb);
-    { const frag_t pf = a_pack<BF>(s[0], 0);
-#pragma unroll
-      for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(tr4_frag<BF>(ta, d), pf, o[d]); }
-    tr4_wait1(tb);
-    tr4_issue<32 * AROW>(vt, vo, ta);
-    { const frag_t pf = a_pack<BF>(s[0], 1);
-#pragma unroll
-      for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(tr4_frag<BF>(tb, d), pf, o[d]); }
-    tr4_wait1(ta);
-    tr4_issue<48 * AROW>(vt, vo, tb);
-    { const frag_t pf = a_pack<BF>(s[1], 0);
-#pragma unroll
-      for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(tr4_frag<BF>(ta, d), pf, o[d]); }
-    tr4_wait1(tb);
-    { const frag_t pf = a_pack<BF>(s[1], 1);
-#pragma unroll
-      for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(tr4_frag<BF>(tb, d), pf, o[d]); }
-}
-
-template <bool BF, int DBG = 0>
-__global__ __launch_bounds__(FNT, 2) void attn_fwd_v2_kernel(const AttnArgs a) {
-    using frag_t = typename AFrag<BF>::type;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
-    int xb;
-    int64_t bh;
-    const int nxb = (int)((a.Sq + FQ - 1) / FQ);
-    a_block_map(nxb, (int)(a.B * a.H), a.xcd_map, xb, bh);
-    const int qblk = nxb - 1 - xb; // longest blocks first
-    const int64_t q0 = (int64_t)qblk * FQ, qw = q0 + wid * 32, m = qw + xl;
-    const bool active = qw < a.Sq && !((DBG & 32) && wid >= 4) && !((DBG & 64) && (wid & 1)); // partial last block; ablations 32 / 64 idle half the waves
-    const char *Kg = a.k + bh * a.Skv * AROW;
-    const char *Vg = a.v + bh * a.Skv * AROW;
-
-    frag_t qf[8];
-    if (active) {
-        const char *Qg = a.q + (bh * a.Sq + m) * AROW;
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const frag_t *)(Qg + (kk * 16 + 8 * hl) * 2);
-    } else {
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) qf[kk][j] = 0;
-    }
-    int ko[8], vo[4][2];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) ko[kk] = a_off(xl, kk * 2 + hl);
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        vo[d][0] = a_tr_lane_off(d * 32, 0);
-        vo[d][1] = a_tr_lane_off(d * 32, 1);
-    }
-
-    f32x16 o[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
-    float m_i = -INFINITY, l_i = 0.f;
-    const float c = a.scale * kLog2e;
-
-    const int64_t q_end = q0 + FQ < a.Sq ? q0 + FQ : a.Sq;
-    const int64_t kv_end = a.Skv < q_end ? a.Skv : q_end;
-    const int nt = (int)((kv_end + ABK - 1) / ABK);
-    // 3-deep LDS ring fed by LDS-DMA: tiles t+1 and t+2 are in flight while tile t is consumed. One DMA
-    // round trip (~1-2 us under load) is longer than one tile of compute, so a single tile of prefetch
-    // leaves the loop latency-bound. Every wave issues exactly 4 DMA operations per tile (tiles past the end
-    // re-fetch the last one) so a COUNTED s_waitcnt vmcnt(4) means "tile t has landed"; the raw s_barrier
-    // (a __syncthreads() would drain the ring with vmcnt(0)) publishes it and retires the buffer tile t+2
-    // overwrites.
-    auto stage = [&](int tile, char *buf) {
-        const int64_t kv = (int64_t)(tile < nt ? tile : nt - 1) * ABK;
-        f_stage(Kg + kv * AROW, Vg + kv * AROW, buf);
-    };
-    stage(0, smem);
-    stage(1, smem + FBUF);
-    for (int t = 0; t < nt; ++t) {
-        const int64_t kv0 = (int64_t)t * ABK;
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        if (!(DBG & 16)) __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (!(DBG & 8)) stage(t + 2, smem + ((t + 2) % FRING) * FBUF);
-        else { stage(0, smem + 4 * FBUF); } // ablation: keep the DMA count, hit one hot tile, never read it
-        const char *cur = smem + (t % FRING) * FBUF;
-        // this wave's relation to the tile: entirely visible, on the diagonal, or entirely masked
-        const bool skip = !active || kv0 > qw + 31;
-        const bool diag = kv0 + ABK - 1 > qw;
-        if (!skip) {
-            if (diag) f_tile<BF, true, DBG>(cur, qf, ko, vo, o, m_i, l_i, c, kv0, m, hl);
-            else f_tile<BF, false, DBG>(cur, qf, ko, vo, o, m_i, l_i, c, kv0, m, hl);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // drain the ring before LDS is reused
-    __syncthreads();
-    // K/V buffers are dead: reuse LDS as per-wave output slabs (8 x 32 x OPAD bytes)
-    if (active) {
-        a_store_rows<BF>(smem + wid * 32 * OPAD, a.out + (bh * a.Sq + qw) * AROW, o, 1.f / l_i);
-        if (a.lse && hl == 0) a.lse[bh * a.Sq + m] = (m_i * c + __builtin_amdgcn_logf(l_i)) * kLn2;
-    }
-}
-
 // ------------------------------------------------------------------------------------------
-// forward, v3 = v2 with the two waves of each SIMD STAGGERED. Ablation of v2 (KF_ATTN_DBG) shows its QK,
-// softmax and PV costs add up (0.37 + 0.55 + 0.47 ms of 1.96): all eight waves leave the tile barrier
+// forward: the two waves of each SIMD are STAGGERED. A compile-time ablation of the unstaggered version of this kernel
+// (removed; numbers in DESIGN.md) showed its QK, softmax and PV costs add up (0.37 + 0.55 + 0.47 ms of 1.96): all eight
+// waves leave the tile barrier
 // together, so both waves of a SIMD sit in the same phase and the matrix pipe idles while both do
 // softmax arithmetic. Here waves 4-7 run one phase late: in tile interval t they do PV(t-1), QK(t),
 // softmax(t) while waves 0-3 do QK(t), softmax(t), PV(t) — two of the three phases pair matrix work
@@ -763,85 +441,6 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const char *o, const ch
 }
 
 // ------------------------------------------------------------------------------------------
-// backward: dQ. Same skeleton as the forward; per KV tile S^T, dP^T, then dQ^T += K^T dS^T.
-// ------------------------------------------------------------------------------------------
-template <bool BF>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
-    using frag_t = typename AFrag<BF>::type;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *Kt = smem, *Vt = smem + ABK * AROW;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
-    const int qblk = gridDim.x - 1 - blockIdx.x;
-    const int64_t bh = blockIdx.y;
-    const int64_t q0 = (int64_t)qblk * ABQ, qw = q0 + wid * 32, m = qw + xl;
-    const char *Qg = a.q + (bh * a.Sq + m) * AROW;
-    const char *dOg = a.d_o + (bh * a.Sq + m) * AROW;
-    const char *Kg = a.k + bh * a.Skv * AROW;
-    const char *Vg = a.v + bh * a.Skv * AROW;
-
-    frag_t qf[8], dof[8];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-        qf[kk] = *(const frag_t *)(Qg + (kk * 16 + 8 * hl) * 2);
-        dof[kk] = *(const frag_t *)(dOg + (kk * 16 + 8 * hl) * 2);
-    }
-    const float c = a.scale * kLog2e;
-    const float lse2 = a.lse_r[bh * a.Sq + m] * kLog2e;
-    const float dlt = a.delta[bh * a.Sq + m];
-
-    f32x16 dq[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) dq[d][e] = 0.f;
-
-    const int64_t kv_end = a.Skv < q0 + ABQ ? a.Skv : q0 + ABQ;
-    const int nt = (int)((kv_end + ABK - 1) / ABK);
-    Stage4 kr, vr;
-    a_gload(Kg, kr);
-    a_gload(Vg, vr);
-    for (int t = 0; t < nt; ++t) {
-        const int64_t kv0 = (int64_t)t * ABK;
-        __syncthreads();
-        a_lstore(Kt, kr);
-        a_lstore(Vt, vr);
-        __syncthreads();
-        if (t + 1 < nt) {
-            a_gload(Kg + (kv0 + ABK) * AROW, kr);
-            a_gload(Vg + (kv0 + ABK) * AROW, vr);
-        }
-        if (kv0 > qw + 31) continue;
-        const bool need_mask = kv0 + ABK - 1 > qw;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            f32x16 s, dp;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                s = a_mfma<BF>(a_row_frag<BF>(Kt, sub * 32 + xl, kk * 2 + hl), qf[kk], s);
-                dp = a_mfma<BF>(a_row_frag<BF>(Vt, sub * 32 + xl, kk * 2 + hl), dof[kk], dp);
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                float p = __builtin_amdgcn_exp2f(s[e] * c - lse2);
-                if (need_mask && kv0 + sub * 32 + a_row(e, hl) > m) p = 0.f;
-                s[e] = p * (dp[e] - dlt);
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const frag_t df = a_pack<BF>(s, s2);
-#pragma unroll
-                for (int d = 0; d < 4; ++d)
-                    dq[d] = a_mfma<BF>(a_tr_frag<BF>(Kt, sub * 32 + s2 * 16, d * 32), df, dq[d]);
-            }
-        }
-    }
-    __syncthreads();
-    a_store_rows<BF>(smem + wid * 32 * OPAD, a.dq + (bh * a.Sq + qw) * AROW, dq, a.scale);
-}
-
-// ------------------------------------------------------------------------------------------
 // backward: dQ, v2 — the forward-v2 skeleton (8 waves x 32 queries, two waves per SIMD, K/V tiles
 // double-buffered, one barrier per tile). Per 32-key sub-tile: S^T = K Q^T, dP^T = V dO^T,
 // dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T (K^T through transposed reads of the same K image).
@@ -974,96 +573,11 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a
 }
 
 // ------------------------------------------------------------------------------------------
-// backward: dK, dV. One block = 128 keys (32 per wave, key on the lane); sweeps 32-query slices
-// from the diagonal down. Per slice: S = Q K^T, dP = dO V^T (A = Q / dO rows from LDS, B = K / V
-// fragments in registers), dV^T += dO^T P, dK^T += Q^T dS (A via transposed reads).
+// backward: dK, dV ("key on the lane"); both kernels sweep 32-query slices from the block's diagonal down. Per slice:
+// S = Q K^T, dP = dO V^T (A = Q / dO rows from LDS, B = K / V fragments), dV^T += dO^T P, dK^T += Q^T dS (A via
+// transposed reads).
 // ------------------------------------------------------------------------------------------
-constexpr int BKB = 128; // keys per block
 constexpr int BQS = 32;  // queries per slice
-
-template <bool BF>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
-    using frag_t = typename AFrag<BF>::type;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *Qt = smem, *dOt = smem + BQS * AROW;
-    float *lse_s = (float *)(smem + 2 * BQS * AROW), *dlt_s = lse_s + BQS;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
-    const int64_t bh = blockIdx.y;
-    const int64_t k0 = (int64_t)blockIdx.x * BKB, kw = k0 + wid * 32, n = kw + xl;
-    const char *Kg = a.k + (bh * a.Skv + n) * AROW;
-    const char *Vg = a.v + (bh * a.Skv + n) * AROW;
-    const char *Qg = a.q + bh * a.Sq * AROW;
-    const char *dOg = a.d_o + bh * a.Sq * AROW;
-    const float *lse_g = a.lse_r + bh * a.Sq, *dlt_g = a.delta + bh * a.Sq;
-
-    frag_t kf[8], vf[8];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-        kf[kk] = *(const frag_t *)(Kg + (kk * 16 + 8 * hl) * 2);
-        vf[kk] = *(const frag_t *)(Vg + (kk * 16 + 8 * hl) * 2);
-    }
-    f32x16 dk[4], dv[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { dk[d][e] = 0.f; dv[d][e] = 0.f; }
-    const float c = a.scale * kLog2e;
-
-    const int ns = (int)(a.Sq / BQS);
-    int sl = (int)(k0 / BQS); // first slice holding a query >= the block's first key
-    Stage2 qr, dr;
-    float lr = 0.f, tr = 0.f;
-    if (sl < ns) {
-        a_gload(Qg + (int64_t)sl * BQS * AROW, qr);
-        a_gload(dOg + (int64_t)sl * BQS * AROW, dr);
-        if (threadIdx.x < BQS) { lr = lse_g[sl * BQS + threadIdx.x]; tr = dlt_g[sl * BQS + threadIdx.x]; }
-    }
-    for (; sl < ns; ++sl) {
-        const int64_t qs = (int64_t)sl * BQS;
-        __syncthreads();
-        a_lstore(Qt, qr);
-        a_lstore(dOt, dr);
-        if (threadIdx.x < BQS) { lse_s[threadIdx.x] = lr * kLog2e; dlt_s[threadIdx.x] = tr; }
-        __syncthreads();
-        if (sl + 1 < ns) {
-            a_gload(Qg + (qs + BQS) * AROW, qr);
-            a_gload(dOg + (qs + BQS) * AROW, dr);
-            if (threadIdx.x < BQS) { lr = lse_g[qs + BQS + threadIdx.x]; tr = dlt_g[qs + BQS + threadIdx.x]; }
-        }
-        if (qs + BQS - 1 < kw) continue; // every query of the slice precedes this wave's keys
-        const bool need_mask = qs < kw + 31;
-
-        f32x16 s, dp;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            s = a_mfma<BF>(a_row_frag<BF>(Qt, xl, kk * 2 + hl), kf[kk], s);
-            dp = a_mfma<BF>(a_row_frag<BF>(dOt, xl, kk * 2 + hl), vf[kk], dp);
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int r = a_row(e, hl);
-            float p = __builtin_amdgcn_exp2f(s[e] * c - lse_s[r]);
-            if (need_mask && n > qs + r) p = 0.f;
-            s[e] = p;
-            dp[e] = p * (dp[e] - dlt_s[r]);
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const frag_t pf = a_pack<BF>(s, s2), df = a_pack<BF>(dp, s2);
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                dv[d] = a_mfma<BF>(a_tr_frag<BF>(dOt, s2 * 16, d * 32), pf, dv[d]);
-                dk[d] = a_mfma<BF>(a_tr_frag<BF>(Qt, s2 * 16, d * 32), df, dk[d]);
-            }
-        }
-    }
-    __syncthreads();
-    // slabs: 4 waves x 32 rows x OPAD bytes (needs 33792 B of LDS)
-    a_store_rows<BF>(smem + wid * 32 * OPAD, a.dv + (bh * a.Skv + kw) * AROW, dv, 1.f);
-    a_store_rows<BF>(smem + wid * 32 * OPAD, a.dk + (bh * a.Skv + kw) * AROW, dk, a.scale);
-}
 
 // ------------------------------------------------------------------------------------------
 // backward: dK, dV, v2 — 8 waves x 32 keys (256-key block), two waves per SIMD. Q / dO slices of 32
@@ -1222,162 +736,6 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dkv_v2_kernel(const AttnArgs 
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// backward: dK, dV, v3 — 4 waves x 32 keys, ONE wave per SIMD with the whole 512-register file:
-// dK^T/dV^T accumulators (128) and the K and V fragments (64) stay in registers and the scheduler is
-// free to keep a full phase of LDS fragment reads in flight. Q / dO slices stream through a 3-deep
-// LDS ring by LDS-DMA: two slices are in flight behind a COUNTED s_waitcnt vmcnt and a raw s_barrier
-// (one barrier per slice; __syncthreads() would drain the ring with vmcnt(0)).
-// ------------------------------------------------------------------------------------------
-constexpr int K3LDS = 3 * KSL;
-static_assert(K3LDS >= 4 * 32 * OPAD, "epilogue slabs must fit");
-
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-// The per-row lse | delta block of a slice is written by LDS-DMA. A plain LDS read of it makes hipcc drain
-// the whole DMA ring (s_waitcnt vmcnt(0): it cannot disambiguate the read from the DMA in flight), so the
-// eight 16-byte reads are issued from ONE asm statement with their own lgkmcnt(0) (guide §5.7 form (i)).
-__device__ __forceinline__ void kv3_read_rows(const float *lse_s, int hl, f32x4 (&l)[4], f32x4 (&d)[4]) {
-    const unsigned addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float *)lse_s + 16u * hl;
-    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:32\n\tds_read_b128 %2, %8 offset:64\n\tds_read_b128 %3, %8 offset:96\n\t"
-                 "ds_read_b128 %4, %8 offset:128\n\tds_read_b128 %5, %8 offset:160\n\tds_read_b128 %6, %8 offset:192\n\t"
-                 "ds_read_b128 %7, %8 offset:224\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(l[0]), "=&v"(l[1]), "=&v"(l[2]), "=&v"(l[3]), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
-                 : "v"(addr)
-                 : "memory");
-}
-
-template <bool BF, bool MASK>
-__device__ __forceinline__ void kv3_slice(const char *buf, const typename AFrag<BF>::type (&kf)[8], const typename AFrag<BF>::type (&vf)[8],
-                                          const int (&ko)[8], const int (&vo)[4][2], f32x16 (&dk)[4], f32x16 (&dv)[4], float c, int64_t qs,
-                                          int64_t n, int hl) {
-    using frag_t = typename AFrag<BF>::type;
-    const char *qt = buf, *dot = buf + BQS * AROW;
-    const float *lse_s = (const float *)(buf + 2 * BQS * AROW);
-    f32x16 s, dp;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) s = a_mfma<BF>(*(const frag_t *)(qt + ko[kk]), kf[kk], s);
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) dp = a_mfma<BF>(*(const frag_t *)(dot + ko[kk]), vf[kk], dp);
-    f32x4 l4[4], d4[4]; // accumulator rows 8*g4 + 4*hl + {0..3}
-    kv3_read_rows(lse_s, hl, l4, d4);
-    Tr4 to0, tq0, to1, tq1;
-    tr4_issue<0>(dot, vo, to0); // first k-step's dO^T and Q^T fragments fly under the softmax arithmetic
-    tr4_issue<0>(qt, vo, tq0);
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int e = 4 * g4 + j;
-            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], c, -l4[g4][j] * kLog2e));
-            if (MASK && n > qs + 8 * g4 + 4 * hl + j) p = 0.f;
-            s[e] = p;
-            dp[e] = p * (dp[e] - d4[g4][j]);
-        }
-    }
-    tr4_wait(to0, tq0);
-    tr4_issue<16 * AROW>(dot, vo, to1); // second k-step's fragments fly under the first k-step's 8 MFMAs
-    tr4_issue<16 * AROW>(qt, vo, tq1);
-    {
-        const frag_t pf = a_pack<BF>(s, 0), df = a_pack<BF>(dp, 0);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) dv[d] = a_mfma<BF>(tr4_frag<BF>(to0, d), pf, dv[d]);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) dk[d] = a_mfma<BF>(tr4_frag<BF>(tq0, d), df, dk[d]);
-    }
-    tr4_wait(to1, tq1);
-    {
-        const frag_t pf = a_pack<BF>(s, 1), df = a_pack<BF>(dp, 1);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) dv[d] = a_mfma<BF>(tr4_frag<BF>(to1, d), pf, dv[d]);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) dk[d] = a_mfma<BF>(tr4_frag<BF>(tq1, d), df, dk[d]);
-    }
-}
-
-template <bool BF>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_v3_kernel(const AttnArgs a) {
-    using frag_t = typename AFrag<BF>::type;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
-    const int64_t bh = blockIdx.y;
-    const int64_t k0 = (int64_t)blockIdx.x * BKB, kw = k0 + wid * 32, n = kw + xl;
-    const char *Kg = a.k + (bh * a.Skv + n) * AROW;
-    const char *Vg = a.v + (bh * a.Skv + n) * AROW;
-    const char *Qg = a.q + bh * a.Sq * AROW;
-    const char *dOg = a.d_o + bh * a.Sq * AROW;
-    const float *lse_g = a.lse_r + bh * a.Sq, *dlt_g = a.delta + bh * a.Sq;
-
-    frag_t kf[8], vf[8];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-        kf[kk] = *(const frag_t *)(Kg + (kk * 16 + 8 * hl) * 2);
-        vf[kk] = *(const frag_t *)(Vg + (kk * 16 + 8 * hl) * 2);
-    }
-    int ko[8], vo[4][2];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) ko[kk] = a_off(xl, kk * 2 + hl);
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        vo[d][0] = a_tr_lane_off(d * 32, 0);
-        vo[d][1] = a_tr_lane_off(d * 32, 1);
-    }
-    f32x16 dk[4], dv[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { dk[d][e] = 0.f; dv[d][e] = 0.f; }
-    const float c = a.scale * kLog2e;
-
-    // LDS-DMA of one slice: Q tile and dO tile are 8 wave-instructions each (2 + 2 per wave) plus one
-    // 4-byte-per-lane instruction for lse | delta — issued by EVERY wave (identical bytes) so that every
-    // wave has exactly 5 DMA operations per slice and one counted wait serves all.
-    const int ns = (int)(a.Sq / BQS);
-    auto stage = [&](int sl_, char *buf) {
-        sl_ = sl_ < ns ? sl_ : ns - 1; // past the end: re-fetch the last slice (keeps the counts uniform; never consumed)
-        const int64_t qs_ = (int64_t)sl_ * BQS;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row0 = (wid * 2 + i) * 4, row = row0 + (lane >> 4), pos = lane & 15;
-            const int chunk = pos ^ (((row & 3) << 2) | ((row >> 2) & 3));
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Qg + (qs_ + row) * AROW + chunk * 16),
-                                             (__attribute__((address_space(3))) void *)(buf + row0 * AROW), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dOg + (qs_ + row) * AROW + chunk * 16),
-                                             (__attribute__((address_space(3))) void *)(buf + BQS * AROW + row0 * AROW), 16, 0, 0);
-        }
-        const float *src = lane < BQS ? lse_g + qs_ + lane : dlt_g + qs_ + lane - BQS;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                         (__attribute__((address_space(3))) void *)(buf + 2 * BQS * AROW), 4, 0, 0);
-    };
-    int sl = (int)(k0 / BQS); // first slice holding a query >= the block's first key
-    if (sl < ns) {
-        stage(sl, smem);
-        stage(sl + 1, smem + KSL);
-    }
-    for (int it = 0; sl < ns; ++sl, ++it) {
-        const int64_t qs = (int64_t)sl * BQS;
-        // slice `sl` has landed once all but this wave's 5 youngest DMA operations (slice sl+1) are done ...
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        // ... for every wave, and every wave is past its reads of the buffer slice sl+2 will overwrite
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        stage(sl + 2, smem + ((it + 2) % 3) * KSL);
-        const char *cur = smem + (it % 3) * KSL;
-        const bool skip = qs + BQS - 1 < kw; // every query of the slice precedes this wave's keys
-        const bool diag = qs < kw + 31;
-        if (!skip) {
-            if (diag) kv3_slice<BF, true>(cur, kf, vf, ko, vo, dk, dv, c, qs, n, hl);
-            else kv3_slice<BF, false>(cur, kf, vf, ko, vo, dk, dv, c, qs, n, hl);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // drain the ring before LDS is reused
-    __syncthreads();
-    a_store_rows<BF>(smem + wid * 32 * OPAD, a.dv + (bh * a.Skv + kw) * AROW, dv, 1.f);
-    a_store_rows<BF>(smem + wid * 32 * OPAD, a.dk + (bh * a.Skv + kw) * AROW, dk, a.scale);
-}
-
 // ==========================================================================================
 // backward: dK, dV, v4 - 4 waves x 32 keys, ONE wave per SIMD and the 512-register budget that goes with it.
 // The two-waves-per-SIMD kernel above cannot keep enough LDS reads in flight (256 registers, 128 of them
@@ -1462,20 +820,6 @@ __device__ __forceinline__ f32x16 k4_acc(const f32x4 (&c)[4]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) r[4 * g + j] = c[g][j];
     return r;
-}
-// p = exp2(c S'), dS = p dP' on one slice; S' and dP' arrive with their row constants folded in
-template <bool BF, bool MASK>
-__device__ __forceinline__ void k4_softmax(f32x16 &s, f32x16 &dp, float c, int64_t qs, int64_t n, int hl, typename AFrag<BF>::type (&pf)[2],
-                                           typename AFrag<BF>::type (&df)[2]) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        float p = __builtin_amdgcn_exp2f(s[e] * c);
-        if (MASK && n > qs + a_row(e, hl)) p = 0.f;
-        s[e] = p;
-        dp[e] = p * dp[e];
-    }
-    pf[0] = a_pack<BF>(s, 0); pf[1] = a_pack<BF>(s, 1);
-    df[0] = a_pack<BF>(dp, 0); df[1] = a_pack<BF>(dp, 1);
 }
 
 template <bool BF>
@@ -1981,7 +1325,7 @@ __global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const AttnArgs a)
 }
 
 static bool mfma_ok(int dtype, int64_t Sq, int64_t Skv, int64_t D) {
-    return (dtype == KF_BF16 || dtype == KF_F16) && D == AD && Sq % ABQ == 0 && Skv % BKB == 0 && Sq > 0 && Skv > 0;
+    return (dtype == KF_BF16 || dtype == KF_F16) && D == AD && Sq % 128 == 0 && Skv % 128 == 0 && Sq > 0 && Skv > 0;
 }
 
 static inline size_t a_align(size_t v) { return (v + 255) / 256 * 256; }
@@ -2017,50 +1361,15 @@ extern "C" int kf_attn_fwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
     a.q = (const char *)q; a.k = (const char *)k; a.v = (const char *)v; a.out = (char *)o; a.lse = lse;
     a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.D = D;
     a.scale = 1.0f / sqrtf((float)D);
-    { const char *e = getenv("KF_ATTN_DBG"); a.dbg = e ? atoi(e) : 0; }
     a.xcd_map = ((B * H) % 8 == 0) && !getenv("KF_ATTN_NO_XCD");
     if (mfma_ok(dtype, Sq, Skv, D)) {
-        const bool use_v1 = getenv("KF_ATTN_FWD_V1") != nullptr; // A/B switch for the first-generation kernel
-        if (use_v1) {
-            const size_t lds = 4 * 32 * OPAD; // >= 2 * ABK * AROW
-            dim3 grid((unsigned)(Sq / ABQ), (unsigned)(B * H));
-            KF_PROF("attn_fwd_mfma_v1", st);
-            if ((rc = set_lds(attn_fwd_mfma_kernel<true>, lds)) != KF_OK) return rc;
-            if ((rc = set_lds(attn_fwd_mfma_kernel<false>, lds)) != KF_OK) return rc;
-            if (dtype == KF_BF16) attn_fwd_mfma_kernel<true><<<grid, 256, lds, st>>>(a);
-            else attn_fwd_mfma_kernel<false><<<grid, 256, lds, st>>>(a);
-            KF_LAUNCH_CHECK();
-            return KF_OK;
-        }
-        if (!getenv("KF_ATTN_FWD_V2") && !a.dbg) { // default: the staggered-waves kernel; v2 (with its ablation switches) stays for A/B
-            const size_t lds3 = SRING * FBUF;
-            dim3 grid3((unsigned)(((Sq + FQ - 1) / FQ) * B * H));
-            KF_PROF("attn_fwd_mfma", st);
-            if ((rc = set_lds(attn_fwd_v3_kernel<true>, lds3)) != KF_OK) return rc;
-            if ((rc = set_lds(attn_fwd_v3_kernel<false>, lds3)) != KF_OK) return rc;
-            if (dtype == KF_BF16) attn_fwd_v3_kernel<true><<<grid3, FNT, lds3, st>>>(a);
-            else attn_fwd_v3_kernel<false><<<grid3, FNT, lds3, st>>>(a);
-            KF_LAUNCH_CHECK();
-            return KF_OK;
-        }
-        const size_t lds = (a.dbg & 8) ? 5 * FBUF : FRING * FBUF; // 96 KiB ring; the epilogue's 8 x 32 x OPAD slabs fit inside
-        dim3 grid((unsigned)(((Sq + FQ - 1) / FQ) * B * H));
-        KF_PROF("attn_fwd_mfma_v2", st);
-        if ((rc = set_lds(attn_fwd_v2_kernel<true>, lds)) != KF_OK) return rc;
-        if ((rc = set_lds(attn_fwd_v2_kernel<false>, lds)) != KF_OK) return rc;
-        if (a.dbg && dtype == KF_BF16) { // timing-only ablations (wrong results): KF_ATTN_DBG = 1 noQK, 2 no softmax, 4 no PV, 8 no new DMA, 16 no barrier
-#define KF_DBG_CASE(N)                                                                         \
-    case N:                                                                                    \
-        if ((rc = set_lds(attn_fwd_v2_kernel<true, N>, lds)) != KF_OK) return rc;              \
-        attn_fwd_v2_kernel<true, N><<<grid, FNT, lds, st>>>(a);                                \
-        break;
-            switch (a.dbg) {
-                KF_DBG_CASE(1) KF_DBG_CASE(2) KF_DBG_CASE(4) KF_DBG_CASE(6) KF_DBG_CASE(7) KF_DBG_CASE(8) KF_DBG_CASE(16) KF_DBG_CASE(24) KF_DBG_CASE(32) KF_DBG_CASE(64)
-            default: KF_REQUIRE(false, KF_ERR_INVALID, "KF_ATTN_DBG=%d has no instantiation", a.dbg);
-            }
-#undef KF_DBG_CASE
-        } else if (dtype == KF_BF16) attn_fwd_v2_kernel<true><<<grid, FNT, lds, st>>>(a);
-        else attn_fwd_v2_kernel<false><<<grid, FNT, lds, st>>>(a);
+        const size_t lds3 = SRING * FBUF;
+        dim3 grid3((unsigned)(((Sq + FQ - 1) / FQ) * B * H));
+        KF_PROF("attn_fwd_mfma", st);
+        if ((rc = set_lds(attn_fwd_v3_kernel<true>, lds3)) != KF_OK) return rc;
+        if ((rc = set_lds(attn_fwd_v3_kernel<false>, lds3)) != KF_OK) return rc;
+        if (dtype == KF_BF16) attn_fwd_v3_kernel<true><<<grid3, FNT, lds3, st>>>(a);
+        else attn_fwd_v3_kernel<false><<<grid3, FNT, lds3, st>>>(a);
         KF_LAUNCH_CHECK();
         return KF_OK;
     }
@@ -2121,13 +1430,7 @@ extern "C" int kf_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
     a.scale = 1.0f / sqrtf((float)D);
     const int64_t nrows = B * H * Sq;
     if (mfma_ok(dtype, Sq, Skv, D)) {
-        const size_t lds = 4 * 32 * OPAD;
-        dim3 gq((unsigned)(Sq / ABQ), (unsigned)(B * H)), gk((unsigned)(Skv / BKB), (unsigned)(B * H));
         const unsigned gd = (unsigned)((nrows + 15) / 16);
-        if ((rc = set_lds(attn_bwd_dq_kernel<true>, lds)) != KF_OK) return rc;
-        if ((rc = set_lds(attn_bwd_dkv_kernel<true>, lds)) != KF_OK) return rc;
-        if ((rc = set_lds(attn_bwd_dq_kernel<false>, lds)) != KF_OK) return rc;
-        if ((rc = set_lds(attn_bwd_dkv_kernel<false>, lds)) != KF_OK) return rc;
         const bool bf = dtype == KF_BF16;
         {
             KF_PROF("attn_bwd_delta", st);
@@ -2135,12 +1438,7 @@ extern "C" int kf_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
             else attn_delta_kernel<false><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, sqrtf((float)D));
             KF_LAUNCH_CHECK();
         }
-        if (getenv("KF_ATTN_DKV_V1")) { // A/B switch for the first-generation kernel
-            KF_PROF("attn_bwd_dkv_mfma_v1", st);
-            if (bf) attn_bwd_dkv_kernel<true><<<gk, 256, lds, st>>>(a);
-            else attn_bwd_dkv_kernel<false><<<gk, 256, lds, st>>>(a);
-            KF_LAUNCH_CHECK();
-        } else if (!getenv("KF_ATTN_DKV_V2") && !getenv("KF_ATTN_DKV_V3")) { // default: one wave per SIMD, pinned MFMA / VALU interleave
+        if (!getenv("KF_ATTN_DKV_V2")) { // default: one wave per SIMD, pinned MFMA / VALU interleave
             dim3 gk4((unsigned)((Skv / K4B) * B * H));
             if ((rc = set_lds(attn_bwd_dkv_v4_kernel<true>, K4LDS)) != KF_OK) return rc;
             if ((rc = set_lds(attn_bwd_dkv_v4_kernel<false>, K4LDS)) != KF_OK) return rc;
@@ -2148,14 +1446,7 @@ extern "C" int kf_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
             if (bf) attn_bwd_dkv_v4_kernel<true><<<gk4, 256, K4LDS, st>>>(a);
             else attn_bwd_dkv_v4_kernel<false><<<gk4, 256, K4LDS, st>>>(a);
             KF_LAUNCH_CHECK();
-        } else if (getenv("KF_ATTN_DKV_V3")) {
-            if ((rc = set_lds(attn_bwd_dkv_v3_kernel<true>, K3LDS)) != KF_OK) return rc;
-            if ((rc = set_lds(attn_bwd_dkv_v3_kernel<false>, K3LDS)) != KF_OK) return rc;
-            KF_PROF("attn_bwd_dkv_mfma_v3", st);
-            if (bf) attn_bwd_dkv_v3_kernel<true><<<gk, 256, K3LDS, st>>>(a);
-            else attn_bwd_dkv_v3_kernel<false><<<gk, 256, K3LDS, st>>>(a);
-            KF_LAUNCH_CHECK();
-        } else {
+        } else { // A/B switch: the two-waves-per-SIMD kernel it replaced
             dim3 gk2((unsigned)(((Skv + KVB - 1) / KVB) * B * H));
             if ((rc = set_lds(attn_bwd_dkv_v2_kernel<true>, KLDS)) != KF_OK) return rc;
             if ((rc = set_lds(attn_bwd_dkv_v2_kernel<false>, KLDS)) != KF_OK) return rc;
@@ -2164,19 +1455,13 @@ extern "C" int kf_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
             else attn_bwd_dkv_v2_kernel<false><<<gk2, FNT, KLDS, st>>>(a);
             KF_LAUNCH_CHECK();
         }
-        if (getenv("KF_ATTN_DQ_V1")) { // A/B switch for the first-generation kernel
-            KF_PROF("attn_bwd_dq_mfma_v1", st);
-            if (bf) attn_bwd_dq_kernel<true><<<gq, 256, lds, st>>>(a);
-            else attn_bwd_dq_kernel<false><<<gq, 256, lds, st>>>(a);
-            KF_LAUNCH_CHECK();
-        } else {
-            const size_t lds2 = QLDS;
+        {
             dim3 gq2((unsigned)(((Sq + FQ - 1) / FQ) * B * H));
-            if ((rc = set_lds(attn_bwd_dq_v2_kernel<true>, lds2)) != KF_OK) return rc;
-            if ((rc = set_lds(attn_bwd_dq_v2_kernel<false>, lds2)) != KF_OK) return rc;
+            if ((rc = set_lds(attn_bwd_dq_v2_kernel<true>, QLDS)) != KF_OK) return rc;
+            if ((rc = set_lds(attn_bwd_dq_v2_kernel<false>, QLDS)) != KF_OK) return rc;
             KF_PROF("attn_bwd_dq_mfma", st);
-            if (bf) attn_bwd_dq_v2_kernel<true><<<gq2, FNT, lds2, st>>>(a);
-            else attn_bwd_dq_v2_kernel<false><<<gq2, FNT, lds2, st>>>(a);
+            if (bf) attn_bwd_dq_v2_kernel<true><<<gq2, FNT, QLDS, st>>>(a);
+            else attn_bwd_dq_v2_kernel<false><<<gq2, FNT, QLDS, st>>>(a);
             KF_LAUNCH_CHECK();
         }
         return KF_OK;

@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--H", type=int, default=32)
     ap.add_argument("--S", type=int, default=4096)
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--variants", default="default")  # comma list of ENV=1 settings, e.g. default,KF_ATTN_FWD_V1
+    ap.add_argument("--variants", default="default")  # comma list of ENV=1 settings, e.g. default,KF_ATTN_DKV_V2
     ap.add_argument("--no-bwd", action="store_true")
     args = ap.parse_args()
     B, Hh, S, D = args.B, args.H, args.S, 128
