@@ -649,8 +649,11 @@ static bool h_fast_ok(int64_t M, int64_t N, int64_t K) { return M % H_BM == 0 &&
 
 using namespace kf;
 
+// the 256-tile kernel when its grid covers most of the chip (256 CUs, one 8-wave block each); smaller problems get four
+// times as many 128-tile blocks instead (2048^3: 64 tiles of 256^2 would leave three quarters of the CUs idle)
 static bool h256_ok(int64_t M, int64_t N, int64_t K) {
-    return M % G_BM == 0 && N % G_BN == 0 && K % G_BK == 0 && M > 0 && N > 0 && K > 0 && !getenv("KF_GEMM_128");
+    return M % G_BM == 0 && N % G_BN == 0 && K % G_BK == 0 && M > 0 && N > 0 && K > 0 && (M / G_BM) * (N / G_BN) >= 160 &&
+           !getenv("KF_GEMM_128");
 }
 
 extern "C" int kf_gemm_workspace_bytes(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, size_t *bytes) {

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""BASELINE configs C2 / C4 and the MFMA-utilisation sweep: GEMM through the C ABI at several sizes, layouts and epilogues;
+per-launch HIP-event times from the library's profiling mode. Writes one JSON object (profiles/r01_gemm_sweep.json)."""
+import argparse
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from kfunca_amd import hip_abi as H  # noqa: E402
+
+PEAK = {"bf16": 2500.0, "f32": 157.3}  # dense MFMA TFLOP/s (MI355X_MICROARCH.md)
+
+
+def bf16(rng, shape):
+    x = rng.uniform(-1, 1, size=shape).astype(np.float32)
+    u = x.view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+
+
+def timed(fn, rounds):
+    fn()
+    H.device_sync()
+    H.profile_reset()
+    H.profile_enable(True)
+    for _ in range(rounds):
+        fn()
+    H.device_sync()
+    H.profile_enable(False)
+    res = H.profile_results()
+    return sum(v[0] for v in res.values()) / rounds, sorted(res)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=10)
+    ap.add_argument("--json", default="")
+    args = ap.parse_args()
+    H.set_device(0)
+    rng = np.random.default_rng(1004)  # seed = 1000 + config number (C4)
+    out = {}
+    for dt, code, sizes in (("bf16", H.BF16, (1024, 2048, 4096, 8192)), ("f32", H.F32, (1024, 2048, 4096))):
+        for n in sizes:
+            mk = (lambda: bf16(rng, (n, n))) if code == H.BF16 else (lambda: rng.uniform(-1, 1, size=(n, n)).astype(np.float32))
+            A, B, G = (H.DevBuf.from_numpy(mk()) for _ in range(3))
+            es = 2 if code == H.BF16 else 4
+            C = H.DevBuf(es * n * n)
+            bias = H.DevBuf.from_numpy(mk()[0].copy())
+            need = max(H.gemm_workspace_bytes(code, ta, tb, n, n, n) for ta, tb in ((0, 0), (0, 1), (1, 0)))
+            ws = H.DevBuf(max(need, 16))
+            rounds = args.rounds if n <= 4096 else max(3, args.rounds // 2)
+            cases = {
+                "NN fwd": lambda: H.gemm(code, 0, 0, n, n, n, 1.0, A.ptr, n, B.ptr, n, 0.0, C.ptr, n, 0, None, ws.ptr, need),
+                "NT dA": lambda: H.gemm(code, 0, 1, n, n, n, 1.0, G.ptr, n, B.ptr, n, 0.0, C.ptr, n, 0, None, ws.ptr, need),
+                "TN dB": lambda: H.gemm(code, 1, 0, n, n, n, 1.0, A.ptr, n, G.ptr, n, 0.0, C.ptr, n, 0, None, ws.ptr, need),
+                "NN alpha*AB + beta*C + bias row (C4 epilogue)":
+                    lambda: H.gemm(code, 0, 0, n, n, n, 0.5, A.ptr, n, B.ptr, n, 2.0, C.ptr, n, H.EPI_BIAS_ROW, bias.ptr, ws.ptr, need),
+            }
+            for tag, fn in cases.items():
+                ms, kernels = timed(fn, rounds)
+                tf = 2.0 * n ** 3 / (ms * 1e-3) / 1e12
+                out[f"{dt} {n}^3 {tag}"] = {"ms": ms, "TFLOP/s": tf, "frac_of_mfma_peak": tf / PEAK[dt], "kernels": kernels}
+                print(f"{dt} {n:5d}^3 {tag:48s} {ms:9.4f} ms {tf:8.1f} TF/s  {tf / PEAK[dt] * 100:5.1f}% of {PEAK[dt]:.0f}  {kernels}", flush=True)
+            fb = sum(out[f"{dt} {n}^3 {t}"]["ms"] for t in ("NN fwd", "NT dA", "TN dB"))
+            out[f"{dt} {n}^3 fwd+bwd"] = {"ms": fb, "TFLOP/s": 6.0 * n ** 3 / (fb * 1e-3) / 1e12, "frac_of_mfma_peak": 6.0 * n ** 3 / (fb * 1e-3) / 1e12 / PEAK[dt]}
+            print(f"{dt} {n:5d}^3 fwd+bwd {fb:9.4f} ms {out[f'{dt} {n}^3 fwd+bwd']['TFLOP/s']:8.1f} TF/s", flush=True)
+    if args.json:
+        Path(args.json).write_text(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
