@@ -97,6 +97,15 @@ int kf_event_record(void *event, void *stream);
 int kf_event_sync(void *event);
 int kf_event_elapsed_ms(void *start, void *stop, float *ms);
 
+/* HIP graphs for launch-bound sequences (no reference counterpart: its Launcher submits kernel by kernel,
+ * launcher_cuda.h:330-354). Every compute entry of this library only enqueues work on the stream it is given and owns
+ * no memory, so a sequence of calls between begin and end is recorded instead of executed; kf_graph_launch replays it
+ * with one submission. `stream` must be a stream from kf_stream_create (not NULL). */
+int kf_graph_begin_capture(void *stream);
+int kf_graph_end_capture(void *stream, void **graph_exec);
+int kf_graph_launch(void *graph_exec, void *stream);
+int kf_graph_destroy(void *graph_exec);
+
 /* per-launch timing mode: replaces Launcher::set_profiling_mode + the cudaEvent pair around each
  * submit (launcher_cuda.h:253-255,336-345). While enabled, every kernel launch made through this
  * library is bracketed by a HIP event pair on its own stream (no host sync); kf_profile_get()

@@ -161,6 +161,37 @@ int kf_stream_create(void **stream) {
     return KF_OK;
 }
 
+int kf_graph_begin_capture(void *stream) {
+    KF_REQUIRE(stream, KF_ERR_INVALID, "kf_graph_begin_capture: capture needs a stream from kf_stream_create, not the null stream");
+    KF_HIP_TRY(hipStreamBeginCapture(as_stream(stream), hipStreamCaptureModeRelaxed));
+    return KF_OK;
+}
+
+int kf_graph_end_capture(void *stream, void **graph_exec) {
+    KF_REQUIRE(stream && graph_exec, KF_ERR_INVALID, "kf_graph_end_capture: null argument");
+    hipGraph_t g = nullptr;
+    KF_HIP_TRY(hipStreamEndCapture(as_stream(stream), &g));
+    KF_REQUIRE(g, KF_ERR_HIP, "kf_graph_end_capture: the capture was invalidated");
+    hipGraphExec_t ge = nullptr;
+    hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    KF_HIP_TRY(e);
+    *graph_exec = ge;
+    return KF_OK;
+}
+
+int kf_graph_launch(void *graph_exec, void *stream) {
+    KF_REQUIRE(graph_exec, KF_ERR_INVALID, "kf_graph_launch: null graph");
+    KF_HIP_TRY(hipGraphLaunch((hipGraphExec_t)graph_exec, as_stream(stream)));
+    return KF_OK;
+}
+
+int kf_graph_destroy(void *graph_exec) {
+    if (!graph_exec) return KF_OK;
+    KF_HIP_TRY(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
+    return KF_OK;
+}
+
 int kf_stream_destroy(void *stream) {
     if (!stream) return KF_OK;
     KF_HIP_TRY(hipStreamDestroy(as_stream(stream)));

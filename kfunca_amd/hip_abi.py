@@ -36,7 +36,7 @@ EXPORTS = [
     "kf_last_error", "kf_abi_version", "kf_device_count", "kf_set_device", "kf_get_device", "kf_malloc", "kf_free",
     "kf_memcpy_h2d", "kf_memcpy_d2h", "kf_memcpy_d2d", "kf_memset_zero", "kf_stream_create", "kf_stream_destroy",
     "kf_stream_sync", "kf_stream_wait_event", "kf_device_sync", "kf_event_create", "kf_event_destroy", "kf_event_record", "kf_event_sync",
-    "kf_event_elapsed_ms", "kf_profile_enable", "kf_profile_reset", "kf_profile_count", "kf_profile_get",
+    "kf_event_elapsed_ms", "kf_graph_begin_capture", "kf_graph_end_capture", "kf_graph_launch", "kf_graph_destroy", "kf_profile_enable", "kf_profile_reset", "kf_profile_count", "kf_profile_get",
     "kf_device_props_get", "kf_elementwise", "kf_reduce_workspace_bytes", "kf_reduce",
     "kf_reduce_moments_workspace_bytes", "kf_reduce_moments",
     "kf_index_put", "kf_gemm_workspace_bytes", "kf_gemm", "kf_attn_fwd", "kf_attn_bwd_workspace_bytes",
@@ -91,6 +91,10 @@ def lib():
         _lib.kf_event_record.argtypes = [vp, vp]
         _lib.kf_event_sync.argtypes = [vp]
         _lib.kf_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]
+        _lib.kf_graph_begin_capture.argtypes = [vp]
+        _lib.kf_graph_end_capture.argtypes = [vp, C.POINTER(vp)]
+        _lib.kf_graph_launch.argtypes = [vp, vp]
+        _lib.kf_graph_destroy.argtypes = [vp]
         _lib.kf_device_props_get.argtypes = [C.c_int, C.POINTER(DeviceProps)]
         _lib.kf_elementwise.argtypes = [C.c_int, C.POINTER(IterDesc), C.c_int, C.c_double, vp]
         _lib.kf_reduce_workspace_bytes.argtypes = [C.POINTER(IterDesc), C.POINTER(sz)]
@@ -144,6 +148,37 @@ class Stream:
     def __del__(self):
         if getattr(self, "handle", None) and _lib is not None:
             _lib.kf_stream_destroy(self.handle)
+            self.handle = None
+
+
+class Graph:
+    """A captured sequence of library calls on one stream (kf_graph_*): `with Graph.capture(stream) as g: ...` then g.launch()."""
+
+    def __init__(self, stream: Stream):
+        self.stream, self.handle = stream, None
+
+    @classmethod
+    def capture(cls, stream: Stream):
+        return cls(stream)
+
+    def __enter__(self):
+        check(lib().kf_graph_begin_capture(self.stream.handle))
+        return self
+
+    def __exit__(self, et, ev, tb):
+        h = C.c_void_p()
+        rc = lib().kf_graph_end_capture(self.stream.handle, C.byref(h))
+        if et is None:
+            check(rc)
+            self.handle = h.value
+        return False
+
+    def launch(self, stream: Stream = None):
+        check(lib().kf_graph_launch(self.handle, (stream or self.stream).handle))
+
+    def __del__(self):
+        if getattr(self, "handle", None) and _lib is not None:
+            _lib.kf_graph_destroy(self.handle)
             self.handle = None
 
 

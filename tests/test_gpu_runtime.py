@@ -57,3 +57,58 @@ def test_rccl_single_rank_allreduce():
     rc = H.lib().kf_allreduce_sum(comm, d.ptr, x.size, H.BOOL, s.handle)
     assert rc == H.KF_ERR_UNSUPPORTED
     H.check(H.lib().kf_comm_destroy(comm))
+
+
+def test_graph_capture_of_a_launch_bound_sequence():
+    """C1-size ops (1024 x 1024 fp32 add + sum) are launch-bound. The compute entries only enqueue on the caller's stream and
+    own no memory, so a chain of them records into a HIP graph and replays with one submission: same bits, less host time."""
+    import time
+    s = H.Stream()
+    n = 1024
+    rng = np.random.default_rng(3)
+    a_h, b_h = rng.uniform(-10, 10, (n, n)).astype(np.float32), rng.uniform(-10, 10, (n, n)).astype(np.float32)
+    a, b = H.DevBuf.from_numpy(a_h), H.DevBuf.from_numpy(b_h)
+    c, r = H.DevBuf(4 * n * n), H.DevBuf(4 * n)
+    va, vb, vc = (H.View(x.ptr, (n, n), (n, 1), H.F32) for x in (a, b, c))
+    vr = H.View(r.ptr, (n, 1), (1, 1), H.F32)
+    d_add = H.make_desc([vc], [va, vb])
+    d_acc = H.make_desc([vc], [vc, vb])
+    d_sum = H.make_reduce_desc(vr, vc, 1)
+    need = C.c_size_t(0)
+    H.check(H.lib().kf_reduce_workspace_bytes(C.byref(d_sum), C.byref(need)))
+    ws = H.DevBuf(max(need.value, 16))
+    reps = 40
+
+    def chain():  # c = a + b; c += b (reps times); r = sum(c, 1)
+        H.elementwise(H.EW_ADD, d_add, H.F32, stream=s.handle)
+        for _ in range(reps):
+            H.elementwise(H.EW_ADD, d_acc, H.F32, stream=s.handle)
+        H.check(H.lib().kf_reduce(H.RED_SUM, C.byref(d_sum), ws.ptr, need.value, s.handle))
+
+    chain()
+    s.sync()
+    want_c, want_r = c.to_numpy((n, n), np.float32), r.to_numpy((n, 1), np.float32)
+    ref = a_h + b_h
+    for _ in range(reps):
+        ref = ref + b_h
+    assert np.array_equal(want_c, ref)  # fp32 adds are exactly rounded: bit-exact against numpy
+    t0 = time.perf_counter()
+    for _ in range(5):
+        chain()
+    s.sync()
+    eager = (time.perf_counter() - t0) / 5
+    with H.Graph.capture(s) as g:
+        chain()
+    H.check(H.lib().kf_memset_zero(c.ptr, 4 * n * n, s.handle))
+    g.launch()
+    s.sync()
+    assert np.array_equal(c.to_numpy((n, n), np.float32), want_c) and np.array_equal(r.to_numpy((n, 1), np.float32), want_r)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        g.launch()
+    s.sync()
+    graph = (time.perf_counter() - t0) / 5
+    print(f"chain of {reps + 2} launches: eager {eager * 1e6:.0f} us, graph {graph * 1e6:.0f} us")
+    assert graph < eager * 1.2
+    with pytest.raises(H.KfError):
+        H.check(H.lib().kf_graph_begin_capture(None))
