@@ -322,6 +322,26 @@ void check_attention(const Tensor &q, const Tensor &k, const Tensor &v) {
     CHECK_FAIL(q.device() == k.device() && q.device() == v.device());
 }
 
+// The MFMA kernels want D = 128 and sequence lengths that are multiples of 128; everything else takes the generic
+// vector-ALU kernel (two orders of magnitude slower). For 16-bit tensors with D = 128 and Skv >= Sq the lengths can be
+// padded with zero rows at no cost in results: a padded key n >= Skv >= Sq > m is above the diagonal of every real query,
+// and a padded query has q = 0 and dO = 0, so it contributes exactly zero to dK and dV.
+bool pad_for_mfma(const Tensor &q, const Tensor &k) {
+    const int64_t Sq = q.shape(2), Skv = k.shape(2);
+    return (q.dtype() == ScalarType::Half || q.dtype() == ScalarType::BFloat16) && q.shape(3) == 128 && Skv >= Sq && Sq > 0 &&
+           (Sq % 128 != 0 || Skv % 128 != 0);
+}
+int64_t round128(int64_t s) { return (s + 127) / 128 * 128; }
+Tensor pad_rows(const Tensor &t, int64_t rows) { // [B,H,S,...] -> [B,H,rows,...], zero-filled tail
+    auto shape = t.sizes();
+    const int64_t S = shape[2];
+    shape[2] = rows;
+    Tensor p = zeros(shape, t.dtype(), t.device());
+    Tensor head = p.narrow(2, 0, S);
+    copy_(head, t);
+    return p;
+}
+
 class AttentionGradFunction : public GradFunction {
 public:
     AttentionGradFunction(const Tensor &q, const Tensor &k, const Tensor &v, const Tensor &out, const Tensor &lse) : out_(out), lse_(lse) {
@@ -341,6 +361,10 @@ private:
 std::tuple<Tensor, Tensor> causal_attention_fwd(const Tensor &q, const Tensor &k, const Tensor &v) {
     check_attention(q, k, v);
     const int64_t B = q.shape(0), H = q.shape(1), Sq = q.shape(2), D = q.shape(3), Skv = k.shape(2);
+    if (pad_for_mfma(q, k)) {
+        auto [outp, lsep] = causal_attention_fwd(pad_rows(q, round128(Sq)), pad_rows(k, round128(Skv)), pad_rows(v, round128(Skv)));
+        return {outp.narrow(2, 0, Sq).contiguous(), lsep.narrow(2, 0, Sq).contiguous()};
+    }
     Tensor out = empty_like(q);
     Tensor lse = empty({B, H, Sq}, ScalarType::Float, q.device());
     DEV_CALL(kf_attn_fwd(code(q.dtype()), B, H, Sq, Skv, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
@@ -353,6 +377,12 @@ std::tuple<Tensor, Tensor, Tensor> causal_attention_bwd(const Tensor &q, const T
     check_attention(q, k, v);
     CHECK_FAIL(grad_out.sizes() == q.sizes() && grad_out.dtype() == q.dtype());
     const int64_t B = q.shape(0), H = q.shape(1), Sq = q.shape(2), D = q.shape(3), Skv = k.shape(2);
+    if (pad_for_mfma(q, k)) {
+        const int64_t Sqp = round128(Sq), Skp = round128(Skv);
+        auto [dqp, dkp, dvp] = causal_attention_bwd(pad_rows(q, Sqp), pad_rows(k, Skp), pad_rows(v, Skp), pad_rows(out, Sqp), pad_rows(lse, Sqp),
+                                                    pad_rows(grad_out.contiguous(), Sqp));
+        return {dqp.narrow(2, 0, Sq).contiguous(), dkp.narrow(2, 0, Skv).contiguous(), dvp.narrow(2, 0, Skv).contiguous()};
+    }
     Tensor go = grad_out.contiguous();
     Tensor dq = empty_like(q), dk = empty_like(k), dv = empty_like(v);
     size_t need = 0;

@@ -298,6 +298,34 @@ def test_causal_attention_golden_and_backward():  # test_nn.py:11-33 + backward
         close(t.grad().float(), O.bf16_to_f32(ref), atol=3e-2, rtol=2e-2)
 
 
+def test_ragged_16bit_attention_takes_the_mfma_kernels():
+    """Sequence lengths that are not multiples of 128 (D = 128, Skv >= Sq): the operator pads with zero rows, which leaves
+    every result unchanged (padded keys are above every real query's diagonal; padded queries carry q = 0, dO = 0), and the
+    MFMA kernels run instead of the generic vector-ALU one."""
+    from kfunca_amd import hip_abi as H
+    rng = np.random.default_rng(16)
+    for (B, Hh, Sq, Skv) in ((2, 2, 200, 200), (1, 2, 130, 300), (1, 1, 1, 1)):
+        q, k, v, go = (rng.uniform(-1, 1, s).astype(np.float32) for s in ((B, Hh, Sq, 128), (B, Hh, Skv, 128), (B, Hh, Skv, 128), (B, Hh, Sq, 128)))
+        tq, tk, tv = (kfunca.from_numpy(x, 0).bfloat16() for x in (q, k, v))
+        for t in (tq, tk, tv):
+            t.set_requires_grad(True)
+        H.profile_reset()
+        H.profile_enable(True)
+        out = kfunca.causal_attention(tq, tk, tv)
+        out.backward(kfunca.from_numpy(go, 0).bfloat16())
+        kfunca.synchronize()
+        H.profile_enable(False)
+        names = set(H.profile_results())
+        assert {"attn_fwd_mfma", "attn_bwd_dkv_mfma", "attn_bwd_dq_mfma"} <= names and not any("generic" in n for n in names), names
+        assert out.sizes() == [B, Hh, Sq, 128]
+        qb, kb, vb, gb = (O.f32_to_bf16(x) for x in (q, k, v, go))
+        o_ref, _ = O.attn_fwd(qb, kb, vb, code=O.BF16)
+        close(out.float(), O.bf16_to_f32(o_ref), atol=2e-2, rtol=2e-2)
+        for t, ref in zip((tq, tk, tv), O.attn_bwd(qb, kb, vb, gb, code=O.BF16)):
+            assert t.grad().sizes() == list(ref.shape)
+            close(t.grad().float(), O.bf16_to_f32(ref), atol=3e-2, rtol=2e-2)
+
+
 def test_allocator_reuse_and_scope():
     base = kfunca.memstat_dict(0)
     t = kfunca.empty([1 << 20], kfunca.float, 0)
