@@ -22,7 +22,11 @@ namespace {
 // every element offset distinct and the view fills a dense block (reference memory_overlap.h:10-28)
 bool non_overlapping_and_dense(const IterOperand &t) {
     std::vector<std::pair<int64_t, int64_t>> v; // (stride, size)
-    for (int i = t.ndim - 1; i >= 0; --i) v.emplace_back(t.stride[i], t.shape[i]);
+    for (int i = t.ndim - 1; i >= 0; --i) {
+        if (t.shape[i] == 0) return true; // no elements: nothing can overlap
+        if (t.shape[i] == 1) continue;    // the stride of an extent-1 dim addresses nothing
+        v.emplace_back(t.stride[i], t.shape[i]);
+    }
     std::stable_sort(v.begin(), v.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
     int64_t expect = 1;
     for (auto &p : v) {
@@ -36,6 +40,7 @@ bool non_overlapping_and_dense(const IterOperand &t) {
 std::pair<uintptr_t, uintptr_t> byte_range(const IterOperand &t) {
     int64_t lo = 0, hi = 0;
     for (int i = 0; i < t.ndim; ++i) {
+        if (t.shape[i] == 0) return {1, 0}; // empty operand: an empty range, overlaps nothing
         const int64_t span = (t.shape[i] - 1) * t.stride[i];
         (span >= 0 ? hi : lo) += span;
     }
