@@ -226,10 +226,16 @@ int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K
  * inference): lse = m + log(l), the natural-log-sum-exp of the scaled, masked scores.
  * O = softmax(mask(Q K^T / sqrt(D))) V, mask keeps key n for query m iff m >= n (absolute
  * indices, top-left aligned: causal_attention_ref.h:36-41).
- * dtype in {KF_F32 (any D <= 256, any Sq/Skv), KF_BF16, KF_F16 (D in {64,128})}.
+ * dtype in {KF_F32, KF_BF16, KF_F16}, D <= 256, any Sq / Skv. The MFMA kernels take 16-bit tensors with D = 128 and
+ * Sq, Skv multiples of 128; everything else runs the generic vector-ALU kernels (correct, about 100x slower).
+ * The *_scaled forms take the softmax scale explicitly instead of 1 / sqrt(D): a host that zero-pads a smaller head
+ * size up to 128 columns (zero columns change neither Q K^T nor P V) passes 1 / sqrt(its own D) and lands on the MFMA
+ * kernels - kfunca_amd's causal_attention does exactly that.
  */
 int kf_attn_fwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, const void *q,
                 const void *k, const void *v, void *o, float *lse, void *stream);
+int kf_attn_fwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, float scale, const void *q,
+                       const void *k, const void *v, void *o, float *lse, void *stream);
 /*
  * dq,dk,dv from d_o. Needs o and lse from the forward. workspace holds delta[B,H,Sq] f32 and an
  * f32 dq accumulator; kf_attn_bwd_workspace_bytes() says how much; no initialisation needed.
@@ -239,6 +245,9 @@ int kf_attn_bwd_workspace_bytes(int dtype, int64_t B, int64_t H, int64_t Sq, int
 int kf_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, const void *q,
                 const void *k, const void *v, const void *o, const float *lse, const void *d_o, void *dq,
                 void *dk, void *dv, void *workspace, size_t workspace_bytes, void *stream);
+int kf_attn_bwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, float scale, const void *q,
+                       const void *k, const void *v, const void *o, const float *lse, const void *d_o, void *dq,
+                       void *dk, void *dv, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- collectives (RCCL over xGMI): the one exchange step of the batch-sharded path (§8e) ---- */
 #define KF_COMM_ID_BYTES 128

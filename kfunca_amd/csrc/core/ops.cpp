@@ -4,6 +4,7 @@
 #include "ops.h"
 
 #include <algorithm>
+#include <cmath>
 
 #include "device_api.h"
 #include "tensor_iterator.h"
@@ -323,23 +324,31 @@ void check_attention(const Tensor &q, const Tensor &k, const Tensor &v) {
 }
 
 // The MFMA kernels want D = 128 and sequence lengths that are multiples of 128; everything else takes the generic
-// vector-ALU kernel (two orders of magnitude slower). For 16-bit tensors with D = 128 and Skv >= Sq the lengths can be
-// padded with zero rows at no cost in results: a padded key n >= Skv >= Sq > m is above the diagonal of every real query,
-// and a padded query has q = 0 and dO = 0, so it contributes exactly zero to dK and dV.
+// vector-ALU kernel (two orders of magnitude slower). For 16-bit tensors with D <= 128 and Skv >= Sq both can be padded
+// with zeros at no cost in results: zero columns change neither Q K^T nor P V (the softmax scale stays 1 / sqrt(D) of the
+// real head size: kf_attn_*_scaled); a padded key n >= Skv >= Sq > m is above the diagonal of every real query; a padded
+// query has q = 0 and dO = 0, so it contributes exactly zero to dK and dV.
 bool pad_for_mfma(const Tensor &q, const Tensor &k) {
-    const int64_t Sq = q.shape(2), Skv = k.shape(2);
-    return (q.dtype() == ScalarType::Half || q.dtype() == ScalarType::BFloat16) && q.shape(3) == 128 && Skv >= Sq && Sq > 0 &&
-           (Sq % 128 != 0 || Skv % 128 != 0);
+    const int64_t Sq = q.shape(2), Skv = k.shape(2), D = q.shape(3);
+    return (q.dtype() == ScalarType::Half || q.dtype() == ScalarType::BFloat16) && D > 0 && D <= 128 && Skv >= Sq && Sq > 0 &&
+           (D != 128 || Sq % 128 != 0 || Skv % 128 != 0);
 }
 int64_t round128(int64_t s) { return (s + 127) / 128 * 128; }
-Tensor pad_rows(const Tensor &t, int64_t rows) { // [B,H,S,...] -> [B,H,rows,...], zero-filled tail
+Tensor pad_to(const Tensor &t, int64_t rows, int64_t cols) { // [B,H,S,D] -> [B,H,rows,cols] (or [B,H,S] -> [B,H,rows]), zero-filled
     auto shape = t.sizes();
     const int64_t S = shape[2];
     shape[2] = rows;
+    if (shape.size() == 4) shape[3] = cols;
     Tensor p = zeros(shape, t.dtype(), t.device());
     Tensor head = p.narrow(2, 0, S);
+    if (shape.size() == 4) head = head.narrow(3, 0, t.shape(3));
     copy_(head, t);
     return p;
+}
+Tensor unpad(const Tensor &t, int64_t rows, int64_t cols) {
+    Tensor v = t.narrow(2, 0, rows);
+    if (t.dim() == 4) v = v.narrow(3, 0, cols);
+    return v.contiguous();
 }
 
 class AttentionGradFunction : public GradFunction {
@@ -362,8 +371,13 @@ std::tuple<Tensor, Tensor> causal_attention_fwd(const Tensor &q, const Tensor &k
     check_attention(q, k, v);
     const int64_t B = q.shape(0), H = q.shape(1), Sq = q.shape(2), D = q.shape(3), Skv = k.shape(2);
     if (pad_for_mfma(q, k)) {
-        auto [outp, lsep] = causal_attention_fwd(pad_rows(q, round128(Sq)), pad_rows(k, round128(Skv)), pad_rows(v, round128(Skv)));
-        return {outp.narrow(2, 0, Sq).contiguous(), lsep.narrow(2, 0, Sq).contiguous()};
+        const int64_t Sqp = round128(Sq), Skp = round128(Skv);
+        Tensor qp = pad_to(q, Sqp, 128), kp = pad_to(k, Skp, 128), vp = pad_to(v, Skp, 128);
+        Tensor outp = empty_like(qp);
+        Tensor lsep = empty({B, H, Sqp}, ScalarType::Float, q.device());
+        DEV_CALL(kf_attn_fwd_scaled(code(q.dtype()), B, H, Sqp, Skp, 128, 1.0f / std::sqrt((float)D), qp.data_ptr(), kp.data_ptr(), vp.data_ptr(),
+                                    outp.data_ptr(), static_cast<float *>(lsep.data_ptr()), dev::stream(q.device())));
+        return {unpad(outp, Sq, D), unpad(lsep, Sq, 0)};
     }
     Tensor out = empty_like(q);
     Tensor lse = empty({B, H, Sq}, ScalarType::Float, q.device());
@@ -379,9 +393,16 @@ std::tuple<Tensor, Tensor, Tensor> causal_attention_bwd(const Tensor &q, const T
     const int64_t B = q.shape(0), H = q.shape(1), Sq = q.shape(2), D = q.shape(3), Skv = k.shape(2);
     if (pad_for_mfma(q, k)) {
         const int64_t Sqp = round128(Sq), Skp = round128(Skv);
-        auto [dqp, dkp, dvp] = causal_attention_bwd(pad_rows(q, Sqp), pad_rows(k, Skp), pad_rows(v, Skp), pad_rows(out, Sqp), pad_rows(lse, Sqp),
-                                                    pad_rows(grad_out.contiguous(), Sqp));
-        return {dqp.narrow(2, 0, Sq).contiguous(), dkp.narrow(2, 0, Skv).contiguous(), dvp.narrow(2, 0, Skv).contiguous()};
+        Tensor qp = pad_to(q, Sqp, 128), kp = pad_to(k, Skp, 128), vp = pad_to(v, Skp, 128), op = pad_to(out, Sqp, 128);
+        Tensor lp = pad_to(lse, Sqp, 0), gp = pad_to(grad_out.contiguous(), Sqp, 128);
+        Tensor dqp = empty_like(qp), dkp = empty_like(kp), dvp = empty_like(vp);
+        size_t need = 0;
+        DEV_CALL(kf_attn_bwd_workspace_bytes(code(q.dtype()), B, H, Sqp, Skp, 128, &need));
+        DataPtr scratch = DeviceAllocator::GetInstance()->allocate(need, q.device());
+        DEV_CALL(kf_attn_bwd_scaled(code(q.dtype()), B, H, Sqp, Skp, 128, 1.0f / std::sqrt((float)D), qp.data_ptr(), kp.data_ptr(), vp.data_ptr(),
+                                    op.data_ptr(), static_cast<const float *>(lp.data_ptr()), gp.data_ptr(), dqp.data_ptr(), dkp.data_ptr(),
+                                    dvp.data_ptr(), scratch.get(), need, dev::stream(q.device())));
+        return {unpad(dqp, Sq, D), unpad(dkp, Skv, D), unpad(dvp, Skv, D)};
     }
     Tensor go = grad_out.contiguous();
     Tensor dq = empty_like(q), dk = empty_like(k), dv = empty_like(v);

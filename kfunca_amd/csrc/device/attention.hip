@@ -1350,6 +1350,11 @@ static int check_common(const char *who, int dtype, int64_t B, int64_t H, int64_
 
 extern "C" int kf_attn_fwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, const void *q,
                            const void *k, const void *v, void *o, float *lse, void *stream) {
+    return kf_attn_fwd_scaled(dtype, B, H, Sq, Skv, D, D > 0 ? 1.0f / sqrtf((float)D) : 1.0f, q, k, v, o, lse, stream);
+}
+
+extern "C" int kf_attn_fwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, float scale, const void *q,
+                                  const void *k, const void *v, void *o, float *lse, void *stream) {
     int rc = check_common("kf_attn_fwd", dtype, B, H, Sq, Skv, D);
     if (rc != KF_OK) return rc;
     if (B * H == 0 || Sq == 0) return KF_OK;
@@ -1360,7 +1365,8 @@ extern "C" int kf_attn_fwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
     memset(&a, 0, sizeof(a));
     a.q = (const char *)q; a.k = (const char *)k; a.v = (const char *)v; a.out = (char *)o; a.lse = lse;
     a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.D = D;
-    a.scale = 1.0f / sqrtf((float)D);
+    KF_REQUIRE(scale > 0.f && scale < INFINITY, KF_ERR_INVALID, "attention: the softmax scale must be positive and finite");
+    a.scale = scale;
     a.xcd_map = ((B * H) % 8 == 0) && !getenv("KF_ATTN_NO_XCD");
     if (mfma_ok(dtype, Sq, Skv, D)) {
         const size_t lds3 = SRING * FBUF;
@@ -1410,6 +1416,13 @@ extern "C" int kf_attn_bwd_workspace_bytes(int dtype, int64_t B, int64_t H, int6
 extern "C" int kf_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, const void *q,
                            const void *k, const void *v, const void *o, const float *lse, const void *d_o, void *dq,
                            void *dk, void *dv, void *workspace, size_t workspace_bytes, void *stream) {
+    return kf_attn_bwd_scaled(dtype, B, H, Sq, Skv, D, D > 0 ? 1.0f / sqrtf((float)D) : 1.0f, q, k, v, o, lse, d_o, dq, dk, dv, workspace,
+                              workspace_bytes, stream);
+}
+
+extern "C" int kf_attn_bwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, float scale, const void *q,
+                                  const void *k, const void *v, const void *o, const float *lse, const void *d_o, void *dq,
+                                  void *dk, void *dv, void *workspace, size_t workspace_bytes, void *stream) {
     int rc = check_common("kf_attn_bwd", dtype, B, H, Sq, Skv, D);
     if (rc != KF_OK) return rc;
     if (B * H == 0 || Sq == 0 || Skv == 0) return KF_OK;
@@ -1427,15 +1440,16 @@ extern "C" int kf_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
     a.ndelta = (float *)((char *)workspace + 2 * a_align((size_t)B * H * Sq * sizeof(float)));
     a.xcd_map = ((B * H) % 8 == 0) && !getenv("KF_ATTN_NO_XCD");
     a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.D = D;
-    a.scale = 1.0f / sqrtf((float)D);
+    KF_REQUIRE(scale > 0.f && scale < INFINITY, KF_ERR_INVALID, "attention: the softmax scale must be positive and finite");
+    a.scale = scale;
     const int64_t nrows = B * H * Sq;
     if (mfma_ok(dtype, Sq, Skv, D)) {
         const unsigned gd = (unsigned)((nrows + 15) / 16);
         const bool bf = dtype == KF_BF16;
         {
             KF_PROF("attn_bwd_delta", st);
-            if (bf) attn_delta_kernel<true><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, sqrtf((float)D));
-            else attn_delta_kernel<false><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, sqrtf((float)D));
+            if (bf) attn_delta_kernel<true><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, 1.0f / a.scale);
+            else attn_delta_kernel<false><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, 1.0f / a.scale);
             KF_LAUNCH_CHECK();
         }
         if (!getenv("KF_ATTN_DKV_V2")) { // default: one wave per SIMD, pinned MFMA / VALU interleave

@@ -39,8 +39,8 @@ EXPORTS = [
     "kf_event_elapsed_ms", "kf_graph_begin_capture", "kf_graph_end_capture", "kf_graph_launch", "kf_graph_destroy", "kf_profile_enable", "kf_profile_reset", "kf_profile_count", "kf_profile_get",
     "kf_device_props_get", "kf_elementwise", "kf_reduce_workspace_bytes", "kf_reduce",
     "kf_reduce_moments_workspace_bytes", "kf_reduce_moments",
-    "kf_index_put", "kf_gemm_workspace_bytes", "kf_gemm", "kf_attn_fwd", "kf_attn_bwd_workspace_bytes",
-    "kf_attn_bwd", "kf_comm_unique_id", "kf_comm_init", "kf_comm_destroy", "kf_allreduce_sum",
+    "kf_index_put", "kf_gemm_workspace_bytes", "kf_gemm", "kf_attn_fwd", "kf_attn_fwd_scaled", "kf_attn_bwd_workspace_bytes",
+    "kf_attn_bwd", "kf_attn_bwd_scaled", "kf_comm_unique_id", "kf_comm_init", "kf_comm_destroy", "kf_allreduce_sum",
 ]
 
 
@@ -108,6 +108,8 @@ def lib():
         _lib.kf_attn_fwd.argtypes = [C.c_int, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp]
         _lib.kf_attn_bwd_workspace_bytes.argtypes = [C.c_int, i64, i64, i64, i64, i64, C.POINTER(sz)]
         _lib.kf_attn_bwd.argtypes = [C.c_int, i64, i64, i64, i64, i64] + [vp] * 10 + [sz, vp]
+        _lib.kf_attn_fwd_scaled.argtypes = [C.c_int, i64, i64, i64, i64, i64, C.c_float, vp, vp, vp, vp, vp, vp]
+        _lib.kf_attn_bwd_scaled.argtypes = [C.c_int, i64, i64, i64, i64, i64, C.c_float] + [vp] * 10 + [sz, vp]
         _lib.kf_comm_unique_id.argtypes = [C.c_char_p]
         _lib.kf_comm_init.argtypes = [C.POINTER(vp), C.c_char_p, C.c_int, C.c_int]
         _lib.kf_comm_destroy.argtypes = [vp]

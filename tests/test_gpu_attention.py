@@ -207,3 +207,29 @@ def test_backward_is_bitwise_reproducible():
                 for nme, a0, a1 in zip(("dq", "dk", "dv"), first, again):
                     assert np.array_equal(a0.view(np.uint16), a1.view(np.uint16)), (code, Sq, Skv, rep, nme)
                 del junk
+
+
+def test_scaled_entry_points_equal_the_default_scale():
+    """kf_attn_fwd_scaled / kf_attn_bwd_scaled with scale = 1 / sqrt(D) are the plain entries, bit for bit; another scale
+    behaves like pre-scaling the scores (checked against the oracle on Q * (scale * sqrt(D)) in f32)."""
+    import ctypes as C
+    code, B, Hh, S, D = H.BF16, 1, 2, 256, 128
+    rng = np.random.default_rng(91)
+    q, k, v, go = (O.f32_to_bf16(rng.uniform(-1, 1, (B, Hh, S, D)).astype(np.float32)) for _ in range(4))
+    o, lse = fwd(code, q, k, v)
+    bufs = [H.DevBuf.from_numpy(x) for x in (q, k, v)]
+    o2, l2 = H.DevBuf(q.nbytes), H.DevBuf(4 * B * Hh * S)
+    H.check(H.lib().kf_attn_fwd_scaled(code, B, Hh, S, S, D, C.c_float(1.0 / np.sqrt(np.float32(D))), bufs[0].ptr, bufs[1].ptr, bufs[2].ptr,
+                                       o2.ptr, l2.ptr, None))
+    H.device_sync()
+    assert np.array_equal(o2.to_numpy(q.shape, q.dtype), o) and np.array_equal(l2.to_numpy((B, Hh, S), np.float32), lse)
+    with pytest.raises(H.KfError):
+        H.check(H.lib().kf_attn_fwd_scaled(code, B, Hh, S, S, D, C.c_float(0.0), bufs[0].ptr, bufs[1].ptr, bufs[2].ptr, o2.ptr, l2.ptr, None))
+    # f32 generic path with half the default scale == default scale on Q / 2
+    qf, kf_, vf = (rng.uniform(-1, 1, (1, 1, 40, 32)).astype(np.float32) for _ in range(3))
+    b2 = [H.DevBuf.from_numpy(x) for x in (qf, kf_, vf)]
+    o3, l3 = H.DevBuf(qf.nbytes), H.DevBuf(4 * 40)
+    H.check(H.lib().kf_attn_fwd_scaled(H.F32, 1, 1, 40, 40, 32, C.c_float(0.5 / np.sqrt(np.float32(32))), b2[0].ptr, b2[1].ptr, b2[2].ptr, o3.ptr, l3.ptr, None))
+    H.device_sync()
+    want, _ = O.attn_fwd(qf * np.float32(0.5), kf_, vf)
+    assert_close(o3.to_numpy(qf.shape, np.float32), want, what="explicit scale")

@@ -299,13 +299,14 @@ def test_causal_attention_golden_and_backward():  # test_nn.py:11-33 + backward
 
 
 def test_ragged_16bit_attention_takes_the_mfma_kernels():
-    """Sequence lengths that are not multiples of 128 (D = 128, Skv >= Sq): the operator pads with zero rows, which leaves
-    every result unchanged (padded keys are above every real query's diagonal; padded queries carry q = 0, dO = 0), and the
-    MFMA kernels run instead of the generic vector-ALU one."""
+    """Sequence lengths that are not multiples of 128 and head sizes below 128 (16-bit, Skv >= Sq): the operator pads with
+    zeros, which leaves every result unchanged (zero columns add nothing to Q K^T or P V and the softmax scale stays
+    1 / sqrt(D); padded keys are above every real query's diagonal; padded queries carry q = 0, dO = 0), and the MFMA kernels
+    run instead of the generic vector-ALU one."""
     from kfunca_amd import hip_abi as H
     rng = np.random.default_rng(16)
-    for (B, Hh, Sq, Skv) in ((2, 2, 200, 200), (1, 2, 130, 300), (1, 1, 1, 1)):
-        q, k, v, go = (rng.uniform(-1, 1, s).astype(np.float32) for s in ((B, Hh, Sq, 128), (B, Hh, Skv, 128), (B, Hh, Skv, 128), (B, Hh, Sq, 128)))
+    for (B, Hh, Sq, Skv, D) in ((2, 2, 200, 200, 128), (1, 2, 130, 300, 128), (1, 1, 1, 1, 128), (2, 3, 256, 256, 64), (1, 2, 100, 140, 80)):
+        q, k, v, go = (rng.uniform(-1, 1, s).astype(np.float32) for s in ((B, Hh, Sq, D), (B, Hh, Skv, D), (B, Hh, Skv, D), (B, Hh, Sq, D)))
         tq, tk, tv = (kfunca.from_numpy(x, 0).bfloat16() for x in (q, k, v))
         for t in (tq, tk, tv):
             t.set_requires_grad(True)
@@ -317,7 +318,7 @@ def test_ragged_16bit_attention_takes_the_mfma_kernels():
         H.profile_enable(False)
         names = set(H.profile_results())
         assert {"attn_fwd_mfma", "attn_bwd_dkv_mfma", "attn_bwd_dq_mfma"} <= names and not any("generic" in n for n in names), names
-        assert out.sizes() == [B, Hh, Sq, 128]
+        assert out.sizes() == [B, Hh, Sq, D]
         qb, kb, vb, gb = (O.f32_to_bf16(x) for x in (q, k, v, go))
         o_ref, _ = O.attn_fwd(qb, kb, vb, code=O.BF16)
         close(out.float(), O.bf16_to_f32(o_ref), atol=2e-2, rtol=2e-2)
