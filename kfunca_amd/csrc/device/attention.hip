@@ -25,6 +25,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -1093,6 +1094,153 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
 }
 
 // ==========================================================================================
+// forward, f32 (the reference's dtype: CausalAttentionForwardFN<float, 64 | 128>, causal_attention.h:66-258), on the
+// exact-f32 matrix instruction v_mfma_f32_32x32x2_f32 (a k-ordered fma chain, 157 TFLOP/s dense, 1/16 of the bf16 rate -
+// so this kernel is matrix-pipe bound by a wide margin and needs no scheduling tricks). Query on the lane, 4 waves x 32
+// queries, 32-key K / V tiles in LDS (rows padded by 4 floats: conflict-free ds_read_b128 row reads).
+//   S^T = K Q^T: A = K[key][k] from LDS, B = Q[query][k] from registers; lane half hl owns k in [hl D/2, (hl+1) D/2) of
+//   BOTH operands (any consistent assignment of k to the two halves is a valid MFMA), so every LDS read is 16 B of one row.
+//   O^T += V^T P^T: step e uses the two keys row(e, 0), row(e, 1) the S accumulator register e holds for the two lane
+//   halves - P is consumed straight out of the accumulator, no shuffle, no conversion; A = V[row(e, hl)][d] from LDS.
+// ==========================================================================================
+constexpr int XQ = 128, XK = 32; // queries per block, keys per tile
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_fwd_f32_mfma_kernel(const AttnArgs a) {
+    constexpr int DP = D + 4, HD = D / 2, ND = D / 32; // padded row (floats); k per lane half; 32-column blocks of O
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *Ks = (float *)smem, *Vs = Ks + XK * DP;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5, t = threadIdx.x;
+    int xb;
+    int64_t bh;
+    const int nxb = (int)((a.Sq + XQ - 1) / XQ);
+    a_block_map(nxb, (int)(a.B * a.H), a.xcd_map, xb, bh);
+    const int qblk = nxb - 1 - xb; // longest blocks first
+    const int64_t q0 = (int64_t)qblk * XQ, qw = q0 + wid * 32, m = qw + xl;
+    const bool active = qw < a.Sq; // Sq % 32 == 0: whole waves
+    const float *Kg = (const float *)a.k + bh * a.Skv * D;
+    const float *Vg = (const float *)a.v + bh * a.Skv * D;
+
+    float qreg[HD];
+    if (active) {
+        const float4 *Qg = (const float4 *)((const float *)a.q + (bh * a.Sq + m) * D + hl * HD);
+#pragma unroll
+        for (int j = 0; j < HD / 4; ++j) {
+            const float4 v = Qg[j];
+            qreg[4 * j] = v.x; qreg[4 * j + 1] = v.y; qreg[4 * j + 2] = v.z; qreg[4 * j + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < HD; ++j) qreg[j] = 0.f;
+    }
+    f32x16 o[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
+    float m_i = -INFINITY, l_i = 0.f;
+    const float c = a.scale * kLog2e;
+
+    const int64_t q_end = q0 + XQ < a.Sq ? q0 + XQ : a.Sq;
+    const int64_t kv_end = a.Skv < q_end ? a.Skv : q_end;
+    const int nt = (int)((kv_end + XK - 1) / XK);
+    // tile staging: XK x D floats = XK * D / 4 float4, 256 threads
+    constexpr int NV = XK * D / 4 / 256; // float4 per thread per tile (4 at D = 128, 2 at D = 64)
+    // named registers, not arrays: hipcc keeps float4[N] staging arrays that cross a loop in scratch
+    float4 k0, k1, k2, k3, v0, v1, v2, v3;
+    k2 = k3 = v2 = v3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto src = [&](const float *g, int tile, int i) __attribute__((always_inline)) {
+        const int id = t + 256 * i, row = id / (D / 4), c4 = id % (D / 4);
+        return (const float4 *)(g + ((int64_t)tile * XK + row) * D + 4 * c4);
+    };
+    auto dst = [&](float *l, int i) __attribute__((always_inline)) {
+        const int id = t + 256 * i, row = id / (D / 4), c4 = id % (D / 4);
+        return (float4 *)(l + row * DP + 4 * c4);
+    };
+    auto gload = [&](int tile) __attribute__((always_inline)) {
+        k0 = *src(Kg, tile, 0); k1 = *src(Kg, tile, 1); v0 = *src(Vg, tile, 0); v1 = *src(Vg, tile, 1);
+        if constexpr (NV == 4) { k2 = *src(Kg, tile, 2); k3 = *src(Kg, tile, 3); v2 = *src(Vg, tile, 2); v3 = *src(Vg, tile, 3); }
+    };
+    auto lstore = [&]() __attribute__((always_inline)) {
+        *dst(Ks, 0) = k0; *dst(Ks, 1) = k1; *dst(Vs, 0) = v0; *dst(Vs, 1) = v1;
+        if constexpr (NV == 4) { *dst(Ks, 2) = k2; *dst(Ks, 3) = k3; *dst(Vs, 2) = v2; *dst(Vs, 3) = v3; }
+    };
+    gload(0);
+    for (int tl = 0; tl < nt; ++tl) {
+        const int64_t kv0 = (int64_t)tl * XK;
+        __syncthreads(); // every wave is done with the previous tile
+        lstore();
+        __syncthreads();
+        if (tl + 1 < nt) gload(tl + 1); // in flight under this tile's 128 MFMAs
+        if (!active || kv0 > qw + 31) continue;
+        // ---- S^T = K Q^T
+        f32x16 sv;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sv[e] = 0.f;
+        const float *krow = Ks + xl * DP + hl * HD;
+#pragma unroll
+        for (int j = 0; j < HD / 4; ++j) {
+            const float4 kk = *(const float4 *)(krow + 4 * j);
+            sv = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.x, qreg[4 * j], sv, 0, 0, 0);
+            sv = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.y, qreg[4 * j + 1], sv, 0, 0, 0);
+            sv = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.z, qreg[4 * j + 2], sv, 0, 0, 0);
+            sv = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.w, qreg[4 * j + 3], sv, 0, 0, 0);
+        }
+        // ---- online softmax (one query per lane; the other lane half holds the other 16 keys)
+        const bool need_mask = kv0 + XK - 1 > qw;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (need_mask && kv0 + a_row(e, hl) > m) sv[e] = -INFINITY;
+            mx = fmaxf(mx, sv[e]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_i, mx);
+        const float mc = m_new * c;
+        const float alpha = __builtin_amdgcn_exp2f(m_i * c - mc);
+        float rs = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[e], c, -mc));
+            sv[e] = p;
+            rs += p;
+        }
+        rs += __shfl_xor(rs, 32, 64);
+        l_i = l_i * alpha + rs;
+        m_i = m_new;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float *vrow = Vs + a_row(e, hl) * DP + xl;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32 * d], sv[e], o[d], 0, 0, 0);
+        }
+    }
+    // ---- epilogue: O^T tiles -> rows through LDS (reuses the tile buffers), 16-byte coalesced stores
+    __syncthreads();
+    float *slab = (float *)smem + wid * 32 * (D + 4); // [32 queries][D + 4]
+    if (active) {
+        const float inv = 1.f / l_i;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) slab[xl * (D + 4) + 32 * d + a_row(e, hl)] = o[d][e] * inv;
+        // the wave reads back what it wrote: LDS operations of one wave complete in order
+        float *og = (float *)a.out + (bh * a.Sq + qw) * D;
+#pragma unroll
+        for (int i = 0; i < 32 * D / 4 / 64; ++i) {
+            const int id = lane + 64 * i, row = id / (D / 4), c4 = id % (D / 4);
+            *(float4 *)(og + (int64_t)row * D + 4 * c4) = *(const float4 *)(slab + row * (D + 4) + 4 * c4);
+        }
+        if (a.lse && hl == 0) a.lse[bh * a.Sq + m] = (m_i * c + __builtin_amdgcn_logf(l_i)) * kLn2;
+    }
+}
+
+// ==========================================================================================
 // generic path: f32 math on the vector ALU, any Sq / Skv, D <= 256, f32 / bf16 / f16 storage.
 // One block = 16 queries; key tiles of 32; 256 threads.
 // ==========================================================================================
@@ -1376,6 +1524,21 @@ extern "C" int kf_attn_fwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, i
         if ((rc = set_lds(attn_fwd_v3_kernel<false>, lds3)) != KF_OK) return rc;
         if (dtype == KF_BF16) attn_fwd_v3_kernel<true><<<grid3, FNT, lds3, st>>>(a);
         else attn_fwd_v3_kernel<false><<<grid3, FNT, lds3, st>>>(a);
+        KF_LAUNCH_CHECK();
+        return KF_OK;
+    }
+    if (dtype == KF_F32 && (D == 64 || D == 128) && Sq % 32 == 0 && Skv % 32 == 0 && !getenv("KF_ATTN_F32_GENERIC")) {
+        // the reference's own fast path (f32, head size 64 or 128): exact-f32 MFMA
+        const size_t ldsx = std::max((size_t)2 * XK * (D + 4), (size_t)4 * 32 * (D + 4)) * sizeof(float);
+        dim3 gridx((unsigned)(((Sq + XQ - 1) / XQ) * B * H));
+        KF_PROF("attn_fwd_f32_mfma", st);
+        if (D == 128) {
+            if ((rc = set_lds(attn_fwd_f32_mfma_kernel<128>, ldsx)) != KF_OK) return rc;
+            attn_fwd_f32_mfma_kernel<128><<<gridx, 256, ldsx, st>>>(a);
+        } else {
+            if ((rc = set_lds(attn_fwd_f32_mfma_kernel<64>, ldsx)) != KF_OK) return rc;
+            attn_fwd_f32_mfma_kernel<64><<<gridx, 256, ldsx, st>>>(a);
+        }
         KF_LAUNCH_CHECK();
         return KF_OK;
     }

@@ -233,3 +233,20 @@ def test_scaled_entry_points_equal_the_default_scale():
     H.device_sync()
     want, _ = O.attn_fwd(qf * np.float32(0.5), kf_, vf)
     assert_close(o3.to_numpy(qf.shape, np.float32), want, what="explicit scale")
+
+
+@pytest.mark.parametrize("B,Hh,Sq,Skv,D", [(1, 2, 128, 128, 128), (2, 3, 96, 160, 64), (1, 1, 512, 512, 128), (1, 2, 32, 256, 64), (1, 1, 288, 64, 128)])
+def test_f32_mfma_forward_vs_oracle(B, Hh, Sq, Skv, D):
+    """The reference's own fast path (f32, D in {64, 128}) on the exact-f32 MFMA: reference tolerance 1e-3 on U(-10, 10)
+    inputs (test_nn.py:11-33), and 2e-5 on U(-1, 1) where no logit saturates."""
+    rng = np.random.default_rng(Sq * 7 + Skv + D)
+    for lo, hi, tol in ((-10, 10, 1e-3), (-1, 1, 2e-5)):
+        q, k, v = (rng.uniform(lo, hi, s).astype(np.float32) for s in ((B, Hh, Sq, D), (B, Hh, Skv, D), (B, Hh, Skv, D)))
+        H.profile_reset()
+        H.profile_enable(True)
+        o, lse = fwd(H.F32, q, k, v)
+        H.profile_enable(False)
+        assert "attn_fwd_f32_mfma" in H.profile_results()
+        o_ref, lse_ref = O.attn_fwd(q, k, v)
+        assert_close(o, o_ref, rtol=tol, atol=tol, what=f"f32 mfma fwd {lo}")
+        assert_close(lse, lse_ref, rtol=1e-5, atol=1e-3 if hi == 10 else 1e-4, what="lse")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Timing of the non-MFMA attention paths (f32 — the reference's dtype — and 16-bit shapes the MFMA kernels do not
-cover) through the C ABI; HIP-event times from the library's profiling mode."""
+"""Timing of the f32 attention paths (the reference's dtype: exact-f32 MFMA forward, generic backward) and of 16-bit shapes
+the bf16 MFMA kernels do not cover, through the C ABI; HIP-event times from the library's profiling mode."""
 import argparse
 import sys
 from pathlib import Path
