@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KF_ABI_VERSION 1
+#define KF_ABI_VERSION 2 /* 2: + kf_reduce_moments*, KF_EW_*_SCALAR, kf_graph_*, kf_attn_*_scaled (additive) */
 
 /* ---- status ------------------------------------------------------------------------------ */
 enum {
