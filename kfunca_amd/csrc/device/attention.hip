@@ -49,6 +49,7 @@ struct AttnArgs {
     int64_t B, H, Sq, Skv, D;
     float scale;
     int xcd_map; // 1: nbh % 8 == 0, heads are pinned to XCDs (a_block_map)
+    float defer; // forward: adopt a new running maximum only beyond this many exponent units (kDeferMax; -inf: always)
 };
 
 // XCD-aware block order for the v2 kernels (1-D grid of nx * nbh blocks). Hardware deals block ids round-robin
@@ -242,10 +243,11 @@ __device__ __forceinline__ void f_stage(const char *kg, const char *vg, char *bu
 // with vector work. Costs one more ring slot (V of tile t-1 must survive interval t).
 // ------------------------------------------------------------------------------------------
 constexpr int SRING = 4;
+constexpr float kDeferMax = 8.0f;
 
 template <bool BF, bool MASK>
 __device__ __forceinline__ void s_qk_sm(const char *buf, const typename AFrag<BF>::type (&qf)[8], const int (&ko)[8], f32x16 (&o)[4],
-                                        typename AFrag<BF>::type (&pf)[4], float &m_i, float &l_i, float c, int64_t kv0, int64_t m, int hl) {
+                                        typename AFrag<BF>::type (&pf)[4], float &m_i, float &l_i, float c, int64_t kv0, int64_t m, int hl, float defer) {
     using frag_t = typename AFrag<BF>::type;
     f32x16 s[2];
 #pragma unroll
@@ -269,9 +271,20 @@ __device__ __forceinline__ void s_qk_sm(const char *buf, const typename AFrag<BF
             mx = fmaxf(mx, s[sub][e]);
         }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_i, mx);
-    const float mc = m_new * c;
-    const float alpha = __builtin_amdgcn_exp2f(m_i * c - mc);
+    // deferred running maximum: m_i (raw score units) is the maximum IN USE; a larger one is adopted - and O, l rescaled: 66
+    // multiplies - only when some query of the wave exceeds it by more than kDeferMax exponent units. Until then p can reach
+    // 2^kDeferMax, which neither the 16-bit P nor the f32 row sum minds; after the first few tiles the branch is rarely taken.
+    if (__builtin_amdgcn_ballot_w64((mx - m_i) * c > defer) != 0) {
+        const float m_new = fmaxf(m_i, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * c);
+        l_i *= alpha;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+        m_i = m_new;
+    }
+    const float mc = m_i * c;
     float rs = 0.f;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -282,12 +295,7 @@ __device__ __forceinline__ void s_qk_sm(const char *buf, const typename AFrag<BF
             rs += p;
         }
     rs += __shfl_xor(rs, 32, 64);
-    l_i = l_i * alpha + rs;
-    m_i = m_new;
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
+    l_i += rs;
     pf[0] = a_pack<BF>(s[0], 0);
     pf[1] = a_pack<BF>(s[0], 1);
     pf[2] = a_pack<BF>(s[1], 0);
@@ -390,8 +398,8 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
         if (late && pending) s_pv<BF>(smem + ((t + SRING - 1) % SRING) * FBUF + FTILE, vo, pf, o);
         pending = false;
         if (!skip) {
-            if (diag) s_qk_sm<BF, true>(cur, qf, ko, o, pf, m_i, l_i, c, kv0, m, hl);
-            else s_qk_sm<BF, false>(cur, qf, ko, o, pf, m_i, l_i, c, kv0, m, hl);
+            if (diag) s_qk_sm<BF, true>(cur, qf, ko, o, pf, m_i, l_i, c, kv0, m, hl, a.defer);
+            else s_qk_sm<BF, false>(cur, qf, ko, o, pf, m_i, l_i, c, kv0, m, hl, a.defer);
             if (late) pending = true;
             else s_pv<BF>(cur + FTILE, vo, pf, o);
         }
@@ -1516,6 +1524,7 @@ extern "C" int kf_attn_fwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, i
     KF_REQUIRE(scale > 0.f && scale < INFINITY, KF_ERR_INVALID, "attention: the softmax scale must be positive and finite");
     a.scale = scale;
     a.xcd_map = ((B * H) % 8 == 0) && !getenv("KF_ATTN_NO_XCD");
+    a.defer = getenv("KF_ATTN_NO_DEFER") ? -INFINITY : kDeferMax; // A/B switch: rescale O at every tile
     if (mfma_ok(dtype, Sq, Skv, D)) {
         const size_t lds3 = SRING * FBUF;
         dim3 grid3((unsigned)(((Sq + FQ - 1) / FQ) * B * H));
