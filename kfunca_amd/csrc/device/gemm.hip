@@ -478,9 +478,9 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_h256_kernel(const GemmArgs g) {
     _Pragma("unroll") for (int t = 0; t < NTL; ++t) {                                                 \
         if constexpr (TR) {                                                                           \
             const unsigned x = (unsigned)((lbT ^ ((EC) + t * 32)) + pbT) + smem_u + (unsigned)((HB) - smem); \
-            if constexpr (PART == 0 || PART == 2) FR[t][0] = g_tr_frag<BF, 0>(x);                     \
-            if constexpr (PART == 1 || PART == 2) FR[t][1] = g_tr_frag<BF, 8192 + 128>(x);            \
-        } else if constexpr (PART == 0 || PART == 2) {                                                \
+            if constexpr ((PART) == 0 || (PART) == 2) FR[t][0] = g_tr_frag<BF, 0>(x);                     \
+            if constexpr ((PART) == 1 || (PART) == 2) FR[t][1] = g_tr_frag<BF, 8192 + 128>(x);            \
+        } else if constexpr ((PART) == 0 || (PART) == 2) {                                                \
             FR[t][0] = *(const frag_t *)((HB) + t * 2048 + offk0);                                    \
             FR[t][1] = *(const frag_t *)((HB) + t * 2048 + offk1);                                    \
         }                                                                                             \
@@ -488,6 +488,7 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_h256_kernel(const GemmArgs g) {
 // the asm-issued transposed reads are invisible to the compiler's wait insertion: counted lgkmcnt waits by hand,
 // placed AFTER the barrier (the reads' latency overlaps the barrier wait, as the compiler arranges for ds_read_b128)
 #define G_LGKM(N)                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                   \
     asm volatile("s_waitcnt lgkmcnt(%c0)" ::"n"(N) : "memory");          \
     __builtin_amdgcn_sched_barrier(0);
 #define G_MFMA(KS, ACC, NOFF, MOFF, BF_, AF_)                                                           \
@@ -495,19 +496,21 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_h256_kernel(const GemmArgs g) {
         _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                 \
             ACC[NOFF + n][MOFF + m] = g_mfma16<BF>(BF_[n][KS], AF_[m][KS], ACC[NOFF + n][MOFF + m]);
     constexpr int NLA = 8; // k-step-1 read instructions of a transposed A half-tile (4 tiles x lo, hi)
+    constexpr bool SPLITB = TRA && TRB; // both operands transposed: B's k-step 1 moves into the matrix segment too
 
     for (int kt = 0; kt < nt; ++kt) {
         const char *buf = smem + (kt & 1) * G_TILE;
         const char *ha0 = buf + abase, *hb0 = buf + G_HALF + bbase, *ha1 = buf + 2 * G_HALF + abase, *hb1 = buf + 3 * G_HALF + bbase;
         // ---------------- phase 0: (A0, B0) ----------------
-        G_LOAD(b0, 2, hb0, TRB, ecB, 2)
+        G_LOAD(b0, 2, hb0, TRB, ecB, (SPLITB ? 0 : 2))
         G_LOAD(a0, 4, ha0, TRA, ecA, 0)
         stage(2, kt + 1);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         G_SEG_END()
         if constexpr (TRA) {
+            if constexpr (SPLITB) { G_LOAD(b0, 2, hb0, TRB, ecB, 1) }
             G_LOAD(a0, 4, ha0, TRA, ecA, 1)
-            G_LGKM(NLA)
+            G_LGKM(NLA + (SPLITB ? 4 : 0))
         } else if constexpr (TRB) {
             G_LGKM(0)
         }
@@ -533,13 +536,19 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_h256_kernel(const GemmArgs g) {
         __builtin_amdgcn_s_setprio(0);
         G_SEG_END()
         // ---------------- phase 2: (A1, B1) ----------------
-        G_LOAD(b1, 2, hb1, TRB, ecB, 2)
+        G_LOAD(b1, 2, hb1, TRB, ecB, (SPLITB ? 0 : 2))
         stage(0, kt + 2);
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         G_SEG_END()
-        if constexpr (TRB) { G_LGKM(0) }
+        if constexpr (SPLITB) {
+            G_LOAD(b1, 2, hb1, TRB, ecB, 1)
+            G_LGKM(4)
+        } else if constexpr (TRB) {
+            G_LGKM(0)
+        }
         __builtin_amdgcn_s_setprio(1);
         G_MFMA(0, acc, 2, 4, b1, a1)
+        if constexpr (SPLITB) { G_LGKM(0) }
         G_MFMA(1, acc, 2, 4, b1, a1)
         __builtin_amdgcn_s_setprio(0);
         G_SEG_END()
