@@ -29,6 +29,7 @@ struct GemmArgs {
     int64_t M, N, K, lda, ldb, ldc;
     float alpha, beta;
     int epilogue;
+    int group_m; // tile rows per group of the grouped tile order (0: row-major)
 };
 
 // XCD-aware remap: consecutive logical tile ids land on the same XCD (its own 4 MiB L2) so
@@ -37,6 +38,21 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {
     const uint32_t nx = 8, xcd = bid % nx, q = nwg / nx, r = nwg % nx;
     const uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + bid / nx;
+}
+
+// Grouped tile order: logical ids walk groups of `gm` tile rows column by column, so the q consecutive ids one XCD
+// owns (xcd_remap) cover a gm x (q / gm) rectangle of C: gm A panels + q / gm B panels through that XCD's L2 instead of
+// one A panel + a whole row of B panels.
+__device__ __forceinline__ void grouped_tile(uint32_t id, uint32_t tiles_m, uint32_t tiles_n, uint32_t gm, uint32_t &tm, uint32_t &tn) {
+    if (gm == 0) {
+        tm = id / tiles_n;
+        tn = id % tiles_n;
+        return;
+    }
+    const uint32_t per = gm * tiles_n, grp = id / per, first = grp * gm;
+    const uint32_t rows = min(gm, tiles_m - first), in = id - grp * per;
+    tm = first + in % rows;
+    tn = in / rows;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -385,8 +401,9 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_h256_kernel(const GemmArgs g) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int wr = __builtin_amdgcn_readfirstlane(wid) >> 2, wc = __builtin_amdgcn_readfirstlane(wid) & 3;
     const uint32_t tiles_n = (uint32_t)(g.N / G_BN);
-    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int64_t m0 = (int64_t)(tile / tiles_n) * G_BM, n0 = (int64_t)(tile % tiles_n) * G_BN;
+    uint32_t tm, tn;
+    grouped_tile(xcd_remap(blockIdx.x, gridDim.x), (uint32_t)(g.M / G_BM), tiles_n, (uint32_t)g.group_m, tm, tn);
+    const int64_t m0 = (int64_t)tm * G_BM, n0 = (int64_t)tn * G_BN;
     const int nt = (int)(g.K / G_BK);
 
     // ---- LDS-DMA source pointers. K-contiguous operand: wave w moves rows (2w + i) * 8 .. + 7 (i = 0, 1) of every
@@ -708,7 +725,11 @@ extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N
     KF_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, KF_ERR_INVALID, "kf_gemm: leading dimension too small");
     KF_REQUIRE(epilogue == KF_EPI_NONE || (epilogue == KF_EPI_BIAS_ROW && bias), KF_ERR_INVALID, "kf_gemm: bad epilogue");
     hipStream_t st = as_stream(stream);
-    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, beta, epilogue};
+    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, beta, epilogue, 0};
+    {
+        const char *e = getenv("KF_GEMM_GROUP_M");
+        g.group_m = e ? atoi(e) : 4;
+    }
 
     const bool al16 = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0);
     if (dtype == KF_F32 && M % F_BM == 0 && N % F_BN == 0 && K % F_BK == 0 && K > 0 && al16 && lda % 4 == 0 && ldb % 4 == 0) {

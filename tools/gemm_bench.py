@@ -40,7 +40,8 @@ def main():
             for e in [x for x in os.environ if x.startswith("KF_GEMM")]:
                 del os.environ[e]
             if v != "default":
-                os.environ[v] = "1"
+                name, _, val = v.partition("=")
+                os.environ[name] = val or "1"
             for tag, ta, tb, X, Y in (("NN fwd", 0, 0, A, W), ("NT dA", 0, 1, G, W), ("TN dB", 1, 0, A, G)):
                 H.profile_reset()
                 H.profile_enable(True)
