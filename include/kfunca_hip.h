@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KF_ABI_VERSION 2 /* 2: + kf_reduce_moments*, KF_EW_*_SCALAR, kf_graph_*, kf_attn_*_scaled (additive) */
+#define KF_ABI_VERSION 3 /* 2: + kf_reduce_moments*, KF_EW_*_SCALAR, kf_graph_*, kf_attn_*_scaled; 3: + kf_sort* (all additive) */
 
 /* ---- status ------------------------------------------------------------------------------ */
 enum {
@@ -201,6 +201,21 @@ int kf_reduce_moments(int mode, const kf_iter_desc *desc, double correction, dou
  */
 int kf_index_put(const kf_iter_desc *desc, int nidx, const int64_t *sizes, const int64_t *strides_bytes,
                  void *stream);
+
+/* ---- sort: replaces sort_ops_kernel.h (segmented_sort_pairs, sort_ops_kernel.cu:402-505) ----- */
+/*
+ * Stable sort of nseg contiguous segments of n keys each (what sort_stable_kernel, sort_ops_kernel.cu:556-618, hands to
+ * segmented_sort_pairs<scalar_t, int64_t>(keys_in, keys_out, nullptr, values_out, nsegments, nsort, descending)):
+ * keys_out[s][j] = the j-th key of segment s in ascending (descending != 0: descending) order, pos_out[s][j] = its
+ * int64 position inside the input segment; equal keys keep their input order in both directions. Order is that of the
+ * reference's key transforms (sorting_common.h:23-260): integers by value; floats by value with -0.0 before +0.0 and
+ * NaNs by bit pattern (positive NaNs last, negative NaNs first, ascending). Every dtype except KF_BOOL; n <= INT_MAX.
+ * keys_in and keys_out must be different buffers. Segments of at most 8192 keys are sorted in LDS and need no
+ * workspace; longer ones take kf_sort_workspace_bytes() of caller scratch (16-byte aligned, need not be zeroed).
+ */
+size_t kf_sort_workspace_bytes(int dtype, int64_t nseg, int64_t n);
+int kf_sort(int dtype, const void *keys_in, void *keys_out, int64_t *pos_out, int64_t nseg, int64_t n, int descending,
+            void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- GEMM: replaces gemm_kernel.h:5 (+ NT/TN forms the backward needs) --------------------- */
 enum {

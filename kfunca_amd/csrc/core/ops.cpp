@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <limits>
 
 #include "device_api.h"
 #include "tensor_iterator.h"
@@ -64,11 +65,6 @@ void run_moments(TensorIterator &iter, int mode, double correction, double eps) 
     DataPtr scratch;
     if (need) scratch = DeviceAllocator::GetInstance()->allocate(need, device);
     DEV_CALL(kf_reduce_moments(mode, &d, correction, eps, scratch.get(), need, dev::stream(device)));
-}
-
-[[noreturn]] void out_of_scope(const char *what) {
-    CHECK_FAIL(false, what, " is outside the tensor-kernel hot path this build covers (SURVEY.md §8f); not implemented");
-    std::abort();
 }
 
 } // namespace
@@ -219,8 +215,79 @@ std::tuple<Tensor, Tensor> norm_stat(const Tensor &self, int64_t dim) {
     run_moments(iter, KF_MOM_INVSTD, 0.0, /*eps=*/1e-12);
     return std::make_tuple(save_mean, save_invstd);
 }
-std::tuple<Tensor, Tensor> sort(const Tensor &, int64_t, bool) { out_of_scope("sort"); }
-std::tuple<Tensor, Tensor> topk(const Tensor &, int64_t, int64_t, bool) { out_of_scope("topk"); }
+// ---- sort / topk (sort_ops.cpp:6-19 + the host half of sort_ops_kernel.cu:507-632) ---------------------------
+namespace {
+
+// Dense strides over self's sizes that keep the memory order of the other dims and make `dim` the fastest
+// (infer_dense_strides_dim_last, sort_ops_kernel.cu:523-554).
+std::vector<int64_t> dense_strides_dim_last(const Tensor &self, int64_t dim) {
+    const int nd = self.dim();
+    std::vector<int> order;
+    for (int i = 0; i < nd; ++i)
+        if (i != dim) order.push_back(i);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return self.stride(x) > self.stride(y); });
+    order.push_back((int)dim);
+    std::vector<int64_t> strides(nd);
+    int64_t run = 1;
+    for (int i = nd - 1; i >= 0; --i) {
+        strides[order[i]] = run;
+        run *= self.shape(order[i]);
+    }
+    return strides;
+}
+
+} // namespace
+
+std::tuple<Tensor, Tensor> sort(const Tensor &self, int64_t dim, bool descending) {
+    CHECK_FAIL(self.defined());
+    CHECK_FAIL(self.dim() > 0 && dim >= -self.dim() && dim < self.dim(), "dim ", dim, " out of range");
+    dim = maybe_wrap_dim((int)dim, self.dim());
+    const int64_t numel = self.numel(), nsort = self.shape((int)dim);
+    CHECK_FAIL(nsort <= std::numeric_limits<int>::max(), "The dimension being sorted can not have more than INT_MAX elements.");
+    CHECK_FAIL(self.dtype() != ScalarType::Bool, "Sort currently does not support bool dtypes.");
+
+    // keys with the sorted dim contiguous: self itself, or a dense copy with that dim last (sort_ops_kernel.cu:572-581)
+    const bool direct = self.is_contiguous() && self.stride((int)dim) == 1;
+    Tensor keys = self;
+    if (!direct) {
+        keys = empty_strided(self.sizes(), dense_strides_dim_last(self, dim), self.dtype(), self.device());
+        keys.copy_(self);
+    }
+    Tensor values = empty_strided(keys.sizes(), keys.strides(), keys.dtype(), keys.device());
+    Tensor indices = empty_strided(keys.sizes(), keys.strides(), ScalarType::Long, keys.device());
+    if (numel > 0) {
+        const int64_t nseg = numel / nsort;
+        const int dt = code(self.dtype());
+        const size_t need = kf_sort_workspace_bytes(dt, nseg, nsort);
+        DataPtr scratch;
+        if (need) scratch = DeviceAllocator::GetInstance()->allocate(need, self.device());
+        DEV_CALL(kf_sort(dt, keys.data_ptr(), values.data_ptr(), static_cast<int64_t *>(indices.data_ptr()), nseg, nsort, descending,
+                         scratch.get(), need, dev::stream(self.device())));
+    }
+    if (direct) return std::make_tuple(values, indices);
+    Tensor values_out = empty_like(self); // back to self's layout (sort_ops_kernel.cu:609-614)
+    Tensor indices_out = empty(self.sizes(), ScalarType::Long, self.device());
+    values_out.copy_(values);
+    indices_out.copy_(indices);
+    return std::make_tuple(values_out, indices_out);
+}
+
+// topk_with_sort (sort_ops_kernel.cu:620-632): the first k entries of the stable sort along dim
+std::tuple<Tensor, Tensor> topk(const Tensor &self, int64_t k, int64_t dim, bool largest) {
+    CHECK_FAIL(self.defined());
+    CHECK_FAIL(self.dim() > 0 && dim >= -self.dim() && dim < self.dim(), "dim ", dim, " out of range");
+    dim = maybe_wrap_dim((int)dim, self.dim());
+    CHECK_FAIL(k >= 0 && k <= self.shape((int)dim), "k ", k, " out of range for a dimension of ", self.shape((int)dim));
+    Tensor sorted_values, sorted_indices;
+    std::tie(sorted_values, sorted_indices) = sort(self, dim, largest);
+    auto sizes = self.sizes();
+    sizes[dim] = k;
+    Tensor values = empty(sizes, self.dtype(), self.device());
+    Tensor indices = empty(sizes, ScalarType::Long, self.device());
+    values.copy_(sorted_values.narrow(dim, 0, k));
+    indices.copy_(sorted_indices.narrow(dim, 0, k));
+    return std::make_tuple(values, indices);
+}
 
 // ---- GEMM (gemm_ops.cpp:6-16 + the checks of gemm_kernel.cu:8-25) -----------------------------------------
 namespace {

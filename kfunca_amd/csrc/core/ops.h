@@ -50,7 +50,7 @@ Tensor causal_attention(const Tensor &q, const Tensor &k, const Tensor &v);
 Tensor &index_put_(Tensor &self, const std::vector<Tensor> &indices, const Tensor &values);
 Tensor concat(const std::vector<Tensor> tensors, int64_t dim);
 std::vector<Tensor> tensor_split(const Tensor &self, std::vector<int64_t> indices, int64_t dim);
-// norm_ops.h, sort_ops.h: outside the hot-path scope — raise
+// norm_ops.h, sort_ops.h
 std::tuple<Tensor, Tensor> norm_stat(const Tensor &self, int64_t dim);
 std::tuple<Tensor, Tensor> sort(const Tensor &self, int64_t dim, bool descending);
 std::tuple<Tensor, Tensor> topk(const Tensor &self, int64_t k, int64_t dim, bool largest);

@@ -39,7 +39,7 @@ EXPORTS = [
     "kf_event_elapsed_ms", "kf_graph_begin_capture", "kf_graph_end_capture", "kf_graph_launch", "kf_graph_destroy", "kf_profile_enable", "kf_profile_reset", "kf_profile_count", "kf_profile_get",
     "kf_device_props_get", "kf_elementwise", "kf_reduce_workspace_bytes", "kf_reduce",
     "kf_reduce_moments_workspace_bytes", "kf_reduce_moments",
-    "kf_index_put", "kf_gemm_workspace_bytes", "kf_gemm", "kf_attn_fwd", "kf_attn_fwd_scaled", "kf_attn_bwd_workspace_bytes",
+    "kf_index_put", "kf_sort_workspace_bytes", "kf_sort", "kf_gemm_workspace_bytes", "kf_gemm", "kf_attn_fwd", "kf_attn_fwd_scaled", "kf_attn_bwd_workspace_bytes",
     "kf_attn_bwd", "kf_attn_bwd_scaled", "kf_comm_unique_id", "kf_comm_init", "kf_comm_destroy", "kf_allreduce_sum",
 ]
 
@@ -102,6 +102,9 @@ def lib():
         _lib.kf_reduce_moments_workspace_bytes.argtypes = [C.POINTER(IterDesc), C.POINTER(sz)]
         _lib.kf_reduce_moments.argtypes = [C.c_int, C.POINTER(IterDesc), C.c_double, C.c_double, vp, sz, vp]
         _lib.kf_index_put.argtypes = [C.POINTER(IterDesc), C.c_int, C.POINTER(i64), C.POINTER(i64), vp]
+        _lib.kf_sort_workspace_bytes.argtypes = [C.c_int, i64, i64]
+        _lib.kf_sort_workspace_bytes.restype = sz
+        _lib.kf_sort.argtypes = [C.c_int, vp, vp, vp, i64, i64, C.c_int, vp, sz, vp]
         _lib.kf_gemm_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, i64, i64, i64, C.POINTER(sz)]
         _lib.kf_gemm.argtypes = [C.c_int, C.c_int, C.c_int, i64, i64, i64, C.c_float, vp, i64, vp, i64, C.c_float,
                                  vp, i64, C.c_int, vp, vp, sz, vp]
@@ -375,6 +378,23 @@ def index_put(desc: IterDesc, sizes, strides_bytes, stream=None):
     a = (C.c_int64 * n)(*sizes)
     b = (C.c_int64 * n)(*strides_bytes)
     check(lib().kf_index_put(C.byref(desc), n, a, b, stream))
+
+
+def sort_segments(keys: np.ndarray, descending=False, code=None, stream=None):
+    """keys [nseg, n] (host) -> (sorted keys, int64 positions) through kf_sort; code overrides the dtype (BF16 as uint16)."""
+    keys = np.ascontiguousarray(keys)
+    nseg, n = keys.shape
+    code = NP2CODE[keys.dtype] if code is None else code
+    if keys.size == 0:
+        check(lib().kf_sort(code, None, None, None, nseg, n, int(descending), None, 0, stream))
+        return keys.copy(), np.zeros(keys.shape, np.int64)
+    src = DevBuf.from_numpy(keys)
+    dst, pos = DevBuf(keys.nbytes), DevBuf(keys.size * 8)
+    need = lib().kf_sort_workspace_bytes(code, nseg, n)
+    ws = DevBuf(need) if need else None
+    check(lib().kf_sort(code, src.ptr, dst.ptr, pos.ptr, nseg, n, int(descending), ws.ptr if ws else None, need, stream))
+    device_sync()
+    return dst.to_numpy(keys.shape, keys.dtype), pos.to_numpy(keys.shape, np.int64)
 
 
 def gemm_workspace_bytes(dtype, trans_a, trans_b, M, N, K) -> int:

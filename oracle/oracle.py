@@ -219,3 +219,43 @@ def attn_bwd(q, k, v, d_o, code=None):
 
 def num_threads() -> int:
     return lib().orc_num_threads()
+
+
+# ---- sort (numpy restatement: byte / integer work) ------------------------------------------------------
+_KEY_KIND = {U8: "u", I8: "i", I16: "i", I32: "i", I64: "i", F16: "f", BF16: "f", F32: "f", F64: "f"}
+
+
+def sort_key(x: np.ndarray, code=None) -> np.ndarray:
+    """The reference's order-preserving unsigned key (KeyTraits<T>::convert, src/device/utils/sorting_common.h:23-260):
+    unsigned: identity; signed: + 2^(bits-1); floating (any width): x ^ (sign ? all ones : sign bit)."""
+    c = code_of(x, code)
+    if c not in _KEY_KIND:
+        raise ValueError("Sort currently does not support bool dtypes.")  # sort_ops_kernel.cu:569-570
+    w = x.dtype.itemsize
+    ut = {1: np.uint8, 2: np.uint16, 4: np.uint32, 8: np.uint64}[w]
+    u = np.ascontiguousarray(x).view(ut)
+    sign = ut(1 << (8 * w - 1))
+    if _KEY_KIND[c] == "u":
+        return u
+    if _KEY_KIND[c] == "i":
+        return u ^ sign
+    return u ^ np.where(u & sign, ut(~ut(0)), sign).astype(ut)
+
+
+def sort_stable(x: np.ndarray, dim: int, descending: bool, code=None):
+    """sort_stable_kernel (src/device/sort_ops_kernel.cu:556-618): least-significant-digit radix sort of the converted keys
+    with int64 positions as values (sorting_radix_sort.h); descending walks the digit bins in reverse, i.e. an ascending
+    stable sort of the complemented key. Returns (values, indices) shaped like x."""
+    key = sort_key(x, code)
+    if descending:
+        key = ~key
+    idx = np.argsort(key, axis=dim, kind="stable").astype(np.int64)
+    return np.take_along_axis(x, idx, axis=dim), idx
+
+
+def topk(x: np.ndarray, k: int, dim: int, largest: bool, code=None):
+    """topk_with_sort (sort_ops_kernel.cu:620-632): the first k entries of the stable sort along dim."""
+    v, i = sort_stable(x, dim, largest, code)
+    sl = [slice(None)] * x.ndim
+    sl[dim] = slice(0, k)
+    return v[tuple(sl)].copy(), i[tuple(sl)].copy()

@@ -219,9 +219,61 @@ def attention():
     np.savez_compressed(OUT / "attention.npz", **d)
 
 
+def sort():
+    d = {}
+    # test_tensor.py:169-192 test_sort_small_slice: torch.sort(arr, dim, descending, stable=True), U(-1000, 1000) cast to
+    # f32 / f64 / i32 (the i32 cast makes many duplicates: the stability cases). Small shapes stored, larger ones by digest.
+    shapes = [[2, 3, 4], [23, 11, 23], [11, 23, 64], [13, 65, 1049], [5, 11, 22223]]
+    n = 0
+    for dt in (np.float32, np.float64, np.int32):
+        for desc in (False, True):
+            for dim in (2, 1, 0):
+                for shape in shapes:
+                    seed = 300 + n
+                    arr = np.random.default_rng(seed).uniform(-1000, 1000, size=shape).astype(dt)
+                    res, ind = torch.sort(torch.from_numpy(arr), dim=dim, descending=desc, stable=True)
+                    res, ind = res.numpy(), ind.numpy()
+                    tag = f"s{n}"
+                    d[tag + "_meta"] = np.array([seed, dim, int(desc)] + shape)
+                    d[tag + "_dtype"] = np.array(np.dtype(dt).str)
+                    d[tag + "_sha_in"] = sha(arr)
+                    if arr.size <= 6000:
+                        d[tag + "_res"], d[tag + "_ind"] = res, ind
+                    else:
+                        d[tag + "_sha_out"] = sha(res, ind)
+                    n += 1
+    d["n_sort"] = np.array([n])
+    # test_tensor.py:194-201 test_sort_large_slice: np.sort / np.argsort(kind='stable') of f32 (4, 1024000), axis 1
+    arr = np.random.default_rng(290).uniform(-1000, 1000, size=(4, 1024000)).astype(np.float32)
+    d["large_seed"], d["large_sha_in"] = np.array([290]), sha(arr)
+    d["large_sha_out"] = sha(np.sort(arr, axis=1), np.argsort(arr, axis=1, kind="stable").astype(np.int64))
+    # test_tensor.py:203-222 test_topk_small: torch.topk(arr, 8, dim, largest) VALUES (the test does not compare indices)
+    n = 0
+    for dt in (np.float32, np.float64, np.int32):
+        for largest in (False, True):
+            for dim in (2, 1, 0):
+                for shape in ([13, 65, 1049], [33, 22, 22223]):
+                    seed = 500 + n
+                    arr = np.random.default_rng(seed).uniform(-100000, 100000, size=shape).astype(dt)
+                    res, _ = torch.topk(torch.from_numpy(arr), 8, dim=dim, largest=largest)
+                    tag = f"t{n}"
+                    d[tag + "_meta"] = np.array([seed, dim, int(largest)] + shape)
+                    d[tag + "_dtype"] = np.array(np.dtype(dt).str)
+                    d[tag + "_sha_in"] = sha(arr)
+                    d[tag + "_sha_out"] = sha(res.numpy())
+                    n += 1
+    d["n_topk"] = np.array([n])
+    # test_tensor.py:224-231 test_topk_large: f32 (4, 1024000), k in {2049, 22223}, largest, values only
+    for i, k in enumerate((2049, 22223)):
+        arr = np.random.default_rng(291 + i).uniform(-10000, 10000, size=(4, 1024000)).astype(np.float32)
+        res, _ = torch.topk(torch.from_numpy(arr), k, dim=1, largest=True)
+        d[f"tl{i}_meta"], d[f"tl{i}_sha_in"], d[f"tl{i}_sha_out"] = np.array([291 + i, k]), sha(arr), sha(res.numpy())
+    np.savez_compressed(OUT / "sort.npz", **d)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    for f in (elementwise, shape_ops, reductions, moments, gemm, attention):
+    for f in (elementwise, shape_ops, reductions, moments, gemm, attention, sort):
         if len(sys.argv) > 1 and f.__name__ not in sys.argv[1:]:
             continue
         f()

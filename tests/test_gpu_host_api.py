@@ -338,11 +338,63 @@ def test_allocator_reuse_and_scope():
     assert st["driver_allocs"] <= base["driver_allocs"] + 1
     z = kfunca.zeros([7, 5], kfunca.int, 0)
     assert not z.numpy().any()
-    for call in (lambda: z.sort(0, False), lambda: z.topk(1, 0, True)):
-        with pytest.raises(RuntimeError, match="outside the tensor-kernel hot path"):
-            call()
+    with pytest.raises(RuntimeError, match="does not support bool"):  # sort_ops_kernel.cu:569-570
+        kfunca.zeros([4], kfunca.bool, 0).sort(0, False)
+    with pytest.raises(RuntimeError, match="out of range"):
+        z.topk(9, 0, True)
     for call in (lambda: z.norm_stat(0), lambda: z.mean_var(0, False)):  # floating dtypes only, as the reference's dispatch
         with pytest.raises(RuntimeError, match="Unsupported ScalarType"):
             call()
     assert "tensor(shape=[7,5]" in repr(z)
     assert z.item([1, 2]) == 0
+
+
+def test_sort_small_slice():  # test_tensor.py:169-192 (shapes, dims, dtypes, both directions; seeds fixed)
+    g = golden("sort")
+    from tests.helpers import sha
+    for n in range(int(g["n_sort"][0])):
+        meta = g[f"s{n}_meta"]
+        seed, dim, desc, shape = int(meta[0]), int(meta[1]), bool(meta[2]), [int(v) for v in meta[3:]]
+        arr = np.random.default_rng(seed).uniform(-1000, 1000, size=shape).astype(np.dtype(str(g[f"s{n}_dtype"])))
+        res, ind = kfunca.from_numpy(arr, 0).sort(dim, desc)
+        assert res.sizes() == shape and ind.sizes() == shape and ind.dtype() == kfunca.long
+        res, ind = res.numpy(), ind.numpy()
+        if f"s{n}_res" in g:
+            assert np.array_equal(res, g[f"s{n}_res"]) and np.array_equal(ind, g[f"s{n}_ind"]), (n, shape, dim, desc)
+        else:
+            assert np.array_equal(sha(res, ind), g[f"s{n}_sha_out"]), (n, shape, dim, desc)
+
+
+def test_sort_views_and_negative_dim():
+    rng = np.random.default_rng(801)
+    arr = rng.integers(-50, 50, size=(6, 40, 9)).astype(np.int32)
+    t = kfunca.from_numpy(arr, 0).permute(2, 0, 1)  # non-contiguous input: the dense dim-last copy path
+    ref = arr.transpose(2, 0, 1)
+    for dim in (-1, 0, 1):
+        for desc in (False, True):
+            v, i = t.sort(dim, desc)
+            wv, wi = O.sort_stable(np.ascontiguousarray(ref), dim % 3, desc)
+            assert np.array_equal(v.numpy(), wv) and np.array_equal(i.numpy(), wi)
+    e = kfunca.empty([3, 0, 5], kfunca.float, 0)
+    v, i = e.sort(1, False)
+    assert v.sizes() == [3, 0, 5] and i.sizes() == [3, 0, 5]
+
+
+def test_topk_small_and_large():  # test_tensor.py:203-231: values of torch.topk (the reference does not compare indices)
+    g = golden("sort")
+    from tests.helpers import sha
+    for n in range(int(g["n_topk"][0])):
+        meta = g[f"t{n}_meta"]
+        seed, dim, largest, shape = int(meta[0]), int(meta[1]), bool(meta[2]), [int(v) for v in meta[3:]]
+        arr = np.random.default_rng(seed).uniform(-100000, 100000, size=shape).astype(np.dtype(str(g[f"t{n}_dtype"])))
+        res, ind = kfunca.from_numpy(arr, 0).topk(8, dim, largest)
+        want = list(shape)
+        want[dim] = 8
+        assert res.sizes() == want and ind.sizes() == want
+        assert np.array_equal(sha(res.numpy()), g[f"t{n}_sha_out"]), (n, shape, dim, largest)
+        assert np.array_equal(np.take_along_axis(arr, ind.numpy(), axis=dim), res.numpy())
+    for i in range(2):
+        seed, k = (int(v) for v in g[f"tl{i}_meta"])
+        arr = np.random.default_rng(seed).uniform(-10000, 10000, size=(4, 1024000)).astype(np.float32)
+        res, ind = kfunca.from_numpy(arr, 0).topk(k, 1, True)
+        assert np.array_equal(sha(res.numpy()), g[f"tl{i}_sha_out"])

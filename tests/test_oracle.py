@@ -188,3 +188,49 @@ def test_attention_backward():
         dq, dk, dv = O.attn_bwd(q, k, v, go)
         for n, got in (("dq", dq), ("dk", dk), ("dv", dv)):
             assert_close(got, g[f"bwd{i}_{n}"], rtol=1e-4, atol=1e-5, what=f"bwd case {i} {n}")
+
+
+# ---- sort / topk: the oracle against the reference tests' torch.sort(stable=True) / np.argsort / torch.topk -------
+def _sort_cases(g, prefix, count_key):
+    for n in range(int(g[count_key][0])):
+        meta = g[f"{prefix}{n}_meta"]
+        seed, dim, flag, shape = int(meta[0]), int(meta[1]), bool(meta[2]), [int(v) for v in meta[3:]]
+        yield n, seed, dim, flag, shape, np.dtype(str(g[f"{prefix}{n}_dtype"]))
+
+
+def test_sort_oracle_matches_reference_test_expressions():
+    from tests.helpers import sha
+    g = golden("sort")
+    for n, seed, dim, desc, shape, dt in _sort_cases(g, "s", "n_sort"):
+        arr = np.random.default_rng(seed).uniform(-1000, 1000, size=shape).astype(dt)
+        assert np.array_equal(sha(arr), g[f"s{n}_sha_in"])
+        res, ind = O.sort_stable(arr, dim, desc)
+        assert ind.dtype == np.int64
+        if f"s{n}_res" in g:
+            assert np.array_equal(res, g[f"s{n}_res"]) and np.array_equal(ind, g[f"s{n}_ind"]), (n, shape, dim, desc, dt)
+        else:
+            assert np.array_equal(sha(res, ind), g[f"s{n}_sha_out"]), (n, shape, dim, desc, dt)
+
+
+def test_topk_oracle_matches_reference_test_expressions():
+    from tests.helpers import sha
+    g = golden("sort")
+    for n, seed, dim, largest, shape, dt in _sort_cases(g, "t", "n_topk"):
+        if np.prod(shape) > 2_000_000 and n % 3:  # keep the CPU suite short: every third of the 16 M-element cases
+            continue
+        arr = np.random.default_rng(seed).uniform(-100000, 100000, size=shape).astype(dt)
+        assert np.array_equal(sha(arr), g[f"t{n}_sha_in"])
+        res, _ = O.topk(arr, 8, dim, largest)
+        assert np.array_equal(sha(res), g[f"t{n}_sha_out"]), (n, shape, dim, largest, dt)
+
+
+def test_sort_key_order_special_values():
+    # KeyTraits order (sorting_common.h:40-55): -NaN < -inf < ... < -0.0 < +0.0 < ... < +inf < +NaN
+    x = np.array([np.nan, np.inf, 1.0, 0.0, -0.0, -1.0, -np.inf, -np.nan], dtype=np.float32)
+    x[7] = np.frombuffer(np.uint32(0xFFC00000).tobytes(), np.float32)[0]
+    v, i = O.sort_stable(x[None, :], 1, False)
+    assert i[0].tolist() == [7, 6, 5, 4, 3, 2, 1, 0]
+    v, i = O.sort_stable(x[None, :], 1, True)
+    assert i[0].tolist() == [0, 1, 2, 3, 4, 5, 6, 7]
+    with pytest.raises(ValueError):
+        O.sort_key(np.zeros(3, np.bool_))

@@ -123,6 +123,19 @@ def main():
     d = H.make_desc([sv], [view(a, (m,), H.F32), view(i0, (m,), H.I64), view(i1, (m,), H.I64)])
     ms, k = timed("index_put", lambda: H.index_put(d, [65536, 4096], [4096 * 4, 4]), args.rounds)
     record("index_put_ 16Mi x f32 (2 int64 indices)", ms, m * (16 + 8), k)
+    # stable sort with int64 positions: algorithmic bytes = keys in + keys out + 8-byte positions out (16 B per f32 key);
+    # the radix path really moves ~4 passes x (2 key reads + key write + position read + write)
+    keys = rng.standard_normal(1 << 26).astype(np.float32)
+    H.check(H.lib().kf_memcpy_h2d(a.ptr, keys.ctypes.data, keys.nbytes, None))
+    H.device_sync()
+    for (nseg, n, tag) in ((4, 1024000, "sort f32 [4, 1024000] (reference's large case)"), (1, 1 << 26, "sort f32 [1, 64Mi]"),
+                           (16384, 4096, "sort f32 [16384, 4096] (LDS bitonic)"), (1 << 20, 64, "sort f32 [1Mi, 64] (LDS bitonic)")):
+        need = H.lib().kf_sort_workspace_bytes(H.F32, nseg, n)
+        ws = H.DevBuf(max(need, 16))
+        ms, k = timed(tag, lambda: H.check(H.lib().kf_sort(H.F32, a.ptr, b.ptr, c.ptr, nseg, n, 0, ws.ptr, need, None)), args.rounds)
+        record(tag, ms, 16 * nseg * n, k)
+        out[tag]["Mkeys/s"] = nseg * n / (ms * 1e-3) / 1e6
+        print(f"{'':44s} {out[tag]['Mkeys/s']:.0f} Mkeys/s")
     if args.json:
         Path(args.json).write_text(json.dumps(out, indent=1))
 
