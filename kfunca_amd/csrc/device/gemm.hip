@@ -587,40 +587,69 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_h256_kernel(const GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue. acc[n][m][e] = C[m0 + wr*128 + m*16 + (lane & 15)][n0 + wc*64 + n*16 + (lane >> 4)*4 + e]:
-    // four consecutive columns per lane -> one 8-byte store per accumulator tile. A transposed-read operand splits
-    // its 256 rows / columns into halves 0..127 | 128..255 instead (whole 256-B lines per DMA row), so a wave's
-    // tiles are then {half*128 + wr*64 + ..} / {half*128 + wc*32 + ..}.
+    // four consecutive columns per lane. Column tiles n and n + 1 are neighbours, so one v_permlane16_swap per register
+    // pair (16-lane row 1 of tile n <-> row 0 of tile n + 1, row 3 <-> row 2) leaves every lane with EIGHT consecutive
+    // columns: one 16-byte store per lane, 64 contiguous bytes per C row per instruction instead of 32 (8-byte stores
+    // wrote 2.4x the algorithmic bytes beyond L2). A transposed-read operand splits its 256 rows / columns into halves
+    // 0..127 | 128..255 instead (whole 256-B lines per DMA row), so a wave's tiles are then
+    // {half*128 + wr*64 + ..} / {half*128 + wc*32 + ..}.
     uint16_t *C = (uint16_t *)g.C;
+    const bool wide = g.ldc % 8 == 0 && (uintptr_t)g.C % 16 == 0;
+    auto colbase = [&](int n) { return TRB ? (n >> 1) * 128 + wc * 32 + (n & 1) * 16 : wc * 64 + n * 16; };
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int64_t col = n0 + (TRB ? (n >> 1) * 128 + wc * 32 + (n & 1) * 16 : wc * 64 + n * 16) + fg * 4;
-        float bias[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int np = 0; np < 4; np += 2) {
+        float bias[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         if (g.epilogue == KF_EPI_BIAS_ROW) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const uint16_t bb = ((const uint16_t *)g.bias)[col + e];
-                bias[e] = BF ? bf16_to_f32(bf16_t{bb}) : f16_to_f32(f16_t{bb});
-            }
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint16_t bb = ((const uint16_t *)g.bias)[n0 + colbase(np + t) + fg * 4 + e];
+                    bias[t][e] = BF ? bf16_to_f32(bf16_t{bb}) : f16_to_f32(f16_t{bb});
+                }
         }
+        // after the exchange: lane rows 0 / 2 hold columns 0..7 / 8..15 of tile np, rows 1 / 3 those of tile np + 1
+        const int64_t col = n0 + ((fg & 1) ? colbase(np + 1) : colbase(np)) + (fg >> 1) * 8;
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const int64_t row = m0 + (TRA ? (m >> 2) * 128 + wr * 64 + (m & 3) * 16 : wr * 128 + m * 16) + fr;
             uint16_t *dst = C + row * g.ldc + col;
-            uint16_t h[4];
-            uint2 old = {0, 0};
-            if (g.beta != 0.f) old = *(const uint2 *)dst;
-            const uint16_t o16[4] = {(uint16_t)(old.x & 0xffff), (uint16_t)(old.x >> 16), (uint16_t)(old.y & 0xffff), (uint16_t)(old.y >> 16)};
+            float v[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float v = g.alpha * acc[n][m][e];
-                if (g.beta != 0.f) v += g.beta * (BF ? bf16_to_f32(bf16_t{o16[e]}) : f16_to_f32(f16_t{o16[e]}));
-                v += bias[e];
-                h[e] = BF ? f32_to_bf16(v).x : f32_to_f16(v).x;
+                const float lo = g.alpha * acc[np][m][e] + bias[0][e], hi = g.alpha * acc[np + 1][m][e] + bias[1][e];
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+                v[e] = __uint_as_float(sw[0]);
+                v[4 + e] = __uint_as_float(sw[1]);
             }
-            uint2 w;
-            w.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
-            w.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
-            *(uint2 *)dst = w;
+            if (g.beta != 0.f) {
+                uint32_t ow[4];
+                if (wide) {
+                    const uint4 old = *(const uint4 *)dst;
+                    ow[0] = old.x, ow[1] = old.y, ow[2] = old.z, ow[3] = old.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ow[e] = (uint32_t)dst[2 * e] | ((uint32_t)dst[2 * e + 1] << 16);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint16_t o = (uint16_t)(ow[e >> 1] >> ((e & 1) * 16));
+                    v[e] += g.beta * (BF ? bf16_to_f32(bf16_t{o}) : f16_to_f32(f16_t{o}));
+                }
+            }
+            uint32_t w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint16_t h0 = BF ? f32_to_bf16(v[2 * e]).x : f32_to_f16(v[2 * e]).x;
+                const uint16_t h1 = BF ? f32_to_bf16(v[2 * e + 1]).x : f32_to_f16(v[2 * e + 1]).x;
+                w[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+            }
+            if (wide) {
+                *(uint4 *)dst = uint4{w[0], w[1], w[2], w[3]};
+            } else { // C rows not 16-byte aligned
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[e] = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+            }
         }
     }
 }
@@ -743,7 +772,7 @@ extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N
         return KF_OK;
     }
     if ((dtype == KF_BF16 || dtype == KF_F16) && h_fast_ok(M, N, K) && al16 && lda % 8 == 0 && ldb % 8 == 0) {
-        if (h256_ok(M, N, K) && g.ldc % 4 == 0 && (uintptr_t)C % 8 == 0) { // every operand layout is consumed in place
+        if (h256_ok(M, N, K)) { // every operand layout is consumed in place
             KF_PROF(dtype == KF_BF16 ? "gemm_bf16_mfma" : "gemm_f16_mfma", st);
             return dtype == KF_BF16 ? launch_h256<true>(g, trans_a != 0, !trans_b, st) : launch_h256<false>(g, trans_a != 0, !trans_b, st);
         }

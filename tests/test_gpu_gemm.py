@@ -133,6 +133,42 @@ def test_16bit_vs_oracle(code, eps, M, N, K):
     assert (np.abs(got - want) <= 2 * eps * np.abs(want) + 2e-6 * mag + 2 * eps).all(), "epilogue"
 
 
+@pytest.mark.parametrize("code,eps", [(H.BF16, 2.0 ** -8), (H.F16, 2.0 ** -11)])
+def test_256_tile_kernel_layouts_epilogue_and_unaligned_c(code, eps):
+    """The 256-tile kernel only runs on grids of >= 160 tiles: 2560 x 4096 (K small keeps the oracle cheap). Every operand
+    layout, alpha / beta / row bias, and a C whose rows are not 16-byte aligned (the narrow-store epilogue)."""
+    rng = np.random.default_rng(77 + code)
+    M, N, K = 2560, 4096, 192
+    a = O.from_float(rng.uniform(-1, 1, (M, K)).astype(np.float32), code)
+    b = O.from_float(rng.uniform(-1, 1, (K, N)).astype(np.float32), code)
+    af, bf = f64(a, code), f64(b, code)
+    want, mag = af @ bf, np.abs(af) @ np.abs(bf)
+    for ta in (False, True):
+        for tb in (False, True):
+            sa, sb = (a.T.copy() if ta else a), (b.T.copy() if tb else b)
+            got = f64(run_gemm(code, sa, sb, ta, tb), code)
+            assert (np.abs(got - want) <= eps * np.abs(want) + 1e-6 * mag + 1e-30).all(), (code, ta, tb)
+    bias = O.from_float(rng.uniform(-1, 1, (N,)).astype(np.float32), code)
+    c = O.from_float(rng.uniform(-1, 1, (M, N)).astype(np.float32), code)
+    want_e = 0.5 * want + 2.0 * f64(c, code) + f64(bias, code)[None, :]
+    for tb in (False, True):
+        sb = b.T.copy() if tb else b
+        got = f64(run_gemm(code, a, sb, tb=tb, alpha=0.5, beta=2.0, c=c.copy(), bias=bias), code)
+        assert (np.abs(got - want_e) <= 2 * eps * np.abs(want_e) + 2e-6 * mag + 2 * eps).all(), ("epilogue", tb)
+    # C with ldc = N + 4 (rows 8-byte aligned only): columns beyond N must stay untouched
+    ldc = N + 4
+    cp = np.full((M, ldc), 7.0, dtype=np.float32)
+    cp[:, :N] = f64(c, code)
+    cpad = O.from_float(cp, code)
+    da, db, dc, dbias = H.DevBuf.from_numpy(a), H.DevBuf.from_numpy(b), H.DevBuf.from_numpy(cpad), H.DevBuf.from_numpy(bias)
+    assert H.gemm_workspace_bytes(code, False, False, M, N, K) == 0
+    H.gemm(code, False, False, M, N, K, 0.5, da.ptr, K, db.ptr, N, 2.0, dc.ptr, ldc, H.EPI_BIAS_ROW, dbias.ptr, None, 0)
+    H.device_sync()
+    got = f64(dc.to_numpy((M, ldc), a.dtype), code)
+    assert (got[:, N:] == 7.0).all()
+    assert (np.abs(got[:, :N] - want_e) <= 2 * eps * np.abs(want_e) + 2e-6 * mag + 2 * eps).all(), "unaligned C"
+
+
 def test_linearity_at_full_size():
     """Size-independent property at BASELINE size 4096^3 bf16: (A1 + A2) B == A1 B + A2 B within rounding,
     and a column-sparse probe: B = one-hot columns selects columns of A exactly."""
