@@ -242,6 +242,17 @@ __device__ __forceinline__ void f_stage(const char *kg, const char *vg, char *bu
 // softmax(t) while waves 0-3 do QK(t), softmax(t), PV(t) — two of the three phases pair matrix work
 // with vector work. Costs one more ring slot (V of tile t-1 must survive interval t).
 // ------------------------------------------------------------------------------------------
+// combine a value with the one held by the lane 32 away: ONE v_permlane32_swap (VALU) instead of a ds_bpermute round trip
+// through the LDS crossbar. swap(x, x) leaves {lower half's x in all lanes, upper half's x in all lanes}.
+__device__ __forceinline__ float a_half_max(float x) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+}
+__device__ __forceinline__ float a_half_sum(float x) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
+
 constexpr int SRING = 4;
 constexpr float kDeferMax = 8.0f;
 
@@ -270,7 +281,7 @@ __device__ __forceinline__ void s_qk_sm(const char *buf, const typename AFrag<BF
             if (MASK && kv0 + sub * 32 + a_row(e, hl) > m) s[sub][e] = -INFINITY;
             mx = fmaxf(mx, s[sub][e]);
         }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = a_half_max(mx);
     // deferred running maximum: m_i (raw score units) is the maximum IN USE; a larger one is adopted - and O, l rescaled: 66
     // multiplies - only when some query of the wave exceeds it by more than kDeferMax exponent units. Until then p can reach
     // 2^kDeferMax, which neither the 16-bit P nor the f32 row sum minds; after the first few tiles the branch is rarely taken.
@@ -294,7 +305,7 @@ __device__ __forceinline__ void s_qk_sm(const char *buf, const typename AFrag<BF
             s[sub][e] = p;
             rs += p;
         }
-    rs += __shfl_xor(rs, 32, 64);
+    rs = a_half_sum(rs);
     l_i += rs;
     pf[0] = a_pack<BF>(s[0], 0);
     pf[1] = a_pack<BF>(s[0], 1);
@@ -1202,7 +1213,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_mfma_kernel(const AttnArg
             if (need_mask && kv0 + a_row(e, hl) > m) sv[e] = -INFINITY;
             mx = fmaxf(mx, sv[e]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = a_half_max(mx);
         const float m_new = fmaxf(m_i, mx);
         const float mc = m_new * c;
         const float alpha = __builtin_amdgcn_exp2f(m_i * c - mc);
@@ -1213,7 +1224,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_mfma_kernel(const AttnArg
             sv[e] = p;
             rs += p;
         }
-        rs += __shfl_xor(rs, 32, 64);
+        rs = a_half_sum(rs);
         l_i = l_i * alpha + rs;
         m_i = m_new;
 #pragma unroll

@@ -14,6 +14,8 @@
 //            case: f64 123x457x234, test/test_gemm.py:9-17).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace kf {
@@ -654,6 +656,248 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_h256_kernel(const GemmArgs g) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// bf16 / f16, large shapes, second form: the same 256 x 256 x 64 block tile and the same LDS images, but FOUR waves
+// (2 x 2, 128 x 128 of C per wave), ONE wave per SIMD with the whole register file: 256 accumulator registers (AGPRs)
+// + two sets of fragments (2 x 64 VGPRs). A wave reads each LDS byte for 128 rows / columns of MFMA work instead of 64
+// (LDS traffic per K tile 128 KiB instead of 192), there is ONE barrier per K tile instead of eight, and nothing
+// depends on a partner wave: the fragments of the next k-step are read under the 64 MFMAs of the current one.
+//     S0: 64 MFMAs of (tile t, k-step 0) | under them: read fragments (t, k-step 1)
+//     P : s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier   - tile t + 1 has landed for everyone, tile t's buffer is free
+//     S1: 64 MFMAs of (t, k-step 1)      | under them: 16 DMA operations of tile t + 2, read fragments (t + 1, k-step 0)
+// Half-tiles: HA0 / HA1 = rows 0..127 / 128..255 of the A tile, HB0 / HB1 likewise for B; wave (wr, wc) reads HA[wr], HB[wc].
+// ------------------------------------------------------------------------------------------
+constexpr int W4_NT = 256;
+#ifndef W4_DMA_GROUPS
+#define W4_DMA_GROUPS 16 // the 16 LDS-DMA operations of a K tile go behind the first W4_DMA_GROUPS x 4 MFMAs after the barrier (4, 8 or 16)
+#endif
+
+// DIAG (diagnostic build only, tools/gemm_clock.py): stamps s_memtime / s_memrealtime around the main loop and writes the
+// two differences to g.bias (a buffer nothing else reads) - the in-kernel clock is their ratio x 100 MHz.
+template <bool BF, bool TRA, bool TRB, bool DIAG = false>
+__global__ __launch_bounds__(W4_NT) void gemm_w4_kernel(const GemmArgs g) {
+    using frag_t = typename HFrag<BF>::type;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const uint32_t tiles_n = (uint32_t)(g.N / G_BN);
+    uint32_t tm, tn;
+    grouped_tile(xcd_remap(blockIdx.x, gridDim.x), (uint32_t)(g.M / G_BM), tiles_n, (uint32_t)g.group_m, tm, tn);
+    const int64_t m0 = (int64_t)tm * G_BM, n0 = (int64_t)tn * G_BN;
+    const int nt = (int)(g.K / G_BK);
+
+    // ---- LDS-DMA: a half-tile is 16 operations of 1 KiB; wave w issues operations w*4 + i, i = 0..3.
+    // K-contiguous operand: operation j moves rows 8j..8j+7 (128 B each; source chunk = position ^ ((row >> 1) & 7), which
+    // depends on i only through i & 1). Transposed-read operand: operation j moves k rows 4j..4j+3 (256 B each; source
+    // chunk ^ (k & 3) << 2; 32 B of padding after every pair of operations).
+    const char *srcA[2], *srcB[2]; // [i & 1]
+    int64_t opstepA, opstepB, halfA, halfB, kstepA, kstepB;
+    {
+        const int pos = lane & 7, r8 = lane >> 3;
+        const int j0 = ((lane & 15) ^ (((lane >> 4) & 3) << 2)) * 8;
+        if constexpr (TRA) {
+            srcA[0] = srcA[1] = (const char *)g.A + ((int64_t)(wid * 16 + (lane >> 4)) * g.lda + m0 + j0) * 2;
+            opstepA = 4 * g.lda * 2, halfA = 128 * 2, kstepA = (int64_t)G_BK * g.lda * 2;
+        } else {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                srcA[p] = (const char *)g.A + (m0 + wid * 32 + r8) * g.lda * 2 + ((pos ^ ((p * 4 + (lane >> 4)) & 7)) << 4);
+            opstepA = 8 * g.lda * 2, halfA = 128 * g.lda * 2, kstepA = G_BK * 2;
+        }
+        if constexpr (TRB) {
+            srcB[0] = srcB[1] = (const char *)g.B + ((int64_t)(wid * 16 + (lane >> 4)) * g.ldb + n0 + j0) * 2;
+            opstepB = 4 * g.ldb * 2, halfB = 128 * 2, kstepB = (int64_t)G_BK * g.ldb * 2;
+        } else {
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                srcB[p] = (const char *)g.B + (n0 + wid * 32 + r8) * g.ldb * 2 + ((pos ^ ((p * 4 + (lane >> 4)) & 7)) << 4);
+            opstepB = 8 * g.ldb * 2, halfB = 128 * g.ldb * 2, kstepB = G_BK * 2;
+        }
+    }
+    // one DMA operation: which = 0 HA0, 1 HB0, 2 HA1, 3 HB1 (also the slot inside a tile buffer), i = 0..3
+    auto stage_op = [&](int which, int i, int kt) __attribute__((always_inline)) {
+        const int64_t ktc = kt < nt ? kt : nt - 1; // past the end: re-fetch the last tile (never read)
+        const bool isB = which & 1;
+        const int h = which >> 1, j = wid * 4 + i;
+        const bool tr = isB ? TRB : TRA;
+        const char *src = (isB ? srcB[i & 1] + i * opstepB + h * halfB + ktc * kstepB : srcA[i & 1] + i * opstepA + h * halfA + ktc * kstepA);
+        char *dst = smem + (kt & 1) * G_TILE + which * G_HALF + j * 1024 + (tr ? 32 * (j >> 1) : 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src, (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+    };
+
+    // ---- fragment reads (same images and address forms as gemm_h256_kernel)
+    const int fr = lane & 15, fg = lane >> 4;
+    const int sw = (fr >> 1) & 7;
+    const int offk[2] = {fr * 128 + (((0 + fg) ^ sw) << 4), fr * 128 + (((4 + fg) ^ sw) << 4)};
+    const int tq = fr >> 2;
+    const int lbT = fg * 2048 + tq * 256 + (((((fr & 3) >> 1)) ^ (tq << 2)) << 4) + 8 * (fr & 1);
+    const int pbT = 32 * fg;
+    const unsigned smem_u = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)smem;
+
+    f32x4 acc[8][8]; // [n-tile][m-tile]: D = B_frag x A_frag, i.e. C^T tiles
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    frag_t fa[2][8], fb[2][8]; // [set][tile]
+
+    // Everything in the loop is volatile inline asm, i.e. issued exactly in source order: MFMAs with "+a" accumulators (all
+    // 256 AGPRs, updated in place - left to itself the register allocator rotates accumulator tiles through copies at
+    // this pressure), fragment reads, and the counted waits that publish them. An accumulator is touched once per
+    // k-step (64 MFMAs apart) and fragments are consumed only after an lgkmcnt(0), so no MFMA hazard needs padding.
+    auto rd = [&](frag_t &dst, unsigned base, auto off) __attribute__((always_inline)) {
+        asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=v"(dst) : "v"(base), "n"(decltype(off)::value));
+    };
+    auto mm = [&](f32x4 &c, const frag_t &b, const frag_t &a) __attribute__((always_inline)) {
+        if constexpr (BF) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(b), "v"(a));
+        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(b), "v"(a));
+    };
+    // read number r (0..15) of a k-step: A tiles 0..7, then B tiles 0..7
+#define W4_READ1(SET, KS, BUFU, R)                                                                             \
+    {                                                                                                          \
+        constexpr int t = (R) & 7;                                                                             \
+        if constexpr ((R) < 8) {                                                                               \
+            if constexpr (TRA) {                                                                               \
+                const unsigned x = (unsigned)((lbT ^ (t * 32)) + pbT) + (BUFU) + (2 * wr) * G_HALF;            \
+                if constexpr ((KS) == 0) fa[SET][t] = g_tr_frag<BF, 0>(x); else fa[SET][t] = g_tr_frag<BF, 8192 + 128>(x); \
+            } else {                                                                                           \
+                rd(fa[SET][t], (BUFU) + (2 * wr) * G_HALF + offk[KS], std::integral_constant<int, t * 2048>{}); \
+            }                                                                                                  \
+        } else {                                                                                               \
+            if constexpr (TRB) {                                                                               \
+                const unsigned x = (unsigned)((lbT ^ (t * 32)) + pbT) + (BUFU) + (2 * wc + 1) * G_HALF;        \
+                if constexpr ((KS) == 0) fb[SET][t] = g_tr_frag<BF, 0>(x); else fb[SET][t] = g_tr_frag<BF, 8192 + 128>(x); \
+            } else {                                                                                           \
+                rd(fb[SET][t], (BUFU) + (2 * wc + 1) * G_HALF + offk[KS], std::integral_constant<int, t * 2048>{}); \
+            }                                                                                                  \
+        }                                                                                                      \
+    }
+    // one k-step: 64 MFMAs on fragment set SET; after every fourth one, read R of the next fragment set and (DMA) one
+    // LDS-DMA operation of tile kt + 2
+#define W4_STEP(SET, NKS, NBUFU, DMA)                                                                          \
+    W4_GROUP(SET, NKS, NBUFU, DMA, 0) W4_GROUP(SET, NKS, NBUFU, DMA, 1) W4_GROUP(SET, NKS, NBUFU, DMA, 2) W4_GROUP(SET, NKS, NBUFU, DMA, 3) \
+    W4_GROUP(SET, NKS, NBUFU, DMA, 4) W4_GROUP(SET, NKS, NBUFU, DMA, 5) W4_GROUP(SET, NKS, NBUFU, DMA, 6) W4_GROUP(SET, NKS, NBUFU, DMA, 7) \
+    W4_GROUP(SET, NKS, NBUFU, DMA, 8) W4_GROUP(SET, NKS, NBUFU, DMA, 9) W4_GROUP(SET, NKS, NBUFU, DMA, 10) W4_GROUP(SET, NKS, NBUFU, DMA, 11) \
+    W4_GROUP(SET, NKS, NBUFU, DMA, 12) W4_GROUP(SET, NKS, NBUFU, DMA, 13) W4_GROUP(SET, NKS, NBUFU, DMA, 14) W4_GROUP(SET, NKS, NBUFU, DMA, 15)
+#define W4_GROUP(SET, NKS, NBUFU, DMA, G)                                                                      \
+    {                                                                                                          \
+        constexpr int n = (G) >> 1, mb = ((G) & 1) * 4;                                                        \
+        mm(acc[n][mb + 0], fb[SET][n], fa[SET][mb + 0]);                                                       \
+        if constexpr (DMA && (G) < W4_DMA_GROUPS) stage_op((G) * (16 / W4_DMA_GROUPS) / 4, (G) * (16 / W4_DMA_GROUPS) % 4, kt + 2); \
+        W4_READ1(1 - (SET), NKS, NBUFU, G)                                                                     \
+        mm(acc[n][mb + 1], fb[SET][n], fa[SET][mb + 1]);                                                       \
+        if constexpr (DMA && (G) < W4_DMA_GROUPS && W4_DMA_GROUPS <= 8) stage_op(((G) * (16 / W4_DMA_GROUPS) + 1) / 4, ((G) * (16 / W4_DMA_GROUPS) + 1) % 4, kt + 2); \
+        mm(acc[n][mb + 2], fb[SET][n], fa[SET][mb + 2]);                                                       \
+        if constexpr (DMA && (G) < W4_DMA_GROUPS && W4_DMA_GROUPS <= 4) stage_op(((G) * 4 + 2) / 4, ((G) * 4 + 2) % 4, kt + 2); \
+        mm(acc[n][mb + 3], fb[SET][n], fa[SET][mb + 3]);                                                       \
+        if constexpr (DMA && (G) < W4_DMA_GROUPS && W4_DMA_GROUPS <= 4) stage_op(((G) * 4 + 3) / 4, ((G) * 4 + 3) % 4, kt + 2); \
+    }
+
+    // ---- prologue: tiles 0 and 1 in flight, tile 0 landed, fragments (0, k-step 0) in set 0
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int which = 0; which < 4; ++which)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) stage_op(which, i, kt);
+    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+#define W4_R(R) W4_READ1(0, 0, smem_u, R)
+    W4_R(0) W4_R(1) W4_R(2) W4_R(3) W4_R(4) W4_R(5) W4_R(6) W4_R(7) W4_R(8) W4_R(9) W4_R(10) W4_R(11) W4_R(12) W4_R(13) W4_R(14) W4_R(15)
+#undef W4_R
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    uint64_t t0 = 0, r0 = 0;
+    if constexpr (DIAG) {
+        t0 = __builtin_amdgcn_s_memtime();
+        r0 = __builtin_amdgcn_s_memrealtime();
+    }
+    for (int kt = 0; kt < nt; ++kt) {
+        const unsigned bufu = smem_u + (kt & 1) * G_TILE, nbufu = smem_u + ((kt + 1) & 1) * G_TILE;
+        W4_STEP(0, 1, bufu, false)                                                        // S0
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");          // P
+        W4_STEP(1, 0, nbufu, true)                                                        // S1
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#undef W4_STEP
+#undef W4_GROUP
+#undef W4_READ1
+    if constexpr (DIAG) {
+        const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) {
+            uint64_t *d = (uint64_t *)g.bias + 2 * (size_t)blockIdx.x;
+            d[0] = t1 - t0;
+            d[1] = r1 - r0;
+        }
+    }
+    // the last MFMAs are still in the pipe: nothing may read their accumulators yet. The "+a" operands order every
+    // compiler-generated read (epilogue, spill code) of the last row of tiles behind the wait.
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15"
+                 : "+a"(acc[7][0]), "+a"(acc[7][1]), "+a"(acc[7][2]), "+a"(acc[7][3]), "+a"(acc[7][4]), "+a"(acc[7][5]), "+a"(acc[7][6]), "+a"(acc[7][7])
+                 :
+                 : "memory");
+
+    // ---- epilogue: as gemm_h256_kernel's (lane exchange between neighbouring column tiles, 16-byte stores)
+    uint16_t *C = (uint16_t *)g.C;
+    const bool wide = g.ldc % 8 == 0 && (uintptr_t)g.C % 16 == 0;
+#pragma unroll
+    for (int np = 0; np < 8; np += 2) {
+        float bias[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (g.epilogue == KF_EPI_BIAS_ROW) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint16_t bb = ((const uint16_t *)g.bias)[n0 + wc * 128 + (np + t) * 16 + fg * 4 + e];
+                    bias[t][e] = BF ? bf16_to_f32(bf16_t{bb}) : f16_to_f32(f16_t{bb});
+                }
+        }
+        const int64_t col = n0 + wc * 128 + (np + (fg & 1)) * 16 + (fg >> 1) * 8;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int64_t row = m0 + wr * 128 + m * 16 + fr;
+            uint16_t *dst = C + row * g.ldc + col;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float lo = g.alpha * acc[np][m][e] + bias[0][e], hi = g.alpha * acc[np + 1][m][e] + bias[1][e];
+                const auto swp = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+                v[e] = __uint_as_float(swp[0]);
+                v[4 + e] = __uint_as_float(swp[1]);
+            }
+            if (g.beta != 0.f) {
+                uint32_t ow[4];
+                if (wide) {
+                    const uint4 old = *(const uint4 *)dst;
+                    ow[0] = old.x, ow[1] = old.y, ow[2] = old.z, ow[3] = old.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ow[e] = (uint32_t)dst[2 * e] | ((uint32_t)dst[2 * e + 1] << 16);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint16_t o = (uint16_t)(ow[e >> 1] >> ((e & 1) * 16));
+                    v[e] += g.beta * (BF ? bf16_to_f32(bf16_t{o}) : f16_to_f32(f16_t{o}));
+                }
+            }
+            uint32_t w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint16_t h0 = BF ? f32_to_bf16(v[2 * e]).x : f32_to_f16(v[2 * e]).x;
+                const uint16_t h1 = BF ? f32_to_bf16(v[2 * e + 1]).x : f32_to_f16(v[2 * e + 1]).x;
+                w[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+            }
+            if (wide) {
+                *(uint4 *)dst = uint4{w[0], w[1], w[2], w[3]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dst[e] = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+            }
+        }
+    }
+}
+
 // tiled 16-bit transpose: dst[c][r] = src[r][c]; 64x64 tiles through LDS, bit-exact. Full tiles with 16-byte
 // aligned rows move 16 B per lane on both the read and the write side (the LDS tile is written transposed,
 // 2 bytes at a time, and read back along the new contiguous dim); ragged tiles fall back to 2-byte accesses.
@@ -734,11 +978,47 @@ static int launch_h256(const GemmArgs &g, bool tra, bool trb, hipStream_t st) {
         }                                                                                                                 \
         gemm_h256_kernel<BF, TA, TB><<<grid, G_NT, G_LDS, st>>>(g);                                                       \
     }
+#define KF_W4(TA, TB)                                                                                                     \
+    {                                                                                                                     \
+        static bool attr = false;                                                                                         \
+        if (!attr) {                                                                                                      \
+            KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_w4_kernel<BF, TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS)); \
+            attr = true;                                                                                                  \
+        }                                                                                                                 \
+        gemm_w4_kernel<BF, TA, TB><<<grid, W4_NT, G_LDS, st>>>(g);                                                        \
+    }
+    // both forms run at the clock the chip holds under the load (tools/gemm_clock.py) and end up within a few % of each
+    // other; the 4-wave form is ahead while the grid is at most two rounds of tiles, the 8-wave form on larger grids
+    const bool w4 = getenv("KF_GEMM_W4") ? true : (getenv("KF_GEMM_W8") ? false : grid <= 512);
+    if (w4) {
+        if (!tra && !trb) KF_W4(false, false)
+        else if (!tra && trb) KF_W4(false, true)
+        else if (tra && !trb) KF_W4(true, false)
+        else KF_W4(true, true)
+        KF_LAUNCH_CHECK();
+        return KF_OK;
+    }
+#undef KF_W4
     if (!tra && !trb) KF_H256(false, false)
     else if (!tra && trb) KF_H256(false, true)
     else if (tra && !trb) KF_H256(true, false)
     else KF_H256(true, true)
 #undef KF_H256
+    KF_LAUNCH_CHECK();
+    return KF_OK;
+}
+
+// diagnostic entry (not part of the C ABI; tools/gemm_clock.py): bf16 A [M,K] x B stored [N,K] through the 4-wave kernel with
+// clock stamps; diag receives {core-clock cycles, 100 MHz ticks} of the main loop per workgroup
+extern "C" int kfdbg_gemm_clock(int64_t M, int64_t N, int64_t K, const void *A, const void *B, void *C, void *diag, void *stream) {
+    KF_REQUIRE(h256_ok(M, N, K) && A && B && C && diag, KF_ERR_INVALID, "kfdbg_gemm_clock: 256-tile shapes only");
+    GemmArgs g{A, B, C, diag, M, N, K, K, K, N, 1.f, 0.f, KF_EPI_NONE, 4};
+    static bool attr = false;
+    if (!attr) {
+        KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_w4_kernel<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+        attr = true;
+    }
+    gemm_w4_kernel<true, false, false, true><<<(unsigned)((M / G_BM) * (N / G_BN)), W4_NT, G_LDS, as_stream(stream)>>>(g);
     KF_LAUNCH_CHECK();
     return KF_OK;
 }
