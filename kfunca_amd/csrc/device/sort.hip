@@ -12,8 +12,8 @@
 //   * n <= 8192: one block sorts spb segments in LDS with a bitonic network over (key, position) composites -
 //     positions are unique, so the total order IS the stable order and no ranking pass is needed. Short segments share a
 //     block (2048 slots per block), so [68185 segments x 13 keys] does not launch 68185 nearly empty blocks.
-//   * n > 8192: least-significant-digit radix sort, 8-bit digits (one pass per key byte), three launches per pass:
-//     tile histograms -> per-segment exclusive scan -> stable scatter. A tile is 4096 keys, 1024 consecutive keys per wave.
+//   * n > 8192: least-significant-digit radix sort, 8-bit digits (one pass per key byte), four launches per pass:
+//     tile histograms -> two-level exclusive scan (inside chunks of 64 tiles, then over the chunks) -> stable scatter. A tile is 4096 keys, 1024 consecutive keys per wave.
 //     Ranking inside a wave is by digit match: 8 ballots give each lane the set of lanes holding its digit, the lane's
 //     rank is a popcount below itself - no per-key atomics, stable by construction. The tile is first reordered in LDS,
 //     then written out, so every digit's run leaves as consecutive addresses. The first pass reads the caller's typed
@@ -148,9 +148,10 @@ struct RadixArgs {
     void *dst_keys; // ordered keys of U, or typed keys (last pass)
     void *dst_pos;  // uint32 positions, or int64 (last pass)
     uint32_t *counts;     // [nseg][ntiles][256]: tile histograms, then exclusive prefix over the tiles of a segment
+    uint32_t *chunk_base; // [nseg][nchunks][256]: chunk totals, then exclusive prefix over the chunks of a segment
     uint32_t *digit_base; // [nseg][256]: exclusive prefix over the digits of a segment
     int64_t n;
-    int ntiles, shift, first, last, desc;
+    int ntiles, nchunks, shift, first, last, desc;
 };
 
 template <typename U, int W, int KIND>
@@ -181,7 +182,27 @@ __global__ __launch_bounds__(R_NT) void radix_hist_kernel(const RadixArgs a) {
     a.counts[((size_t)seg * a.ntiles + tile) * 256 + tid] = c;
 }
 
-// one block per segment: thread group g of 4 walks a quarter of the tiles for digit d = tid & 255
+// Exclusive prefix of the tile histograms, per digit, in two levels so that one very long segment is not one block's
+// serial walk: (1) one block per chunk of R_CHUNK tiles turns its tiles' counts into prefixes inside the chunk and writes
+// the chunk totals; (2) one block per segment (thread group g of 4 walks a quarter of the chunks for digit d = tid & 255)
+// turns the chunk totals into prefixes over the chunks and scans the digit totals into digit_base.
+constexpr int R_CHUNK = 64;
+
+__global__ __launch_bounds__(256) void radix_scan_tiles_kernel(uint32_t *counts, uint32_t *chunk_sum, int ntiles, int nchunks) {
+    const int d = threadIdx.x, chunk = blockIdx.x % nchunks;
+    const int64_t seg = blockIdx.x / nchunks;
+    const int t0 = chunk * R_CHUNK, t1 = min(t0 + R_CHUNK, ntiles);
+    uint32_t *c = counts + ((size_t)seg * ntiles + t0) * 256 + d;
+    uint32_t run = 0;
+#pragma unroll 8
+    for (int t = 0; t < t1 - t0; ++t) {
+        const uint32_t v = c[(size_t)t * 256];
+        c[(size_t)t * 256] = run;
+        run += v;
+    }
+    chunk_sum[((size_t)seg * nchunks + chunk) * 256 + d] = run;
+}
+
 __global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *counts, uint32_t *digit_base, int ntiles) {
     __shared__ uint32_t part[4][256];
     __shared__ uint32_t wsum[4];
@@ -284,7 +305,8 @@ __global__ __launch_bounds__(R_NT) void radix_scatter_kernel(const RadixArgs a) 
         for (int i = 0; i < w; ++i) off += wsum[i];
         const uint32_t ex = off + inc - total;
         dstart[tid] = ex;
-        gbase[tid] = a.counts[((size_t)seg * a.ntiles + tile) * 256 + tid] + a.digit_base[(size_t)seg * 256 + tid] - ex;
+        gbase[tid] = a.counts[((size_t)seg * a.ntiles + tile) * 256 + tid] + a.chunk_base[((size_t)seg * a.nchunks + tile / R_CHUNK) * 256 + tid] +
+                     a.digit_base[(size_t)seg * 256 + tid] - ex;
     }
     __syncthreads();
 #pragma unroll
@@ -316,8 +338,8 @@ constexpr int64_t kSmallMax = 8192;
 
 struct SortPlan {
     bool small;
-    int ntiles;
-    size_t key_bytes, pos_bytes, counts_bytes, base_bytes, total;
+    int ntiles, nchunks;
+    size_t key_bytes, pos_bytes, counts_bytes, chunk_bytes, base_bytes, total;
 };
 static inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 static SortPlan make_plan(int dtype, int64_t nseg, int64_t n) {
@@ -328,9 +350,11 @@ static SortPlan make_plan(int dtype, int64_t nseg, int64_t n) {
     p.ntiles = (int)((n + R_TILE - 1) / R_TILE);
     p.key_bytes = up256((size_t)nseg * n * usz);
     p.pos_bytes = up256((size_t)nseg * n * 4);
+    p.nchunks = (p.ntiles + R_CHUNK - 1) / R_CHUNK;
     p.counts_bytes = up256((size_t)nseg * p.ntiles * 256 * 4);
+    p.chunk_bytes = up256((size_t)nseg * p.nchunks * 256 * 4);
     p.base_bytes = up256((size_t)nseg * 256 * 4);
-    p.total = 2 * p.key_bytes + 2 * p.pos_bytes + p.counts_bytes + p.base_bytes;
+    p.total = 2 * p.key_bytes + 2 * p.pos_bytes + p.counts_bytes + p.chunk_bytes + p.base_bytes;
     return p;
 }
 
@@ -363,7 +387,8 @@ static int run_sort(const void *in, void *out, int64_t *pos, int64_t nseg, int64
     char *keys[2] = {ws, ws + p.key_bytes};
     char *poss[2] = {ws + 2 * p.key_bytes, ws + 2 * p.key_bytes + p.pos_bytes};
     uint32_t *counts = (uint32_t *)(ws + 2 * p.key_bytes + 2 * p.pos_bytes);
-    uint32_t *dbase = (uint32_t *)((char *)counts + p.counts_bytes);
+    uint32_t *cbase = (uint32_t *)((char *)counts + p.counts_bytes);
+    uint32_t *dbase = (uint32_t *)((char *)cbase + p.chunk_bytes);
     const int64_t grid = nseg * p.ntiles;
     KF_REQUIRE(grid <= 0x7fffffff && nseg <= 0x7fffffff, KF_ERR_INDEX_RANGE, "kf_sort: too many tiles");
     KF_PROF("sort_radix", st);
@@ -376,13 +401,16 @@ static int run_sort(const void *in, void *out, int64_t *pos, int64_t nseg, int64
         a.dst_keys = a.last ? out : (void *)keys[pass & 1];
         a.dst_pos = a.last ? (void *)pos : (void *)poss[pass & 1];
         a.counts = counts;
+        a.chunk_base = cbase;
         a.digit_base = dbase;
         a.n = n;
         a.ntiles = p.ntiles;
+        a.nchunks = p.nchunks;
         a.shift = 8 * pass;
         a.desc = desc;
         radix_hist_kernel<U, W, KIND><<<(unsigned)grid, R_NT, 0, st>>>(a);
-        radix_scan_kernel<<<(unsigned)nseg, 1024, 0, st>>>(counts, dbase, p.ntiles);
+        radix_scan_tiles_kernel<<<(unsigned)(nseg * p.nchunks), 256, 0, st>>>(counts, cbase, p.ntiles, p.nchunks);
+        radix_scan_kernel<<<(unsigned)nseg, 1024, 0, st>>>(cbase, dbase, p.nchunks);
         radix_scatter_kernel<U, W, KIND><<<(unsigned)grid, R_NT, 0, st>>>(a);
         KF_LAUNCH_CHECK();
     }
