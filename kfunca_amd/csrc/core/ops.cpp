@@ -137,16 +137,89 @@ Tensor add(const Tensor &self, double s) {
     if (out.requires_grad()) out.set_grad_fn(new AddScalarGradFunction(self));
     return out;
 }
-Tensor sub(const Tensor &self, double s) { Tensor out; binary_scalar_out(KF_EW_SUB, out, self, s); return out; }
-Tensor mul(const Tensor &self, double s) { Tensor out; binary_scalar_out(KF_EW_MUL, out, self, s); return out; }
-Tensor div(const Tensor &self, double s) { Tensor out; binary_scalar_out(KF_EW_DIV, out, self, s); return out; }
+namespace {
+class ScaleGradFunction : public GradFunction { // d(a * c) = g * c (c = 1 / s for a / s)
+public:
+    ScaleGradFunction(const Tensor &a, double c) : c_(c) { inputs = {a}; }
+    std::vector<Tensor> backward(Tensor g) override {
+        Tensor out;
+        binary_scalar_out(KF_EW_MUL, out, g, c_);
+        return {out};
+    }
+
+private:
+    double c_;
+};
+} // namespace
+Tensor sub(const Tensor &self, double s) {
+    Tensor out;
+    binary_scalar_out(KF_EW_SUB, out, self, s);
+    out.set_requires_grad(self.requires_grad());
+    if (out.requires_grad()) out.set_grad_fn(new AddScalarGradFunction(self));
+    return out;
+}
+Tensor mul(const Tensor &self, double s) {
+    Tensor out;
+    binary_scalar_out(KF_EW_MUL, out, self, s);
+    out.set_requires_grad(self.requires_grad());
+    if (out.requires_grad()) out.set_grad_fn(new ScaleGradFunction(self, s));
+    return out;
+}
+Tensor div(const Tensor &self, double s) {
+    Tensor out;
+    binary_scalar_out(KF_EW_DIV, out, self, s);
+    out.set_requires_grad(self.requires_grad());
+    if (out.requires_grad()) out.set_grad_fn(new ScaleGradFunction(self, 1.0 / s));
+    return out;
+}
 Tensor &add_(Tensor &self, double s) { return binary_scalar_out(KF_EW_ADD, self, self, s); }
 Tensor &sub_(Tensor &self, double s) { return binary_scalar_out(KF_EW_SUB, self, self, s); }
 Tensor &mul_(Tensor &self, double s) { return binary_scalar_out(KF_EW_MUL, self, self, s); }
 Tensor &div_(Tensor &self, double s) { return binary_scalar_out(KF_EW_DIV, self, self, s); }
 
-Tensor sub(const Tensor &l, const Tensor &r) { Tensor out; sub_out(out, l, r); return out; }
-Tensor mul(const Tensor &l, const Tensor &r) { Tensor out; mul_out(out, l, r); return out; }
+namespace {
+// d(a - b) = (g, -g); d(a * b) = (g * b, g * a). Same-shape operands only: a broadcast operand's gradient would need the
+// matching reduction, which nothing on the path (residual adds, gating) asks for.
+class SubGradFunction : public GradFunction {
+public:
+    SubGradFunction(const Tensor &l, const Tensor &r) { inputs = {l, r}; }
+    std::vector<Tensor> backward(Tensor g) override {
+        std::vector<Tensor> out(2);
+        if (inputs[0].requires_grad()) out[0] = g;
+        if (inputs[1].requires_grad()) binary_scalar_out(KF_EW_MUL, out[1], g, -1.0);
+        return out;
+    }
+};
+class MulGradFunction : public GradFunction {
+public:
+    MulGradFunction(const Tensor &l, const Tensor &r) { inputs = {l, r}; }
+    std::vector<Tensor> backward(Tensor g) override {
+        std::vector<Tensor> out(2);
+        if (inputs[0].requires_grad()) mul_out(out[0], g, inputs[1]);
+        if (inputs[1].requires_grad()) mul_out(out[1], g, inputs[0]);
+        return out;
+    }
+};
+bool same_shape(const Tensor &a, const Tensor &b) { return a.sizes() == b.sizes(); }
+} // namespace
+Tensor sub(const Tensor &l, const Tensor &r) {
+    Tensor out;
+    sub_out(out, l, r);
+    if ((l.requires_grad() || r.requires_grad()) && same_shape(l, r)) {
+        out.set_requires_grad(true);
+        out.set_grad_fn(new SubGradFunction(l, r));
+    }
+    return out;
+}
+Tensor mul(const Tensor &l, const Tensor &r) {
+    Tensor out;
+    mul_out(out, l, r);
+    if ((l.requires_grad() || r.requires_grad()) && same_shape(l, r)) {
+        out.set_requires_grad(true);
+        out.set_grad_fn(new MulGradFunction(l, r));
+    }
+    return out;
+}
 Tensor div(const Tensor &l, const Tensor &r) { Tensor out; div_out(out, l, r); return out; }
 
 // ---- unary / nullary (unary_ops.cpp:7-24, nullary_ops.cpp:6-14) --------------------------------------
@@ -156,9 +229,24 @@ Tensor &copy_(Tensor &self, const Tensor &other) {
     return self;
 }
 
+namespace {
+class CloneGradFunction : public GradFunction { // contiguous() / clone: the gradient passes through
+public:
+    explicit CloneGradFunction(const Tensor &a) { inputs = {a}; }
+    std::vector<Tensor> backward(Tensor g) override { return {g}; }
+};
+class ConvertGradFunction : public GradFunction { // dtype conversion: the gradient is converted back
+public:
+    explicit ConvertGradFunction(const Tensor &a) { inputs = {a}; }
+    std::vector<Tensor> backward(Tensor g) override { return {g.dtype() == inputs[0].dtype() ? g : convert(g, inputs[0].dtype())}; }
+};
+} // namespace
+
 Tensor clone(const Tensor &self) {
     Tensor out = empty_like(self);
     copy_(out, self);
+    out.set_requires_grad(self.requires_grad());
+    if (out.requires_grad()) out.set_grad_fn(new CloneGradFunction(self));
     return out;
 }
 
@@ -166,6 +254,8 @@ Tensor convert(const Tensor &self, ScalarType dtype) {
     Tensor out = empty(self.sizes(), dtype, self.device());
     auto iter = TensorIterator().add_output(out).add_input(self).build_for_loops();
     run_elementwise(iter, KF_EW_COPY, ScalarType::Undefined);
+    out.set_requires_grad(self.requires_grad() && is_floating_type(dtype));
+    if (out.requires_grad()) out.set_grad_fn(new ConvertGradFunction(self));
     return out;
 }
 
@@ -524,6 +614,26 @@ Tensor &index_put_(Tensor &self, const std::vector<Tensor> &indices, const Tenso
 }
 
 // ---- shape ops (tensor_shape.cpp:41-89) ----------------------------------------------------------------------------
+namespace {
+class CatGradFunction : public GradFunction { // each input's gradient is its window of g
+public:
+    CatGradFunction(const std::vector<Tensor> &ts, int dim) : dim_(dim) { inputs = ts; }
+    std::vector<Tensor> backward(Tensor g) override {
+        std::vector<Tensor> out(inputs.size());
+        int64_t at = 0;
+        for (size_t i = 0; i < inputs.size(); ++i) {
+            const int64_t len = inputs[i].shape(dim_);
+            if (inputs[i].requires_grad()) out[i] = g.narrow(dim_, at, len);
+            at += len;
+        }
+        return out;
+    }
+
+private:
+    int dim_;
+};
+} // namespace
+
 Tensor concat(const std::vector<Tensor> tensors, int64_t dim) {
     CHECK_FAIL(!tensors.empty(), "concat expects a non-empty list");
     const Tensor &first = tensors[0];
@@ -542,10 +652,16 @@ Tensor concat(const std::vector<Tensor> tensors, int64_t dim) {
     out_size[d] = total;
     Tensor result = empty(out_size, first.dtype(), first.device());
     int64_t at = 0;
+    bool any_grad = false;
     for (const Tensor &t : tensors) {
         Tensor window = result.narrow(d, at, t.shape(d));
         window.copy_(t);
         at += t.shape(d);
+        any_grad = any_grad || t.requires_grad();
+    }
+    if (any_grad) {
+        result.set_requires_grad(true);
+        result.set_grad_fn(new CatGradFunction(tensors, d));
     }
     return result;
 }

@@ -6,6 +6,7 @@
 #include <limits>
 #include <queue>
 #include <unordered_map>
+#include <unordered_set>
 
 #include "device_api.h"
 #include "ops.h"
@@ -167,10 +168,38 @@ Tensor &Tensor::fill_(const any_t &value) { return gpu::fill_(*this, value); }
 Tensor Tensor::contiguous() const { return is_contiguous() ? *this : gpu::clone(*this); }
 
 // ---- views: pure metadata, bit-exact by construction (reference tensor.cpp:167-290) ------------
+namespace {
+// Backward of every view (permute / slice / select / narrow / view / split all funnel through as_strided): the gradient
+// of the base is a buffer laid out like the base's storage, zero outside the view, holding g inside it. The reference's
+// autograd stops at add (binary_ops.cpp:16-33); this is what lets a whole block (config C5) run through Tensor::backward.
+class ViewGradFunction : public GradFunction {
+public:
+    ViewGradFunction(const Tensor &base, std::vector<int64_t> sizes, std::vector<int64_t> strides, int64_t offset)
+        : sizes_(std::move(sizes)), strides_(std::move(strides)), offset_(offset) {
+        inputs = {base};
+    }
+    std::vector<Tensor> backward(Tensor g) override {
+        const Tensor &base = inputs[0];
+        const int64_t n = (int64_t)(base.storage_bytes() / (size_t)base.element_size_in_bytes());
+        int64_t numel = 1;
+        for (int64_t v : sizes_) numel *= v;
+        Tensor buf = numel == n ? empty({n}, base.dtype(), base.device()) : zeros({n}, base.dtype(), base.device());
+        Tensor gv = buf.as_strided(sizes_, strides_, offset_);
+        gv.copy_(g);
+        return {buf.as_strided(base.sizes(), base.strides(), base.storage_offset())};
+    }
+
+private:
+    std::vector<int64_t> sizes_, strides_;
+    int64_t offset_;
+};
+} // namespace
+
 Tensor Tensor::as_strided(std::vector<int64_t> sizes, std::vector<int64_t> strides, int64_t storage_offset) const {
     auto impl = new TensorImpl(*impl_.get());
     Tensor out = make_tensor_(impl);
     impl->as_strided_(sizes, strides, storage_offset);
+    if (requires_grad()) out.set_grad_fn(new ViewGradFunction(*this, out.sizes(), out.strides(), out.storage_offset()));
     return out;
 }
 
@@ -295,12 +324,14 @@ void Tensor::update_grad(Tensor grad) {
 void Tensor::backward(Tensor grad_output) {
     // pass 1: how many consumers will feed each differentiable tensor
     std::unordered_map<TensorImpl *, int> pending;
+    std::unordered_set<TensorImpl *> expanded;
     std::queue<Tensor *> work;
     work.push(this);
     while (!work.empty()) {
         Tensor *t = work.front();
         work.pop();
         if (!t->has_grad_fn()) continue;
+        if (!expanded.insert(t->impl()).second) continue; // reached again through another consumer: its inputs are counted once
         for (auto &in : t->grad_fn_->inputs) {
             if (!in.requires_grad()) continue;
             pending[in.impl()] += 1;

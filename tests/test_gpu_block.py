@@ -1,0 +1,144 @@
+"""-m gpu: BASELINE config C5 as a parity case - one causal-attention transformer block, forward + backward, built ONLY from
+operators the reference API has (gemm, view / permute / contiguous / split, causal_attention, add, mul: SURVEY.md §8d) and run
+through Tensor.backward. The reference's autograd stops at add, so the expected values come from torch-CPU autograd on the
+same expression in f32 (a floating-point path: tolerances stated below). The batch-sharded form is checked by summing the
+weight gradients of two half-batches (what the RCCL all-reduce does across ranks)."""
+import numpy as np
+import pytest
+import torch
+
+import kfunca_amd as kfunca
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def block(x, w, B, S, H, D, api):
+    """x [B*S, d]; w = (Wqkv [d, 3d], Wo [d, d], Wg [d, f], Wu [d, f], Wd [f, d])."""
+    d = H * D
+    qkv = api.gemm(x, w[0])                                  # [T, 3d]
+    q, k, v = api.split(qkv, [d, d, d], 1)
+    heads = [api.contiguous(api.permute(api.view(t_, [B, S, H, D]), [0, 2, 1, 3])) for t_ in (api.contiguous(q), api.contiguous(k), api.contiguous(v))]
+    a = api.attention(*heads)                                # [B, H, S, D]
+    a = api.view(api.contiguous(api.permute(a, [0, 2, 1, 3])), [B * S, d])
+    h = api.add(x, api.gemm(a, w[1]))                        # residual
+    gate, up = api.gemm(h, w[2]), api.gemm(h, w[3])
+    return api.add(h, api.gemm(api.mul(gate, up), w[4]))     # gating is a plain product: the reference has no activation op
+
+
+class KfApi:
+    gemm = staticmethod(lambda a, b: kfunca.gemm(a, b, 1.0, 0.0))
+    split = staticmethod(lambda t, sizes, dim: t.split(sizes, dim))
+    view = staticmethod(lambda t, s: t.view(*s))
+    permute = staticmethod(lambda t, p: t.permute(*p))
+    contiguous = staticmethod(lambda t: t.contiguous())
+    attention = staticmethod(kfunca.causal_attention)
+    add = staticmethod(lambda a, b: a + b)
+    mul = staticmethod(lambda a, b: a * b)
+
+
+class TorchApi:
+    gemm = staticmethod(lambda a, b: a @ b)
+    split = staticmethod(lambda t, sizes, dim: torch.split(t, sizes, dim))
+    view = staticmethod(lambda t, s: t.reshape(s))
+    permute = staticmethod(lambda t, p: t.permute(*p))
+    contiguous = staticmethod(lambda t: t.contiguous())
+    attention = staticmethod(lambda q, k, v: torch.nn.functional.scaled_dot_product_attention(q, k, v, is_causal=True))
+    add = staticmethod(lambda a, b: a + b)
+    mul = staticmethod(lambda a, b: a * b)
+
+
+def make(rng, B, S, H, D, f):
+    d = H * D
+    x = rng.uniform(-1, 1, (B * S, d)).astype(np.float32)
+    w = [(rng.uniform(-1, 1, shp) / np.sqrt(shp[0])).astype(np.float32) for shp in ((d, 3 * d), (d, d), (d, f), (d, f), (f, d))]
+    g = rng.uniform(-1, 1, (B * S, d)).astype(np.float32)
+    return x, w, g
+
+
+def run_torch(x, w, g, B, S, H, D):
+    tx = torch.tensor(x, requires_grad=True)
+    tw = [torch.tensor(a, requires_grad=True) for a in w]
+    y = block(tx, tw, B, S, H, D, TorchApi)
+    y.backward(torch.tensor(g))
+    return y.detach().numpy(), tx.grad.numpy(), [a.grad.numpy() for a in tw]
+
+
+def run_kf(x, w, g, B, S, H, D, bf16=False):
+    def up(a):
+        t = kfunca.from_numpy(a, 0)
+        t = t.bfloat16() if bf16 else t
+        t.set_requires_grad(True)
+        return t
+    tx, tw = up(x), [up(a) for a in w]
+    y = block(tx, tw, B, S, H, D, KfApi)
+    tg = kfunca.from_numpy(g, 0)
+    y.backward(tg.bfloat16() if bf16 else tg)
+    out = lambda t: (t.float() if bf16 else t).numpy()  # noqa: E731
+    return out(y), out(tx.grad()), [out(a.grad()) for a in tw]
+
+
+def rel_err(got, want):
+    return float(np.abs(got - want).max() / (np.abs(want).max() + 1e-30))
+
+
+@pytest.mark.parametrize("B,S,H,D,f", [(2, 64, 2, 64, 256), (1, 96, 3, 128, 128)])
+def test_block_f32_forward_backward_vs_torch_autograd(B, S, H, D, f):
+    rng = np.random.default_rng(900 + S)
+    x, w, g = make(rng, B, S, H, D, f)
+    y0, dx0, dw0 = run_torch(x, w, g, B, S, H, D)
+    y1, dx1, dw1 = run_kf(x, w, g, B, S, H, D)
+    # f32 end to end (exact-f32 MFMA GEMMs and attention): 1e-4 of the tensor's scale; the reference's own bar is 1e-3
+    assert rel_err(y1, y0) < 1e-4 and rel_err(dx1, dx0) < 1e-4
+    for a, b in zip(dw1, dw0):
+        assert a.shape == b.shape and rel_err(a, b) < 1e-4
+
+
+def test_block_bf16_and_batch_sharded_gradients():
+    B, S, H, D, f = 2, 128, 2, 128, 512
+    rng = np.random.default_rng(910)
+    x, w, g = make(rng, B, S, H, D, f)
+    xb, gb = (O.bf16_to_f32(O.f32_to_bf16(a)) for a in (x, g))
+    wb = [O.bf16_to_f32(O.f32_to_bf16(a)) for a in w]
+    y0, dx0, dw0 = run_torch(xb, wb, gb, B, S, H, D)
+    y1, dx1, dw1 = run_kf(xb, wb, gb, B, S, H, D, bf16=True)
+    # bf16 storage between every operator (8 mantissa bits, ~10 roundings deep): 3e-2 of the tensor's scale
+    assert rel_err(y1, y0) < 3e-2 and rel_err(dx1, dx0) < 3e-2
+    for a, b in zip(dw1, dw0):
+        assert rel_err(a, b) < 3e-2
+    # data-parallel form: rank r runs batch element r with the same weights; dW = sum over ranks (the all-reduce), f32 here
+    T = S
+    parts = [run_kf(xb[r * T:(r + 1) * T], wb, gb[r * T:(r + 1) * T], 1, S, H, D) for r in range(B)]
+    _, dxf, dwf = run_kf(xb, wb, gb, B, S, H, D)
+    assert rel_err(np.concatenate([p[1] for p in parts]), dxf) < 1e-5
+    for i in range(len(wb)):
+        assert rel_err(sum(p[2][i] for p in parts), dwf[i]) < 1e-4
+
+
+def test_view_slice_mul_scalar_cat_gradients():
+    rng = np.random.default_rng(920)
+    a = rng.uniform(-1, 1, (6, 10)).astype(np.float32)
+    b = rng.uniform(-1, 1, (6, 4)).astype(np.float32)
+    g = rng.uniform(-1, 1, (4, 3, 5)).astype(np.float32)
+
+    def expr(A, Bm, cat, is_torch):
+        left = A[:, 2:8] * 0.5 - 1.0                         # slice view, scalar ops
+        z = cat([left, Bm * Bm], 1)                          # [6, 10]
+        z = z - A / 4.0
+        z = (z.permute(1, 0) if not is_torch else z.permute(1, 0)).contiguous()
+        z = z.view(2, 5, 6) if not is_torch else z.reshape(2, 5, 6)
+        return z[:, 1:4, 1:6:1].permute(2, 1, 0)[:4]         # [4, 3, 2] ... select a window again
+
+    ta, tb = torch.tensor(a, requires_grad=True), torch.tensor(b, requires_grad=True)
+    yt = expr(ta, tb, torch.cat, True)
+    gt = torch.tensor(g[:, :, :2].copy())
+    yt.backward(gt)
+    ka, kb = kfunca.from_numpy(a, 0), kfunca.from_numpy(b, 0)
+    ka.set_requires_grad(True)
+    kb.set_requires_grad(True)
+    yk = expr(ka, kb, kfunca.cat, False)
+    assert yk.sizes() == list(yt.shape)
+    assert np.allclose(yk.contiguous().numpy(), yt.detach().numpy(), atol=1e-6)
+    yk.backward(kfunca.from_numpy(g[:, :, :2].copy(), 0))
+    assert np.allclose(ka.grad().numpy(), ta.grad.numpy(), atol=1e-6)
+    assert np.allclose(kb.grad().numpy(), tb.grad.numpy(), atol=1e-6)

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""BASELINE config C5 on ONE GPU's shard (per-GPU batch 1): a bf16 causal-attention transformer block forward + backward
+through the Python operator API and Tensor.backward - d_model 4096, 32 heads x 128, S 4096, gated MLP of width 16384, only
+operators the reference API has. Reports ms per step, tokens/s and the TFLOP/s of the block's matrix work
+(GEMMs 6·T·d·(4d + 3f), attention 14·S²·d / 2 per batch element); per-kernel times from the library's profiling mode."""
+import argparse
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import kfunca_amd as kfunca  # noqa: E402
+from kfunca_amd import hip_abi as H  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--json", default="")
+    args = ap.parse_args()
+    B, S, Hh, D, f = 1, 4096, 32, 128, 16384
+    d, T = Hh * D, B * S
+    rng = np.random.default_rng(1005)
+
+    def param(shape, scale):
+        t = kfunca.from_numpy((rng.uniform(-1, 1, shape) * scale).astype(np.float32), 0).bfloat16()
+        t.set_requires_grad(True)
+        return t
+
+    x = param((T, d), 1.0)
+    w = [param(s, 1.0 / np.sqrt(s[0])) for s in ((d, 3 * d), (d, d), (d, f), (d, f), (f, d))]
+    g = kfunca.from_numpy(rng.uniform(-1, 1, (T, d)).astype(np.float32), 0).bfloat16()
+
+    def step():
+        qkv = kfunca.gemm(x, w[0], 1.0, 0.0)
+        q, k, v = (t.contiguous().view(B, S, Hh, D).permute(0, 2, 1, 3).contiguous() for t in qkv.split([d, d, d], 1))
+        a = kfunca.causal_attention(q, k, v).permute(0, 2, 1, 3).contiguous().view(T, d)
+        h = x + kfunca.gemm(a, w[1], 1.0, 0.0)
+        y = h + kfunca.gemm(kfunca.gemm(h, w[2], 1.0, 0.0) * kfunca.gemm(h, w[3], 1.0, 0.0), w[4], 1.0, 0.0)
+        y.backward(g)
+
+    for _ in range(args.warmup):
+        step()
+    kfunca.synchronize(0)
+    H.profile_reset()
+    H.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    kfunca.synchronize(0)
+    t1 = time.perf_counter()
+    H.profile_enable(False)
+    ms = (t1 - t0) / args.steps * 1e3
+    flops = 6.0 * T * d * (4 * d + 3 * f) + 14.0 * B * S * S * d / 2
+    prof = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps} for k, v in H.profile_results().items()}
+    out = {"config": "C5 shard: bf16 block fwd+bwd, B=1 S=4096 d=4096 H=32 D=128 f=16384, Python operator API + Tensor.backward",
+           "ms_per_step": ms, "tokens_per_s": T / (ms * 1e-3), "matrix_tflops": flops / (ms * 1e-3) / 1e12,
+           "device_ms_per_step": sum(v["ms_per_step"] for v in prof.values()), "kernels": prof}
+    print(json.dumps(out, indent=1))
+    if args.json:
+        Path(args.json).write_text(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
