@@ -971,20 +971,12 @@ static int launch_h256(const GemmArgs &g, bool tra, bool trb, hipStream_t st) {
     const unsigned grid = (unsigned)((g.M / G_BM) * (g.N / G_BN));
 #define KF_H256(TA, TB)                                                                                                   \
     {                                                                                                                     \
-        static bool attr = false;                                                                                         \
-        if (!attr) {                                                                                                      \
-            KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_h256_kernel<BF, TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS)); \
-            attr = true;                                                                                                  \
-        }                                                                                                                 \
+        KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_h256_kernel<BF, TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS)); \
         gemm_h256_kernel<BF, TA, TB><<<grid, G_NT, G_LDS, st>>>(g);                                                       \
     }
 #define KF_W4(TA, TB)                                                                                                     \
     {                                                                                                                     \
-        static bool attr = false;                                                                                         \
-        if (!attr) {                                                                                                      \
-            KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_w4_kernel<BF, TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS)); \
-            attr = true;                                                                                                  \
-        }                                                                                                                 \
+        KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_w4_kernel<BF, TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS)); \
         gemm_w4_kernel<BF, TA, TB><<<grid, W4_NT, G_LDS, st>>>(g);                                                        \
     }
     // both forms run at the clock the chip holds under the load (tools/gemm_clock.py) and end up within a few % of each
@@ -1013,11 +1005,7 @@ static int launch_h256(const GemmArgs &g, bool tra, bool trb, hipStream_t st) {
 extern "C" int kfdbg_gemm_clock(int64_t M, int64_t N, int64_t K, const void *A, const void *B, void *C, void *diag, void *stream) {
     KF_REQUIRE(h256_ok(M, N, K) && A && B && C && diag, KF_ERR_INVALID, "kfdbg_gemm_clock: 256-tile shapes only");
     GemmArgs g{A, B, C, diag, M, N, K, K, K, N, 1.f, 0.f, KF_EPI_NONE, 4};
-    static bool attr = false;
-    if (!attr) {
-        KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_w4_kernel<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
-        attr = true;
-    }
+    KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_w4_kernel<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
     gemm_w4_kernel<true, false, false, true><<<(unsigned)((M / G_BM) * (N / G_BN)), W4_NT, G_LDS, as_stream(stream)>>>(g);
     KF_LAUNCH_CHECK();
     return KF_OK;
@@ -1083,18 +1071,10 @@ extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N
         const size_t lds = 4 * H_TILE_BYTES;
         KF_PROF(dtype == KF_BF16 ? "gemm_bf16_mfma_128" : "gemm_f16_mfma_128", st);
         if (dtype == KF_BF16) {
-            static bool attr_bf = false;
-            if (!attr_bf) {
-                KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_h_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_bf = true;
-            }
+            KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_h_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             gemm_h_kernel<true><<<grid, 256, lds, st>>>(g);
         } else {
-            static bool attr_h = false;
-            if (!attr_h) {
-                KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_h_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_h = true;
-            }
+            KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_h_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             gemm_h_kernel<false><<<grid, 256, lds, st>>>(g);
         }
         KF_LAUNCH_CHECK();

@@ -371,12 +371,8 @@ static int run_sort(const void *in, void *out, int64_t *pos, int64_t nseg, int64
         int nthr = E / 2;
         nthr = nthr < 64 ? 64 : (nthr > 1024 ? 1024 : (nthr + 63) / 64 * 64);
         const size_t lds = Slots<U>::bytes(E);
-        static bool attr = false;
-        if (!attr) {
-            KF_HIP_TRY(hipFuncSetAttribute((const void *)sort_small_kernel<U, W, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        KF_HIP_TRY(hipFuncSetAttribute((const void *)sort_small_kernel<U, W, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)Slots<U>::bytes((int)kSmallMax)));
-            attr = true;
-        }
         const int64_t grid = (nseg + a.spb - 1) / a.spb;
         KF_REQUIRE(grid <= 0x7fffffff, KF_ERR_INDEX_RANGE, "kf_sort: too many segments");
         KF_PROF("sort_bitonic_lds", st);

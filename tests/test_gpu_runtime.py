@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from kfunca_amd import hip_abi as H
+from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
@@ -112,3 +113,52 @@ def test_graph_capture_of_a_launch_bound_sequence():
     assert graph < eager * 1.2
     with pytest.raises(H.KfError):
         H.check(H.lib().kf_graph_begin_capture(None))
+
+
+def test_graph_capture_of_a_training_step_sequence():
+    """The bench's per-step sequence in miniature - the three GEMMs on the 256-tile kernels, attention forward + backward (MFMA
+    kernels: LDS-DMA, large dynamic LDS) and a sort - captured into one HIP graph and replayed: bit-identical to the eager run."""
+    s = H.Stream()
+    rng = np.random.default_rng(5)
+    M, N, K = 2560, 4096, 128
+
+    def bf(shape):
+        return O.f32_to_bf16(rng.uniform(-1, 1, shape).astype(np.float32))
+
+    A, Bm, G = H.DevBuf.from_numpy(bf((M, K))), H.DevBuf.from_numpy(bf((K, N))), H.DevBuf.from_numpy(bf((M, N)))
+    Cc, dA, dB = H.DevBuf(2 * M * N), H.DevBuf(2 * M * K), H.DevBuf(2 * K * N)
+    Bh, Hh, S, D = 1, 2, 256, 128
+    q, k, v, do = (H.DevBuf.from_numpy(bf((Bh, Hh, S, D))) for _ in range(4))
+    o, dq, dk, dv = (H.DevBuf(2 * Bh * Hh * S * D) for _ in range(4))
+    lse = H.DevBuf(4 * Bh * Hh * S)
+    need = H.attn_bwd_workspace_bytes(H.BF16, Bh, Hh, S, S, D)
+    ws = H.DevBuf(need)
+    keys = H.DevBuf.from_numpy(rng.standard_normal((3, 20000)).astype(np.float32))
+    skeys, spos = H.DevBuf(4 * 60000), H.DevBuf(8 * 60000)
+    sneed = H.lib().kf_sort_workspace_bytes(H.F32, 3, 20000)
+    sws = H.DevBuf(sneed)
+    assert H.gemm_workspace_bytes(H.BF16, False, False, M, N, K) == 0  # the 256-tile kernels read every layout in place
+    gneed = max(H.gemm_workspace_bytes(H.BF16, False, True, M, K, N), H.gemm_workspace_bytes(H.BF16, True, False, K, N, M), 16)
+    gws = H.DevBuf(gneed)  # the small backward products take the 128-tile kernel and its re-layout scratch
+
+    def step():
+        H.gemm(H.BF16, False, False, M, N, K, 1.0, A.ptr, K, Bm.ptr, N, 0.0, Cc.ptr, N, stream=s.handle)      # C = A B
+        H.gemm(H.BF16, False, True, M, K, N, 1.0, G.ptr, N, Bm.ptr, N, 0.0, dA.ptr, K, workspace=gws.ptr, workspace_bytes=gneed, stream=s.handle)  # dA = G B^T
+        H.gemm(H.BF16, True, False, K, N, M, 1.0, A.ptr, K, G.ptr, N, 0.0, dB.ptr, N, workspace=gws.ptr, workspace_bytes=gneed, stream=s.handle)  # dB = A^T G
+        H.attn_fwd(H.BF16, Bh, Hh, S, S, D, q.ptr, k.ptr, v.ptr, o.ptr, lse.ptr, stream=s.handle)
+        H.attn_bwd(H.BF16, Bh, Hh, S, S, D, q.ptr, k.ptr, v.ptr, o.ptr, lse.ptr, do.ptr, dq.ptr, dk.ptr, dv.ptr, ws.ptr, need, stream=s.handle)
+        H.check(H.lib().kf_sort(H.F32, keys.ptr, skeys.ptr, spos.ptr, 3, 20000, 1, sws.ptr, sneed, s.handle))
+
+    outs = [(Cc, 2 * M * N), (dA, 2 * M * K), (dB, 2 * K * N), (o, 2 * Bh * Hh * S * D), (dq, 2 * Bh * Hh * S * D), (dk, 2 * Bh * Hh * S * D),
+            (dv, 2 * Bh * Hh * S * D), (skeys, 4 * 60000), (spos, 8 * 60000)]
+    step()
+    s.sync()
+    want = [b.to_numpy((n,), np.uint8).copy() for b, n in outs]
+    with H.Graph.capture(s) as g:
+        step()
+    for b, n in outs:
+        H.check(H.lib().kf_memset_zero(b.ptr, n, s.handle))
+    g.launch()
+    s.sync()
+    for (b, n), w in zip(outs, want):
+        assert np.array_equal(b.to_numpy((n,), np.uint8), w)
