@@ -50,6 +50,8 @@ struct AttnArgs {
     float scale;
     int xcd_map; // 1: nbh % 8 == 0, heads are pinned to XCDs (a_block_map)
     float defer; // forward: adopt a new running maximum only beyond this many exponent units (kDeferMax; -inf: always)
+    int persist;     // k > 0: a workgroup handles k pairs {block x, its causal mirror}: equal work per workgroup (k = 1 is used)
+    int persist_rev; // the short block of a pair first
 };
 
 // XCD-aware block order for the v2 kernels (1-D grid of nx * nbh blocks). Hardware deals block ids round-robin
@@ -343,19 +345,35 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
     using frag_t = typename AFrag<BF>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
-    int xb;
+    int xb0;
     int64_t bh;
     const int nxb = (int)((a.Sq + FQ - 1) / FQ);
-    a_block_map(nxb, (int)(a.B * a.H), a.xcd_map, xb, bh);
-    const int qblk = nxb - 1 - xb; // longest blocks first
-    // query rows are dealt so that each SIMD's early wave (w) and late wave (w + 4) own ADJACENT 32-row groups:
-    // their causal work differs by at most one tile
+    // a.persist (nxb even): a workgroup takes query block x AND its mirror nxb - 1 - x of the same (batch, head), so every
+    // workgroup has the same causal work (nxb + 1 key tiles' worth) and half as many workgroups are dispatched
+    const int nwx = a.persist ? nxb / (2 * a.persist) : nxb; // workgroups per (batch, head)
+    a_block_map(nwx, (int)(a.B * a.H), a.xcd_map, xb0, bh);
     const int rgrp = ((wid & 3) << 1) | (wid >> 2);
-    const int64_t q0 = (int64_t)qblk * FQ, qw = q0 + rgrp * 32, m = qw + xl;
-    const bool active = qw < a.Sq;
     const bool late = __builtin_amdgcn_readfirstlane(wid) >= 4;
     const char *Kg = a.k + bh * a.Skv * AROW;
     const char *Vg = a.v + bh * a.Skv * AROW;
+    int ko[8], vo[4][2];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) ko[kk] = a_off(xl, kk * 2 + hl);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        vo[d][0] = a_tr_lane_off(d * 32, 0);
+        vo[d][1] = a_tr_lane_off(d * 32, 1);
+    }
+    const float c = a.scale * kLog2e;
+#pragma nounroll
+  for (int pass = 0; pass < (a.persist ? 2 * a.persist : 1); ++pass) {
+    const int xp = xb0 + (pass >> 1) * nwx;           // pair index: blocks xp and nxb - 1 - xp
+    const int xb = ((pass & 1) != (a.persist_rev != 0)) ? nxb - 1 - xp : xp;
+    const int qblk = nxb - 1 - xb; // longest blocks first
+    // query rows are dealt so that each SIMD's early wave (w) and late wave (w + 4) own ADJACENT 32-row groups:
+    // their causal work differs by at most one tile
+    const int64_t q0 = (int64_t)qblk * FQ, qw = q0 + rgrp * 32, m = qw + xl;
+    const bool active = qw < a.Sq;
 
     frag_t qf[8];
     if (active) {
@@ -368,21 +386,12 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) qf[kk][j] = 0;
     }
-    int ko[8], vo[4][2];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) ko[kk] = a_off(xl, kk * 2 + hl);
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        vo[d][0] = a_tr_lane_off(d * 32, 0);
-        vo[d][1] = a_tr_lane_off(d * 32, 1);
-    }
     f32x16 o[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
     float m_i = -INFINITY, l_i = 0.f;
-    const float c = a.scale * kLog2e;
     frag_t pf[4];
     bool pending = false; // late waves: P of the previous tile still waits for its PV
 
@@ -422,6 +431,8 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
         a_store_rows<BF>(smem + wid * 32 * OPAD, a.out + (bh * a.Sq + qw) * AROW, o, 1.f / l_i);
         if (a.lse && hl == 0) a.lse[bh * a.Sq + m] = (m_i * c + __builtin_amdgcn_logf(l_i)) * kLn2;
     }
+    if (a.persist) __syncthreads(); // the staging slabs overlap the ring the next block fills
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -520,16 +531,31 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a
     using frag_t = typename AFrag<BF>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
-    int xb;
+    int xb0;
     int64_t bh;
     const int nxb = (int)((a.Sq + FQ - 1) / FQ);
-    a_block_map(nxb, (int)(a.B * a.H), a.xcd_map, xb, bh);
-    const int qblk = nxb - 1 - xb; // longest blocks first
-    const int64_t q0 = (int64_t)qblk * FQ, qw = q0 + wid * 32, m = qw + xl;
-    const bool active = qw < a.Sq;
+    // a.persist: a workgroup takes query block x and its causal mirror nxb - 1 - x (equal work per workgroup, as in the forward)
+    const int nwx = a.persist ? nxb / (2 * a.persist) : nxb;
+    a_block_map(nwx, (int)(a.B * a.H), a.xcd_map, xb0, bh);
     const char *Kg = a.k + bh * a.Skv * AROW;
     const char *Vg = a.v + bh * a.Skv * AROW;
     char *doslab = smem + FRING * FBUF + wid * QSLAB; // this wave's dO rows, same swizzled image as a K tile (B operand of dP^T)
+    int ko[8], vo[4][2];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) ko[kk] = a_off(xl, kk * 2 + hl);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        vo[d][0] = a_tr_lane_off(d * 32, 0);
+        vo[d][1] = a_tr_lane_off(d * 32, 1);
+    }
+    const float c = a.scale * kLog2e;
+#pragma nounroll
+  for (int pass = 0; pass < (a.persist ? 2 * a.persist : 1); ++pass) {
+    const int xp = xb0 + (pass >> 1) * nwx;
+    const int xb = ((pass & 1) != (a.persist_rev != 0)) ? nxb - 1 - xp : xp;
+    const int qblk = nxb - 1 - xb; // longest blocks first
+    const int64_t q0 = (int64_t)qblk * FQ, qw = q0 + wid * 32, m = qw + xl;
+    const bool active = qw < a.Sq;
 
     frag_t qf[8];
     float lse2 = 0.f, dlt = 0.f;
@@ -548,20 +574,11 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a
 #pragma unroll
             for (int j = 0; j < 8; ++j) qf[kk][j] = 0;
     }
-    int ko[8], vo[4][2];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) ko[kk] = a_off(xl, kk * 2 + hl);
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        vo[d][0] = a_tr_lane_off(d * 32, 0);
-        vo[d][1] = a_tr_lane_off(d * 32, 1);
-    }
     f32x16 dq[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
         for (int e = 0; e < 16; ++e) dq[d][e] = 0.f;
-    const float c = a.scale * kLog2e;
 
     const int64_t q_end = q0 + FQ < a.Sq ? q0 + FQ : a.Sq;
     const int64_t kv_end = a.Skv < q_end ? a.Skv : q_end;
@@ -590,6 +607,8 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (active) a_store_rows<BF>(smem + wid * 32 * OPAD, a.dq + (bh * a.Sq + qw) * AROW, dq, a.scale);
+    if (a.persist) __syncthreads(); // the staging slabs overlap the ring the next block fills
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -847,12 +866,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     using frag_t = typename AFrag<BF>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), xl = lane & 31, hl = lane >> 5;
-    int xb;
+    int xb0;
     int64_t bh;
-    a_block_map((int)(a.Skv / K4B), (int)(a.B * a.H), a.xcd_map, xb, bh);
-    const int64_t k0 = (int64_t)xb * K4B, kw = k0 + wid * 32, n = kw + xl;
+    // a.persist: a workgroup takes key block x and its causal mirror nkb - 1 - x (equal work per workgroup, as in the forward)
+    const int nkb = (int)(a.Skv / K4B), nwx = a.persist ? nkb / (2 * a.persist) : nkb;
+    a_block_map(nwx, (int)(a.B * a.H), a.xcd_map, xb0, bh);
     const char *Qg = a.q + bh * a.Sq * AROW;
     const char *dOg = a.d_o + bh * a.Sq * AROW;
+#pragma nounroll
+  for (int pass = 0; pass < (a.persist ? 2 * a.persist : 1); ++pass) {
+    const int xp = xb0 + (pass >> 1) * nwx;
+    const int xb = ((pass & 1) != (a.persist_rev != 0)) ? nkb - 1 - xp : xp;
+    const int64_t k0 = (int64_t)xb * K4B, kw = k0 + wid * 32, n = kw + xl;
 
     frag_t kf[8], vf[8]; // this wave's 32 keys: B operands of S = Q K^T and dP = dO V^T
     {
@@ -1110,6 +1135,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     __syncthreads();
     a_store_rows<BF>(smem + wid * 32 * OPAD, a.dv + (bh * a.Skv + kw) * AROW, dv, 1.f);
     a_store_rows<BF>(smem + wid * 32 * OPAD, a.dk + (bh * a.Skv + kw) * AROW, dk, a.scale);
+    if (a.persist) __syncthreads(); // the staging slabs overlap the ring the next block fills
+  }
 }
 
 // ==========================================================================================
@@ -1538,7 +1565,9 @@ extern "C" int kf_attn_fwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, i
     a.defer = getenv("KF_ATTN_NO_DEFER") ? -INFINITY : kDeferMax; // A/B switch: rescale O at every tile
     if (mfma_ok(dtype, Sq, Skv, D)) {
         const size_t lds3 = SRING * FBUF;
-        dim3 grid3((unsigned)(((Sq + FQ - 1) / FQ) * B * H));
+        const int64_t nxb3 = (Sq + FQ - 1) / FQ;
+        a.persist = (nxb3 % 2 == 0 && nxb3 >= 4 && !getenv("KF_ATTN_NO_PAIR")) ? 1 : 0;
+        dim3 grid3((unsigned)((a.persist ? nxb3 / (2 * a.persist) : nxb3) * B * H));
         KF_PROF("attn_fwd_mfma", st);
         if ((rc = set_lds(attn_fwd_v3_kernel<true>, lds3)) != KF_OK) return rc;
         if ((rc = set_lds(attn_fwd_v3_kernel<false>, lds3)) != KF_OK) return rc;
@@ -1636,7 +1665,10 @@ extern "C" int kf_attn_bwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, i
             KF_LAUNCH_CHECK();
         }
         if (!getenv("KF_ATTN_DKV_V2")) { // default: one wave per SIMD, pinned MFMA / VALU interleave
-            dim3 gk4((unsigned)((Skv / K4B) * B * H));
+            const int64_t nkb4 = Skv / K4B;
+            a.persist = (nkb4 % 2 == 0 && nkb4 >= 4 && !getenv("KF_ATTN_NO_PAIR")) ? 1 : 0;
+            a.persist_rev = 1; // the short block of the pair first: 2.17 ms against 2.32 the other way round (2.22 unpaired)
+            dim3 gk4((unsigned)((a.persist ? nkb4 / 2 : nkb4) * B * H));
             if ((rc = set_lds(attn_bwd_dkv_v4_kernel<true>, K4LDS)) != KF_OK) return rc;
             if ((rc = set_lds(attn_bwd_dkv_v4_kernel<false>, K4LDS)) != KF_OK) return rc;
             KF_PROF("attn_bwd_dkv_mfma", st);
@@ -1644,6 +1676,7 @@ extern "C" int kf_attn_bwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, i
             else attn_bwd_dkv_v4_kernel<false><<<gk4, 256, K4LDS, st>>>(a);
             KF_LAUNCH_CHECK();
         } else { // A/B switch: the two-waves-per-SIMD kernel it replaced
+            a.persist = 0;
             dim3 gk2((unsigned)(((Skv + KVB - 1) / KVB) * B * H));
             if ((rc = set_lds(attn_bwd_dkv_v2_kernel<true>, KLDS)) != KF_OK) return rc;
             if ((rc = set_lds(attn_bwd_dkv_v2_kernel<false>, KLDS)) != KF_OK) return rc;
@@ -1653,7 +1686,10 @@ extern "C" int kf_attn_bwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, i
             KF_LAUNCH_CHECK();
         }
         {
-            dim3 gq2((unsigned)(((Sq + FQ - 1) / FQ) * B * H));
+            const int64_t nxq = (Sq + FQ - 1) / FQ;
+            a.persist = (nxq % 2 == 0 && nxq >= 4 && !getenv("KF_ATTN_NO_PAIR")) ? 1 : 0;
+            a.persist_rev = 0;
+            dim3 gq2((unsigned)((a.persist ? nxq / 2 : nxq) * B * H));
             if ((rc = set_lds(attn_bwd_dq_v2_kernel<true>, QLDS)) != KF_OK) return rc;
             if ((rc = set_lds(attn_bwd_dq_v2_kernel<false>, QLDS)) != KF_OK) return rc;
             KF_PROF("attn_bwd_dq_mfma", st);
