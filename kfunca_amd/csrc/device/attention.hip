@@ -1157,15 +1157,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_mfma_kernel(const AttnArg
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *Ks = (float *)smem, *Vs = Ks + XK * DP;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5, t = threadIdx.x;
-    int xb;
+    int xb0;
     int64_t bh;
     const int nxb = (int)((a.Sq + XQ - 1) / XQ);
-    a_block_map(nxb, (int)(a.B * a.H), a.xcd_map, xb, bh);
+    const int nwx = a.persist ? nxb / (2 * a.persist) : nxb; // a.persist: a block and its causal mirror per workgroup (see attn_fwd_v3_kernel)
+    a_block_map(nwx, (int)(a.B * a.H), a.xcd_map, xb0, bh);
+    const float *Kg = (const float *)a.k + bh * a.Skv * D;
+    const float *Vg = (const float *)a.v + bh * a.Skv * D;
+  for (int pass = 0; pass < (a.persist ? 2 * a.persist : 1); ++pass) {
+    const int xp = xb0 + (pass >> 1) * nwx;
+    const int xb = (pass & 1) ? nxb - 1 - xp : xp;
     const int qblk = nxb - 1 - xb; // longest blocks first
     const int64_t q0 = (int64_t)qblk * XQ, qw = q0 + wid * 32, m = qw + xl;
     const bool active = qw < a.Sq; // Sq % 32 == 0: whole waves
-    const float *Kg = (const float *)a.k + bh * a.Skv * D;
-    const float *Vg = (const float *)a.v + bh * a.Skv * D;
 
     float qreg[HD];
     if (active) {
@@ -1284,6 +1288,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_mfma_kernel(const AttnArg
         }
         if (a.lse && hl == 0) a.lse[bh * a.Sq + m] = (m_i * c + __builtin_amdgcn_logf(l_i)) * kLn2;
     }
+    // (the next block's first __syncthreads() comes before its first tile store: the slabs are read by then)
+  }
 }
 
 // ==========================================================================================
@@ -1579,7 +1585,9 @@ extern "C" int kf_attn_fwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, i
     if (dtype == KF_F32 && (D == 64 || D == 128) && Sq % 32 == 0 && Skv % 32 == 0 && !getenv("KF_ATTN_F32_GENERIC")) {
         // the reference's own fast path (f32, head size 64 or 128): exact-f32 MFMA
         const size_t ldsx = std::max((size_t)2 * XK * (D + 4), (size_t)4 * 32 * (D + 4)) * sizeof(float);
-        dim3 gridx((unsigned)(((Sq + XQ - 1) / XQ) * B * H));
+        const int64_t nxx = (Sq + XQ - 1) / XQ;
+        a.persist = (nxx % 2 == 0 && nxx >= 4 && !getenv("KF_ATTN_NO_PAIR")) ? 1 : 0;
+        dim3 gridx((unsigned)((a.persist ? nxx / 2 : nxx) * B * H));
         KF_PROF("attn_fwd_f32_mfma", st);
         if (D == 128) {
             if ((rc = set_lds(attn_fwd_f32_mfma_kernel<128>, ldsx)) != KF_OK) return rc;
