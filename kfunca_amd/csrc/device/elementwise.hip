@@ -263,6 +263,39 @@ __global__ __launch_bounds__(kBlock) void ew_transpose_kernel(const TransArgs a)
     }
 }
 
+// The same tile with 16-byte global accesses on BOTH sides (4- and 2-byte elements, whole tiles, 16-byte aligned rows): a lane
+// loads one pack of V = 16 / sizeof(U) consecutive elements of an input row, scatters it into the tile with V LDS stores,
+// then gathers V elements of one tile COLUMN (V LDS loads) into the pack it stores to the output row. One tile per block.
+// Row stride TD + 1 (4-byte elements: a lane group's V-row steps land on distinct banks) or TD + 2 (2-byte).
+template <typename U>
+__global__ __launch_bounds__(kBlock) void ew_transpose_vec_kernel(const TransArgs a) {
+    constexpr int TD = 64, V = 16 / (int)sizeof(U), G = TD / V; // packs per tile row
+    __shared__ U tile[TD][TD + (sizeof(U) >= 4 ? 1 : 2)];
+    const uint32_t blk = blockIdx.x;
+    const uint32_t bt = blk / (a.tiles0 * a.tiles1), rem = blk - bt * (a.tiles0 * a.tiles1);
+    const uint32_t t1 = rem / a.tiles0, t0 = rem - t1 * a.tiles0;
+    uint32_t boff[2];
+    a.bc.get(bt, boff);
+    const uint32_t i0 = t0 * TD, j0 = t1 * TD;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < TD * G / kBlock; ++k) { // input rows (dim 0), packs along dim j
+        const int id = t + k * kBlock, r = id / G, g = id % G;
+        const Pack<U, V> p = *(const Pack<U, V> *)(a.in + boff[1] + (size_t)(i0 + r) * a.in_s0 + (size_t)(j0 + g * V) * sizeof(U));
+#pragma unroll
+        for (int e = 0; e < V; ++e) tile[r][g * V + e] = p.v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TD * G / kBlock; ++k) { // output rows (dim j), packs along dim 0
+        const int id = t + k * kBlock, r = id / G, g = id % G;
+        Pack<U, V> p;
+#pragma unroll
+        for (int e = 0; e < V; ++e) p.v[e] = tile[g * V + e][r];
+        *(Pack<U, V> *)(a.out + boff[0] + (size_t)(j0 + r) * a.out_s1 + (size_t)(i0 + g * V) * sizeof(U)) = p;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // contiguous float-family conversion (f32 <-> bf16 <-> f16: Tensor::half()/bfloat16()/float()),
 // 8 elements per lane: 16-B accesses on the 16-bit side, 2 x 16 B on the f32 side
@@ -385,8 +418,17 @@ static int launch_same(const kf_iter_desc *d, int op, uint64_t fill_bits, hipStr
             const int64_t total = (int64_t)t.tiles0 * t.tiles1 * nbatch;
             if (OffsetCalc<2>::build(t.bc, &bd, two, 1) && total < 0x7fffffffLL) {
                 t.nbatch = (uint32_t)nbatch;
-                const int grid = (int)(total < 256 * 16 ? total : 256 * 16);
-                ew_transpose_kernel<T><<<grid, kBlock, 0, st>>>(t);
+                // whole tiles, 16-byte aligned rows on both sides and every batch offset: the 16-byte-per-lane form
+                bool vec_ok = (sizeof(T) == 4 || sizeof(T) == 2) && t.n0 % 64 == 0 && t.n1 % 64 == 0 && t.in_s0 % 16 == 0 && t.out_s1 % 16 == 0 &&
+                              (uintptr_t)t.in % 16 == 0 && (uintptr_t)t.out % 16 == 0;
+                for (int i = 0; vec_ok && i < nb; ++i)
+                    if (bd.stride_bytes[0][i] % 16 || bd.stride_bytes[1][i] % 16) vec_ok = false;
+                if (vec_ok) {
+                    if constexpr (sizeof(T) == 4 || sizeof(T) == 2) ew_transpose_vec_kernel<T><<<(unsigned)total, kBlock, 0, st>>>(t);
+                } else {
+                    const int grid = (int)(total < 256 * 16 ? total : 256 * 16);
+                    ew_transpose_kernel<T><<<grid, kBlock, 0, st>>>(t);
+                }
                 KF_LAUNCH_CHECK();
                 return KF_OK;
             }

@@ -229,7 +229,7 @@ def test_tiled_transpose_and_vector_convert_paths():
     rng = np.random.default_rng(11)
     for code in (H.U8, H.I16, H.F32, H.F64, H.BF16):
         for shape, perm in (((70, 130), (1, 0)), ((3, 65, 129), (0, 2, 1)), ((5, 33, 4, 70), (3, 1, 2, 0)), ((2, 256, 64), (2, 0, 1)),
-                            ((17, 16), (1, 0))):
+                            ((17, 16), (1, 0)), ((128, 192), (1, 0)), ((3, 128, 64), (0, 2, 1)), ((2, 3, 64, 128), (1, 0, 3, 2))):  # whole tiles: 16-byte form
             x = rand_of(rng, shape, code)
             v = x.transpose(perm)
             got = gpu_copy(Dev(v, code, base=x), Dev.empty(v.shape, code)).get()
