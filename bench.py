@@ -160,6 +160,7 @@ def main():
         h = C.c_void_p()
         H.check(H.lib().kf_comm_init(C.byref(h), ident[0], rank, world))
         comm = h.value
+        C.CDLL(None).fflush(None)  # RCCL leaves its version banner in the C stdout buffer: out with it now, so the JSON line is the last line
 
     wl = Workload(rank)
     stream = H.Stream()
@@ -235,9 +236,13 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
     if comm is not None:
         H.check(lib.kf_comm_destroy(comm))
+    C.CDLL(None).fflush(None)
+    if dist is not None:
+        dist.barrier()  # every rank's library output is out before rank 0 prints THE line
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
