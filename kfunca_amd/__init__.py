@@ -30,8 +30,13 @@ def _load():
     return _native
 
 
+_SUBMODULES = ("_build", "_C", "hip_abi", "parallel")
+
+
 def __getattr__(name):
-    if name.startswith("__"):
+    # `from kfunca_amd import _build` asks the package for the attribute first: submodule names must fall through to the
+    # import system (AttributeError), or a clean checkout could never build the native module it is about to be told is missing
+    if name.startswith("__") or name in _SUBMODULES:
         raise AttributeError(name)
     return getattr(_load(), name)
 
