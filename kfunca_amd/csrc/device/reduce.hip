@@ -285,6 +285,53 @@ __global__ __launch_bounds__(kRB) void reduce_outer_kernel(const RedArgs a, cons
     }
 }
 
+// ---- outer, small problems: ONE launch. A block is 16 columns x 16 row groups (a split over blocks would need the fold
+// launch: two launches of ~10 us each are what a 1024 x 1024 column sum cost). Each lane walks R / 16 rows with 8 loads in
+// flight, the 16 row groups meet in LDS in fixed order - same bits run to run.
+template <typename T, typename Ops>
+__global__ __launch_bounds__(kRB) void reduce_outer_tall_kernel(const RedArgs a, const typename Ops::Fin fin) {
+    using A = typename Ops::A;
+    using X = typename Ops::X;
+    __shared__ A smem[16][17];
+    const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int64_t c = (int64_t)blockIdx.x * 16 + lx;
+    const bool live = c < a.C;
+    for (uint32_t z = blockIdx.z; z < a.nouter; z += gridDim.z) {
+        uint32_t off[3];
+        a.oc.get(z, off);
+        A acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = Ops::zero();
+        if (live) {
+            const char *col = a.in + off[1] + c * sizeof(T);
+            int64_t r = ly;
+            for (; r + 112 < a.R; r += 128) {
+                X x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = r_load<T>(col + (r + 16 * u) * a.r_stride);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const X one[1] = {x[u]};
+                    Ops::template add_pack<1>(acc[u], one);
+                }
+            }
+            for (; r < a.R; r += 16) {
+                const X one[1] = {r_load<T>(col + r * a.r_stride)};
+                Ops::template add_pack<1>(acc[0], one);
+            }
+        }
+        A tot = Ops::comb(Ops::comb(Ops::comb(acc[0], acc[1]), Ops::comb(acc[2], acc[3])), Ops::comb(Ops::comb(acc[4], acc[5]), Ops::comb(acc[6], acc[7])));
+        __syncthreads();
+        smem[ly][lx] = tot;
+        __syncthreads();
+        if (ly == 0 && live) {
+            A t = smem[0][lx];
+            for (int g = 1; g < 16; ++g) t = Ops::comb(t, smem[g][lx]);
+            fin.store(a, off[0], off[2], (uint32_t)c, t);
+        }
+    }
+}
+
 // second stage: fold partials[nsplit][nout] in split order
 template <typename T, typename Ops>
 __global__ __launch_bounds__(kRB) void reduce_fold_kernel(const RedArgs a, const typename Ops::Fin fin, int outer_layout) {
@@ -333,6 +380,7 @@ struct Plan {
     int vec = 1;
     int tx = 1;
     int nsplit = 1;
+    bool tall = false; // outer path: single-launch 16-column x 16-row-group blocks (small problems)
     int64_t R = 1, r_stride = 0, C = 1;
     int64_t nout = 1, nouter = 1, rtot = 1;
     int red_dims[KF_MAX_DIMS], nred = 0;
@@ -430,6 +478,12 @@ static int make_plan(const kf_iter_desc *d, Plan &p, bool moments = false) {
             if (ns < 1) ns = 1;
         }
         p.nsplit = (int)ns;
+        // small column reductions that would be split: one launch of 16-column x 16-row-group blocks instead of split + fold
+        const int64_t in_bytes = p.R * p.C * p.nouter * es;
+        if (ns > 1 && in_bytes <= ((int64_t)16 << 20) && (p.C + 15) / 16 * p.nouter >= 32 && !getenv("KF_REDUCE_NO_TALL")) {
+            p.tall = true;
+            p.nsplit = 1;
+        }
     } else {
         p.path = PATH_GENERIC;
     }
@@ -500,6 +554,12 @@ static int run_reduce(const char *what, const kf_iter_desc *d, const Plan &p, co
         // out_dims[0] is dim 1 (the contiguous one) because dims are visited in order
         KF_REQUIRE(build_out_calc(1), KF_ERR_INVALID, "kf_reduce: bad shape/stride");
         const int64_t gx = (p.C + (int64_t)kWave * p.vec - 1) / ((int64_t)kWave * p.vec);
+        if (p.tall) {
+            dim3 gt((unsigned)((p.C + 15) / 16), 1, (unsigned)(p.nouter < 1024 ? p.nouter : 1024));
+            reduce_outer_tall_kernel<T, Ops><<<gt, kRB, 0, st>>>(a, fin);
+            KF_LAUNCH_CHECK();
+            return KF_OK;
+        }
         dim3 grid((unsigned)gx, (unsigned)p.nsplit, (unsigned)(p.nouter < 1024 ? p.nouter : 1024));
         if (p.vec > 1)
             reduce_outer_kernel<T, Ops, 16 / sizeof(T)><<<grid, kRB, 0, st>>>(a, fin);
