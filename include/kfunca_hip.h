@@ -228,7 +228,8 @@ enum {
  *   trans_b == 0: B is stored [K,N] (ldb >= N);  trans_b == 1: B is stored [N,K] (ldb >= K)
  * dtype in {KF_F32, KF_F64, KF_F16, KF_BF16}; A, B, C share it; accumulation is f32 (f64 for f64).
  * beta == 0 never reads C (the reference reads uninitialised memory there, gemm_ops.cpp:10-16).
- * f16/bf16 may need scratch for operand re-layout: kf_gemm_workspace_bytes() says how much.
+ * Every kernel reads every operand layout in place: kf_gemm_workspace_bytes() reports 0 for every shape (the query and the
+ * workspace arguments stay for ABI stability; pass NULL / 0).
  */
 int kf_gemm_workspace_bytes(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, size_t *bytes);
 int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const void *A,
@@ -252,8 +253,8 @@ int kf_attn_fwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_
 int kf_attn_fwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, float scale, const void *q,
                        const void *k, const void *v, void *o, float *lse, void *stream);
 /*
- * dq,dk,dv from d_o. Needs o and lse from the forward. workspace holds delta[B,H,Sq] f32 and an
- * f32 dq accumulator; kf_attn_bwd_workspace_bytes() says how much; no initialisation needed.
+ * dq,dk,dv from d_o. Needs o and lse from the forward. workspace holds delta[B,H,Sq] f32 and the two
+ * row-constant arrays the dK/dV kernel reads; kf_attn_bwd_workspace_bytes() says how much; no initialisation needed.
  */
 int kf_attn_bwd_workspace_bytes(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D,
                                 size_t *bytes);

@@ -268,7 +268,50 @@ __device__ __forceinline__ void h_stage(const char *gbase, int64_t ld_bytes, int
     }
 }
 
-template <bool BF>
+typedef __attribute__((ext_vector_type(4))) short g_s16x4;
+typedef __attribute__((ext_vector_type(8))) short g_s16x8;
+
+// An operand whose contraction dim is the strided one (A stored [K,M], B stored [K,N]) is staged as it lies in memory: a
+// [64 k][128 rows / columns] image with 256-B rows, 16-B chunk ch of k-row r at chunk position
+// ch ^ (((r & 3) << 2) | ((r >> 2) & 3)) (conflict-free for the 4-row x 16-column blocks ds_read_b64_tr_b16 moves; the same
+// image as the attention kernels' K / V tiles). One wave-instruction moves 4 k-rows x 256 B.
+__device__ __forceinline__ int h_tr_off(int row, int ch) { return row * 256 + ((ch ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
+__device__ __forceinline__ void h_stage_tr(const char *gbase, int64_t ld_bytes, int64_t x0, int64_t k0, char *lds_tile) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row0 = (wid * 4 + i) * 4;
+        const int row = row0 + (lane >> 4), pos = lane & 15;
+        const int chunk = pos ^ (((row & 3) << 2) | ((row >> 2) & 3));
+        const char *src = gbase + (k0 + row) * ld_bytes + (x0 + chunk * 8) * 2;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                         (__attribute__((address_space(3))) void *)(lds_tile + row0 * 256), 16, 0, 0);
+    }
+}
+// 32 (rows / columns cb..cb+31) x 16 (k) fragment in the STANDARD k order (lane half h holds k = 8 h .. 8 h + 7): two
+// transposed reads of k-rows 8 h + {0..3} and 8 h + {4..7}. Per-lane offsets of the two reads for k-step 0; k-step ks adds
+// ks * 16 * 256 (the swizzle only sees the row modulo 16).
+__device__ __forceinline__ void h_tr_lane_off(int cb, int (&off)[2]) {
+    const int lane = threadIdx.x & 63;
+    const int gq = lane >> 4, ii = lane & 15, qq = ii >> 2, p = ii & 3, h = gq >> 1;
+    const int ch = ((cb + 16 * (gq & 1)) >> 3) + (p >> 1);
+#pragma unroll
+    for (int second = 0; second < 2; ++second) off[second] = h_tr_off(8 * h + qq + 4 * second, ch) + 8 * (p & 1);
+}
+template <bool BF, int OFF>
+__device__ __forceinline__ typename HFrag<BF>::type h_tr_frag(unsigned a0, unsigned a1) {
+    g_s16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%c4\n\tds_read_b64_tr_b16 %1, %3 offset:%c4"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(a0), "v"(a1), "n"(OFF)
+                 : "memory");
+    g_s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(typename HFrag<BF>::type, r);
+}
+
+template <bool BF, bool TRA, bool TRB>
 __global__ __launch_bounds__(256) void gemm_h_kernel(const GemmArgs g) {
     using frag_t = typename HFrag<BF>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[]; // [2 buffers][A tile | B tile]
@@ -289,31 +332,42 @@ __global__ __launch_bounds__(256) void gemm_h_kernel(const GemmArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    h_stage(A, lda_b, m0, 0, smem);
-    h_stage(B, ldb_b, n0, 0, smem + H_TILE_BYTES);
+    auto stage_tile = [&](int t, char *buf) __attribute__((always_inline)) {
+        if constexpr (TRA) h_stage_tr(A, lda_b, m0, (int64_t)t * H_BK, buf);
+        else h_stage(A, lda_b, m0, (int64_t)t * H_BK * 2, buf);
+        if constexpr (TRB) h_stage_tr(B, ldb_b, n0, (int64_t)t * H_BK, buf + H_TILE_BYTES);
+        else h_stage(B, ldb_b, n0, (int64_t)t * H_BK * 2, buf + H_TILE_BYTES);
+    };
+    int toffA[2][2], toffB[2][2]; // transposed-read operands: [tile i][first / second read]
+    if constexpr (TRA) { h_tr_lane_off(wr * 64, toffA[0]); h_tr_lane_off(wr * 64 + 32, toffA[1]); }
+    if constexpr (TRB) { h_tr_lane_off(wc * 64, toffB[0]); h_tr_lane_off(wc * 64 + 32, toffB[1]); }
+    const unsigned smem_u = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)smem;
+
+    stage_tile(0, smem);
     __syncthreads(); // emits s_waitcnt vmcnt(0) for the LDS-DMA in flight, then s_barrier
 
     const int nt = (int)(g.K / H_BK);
     for (int t = 0; t < nt; ++t) {
         char *cur = smem + (t & 1) * 2 * H_TILE_BYTES;
         char *nxt = smem + ((t + 1) & 1) * 2 * H_TILE_BYTES;
-        if (t + 1 < nt) {
-            h_stage(A, lda_b, m0, (int64_t)(t + 1) * H_BK * 2, nxt);
-            h_stage(B, ldb_b, n0, (int64_t)(t + 1) * H_BK * 2, nxt + H_TILE_BYTES);
+        const unsigned cur_u = smem_u + (unsigned)((t & 1) * 2 * H_TILE_BYTES);
+        if (t + 1 < nt) stage_tile(t + 1, nxt);
+#define KF_H_STEP(KS)                                                                                                  \
+        {                                                                                                              \
+            frag_t a[2], b[2];                                                                                         \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                            \
+                if constexpr (TRA) a[i] = h_tr_frag<BF, (KS) * 16 * 256>(cur_u + toffA[i][0], cur_u + toffA[i][1]);     \
+                else a[i] = *(const frag_t *)(cur + h_lds_off(wr * 64 + i * 32 + xl, (KS) * 2 + hl));                  \
+                if constexpr (TRB) b[i] = h_tr_frag<BF, (KS) * 16 * 256>(cur_u + H_TILE_BYTES + toffB[i][0], cur_u + H_TILE_BYTES + toffB[i][1]); \
+                else b[i] = *(const frag_t *)(cur + H_TILE_BYTES + h_lds_off(wc * 64 + i * 32 + xl, (KS) * 2 + hl));   \
+            }                                                                                                          \
+            if constexpr (TRA || TRB) /* the asm-issued reads are invisible to the compiler's wait insertion */        \
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : : "memory");     \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                              \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = h_mfma<BF>(a[i], b[j], acc[i][j]);           \
         }
-#pragma unroll
-        for (int ks = 0; ks < H_BK / 16; ++ks) {
-            frag_t a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = *(const frag_t *)(cur + h_lds_off(wr * 64 + i * 32 + xl, ks * 2 + hl));
-                b[i] = *(const frag_t *)(cur + H_TILE_BYTES + h_lds_off(wc * 64 + i * 32 + xl, ks * 2 + hl));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = h_mfma<BF>(a[i], b[j], acc[i][j]);
-        }
+        KF_H_STEP(0) KF_H_STEP(1) KF_H_STEP(2) KF_H_STEP(3)
+#undef KF_H_STEP
         __syncthreads();
     }
 
@@ -371,8 +425,6 @@ constexpr int G_HALF = 128 * G_BK * 2 + 256; // 16 KiB + the transposed image's 
 constexpr int G_TILE = 4 * G_HALF;          // HA0 | HB0 | HA1 | HB1
 constexpr int G_LDS = 2 * G_TILE;           // 130 KiB
 
-typedef __attribute__((ext_vector_type(4))) short g_s16x4;
-typedef __attribute__((ext_vector_type(8))) short g_s16x8;
 
 // one 16 (m or n) x 32 (k) fragment out of a [k][256 B] image: rows 8*(lane>>4) + {0..3} and + {4..7} of the k-step
 template <bool BF, int OFF>
@@ -898,48 +950,6 @@ __global__ __launch_bounds__(W4_NT) void gemm_w4_kernel(const GemmArgs g) {
     }
 }
 
-// tiled 16-bit transpose: dst[c][r] = src[r][c]; 64x64 tiles through LDS, bit-exact. Full tiles with 16-byte
-// aligned rows move 16 B per lane on both the read and the write side (the LDS tile is written transposed,
-// 2 bytes at a time, and read back along the new contiguous dim); ragged tiles fall back to 2-byte accesses.
-__global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t *src, int64_t ld_src, uint16_t *dst, int64_t ld_dst,
-                                                           int64_t R, int64_t Cc) {
-    __shared__ __attribute__((aligned(16))) uint16_t tile[64][72]; // [c][r], 144-B rows keep 16-B alignment
-    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
-    const int t = threadIdx.x;
-    const bool fast = r0 + 64 <= R && c0 + 64 <= Cc && ld_src % 8 == 0 && ld_dst % 8 == 0 && ((uintptr_t)src % 16 == 0) &&
-                      ((uintptr_t)dst % 16 == 0);
-    if (fast) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = t + 256 * i, r = id >> 3, cq = id & 7; // row r, columns 8*cq .. 8*cq+7
-            const uint4 v = *(const uint4 *)(src + (r0 + r) * ld_src + c0 + cq * 8);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                tile[cq * 8 + 2 * e][r] = (uint16_t)(w[e] & 0xffff);
-                tile[cq * 8 + 2 * e + 1][r] = (uint16_t)(w[e] >> 16);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = t + 256 * i, c = id >> 3, rq = id & 7;
-            *(uint4 *)(dst + (c0 + c) * ld_dst + r0 + rq * 8) = *(const uint4 *)&tile[c][rq * 8];
-        }
-        return;
-    }
-    const int tx = t & 63, ty = t >> 6;
-    for (int i = ty; i < 64; i += 4) {
-        const int64_t r = r0 + i, c = c0 + tx;
-        if (r < R && c < Cc) tile[tx][i] = src[r * ld_src + c];
-    }
-    __syncthreads();
-    for (int i = ty; i < 64; i += 4) {
-        const int64_t c = c0 + i, r = r0 + tx;
-        if (r < R && c < Cc) dst[c * ld_dst + r] = tile[i][tx];
-    }
-}
-
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 static bool h_fast_ok(int64_t M, int64_t N, int64_t K) { return M % H_BM == 0 && N % H_BN == 0 && K % H_BK == 0 && M > 0 && N > 0 && K > 0; }
@@ -958,11 +968,8 @@ static bool h256_ok(int64_t M, int64_t N, int64_t K) {
 extern "C" int kf_gemm_workspace_bytes(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, size_t *bytes) {
     KF_REQUIRE(bytes, KF_ERR_INVALID, "kf_gemm_workspace_bytes: null out pointer");
     *bytes = 0;
-    // the 256-tile kernel reads every layout in place; the 128-tile one wants K-contiguous operands and re-lays the others
-    if ((dtype == KF_BF16 || dtype == KF_F16) && h_fast_ok(M, N, K) && !h256_ok(M, N, K)) {
-        if (trans_a) *bytes += align_up((size_t)M * K * 2, 256);
-        if (!trans_b) *bytes += align_up((size_t)K * N * 2, 256);
-    }
+    // every kernel reads every operand layout in place: no GEMM needs scratch (the entry stays for ABI stability)
+    (void)dtype; (void)trans_a; (void)trans_b; (void)M; (void)N; (void)K;
     return KF_OK;
 }
 
@@ -1044,39 +1051,23 @@ extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N
             KF_PROF(dtype == KF_BF16 ? "gemm_bf16_mfma" : "gemm_f16_mfma", st);
             return dtype == KF_BF16 ? launch_h256<true>(g, trans_a != 0, !trans_b, st) : launch_h256<false>(g, trans_a != 0, !trans_b, st);
         }
-        size_t need = 0;
-        if (trans_a) need += align_up((size_t)M * K * 2, 256);
-        if (!trans_b) need += align_up((size_t)K * N * 2, 256);
-        KF_REQUIRE(need == 0 || (workspace && workspace_bytes >= need && (uintptr_t)workspace % 16 == 0), KF_ERR_WORKSPACE,
-                   "kf_gemm: workspace of %zu bytes (16-B aligned) required, got %zu", need, workspace_bytes);
-        char *ws = (char *)workspace;
-        if (trans_a) { // stored [K,M] -> [M,K]
-            dim3 grid((unsigned)((M + 63) / 64), (unsigned)((K + 63) / 64));
-            KF_PROF("gemm_relayout16", st);
-            transpose16_kernel<<<grid, 256, 0, st>>>((const uint16_t *)A, lda, (uint16_t *)ws, K, K, M);
-            KF_LAUNCH_CHECK();
-            g.A = ws;
-            g.lda = K;
-            ws += align_up((size_t)M * K * 2, 256);
-        }
-        if (!trans_b) { // stored [K,N] -> [N,K]
-            dim3 grid((unsigned)((N + 63) / 64), (unsigned)((K + 63) / 64));
-            KF_PROF("gemm_relayout16", st);
-            transpose16_kernel<<<grid, 256, 0, st>>>((const uint16_t *)B, ldb, (uint16_t *)ws, K, K, N);
-            KF_LAUNCH_CHECK();
-            g.B = ws;
-            g.ldb = K;
-        }
         const unsigned grid = (unsigned)((M / H_BM) * (N / H_BN));
         const size_t lds = 4 * H_TILE_BYTES;
         KF_PROF(dtype == KF_BF16 ? "gemm_bf16_mfma_128" : "gemm_f16_mfma_128", st);
-        if (dtype == KF_BF16) {
-            KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_h_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            gemm_h_kernel<true><<<grid, 256, lds, st>>>(g);
-        } else {
-            KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_h_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            gemm_h_kernel<false><<<grid, 256, lds, st>>>(g);
-        }
+        const bool tra = trans_a != 0, trb = !trans_b; // transposed-read operands: consumed as they lie in memory, no re-layout pass
+#define KF_H128(BF_, TA, TB)                                                                                                   \
+    {                                                                                                                          \
+        KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_h_kernel<BF_, TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        gemm_h_kernel<BF_, TA, TB><<<grid, 256, lds, st>>>(g);                                                                 \
+    }
+#define KF_H128_L(BF_)                                  \
+    if (!tra && !trb) KF_H128(BF_, false, false)         \
+    else if (!tra && trb) KF_H128(BF_, false, true)      \
+    else if (tra && !trb) KF_H128(BF_, true, false)      \
+    else KF_H128(BF_, true, true)
+        if (dtype == KF_BF16) { KF_H128_L(true) } else { KF_H128_L(false) }
+#undef KF_H128_L
+#undef KF_H128
         KF_LAUNCH_CHECK();
         return KF_OK;
     }
