@@ -124,23 +124,26 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GemmArgs g, int
 // ------------------------------------------------------------------------------------------
 constexpr int F_BM = 128, F_BN = 128, F_BK = 16, F_LD = 132;
 
-// stage one operand tile (128 x 16) into registers; KCONTIG: global rows are along the 128-axis
-// with k contiguous; else global rows are k with the 128-axis contiguous. (Two named float4s, not
-// an array: hipcc keeps a by-reference float4[2] in scratch.)
-template <bool KCONTIG>
+// stage one operand tile (T x 16, T = 128 or 64) into registers; KCONTIG: global rows are along the T-axis with k contiguous;
+// else global rows are k with the T-axis contiguous. (Two named float4s, not an array: hipcc keeps a by-reference float4[2]
+// in scratch; the 64-wide tile uses the first one only.)
+template <bool KCONTIG, int T>
 __device__ __forceinline__ void f32_load_tile(const float *base, int64_t ld, int64_t x0, int64_t k0, float4 &r0, float4 &r1) {
     const int t = threadIdx.x;
     if constexpr (KCONTIG) {
         const int row = t / 4, kq = t % 4;
         r0 = *(const float4 *)(base + (x0 + row) * ld + k0 + kq * 4);
-        r1 = *(const float4 *)(base + (x0 + row + 64) * ld + k0 + kq * 4);
-    } else {
+        if constexpr (T == 128) r1 = *(const float4 *)(base + (x0 + row + 64) * ld + k0 + kq * 4);
+    } else if constexpr (T == 128) {
         const int k = t / 32, xq = t % 32;
         r0 = *(const float4 *)(base + (k0 + k) * ld + x0 + xq * 4);
         r1 = *(const float4 *)(base + (k0 + k + 8) * ld + x0 + xq * 4);
+    } else {
+        const int k = t / 16, xq = t % 16;
+        r0 = *(const float4 *)(base + (k0 + k) * ld + x0 + xq * 4);
     }
 }
-template <bool KCONTIG>
+template <bool KCONTIG, int T>
 __device__ __forceinline__ void f32_write_tile(float (*s)[F_LD], const float4 &r0, const float4 &r1) {
     const int t = threadIdx.x;
     if constexpr (KCONTIG) {
@@ -149,42 +152,50 @@ __device__ __forceinline__ void f32_write_tile(float (*s)[F_LD], const float4 &r
         s[kq * 4 + 1][row] = r0.y;
         s[kq * 4 + 2][row] = r0.z;
         s[kq * 4 + 3][row] = r0.w;
-        s[kq * 4 + 0][row + 64] = r1.x;
-        s[kq * 4 + 1][row + 64] = r1.y;
-        s[kq * 4 + 2][row + 64] = r1.z;
-        s[kq * 4 + 3][row + 64] = r1.w;
-    } else {
+        if constexpr (T == 128) {
+            s[kq * 4 + 0][row + 64] = r1.x;
+            s[kq * 4 + 1][row + 64] = r1.y;
+            s[kq * 4 + 2][row + 64] = r1.z;
+            s[kq * 4 + 3][row + 64] = r1.w;
+        }
+    } else if constexpr (T == 128) {
         const int k = t / 32, xq = t % 32;
         *(float4 *)&s[k][xq * 4] = r0;
         *(float4 *)&s[k + 8][xq * 4] = r1;
+    } else {
+        const int k = t / 16, xq = t % 16;
+        *(float4 *)&s[k][xq * 4] = r0;
     }
 }
 
-template <bool TA, bool TB>
+// T = 128: 2 x 2 MFMA tiles per wave; T = 64 (small problems: four times as many blocks): one
+template <bool TA, bool TB, int T>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
+    constexpr int NI = T / 64;
     __shared__ __attribute__((aligned(16))) float As[2][F_BK][F_LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][F_BK][F_LD];
     const float *A = (const float *)g.A, *B = (const float *)g.B;
     float *C = (float *)g.C;
-    const uint32_t tiles_n = (uint32_t)(g.N / F_BN);
+    const uint32_t tiles_n = (uint32_t)(g.N / T);
     const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int64_t m0 = (int64_t)(tile / tiles_n) * F_BM, n0 = (int64_t)(tile % tiles_n) * F_BN;
+    const int64_t m0 = (int64_t)(tile / tiles_n) * T, n0 = (int64_t)(tile % tiles_n) * T;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int wr = wid >> 1, wc = wid & 1;
 
-    f32x16 acc[2][2];
+    f32x16 acc[NI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     float4 ra0, ra1, rb0, rb1;
-    f32_load_tile<!TA>(A, g.lda, m0, 0, ra0, ra1);
-    f32_load_tile<TB>(B, g.ldb, n0, 0, rb0, rb1);
-    f32_write_tile<!TA>(As[0], ra0, ra1);
-    f32_write_tile<TB>(Bs[0], rb0, rb1);
+    ra1 = rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32_load_tile<!TA, T>(A, g.lda, m0, 0, ra0, ra1);
+    f32_load_tile<TB, T>(B, g.ldb, n0, 0, rb0, rb1);
+    f32_write_tile<!TA, T>(As[0], ra0, ra1);
+    f32_write_tile<TB, T>(Bs[0], rb0, rb1);
     __syncthreads();
 
     const int nt = (int)(g.K / F_BK);
@@ -192,39 +203,39 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
         if (t + 1 < nt) {
-            f32_load_tile<!TA>(A, g.lda, m0, (int64_t)(t + 1) * F_BK, ra0, ra1);
-            f32_load_tile<TB>(B, g.ldb, n0, (int64_t)(t + 1) * F_BK, rb0, rb1);
+            f32_load_tile<!TA, T>(A, g.lda, m0, (int64_t)(t + 1) * F_BK, ra0, ra1);
+            f32_load_tile<TB, T>(B, g.ldb, n0, (int64_t)(t + 1) * F_BK, rb0, rb1);
         }
 #pragma unroll
         for (int ks = 0; ks < F_BK; ks += 2) {
-            float a[2], b[2];
+            float a[NI], b[NI];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                a[i] = As[cur][ks + kl][wr * 64 + i * 32 + xl];
-                b[i] = Bs[cur][ks + kl][wc * 64 + i * 32 + xl];
+            for (int i = 0; i < NI; ++i) {
+                a[i] = As[cur][ks + kl][wr * (T / 2) + i * 32 + xl];
+                b[i] = Bs[cur][ks + kl][wc * (T / 2) + i * 32 + xl];
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
         if (t + 1 < nt) {
-            f32_write_tile<!TA>(As[cur ^ 1], ra0, ra1);
-            f32_write_tile<TB>(Bs[cur ^ 1], rb0, rb1);
+            f32_write_tile<!TA, T>(As[cur ^ 1], ra0, ra1);
+            f32_write_tile<TB, T>(Bs[cur ^ 1], rb0, rb1);
         }
         __syncthreads();
     }
 
     // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t n = n0 + wc * 64 + j * 32 + xl;
+        for (int j = 0; j < NI; ++j) {
+            const int64_t n = n0 + wc * (T / 2) + j * 32 + xl;
             const float bias = g.epilogue == KF_EPI_BIAS_ROW ? ((const float *)g.bias)[n] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int64_t m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kl;
+                const int64_t m = m0 + wr * (T / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kl;
                 float v = g.alpha * acc[i][j][e];
                 if (g.beta != 0.f) v += g.beta * C[m * g.ldc + n];
                 C[m * g.ldc + n] = v + bias;
@@ -1036,13 +1047,20 @@ extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N
     }
 
     const bool al16 = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0);
-    if (dtype == KF_F32 && M % F_BM == 0 && N % F_BN == 0 && K % F_BK == 0 && K > 0 && al16 && lda % 4 == 0 && ldb % 4 == 0) {
-        const unsigned grid = (unsigned)((M / F_BM) * (N / F_BN));
+    if (dtype == KF_F32 && M % 64 == 0 && N % 64 == 0 && K % F_BK == 0 && K > 0 && al16 && lda % 4 == 0 && ldb % 4 == 0) {
+        // 128-tiles unless they would leave a quarter of the CUs idle and 64-tiles are possible... or are the only option
+        const bool t128 = M % F_BM == 0 && N % F_BN == 0 && (M / F_BM) * (N / F_BN) >= 192;
         KF_PROF("gemm_f32_mfma", st);
-        if (!trans_a && !trans_b) gemm_f32_kernel<false, false><<<grid, 256, 0, st>>>(g);
-        else if (!trans_a && trans_b) gemm_f32_kernel<false, true><<<grid, 256, 0, st>>>(g);
-        else if (trans_a && !trans_b) gemm_f32_kernel<true, false><<<grid, 256, 0, st>>>(g);
-        else gemm_f32_kernel<true, true><<<grid, 256, 0, st>>>(g);
+#define KF_F32G(T_)                                                                                          \
+    {                                                                                                        \
+        const unsigned grid = (unsigned)((M / T_) * (N / T_));                                               \
+        if (!trans_a && !trans_b) gemm_f32_kernel<false, false, T_><<<grid, 256, 0, st>>>(g);                \
+        else if (!trans_a && trans_b) gemm_f32_kernel<false, true, T_><<<grid, 256, 0, st>>>(g);             \
+        else if (trans_a && !trans_b) gemm_f32_kernel<true, false, T_><<<grid, 256, 0, st>>>(g);             \
+        else gemm_f32_kernel<true, true, T_><<<grid, 256, 0, st>>>(g);                                       \
+    }
+        if (t128) KF_F32G(128) else KF_F32G(64)
+#undef KF_F32G
         KF_LAUNCH_CHECK();
         return KF_OK;
     }
