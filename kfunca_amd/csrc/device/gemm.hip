@@ -2,14 +2,13 @@
 //
 // Replaces src/device/gemm_kernel.cu:8-38, whose arithmetic is an un-vendored CUTLASS SIMT GEMM
 // (src/device/launcher_cuda.h:537-614). Hand-written for CDNA4:
-//   f32      v_mfma_f32_32x32x2_f32 (exact f32 fma chain), 128x128x16 block tile, 4 waves each
-//            owning 64x64, LDS tiles kept k-major so every fragment read is a conflict-free
-//            ds_read_b32; all four op(A)/op(B) layouts are consumed in place.
-//   bf16/f16 v_mfma_f32_32x32x16_{bf16,f16}, 128x128x64 block tile, direct-to-LDS staging
-//            (global_load_lds_dwordx4, XOR-swizzled through the SOURCE address so ds_read_b128 is
-//            conflict-free), double-buffered LDS, one barrier per K tile, XCD-aware tile order.
-//            The kernel consumes K-contiguous operands (A as [M,K], B as [N,K]); the other layouts
-//            are re-laid by a tiled transpose into caller-supplied scratch.
+//   f32      v_mfma_f32_32x32x2_f32 (exact f32 fma chain), 128x128x16 block tile (64x64x16 for small grids), LDS tiles
+//            kept k-major so every fragment read is a conflict-free ds_read_b32.
+//   bf16/f16 large grids: 256x256x64 block tile, v_mfma_f32_16x16x32, LDS-DMA staging - an 8-wave form (two waves per SIMD
+//            half a phase apart) and a 4-wave form (one wave per SIMD, 256 in-place AGPR accumulators);
+//            smaller grids: 128x128x64 block tile, v_mfma_f32_32x32x16, double-buffered LDS, one barrier per K tile.
+//   Every kernel consumes all four op(A) / op(B) layouts in place: an operand whose contraction dim is the strided one is
+//   staged as it lies in memory and read with ds_read_b64_tr_b16 - no re-layout pass, no workspace.
 //   f64 / ragged shapes: a plain LDS-tiled FMA kernel (the reference's only GEMM test is this
 //            case: f64 123x457x234, test/test_gemm.py:9-17).
 #include <stdlib.h>
