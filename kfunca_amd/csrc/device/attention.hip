@@ -20,7 +20,9 @@
 //    dK/dV kernel (key on the lane: S, dP, dV^T += dO^T P, dK^T += Q^T dS). Recomputing S/dP
 //    in both kernels costs 7 products instead of 5 but needs no atomics: dQ is bitwise
 //    reproducible and there is no global-atomic floor.
-//  * generic path (f32 — the reference's own dtype — or any ragged shape/head size <= 256):
+//    A workgroup takes a block and its causal mirror, so all workgroups carry the same work (a_block_map, `persist`).
+//  * f32 forward (the reference's own dtype and fast path, D = 64 | 128): exact-f32 MFMA kernel.
+//  * generic path (any other dtype / ragged shape / head size <= 256, and the f32 backward):
 //    LDS-tiled f32 online-softmax kernel; backward by two LDS-tiled f32 kernels.
 #include <math.h>
 #include <stdlib.h>
