@@ -1295,6 +1295,264 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_mfma_kernel(const AttnArg
 }
 
 // ==========================================================================================
+// backward, f32, on v_mfma_f32_32x32x2_f32 (no reference counterpart: the reference has no backward at all). Same
+// orientation tricks as the f32 forward: every product keeps "the other index" on the lane, so P and dS are consumed
+// straight out of accumulator registers as the B operand of the next product.
+//   dQ kernel (query on the lane, 4 waves x 32 queries, 32-key K / V tiles in LDS):
+//       S^T = K Q^T,  dP^T = V dO^T   (A = K / V rows from LDS, B = Q / dO registers; lane half hl owns k in [hl D/2, ..))
+//       dS^T = P^T o (dP^T - delta);   dQ^T += K^T dS^T  (A = K[key row(e, hl)][d] from LDS, B = dS register e)
+//   dK/dV kernel (key on the lane, 4 waves x 32 keys, 32-query Q / dO tiles + their lse / delta in LDS; one wave per SIMD:
+//   128 accumulator + 128 operand registers):
+//       S = Q K^T,  dP = dO V^T  (A = Q / dO rows from LDS, B = K / V registers);  P = exp2(c S - lse),  dS = P o (dP - delta)
+//       dV^T += dO^T P  (A = dO[query row(e, hl)][d]),   dK^T += Q^T dS  (A = Q[query row(e, hl)][d])
+// Exact-f32 fma chains throughout; deterministic (no atomics); causal pairing as in the other kernels.
+// ==========================================================================================
+template <int D>
+__device__ __forceinline__ void x_store_rows(float *slab, float *dst, const f32x16 *acc, float mul) {
+    // acc[d-block][e] = X^T[32 d + row(e, hl)][row-on-lane xl] -> 32 rows of D floats, 16-byte coalesced stores
+    const int lane = threadIdx.x & 63, xl = lane & 31, hl = lane >> 5;
+#pragma unroll
+    for (int d = 0; d < D / 32; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) slab[xl * (D + 4) + 32 * d + a_row(e, hl)] = acc[d][e] * mul;
+#pragma unroll
+    for (int i = 0; i < 32 * D / 4 / 64; ++i) {
+        const int id = lane + 64 * i, row = id / (D / 4), c4 = id % (D / 4);
+        *(float4 *)(dst + (int64_t)row * D + 4 * c4) = *(const float4 *)(slab + row * (D + 4) + 4 * c4);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_f32_mfma_kernel(const AttnArgs a) {
+    constexpr int DP = D + 4, HD = D / 2, ND = D / 32, NV = XK * D / 4 / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *Ks = (float *)smem, *Vs = Ks + XK * DP;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5, t = threadIdx.x;
+    int xb0;
+    int64_t bh;
+    const int nxb = (int)((a.Sq + XQ - 1) / XQ);
+    const int nwx = a.persist ? nxb / (2 * a.persist) : nxb;
+    a_block_map(nwx, (int)(a.B * a.H), a.xcd_map, xb0, bh);
+    const float *Kg = (const float *)a.k + bh * a.Skv * D;
+    const float *Vg = (const float *)a.v + bh * a.Skv * D;
+    const float c = a.scale * kLog2e;
+#pragma nounroll
+  for (int pass = 0; pass < (a.persist ? 2 * a.persist : 1); ++pass) {
+    const int xp = xb0 + (pass >> 1) * nwx;
+    const int xb = (pass & 1) ? nxb - 1 - xp : xp;
+    const int qblk = nxb - 1 - xb;
+    const int64_t q0 = (int64_t)qblk * XQ, qw = q0 + wid * 32, m = qw + xl;
+    const bool active = qw < a.Sq;
+    float qreg[HD], doreg[HD];
+    float lse2 = 0.f, dlt = 0.f;
+    if (active) {
+        const float4 *Qg = (const float4 *)((const float *)a.q + (bh * a.Sq + m) * D + hl * HD);
+        const float4 *Og = (const float4 *)((const float *)a.d_o + (bh * a.Sq + m) * D + hl * HD);
+#pragma unroll
+        for (int j = 0; j < HD / 4; ++j) {
+            const float4 v = Qg[j], w = Og[j];
+            qreg[4 * j] = v.x; qreg[4 * j + 1] = v.y; qreg[4 * j + 2] = v.z; qreg[4 * j + 3] = v.w;
+            doreg[4 * j] = w.x; doreg[4 * j + 1] = w.y; doreg[4 * j + 2] = w.z; doreg[4 * j + 3] = w.w;
+        }
+        lse2 = a.lse_r[bh * a.Sq + m] * kLog2e;
+        dlt = a.delta[bh * a.Sq + m];
+    } else {
+#pragma unroll
+        for (int j = 0; j < HD; ++j) { qreg[j] = 0.f; doreg[j] = 0.f; }
+    }
+    f32x16 dq[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dq[d][e] = 0.f;
+    const int64_t q_end = q0 + XQ < a.Sq ? q0 + XQ : a.Sq;
+    const int64_t kv_end = a.Skv < q_end ? a.Skv : q_end;
+    const int nt = (int)((kv_end + XK - 1) / XK);
+    float4 k0, k1, k2, k3, v0, v1, v2, v3;
+    k2 = k3 = v2 = v3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto src = [&](const float *g, int tile, int i) __attribute__((always_inline)) {
+        const int id = t + 256 * i, row = id / (D / 4), c4 = id % (D / 4);
+        return (const float4 *)(g + ((int64_t)tile * XK + row) * D + 4 * c4);
+    };
+    auto dst = [&](float *l, int i) __attribute__((always_inline)) {
+        const int id = t + 256 * i, row = id / (D / 4), c4 = id % (D / 4);
+        return (float4 *)(l + row * DP + 4 * c4);
+    };
+    auto gload = [&](int tile) __attribute__((always_inline)) {
+        k0 = *src(Kg, tile, 0); k1 = *src(Kg, tile, 1); v0 = *src(Vg, tile, 0); v1 = *src(Vg, tile, 1);
+        if constexpr (NV == 4) { k2 = *src(Kg, tile, 2); k3 = *src(Kg, tile, 3); v2 = *src(Vg, tile, 2); v3 = *src(Vg, tile, 3); }
+    };
+    auto lstore = [&]() __attribute__((always_inline)) {
+        *dst(Ks, 0) = k0; *dst(Ks, 1) = k1; *dst(Vs, 0) = v0; *dst(Vs, 1) = v1;
+        if constexpr (NV == 4) { *dst(Ks, 2) = k2; *dst(Ks, 3) = k3; *dst(Vs, 2) = v2; *dst(Vs, 3) = v3; }
+    };
+    gload(0);
+    for (int tl = 0; tl < nt; ++tl) {
+        const int64_t kv0 = (int64_t)tl * XK;
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (tl + 1 < nt) gload(tl + 1);
+        if (!active || kv0 > qw + 31) continue;
+        f32x16 sv, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { sv[e] = 0.f; dp[e] = 0.f; }
+        const float *krow = Ks + xl * DP + hl * HD, *vrow = Vs + xl * DP + hl * HD;
+#pragma unroll
+        for (int j = 0; j < HD / 4; ++j) {
+            const float4 kk = *(const float4 *)(krow + 4 * j);
+            sv = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.x, qreg[4 * j], sv, 0, 0, 0);
+            sv = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.y, qreg[4 * j + 1], sv, 0, 0, 0);
+            sv = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.z, qreg[4 * j + 2], sv, 0, 0, 0);
+            sv = __builtin_amdgcn_mfma_f32_32x32x2f32(kk.w, qreg[4 * j + 3], sv, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < HD / 4; ++j) {
+            const float4 vv = *(const float4 *)(vrow + 4 * j);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.x, doreg[4 * j], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.y, doreg[4 * j + 1], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.z, doreg[4 * j + 2], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.w, doreg[4 * j + 3], dp, 0, 0, 0);
+        }
+        const bool need_mask = kv0 + XK - 1 > qw;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[e], c, -lse2));
+            if (need_mask && kv0 + a_row(e, hl) > m) p = 0.f;
+            sv[e] = p * (dp[e] - dlt);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float *kr = Ks + a_row(e, hl) * DP + xl;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) dq[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[32 * d], sv[e], dq[d], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    if (active) x_store_rows<D>((float *)smem + wid * 32 * (D + 4), (float *)a.dq + (bh * a.Sq + qw) * D, dq, a.scale);
+    // (the next block's first __syncthreads() comes before its first tile store: the slabs are read by then)
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_f32_mfma_kernel(const AttnArgs a) {
+    constexpr int DP = D + 4, HD = D / 2, ND = D / 32, NV = XK * D / 4 / 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *Qs = (float *)smem, *Os = Qs + XK * DP, *Ls = Os + XK * DP; // Q tile | dO tile | lse2[32] | delta[32]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5, t = threadIdx.x;
+    int xb0;
+    int64_t bh;
+    const int nkb = (int)((a.Skv + XQ - 1) / XQ);
+    const int nwx = a.persist ? nkb / (2 * a.persist) : nkb;
+    a_block_map(nwx, (int)(a.B * a.H), a.xcd_map, xb0, bh);
+    const float *Qg = (const float *)a.q + bh * a.Sq * D;
+    const float *Og = (const float *)a.d_o + bh * a.Sq * D;
+    const float c = a.scale * kLog2e;
+#pragma nounroll
+  for (int pass = 0; pass < (a.persist ? 2 * a.persist : 1); ++pass) {
+    const int xp = xb0 + (pass >> 1) * nwx;
+    const int xb = (pass & 1) ? xp : nkb - 1 - xp; // the short block (late keys) first
+    const int64_t k0b = (int64_t)xb * XQ, kw = k0b + wid * 32, n = kw + xl;
+    const bool active = kw < a.Skv;
+    float kreg[HD], vreg[HD];
+    if (active) {
+        const float4 *Kp = (const float4 *)((const float *)a.k + (bh * a.Skv + n) * D + hl * HD);
+        const float4 *Vp = (const float4 *)((const float *)a.v + (bh * a.Skv + n) * D + hl * HD);
+#pragma unroll
+        for (int j = 0; j < HD / 4; ++j) {
+            const float4 v = Kp[j], w = Vp[j];
+            kreg[4 * j] = v.x; kreg[4 * j + 1] = v.y; kreg[4 * j + 2] = v.z; kreg[4 * j + 3] = v.w;
+            vreg[4 * j] = w.x; vreg[4 * j + 1] = w.y; vreg[4 * j + 2] = w.z; vreg[4 * j + 3] = w.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < HD; ++j) { kreg[j] = 0.f; vreg[j] = 0.f; }
+    }
+    f32x16 dk[ND], dv[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk[d][e] = 0.f; dv[d][e] = 0.f; }
+    const int t0 = (int)(k0b / XK), nt = (int)((a.Sq + XK - 1) / XK); // query tiles holding a query >= the block's first key
+    float4 q0r, q1r, q2r, q3r, o0r, o1r, o2r, o3r;
+    q2r = q3r = o2r = o3r = make_float4(0.f, 0.f, 0.f, 0.f);
+    float rc = 0.f; // threads 0..31: lse2 of the tile's query t, threads 32..63: its delta
+    auto src = [&](const float *g, int tile, int i) __attribute__((always_inline)) {
+        const int id = t + 256 * i, row = id / (D / 4), c4 = id % (D / 4);
+        return (const float4 *)(g + ((int64_t)tile * XK + row) * D + 4 * c4);
+    };
+    auto dst = [&](float *l, int i) __attribute__((always_inline)) {
+        const int id = t + 256 * i, row = id / (D / 4), c4 = id % (D / 4);
+        return (float4 *)(l + row * DP + 4 * c4);
+    };
+    auto gload = [&](int tile) __attribute__((always_inline)) {
+        q0r = *src(Qg, tile, 0); q1r = *src(Qg, tile, 1); o0r = *src(Og, tile, 0); o1r = *src(Og, tile, 1);
+        if constexpr (NV == 4) { q2r = *src(Qg, tile, 2); q3r = *src(Qg, tile, 3); o2r = *src(Og, tile, 2); o3r = *src(Og, tile, 3); }
+        if (t < 32) rc = a.lse_r[bh * a.Sq + (int64_t)tile * XK + t] * kLog2e;
+        else if (t < 64) rc = a.delta[bh * a.Sq + (int64_t)tile * XK + t - 32];
+    };
+    auto lstore = [&]() __attribute__((always_inline)) {
+        *dst(Qs, 0) = q0r; *dst(Qs, 1) = q1r; *dst(Os, 0) = o0r; *dst(Os, 1) = o1r;
+        if constexpr (NV == 4) { *dst(Qs, 2) = q2r; *dst(Qs, 3) = q3r; *dst(Os, 2) = o2r; *dst(Os, 3) = o3r; }
+        if (t < 64) Ls[t] = rc;
+    };
+    if (t0 < nt) gload(t0);
+    for (int tl = t0; tl < nt; ++tl) {
+        const int64_t qt0 = (int64_t)tl * XK;
+        __syncthreads();
+        lstore();
+        __syncthreads();
+        if (tl + 1 < nt) gload(tl + 1);
+        if (!active || qt0 + 31 < kw) continue; // every query of the tile is before this wave's first key
+        f32x16 sv, dp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { sv[e] = 0.f; dp[e] = 0.f; }
+        const float *qrow = Qs + xl * DP + hl * HD, *orow = Os + xl * DP + hl * HD;
+#pragma unroll
+        for (int j = 0; j < HD / 4; ++j) {
+            const float4 qq = *(const float4 *)(qrow + 4 * j);
+            sv = __builtin_amdgcn_mfma_f32_32x32x2f32(qq.x, kreg[4 * j], sv, 0, 0, 0);
+            sv = __builtin_amdgcn_mfma_f32_32x32x2f32(qq.y, kreg[4 * j + 1], sv, 0, 0, 0);
+            sv = __builtin_amdgcn_mfma_f32_32x32x2f32(qq.z, kreg[4 * j + 2], sv, 0, 0, 0);
+            sv = __builtin_amdgcn_mfma_f32_32x32x2f32(qq.w, kreg[4 * j + 3], sv, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < HD / 4; ++j) {
+            const float4 oo = *(const float4 *)(orow + 4 * j);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(oo.x, vreg[4 * j], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(oo.y, vreg[4 * j + 1], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(oo.z, vreg[4 * j + 2], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(oo.w, vreg[4 * j + 3], dp, 0, 0, 0);
+        }
+        const bool need_mask = qt0 < kw + 31; // some query of the tile is before some key of the wave
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = a_row(e, hl);
+            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv[e], c, -Ls[r]));
+            if (need_mask && n > qt0 + r) p = 0.f;
+            sv[e] = p;
+            dp[e] = p * (dp[e] - Ls[32 + r]);
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float *orw = Os + a_row(e, hl) * DP + xl, *qrw = Qs + a_row(e, hl) * DP + xl;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) {
+                dv[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(orw[32 * d], sv[e], dv[d], 0, 0, 0);
+                dk[d] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrw[32 * d], dp[e], dk[d], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    if (active) {
+        float *slab = (float *)smem + wid * 32 * (D + 4);
+        x_store_rows<D>(slab, (float *)a.dv + (bh * a.Skv + kw) * D, dv, 1.f);
+        x_store_rows<D>(slab, (float *)a.dk + (bh * a.Skv + kw) * D, dk, a.scale);
+    }
+  }
+}
+
+// ==========================================================================================
 // generic path: f32 math on the vector ALU, any Sq / Skv, D <= 256, f32 / bf16 / f16 storage.
 // One block = 16 queries; key tiles of 32; 256 threads.
 // ==========================================================================================
@@ -1709,10 +1967,48 @@ extern "C" int kf_attn_bwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, i
         }
         return KF_OK;
     }
+    const unsigned gd = (unsigned)((nrows + 3) / 4);
+    if (dtype == KF_F32 && (D == 64 || D == 128) && Sq % 32 == 0 && Skv % 32 == 0 && !getenv("KF_ATTN_F32_GENERIC")) {
+        // exact-f32 MFMA backward (the f32 forward's counterpart; the reference has no backward)
+        {
+            KF_PROF("attn_bwd_delta", st);
+            attn_delta_generic_kernel<float><<<gd, 256, 0, st>>>((const float *)o, (const float *)d_o, a.delta, nrows, (int)D);
+            KF_LAUNCH_CHECK();
+        }
+        const size_t tiles = (size_t)2 * XK * (D + 4) * sizeof(float) + 256, slabs = (size_t)4 * 32 * (D + 4) * sizeof(float);
+        const size_t ldsx = std::max(tiles, slabs);
+        const int64_t nxq = (Sq + XQ - 1) / XQ, nkb = (Skv + XQ - 1) / XQ;
+        {
+            a.persist = (nkb % 2 == 0 && nkb >= 4 && !getenv("KF_ATTN_NO_PAIR")) ? 1 : 0;
+            dim3 g((unsigned)((a.persist ? nkb / 2 : nkb) * B * H));
+            KF_PROF("attn_bwd_dkv_f32_mfma", st);
+            if (D == 128) {
+                if ((rc = set_lds(attn_bwd_dkv_f32_mfma_kernel<128>, ldsx)) != KF_OK) return rc;
+                attn_bwd_dkv_f32_mfma_kernel<128><<<g, 256, ldsx, st>>>(a);
+            } else {
+                if ((rc = set_lds(attn_bwd_dkv_f32_mfma_kernel<64>, ldsx)) != KF_OK) return rc;
+                attn_bwd_dkv_f32_mfma_kernel<64><<<g, 256, ldsx, st>>>(a);
+            }
+            KF_LAUNCH_CHECK();
+        }
+        {
+            a.persist = (nxq % 2 == 0 && nxq >= 4 && !getenv("KF_ATTN_NO_PAIR")) ? 1 : 0;
+            dim3 g((unsigned)((a.persist ? nxq / 2 : nxq) * B * H));
+            KF_PROF("attn_bwd_dq_f32_mfma", st);
+            if (D == 128) {
+                if ((rc = set_lds(attn_bwd_dq_f32_mfma_kernel<128>, ldsx)) != KF_OK) return rc;
+                attn_bwd_dq_f32_mfma_kernel<128><<<g, 256, ldsx, st>>>(a);
+            } else {
+                if ((rc = set_lds(attn_bwd_dq_f32_mfma_kernel<64>, ldsx)) != KF_OK) return rc;
+                attn_bwd_dq_f32_mfma_kernel<64><<<g, 256, ldsx, st>>>(a);
+            }
+            KF_LAUNCH_CHECK();
+        }
+        return KF_OK;
+    }
     const int DP = (int)D + 1;
     const size_t lds = sizeof(float) * ((size_t)2 * GQ * DP + (size_t)2 * GK * DP + (size_t)2 * GQ * (GK + 1) + 2 * GK);
     dim3 gq((unsigned)((Sq + GQ - 1) / GQ), (unsigned)(B * H)), gk((unsigned)((Skv + GQ - 1) / GQ), (unsigned)(B * H));
-    const unsigned gd = (unsigned)((nrows + 3) / 4);
     KF_PROF("attn_bwd_generic", st);
 #define KF_GENERIC_BWD(T)                                                                                   \
     attn_delta_generic_kernel<T><<<gd, 256, 0, st>>>((const T *)o, (const T *)d_o, a.delta, nrows, (int)D);  \

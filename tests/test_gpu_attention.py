@@ -275,3 +275,25 @@ def test_f32_mfma_forward_vs_oracle(B, Hh, Sq, Skv, D):
         o_ref, lse_ref = O.attn_fwd(q, k, v)
         assert_close(o, o_ref, rtol=tol, atol=tol, what=f"f32 mfma fwd {lo}")
         assert_close(lse, lse_ref, rtol=1e-5, atol=1e-3 if hi == 10 else 1e-4, what="lse")
+
+
+@pytest.mark.parametrize("B,Hh,Sq,Skv,D", [(1, 2, 128, 128, 128), (2, 3, 96, 160, 64), (1, 2, 512, 512, 128), (1, 2, 1024, 1024, 64), (1, 1, 288, 64, 128),
+                                           (1, 2, 640, 640, 128), (1, 1, 256, 768, 64)])
+def test_f32_mfma_backward_vs_oracle(B, Hh, Sq, Skv, D):
+    """f32 backward on the exact-f32 MFMA (no reference counterpart: pinned to the double-precision oracle). Paired and
+    unpaired block counts, Sq != Skv both ways, both head sizes; 5e-5 of each gradient's scale on U(-1, 1)."""
+    rng = np.random.default_rng(Sq * 3 + Skv + D)
+    q, k, v, go = (rng.uniform(-1, 1, s).astype(np.float32) for s in ((B, Hh, Sq, D), (B, Hh, Skv, D), (B, Hh, Skv, D), (B, Hh, Sq, D)))
+    o, lse = fwd(H.F32, q, k, v)
+    H.profile_reset()
+    H.profile_enable(True)
+    got = bwd(H.F32, q, k, v, o, lse, go)
+    H.profile_enable(False)
+    assert {"attn_bwd_dkv_f32_mfma", "attn_bwd_dq_f32_mfma"} <= set(H.profile_results())
+    want = O.attn_bwd(q, k, v, go)
+    for name, g, w in zip(("dq", "dk", "dv"), got, want):
+        scale = np.abs(w).max() + 1e-30
+        assert np.isfinite(g).all() and np.abs(g - w).max() <= 5e-5 * scale, (name, float(np.abs(g - w).max() / scale))
+    again = bwd(H.F32, q, k, v, o, lse, go)  # no atomics: bitwise reproducible
+    for a0, a1 in zip(got, again):
+        assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32))
