@@ -242,8 +242,9 @@ int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K
  * inference): lse = m + log(l), the natural-log-sum-exp of the scaled, masked scores.
  * O = softmax(mask(Q K^T / sqrt(D))) V, mask keeps key n for query m iff m >= n (absolute
  * indices, top-left aligned: causal_attention_ref.h:36-41).
- * dtype in {KF_F32, KF_BF16, KF_F16}, D <= 256, any Sq / Skv. The MFMA kernels take 16-bit tensors with D = 128 and
- * Sq, Skv multiples of 128; everything else runs the generic vector-ALU kernels (correct, about 100x slower).
+ * dtype in {KF_F32, KF_BF16, KF_F16}, D <= 256, any Sq / Skv. Matrix-core kernels, forward and backward: 16-bit tensors
+ * with D = 128 and Sq, Skv multiples of 128; f32 tensors (the reference's dtype: exact-f32 MFMA) with D = 64 or 128 and
+ * Sq, Skv multiples of 32. Everything else runs the generic vector-ALU kernels (correct, 20-100x slower).
  * The *_scaled forms take the softmax scale explicitly instead of 1 / sqrt(D): a host that zero-pads a smaller head
  * size up to 128 columns (zero columns change neither Q K^T nor P V) passes 1 / sqrt(its own D) and lands on the MFMA
  * kernels - kfunca_amd's causal_attention does exactly that.
