@@ -485,12 +485,24 @@ void check_attention(const Tensor &q, const Tensor &k, const Tensor &v) {
 // with zeros at no cost in results: zero columns change neither Q K^T nor P V (the softmax scale stays 1 / sqrt(D) of the
 // real head size: kf_attn_*_scaled); a padded key n >= Skv >= Sq > m is above the diagonal of every real query; a padded
 // query has q = 0 and dO = 0, so it contributes exactly zero to dK and dV.
-bool pad_for_mfma(const Tensor &q, const Tensor &k) {
+// The same holds for f32 tensors and the exact-f32 MFMA kernels (head size 64 or 128, rows in multiples of 32).
+struct PadPlan {
+    bool pad = false;
+    int64_t Sqp = 0, Skp = 0, Dp = 0;
+};
+PadPlan pad_for_mfma(const Tensor &q, const Tensor &k) {
     const int64_t Sq = q.shape(2), Skv = k.shape(2), D = q.shape(3);
-    return (q.dtype() == ScalarType::Half || q.dtype() == ScalarType::BFloat16) && D > 0 && D <= 128 && Skv >= Sq && Sq > 0 &&
-           (D != 128 || Sq % 128 != 0 || Skv % 128 != 0);
+    PadPlan p;
+    if (!(D > 0 && D <= 128 && Skv >= Sq && Sq > 0)) return p;
+    const bool h16 = q.dtype() == ScalarType::Half || q.dtype() == ScalarType::BFloat16;
+    if (!h16 && q.dtype() != ScalarType::Float) return p;
+    const int64_t rows = h16 ? 128 : 32;
+    p.Dp = h16 ? 128 : (D <= 64 ? 64 : 128);
+    p.Sqp = (Sq + rows - 1) / rows * rows;
+    p.Skp = (Skv + rows - 1) / rows * rows;
+    p.pad = p.Dp != D || p.Sqp != Sq || p.Skp != Skv;
+    return p;
 }
-int64_t round128(int64_t s) { return (s + 127) / 128 * 128; }
 Tensor pad_to(const Tensor &t, int64_t rows, int64_t cols) { // [B,H,S,D] -> [B,H,rows,cols] (or [B,H,S] -> [B,H,rows]), zero-filled
     auto shape = t.sizes();
     const int64_t S = shape[2];
@@ -527,12 +539,12 @@ private:
 std::tuple<Tensor, Tensor> causal_attention_fwd(const Tensor &q, const Tensor &k, const Tensor &v) {
     check_attention(q, k, v);
     const int64_t B = q.shape(0), H = q.shape(1), Sq = q.shape(2), D = q.shape(3), Skv = k.shape(2);
-    if (pad_for_mfma(q, k)) {
-        const int64_t Sqp = round128(Sq), Skp = round128(Skv);
-        Tensor qp = pad_to(q, Sqp, 128), kp = pad_to(k, Skp, 128), vp = pad_to(v, Skp, 128);
+    if (const PadPlan pp = pad_for_mfma(q, k); pp.pad) {
+        const int64_t Sqp = pp.Sqp, Skp = pp.Skp, Dp = pp.Dp;
+        Tensor qp = pad_to(q, Sqp, Dp), kp = pad_to(k, Skp, Dp), vp = pad_to(v, Skp, Dp);
         Tensor outp = empty_like(qp);
         Tensor lsep = empty({B, H, Sqp}, ScalarType::Float, q.device());
-        DEV_CALL(kf_attn_fwd_scaled(code(q.dtype()), B, H, Sqp, Skp, 128, 1.0f / std::sqrt((float)D), qp.data_ptr(), kp.data_ptr(), vp.data_ptr(),
+        DEV_CALL(kf_attn_fwd_scaled(code(q.dtype()), B, H, Sqp, Skp, Dp, 1.0f / std::sqrt((float)D), qp.data_ptr(), kp.data_ptr(), vp.data_ptr(),
                                     outp.data_ptr(), static_cast<float *>(lsep.data_ptr()), dev::stream(q.device())));
         return {unpad(outp, Sq, D), unpad(lsep, Sq, 0)};
     }
@@ -548,15 +560,15 @@ std::tuple<Tensor, Tensor, Tensor> causal_attention_bwd(const Tensor &q, const T
     check_attention(q, k, v);
     CHECK_FAIL(grad_out.sizes() == q.sizes() && grad_out.dtype() == q.dtype());
     const int64_t B = q.shape(0), H = q.shape(1), Sq = q.shape(2), D = q.shape(3), Skv = k.shape(2);
-    if (pad_for_mfma(q, k)) {
-        const int64_t Sqp = round128(Sq), Skp = round128(Skv);
-        Tensor qp = pad_to(q, Sqp, 128), kp = pad_to(k, Skp, 128), vp = pad_to(v, Skp, 128), op = pad_to(out, Sqp, 128);
-        Tensor lp = pad_to(lse, Sqp, 0), gp = pad_to(grad_out.contiguous(), Sqp, 128);
+    if (const PadPlan pp = pad_for_mfma(q, k); pp.pad) {
+        const int64_t Sqp = pp.Sqp, Skp = pp.Skp, Dp = pp.Dp;
+        Tensor qp = pad_to(q, Sqp, Dp), kp = pad_to(k, Skp, Dp), vp = pad_to(v, Skp, Dp), op = pad_to(out, Sqp, Dp);
+        Tensor lp = pad_to(lse, Sqp, 0), gp = pad_to(grad_out.contiguous(), Sqp, Dp);
         Tensor dqp = empty_like(qp), dkp = empty_like(kp), dvp = empty_like(vp);
         size_t need = 0;
-        DEV_CALL(kf_attn_bwd_workspace_bytes(code(q.dtype()), B, H, Sqp, Skp, 128, &need));
+        DEV_CALL(kf_attn_bwd_workspace_bytes(code(q.dtype()), B, H, Sqp, Skp, Dp, &need));
         DataPtr scratch = DeviceAllocator::GetInstance()->allocate(need, q.device());
-        DEV_CALL(kf_attn_bwd_scaled(code(q.dtype()), B, H, Sqp, Skp, 128, 1.0f / std::sqrt((float)D), qp.data_ptr(), kp.data_ptr(), vp.data_ptr(),
+        DEV_CALL(kf_attn_bwd_scaled(code(q.dtype()), B, H, Sqp, Skp, Dp, 1.0f / std::sqrt((float)D), qp.data_ptr(), kp.data_ptr(), vp.data_ptr(),
                                     op.data_ptr(), static_cast<const float *>(lp.data_ptr()), gp.data_ptr(), dqp.data_ptr(), dkp.data_ptr(),
                                     dvp.data_ptr(), scratch.get(), need, dev::stream(q.device())));
         return {unpad(dqp, Sq, D), unpad(dkp, Skv, D), unpad(dvp, Skv, D)};

@@ -327,6 +327,31 @@ def test_ragged_16bit_attention_takes_the_mfma_kernels():
             close(t.grad().float(), O.bf16_to_f32(ref), atol=3e-2, rtol=2e-2)
 
 
+def test_ragged_f32_attention_takes_the_f32_mfma_kernels():
+    """The same padding for f32 tensors (rows to multiples of 32, head size to 64 or 128): ragged shapes of the reference's own
+    dtype - its third test shape, 65 x 33 keys... with Skv >= Sq - run on the exact-f32 MFMA kernels, forward and backward."""
+    from kfunca_amd import hip_abi as H
+    rng = np.random.default_rng(17)
+    for (B, Hh, Sq, Skv, D) in ((2, 2, 65, 65, 123), (1, 2, 33, 100, 64), (1, 3, 200, 200, 128), (1, 1, 1, 7, 16)):
+        q, k, v, go = (rng.uniform(-1, 1, s).astype(np.float32) for s in ((B, Hh, Sq, D), (B, Hh, Skv, D), (B, Hh, Skv, D), (B, Hh, Sq, D)))
+        tq, tk, tv = (kfunca.from_numpy(x, 0) for x in (q, k, v))
+        for t in (tq, tk, tv):
+            t.set_requires_grad(True)
+        H.profile_reset()
+        H.profile_enable(True)
+        out = kfunca.causal_attention(tq, tk, tv)
+        out.backward(kfunca.from_numpy(go, 0))
+        kfunca.synchronize()
+        H.profile_enable(False)
+        names = set(H.profile_results())
+        assert {"attn_fwd_f32_mfma", "attn_bwd_dkv_f32_mfma", "attn_bwd_dq_f32_mfma"} <= names and not any("generic" in n for n in names), names
+        o_ref, _ = O.attn_fwd(q, k, v)
+        close(out, o_ref, atol=2e-5, rtol=2e-5)
+        for t, ref in zip((tq, tk, tv), O.attn_bwd(q, k, v, go)):
+            assert t.grad().sizes() == list(ref.shape)
+            close(t.grad(), ref, atol=5e-5, rtol=1e-4)
+
+
 def test_allocator_reuse_and_scope():
     base = kfunca.memstat_dict(0)
     t = kfunca.empty([1 << 20], kfunca.float, 0)
