@@ -397,6 +397,39 @@ void launch_gemm(ScalarType dt, bool ta, bool tb, int64_t M, int64_t N, int64_t 
                      dev::stream(device)));
 }
 
+// Shapes the matrix-core kernels do not take (M, N, K off their tile multiples) are zero-padded on the host side of the
+// boundary when the problem is big enough to care: zero rows / columns add nothing to any product, the copies cost
+// O(MK + KN + MN) against O(MNK), and the ragged case (a 50257-column projection, say) runs on the MFMA kernels instead
+// of the scalar fallback. A2 / B2 are the STORED contiguous 2-D operands, C2 is [M, N].
+Tensor pad2d(const Tensor &t, int64_t rows, int64_t cols) {
+    if (t.shape(0) == rows && t.shape(1) == cols) return t;
+    Tensor p = zeros({rows, cols}, t.dtype(), t.device());
+    Tensor head = p.narrow(0, 0, t.shape(0)).narrow(1, 0, t.shape(1));
+    copy_(head, t);
+    return p;
+}
+void gemm_any(ScalarType dt, bool ta, bool tb, int64_t M, int64_t N, int64_t K, float alpha, const Tensor &A2, const Tensor &B2, float beta,
+              Tensor &C2, int device) {
+    int64_t am = 0, ak = 0;
+    if (dt == ScalarType::Half || dt == ScalarType::BFloat16) { am = 128; ak = 64; }
+    else if (dt == ScalarType::Float) { am = 64; ak = 16; }
+    const bool aligned = am && M % am == 0 && N % am == 0 && K % ak == 0;
+    if (!am || aligned || M * N * K < ((int64_t)1 << 22)) {
+        launch_gemm(dt, ta, tb, M, N, K, alpha, A2.data_ptr(), A2.shape(1), B2.data_ptr(), B2.shape(1), beta, C2.data_ptr(), N, device);
+        return;
+    }
+    auto up = [](int64_t v, int64_t a) { return (v + a - 1) / a * a; };
+    const int64_t Mp = up(M, am), Np = up(N, am), Kp = up(K, ak);
+    Tensor Ap = pad2d(A2, ta ? Kp : Mp, ta ? Mp : Kp), Bp = pad2d(B2, tb ? Np : Kp, tb ? Kp : Np);
+    const bool same_c = Mp == M && Np == N;
+    Tensor Cp = same_c ? C2 : (beta != 0.f ? pad2d(C2, Mp, Np) : empty({Mp, Np}, dt, device));
+    launch_gemm(dt, ta, tb, Mp, Np, Kp, alpha, Ap.data_ptr(), Ap.shape(1), Bp.data_ptr(), Bp.shape(1), beta, Cp.data_ptr(), Np, device);
+    if (!same_c) {
+        Tensor head = Cp.narrow(0, 0, M).narrow(1, 0, N);
+        copy_(C2, head);
+    }
+}
+
 // dA = alpha * dC B^T, dB = alpha * A^T dC with A flattened to [M,K] (no reference counterpart)
 class GemmGradFunction : public GradFunction {
 public:
@@ -406,13 +439,15 @@ public:
         const int64_t K = b.shape(0), N = b.shape(1), M = a.numel() / K;
         Tensor gc = g.contiguous();
         std::vector<Tensor> out(2);
+        Tensor g2 = gc.view({M, N}), a2 = a.view({M, K});
         if (a.requires_grad()) {
             out[0] = empty(a.sizes(), a.dtype(), a.device());
-            launch_gemm(a.dtype(), false, true, M, K, N, alpha_, gc.data_ptr(), N, b.data_ptr(), N, 0.f, out[0].data_ptr(), K, a.device());
+            Tensor c2 = out[0].view({M, K});
+            gemm_any(a.dtype(), false, true, M, K, N, alpha_, g2, b, 0.f, c2, a.device());
         }
         if (b.requires_grad()) {
             out[1] = empty(b.sizes(), b.dtype(), b.device());
-            launch_gemm(a.dtype(), true, false, K, N, M, alpha_, a.data_ptr(), K, gc.data_ptr(), N, 0.f, out[1].data_ptr(), N, b.device());
+            gemm_any(a.dtype(), true, false, K, N, M, alpha_, a2, g2, 0.f, out[1], b.device());
         }
         return out;
     }
@@ -437,7 +472,8 @@ void gemm_out(Tensor &out, const Tensor &a, const Tensor &b, float alpha, float 
     CHECK_FAIL(n > 0 && out.numel() / n == m);
     CHECK_FAIL(gemm_dtype_ok(a.dtype()), "Unsupported ScalarType ", a.dtype());
     CHECK_FAIL(a.device() == b.device() && a.device() == out.device());
-    launch_gemm(a.dtype(), false, false, m, n, k, alpha, a.data_ptr(), k, b.data_ptr(), n, beta, out.data_ptr(), n, a.device());
+    Tensor a2 = a.view({m, k}), c2 = out.view({m, n});
+    gemm_any(a.dtype(), false, false, m, n, k, alpha, a2, b, beta, c2, a.device());
 }
 
 Tensor gemm(const Tensor &a, const Tensor &b, float alpha, float beta) {
@@ -461,8 +497,7 @@ Tensor gemm_ex(const Tensor &a, bool trans_a, const Tensor &b, bool trans_b, flo
     const int64_t Kb = trans_b ? b.shape(1) : b.shape(0), N = trans_b ? b.shape(0) : b.shape(1);
     CHECK_FAIL(K == Kb);
     Tensor out = empty({M, N}, a.dtype(), a.device());
-    launch_gemm(a.dtype(), trans_a, trans_b, M, N, K, alpha, a.data_ptr(), a.shape(1), b.data_ptr(), b.shape(1), 0.f, out.data_ptr(), N,
-                a.device());
+    gemm_any(a.dtype(), trans_a, trans_b, M, N, K, alpha, a, b, 0.f, out, a.device());
     return out;
 }
 

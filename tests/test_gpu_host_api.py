@@ -423,3 +423,34 @@ def test_topk_small_and_large():  # test_tensor.py:203-231: values of torch.topk
         arr = np.random.default_rng(seed).uniform(-10000, 10000, size=(4, 1024000)).astype(np.float32)
         res, ind = kfunca.from_numpy(arr, 0).topk(k, 1, True)
         assert np.array_equal(sha(res.numpy()), g[f"tl{i}_sha_out"])
+
+
+def test_ragged_gemm_runs_on_the_matrix_cores():
+    """M, N, K off the kernels' tile multiples: the operator zero-pads (big enough problems) and the MFMA kernels run instead
+    of the scalar fallback - forward and both backward products; results as for aligned shapes."""
+    from kfunca_amd import hip_abi as H
+    rng = np.random.default_rng(21)
+    for dt_name, (M, K, N), tol in (("bf16", (1000, 700, 1030), 2e-2), ("f32", (333, 250, 517), 1e-4)):
+        a = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+        b = (rng.uniform(-1, 1, (K, N)) / np.sqrt(K)).astype(np.float32)
+        g = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+        if dt_name == "bf16":
+            a, b, g = (O.bf16_to_f32(O.f32_to_bf16(x)) for x in (a, b, g))
+        up = (lambda x: kfunca.from_numpy(x, 0).bfloat16()) if dt_name == "bf16" else (lambda x: kfunca.from_numpy(x, 0))
+        ta, tb = up(a), up(b)
+        ta.set_requires_grad(True)
+        tb.set_requires_grad(True)
+        H.profile_reset()
+        H.profile_enable(True)
+        c = kfunca.gemm(ta, tb, 1.0, 0.0)
+        c.backward(up(g))
+        kfunca.synchronize()
+        H.profile_enable(False)
+        names = set(H.profile_results())
+        assert any("mfma" in n for n in names) and "gemm_generic" not in names, names
+        out = (lambda t: t.float().numpy()) if dt_name == "bf16" else (lambda t: t.numpy())
+        want = a.astype(np.float64) @ b.astype(np.float64)
+        assert c.sizes() == [M, N] and np.abs(out(c) - want).max() <= tol * np.abs(want).max()
+        wa, wb = g.astype(np.float64) @ b.astype(np.float64).T, a.astype(np.float64).T @ g.astype(np.float64)
+        assert np.abs(out(ta.grad()) - wa).max() <= tol * np.abs(wa).max()
+        assert np.abs(out(tb.grad()) - wb).max() <= tol * np.abs(wb).max()
