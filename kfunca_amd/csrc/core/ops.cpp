@@ -412,7 +412,7 @@ void gemm_any(ScalarType dt, bool ta, bool tb, int64_t M, int64_t N, int64_t K, 
               Tensor &C2, int device) {
     int64_t am = 0, ak = 0;
     if (dt == ScalarType::Half || dt == ScalarType::BFloat16) { am = 128; ak = 64; }
-    else if (dt == ScalarType::Float) { am = 64; ak = 16; }
+    else if (dt == ScalarType::Float || dt == ScalarType::Double) { am = 64; ak = 16; }
     const bool aligned = am && M % am == 0 && N % am == 0 && K % ak == 0;
     if (!am || aligned || M * N * K < ((int64_t)1 << 22)) {
         launch_gemm(dt, ta, tb, M, N, K, alpha, A2.data_ptr(), A2.shape(1), B2.data_ptr(), B2.shape(1), beta, C2.data_ptr(), N, device);

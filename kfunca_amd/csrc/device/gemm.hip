@@ -9,8 +9,9 @@
 //            smaller grids: 128x128x64 block tile, v_mfma_f32_32x32x16, double-buffered LDS, one barrier per K tile.
 //   Every kernel consumes all four op(A) / op(B) layouts in place: an operand whose contraction dim is the strided one is
 //   staged as it lies in memory and read with ds_read_b64_tr_b16 - no re-layout pass, no workspace.
-//   f64 / ragged shapes: a plain LDS-tiled FMA kernel (the reference's only GEMM test is this
-//            case: f64 123x457x234, test/test_gemm.py:9-17).
+//   f64      v_mfma_f64_16x16x4_f64, 64x64x16 block tile (the reference's only GEMM test is f64: 123x457x234,
+//            test/test_gemm.py:9-17 - ragged, so at the C ABI it takes the fallback below; the operator pads it).
+//   ragged shapes: a plain LDS-tiled FMA kernel.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -237,6 +238,115 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
                 const int64_t m = m0 + wr * (T / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kl;
                 float v = g.alpha * acc[i][j][e];
                 if (g.beta != 0.f) v += g.beta * C[m * g.ldc + n];
+                C[m * g.ldc + n] = v + bias;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// f64: v_mfma_f64_16x16x4_f64 (the reference's GEMM is f32 / f64, and its one GEMM test is f64), 64x64x16 block tile,
+// 4 waves each owning 32x32 as 2 x 2 MFMA tiles; k-major LDS tiles as in the f32 kernel; all layouts in place.
+// A / B fragment: one double per lane, row (column) = lane & 15, k = lane >> 4. C / D: col = lane & 15, row = (lane >> 4) + 4 reg.
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(4))) double f64x4;
+constexpr int D_T = 64, D_BK = 16, D_LD = 66;
+
+template <bool KCONTIG>
+__device__ __forceinline__ void f64_load_tile(const double *base, int64_t ld, int64_t x0, int64_t k0, double2 &r0, double2 &r1) {
+    const int t = threadIdx.x;
+    if constexpr (KCONTIG) { // rows along the tile axis, k contiguous: thread = (row, 4 k)
+        const int row = t / 4, kq = t % 4;
+        const double *p = base + (x0 + row) * ld + k0 + kq * 4;
+        r0 = *(const double2 *)p;
+        r1 = *(const double2 *)(p + 2);
+    } else { // k rows, tile axis contiguous: thread = (k, 4 x)
+        const int k = t / 16, xq = t % 16;
+        const double *p = base + (k0 + k) * ld + x0 + xq * 4;
+        r0 = *(const double2 *)p;
+        r1 = *(const double2 *)(p + 2);
+    }
+}
+template <bool KCONTIG>
+__device__ __forceinline__ void f64_write_tile(double (*s)[D_LD], const double2 &r0, const double2 &r1) {
+    const int t = threadIdx.x;
+    if constexpr (KCONTIG) {
+        const int row = t / 4, kq = t % 4;
+        s[kq * 4 + 0][row] = r0.x;
+        s[kq * 4 + 1][row] = r0.y;
+        s[kq * 4 + 2][row] = r1.x;
+        s[kq * 4 + 3][row] = r1.y;
+    } else {
+        const int k = t / 16, xq = t % 16;
+        *(double2 *)&s[k][xq * 4] = r0;
+        *(double2 *)&s[k][xq * 4 + 2] = r1;
+    }
+}
+
+template <bool TA, bool TB>
+__global__ __launch_bounds__(256) void gemm_f64_kernel(const GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) double As[2][D_BK][D_LD];
+    __shared__ __attribute__((aligned(16))) double Bs[2][D_BK][D_LD];
+    const double *A = (const double *)g.A, *B = (const double *)g.B;
+    double *C = (double *)g.C;
+    const uint32_t tiles_n = (uint32_t)(g.N / D_T);
+    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int64_t m0 = (int64_t)(tile / tiles_n) * D_T, n0 = (int64_t)(tile % tiles_n) * D_T;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int wr = wid >> 1, wc = wid & 1;
+    const int fi = lane & 15, fk = lane >> 4;
+
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0;
+
+    double2 ra0, ra1, rb0, rb1;
+    f64_load_tile<!TA>(A, g.lda, m0, 0, ra0, ra1);
+    f64_load_tile<TB>(B, g.ldb, n0, 0, rb0, rb1);
+    f64_write_tile<!TA>(As[0], ra0, ra1);
+    f64_write_tile<TB>(Bs[0], rb0, rb1);
+    __syncthreads();
+
+    const int nt = (int)(g.K / D_BK);
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nt) {
+            f64_load_tile<!TA>(A, g.lda, m0, (int64_t)(t + 1) * D_BK, ra0, ra1);
+            f64_load_tile<TB>(B, g.ldb, n0, (int64_t)(t + 1) * D_BK, rb0, rb1);
+        }
+#pragma unroll
+        for (int ks = 0; ks < D_BK; ks += 4) {
+            double a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = As[cur][ks + fk][wr * 32 + i * 16 + fi];
+                b[i] = Bs[cur][ks + fk][wc * 32 + i * 16 + fi];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (t + 1 < nt) {
+            f64_write_tile<!TA>(As[cur ^ 1], ra0, ra1);
+            f64_write_tile<TB>(Bs[cur ^ 1], rb0, rb1);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t n = n0 + wc * 32 + j * 16 + fi;
+            const double bias = g.epilogue == KF_EPI_BIAS_ROW ? ((const double *)g.bias)[n] : 0.0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t m = m0 + wr * 32 + i * 16 + fk + 4 * e;
+                double v = (double)g.alpha * acc[i][j][e];
+                if (g.beta != 0.f) v += (double)g.beta * C[m * g.ldc + n];
                 C[m * g.ldc + n] = v + bias;
             }
         }
@@ -1060,6 +1170,16 @@ extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N
     }
         if (t128) KF_F32G(128) else KF_F32G(64)
 #undef KF_F32G
+        KF_LAUNCH_CHECK();
+        return KF_OK;
+    }
+    if (dtype == KF_F64 && M % D_T == 0 && N % D_T == 0 && K % D_BK == 0 && K > 0 && al16 && lda % 2 == 0 && ldb % 2 == 0 && !getenv("KF_GEMM_F64_GENERIC")) {
+        const unsigned grid = (unsigned)((M / D_T) * (N / D_T));
+        KF_PROF("gemm_f64_mfma", st);
+        if (!trans_a && !trans_b) gemm_f64_kernel<false, false><<<grid, 256, 0, st>>>(g);
+        else if (!trans_a && trans_b) gemm_f64_kernel<false, true><<<grid, 256, 0, st>>>(g);
+        else if (trans_a && !trans_b) gemm_f64_kernel<true, false><<<grid, 256, 0, st>>>(g);
+        else gemm_f64_kernel<true, true><<<grid, 256, 0, st>>>(g);
         KF_LAUNCH_CHECK();
         return KF_OK;
     }

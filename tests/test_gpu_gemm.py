@@ -82,6 +82,27 @@ def test_f32_vs_oracle(M, N, K):
     assert_close(got, want, rtol=1e-5, atol=1e-5, what="alpha/beta/bias epilogue")
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (128, 192, 80), (256, 64, 1024), (320, 448, 272)])
+def test_f64_mfma_vs_numpy(M, N, K):
+    """f64 on v_mfma_f64_16x16x4_f64 (the reference's GEMM dtypes are f32 and f64; its one GEMM test is f64): every layout,
+    alpha / beta / bias, against numpy f64 at the accumulation bound 1e-13 * sum |a||b| (reference bar: 1e-3)."""
+    rng = np.random.default_rng(M + N * 5 + K)
+    a, b = rng.uniform(-1, 1, (M, K)), rng.uniform(-1, 1, (K, N))
+    mag = np.abs(a) @ np.abs(b)
+    for ta in (False, True):
+        for tb in (False, True):
+            sa, sb = (a.T.copy() if ta else a), (b.T.copy() if tb else b)
+            H.profile_reset()
+            H.profile_enable(True)
+            got = run_gemm(H.F64, sa, sb, ta, tb)
+            H.profile_enable(False)
+            assert "gemm_f64_mfma" in H.profile_results()
+            assert (np.abs(got - a @ b) <= 1e-13 * mag + 1e-300).all(), (ta, tb)
+    bias, c = rng.uniform(-1, 1, (N,)), rng.uniform(-1, 1, (M, N))
+    got = run_gemm(H.F64, a, b, alpha=0.75, beta=-1.5, c=c.copy(), bias=bias)
+    assert (np.abs(got - (0.75 * (a @ b) - 1.5 * c + bias[None, :])) <= 1e-13 * (mag + np.abs(c) + 1)).all()
+
+
 def test_f32_mfma_is_the_fma_chain():
     """v_mfma_f32_32x32x2_f32 accumulates as a k-ordered f32 fma chain (guide: 'bit-for-bit'), which
     is what the oracle restates: with alpha = 1, beta = 0 the two agree exactly."""

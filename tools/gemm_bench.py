@@ -23,15 +23,15 @@ def main():
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--rounds", type=int, default=10)
     ap.add_argument("--variants", default="default")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f64"])
     args = ap.parse_args()
     n = args.n
     H.set_device(0)
     rng = np.random.default_rng(0)
-    DT = H.BF16 if args.dtype == "bf16" else H.F32
-    mk = (lambda: bf16(rng, (n, n))) if DT == H.BF16 else (lambda: rng.uniform(-1, 1, size=(n, n)).astype(np.float32))
+    DT = {"bf16": H.BF16, "f32": H.F32, "f64": H.F64}[args.dtype]
+    mk = (lambda: bf16(rng, (n, n))) if DT == H.BF16 else (lambda: rng.uniform(-1, 1, size=(n, n)).astype(np.float32 if DT == H.F32 else np.float64))
     A, W, G = (H.DevBuf.from_numpy(mk()) for _ in range(3))
-    out = H.DevBuf(4 * n * n)
+    out = H.DevBuf(8 * n * n)
     need = max(H.gemm_workspace_bytes(DT, ta, tb, n, n, n) for ta, tb in ((0, 0), (0, 1), (1, 0)))
     ws = H.DevBuf(max(need, 16))
     res = {}
@@ -58,7 +58,7 @@ def main():
             ms = float(np.median([m for m, _ in xs]))
             cnt = xs[0][1]
             tot += ms
-            tf = f"{2.0 * n ** 3 * cnt / (ms * 1e-3) / 1e12:8.1f} TF/s" if ("mfma" in k or "f32" in k) else ""
+            tf = f"{2.0 * n ** 3 * cnt / (ms * 1e-3) / 1e12:8.1f} TF/s" if ("mfma" in k or "f32" in k or "generic" in k) else ""
             print(f"  {k:22s} {ms / cnt:8.4f} ms x {cnt}  {tf}")
         print(f"  fwd+bwd total {tot:.4f} ms -> {6.0 * n ** 3 / (tot * 1e-3) / 1e12:.1f} TF/s")
 
