@@ -179,6 +179,18 @@ PYBIND11_MODULE(_C, m) {
     });
     m.def("device_count", &dev::device_count);
     m.def("synchronize", [](int device) { dev::synchronize(device); }, py::arg("device") = 0);
+    // HIP graphs over the device's stream (extension; the reference launches kernel by kernel, launcher_cuda.h:330-354): record
+    // whatever the operator API enqueues between begin and end - a whole forward + backward step - and replay it with one
+    // submission. Replays write to the addresses captured: keep the step's tensors alive and do not allocate in between.
+    m.def("graph_begin", [](int device) { DEV_CALL(kf_graph_begin_capture(dev::stream(device))); }, py::arg("device") = 0);
+    m.def("graph_end", [](int device) {
+        void *g = nullptr;
+        DEV_CALL(kf_graph_end_capture(dev::stream(device), &g));
+        return reinterpret_cast<uintptr_t>(g);
+    }, py::arg("device") = 0);
+    m.def("graph_launch", [](uintptr_t g, int device) { DEV_CALL(kf_graph_launch(reinterpret_cast<void *>(g), dev::stream(device))); },
+          py::arg("graph"), py::arg("device") = 0);
+    m.def("graph_destroy", [](uintptr_t g) { DEV_CALL(kf_graph_destroy(reinterpret_cast<void *>(g))); });
     m.def("memstat", []() { utils::memory::DeviceAllocator::GetInstance()->print(); });
     m.def("memstat_dict", [](int device) {
         auto s = utils::memory::DeviceAllocator::GetInstance()->stats(device);

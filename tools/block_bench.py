@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--json", default="")
+    ap.add_argument("--graph", action="store_true", help="capture one step into a HIP graph and time its replays")
     args = ap.parse_args()
     B, S, Hh, D, f = 1, 4096, 32, 128, 16384
     d, T = Hh * D, B * S
@@ -46,18 +47,28 @@ def main():
     for _ in range(args.warmup):
         step()
     kfunca.synchronize(0)
+    graph = None
+    if args.graph:  # the allocator is warm: the captured step re-uses cached blocks, nothing is hipMalloc'ed while recording
+        kfunca.graph_begin(0)
+        step()
+        graph = kfunca.graph_end(0)
+        kfunca.graph_launch(graph, 0)
+        kfunca.synchronize(0)
     H.profile_reset()
-    H.profile_enable(True)
+    H.profile_enable(not args.graph)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        if graph is not None:
+            kfunca.graph_launch(graph, 0)
+        else:
+            step()
     kfunca.synchronize(0)
     t1 = time.perf_counter()
     H.profile_enable(False)
     ms = (t1 - t0) / args.steps * 1e3
     flops = 6.0 * T * d * (4 * d + 3 * f) + 14.0 * B * S * S * d / 2
     prof = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps} for k, v in H.profile_results().items()}
-    out = {"config": "C5 shard: bf16 block fwd+bwd, B=1 S=4096 d=4096 H=32 D=128 f=16384, Python operator API + Tensor.backward",
+    out = {"mode": "hip graph replay" if args.graph else "eager", "config": "C5 shard: bf16 block fwd+bwd, B=1 S=4096 d=4096 H=32 D=128 f=16384, Python operator API + Tensor.backward",
            "ms_per_step": ms, "tokens_per_s": T / (ms * 1e-3), "matrix_tflops": flops / (ms * 1e-3) / 1e12,
            "device_ms_per_step": sum(v["ms_per_step"] for v in prof.values()), "kernels": prof}
     print(json.dumps(out, indent=1))
