@@ -14,7 +14,9 @@ no Python or CPU fallback for any operator.
 import importlib
 
 __all__ = ["device_info", "memstat", "dtype", "empty", "empty_like", "from_numpy", "to_numpy", "zeros",
-           "causal_attention", "gemm", "cat", "tensor"]
+           "causal_attention", "gemm", "cat", "tensor",
+           # extensions over the reference surface
+           "device_count", "synchronize", "memstat_dict", "graph_begin", "graph_end", "graph_launch", "graph_destroy"]
 
 _native = None
 
