@@ -620,167 +620,10 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a
 // ------------------------------------------------------------------------------------------
 constexpr int BQS = 32;  // queries per slice
 
-// ------------------------------------------------------------------------------------------
-// backward: dK, dV, v2 — 8 waves x 32 keys (256-key block), two waves per SIMD. Q / dO slices of 32
-// queries are double-buffered in LDS with one barrier per slice; K fragments live in registers, V
-// fragments in a per-wave LDS slab (the accumulators already take 128 registers); mask code only on
-// the diagonal slice; scheduler fences keep fragment prefetch from spilling.
-// ------------------------------------------------------------------------------------------
-constexpr int KVB = 256;                          // keys per block
-constexpr int KSL = 2 * BQS * AROW + 256;         // one slice buffer: Q tile | dO tile | lse2[32] | delta[32]
-constexpr int KNS = 2;                            // slices consumed per barrier
-constexpr int KLDS = 2 * KNS * KSL + 8 * QSLAB;   // double-buffered slice groups + 8 per-wave V slabs
-static_assert(KLDS >= 8 * 32 * OPAD, "epilogue slabs must fit");
-
-template <bool BF, bool MASK>
-__device__ __forceinline__ void kv_slice(const char *buf, const char *vslab, const typename AFrag<BF>::type (&kf)[8], const int (&ko)[8],
-                                         const int (&vo)[4][2], f32x16 (&dk)[4], f32x16 (&dv)[4], float c, int64_t qs, int64_t n, int hl) {
-    using frag_t = typename AFrag<BF>::type;
-    const char *qt = buf, *dot = buf + BQS * AROW;
-    const float *lse_s = (const float *)(buf + 2 * BQS * AROW), *dlt_s = lse_s + BQS;
-    f32x16 s, dp;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
-#pragma unroll
-    for (int kg = 0; kg < 4; ++kg) { // fenced pairs of k-steps: bounds the fragments in flight (register budget: 256 at 2 waves/SIMD)
-#pragma unroll
-        for (int kk = 2 * kg; kk < 2 * kg + 2; ++kk) s = a_mfma<BF>(*(const frag_t *)(qt + ko[kk]), kf[kk], s);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-#pragma unroll
-        for (int kk = 2 * kg; kk < 2 * kg + 2; ++kk) dp = a_mfma<BF>(*(const frag_t *)(dot + ko[kk]), *(const frag_t *)(vslab + ko[kk]), dp);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4) { // accumulator rows 8*g4 + 4*hl + {0..3}: one float4 of lse / delta each
-        const float4 l4 = *(const float4 *)(lse_s + 8 * g4 + 4 * hl);
-        const float4 d4 = *(const float4 *)(dlt_s + 8 * g4 + 4 * hl);
-        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int e = 4 * g4 + j;
-            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], c, -lv[j] * kLog2e));
-            if (MASK && n > qs + 8 * g4 + 4 * hl + j) p = 0.f;
-            s[e] = p;
-            dp[e] = p * (dp[e] - dvv[j]);
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) { // builtin transposed reads here: the asm issue/wait form costs this kernel registers it does not have
-        const frag_t pf = a_pack<BF>(s, s2), df = a_pack<BF>(dp, s2);
-        const int roff = s2 * 16 * AROW;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) dv[d] = a_mfma<BF>(a_tr_frag2<BF>(dot + roff + vo[d][0], dot + roff + vo[d][1]), pf, dv[d]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) dk[d] = a_mfma<BF>(a_tr_frag2<BF>(qt + roff + vo[d][0], qt + roff + vo[d][1]), df, dk[d]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-template <bool BF>
-__global__ __launch_bounds__(FNT, 2) void attn_bwd_dkv_v2_kernel(const AttnArgs a) {
-    using frag_t = typename AFrag<BF>::type;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
-    int xb;
-    int64_t bh;
-    a_block_map((int)((a.Skv + KVB - 1) / KVB), (int)(a.B * a.H), a.xcd_map, xb, bh);
-    const int64_t k0 = (int64_t)xb * KVB, kw = k0 + wid * 32, n = kw + xl;
-    const bool active = kw < a.Skv;
-    const char *Qg = a.q + bh * a.Sq * AROW;
-    const char *dOg = a.d_o + bh * a.Sq * AROW;
-    const float *lse_g = a.lse_r + bh * a.Sq, *dlt_g = a.delta + bh * a.Sq;
-    char *vslab = smem + 2 * KNS * KSL + wid * QSLAB;
-
-    frag_t kf[8];
-    if (active) {
-        const char *Kg = a.k + (bh * a.Skv + n) * AROW;
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) kf[kk] = *(const frag_t *)(Kg + (kk * 16 + 8 * hl) * 2);
-        const char *Vw = a.v + (bh * a.Skv + kw) * AROW;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a_lst(vslab, lane + 64 * i, a_gld(Vw, lane + 64 * i));
-    } else {
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) kf[kk][j] = 0;
-    }
-    int ko[8], vo[4][2];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) ko[kk] = a_off(xl, kk * 2 + hl);
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        vo[d][0] = a_tr_lane_off(d * 32, 0);
-        vo[d][1] = a_tr_lane_off(d * 32, 1);
-    }
-    f32x16 dk[4], dv[4];
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { dk[d][e] = 0.f; dv[d][e] = 0.f; }
-    const float c = a.scale * kLog2e;
-
-    // staging by LDS-DMA (global_load_lds, no staging registers): a slice is 32 rows x 256 B of Q and of
-    // dO = 8 + 8 wave-instructions of 1 KiB, one of each per wave. The LDS destination is lane-linear,
-    // so the XOR swizzle of the tile image is applied to the per-lane SOURCE chunk. Wave 0 also fetches
-    // lse[32] | delta[32] with one 4-byte-per-lane instruction.
-    const int srow = wid * 4 + (lane >> 4), spos = lane & 15;
-    const int schunk = spos ^ (((srow & 3) << 2) | ((srow >> 2) & 3));
-    const int ns = (int)(a.Sq / BQS);
-    auto stage = [&](int sl_, char *group) { // KNS consecutive slices -> one buffer group
-#pragma unroll
-        for (int j = 0; j < KNS; ++j) {
-            if (sl_ + j >= ns) break;
-            char *buf = group + j * KSL;
-            const int64_t qs_ = (int64_t)(sl_ + j) * BQS;
-            const char *qsrc = Qg + (qs_ + srow) * AROW + schunk * 16;
-            const char *osrc = dOg + (qs_ + srow) * AROW + schunk * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)qsrc,
-                                             (__attribute__((address_space(3))) void *)(buf + wid * 4 * AROW), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)osrc,
-                                             (__attribute__((address_space(3))) void *)(buf + BQS * AROW + wid * 4 * AROW), 16, 0, 0);
-            if (wid == j) {
-                const float *src = lane < BQS ? lse_g + qs_ + lane : dlt_g + qs_ + lane - BQS;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(buf + 2 * BQS * AROW), 4, 0, 0);
-            }
-        }
-    };
-    int sl = (int)(k0 / BQS); // first slice holding a query >= the block's first key
-    if (sl < ns) stage(sl, smem);
-    __syncthreads(); // waits for the LDS-DMA (vmcnt) and the V slab writes
-    for (int it = 0; sl < ns; sl += KNS, ++it) {
-        const char *cur = smem + (it & 1) * KNS * KSL;
-        char *nxt = smem + ((it + 1) & 1) * KNS * KSL;
-        if (sl + KNS < ns) stage(sl + KNS, nxt); // the group every wave finished reading at the last barrier
-#pragma unroll
-        for (int j = 0; j < KNS; ++j) {
-            if (sl + j >= ns) break;
-            const int64_t qs = (int64_t)(sl + j) * BQS;
-            const bool skip = !active || qs + BQS - 1 < kw; // every query of the slice precedes this wave's keys
-            const bool diag = qs < kw + 31;
-            if (!skip) {
-                if (diag) kv_slice<BF, true>(cur + j * KSL, vslab, kf, ko, vo, dk, dv, c, qs, n, hl);
-                else kv_slice<BF, false>(cur + j * KSL, vslab, kf, ko, vo, dk, dv, c, qs, n, hl);
-            }
-        }
-        __syncthreads();
-    }
-    if (active) {
-        a_store_rows<BF>(smem + wid * 32 * OPAD, a.dv + (bh * a.Skv + kw) * AROW, dv, 1.f);
-        a_store_rows<BF>(smem + wid * 32 * OPAD, a.dk + (bh * a.Skv + kw) * AROW, dk, a.scale);
-    }
-}
-
 // ==========================================================================================
 // backward: dK, dV, v4 - 4 waves x 32 keys, ONE wave per SIMD and the 512-register budget that goes with it.
-// The two-waves-per-SIMD kernel above cannot keep enough LDS reads in flight (256 registers, 128 of them
-// accumulators): its waves sit in s_waitcnt two thirds of the time. Here a wave walks a slice as eight quarter-phases
+// A two-waves-per-SIMD form (round 1's first dK/dV kernel, removed) cannot keep enough LDS reads in flight (256 registers,
+// 128 of them accumulators): its waves sat in s_waitcnt two thirds of the time. Here a wave walks a slice as eight quarter-phases
 // of 4 MFMAs (S, S, dP, dP, dV, dV, dK, dK), every quarter-phase's LDS fragments requested two quarter-phases ahead
 // (inline-asm reads, counted lgkmcnt waits that name their destinations). The arithmetic hides under MFMAs of the
 // SAME slice: p = exp2(c S') needs only S, so it runs under the dP chain; dV needs only p, so dS = p dP' runs under
@@ -1791,10 +1634,7 @@ static bool mfma_ok(int dtype, int64_t Sq, int64_t Skv, int64_t D) {
 static inline size_t a_align(size_t v) { return (v + 255) / 256 * 256; }
 
 template <typename K>
-static int set_lds(K kernel, size_t bytes) {
-    KF_HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return KF_OK;
-}
+static int set_lds(K kernel, size_t bytes) { return ensure_dynamic_lds((const void *)kernel, (int)bytes); }
 
 } // namespace kf
 
@@ -1827,12 +1667,12 @@ extern "C" int kf_attn_fwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, i
     a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.D = D;
     KF_REQUIRE(scale > 0.f && scale < INFINITY, KF_ERR_INVALID, "attention: the softmax scale must be positive and finite");
     a.scale = scale;
-    a.xcd_map = ((B * H) % 8 == 0) && !getenv("KF_ATTN_NO_XCD");
-    a.defer = getenv("KF_ATTN_NO_DEFER") ? -INFINITY : kDeferMax; // A/B switch: rescale O at every tile
+    a.xcd_map = ((B * H) % 8 == 0) && !knob(KNOB_ATTN_NO_XCD);
+    a.defer = knob(KNOB_ATTN_NO_DEFER) ? -INFINITY : kDeferMax; // A/B switch: rescale O at every tile
     if (mfma_ok(dtype, Sq, Skv, D)) {
         const size_t lds3 = SRING * FBUF;
         const int64_t nxb3 = (Sq + FQ - 1) / FQ;
-        a.persist = (nxb3 % 2 == 0 && nxb3 >= 4 && !getenv("KF_ATTN_NO_PAIR")) ? 1 : 0;
+        a.persist = (nxb3 % 2 == 0 && nxb3 >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
         dim3 grid3((unsigned)((a.persist ? nxb3 / (2 * a.persist) : nxb3) * B * H));
         KF_PROF("attn_fwd_mfma", st);
         if ((rc = set_lds(attn_fwd_v3_kernel<true>, lds3)) != KF_OK) return rc;
@@ -1842,11 +1682,11 @@ extern "C" int kf_attn_fwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, i
         KF_LAUNCH_CHECK();
         return KF_OK;
     }
-    if (dtype == KF_F32 && (D == 64 || D == 128) && Sq % 32 == 0 && Skv % 32 == 0 && !getenv("KF_ATTN_F32_GENERIC")) {
+    if (dtype == KF_F32 && (D == 64 || D == 128) && Sq % 32 == 0 && Skv % 32 == 0 && !knob(KNOB_ATTN_F32_GENERIC)) {
         // the reference's own fast path (f32, head size 64 or 128): exact-f32 MFMA
         const size_t ldsx = std::max((size_t)2 * XK * (D + 4), (size_t)4 * 32 * (D + 4)) * sizeof(float);
         const int64_t nxx = (Sq + XQ - 1) / XQ;
-        a.persist = (nxx % 2 == 0 && nxx >= 4 && !getenv("KF_ATTN_NO_PAIR")) ? 1 : 0;
+        a.persist = (nxx % 2 == 0 && nxx >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
         dim3 gridx((unsigned)((a.persist ? nxx / 2 : nxx) * B * H));
         KF_PROF("attn_fwd_f32_mfma", st);
         if (D == 128) {
@@ -1918,7 +1758,7 @@ extern "C" int kf_attn_bwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, i
     a.lse_r = lse; a.delta = (float *)workspace;
     a.nlse = (float *)((char *)workspace + a_align((size_t)B * H * Sq * sizeof(float)));
     a.ndelta = (float *)((char *)workspace + 2 * a_align((size_t)B * H * Sq * sizeof(float)));
-    a.xcd_map = ((B * H) % 8 == 0) && !getenv("KF_ATTN_NO_XCD");
+    a.xcd_map = ((B * H) % 8 == 0) && !knob(KNOB_ATTN_NO_XCD);
     a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.D = D;
     KF_REQUIRE(scale > 0.f && scale < INFINITY, KF_ERR_INVALID, "attention: the softmax scale must be positive and finite");
     a.scale = scale;
@@ -1932,9 +1772,9 @@ extern "C" int kf_attn_bwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, i
             else attn_delta_kernel<false><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, 1.0f / a.scale);
             KF_LAUNCH_CHECK();
         }
-        if (!getenv("KF_ATTN_DKV_V2")) { // default: one wave per SIMD, pinned MFMA / VALU interleave
+        { // one wave per SIMD, pinned MFMA / VALU interleave
             const int64_t nkb4 = Skv / K4B;
-            a.persist = (nkb4 % 2 == 0 && nkb4 >= 4 && !getenv("KF_ATTN_NO_PAIR")) ? 1 : 0;
+            a.persist = (nkb4 % 2 == 0 && nkb4 >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
             a.persist_rev = 1; // the short block of the pair first: 2.17 ms against 2.32 the other way round (2.22 unpaired)
             dim3 gk4((unsigned)((a.persist ? nkb4 / 2 : nkb4) * B * H));
             if ((rc = set_lds(attn_bwd_dkv_v4_kernel<true>, K4LDS)) != KF_OK) return rc;
@@ -1943,19 +1783,10 @@ extern "C" int kf_attn_bwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, i
             if (bf) attn_bwd_dkv_v4_kernel<true><<<gk4, 256, K4LDS, st>>>(a);
             else attn_bwd_dkv_v4_kernel<false><<<gk4, 256, K4LDS, st>>>(a);
             KF_LAUNCH_CHECK();
-        } else { // A/B switch: the two-waves-per-SIMD kernel it replaced
-            a.persist = 0;
-            dim3 gk2((unsigned)(((Skv + KVB - 1) / KVB) * B * H));
-            if ((rc = set_lds(attn_bwd_dkv_v2_kernel<true>, KLDS)) != KF_OK) return rc;
-            if ((rc = set_lds(attn_bwd_dkv_v2_kernel<false>, KLDS)) != KF_OK) return rc;
-            KF_PROF("attn_bwd_dkv_mfma_v2", st);
-            if (bf) attn_bwd_dkv_v2_kernel<true><<<gk2, FNT, KLDS, st>>>(a);
-            else attn_bwd_dkv_v2_kernel<false><<<gk2, FNT, KLDS, st>>>(a);
-            KF_LAUNCH_CHECK();
         }
         {
             const int64_t nxq = (Sq + FQ - 1) / FQ;
-            a.persist = (nxq % 2 == 0 && nxq >= 4 && !getenv("KF_ATTN_NO_PAIR")) ? 1 : 0;
+            a.persist = (nxq % 2 == 0 && nxq >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
             a.persist_rev = 0;
             dim3 gq2((unsigned)((a.persist ? nxq / 2 : nxq) * B * H));
             if ((rc = set_lds(attn_bwd_dq_v2_kernel<true>, QLDS)) != KF_OK) return rc;
@@ -1968,7 +1799,7 @@ extern "C" int kf_attn_bwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, i
         return KF_OK;
     }
     const unsigned gd = (unsigned)((nrows + 3) / 4);
-    if (dtype == KF_F32 && (D == 64 || D == 128) && Sq % 32 == 0 && Skv % 32 == 0 && !getenv("KF_ATTN_F32_GENERIC")) {
+    if (dtype == KF_F32 && (D == 64 || D == 128) && Sq % 32 == 0 && Skv % 32 == 0 && !knob(KNOB_ATTN_F32_GENERIC)) {
         // exact-f32 MFMA backward (the f32 forward's counterpart; the reference has no backward)
         {
             KF_PROF("attn_bwd_delta", st);
@@ -1979,7 +1810,7 @@ extern "C" int kf_attn_bwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, i
         const size_t ldsx = std::max(tiles, slabs);
         const int64_t nxq = (Sq + XQ - 1) / XQ, nkb = (Skv + XQ - 1) / XQ;
         {
-            a.persist = (nkb % 2 == 0 && nkb >= 4 && !getenv("KF_ATTN_NO_PAIR")) ? 1 : 0;
+            a.persist = (nkb % 2 == 0 && nkb >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
             dim3 g((unsigned)((a.persist ? nkb / 2 : nkb) * B * H));
             KF_PROF("attn_bwd_dkv_f32_mfma", st);
             if (D == 128) {
@@ -1992,7 +1823,7 @@ extern "C" int kf_attn_bwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, i
             KF_LAUNCH_CHECK();
         }
         {
-            a.persist = (nxq % 2 == 0 && nxq >= 4 && !getenv("KF_ATTN_NO_PAIR")) ? 1 : 0;
+            a.persist = (nxq % 2 == 0 && nxq >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
             dim3 g((unsigned)((a.persist ? nxq / 2 : nxq) * B * H));
             KF_PROF("attn_bwd_dq_f32_mfma", st);
             if (D == 128) {

@@ -88,4 +88,21 @@ struct ProfScope {
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// A/B switches (KF_* environment variables): read ONCE per process, not per launch (getenv walks the whole environment);
+// kf_knobs_reload() re-reads them (tests and tools that flip a switch between two calls).
+enum Knob {
+    KNOB_ATTN_NO_XCD, KNOB_ATTN_NO_DEFER, KNOB_ATTN_NO_PAIR, KNOB_ATTN_F32_GENERIC, KNOB_ATTN_SPLIT_BWD, KNOB_GEMM_128, KNOB_GEMM_W4,
+    KNOB_GEMM_W8, KNOB_GEMM_GROUP_M, KNOB_GEMM_F64_GENERIC, KNOB_REDUCE_NO_TALL, KNOB_GEMM_NO_SPLITK, KNOB_COUNT
+};
+bool knob(Knob k);              // the variable is set
+long knob_int(Knob k, long dflt); // its integer value, dflt when unset
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device), not once per launch
+int ensure_dynamic_lds(const void *kernel, int bytes);
+#define KF_ENSURE_LDS(kernel, bytes)                                                      \
+    do {                                                                                  \
+        int rc_ = ::kf::ensure_dynamic_lds((const void *)(kernel), (int)(bytes));         \
+        if (rc_ != KF_OK) return rc_;                                                     \
+    } while (0)
+
 } // namespace kf

@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GemmArgs g, int
     const T *A = (const T *)g.A, *B = (const T *)g.B;
     T *C = (T *)g.C;
     const int tx = threadIdx.x % 16, ty = threadIdx.x / 16;
-    const int64_t m0 = (int64_t)blockIdx.y * TS, n0 = (int64_t)blockIdx.x * TS;
+    // 1-D grid, N tiles fastest (a 2-D grid's y extent stops at 65535: 2 M flattened rows)
+    const int64_t ntn = (g.N + TS - 1) / TS;
+    const int64_t m0 = (int64_t)(blockIdx.x / ntn) * TS, n0 = (int64_t)(blockIdx.x % ntn) * TS;
     A_t acc[2][2] = {{0, 0}, {0, 0}};
     for (int64_t k0 = 0; k0 < g.K; k0 += TK) {
         for (int i = threadIdx.x; i < TS * TK; i += 256) {
@@ -1082,7 +1084,7 @@ using namespace kf;
 // times as many 128-tile blocks instead (2048^3: 64 tiles of 256^2 would leave three quarters of the CUs idle)
 static bool h256_ok(int64_t M, int64_t N, int64_t K) {
     return M % G_BM == 0 && N % G_BN == 0 && K % G_BK == 0 && M > 0 && N > 0 && K > 0 && (M / G_BM) * (N / G_BN) >= 160 &&
-           !getenv("KF_GEMM_128");
+           !knob(KNOB_GEMM_128);
 }
 
 extern "C" int kf_gemm_workspace_bytes(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, size_t *bytes) {
@@ -1093,22 +1095,26 @@ extern "C" int kf_gemm_workspace_bytes(int dtype, int trans_a, int trans_b, int6
     return KF_OK;
 }
 
+// both 256-tile forms run at the clock the chip holds under the load (tools/gemm_clock.py) and end up within a few % of each
+// other; the 4-wave form is ahead while the grid is at most two rounds of tiles, the 8-wave form on larger grids
+static bool h256_use_w4(int64_t M, int64_t N) {
+    const int64_t grid = (M / G_BM) * (N / G_BN);
+    return knob(KNOB_GEMM_W4) ? true : (knob(KNOB_GEMM_W8) ? false : grid <= 512);
+}
+
 template <bool BF>
-static int launch_h256(const GemmArgs &g, bool tra, bool trb, hipStream_t st) {
+static int launch_h256(const GemmArgs &g, bool tra, bool trb, bool w4, hipStream_t st) {
     const unsigned grid = (unsigned)((g.M / G_BM) * (g.N / G_BN));
 #define KF_H256(TA, TB)                                                                                                   \
     {                                                                                                                     \
-        KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_h256_kernel<BF, TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS)); \
+        KF_ENSURE_LDS((gemm_h256_kernel<BF, TA, TB>), G_LDS); \
         gemm_h256_kernel<BF, TA, TB><<<grid, G_NT, G_LDS, st>>>(g);                                                       \
     }
 #define KF_W4(TA, TB)                                                                                                     \
     {                                                                                                                     \
-        KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_w4_kernel<BF, TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS)); \
+        KF_ENSURE_LDS((gemm_w4_kernel<BF, TA, TB>), G_LDS); \
         gemm_w4_kernel<BF, TA, TB><<<grid, W4_NT, G_LDS, st>>>(g);                                                        \
     }
-    // both forms run at the clock the chip holds under the load (tools/gemm_clock.py) and end up within a few % of each
-    // other; the 4-wave form is ahead while the grid is at most two rounds of tiles, the 8-wave form on larger grids
-    const bool w4 = getenv("KF_GEMM_W4") ? true : (getenv("KF_GEMM_W8") ? false : grid <= 512);
     if (w4) {
         if (!tra && !trb) KF_W4(false, false)
         else if (!tra && trb) KF_W4(false, true)
@@ -1127,16 +1133,19 @@ static int launch_h256(const GemmArgs &g, bool tra, bool trb, hipStream_t st) {
     return KF_OK;
 }
 
-// diagnostic entry (not part of the C ABI; tools/gemm_clock.py): bf16 A [M,K] x B stored [N,K] through the 4-wave kernel with
-// clock stamps; diag receives {core-clock cycles, 100 MHz ticks} of the main loop per workgroup
+// diagnostic entry, compiled only into the separate diagnostic library (-DKF_DIAG_BUILD, kfunca_amd/_build.py build_diag;
+// tools/gemm_clock.py) - never into libkfunca_hip.so: bf16 A [M,K] x B stored [N,K] through the 4-wave kernel with clock
+// stamps; diag receives {core-clock cycles, 100 MHz ticks} of the main loop per workgroup
+#ifdef KF_DIAG_BUILD
 extern "C" int kfdbg_gemm_clock(int64_t M, int64_t N, int64_t K, const void *A, const void *B, void *C, void *diag, void *stream) {
     KF_REQUIRE(h256_ok(M, N, K) && A && B && C && diag, KF_ERR_INVALID, "kfdbg_gemm_clock: 256-tile shapes only");
     GemmArgs g{A, B, C, diag, M, N, K, K, K, N, 1.f, 0.f, KF_EPI_NONE, 4};
-    KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_w4_kernel<true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS));
+    KF_ENSURE_LDS((gemm_w4_kernel<true, false, false, true>), G_LDS);
     gemm_w4_kernel<true, false, false, true><<<(unsigned)((M / G_BM) * (N / G_BN)), W4_NT, G_LDS, as_stream(stream)>>>(g);
     KF_LAUNCH_CHECK();
     return KF_OK;
 }
+#endif
 
 extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const void *A,
                        int64_t lda, const void *B, int64_t ldb, float beta, void *C, int64_t ldc, int epilogue,
@@ -1148,18 +1157,16 @@ extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N
     KF_REQUIRE(A && B && C, KF_ERR_INVALID, "kf_gemm: null operand");
     KF_REQUIRE(lda >= (trans_a ? M : K) && ldb >= (trans_b ? K : N) && ldc >= N, KF_ERR_INVALID, "kf_gemm: leading dimension too small");
     KF_REQUIRE(epilogue == KF_EPI_NONE || (epilogue == KF_EPI_BIAS_ROW && bias), KF_ERR_INVALID, "kf_gemm: bad epilogue");
+    KF_REQUIRE((M + 63) / 64 * ((N + 63) / 64) <= 0x7fffffffLL, KF_ERR_INDEX_RANGE, "kf_gemm: too many output tiles for one launch");
     hipStream_t st = as_stream(stream);
     GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, beta, epilogue, 0};
-    {
-        const char *e = getenv("KF_GEMM_GROUP_M");
-        g.group_m = e ? atoi(e) : 4;
-    }
+    g.group_m = (int)knob_int(KNOB_GEMM_GROUP_M, 4);
 
     const bool al16 = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0);
     if (dtype == KF_F32 && M % 64 == 0 && N % 64 == 0 && K % F_BK == 0 && K > 0 && al16 && lda % 4 == 0 && ldb % 4 == 0) {
         // 128-tiles unless they would leave a quarter of the CUs idle and 64-tiles are possible... or are the only option
         const bool t128 = M % F_BM == 0 && N % F_BN == 0 && (M / F_BM) * (N / F_BN) >= 192;
-        KF_PROF("gemm_f32_mfma", st);
+        KF_PROF(t128 ? "gemm_f32_mfma" : "gemm_f32_mfma_t64", st);
 #define KF_F32G(T_)                                                                                          \
     {                                                                                                        \
         const unsigned grid = (unsigned)((M / T_) * (N / T_));                                               \
@@ -1173,7 +1180,7 @@ extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N
         KF_LAUNCH_CHECK();
         return KF_OK;
     }
-    if (dtype == KF_F64 && M % D_T == 0 && N % D_T == 0 && K % D_BK == 0 && K > 0 && al16 && lda % 2 == 0 && ldb % 2 == 0 && !getenv("KF_GEMM_F64_GENERIC")) {
+    if (dtype == KF_F64 && M % D_T == 0 && N % D_T == 0 && K % D_BK == 0 && K > 0 && al16 && lda % 2 == 0 && ldb % 2 == 0 && !knob(KNOB_GEMM_F64_GENERIC)) {
         const unsigned grid = (unsigned)((M / D_T) * (N / D_T));
         KF_PROF("gemm_f64_mfma", st);
         if (!trans_a && !trans_b) gemm_f64_kernel<false, false><<<grid, 256, 0, st>>>(g);
@@ -1185,8 +1192,9 @@ extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N
     }
     if ((dtype == KF_BF16 || dtype == KF_F16) && h_fast_ok(M, N, K) && al16 && lda % 8 == 0 && ldb % 8 == 0) {
         if (h256_ok(M, N, K)) { // every operand layout is consumed in place
-            KF_PROF(dtype == KF_BF16 ? "gemm_bf16_mfma" : "gemm_f16_mfma", st);
-            return dtype == KF_BF16 ? launch_h256<true>(g, trans_a != 0, !trans_b, st) : launch_h256<false>(g, trans_a != 0, !trans_b, st);
+            const bool w4 = h256_use_w4(M, N); // profile labels name the kernel that ran (tests assert them)
+            KF_PROF(dtype == KF_BF16 ? (w4 ? "gemm_bf16_mfma" : "gemm_bf16_mfma_w8") : (w4 ? "gemm_f16_mfma" : "gemm_f16_mfma_w8"), st);
+            return dtype == KF_BF16 ? launch_h256<true>(g, trans_a != 0, !trans_b, w4, st) : launch_h256<false>(g, trans_a != 0, !trans_b, w4, st);
         }
         const unsigned grid = (unsigned)((M / H_BM) * (N / H_BN));
         const size_t lds = 4 * H_TILE_BYTES;
@@ -1194,7 +1202,7 @@ extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N
         const bool tra = trans_a != 0, trb = !trans_b; // transposed-read operands: consumed as they lie in memory, no re-layout pass
 #define KF_H128(BF_, TA, TB)                                                                                                   \
     {                                                                                                                          \
-        KF_HIP_TRY(hipFuncSetAttribute((const void *)gemm_h_kernel<BF_, TA, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        KF_ENSURE_LDS((gemm_h_kernel<BF_, TA, TB>), (int)lds); \
         gemm_h_kernel<BF_, TA, TB><<<grid, 256, lds, st>>>(g);                                                                 \
     }
 #define KF_H128_L(BF_)                                  \
@@ -1208,7 +1216,9 @@ extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N
         KF_LAUNCH_CHECK();
         return KF_OK;
     }
-    dim3 grid((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32));
+    const int64_t gtiles = ((N + 31) / 32) * ((M + 31) / 32);
+    KF_REQUIRE(gtiles <= 0x7fffffffLL, KF_ERR_INDEX_RANGE, "kf_gemm: %lld output tiles exceed the grid limit", (long long)gtiles);
+    const unsigned grid = (unsigned)gtiles;
     KF_PROF("gemm_generic", st);
     switch (dtype) {
     case KF_F32: gemm_generic_kernel<float><<<grid, 256, 0, st>>>(g, trans_a, trans_b); break;

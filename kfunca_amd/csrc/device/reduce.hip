@@ -480,7 +480,7 @@ static int make_plan(const kf_iter_desc *d, Plan &p, bool moments = false) {
         p.nsplit = (int)ns;
         // small column reductions that would be split: one launch of 16-column x 16-row-group blocks instead of split + fold
         const int64_t in_bytes = p.R * p.C * p.nouter * es;
-        if (ns > 1 && in_bytes <= ((int64_t)16 << 20) && (p.C + 15) / 16 * p.nouter >= 32 && !getenv("KF_REDUCE_NO_TALL")) {
+        if (ns > 1 && in_bytes <= ((int64_t)16 << 20) && (p.C + 15) / 16 * p.nouter >= 32 && !knob(KNOB_REDUCE_NO_TALL)) {
             p.tall = true;
             p.nsplit = 1;
         }

@@ -61,9 +61,62 @@ static void prof_collect() { // folds finished records into per-name sums
 }
 } // namespace kf
 
+// ---- A/B switches and per-kernel attributes, cached ----------------------------------------------
+#include <stdlib.h>
+namespace kf {
+static const char *const g_knob_names[KNOB_COUNT] = {
+    "KF_ATTN_NO_XCD", "KF_ATTN_NO_DEFER", "KF_ATTN_NO_PAIR", "KF_ATTN_F32_GENERIC", "KF_ATTN_SPLIT_BWD", "KF_GEMM_128", "KF_GEMM_W4",
+    "KF_GEMM_W8", "KF_GEMM_GROUP_M", "KF_GEMM_F64_GENERIC", "KF_REDUCE_NO_TALL", "KF_GEMM_NO_SPLITK"};
+static std::mutex g_knob_mu;
+static bool g_knob_loaded = false;
+static bool g_knob_set[KNOB_COUNT];
+static long g_knob_val[KNOB_COUNT];
+static void knobs_load_locked() {
+    for (int i = 0; i < KNOB_COUNT; ++i) {
+        const char *e = getenv(g_knob_names[i]);
+        g_knob_set[i] = e != nullptr;
+        g_knob_val[i] = e ? strtol(e, nullptr, 10) : 0;
+    }
+    g_knob_loaded = true;
+}
+bool knob(Knob k) {
+    if (!g_knob_loaded) {
+        std::lock_guard<std::mutex> lk(g_knob_mu);
+        if (!g_knob_loaded) knobs_load_locked();
+    }
+    return g_knob_set[k];
+}
+long knob_int(Knob k, long dflt) { return knob(k) ? g_knob_val[k] : dflt; }
+
+struct LdsAttr { const void *fn; int dev; int bytes; };
+static std::mutex g_lds_mu;
+static std::vector<LdsAttr> g_lds_attrs;
+int ensure_dynamic_lds(const void *kernel, int bytes) {
+    int dev = 0;
+    KF_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_lds_mu);
+    for (auto &a : g_lds_attrs)
+        if (a.fn == kernel && a.dev == dev) {
+            if (a.bytes >= bytes) return KF_OK;
+            KF_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+            a.bytes = bytes;
+            return KF_OK;
+        }
+    KF_HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    g_lds_attrs.push_back({kernel, dev, bytes});
+    return KF_OK;
+}
+} // namespace kf
+
 using namespace kf;
 
 extern "C" {
+
+int kf_knobs_reload(void) {
+    std::lock_guard<std::mutex> lk(g_knob_mu);
+    knobs_load_locked();
+    return KF_OK;
+}
 
 int kf_profile_enable(int on) { g_prof_on = on != 0; return KF_OK; }
 int kf_profile_reset(void) {

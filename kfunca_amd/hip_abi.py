@@ -36,7 +36,7 @@ EXPORTS = [
     "kf_last_error", "kf_abi_version", "kf_device_count", "kf_set_device", "kf_get_device", "kf_malloc", "kf_free",
     "kf_memcpy_h2d", "kf_memcpy_d2h", "kf_memcpy_d2d", "kf_memset_zero", "kf_stream_create", "kf_stream_destroy",
     "kf_stream_sync", "kf_stream_wait_event", "kf_device_sync", "kf_event_create", "kf_event_destroy", "kf_event_record", "kf_event_sync",
-    "kf_event_elapsed_ms", "kf_graph_begin_capture", "kf_graph_end_capture", "kf_graph_launch", "kf_graph_destroy", "kf_profile_enable", "kf_profile_reset", "kf_profile_count", "kf_profile_get",
+    "kf_event_elapsed_ms", "kf_graph_begin_capture", "kf_graph_end_capture", "kf_graph_launch", "kf_graph_destroy", "kf_profile_enable", "kf_profile_reset", "kf_profile_count", "kf_profile_get", "kf_knobs_reload",
     "kf_device_props_get", "kf_elementwise", "kf_reduce_workspace_bytes", "kf_reduce",
     "kf_reduce_moments_workspace_bytes", "kf_reduce_moments",
     "kf_index_put", "kf_sort_workspace_bytes", "kf_sort", "kf_gemm_workspace_bytes", "kf_gemm", "kf_attn_fwd", "kf_attn_fwd_scaled", "kf_attn_bwd_workspace_bytes",
@@ -430,6 +430,39 @@ def device_sync():
 
 def stream_wait_event(stream, event: "Event"):
     check(lib().kf_stream_wait_event(stream, event.handle))
+
+
+def knobs_reload():
+    """Re-read the KF_* A/B switches from the environment (they are cached per process)."""
+    check(lib().kf_knobs_reload())
+
+
+class knobs:
+    """`with knobs(KF_ATTN_NO_XCD="1"): ...` — set A/B switches for the calls inside the block, restore them after."""
+
+    def __init__(self, **env):
+        self.env, self.old = env, {}
+
+    def __enter__(self):
+        import os
+        for k, v in self.env.items():
+            self.old[k] = os.environ.get(k)
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+        knobs_reload()
+        return self
+
+    def __exit__(self, *exc):
+        import os
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        knobs_reload()
+        return False
 
 
 def profile_enable(on: bool):

@@ -213,20 +213,16 @@ def test_causal_pairing_is_a_schedule_not_arithmetic():
     """A workgroup that takes a block and its causal mirror computes exactly what two workgroups compute: forward, LSE and all
     three gradients are bit-identical with the pairing switched off (`KF_ATTN_NO_PAIR`), on paired shapes (even block counts),
     unpaired ones (odd counts) and Sq != Skv."""
-    import os
     for (B, Hh, Sq, Skv) in ((2, 8, 2048, 2048), (1, 8, 1536, 1536), (1, 4, 1024, 2048), (1, 3, 768, 768)):
         rng = np.random.default_rng(55 + Sq + Skv)
         q, k, v, go = (O.from_float(rng.uniform(-1, 1, s).astype(np.float32), H.BF16)
                        for s in ((B, Hh, Sq, 128), (B, Hh, Skv, 128), (B, Hh, Skv, 128), (B, Hh, Sq, 128)))
-        os.environ.pop("KF_ATTN_NO_PAIR", None)
-        o1, l1 = fwd(H.BF16, q, k, v)
-        g1 = bwd(H.BF16, q, k, v, o1, l1, go)
-        os.environ["KF_ATTN_NO_PAIR"] = "1"
-        try:
+        with H.knobs(KF_ATTN_NO_PAIR=None):
+            o1, l1 = fwd(H.BF16, q, k, v)
+            g1 = bwd(H.BF16, q, k, v, o1, l1, go)
+        with H.knobs(KF_ATTN_NO_PAIR="1"):
             o0, l0 = fwd(H.BF16, q, k, v)
             g0 = bwd(H.BF16, q, k, v, o0, l0, go)
-        finally:
-            os.environ.pop("KF_ATTN_NO_PAIR", None)
         assert np.array_equal(o0, o1) and np.array_equal(l0.view(np.uint32), l1.view(np.uint32)), (Sq, Skv)
         for a0, a1 in zip(g0, g1):
             assert np.array_equal(a0.view(np.uint16), a1.view(np.uint16)), (Sq, Skv)

@@ -55,6 +55,7 @@ def main():
                 for kv in v.split("+"):
                     k, _, val = kv.partition("=")
                     os.environ[k] = val or "1"
+            H.knobs_reload()
             H.profile_reset()
             H.profile_enable(True)
             H.attn_fwd(H.BF16, B, Hh, S, S, D, bufs["q"].ptr, bufs["k"].ptr, bufs["v"].ptr, bufs["o"].ptr, lse.ptr)

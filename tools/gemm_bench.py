@@ -42,6 +42,7 @@ def main():
             if v != "default":
                 name, _, val = v.partition("=")
                 os.environ[name] = val or "1"
+            H.knobs_reload()
             for tag, ta, tb, X, Y in (("NN fwd", 0, 0, A, W), ("NT dA", 0, 1, G, W), ("TN dB", 1, 0, A, G)):
                 H.profile_reset()
                 H.profile_enable(True)
