@@ -100,8 +100,21 @@ def build_oracle(force: bool = False) -> Path:
     src = ROOT / "oracle" / "oracle.c"
     hdr = ROOT / "oracle" / "oracle.h"
     if force or not _newer(ORACLE_LIB, [src, hdr]):
-        _run(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-std=c11", "-o", ORACLE_LIB, src, "-lm"])
+        # fixed ISA baseline + no implicit fma contraction: the checker must behave the same on the GPU box's host CPU
+        _run(["gcc", "-O3", "-march=x86-64-v3", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared", "-std=c11", "-o", ORACLE_LIB, src, "-lm"])
     return ORACLE_LIB
+
+
+def build_diag(force: bool = False) -> Path:
+    """The diagnostic library tools/gemm_clock.py loads (clock-stamped GEMM kernel, -DKF_DIAG_BUILD): a separate .so under
+    _build/, so that nothing diagnostic is exported from libkfunca_hip.so."""
+    BUILD.mkdir(exist_ok=True)
+    out = BUILD / "libkfunca_hip_diag.so"
+    srcs = [CSRC / "device" / "gemm.hip", CSRC / "device" / "runtime.hip"]
+    hdrs = sorted((CSRC / "device").glob("*.h")) + sorted(INCLUDE.glob("*.h"))
+    if force or not _newer(out, srcs + hdrs):
+        _run([_hipcc(), *HIP_FLAGS, "-DKF_DIAG_BUILD", "-shared", "-o", out, *srcs])
+    return out
 
 
 def build_all(force: bool = False):

@@ -36,10 +36,14 @@ def code_of(arr: np.ndarray, code=None) -> int:
     return _NP2CODE[arr.dtype]
 
 
+# a fixed ISA baseline, not -march=native: the .so is built in one container and loaded on another host (the GPU box);
+# -ffp-contract=off keeps a*b+c un-fused unless the source says fmaf, so the bit-exact comparisons do not depend on the host
+CFLAGS = ["-O3", "-march=x86-64-v3", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared", "-std=c11"]
+
+
 def _build():
     import subprocess
-    subprocess.run(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-std=c11", "-o", str(LIB_PATH),
-                    str(HERE / "oracle.c"), "-lm"], check=True)
+    subprocess.run(["gcc", *CFLAGS, "-o", str(LIB_PATH), str(HERE / "oracle.c"), "-lm"], check=True)
 
 
 _lib = None

@@ -117,7 +117,7 @@ def test_16bit_exact_integers_catch_layout_bugs(code):
     """Small integers are exact in bf16/f16 and in f32 accumulation: any fragment/lane/transposed-read
     mistake shows up as a wrong integer. B is asymmetric, A is not the identity."""
     rng = np.random.default_rng(6)
-    M, N, K = (256, 384, 192) if code == H.F16 else (512, 768, 448)  # f16: 128-tile kernel; bf16: 256-tile phase-staggered kernel
+    M, N, K = (256, 384, 192) if code == H.F16 else (512, 768, 448)  # both run the 128-tile kernel (the 256-tile kernels: test_256_tile_kernel_* below and tests/test_gpu_baseline_sizes.py)
     a = rng.integers(-3, 4, (M, K)).astype(np.float32)
     b = (rng.integers(-2, 3, (K, N)) + (np.arange(N)[None, :] % 3 == 0)).astype(np.float32)
     want = a.astype(np.float64) @ b.astype(np.float64)
@@ -156,7 +156,8 @@ def test_16bit_vs_oracle(code, eps, M, N, K):
 
 @pytest.mark.parametrize("code,eps", [(H.BF16, 2.0 ** -8), (H.F16, 2.0 ** -11)])
 def test_256_tile_kernel_layouts_epilogue_and_unaligned_c(code, eps):
-    """The 256-tile kernel only runs on grids of >= 160 tiles: 2560 x 4096 (K small keeps the oracle cheap). Every operand
+    """The 256-tile kernels only run on grids of >= 160 tiles: 2560 x 4096 (K small keeps the oracle cheap) takes the 4-wave
+    form (asserted; the 8-wave form: tests/test_gpu_baseline_sizes.py). Every operand
     layout, alpha / beta / row bias, and a C whose rows are not 16-byte aligned (the narrow-store epilogue)."""
     rng = np.random.default_rng(77 + code)
     M, N, K = 2560, 4096, 192
@@ -167,7 +168,11 @@ def test_256_tile_kernel_layouts_epilogue_and_unaligned_c(code, eps):
     for ta in (False, True):
         for tb in (False, True):
             sa, sb = (a.T.copy() if ta else a), (b.T.copy() if tb else b)
+            H.profile_reset()
+            H.profile_enable(True)
             got = f64(run_gemm(code, sa, sb, ta, tb), code)
+            H.profile_enable(False)
+            assert set(H.profile_results()) == {"gemm_bf16_mfma" if code == H.BF16 else "gemm_f16_mfma"}
             assert (np.abs(got - want) <= eps * np.abs(want) + 1e-6 * mag + 1e-30).all(), (code, ta, tb)
     bias = O.from_float(rng.uniform(-1, 1, (N,)).astype(np.float32), code)
     c = O.from_float(rng.uniform(-1, 1, (M, N)).astype(np.float32), code)

@@ -34,7 +34,8 @@ def main():
     Cb = H.DevBuf(2 * n * n)
     nblk = (n // 256) ** 2
     diag = H.DevBuf(16 * nblk)
-    f = H.lib().kfdbg_gemm_clock
+    from kfunca_amd import _build
+    f = C.CDLL(str(_build.build_diag())).kfdbg_gemm_clock  # the diagnostic build: not part of libkfunca_hip.so
     f.argtypes = [C.c_int64] * 3 + [C.c_void_p] * 5
     t_end = time.time() + args.seconds
     launches = 0
