@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
 """bench.py — the hot path's headline benchmark on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU; see the driver contract)
+    python bench.py --gpus N --steps K --warmup W [--check]
 
-One "step" = one pass of the hot path over one batch of synthetic bf16 tensors, everything through the
-C ABI (include/kfunca_hip.h) with inputs already resident in HBM:
+N > 1 runs one process per GPU. Started by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment) each
+process is one rank; started plainly (`python bench.py --gpus 8`) this process touches no GPU: it starts the N rank
+processes itself (children, never an exec), relays rank 0's JSON line and exits with the worst child status.
+
+One "step" = one pass of the hot path over one batch of synthetic bf16 tensors, everything through the C ABI
+(include/kfunca_hip.h) with inputs already resident in HBM:
     GEMM 4096^3 forward + backward   C = A W,  dA = dC W^T,  dW = A^T dC       (BASELINE target GEMM)
     causal attention forward + backward, B=8 H=32 S=4096 D=128               (BASELINE configs[2] / C3)
-At N > 1 the batch is sharded (weak scaling: every rank runs the per-GPU batch above) and the weight
-gradient dW is sum-all-reduced over RCCL/xGMI on a second stream, overlapped with the attention pass.
+At N > 1 the batch is sharded (weak scaling: every rank runs the per-GPU batch above) and the weight gradient dW is
+sum-all-reduced over RCCL/xGMI (kfunca_amd.parallel.ProcessGroup) on a second stream, overlapped with the attention pass.
 
-Prints ONE JSON line on rank 0: tokens/s over the whole job, per-kernel HIP-event durations, the
-`roofline` of the dominant kernel and a `cpu_baseline` (the CPU oracle timed on a bounded sample).
+Rank 0 prints ONE JSON line: tokens/s over the whole job for the K timed steps, the same over a >= 2 s sustained loop
+(the chip needs ~2 s of back-to-back work to settle its clock), per-kernel HIP-event durations, the all-reduce time and bus
+bandwidth, the `roofline` of the dominant kernel and a `cpu_baseline` (the CPU oracle timed on a bounded sample).
+--check (and always at N = 1): after timing, outputs of the timed buffers are compared with the oracle; with a
+communicator the all-reduced dW is compared with the sum of the ranks' own dW taken over gloo on the host.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
+import math
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -27,20 +37,19 @@ import numpy as np
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-from kfunca_amd import hip_abi as H  # noqa: E402
-
 GEMM_N = 4096
 AB, AH, AS, AD = 8, 32, 4096, 128
 PEAK_MFMA_BF16 = 2500.0  # TFLOP/s dense, MI355X_MICROARCH.md "Peak BF16/FP16 MFMA"
 PEAK_HBM = 8000.0        # GB/s spec, same guide
+XGMI_PEAK = 7 * 153.0    # GB/s per GPU, all links
 
-# algorithmic FLOPs per launch (SURVEY.md §8d): causal attention counts S^2/2 score entries
+# algorithmic FLOPs per launch (SURVEY.md section 8d): causal attention counts S^2/2 score entries
 _PAIR = AB * AH * AS * AS * AD / 2.0
 KERNEL_FLOPS = {
     "gemm_bf16_mfma": 2.0 * GEMM_N ** 3,
     "attn_fwd_mfma": 4.0 * _PAIR,       # QK^T + PV
     "attn_bwd_dkv_mfma": 8.0 * _PAIR,   # S, dP, dV, dK
-    "attn_bwd_dq_mfma": 2.0 * _PAIR,    # dQ (its S / dP recomputation is overhead, not algorithmic work)
+    "attn_bwd_dq_mfma": 2.0 * _PAIR,    # dQ = dS K
 }
 GEMM_FLOPS_STEP = 6.0 * GEMM_N ** 3
 ATTN_FLOPS_STEP = 14.0 * _PAIR
@@ -53,24 +62,37 @@ def bf16_random(rng, shape):
     return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
 
 
+def device_src_sha() -> str:
+    """Content hash of the device sources: profiles/*.json written by tools/pmc_*.py carry it, and a profile whose stamp
+    differs from the tree being benchmarked is not quoted (the GPU box has no .git, so a commit id is not available)."""
+    h = hashlib.sha256()
+    for p in sorted((ROOT / "kfunca_amd" / "csrc" / "device").glob("*")):
+        if p.suffix in (".hip", ".h"):
+            h.update(p.name.encode())
+            h.update(p.read_bytes())
+    return h.hexdigest()[:16]
+
+
 class Workload:
-    def __init__(self, rank):
+    def __init__(self, H, rank):
+        self.H = H
         rng = np.random.default_rng(1003 + 7919 * rank)  # seed = 1000 + config number (C3), rank-offset data
         n = GEMM_N
-        self.A = H.DevBuf.from_numpy(bf16_random(rng, (n, n)))
+        self.A_host = bf16_random(rng, (n, n))
+        self.A = H.DevBuf.from_numpy(self.A_host)
         wrng = np.random.default_rng(1003)                # weights: identical on every rank
-        self.W = H.DevBuf.from_numpy(bf16_random(wrng, (n, n)))
+        self.W_host = bf16_random(wrng, (n, n))
+        self.W = H.DevBuf.from_numpy(self.W_host)
         self.dC = H.DevBuf.from_numpy(bf16_random(rng, (n, n)))
         self.Cc, self.dA, self.dW = H.DevBuf(2 * n * n), H.DevBuf(2 * n * n), H.DevBuf(2 * n * n)
-        need = max(H.gemm_workspace_bytes(H.BF16, ta, tb, n, n, n) for ta, tb in ((0, 0), (0, 1), (1, 0)))
-        self.gws_bytes = need
-        self.gws = H.DevBuf(need)
         nbytes = AB * AH * AS * AD * 2
         self.q, self.k, self.v, self.o, self.do = (H.DevBuf(nbytes) for _ in range(5))
         self.dq, self.dk, self.dv = (H.DevBuf(nbytes) for _ in range(3))
         per_b = nbytes // AB
-        for buf in (self.q, self.k, self.v, self.do):  # one random batch element, replicated on device
+        self.host = {}
+        for name, buf in (("q", self.q), ("k", self.k), ("v", self.v), ("do", self.do)):  # one random batch element, replicated on device
             host = bf16_random(rng, (AH, AS, AD))
+            self.host[name] = host[0].copy()  # head (0, 0), kept for the after-timing spot check
             H.check(H.lib().kf_memcpy_h2d(buf.ptr, host.ctypes.data, per_b, None))
             for b in range(1, AB):
                 H.check(H.lib().kf_memcpy_d2d(buf.ptr + b * per_b, buf.ptr, per_b, None))
@@ -79,22 +101,78 @@ class Workload:
         self.aws = H.DevBuf(self.aws_bytes)
         H.device_sync()
 
-    def step(self, stream, comm=None, comm_stream=None, ev_grad=None, ev_comm=None):
-        n, s = GEMM_N, stream
-        if comm is not None and ev_comm.recorded:  # dW of the previous step must be fully reduced before it is rewritten
+    def step(self, stream, pg=None, comm_stream=None, ev_grad=None, ev_comm=None, comm_events=None):
+        H, n, s = self.H, GEMM_N, stream
+        if pg is not None and ev_comm.recorded:  # dW of the previous step must be fully reduced before it is rewritten
             H.stream_wait_event(s, ev_comm)
-        H.gemm(H.BF16, 0, 0, n, n, n, 1.0, self.A.ptr, n, self.W.ptr, n, 0.0, self.Cc.ptr, n, 0, None, self.gws.ptr, self.gws_bytes, s)
-        H.gemm(H.BF16, 0, 1, n, n, n, 1.0, self.dC.ptr, n, self.W.ptr, n, 0.0, self.dA.ptr, n, 0, None, self.gws.ptr, self.gws_bytes, s)
-        H.gemm(H.BF16, 1, 0, n, n, n, 1.0, self.A.ptr, n, self.dC.ptr, n, 0.0, self.dW.ptr, n, 0, None, self.gws.ptr, self.gws_bytes, s)
-        if comm is not None:  # gradient all-reduce on its own stream, overlapped with the attention pass
+        H.gemm(H.BF16, 0, 0, n, n, n, 1.0, self.A.ptr, n, self.W.ptr, n, 0.0, self.Cc.ptr, n, 0, None, None, 0, s)
+        H.gemm(H.BF16, 0, 1, n, n, n, 1.0, self.dC.ptr, n, self.W.ptr, n, 0.0, self.dA.ptr, n, 0, None, None, 0, s)
+        H.gemm(H.BF16, 1, 0, n, n, n, 1.0, self.A.ptr, n, self.dC.ptr, n, 0.0, self.dW.ptr, n, 0, None, None, 0, s)
+        if pg is not None:  # gradient all-reduce on its own stream, overlapped with the attention pass
             ev_grad.record(s)
             H.stream_wait_event(comm_stream, ev_grad)
-            H.check(H.lib().kf_allreduce_sum(comm, self.dW.ptr, n * n, H.BF16, comm_stream))
+            if comm_events is not None:
+                e0, e1 = H.Event(), H.Event()
+                e0.record(comm_stream)
+            pg.allreduce_sum_device(self.dW.ptr, n * n, H.BF16, comm_stream)
+            if comm_events is not None:
+                e1.record(comm_stream)
+                comm_events.append((e0, e1))
             ev_comm.record(comm_stream)
             ev_comm.recorded = True
         H.attn_fwd(H.BF16, AB, AH, AS, AS, AD, self.q.ptr, self.k.ptr, self.v.ptr, self.o.ptr, self.lse.ptr, s)
         H.attn_bwd(H.BF16, AB, AH, AS, AS, AD, self.q.ptr, self.k.ptr, self.v.ptr, self.o.ptr, self.lse.ptr, self.do.ptr,
                    self.dq.ptr, self.dk.ptr, self.dv.ptr, self.aws.ptr, self.aws_bytes, s)
+
+
+def spot_check(H, wl):
+    """After timing: outputs left in the timed buffers against the oracle (the checker; never inside the timed region).
+    GEMM: 8 rows of C = A W (bf16 inputs, f32 accumulation, one rounding). Attention, head (0, 0): the causal prefix - the
+    first 256 rows of O and LSE equal attention over the first 256 tokens - and the checksum sum_n dV[n] = sum_m dO[m]."""
+    from oracle import oracle as O
+    n = GEMM_N
+    rows = [0, 1, 127, 128, 2047, 3000, 4094, 4095]
+    got = np.empty((len(rows), n), dtype=np.uint16)
+    for i, r in enumerate(rows):
+        H.check(H.lib().kf_memcpy_d2h(got[i].ctypes.data, wl.Cc.ptr + r * n * 2, n * 2, None))
+    want = O.bf16_to_f32(O.gemm(wl.A_host[rows], wl.W_host, code=O.BF16)).astype(np.float64)
+    mag = np.abs(O.bf16_to_f32(wl.A_host[rows]).astype(np.float64)) @ np.abs(O.bf16_to_f32(wl.W_host).astype(np.float64))
+    g = O.bf16_to_f32(got).astype(np.float64)
+    gemm_ok = bool((np.abs(g - want) <= 2.0 ** -7 * np.abs(want) + 2e-6 * mag + 1e-6).all())
+    P = 256
+    q, k, v = (wl.host[x][None, None, :P] for x in ("q", "k", "v"))
+    o_ref, lse_ref = O.attn_fwd(q, k, v, code=O.BF16)
+    o_got = np.empty((P, AD), dtype=np.uint16)
+    H.check(H.lib().kf_memcpy_d2h(o_got.ctypes.data, wl.o.ptr, o_got.nbytes, None))
+    lse_got = np.empty((P,), dtype=np.float32)
+    H.check(H.lib().kf_memcpy_d2h(lse_got.ctypes.data, wl.lse.ptr, lse_got.nbytes, None))
+    attn_ok = bool(np.allclose(O.bf16_to_f32(o_got), O.bf16_to_f32(o_ref)[0, 0], rtol=2e-2, atol=2e-2)
+                   and np.allclose(lse_got, lse_ref[0, 0], rtol=1e-3, atol=2e-3))
+    dv = np.empty((AS, AD), dtype=np.uint16)
+    H.check(H.lib().kf_memcpy_d2h(dv.ctypes.data, wl.dv.ptr, dv.nbytes, None))
+    dv_sum, do_sum = O.bf16_to_f32(dv).astype(np.float64).sum(0), O.bf16_to_f32(wl.host["do"]).astype(np.float64).sum(0)
+    bwd_ok = bool(np.allclose(dv_sum, do_sum, rtol=2e-2, atol=0.5))
+    return {"gemm_rows_vs_oracle": gemm_ok, "attn_prefix_vs_oracle": attn_ok, "attn_dv_checksum": bwd_ok}
+
+
+def check_allreduce(H, wl, pg, stream):
+    """Section 8e's parity sentence on the live buffers: the RCCL-reduced dW must equal the sum over ranks of each rank's own
+    dW = A_r^T dC_r (recomputed here without the collective, summed in f32 over gloo on the host). RCCL adds bf16 values, so
+    each of its N - 1 additions rounds once: |err| <= N 2^-8 sum_r |dW_r| elementwise (N = 1: the all-reduce is the identity
+    and the two must be bit-identical)."""
+    n = GEMM_N
+    reduced = wl.dW.to_numpy((n, n), np.uint16)
+    local = H.DevBuf(2 * n * n)
+    H.gemm(H.BF16, 1, 0, n, n, n, 1.0, wl.A.ptr, n, wl.dC.ptr, n, 0.0, local.ptr, n, 0, None, None, 0, stream)
+    H.device_sync()
+    mine = local.to_numpy((n, n), np.uint16)
+    u = (mine.astype(np.uint32) << 16).view(np.float32)
+    total = pg.allreduce_sum_host(u.copy().reshape(-1)).reshape(n, n)
+    mag = pg.allreduce_sum_host(np.abs(u).reshape(-1).copy()).reshape(n, n)
+    got = (reduced.astype(np.uint32) << 16).view(np.float32)
+    if pg.world == 1:
+        return bool(np.array_equal(reduced, mine))
+    return bool((np.abs(got - total) <= pg.world * 2.0 ** -8 * mag + 1e-6).all())
 
 
 def cpu_baseline():
@@ -126,80 +204,131 @@ def cpu_baseline():
                       f"of each of the 3 GEMMs ({t_gemm:.1f} s), scaled linearly to one step"}
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a torchrun environment: start the N ranks as CHILD processes (this process has
+    not touched, and never touches, a GPU), pass rank 0's output through and return the worst exit status."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+    for ln in lines[:-1]:
+        print(ln, file=sys.stderr)  # library banners etc.: THE line is the last one
+    if lines:
+        print(lines[-1], flush=True)
+    return max(abs(c) for c in codes)
+
+
+def dry_run_cpu(args, rank, world):
+    """The N > 1 plumbing without a GPU (tests/test_parallel_gloo.py): rendezvous, gradient bucket, sum all-reduce over gloo,
+    max-over-ranks timing and the one-line report — the same ProcessGroup calls the GPU path makes, host buffers instead."""
+    from kfunca_amd import parallel
+    pg = parallel.ProcessGroup(backend="gloo")
+    bucket = parallel.GradBucket([(64, 64)], dtype=np.float32)
+    flat = np.full(bucket.numel, float(rank + 1), dtype=np.float32)
+    t0 = time.perf_counter()
+    pg.allreduce_sum_host(flat)
+    elapsed = pg.max_over_ranks(time.perf_counter() - t0)
+    ok = bool((flat == world * (world + 1) / 2).all())
+    pg.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "allreduce_check": ok, "elapsed_s": elapsed}), flush=True)
+    pg.close()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--sustain-seconds", type=float, default=2.0, help="length of the sustained loop after the timed steps (0: skip)")
+    ap.add_argument("--check", action="store_true", help="after timing, verify outputs (oracle spot checks; all-reduced dW vs the gloo sum)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run-cpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        return launch_ranks(args)  # before anything touches the GPU
     if world != args.gpus:
-        if args.gpus != 1 or world != 1:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run_cpu:
+        return dry_run_cpu(args, rank, world)
+
+    from kfunca_amd import hip_abi as H
+    from kfunca_amd import parallel
     if H.device_count() == 0:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     H.set_device(local_rank)
 
-    dist = None
-    comm = None
-    if world > 1:
-        import torch.distributed as dist  # plumbing only: rendezvous, barrier, max-reduce of the timing
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-    if world > 1 or os.environ.get("KF_BENCH_FORCE_COMM"):  # the env knob exercises the collective path on one GPU
-        ident = [None]
-        if rank == 0:
-            buf = C.create_string_buffer(H.COMM_ID_BYTES)
-            H.check(H.lib().kf_comm_unique_id(buf))
-            ident[0] = buf.raw
-        if dist is not None:
-            dist.broadcast_object_list(ident, src=0)
-        h = C.c_void_p()
-        H.check(H.lib().kf_comm_init(C.byref(h), ident[0], rank, world))
-        comm = h.value
-        C.CDLL(None).fflush(None)  # RCCL leaves its version banner in the C stdout buffer: out with it now, so the JSON line is the last line
+    pg = None
+    force_comm = bool(os.environ.get("KF_BENCH_FORCE_COMM"))  # exercises the collective path on one GPU
+    if world > 1 or force_comm:
+        pg = parallel.ProcessGroup(backend="rccl")  # gloo rendezvous (plumbing) + RCCL communicator through the C ABI
+        C.CDLL(None).fflush(None)  # RCCL leaves its version banner in the C stdout buffer: out with it now
 
-    wl = Workload(rank)
+    wl = Workload(H, rank)
     stream = H.Stream()
-    comm_stream = H.Stream() if comm else None
-    ev_grad, ev_comm = (H.Event(), H.Event()) if comm else (None, None)
-    if comm:
+    comm_stream = H.Stream() if pg else None
+    ev_grad, ev_comm = (H.Event(), H.Event()) if pg else (None, None)
+    if pg:
         ev_comm.recorded = False
-    lib = H.lib()
 
     def barrier():
         H.device_sync()
-        if dist is not None:
-            dist.barrier()
+        if pg is not None:
+            pg.barrier()
 
-    def run_step():
-        wl.step(stream.handle, comm, comm_stream.handle if comm else None, ev_grad, ev_comm)
+    def run_step(comm_events=None):
+        wl.step(stream.handle, pg, comm_stream.handle if pg else None, ev_grad, ev_comm, comm_events)
 
     for _ in range(args.warmup):
         run_step()
     barrier()
     H.profile_reset()
     H.profile_enable(True)
+    comm_events = [] if pg else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        run_step()
-    H.device_sync()
-    if dist is not None:
-        dist.barrier()
+        run_step(comm_events)
+    barrier()
     t1 = time.perf_counter()
     H.profile_enable(False)
     elapsed = t1 - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    if pg is not None:
+        elapsed = pg.max_over_ranks(elapsed)
     prof = H.profile_results()
 
+    # sustained loop: the chip settles its clock only after ~2 s of back-to-back work (profiles/r01_gemm_clock.json)
+    sustained = None
+    if args.sustain_seconds > 0:
+        n_sus = max(args.steps, int(math.ceil(args.sustain_seconds / max(elapsed / args.steps, 1e-6))))
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_sus):
+            run_step()
+        barrier()
+        t_sus = time.perf_counter() - t0
+        if pg is not None:
+            t_sus = pg.max_over_ranks(t_sus)
+        sustained = (n_sus, t_sus)
+
+    checks = {}
+    if pg is not None and (args.check or force_comm):
+        checks["allreduce_dw_vs_gloo_sum"] = check_allreduce(H, wl, pg, stream.handle)
+    rc = 0
     if rank == 0:
+        if world == 1 or args.check:
+            checks.update(spot_check(H, wl))
         ms_step = elapsed / args.steps * 1e3
         kern = {k: {"avg_ms": ms / max(cnt, 1), "launches": cnt} for k, (ms, cnt) in prof.items()}
         for k, v in kern.items():
@@ -210,12 +339,14 @@ def main():
         attn_ms = sum(v for k, v in per_step.items() if k.startswith("attn"))
         dom = max((k for k in per_step if k in KERNEL_FLOPS), key=lambda k: per_step[k])
         achieved = kern[dom]["tflops"]
-        # traffic beyond L2 per launch of the dominant kernel: rocprofv3 PMC passes cannot run inside this process;
-        # the committed measurement of the same kernel on the same shape is reported (profiles/r01_pmc_traffic.json)
-        traffic = None
-        tfile = ROOT / "profiles" / "r01_pmc_traffic.json"
-        if tfile.exists():
-            traffic = json.loads(tfile.read_text()).get(dom, {}).get("bytes_per_launch")
+        # traffic beyond L2 per launch of the dominant kernel: rocprofv3 PMC passes cannot run inside this process; the
+        # committed measurement of the same kernel on the same shape is quoted only if it was taken on THESE device sources
+        traffic, traffic_src = None, None
+        for tfile in sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"), reverse=True):
+            tj = json.loads(tfile.read_text())
+            if tj.get("device_src_sha") == device_src_sha():
+                traffic, traffic_src = tj.get(dom, {}).get("bytes_per_launch"), tfile.name
+                break
         out = {
             "metric": "bf16 GEMM TFLOP/s + causal-attn fwd+bwd tokens/s",
             "value": world * TOKENS_STEP / (elapsed / args.steps),
@@ -231,21 +362,37 @@ def main():
             "attn_ms_per_step": attn_ms,
             "kernels": kern,
             "roofline": {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_MFMA_BF16, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_MFMA_BF16, "traffic": traffic,
+                         "frac": achieved / PEAK_MFMA_BF16, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_flops_per_launch": KERNEL_FLOPS[dom]},
+            "device_src_sha": device_src_sha(),
+            "checks": checks,
         }
+        if sustained:
+            out["ms_per_step_sustained"] = sustained[1] / sustained[0] * 1e3
+            out["value_sustained"] = world * TOKENS_STEP / (sustained[1] / sustained[0])
+            out["sustained_steps"] = sustained[0]
+        if comm_events:
+            ms = [e0.elapsed_ms(e1) for e0, e1 in comm_events]
+            nbytes = GEMM_N * GEMM_N * 2
+            t = sum(ms) / len(ms) * 1e-3
+            out["allreduce"] = {"ms": t * 1e3, "message_bytes": nbytes, "dtype": "bf16",
+                                "busbw_GBps": 2.0 * (world - 1) / world * nbytes / t / 1e9 if world > 1 else 0.0,
+                                "xgmi_peak_GBps": XGMI_PEAK, "overlapped_with": "attention forward + backward"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-    if comm is not None:
-        H.check(lib.kf_comm_destroy(comm))
+        if not all(checks.values()):
+            rc = 1
+    if pg is not None and rank != 0 and not all(checks.values()):
+        rc = 1
     C.CDLL(None).fflush(None)
-    if dist is not None:
-        dist.barrier()  # every rank's library output is out before rank 0 prints THE line
+    if pg is not None:
+        pg.barrier()  # every rank's library output is out before rank 0 prints THE line
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    if pg is not None:
+        pg.close()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

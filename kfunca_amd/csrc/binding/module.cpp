@@ -181,16 +181,47 @@ PYBIND11_MODULE(_C, m) {
     m.def("synchronize", [](int device) { dev::synchronize(device); }, py::arg("device") = 0);
     // HIP graphs over the device's stream (extension; the reference launches kernel by kernel, launcher_cuda.h:330-354): record
     // whatever the operator API enqueues between begin and end - a whole forward + backward step - and replay it with one
-    // submission. Replays write to the addresses captured: keep the step's tensors alive and do not allocate in between.
-    m.def("graph_begin", [](int device) { DEV_CALL(kf_graph_begin_capture(dev::stream(device))); }, py::arg("device") = 0);
+    // submission. Replays read and write the addresses captured, so the allocator runs in capture mode meanwhile: every block
+    // the recorded step allocates or frees stays in a pool private to the graph (never re-enters the shared cache) until
+    // graph_destroy - an eager op, a from_numpy or another step between two replays cannot be handed the graph's scratch.
+    // Results the caller still holds when the capture ends are rewritten by every replay (that is the point of replaying).
+    struct GraphHandle { void *exec; uint64_t pool; int device; };
+    static uint64_t open_capture_pool = 0;
+    m.def("graph_begin", [](int device) {
+        void *st = dev::stream(device);
+        open_capture_pool = utils::memory::DeviceAllocator::GetInstance()->begin_capture(device);
+        const int rc = kf_graph_begin_capture(st);
+        if (rc != KF_OK) {
+            utils::memory::DeviceAllocator::GetInstance()->release_graph(open_capture_pool);
+            open_capture_pool = 0;
+            DEV_CALL(rc);
+        }
+    }, py::arg("device") = 0);
     m.def("graph_end", [](int device) {
         void *g = nullptr;
-        DEV_CALL(kf_graph_end_capture(dev::stream(device), &g));
-        return reinterpret_cast<uintptr_t>(g);
+        const uint64_t pool = open_capture_pool;
+        open_capture_pool = 0;
+        const int rc = kf_graph_end_capture(dev::stream(device), &g);
+        utils::memory::DeviceAllocator::GetInstance()->end_capture(pool);
+        if (rc != KF_OK) {
+            utils::memory::DeviceAllocator::GetInstance()->release_graph(pool);
+            DEV_CALL(rc);
+        }
+        return reinterpret_cast<uintptr_t>(new GraphHandle{g, pool, device});
     }, py::arg("device") = 0);
-    m.def("graph_launch", [](uintptr_t g, int device) { DEV_CALL(kf_graph_launch(reinterpret_cast<void *>(g), dev::stream(device))); },
-          py::arg("graph"), py::arg("device") = 0);
-    m.def("graph_destroy", [](uintptr_t g) { DEV_CALL(kf_graph_destroy(reinterpret_cast<void *>(g))); });
+    m.def("graph_launch", [](uintptr_t g, int device) {
+        auto *h = reinterpret_cast<GraphHandle *>(g);
+        CHECK_FAIL(h && h->exec, "graph_launch: null graph");
+        DEV_CALL(kf_graph_launch(h->exec, dev::stream(device)));
+    }, py::arg("graph"), py::arg("device") = 0);
+    m.def("graph_destroy", [](uintptr_t g) {
+        auto *h = reinterpret_cast<GraphHandle *>(g);
+        if (!h) return;
+        dev::synchronize(h->device); // no replay may still be running when its scratch goes back to the shared cache
+        DEV_CALL(kf_graph_destroy(h->exec));
+        utils::memory::DeviceAllocator::GetInstance()->release_graph(h->pool);
+        delete h;
+    });
     m.def("memstat", []() { utils::memory::DeviceAllocator::GetInstance()->print(); });
     m.def("memstat_dict", [](int device) {
         auto s = utils::memory::DeviceAllocator::GetInstance()->stats(device);
@@ -200,6 +231,8 @@ PYBIND11_MODULE(_C, m) {
         d["active_bytes"] = s.active_bytes;
         d["cached_bytes"] = s.cached_bytes;
         d["driver_allocs"] = s.driver_allocs;
+        d["graph_blocks"] = s.graph_blocks;
+        d["graph_bytes"] = s.graph_bytes;
         return d;
     }, py::arg("device") = -1);
 

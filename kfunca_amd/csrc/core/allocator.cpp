@@ -33,23 +33,34 @@ DataPtr DeviceAllocator::allocate(size_t size, int device) {
     dev::set_device(device);
     const size_t rounded = std::max<size_t>(kAlignment, (size + kAlignment - 1) / kAlignment * kAlignment);
     std::lock_guard<std::mutex> lk(mu_);
-    auto &pools = free_[device];
-    if (pools.empty()) pools.resize(kNumPools);
-    Pool &pool = pools[pool_index(size)];
-    Block key{nullptr, size, device, 0, false};
-    auto it = pool.lower_bound(&key); // smallest cached block of this class that fits
-    Block *b;
-    if (it != pool.end()) {
-        b = *it;
-        pool.erase(it);
-    } else {
-        void *p = nullptr;
-        DEV_CALL(kf_malloc(&p, rounded));
-        b = new Block{p, rounded, device, next_id_++, false};
-        by_ptr_[p] = b;
-        ++driver_allocs_;
+    const bool capturing = capturing_ != 0 && capture_device_ == device;
+    Block key{nullptr, size, device, 0, false, 0};
+    Block *b = nullptr;
+    if (capturing) { // first the blocks this capture has already retired
+        auto &gp = graph_free_[capturing_];
+        if (gp.empty()) gp.resize(kNumPools);
+        Pool &pool = gp[pool_index(size)];
+        auto it = pool.lower_bound(&key);
+        if (it != pool.end()) { b = *it; pool.erase(it); }
+    }
+    if (!b) {
+        auto &pools = free_[device];
+        if (pools.empty()) pools.resize(kNumPools);
+        Pool &pool = pools[pool_index(size)];
+        auto it = pool.lower_bound(&key); // smallest cached block of this class that fits
+        if (it != pool.end()) {
+            b = *it;
+            pool.erase(it);
+        } else {
+            void *p = nullptr;
+            DEV_CALL(kf_malloc(&p, rounded));
+            b = new Block{p, rounded, device, next_id_++, false, 0};
+            by_ptr_[p] = b;
+            ++driver_allocs_;
+        }
     }
     b->in_use = true;
+    if (capturing) b->graph = capturing_; // recorded kernels use this address: it stays with the graph until release_graph
     return DataPtr(b->ptr, b->size, device);
 }
 
@@ -59,18 +70,60 @@ void DeviceAllocator::free(void *ptr) {
     if (it == by_ptr_.end() || !it->second->in_use) return;
     Block *b = it->second;
     b->in_use = false;
+    if (capturing_ != 0 && capture_device_ == b->device) b->graph = capturing_; // freed while recording: the graph may still touch it
+    if (b->graph != 0) {
+        auto g = graph_free_.find(b->graph);
+        if (g != graph_free_.end()) {
+            if (g->second.empty()) g->second.resize(kNumPools);
+            g->second[pool_index(b->size)].insert(b);
+            return;
+        }
+        b->graph = 0; // that graph is gone
+    }
     auto &pools = free_[b->device];
     if (pools.empty()) pools.resize(kNumPools);
     pools[pool_index(b->size)].insert(b);
 }
 
+uint64_t DeviceAllocator::begin_capture(int device) {
+    std::lock_guard<std::mutex> lk(mu_);
+    CHECK_FAIL(capturing_ == 0, "a graph capture is already open on device ", capture_device_);
+    capturing_ = ++next_graph_;
+    capture_device_ = device;
+    graph_free_[capturing_].resize(kNumPools);
+    return capturing_;
+}
+
+void DeviceAllocator::end_capture(uint64_t graph_id) {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (capturing_ == graph_id) { capturing_ = 0; capture_device_ = -1; }
+}
+
+void DeviceAllocator::release_graph(uint64_t graph_id) {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (capturing_ == graph_id) { capturing_ = 0; capture_device_ = -1; }
+    auto g = graph_free_.find(graph_id);
+    if (g == graph_free_.end()) return;
+    for (Pool &pool : g->second)
+        for (Block *b : pool) {
+            b->graph = 0;
+            auto &pools = free_[b->device];
+            if (pools.empty()) pools.resize(kNumPools);
+            pools[pool_index(b->size)].insert(b);
+        }
+    graph_free_.erase(g);
+    for (auto &kv : by_ptr_)
+        if (kv.second->graph == graph_id) kv.second->graph = 0; // still alive: back to the shared cache when freed
+}
+
 DeviceAllocator::Stats DeviceAllocator::stats(int device) {
     std::lock_guard<std::mutex> lk(mu_);
-    Stats s{0, 0, 0, 0, driver_allocs_};
+    Stats s{0, 0, 0, 0, driver_allocs_, 0, 0};
     for (auto &kv : by_ptr_) {
         const Block *b = kv.second;
         if (device >= 0 && b->device != device) continue;
         if (b->in_use) { ++s.active_blocks; s.active_bytes += b->size; }
+        else if (b->graph != 0 && graph_free_.count(b->graph)) { ++s.graph_blocks; s.graph_bytes += b->size; } // held for a live graph
         else { ++s.cached_blocks; s.cached_bytes += b->size; }
     }
     return s;

@@ -56,13 +56,22 @@ public:
     void free(void *ptr);
     void print();
 
-    struct Stats { size_t active_blocks, cached_blocks, active_bytes, cached_bytes, driver_allocs; };
+    // Capture mode (HIP graphs): an instantiated graph keeps reading and writing the addresses its kernels were recorded
+    // with, on every replay. While a capture is open on `device`, every block freed there - and, afterwards, every block
+    // that was allocated during the capture - goes to a pool PRIVATE to that graph instead of the shared cache, so no later
+    // allocation can be handed memory a live graph still uses; allocations inside the capture may reuse that private pool
+    // (stream order inside the graph is the recording order). release_graph() returns the pool to the shared cache.
+    uint64_t begin_capture(int device);
+    void end_capture(uint64_t graph_id);
+    void release_graph(uint64_t graph_id);
+
+    struct Stats { size_t active_blocks, cached_blocks, active_bytes, cached_bytes, driver_allocs, graph_blocks, graph_bytes; };
     Stats stats(int device = -1);
     static int pool_index(size_t size);
 
 private:
     DeviceAllocator() = default;
-    struct Block { void *ptr; size_t size; int device; uint32_t id; bool in_use; };
+    struct Block { void *ptr; size_t size; int device; uint32_t id; bool in_use; uint64_t graph; };
     struct BySizeThenPtr {
         bool operator()(const Block *a, const Block *b) const {
             if (a->size != b->size) return a->size < b->size;
@@ -73,6 +82,10 @@ private:
     std::mutex mu_;
     std::map<int, std::vector<Pool>> free_;            // device -> size class -> cached blocks
     std::unordered_map<void *, Block *> by_ptr_;       // every block ever allocated
+    std::map<uint64_t, std::vector<Pool>> graph_free_; // live graph -> size class -> blocks only that graph may reuse
+    uint64_t capturing_ = 0;                           // id of the open capture (0: none) ...
+    int capture_device_ = -1;                          // ... and its device
+    uint64_t next_graph_ = 0;
     uint32_t next_id_ = 0;
     size_t driver_allocs_ = 0;
 };

@@ -8,7 +8,11 @@ namespace dev {
 namespace {
 std::mutex g_mu;
 std::vector<void *> g_streams;
-int g_current = -1;
+// HIP's current device is per THREAD, and the ctypes path (kfunca_amd/hip_abi.py, parallel.py) sets it without going through
+// here: no shadow copy decides whether hipSetDevice is needed - it is always called (~100 ns); this one only answers
+// current_device() for the calling thread.
+thread_local int g_current = -1;
+int g_count = -1;
 } // namespace
 
 int device_count() {
@@ -18,9 +22,12 @@ int device_count() {
 }
 
 void set_device(int device) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    if (device == g_current) return;
-    const int n = device_count();
+    int n;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (g_count < 0) g_count = device_count();
+        n = g_count;
+    }
     CHECK_FAIL(n > 0, "no HIP device is visible: the kfunca_amd operator API has no CPU execution path");
     CHECK_FAIL(device >= 0 && device < n, "device ", device, " out of range (", n, " visible)");
     DEV_CALL(kf_set_device(device));

@@ -2,6 +2,8 @@
 // Behavioural reference: src/core/tensor.cpp, tensor_impl.cpp (cited per function).
 #include "tensor.h"
 
+#include <algorithm>
+
 #include <iomanip>
 #include <limits>
 #include <queue>
@@ -181,9 +183,23 @@ public:
     std::vector<Tensor> backward(Tensor g) override {
         const Tensor &base = inputs[0];
         const int64_t n = (int64_t)(base.storage_bytes() / (size_t)base.element_size_in_bytes());
+        // zero-fill unless the view provably covers every element of the storage exactly once: numel == n alone does not
+        // (an overlapping or stride-0 as_strided view can have numel == n and still leave holes)
         int64_t numel = 1;
         for (int64_t v : sizes_) numel *= v;
-        Tensor buf = numel == n ? empty({n}, base.dtype(), base.device()) : zeros({n}, base.dtype(), base.device());
+        bool dense = numel == n && offset_ == 0;
+        if (dense) { // a permutation of a contiguous layout: sorted by stride, each stride = the product of the smaller extents
+            std::vector<std::pair<int64_t, int64_t>> ds; // (stride, size), size-1 dims dropped
+            for (size_t i = 0; i < sizes_.size(); ++i)
+                if (sizes_[i] != 1) ds.emplace_back(strides_[i], sizes_[i]);
+            std::sort(ds.begin(), ds.end());
+            int64_t expect = 1;
+            for (auto &d : ds) {
+                if (d.first != expect) { dense = false; break; }
+                expect *= d.second;
+            }
+        }
+        Tensor buf = dense ? empty({n}, base.dtype(), base.device()) : zeros({n}, base.dtype(), base.device());
         Tensor gv = buf.as_strided(sizes_, strides_, offset_);
         gv.copy_(g);
         return {buf.as_strided(base.sizes(), base.strides(), base.storage_offset())};

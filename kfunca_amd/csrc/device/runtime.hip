@@ -24,10 +24,11 @@ void set_error(const char *fmt, ...) {
 namespace kf {
 struct ProfRec { std::string name; hipEvent_t e0, e1; };
 static bool g_prof_on = false;
+static int g_capturing = 0; // open stream captures: event records would be captured into the graph, so profiling stands aside
 static std::mutex g_prof_mu;
 static std::vector<ProfRec *> g_prof_recs;
 ProfScope::ProfScope(const char *n, hipStream_t s) : name(n), st(s), rec(nullptr) {
-    if (!g_prof_on) return;
+    if (!g_prof_on || g_capturing) return;
     ProfRec *r = new ProfRec();
     r->name = n;
     if (hipEventCreate(&r->e0) != hipSuccess || hipEventCreate(&r->e1) != hipSuccess) { delete r; return; }
@@ -118,7 +119,11 @@ int kf_knobs_reload(void) {
     return KF_OK;
 }
 
-int kf_profile_enable(int on) { g_prof_on = on != 0; return KF_OK; }
+int kf_profile_enable(int on) {
+    KF_REQUIRE(!(on && g_capturing), KF_ERR_INVALID, "kf_profile_enable: a stream capture is open (timing events would be recorded into the graph)");
+    g_prof_on = on != 0;
+    return KF_OK;
+}
 int kf_profile_reset(void) {
     prof_collect();
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -217,12 +222,14 @@ int kf_stream_create(void **stream) {
 int kf_graph_begin_capture(void *stream) {
     KF_REQUIRE(stream, KF_ERR_INVALID, "kf_graph_begin_capture: capture needs a stream from kf_stream_create, not the null stream");
     KF_HIP_TRY(hipStreamBeginCapture(as_stream(stream), hipStreamCaptureModeRelaxed));
+    ++g_capturing;
     return KF_OK;
 }
 
 int kf_graph_end_capture(void *stream, void **graph_exec) {
     KF_REQUIRE(stream && graph_exec, KF_ERR_INVALID, "kf_graph_end_capture: null argument");
     hipGraph_t g = nullptr;
+    if (g_capturing > 0) --g_capturing;
     KF_HIP_TRY(hipStreamEndCapture(as_stream(stream), &g));
     KF_REQUIRE(g, KF_ERR_HIP, "kf_graph_end_capture: the capture was invalidated");
     hipGraphExec_t ge = nullptr;

@@ -188,3 +188,35 @@ def test_block_step_replays_from_a_hip_graph():
         assert not np.array_equal(a3, a2) and not np.array_equal(a5, a4)
         assert np.allclose(f32(a3) - f32(a2), f32(a4) - f32(a3), rtol=0.1, atol=0.05 * np.abs(f32(a2)).max())
     kfunca.graph_destroy(graph)
+
+
+def test_graph_scratch_never_reenters_the_shared_cache():
+    """Allocator capture mode: temporaries the recorded step allocated and freed stay in a pool private to the graph, so a tensor
+    allocated between two replays can never be handed memory the graph still writes on replay (before: the temporary's block
+    went back to the shared cache at capture time and the next same-size allocation was clobbered by every replay)."""
+    n = 1 << 16
+    rng = np.random.default_rng(931)
+    a, b, c = (rng.uniform(-1, 1, (n,)).astype(np.float32) for _ in range(3))
+    ta, tb, tc = (kfunca.from_numpy(x, 0) for x in (a, b, c))
+    warm = (ta + tb) * tc  # same sizes once eagerly: the cache now holds a block of the temporary's size
+    del warm
+    kfunca.synchronize(0)
+    before = kfunca.memstat_dict(0)
+    kfunca.graph_begin(0)
+    out = (ta + tb) * tc  # the sum is a temporary: freed during the capture
+    graph = kfunca.graph_end(0)
+    held = kfunca.memstat_dict(0)
+    assert held["graph_blocks"] >= 1 and held["graph_bytes"] >= 4 * n, held
+    assert held["cached_blocks"] <= before["cached_blocks"], (before, held)
+    # new tensors of the temporary's size: none may alias the graph's scratch
+    fresh = [kfunca.empty([n], kfunca.dtype.float, 0).fill_(7.0) for _ in range(8)]
+    for _ in range(3):
+        kfunca.graph_launch(graph, 0)
+    kfunca.synchronize(0)
+    assert np.array_equal(out.numpy(), (a + b) * c)
+    for t in fresh:
+        assert (t.numpy() == 7.0).all()
+    del out
+    kfunca.graph_destroy(graph)
+    after = kfunca.memstat_dict(0)
+    assert after["graph_blocks"] == 0 and after["cached_blocks"] >= held["cached_blocks"] + 1, after

@@ -64,3 +64,21 @@ def test_gradient_allreduce_world2_matches_full_batch():
     out = mgr.dict()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def test_bench_launches_its_own_ranks_cpu_dry_run():
+    """`python bench.py --gpus 2` with no torchrun environment starts the two rank processes itself (children of a parent that
+    never touches a GPU), the ranks rendezvous on 127.0.0.1, all-reduce a gradient bucket through kfunca_amd.parallel, and the
+    parent relays rank 0's ONE JSON line and the worst exit status. --dry-run-cpu swaps the RCCL data path for gloo."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, str(Path(__file__).resolve().parent.parent / "bench.py"), "--gpus", "2", "--dry-run-cpu"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line == {"dry_run": True, "n_gpus": 2, "allreduce_check": True, "elapsed_s": line["elapsed_s"]}
