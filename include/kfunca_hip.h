@@ -258,8 +258,12 @@ int kf_attn_fwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_
 int kf_attn_fwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, float scale, const void *q,
                        const void *k, const void *v, void *o, float *lse, void *stream);
 /*
- * dq,dk,dv from d_o. Needs o and lse from the forward. workspace holds delta[B,H,Sq] f32 and the two
- * row-constant arrays the dK/dV kernel reads; kf_attn_bwd_workspace_bytes() says how much; no initialisation needed.
+ * dq,dk,dv from d_o. Needs o and lse from the forward. workspace holds delta[B,H,Sq] f32, the two row-constant arrays the
+ * dK/dV kernel reads and - on the matrix-core path for 16-bit tensors - dS = P o (dP - delta) in 16 bits, B*H*Sq*Skv*2 bytes
+ * (Sq rounded up to 256): the dK/dV kernel writes it, the dQ kernel computes dQ = scale dS K from it, so the backward executes the
+ * 5 matrix products of the algorithm instead of 7. kf_attn_bwd_workspace_bytes() says how much; no initialisation needed.
+ * Beyond 64 GiB of dS, or with KF_ATTN_SPLIT_BWD set, the dQ kernel recomputes S and dP instead (small workspace).
+ * No atomics in either form: dq, dk, dv are bitwise reproducible run to run.
  */
 int kf_attn_bwd_workspace_bytes(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D,
                                 size_t *bytes);

@@ -54,7 +54,22 @@ struct AttnArgs {
     float defer; // forward: adopt a new running maximum only beyond this many exponent units (kDeferMax; -inf: always)
     int persist;     // k > 0: a workgroup handles k pairs {block x, its causal mirror}: equal work per workgroup (k = 1 is used)
     int persist_rev; // the short block of a pair first
+    char *ds;        // backward: dS = P o (dP - delta) in 16 bits, written by the dK/dV kernel, read by the dQ kernel (null: not kept)
+    int64_t ds_nqb, ds_nkwb; // its tile grid: 256-query blocks x 32-key blocks (DS_* below)
 };
+
+// dS workspace (backward): the dK/dV kernel already holds dS = P o (dP - delta) as packed 16-bit MFMA operands; it stores them
+// and the dQ kernel computes dQ = scale dS K from them - 2 matrix products instead of the 6 a recomputing dQ kernel executes
+// (S and dP again), at the price of one 16-bit S x S / 2 round trip through HBM (4.3 GB at B 8, H 32, S 4096: HBM-bound at ~0.8 ms).
+// Layout: tiles of 32 keys x 32 queries (2 KiB), tile (bh, qb, kwb, sl) = 256-query block qb, 32-key block kwb, slice sl of
+// the block, at ((((bh nqb + qb) nkwb + kwb) 8) + sl) 2 KiB - the eight slices of a query block and consecutive key blocks are
+// contiguous, which is the order the dQ kernel streams them in. Inside a tile: [s][key][hl][8 values] where the 8 values are
+// accumulator registers e = 8 s + j of lane half hl, i.e. queries (j & 3) + 8 (2 s + (j >> 2)) + 4 hl of the slice - exactly
+// one packed operand of the dK/dV wave (key on the lane), so a store instruction writes 1 KiB of consecutive bytes.
+constexpr int DS_TILE = 2048;
+__host__ __device__ inline size_t ds_bytes(int64_t nbh, int64_t Sq, int64_t Skv) {
+    return (size_t)nbh * (size_t)((Sq + 255) / 256) * (size_t)(Skv / 32) * 8 * DS_TILE;
+}
 
 // XCD-aware block order for the v2 kernels (1-D grid of nx * nbh blocks). Hardware deals block ids round-robin
 // over the 8 XCDs, each with a private 4 MiB L2. All nx blocks of one (batch, head) re-read that head's K/V
@@ -614,6 +629,140 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a
 }
 
 // ------------------------------------------------------------------------------------------
+// backward: dQ from the stored dS (DS_TILE workspace) - dQ^T += K^T dS^T, the forward's P V half with dS in place of P and K
+// in place of V: 8 waves x 32 queries (a 256-query block; wave w <-> slice w), two waves per SIMD, 64-key steps.
+//   A = K^T fragments through transposed reads of the row-major K tile (the forward's V path: same image, same offsets);
+//   B = dS^T fragments (k = key, column = query): each wave streams ITS slice's two 2 KiB dS tiles per step by LDS-DMA into a
+//       private slab, verbatim ([s][key][hl][16 B]) but for a swap of 64-byte key pairs in the second half - that makes the
+//       image conflict-free for ds_read_b64_tr_b16 (4 keys x 8 query quads of a half-wave = 32 distinct 8-byte units) while
+//       every DMA instruction still reads 1 KiB of consecutive bytes; lane 16 grp + 4 qq + p reads the unit of key
+//       4 h + qq, query quad 4 (grp & 1) + p.
+// The K tile is shared by the workgroup (one barrier per step); the dS slabs are private, so they need no barrier at all.
+// No mask and no row constants: the dK/dV kernel wrote zeros above the diagonal, and only tiles at or below a slice's
+// diagonal are read (key block <= slice). HBM-bound by construction: dS is read exactly once (16 MFMAs per 4 KiB of it).
+// ------------------------------------------------------------------------------------------
+constexpr int DQ_RING = 3;
+constexpr int DQ_SLAB = 2 * DS_TILE;                              // one wave's dS of one 64-key step
+constexpr int DQ_LDS = DQ_RING * FTILE + 8 * DQ_RING * DQ_SLAB;   // K ring 48 KiB + 8 private dS rings 96 KiB
+
+// one 16-key k-step of key block HF of the step: dS^T fragment (2 transposed reads of the private slab) + four K^T fragments
+template <bool BF, int HF, int KS>
+__device__ __forceinline__ void dq_step(const char *kt, const int (&vo)[4][2], unsigned dsb, f32x16 (&dq)[4]) {
+    s16x4 blo, bhi;
+    Tr4 ta;
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%c3\n\tds_read_b64_tr_b16 %1, %2 offset:%c4"
+                 : "=&v"(blo), "=&v"(bhi)
+                 : "v"(dsb), "n"(HF * DS_TILE + KS * 512), "n"(HF * DS_TILE + KS * 512 + 256)
+                 : "memory");
+    tr4_issue<(32 * HF + 16 * KS) * AROW>(kt, vo, ta);
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(blo), "+v"(bhi), "+v"(ta.lo[0]), "+v"(ta.hi[0]), "+v"(ta.lo[1]), "+v"(ta.hi[1]), "+v"(ta.lo[2]), "+v"(ta.hi[2]),
+                   "+v"(ta.lo[3]), "+v"(ta.hi[3])
+                 :
+                 : "memory");
+    s16x8 r;
+    r[0] = blo[0]; r[1] = blo[1]; r[2] = blo[2]; r[3] = blo[3];
+    r[4] = bhi[0]; r[5] = bhi[1]; r[6] = bhi[2]; r[7] = bhi[3];
+    const auto b = __builtin_bit_cast(typename AFrag<BF>::type, r);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) dq[d] = a_mfma<BF>(tr4_frag<BF>(ta, d), b, dq[d]);
+}
+
+template <bool BF>
+__global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_ds_kernel(const AttnArgs a) {
+    using frag_t = typename AFrag<BF>::type;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int xb0;
+    int64_t bh;
+    const int nxb = (int)((a.Sq + FQ - 1) / FQ);
+    const int nwx = a.persist ? nxb / (2 * a.persist) : nxb;
+    a_block_map(nwx, (int)(a.B * a.H), a.xcd_map, xb0, bh);
+    const char *Kg = a.k + bh * a.Skv * AROW;
+    char *slab = smem + DQ_RING * FTILE + wid * DQ_RING * DQ_SLAB;
+    int vo[4][2];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        vo[d][0] = a_tr_lane_off(d * 32, 0);
+        vo[d][1] = a_tr_lane_off(d * 32, 1);
+    }
+    // transposed-read address of the dS^T fragment inside a slab: key 4 h + qq, query quad 4 (grp & 1) + p
+    const int grp = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3, h = grp >> 1;
+    const unsigned smem_u = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)smem;
+    const int sp = grp & 1; // operand s' = query quads 4 s' .. 4 s' + 3
+    const unsigned ds_rd = smem_u + (unsigned)(slab - smem) + sp * 1024 + 64 * ((2 * h + (qq >> 1)) ^ (2 * sp)) + 32 * (qq & 1) + 16 * (pp & 1) + 8 * (pp >> 1);
+    // LDS-DMA source: a piece is one operand half s of a tile (1 KiB, stored [key][hl][16 B]); it lands verbatim except that
+    // in half 1 the 64-byte key pairs a and a ^ 2 trade places (conflict-free transposed reads; every 4 lanes still read 64
+    // consecutive bytes)
+    int ds_src[2];
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) ds_src[pc] = pc * 1024 + (((lane >> 2) ^ (2 * pc)) * 4 + (lane & 3)) * 16;
+    const int krow = lane >> 4, kpos = lane & 15;
+#pragma nounroll
+  for (int pass = 0; pass < (a.persist ? 2 * a.persist : 1); ++pass) {
+    const int xp = xb0 + (pass >> 1) * nwx;
+    const int xb = ((pass & 1) != (a.persist_rev != 0)) ? nxb - 1 - xp : xp;
+    const int qblk = nxb - 1 - xb; // longest blocks first
+    const int64_t q0 = (int64_t)qblk * FQ, qw = q0 + wid * 32;
+    const bool active = qw < a.Sq;
+    const int sl = (int)(qw >> 5); // this wave's slice: key blocks 0 .. sl contribute
+    f32x16 dq[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dq[d][e] = 0.f;
+    const int64_t q_end = q0 + FQ < a.Sq ? q0 + FQ : a.Sq;
+    const int64_t kv_end = a.Skv < q_end ? a.Skv : q_end;
+    const int nt = (int)((kv_end + ABK - 1) / ABK);
+    const char *dsg = a.ds + ((bh * a.ds_nqb + qblk) * a.ds_nkwb * 8 + wid) * DS_TILE; // + kwb * 8 tiles
+    const int kwb_last = (int)(a.ds_nkwb - 1);
+    auto stage = [&](int tile, int slot) { // 2 K pieces (this wave's share of the tile) + 4 dS pieces (its own two tiles)
+        const int tl = tile < nt ? tile : nt - 1;
+        const char *kg = Kg + (int64_t)tl * ABK * AROW;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row0 = (wid * 2 + i) * 4, row = row0 + krow;
+            const int chunk = kpos ^ (((row & 3) << 2) | ((row >> 2) & 3));
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kg + row * AROW + chunk * 16),
+                                             (__attribute__((address_space(3))) void *)(smem + slot * FTILE + row0 * AROW), 16, 0, 0);
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            int kwb = 2 * tl + hf;
+            kwb = kwb < kwb_last ? kwb : kwb_last; // Skv % 64 == 32: the odd last key block has no partner (never consumed)
+            const char *tg = dsg + (int64_t)kwb * 8 * DS_TILE;
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tg + ds_src[pc]),
+                                                 (__attribute__((address_space(3))) void *)(slab + slot * DQ_SLAB + hf * DS_TILE + pc * 1024), 16, 0, 0);
+        }
+    };
+    stage(0, 0);
+    stage(1, 1);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); // step t has landed (this wave's pieces) ...
+        __builtin_amdgcn_s_barrier();                      // ... and the K tile's other pieces; slot (t + 2) % 3 is free again
+        asm volatile("" ::: "memory");
+        stage(t + 2, (t + 2) % DQ_RING);
+        const char *kt = smem + (t % DQ_RING) * FTILE;
+        const unsigned dsb = ds_rd + (unsigned)((t % DQ_RING) * DQ_SLAB);
+        if (active && 2 * t <= sl) { // wave-uniform: key block 2 t lies at or below this slice's diagonal
+            dq_step<BF, 0, 0>(kt, vo, dsb, dq);
+            dq_step<BF, 0, 1>(kt, vo, dsb, dq);
+            if (2 * t + 1 <= sl) {
+                dq_step<BF, 1, 0>(kt, vo, dsb, dq);
+                dq_step<BF, 1, 1>(kt, vo, dsb, dq);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (active) a_store_rows<BF>(smem + wid * 32 * OPAD, a.dq + (bh * a.Sq + qw) * AROW, dq, a.scale);
+    if (a.persist) __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // backward: dK, dV ("key on the lane"); both kernels sweep 32-query slices from the block's diagonal down. Per slice:
 // S = Q K^T, dP = dO V^T (A = Q / dO rows from LDS, B = K / V fragments), dV^T += dO^T P, dK^T += Q^T dS (A via
 // transposed reads).
@@ -706,7 +855,7 @@ __device__ __forceinline__ f32x16 k4_acc(const f32x4 (&c)[4]) {
     return r;
 }
 
-template <bool BF>
+template <bool BF, bool DS>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) {
     using frag_t = typename AFrag<BF>::type;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -763,6 +912,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     }
     const float *rcg = lane < BQS ? a.nlse + bh * a.Sq + lane : a.ndelta + bh * a.Sq + lane - BQS;
     const int ns = (int)(a.Sq / BQS), np = ns / 2;
+    // dS tiles of this wave's 32 keys: tile (qb, kwb, sl) of the workspace, lane (key xl, half hl) writes operand s at
+    // s * 1024 + xl * 32 + hl * 16 (see DS_TILE)
+    const unsigned ds_lane = (unsigned)(xl * 32 + hl * 16);
+    const int64_t ds_wave = ((bh * a.ds_nqb * a.ds_nkwb + (kw >> 5)) * 8) * DS_TILE; // + (qb nkwb 8 + sl) 2 KiB per slice
     // a pair is 10 DMA operations per wave (ids 0..9: slice id / 5; Q rows i, dO rows i for i = 0, 1, then the row
     // constants); they are issued ONE per quarter-phase (an LDS-DMA instruction holds the wave's issue for 60-180 cycles,
     // which a lone wave per SIMD can only hide under MFMAs already queued)
@@ -907,7 +1060,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
             // the next pair has landed - this wave's part, then everyone's - and every wave is past its reads of the
             // previous pair, whose buffer takes pair pr + 3. vmcnt(0), not a counted wait: register spills are VMEM
             // operations too and would be counted among "the youngest"; the pair after next was issued a pair ago.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // With the dS stores in the stream (two per slice, at its end) the wait is COUNTED: the pair being waited for (pr + 1)
+            // was issued in pair pr - 2's last slice; younger than it are that slice's 2 stores, pair pr - 1's 2 + 10 + 2 and this
+            // pair's first slice's 2 = 18 operations (a store that has just been issued takes ~1 us to retire: vmcnt(0) here would
+            // stall every pair on it). The kernel must stay spill-free for this to hold (tools/kernel_resources.py).
+            if constexpr (DS) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if constexpr (!K4_SPREAD) stage_pair(pr + 3, (it + 3) & 3);
@@ -955,6 +1113,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         if constexpr (LAST && K4_SPREAD) {
             stage_piece(std::integral_constant<int, 8>{}, pr + 3, (it + 3) & 3);
             stage_piece(std::integral_constant<int, 9>{}, pr + 3, (it + 3) & 3);
+        }
+        if constexpr (DS) { // the slice's dS, already packed as two MFMA operands: two 1 KiB stores per wave (behind the DMA: K4_VMCNT)
+            const int sl_ = (int)(qs >> 5);
+            const char *tile = a.ds + ds_wave + ((int64_t)(sl_ >> 3) * a.ds_nkwb * 8 + (sl_ & 7)) * DS_TILE;
+            const uint64_t tb = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile) |
+                                ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)tile >> 32)) << 32);
+            // write-through (sc0 sc1): the lines leave the XCD's L2 instead of evicting the Q / dO slices the workgroups of a head
+            // share through it (measured at C3: 2.476 ms against 2.516 plain and 2.528 nt; 2.455 without the stores)
+            asm volatile("global_store_dwordx4 %0, %1, %3 offset:0 sc0 sc1\n\tglobal_store_dwordx4 %0, %2, %3 offset:1024 sc0 sc1"
+                         :
+                         : "v"(ds_lane), "v"(df[0]), "v"(df[1]), "s"(tb)
+                         : "memory");
         }
         sv = svn;
     };
@@ -1633,6 +1803,12 @@ static bool mfma_ok(int dtype, int64_t Sq, int64_t Skv, int64_t D) {
 
 static inline size_t a_align(size_t v) { return (v + 255) / 256 * 256; }
 
+// the MFMA backward keeps dS (2 products for dQ instead of 6) while its workspace stays below 64 GiB; beyond that, and with
+// KF_ATTN_SPLIT_BWD, the dQ kernel recomputes S and dP (round 1's split: small workspace, 40 % more matrix work)
+static bool bwd_keeps_ds(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D) {
+    return mfma_ok(dtype, Sq, Skv, D) && !knob(KNOB_ATTN_SPLIT_BWD) && ds_bytes(B * H, Sq, Skv) <= ((size_t)64 << 30);
+}
+
 template <typename K>
 static int set_lds(K kernel, size_t bytes) { return ensure_dynamic_lds((const void *)kernel, (int)bytes); }
 
@@ -1730,6 +1906,7 @@ extern "C" int kf_attn_bwd_workspace_bytes(int dtype, int64_t B, int64_t H, int6
     int rc = check_common("kf_attn_bwd_workspace_bytes", dtype, B, H, Sq, Skv, D);
     if (rc != KF_OK) return rc;
     *bytes = 3 * a_align((size_t)B * H * Sq * sizeof(float)); // delta | -lse sqrt(D) | -delta
+    if (bwd_keeps_ds(dtype, B, H, Sq, Skv, D)) *bytes += ds_bytes(B * H, Sq, Skv); // + dS in 16 bits (DS_TILE)
     return KF_OK;
 }
 
@@ -1772,26 +1949,41 @@ extern "C" int kf_attn_bwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, i
             else attn_delta_kernel<false><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, 1.0f / a.scale);
             KF_LAUNCH_CHECK();
         }
+        const bool keep_ds = bwd_keeps_ds(dtype, B, H, Sq, Skv, D);
+        a.ds = keep_ds ? (char *)workspace + 3 * a_align((size_t)B * H * Sq * sizeof(float)) : nullptr;
+        a.ds_nqb = (Sq + 255) / 256;
+        a.ds_nkwb = Skv / 32;
         { // one wave per SIMD, pinned MFMA / VALU interleave
             const int64_t nkb4 = Skv / K4B;
             a.persist = (nkb4 % 2 == 0 && nkb4 >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
             a.persist_rev = 1; // the short block of the pair first: 2.17 ms against 2.32 the other way round (2.22 unpaired)
             dim3 gk4((unsigned)((a.persist ? nkb4 / 2 : nkb4) * B * H));
-            if ((rc = set_lds(attn_bwd_dkv_v4_kernel<true>, K4LDS)) != KF_OK) return rc;
-            if ((rc = set_lds(attn_bwd_dkv_v4_kernel<false>, K4LDS)) != KF_OK) return rc;
             KF_PROF("attn_bwd_dkv_mfma", st);
-            if (bf) attn_bwd_dkv_v4_kernel<true><<<gk4, 256, K4LDS, st>>>(a);
-            else attn_bwd_dkv_v4_kernel<false><<<gk4, 256, K4LDS, st>>>(a);
+#define KF_DKV(BF_, DS_)                                                                  \
+    {                                                                                     \
+        if ((rc = set_lds(attn_bwd_dkv_v4_kernel<BF_, DS_>, K4LDS)) != KF_OK) return rc;  \
+        attn_bwd_dkv_v4_kernel<BF_, DS_><<<gk4, 256, K4LDS, st>>>(a);                     \
+    }
+            if (bf) { if (keep_ds) KF_DKV(true, true) else KF_DKV(true, false) }
+            else { if (keep_ds) KF_DKV(false, true) else KF_DKV(false, false) }
+#undef KF_DKV
             KF_LAUNCH_CHECK();
         }
-        {
-            const int64_t nxq = (Sq + FQ - 1) / FQ;
-            a.persist = (nxq % 2 == 0 && nxq >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
-            a.persist_rev = 0;
-            dim3 gq2((unsigned)((a.persist ? nxq / 2 : nxq) * B * H));
+        const int64_t nxq = (Sq + FQ - 1) / FQ;
+        a.persist = (nxq % 2 == 0 && nxq >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
+        a.persist_rev = 0;
+        dim3 gq2((unsigned)((a.persist ? nxq / 2 : nxq) * B * H));
+        if (keep_ds) { // dQ = scale dS K from the stored dS
+            if ((rc = set_lds(attn_bwd_dq_ds_kernel<true>, DQ_LDS)) != KF_OK) return rc;
+            if ((rc = set_lds(attn_bwd_dq_ds_kernel<false>, DQ_LDS)) != KF_OK) return rc;
+            KF_PROF("attn_bwd_dq_mfma", st);
+            if (bf) attn_bwd_dq_ds_kernel<true><<<gq2, FNT, DQ_LDS, st>>>(a);
+            else attn_bwd_dq_ds_kernel<false><<<gq2, FNT, DQ_LDS, st>>>(a);
+            KF_LAUNCH_CHECK();
+        } else { // the recomputing dQ kernel
             if ((rc = set_lds(attn_bwd_dq_v2_kernel<true>, QLDS)) != KF_OK) return rc;
             if ((rc = set_lds(attn_bwd_dq_v2_kernel<false>, QLDS)) != KF_OK) return rc;
-            KF_PROF("attn_bwd_dq_mfma", st);
+            KF_PROF("attn_bwd_dq_mfma_split", st);
             if (bf) attn_bwd_dq_v2_kernel<true><<<gq2, FNT, QLDS, st>>>(a);
             else attn_bwd_dq_v2_kernel<false><<<gq2, FNT, QLDS, st>>>(a);
             KF_LAUNCH_CHECK();

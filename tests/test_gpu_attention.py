@@ -293,3 +293,32 @@ def test_f32_mfma_backward_vs_oracle(B, Hh, Sq, Skv, D):
     again = bwd(H.F32, q, k, v, o, lse, go)  # no atomics: bitwise reproducible
     for a0, a1 in zip(got, again):
         assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32))
+
+
+@pytest.mark.parametrize("code", [H.BF16, H.F16])
+def test_backward_forms_stored_ds_and_recomputing_split(code):
+    """Two backward forms behind one entry. Default: the dK/dV kernel stores dS = P o (dP - delta) in 16 bits and the dQ kernel
+    computes dQ = scale dS K from it (kernel label attn_bwd_dq_mfma, workspace grows by B H Sq Skv 2 bytes). KF_ATTN_SPLIT_BWD:
+    the recomputing dQ kernel (label attn_bwd_dq_mfma_split, small workspace). Both against the oracle; dK and dV are the same
+    kernel arithmetic in both forms and must be bit-identical; shapes cover Sq != Skv and a half-filled last query block."""
+    for (B, Hh, Sq, Skv) in ((1, 2, 512, 512), (2, 1, 384, 640), (1, 3, 640, 256), (1, 2, 128, 128)):
+        rng = np.random.default_rng(21 + Sq + Skv + code)
+        q, k, v, go = (O.from_float(rng.uniform(-1, 1, s).astype(np.float32), code)
+                       for s in ((B, Hh, Sq, 128), (B, Hh, Skv, 128), (B, Hh, Skv, 128), (B, Hh, Sq, 128)))
+        o, lse = fwd(code, q, k, v)
+        want = O.attn_bwd(q, k, v, go, code=code)
+        res = {}
+        for form, env in (("ds", None), ("split", "1")):
+            with H.knobs(KF_ATTN_SPLIT_BWD=env):
+                small = 3 * ((B * Hh * Sq * 4 + 255) // 256 * 256)
+                need = H.attn_bwd_workspace_bytes(code, B, Hh, Sq, Skv, 128)
+                assert need == (small if env else small + B * Hh * ((Sq + 255) // 256) * 256 * Skv * 2), (form, need)
+                H.profile_reset()
+                H.profile_enable(True)
+                res[form] = bwd(code, q, k, v, o, lse, go)
+                H.profile_enable(False)
+                assert ("attn_bwd_dq_mfma_split" if env else "attn_bwd_dq_mfma") in H.profile_results(), (form, H.profile_results())
+            for nme, got, ref in zip(("dq", "dk", "dv"), res[form], want):
+                assert_close(f(got, code), f(ref, code), **TOL_BWD[code], what=f"{form} {nme} {Sq}x{Skv}")
+        assert np.array_equal(res["ds"][1].view(np.uint16), res["split"][1].view(np.uint16))
+        assert np.array_equal(res["ds"][2].view(np.uint16), res["split"][2].view(np.uint16))

@@ -44,7 +44,7 @@ def main():
     need = H.attn_bwd_workspace_bytes(H.BF16, B, Hh, S, S, D)
     ws = H.DevBuf(need)
     pair = B * Hh * S * S * D / 2.0
-    flops = {"attn_fwd_mfma": 4 * pair, "attn_fwd_mfma_v2": 4 * pair, "attn_fwd_mfma_v1": 4 * pair, "attn_bwd_dkv_mfma": 8 * pair, "attn_bwd_dq_mfma": 6 * pair, "attn_bwd_dq_mfma_v1": 6 * pair, "attn_bwd_dkv_mfma_v1": 8 * pair, "attn_bwd_dkv_mfma_v3": 8 * pair, "attn_bwd_dkv_mfma_v2": 8 * pair}
+    flops = {"attn_fwd_mfma": 4 * pair, "attn_fwd_mfma_v2": 4 * pair, "attn_fwd_mfma_v1": 4 * pair, "attn_bwd_dkv_mfma": 8 * pair, "attn_bwd_dq_mfma": 2 * pair, "attn_bwd_dq_mfma_split": 6 * pair, "attn_bwd_dq_mfma_v1": 6 * pair, "attn_bwd_dkv_mfma_v1": 8 * pair, "attn_bwd_dkv_mfma_v3": 8 * pair, "attn_bwd_dkv_mfma_v2": 8 * pair}
     variants = args.variants.split(",")
     results = {v: {} for v in variants}
     for r in range(args.rounds + 1):
