@@ -195,6 +195,27 @@ int kf_reduce_moments_workspace_bytes(const kf_iter_desc *desc, size_t *bytes);
 int kf_reduce_moments(int mode, const kf_iter_desc *desc, double correction, double eps, void *workspace,
                       size_t workspace_bytes, void *stream);
 
+/* ---- row normalisations: finishes the reference's roadmap item rms_norm (README.md:28) on its building block norm_stat
+ *      (norm_ops_kernel.h:5, norm_ops_kernel.cu:6-61; invstd = 1 / sqrt(M2 / n + eps), welford_norm.h:170-187) -------------- */
+enum {
+    KF_NORM_RMS = 0,  /* y = x * rstd * w,                 rstd = 1 / sqrt(mean(x^2) + eps)            */
+    KF_NORM_LAYER = 1 /* y = (x - mean) * rstd * w + b,    rstd = 1 / sqrt(mean((x - mean)^2) + eps)   */
+};
+/*
+ * x, y, dy, dx: [rows, cols] with row stride `ld` elements (ld >= cols); weight, bias, dweight, dbias: [cols] (any may be
+ * NULL: w = 1, b = 0; RMS takes no bias); dtype in {KF_F32, KF_BF16, KF_F16} for all of them; statistics in f32:
+ * mean[rows] (LAYER only), rstd[rows] - the forward writes them (NULL: not kept), the backward reads them.
+ * Backward: dx = rstd * (g - mean(g) - xhat * mean(g * xhat)) with g = dy * w, xhat = (x - mean) * rstd (RMS: no mean(g)
+ * term, mean = 0); dweight = sum_rows dy * xhat, dbias = sum_rows dy - summed in a fixed order through caller scratch of
+ * kf_norm_bwd_workspace_bytes() bytes (no atomics: bitwise reproducible; the scratch needs no initialisation).
+ */
+int kf_norm_fwd(int kind, int dtype, int64_t rows, int64_t cols, int64_t ld, const void *x, const void *weight, const void *bias,
+                double eps, void *y, float *mean, float *rstd, void *stream);
+int kf_norm_bwd_workspace_bytes(int kind, int dtype, int64_t rows, int64_t cols, int64_t ld, size_t *bytes);
+int kf_norm_bwd(int kind, int dtype, int64_t rows, int64_t cols, int64_t ld, const void *x, const void *weight, const float *mean,
+                const float *rstd, const void *dy, void *dx, void *dweight, void *dbias, void *workspace, size_t workspace_bytes,
+                void *stream);
+
 /* ---- index_put_: replaces index_ops_kernel.h:5 --------------------------------------------- */
 /*
  * desc operands: [0] = self viewed with stride 0 (index_ops.cpp:23-25), [1] = values,
@@ -205,6 +226,22 @@ int kf_reduce_moments(int mode, const kf_iter_desc *desc, double correction, dou
  */
 int kf_index_put(const kf_iter_desc *desc, int nidx, const int64_t *sizes, const int64_t *strides_bytes,
                  void *stream);
+
+/* ---- row gather: the reference's roadmap item "embedding" (README.md:30), on the index arithmetic of tensor_index.h:56-104 ---- */
+/*
+ * out[n, :] = table[wrap(idx[n]), :] for n < n: rows of row_bytes bytes, moved as bytes (bit-exact for every dtype); negative
+ * indices wrap once, no bounds check (as the reference's index kernels, tensor_index.h:56-75). idx is int64, on the device.
+ */
+int kf_index_get(const void *table, int64_t nrows, int64_t row_bytes, const int64_t *idx, int64_t n, void *out, void *stream);
+/*
+ * The gather's backward without atomics: dst[r, :] = sum over {n : wrap(idx[n]) == r} of src[n, :], added in input order in f32
+ * (the indices are wrapped, stably sorted with kf_sort, and each run of equal rows is summed by one wave: bitwise
+ * reproducible). Rows no index names are left untouched (zero dst first). dtype in {KF_F32, KF_BF16, KF_F16}; src [n, cols],
+ * dst [nrows, cols] contiguous; caller scratch of kf_index_add_workspace_bytes(n) bytes, no initialisation needed.
+ */
+size_t kf_index_add_workspace_bytes(int64_t n);
+int kf_index_add(int dtype, const int64_t *idx, int64_t n, const void *src, int64_t cols, int64_t nrows, void *dst, void *workspace,
+                 size_t workspace_bytes, void *stream);
 
 /* ---- sort: replaces sort_ops_kernel.h (segmented_sort_pairs, sort_ops_kernel.cu:402-505) ----- */
 /*

@@ -1,4 +1,4 @@
-// index_put_ scatter for gfx950.
+// index_put_ scatter, row gather (embedding) and its sorted scatter-add backward for gfx950.
 // Replaces src/device/index_ops_kernel.cu:3-15 + src/device/utils/tensor_index.h:19-143.
 // One lane per (values, indices...) element: read the int64 index of every indexed dim (coalesced —
 // the index tensors are walked with the iteration space), wrap negatives once, form the byte
@@ -42,9 +42,130 @@ __global__ __launch_bounds__(kIB) void index_put_kernel(const IndexArgs a) {
     }
 }
 
+// ---- row gather (embedding, README.md:30; the read side of the index arithmetic of tensor_index.h:56-104) -------------------
+// out[n, :] = table[wrap(idx[n]), :]: the output is walked as a flat array of U-sized units, one per lane, grid = the problem
+// (this memory system wants many short waves): unit u -> row u / upr, unit u % upr of it. Lanes of one
+// row read the same index word (a broadcast out of L1). Byte mover: bit-exact for every dtype.
+template <typename U>
+__global__ __launch_bounds__(256) void index_get_kernel(const char *table, int64_t nrows, int64_t row_bytes, const int64_t *idx, int64_t units,
+                                                        uint32_t upr, char *out) {
+    const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (u >= units) return;
+    const int64_t n = u / upr;
+    const uint32_t c = (uint32_t)(u - n * upr);
+    int64_t r = idx[n];
+    if (r < 0) r += nrows;
+    *(U *)(out + n * row_bytes + (int64_t)c * sizeof(U)) = *(const U *)(table + r * row_bytes + (int64_t)c * sizeof(U));
+}
+
+// ---- row scatter-add (embedding backward; no reference counterpart) --------------------------------------------------------
+// The indices are wrapped, then stably sorted (kf_sort, int64 keys + positions); then
+// dst[r, :] = sum over the run of equal sorted indices r of src[pos[j], :], added in run order (the stable sort's order =
+// input order): one wave per run START (the other waves leave at once), f32 accumulation, no atomics - bitwise reproducible.
+template <typename T> __device__ __forceinline__ float ia_ld(const T *p) { return (float)*p; }
+template <> __device__ __forceinline__ float ia_ld<bf16_t>(const bf16_t *p) { return bf16_to_f32(*p); }
+template <> __device__ __forceinline__ float ia_ld<f16_t>(const f16_t *p) { return f16_to_f32(*p); }
+template <typename T> __device__ __forceinline__ void ia_st(T *p, float v) { *p = (T)v; }
+template <> __device__ __forceinline__ void ia_st<bf16_t>(bf16_t *p, float v) { *p = f32_to_bf16(v); }
+template <> __device__ __forceinline__ void ia_st<f16_t>(f16_t *p, float v) { *p = f32_to_f16(v); }
+
+__global__ __launch_bounds__(256) void index_wrap_kernel(const int64_t *idx, int64_t n, int64_t nrows, int64_t *out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const int64_t r = idx[i]; out[i] = r < 0 ? r + nrows : r; }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void index_add_sorted_kernel(const int64_t *key, const int64_t *pos, int64_t n, const T *src, int64_t cols,
+                                                               int64_t nrows, T *dst) {
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= n) return;
+    const int64_t k = key[j];
+    if (j > 0 && key[j - 1] == k) return; // not a run start
+    const int64_t r = k; // already wrapped
+    for (int64_t c0 = 0; c0 < cols; c0 += 64 * 4) { // 4 columns per lane per sweep, the run re-walked per column chunk
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int64_t jj = j; jj < n && key[jj] == k; ++jj) {
+            const T *row = src + pos[jj] * cols;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t c = c0 + (int64_t)i * 64 + lane;
+                if (c < cols) acc[i] += ia_ld(row + c);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t c = c0 + (int64_t)i * 64 + lane;
+            if (c < cols) ia_st(dst + r * cols + c, acc[i]);
+        }
+    }
+}
+
 } // namespace kf
 
 using namespace kf;
+
+extern "C" int kf_index_get(const void *table, int64_t nrows, int64_t row_bytes, const int64_t *idx, int64_t n, void *out, void *stream) {
+    KF_REQUIRE(nrows >= 0 && row_bytes >= 0 && n >= 0, KF_ERR_INVALID, "kf_index_get: negative extent");
+    if (n == 0 || row_bytes == 0) return KF_OK;
+    KF_REQUIRE(table && idx && out && nrows > 0, KF_ERR_INVALID, "kf_index_get: null operand or empty table");
+    // the widest unit that divides the row and both base addresses
+    const uintptr_t bits = (uintptr_t)table | (uintptr_t)out | (uintptr_t)row_bytes;
+    const int us = (bits % 16 == 0) ? 16 : (bits % 8 == 0) ? 8 : (bits % 4 == 0) ? 4 : (bits % 2 == 0) ? 2 : 1;
+    const int64_t upr = row_bytes / us, units = upr * n;
+    KF_REQUIRE(upr <= 0xffffffffLL && (units + 255) / 256 <= 0x7fffffffLL, KF_ERR_INDEX_RANGE, "kf_index_get: too many units for one launch");
+    const unsigned grid = (unsigned)((units + 255) / 256);
+    hipStream_t st = as_stream(stream);
+    KF_PROF("index_get", st);
+    const char *t = (const char *)table;
+    char *o = (char *)out;
+    switch (us) {
+    case 16: index_get_kernel<uint4><<<grid, 256, 0, st>>>(t, nrows, row_bytes, idx, units, (uint32_t)upr, o); break;
+    case 8: index_get_kernel<uint64_t><<<grid, 256, 0, st>>>(t, nrows, row_bytes, idx, units, (uint32_t)upr, o); break;
+    case 4: index_get_kernel<uint32_t><<<grid, 256, 0, st>>>(t, nrows, row_bytes, idx, units, (uint32_t)upr, o); break;
+    case 2: index_get_kernel<uint16_t><<<grid, 256, 0, st>>>(t, nrows, row_bytes, idx, units, (uint32_t)upr, o); break;
+    default: index_get_kernel<uint8_t><<<grid, 256, 0, st>>>(t, nrows, row_bytes, idx, units, (uint32_t)upr, o); break;
+    }
+    KF_LAUNCH_CHECK();
+    return KF_OK;
+}
+
+static inline size_t ia_align(size_t v) { return (v + 255) / 256 * 256; }
+
+extern "C" size_t kf_index_add_workspace_bytes(int64_t n) {
+    if (n <= 0) return 0;
+    return 3 * ia_align((size_t)n * 8) + ia_align(kf_sort_workspace_bytes(KF_I64, 1, n)); // wrapped | sorted | positions | sort scratch
+}
+
+extern "C" int kf_index_add(int dtype, const int64_t *idx, int64_t n, const void *src, int64_t cols, int64_t nrows, void *dst, void *workspace,
+                            size_t workspace_bytes, void *stream) {
+    KF_REQUIRE(dtype == KF_F32 || dtype == KF_BF16 || dtype == KF_F16, KF_ERR_UNSUPPORTED, "kf_index_add: dtype %d not supported", dtype);
+    KF_REQUIRE(n >= 0 && cols >= 0 && nrows >= 0, KF_ERR_INVALID, "kf_index_add: negative extent");
+    if (n == 0 || cols == 0) return KF_OK;
+    KF_REQUIRE(idx && src && dst && nrows > 0, KF_ERR_INVALID, "kf_index_add: null operand or empty destination");
+    const size_t need = kf_index_add_workspace_bytes(n);
+    KF_REQUIRE(workspace && workspace_bytes >= need, KF_ERR_WORKSPACE, "kf_index_add: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    KF_REQUIRE((n + 3) / 4 <= 0x7fffffffLL, KF_ERR_INDEX_RANGE, "kf_index_add: too many indices for one launch");
+    hipStream_t st = as_stream(stream);
+    char *ws = (char *)workspace;
+    int64_t *wrapped = (int64_t *)ws, *sorted = (int64_t *)(ws + ia_align((size_t)n * 8)), *pos = (int64_t *)(ws + 2 * ia_align((size_t)n * 8));
+    void *sort_ws = ws + 3 * ia_align((size_t)n * 8);
+    {
+        KF_PROF("index_wrap", st);
+        index_wrap_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(idx, n, nrows, wrapped);
+        KF_LAUNCH_CHECK();
+    }
+    const size_t sws = kf_sort_workspace_bytes(KF_I64, 1, n);
+    int rc = kf_sort(KF_I64, wrapped, sorted, pos, 1, n, 0, sws ? sort_ws : nullptr, sws, stream); // stable: equal rows keep input order
+    if (rc != KF_OK) return rc;
+    const unsigned grid = (unsigned)((n + 3) / 4);
+    KF_PROF("index_add_sorted", st);
+    if (dtype == KF_F32) index_add_sorted_kernel<float><<<grid, 256, 0, st>>>(sorted, pos, n, (const float *)src, cols, nrows, (float *)dst);
+    else if (dtype == KF_BF16) index_add_sorted_kernel<bf16_t><<<grid, 256, 0, st>>>(sorted, pos, n, (const bf16_t *)src, cols, nrows, (bf16_t *)dst);
+    else index_add_sorted_kernel<f16_t><<<grid, 256, 0, st>>>(sorted, pos, n, (const f16_t *)src, cols, nrows, (f16_t *)dst);
+    KF_LAUNCH_CHECK();
+    return KF_OK;
+}
 
 extern "C" int kf_index_put(const kf_iter_desc *d, int nidx, const int64_t *sizes, const int64_t *strides_bytes,
                             void *stream) {

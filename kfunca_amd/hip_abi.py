@@ -22,6 +22,7 @@ EW_ADD, EW_SUB, EW_MUL, EW_DIV, EW_COPY, EW_FILL, EW_ADD_SCALAR, EW_SUB_SCALAR, 
 RED_SUM, RED_MEAN = range(2)
 MOM_VAR, MOM_STD, MOM_INVSTD = range(3)
 EPI_NONE, EPI_BIAS_ROW = range(2)
+NORM_RMS, NORM_LAYER = range(2)
 MAX_DIMS, MAX_TENSORS = 12, 8
 KF_OK, KF_ERR_HIP, KF_ERR_INVALID, KF_ERR_UNSUPPORTED, KF_ERR_INDEX_RANGE, KF_ERR_WORKSPACE, KF_ERR_COMM = range(7)
 COMM_ID_BYTES = 128
@@ -39,7 +40,8 @@ EXPORTS = [
     "kf_event_elapsed_ms", "kf_graph_begin_capture", "kf_graph_end_capture", "kf_graph_launch", "kf_graph_destroy", "kf_profile_enable", "kf_profile_reset", "kf_profile_count", "kf_profile_get", "kf_knobs_reload",
     "kf_device_props_get", "kf_elementwise", "kf_reduce_workspace_bytes", "kf_reduce",
     "kf_reduce_moments_workspace_bytes", "kf_reduce_moments",
-    "kf_index_put", "kf_sort_workspace_bytes", "kf_sort", "kf_gemm_workspace_bytes", "kf_gemm", "kf_attn_fwd", "kf_attn_fwd_scaled", "kf_attn_bwd_workspace_bytes",
+    "kf_norm_fwd", "kf_norm_bwd_workspace_bytes", "kf_norm_bwd",
+    "kf_index_put", "kf_index_get", "kf_index_add_workspace_bytes", "kf_index_add", "kf_sort_workspace_bytes", "kf_sort", "kf_gemm_workspace_bytes", "kf_gemm", "kf_attn_fwd", "kf_attn_fwd_scaled", "kf_attn_bwd_workspace_bytes",
     "kf_attn_bwd", "kf_attn_bwd_scaled", "kf_comm_unique_id", "kf_comm_init", "kf_comm_destroy", "kf_allreduce_sum",
 ]
 
@@ -101,7 +103,14 @@ def lib():
         _lib.kf_reduce.argtypes = [C.c_int, C.POINTER(IterDesc), vp, sz, vp]
         _lib.kf_reduce_moments_workspace_bytes.argtypes = [C.POINTER(IterDesc), C.POINTER(sz)]
         _lib.kf_reduce_moments.argtypes = [C.c_int, C.POINTER(IterDesc), C.c_double, C.c_double, vp, sz, vp]
+        _lib.kf_norm_fwd.argtypes = [C.c_int, C.c_int, i64, i64, i64, vp, vp, vp, C.c_double, vp, vp, vp, vp]
+        _lib.kf_norm_bwd_workspace_bytes.argtypes = [C.c_int, C.c_int, i64, i64, i64, C.POINTER(sz)]
+        _lib.kf_norm_bwd.argtypes = [C.c_int, C.c_int, i64, i64, i64] + [vp] * 9 + [sz, vp]
         _lib.kf_index_put.argtypes = [C.POINTER(IterDesc), C.c_int, C.POINTER(i64), C.POINTER(i64), vp]
+        _lib.kf_index_get.argtypes = [vp, i64, i64, vp, i64, vp, vp]
+        _lib.kf_index_add_workspace_bytes.argtypes = [i64]
+        _lib.kf_index_add_workspace_bytes.restype = sz
+        _lib.kf_index_add.argtypes = [C.c_int, vp, i64, vp, i64, i64, vp, vp, sz, vp]
         _lib.kf_sort_workspace_bytes.argtypes = [C.c_int, i64, i64]
         _lib.kf_sort_workspace_bytes.restype = sz
         _lib.kf_sort.argtypes = [C.c_int, vp, vp, vp, i64, i64, C.c_int, vp, sz, vp]
@@ -373,11 +382,35 @@ def reduce(op, desc: IterDesc, stream=None):
     return ws  # keep alive until the stream is synchronised
 
 
+def norm_fwd(kind, dtype, rows, cols, x, weight, bias, eps, y, mean=None, rstd=None, ld=None, stream=None):
+    check(lib().kf_norm_fwd(kind, dtype, rows, cols, cols if ld is None else ld, x, weight, bias, float(eps), y, mean, rstd, stream))
+
+
+def norm_bwd(kind, dtype, rows, cols, x, weight, mean, rstd, dy, dx, dweight, dbias, ld=None, stream=None):
+    ld = cols if ld is None else ld
+    need = C.c_size_t(0)
+    check(lib().kf_norm_bwd_workspace_bytes(kind, dtype, rows, cols, ld, C.byref(need)))
+    ws = DevBuf(need.value) if need.value else None
+    check(lib().kf_norm_bwd(kind, dtype, rows, cols, ld, x, weight, mean, rstd, dy, dx, dweight, dbias, ws.ptr if ws else None, need.value, stream))
+    return ws  # keep alive until the stream is synchronised
+
+
 def index_put(desc: IterDesc, sizes, strides_bytes, stream=None):
     n = len(sizes)
     a = (C.c_int64 * n)(*sizes)
     b = (C.c_int64 * n)(*strides_bytes)
     check(lib().kf_index_put(C.byref(desc), n, a, b, stream))
+
+
+def index_get(table, nrows, row_bytes, idx, n, out, stream=None):
+    check(lib().kf_index_get(table, nrows, row_bytes, idx, n, out, stream))
+
+
+def index_add(dtype, idx, n, src, cols, nrows, dst, stream=None):
+    need = lib().kf_index_add_workspace_bytes(n)
+    ws = DevBuf(need) if need else None
+    check(lib().kf_index_add(dtype, idx, n, src, cols, nrows, dst, ws.ptr if ws else None, need, stream))
+    return ws  # keep alive until the stream is synchronised
 
 
 def sort_segments(keys: np.ndarray, descending=False, code=None, stream=None):

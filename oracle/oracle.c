@@ -496,6 +496,90 @@ int orc_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64
     return 0;
 }
 
+/* ---- row normalisations (README.md:28 roadmap rms_norm; invstd as welford_norm.h:170-187: 1 / sqrt(M2 / n + eps)) --------
+ * kind 0 = rms (y = x rstd w, rstd = 1 / sqrt(mean(x^2) + eps)), 1 = layer (y = (x - mean) rstd w + b). Statistics and the
+ * whole evaluation in double on the dtype-rounded inputs; outputs rounded once. */
+int orc_norm_fwd(int kind, int dtype, int64_t rows, int64_t cols, const void *x, const void *w, const void *b, double eps, void *y,
+                 float *mean_out, float *rstd_out) {
+    if (!(dtype == ORC_F32 || dtype == ORC_F16 || dtype == ORC_BF16) || (kind != 0 && kind != 1)) return 1;
+    const int es = dt_size(dtype);
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < rows; ++r) {
+        const char *xr = (const char *)x + r * cols * es;
+        double s = 0.0, mean = 0.0, q = 0.0;
+        if (kind == 1) {
+            for (int64_t c = 0; c < cols; ++c) s += ld_d(dtype, xr + c * es);
+            mean = s / (double)cols;
+        }
+        for (int64_t c = 0; c < cols; ++c) { const double d = ld_d(dtype, xr + c * es) - mean; q += d * d; }
+        const double rstd = 1.0 / sqrt(q / (double)cols + eps);
+        if (mean_out) mean_out[r] = (float)mean;
+        if (rstd_out) rstd_out[r] = (float)rstd;
+        for (int64_t c = 0; c < cols; ++c) {
+            double t = (ld_d(dtype, xr + c * es) - mean) * rstd;
+            if (w) t *= ld_d(dtype, (const char *)w + c * es);
+            if (b) t += ld_d(dtype, (const char *)b + c * es);
+            st_d(dtype, (char *)y + (r * cols + c) * es, t);
+        }
+    }
+    return 0;
+}
+
+/* closed-form backward of the above (no reference counterpart): g = dy w, xhat = (x - mean) rstd,
+ * dx = rstd (g - mean(g) - xhat mean(g xhat)) (rms: without the mean(g) term), dw = sum_rows dy xhat, db = sum_rows dy */
+int orc_norm_bwd(int kind, int dtype, int64_t rows, int64_t cols, const void *x, const void *w, double eps, const void *dy, void *dx,
+                 void *dw, void *db) {
+    if (!(dtype == ORC_F32 || dtype == ORC_F16 || dtype == ORC_BF16) || (kind != 0 && kind != 1)) return 1;
+    const int es = dt_size(dtype);
+    double *sw = (double *)calloc((size_t)cols, sizeof(double)), *sb = (double *)calloc((size_t)cols, sizeof(double));
+    if (!sw || !sb) { free(sw); free(sb); return 2; }
+    for (int64_t r = 0; r < rows; ++r) {
+        const char *xr = (const char *)x + r * cols * es, *gr = (const char *)dy + r * cols * es;
+        double s = 0.0, mean = 0.0, q = 0.0;
+        if (kind == 1) {
+            for (int64_t c = 0; c < cols; ++c) s += ld_d(dtype, xr + c * es);
+            mean = s / (double)cols;
+        }
+        for (int64_t c = 0; c < cols; ++c) { const double d = ld_d(dtype, xr + c * es) - mean; q += d * d; }
+        const double rstd = 1.0 / sqrt(q / (double)cols + eps);
+        double s1 = 0.0, s2 = 0.0;
+        for (int64_t c = 0; c < cols; ++c) {
+            const double d = ld_d(dtype, gr + c * es), xh = (ld_d(dtype, xr + c * es) - mean) * rstd;
+            const double g = d * (w ? ld_d(dtype, (const char *)w + c * es) : 1.0);
+            s1 += g;
+            s2 += g * xh;
+            sw[c] += d * xh;
+            sb[c] += d;
+        }
+        s1 = kind == 1 ? s1 / (double)cols : 0.0;
+        s2 /= (double)cols;
+        for (int64_t c = 0; c < cols; ++c) {
+            const double d = ld_d(dtype, gr + c * es), xh = (ld_d(dtype, xr + c * es) - mean) * rstd;
+            const double g = d * (w ? ld_d(dtype, (const char *)w + c * es) : 1.0);
+            st_d(dtype, (char *)dx + (r * cols + c) * es, rstd * (g - s1 - xh * s2));
+        }
+    }
+    for (int64_t c = 0; c < cols; ++c) {
+        if (dw) st_d(dtype, (char *)dw + c * es, sw[c]);
+        if (db) st_d(dtype, (char *)db + c * es, sb[c]);
+    }
+    free(sw);
+    free(sb);
+    return 0;
+}
+
+/* embedding gather (README.md:30 roadmap "embedding"; the read side of tensor_index.h:56-104's index arithmetic):
+ * out[n, :] = table[wrap(idx[n]), :], negative indices wrap once, rows of row_bytes bytes (bit-exact byte copy) */
+int orc_index_get(const void *table, int64_t nrows, int64_t row_bytes, const int64_t *idx, int64_t n, void *out) {
+    for (int64_t i = 0; i < n; ++i) {
+        int64_t r = idx[i];
+        if (r < 0) r += nrows;
+        if (r < 0 || r >= nrows) return 1;
+        memcpy((char *)out + i * row_bytes, (const char *)table + r * row_bytes, (size_t)row_bytes);
+    }
+    return 0;
+}
+
 int orc_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

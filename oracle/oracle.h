@@ -57,6 +57,14 @@ int orc_attn_fwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64
 /* closed-form softmax-Jacobian backward of the above (no reference counterpart) */
 int orc_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, const void *q, const void *k,
                  const void *v, const void *d_o, void *dq, void *dk, void *dv);
+/* rms_norm / layer_norm rows (README.md:28 roadmap item; invstd = 1 / sqrt(M2 / n + eps) as welford_norm.h:170-187); double
+ * arithmetic on the dtype-rounded inputs, x / y / dy / dx contiguous [rows, cols]; kind 0 = rms, 1 = layer */
+int orc_norm_fwd(int kind, int dtype, int64_t rows, int64_t cols, const void *x, const void *w, const void *b, double eps, void *y,
+                 float *mean_out, float *rstd_out);
+int orc_norm_bwd(int kind, int dtype, int64_t rows, int64_t cols, const void *x, const void *w, double eps, const void *dy, void *dx,
+                 void *dw, void *db);
+/* embedding gather (README.md:30): out[n,:] = table[wrap(idx[n]),:], byte copy of rows */
+int orc_index_get(const void *table, int64_t nrows, int64_t row_bytes, const int64_t *idx, int64_t n, void *out);
 /* half.h:150-208 conversions, exposed for the fixtures */
 float orc_bf16_to_f32(uint16_t v);
 uint16_t orc_f32_to_bf16(float f);

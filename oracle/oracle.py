@@ -221,6 +221,55 @@ def attn_bwd(q, k, v, d_o, code=None):
     return dq, dk, dv
 
 
+RMS, LAYER = 0, 1
+
+
+def norm_fwd(kind, x, w=None, b=None, eps=1e-5, code=None):
+    """rows = all leading dims flattened; returns (y, mean[rows] f32, rstd[rows] f32)."""
+    cd = code_of(x, code)
+    x = np.ascontiguousarray(x)
+    cols = x.shape[-1]
+    rows = x.size // cols
+    y = np.empty_like(x)
+    mean, rstd = np.zeros(rows, np.float32), np.zeros(rows, np.float32)
+    f = lib().orc_norm_fwd
+    f.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    p = lambda a: None if a is None else np.ascontiguousarray(a).ctypes.data  # noqa: E731
+    keep = [None if a is None else np.ascontiguousarray(a) for a in (w, b)]
+    _check(f(kind, cd, rows, cols, x.ctypes.data, p(keep[0]), p(keep[1]), float(eps), y.ctypes.data, mean.ctypes.data, rstd.ctypes.data), "norm_fwd")
+    return y, mean, rstd
+
+
+def norm_bwd(kind, x, w, dy, eps=1e-5, code=None, want_db=True):
+    """(dx, dw, db) of norm_fwd; db is None for rms."""
+    cd = code_of(x, code)
+    x, dy = np.ascontiguousarray(x), np.ascontiguousarray(dy)
+    cols = x.shape[-1]
+    rows = x.size // cols
+    dx = np.empty_like(x)
+    dw = np.empty(cols, dtype=x.dtype)
+    db = np.empty(cols, dtype=x.dtype) if (kind == LAYER and want_db) else None
+    wk = None if w is None else np.ascontiguousarray(w)
+    f = lib().orc_norm_bwd
+    f.argtypes = [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_double] + [C.c_void_p] * 4
+    _check(f(kind, cd, rows, cols, x.ctypes.data, None if wk is None else wk.ctypes.data, float(eps), dy.ctypes.data, dx.ctypes.data,
+             dw.ctypes.data, None if db is None else db.ctypes.data), "norm_bwd")
+    return dx, dw, db
+
+
+def index_get(table, idx):
+    """out[n, :] = table[wrap(idx[n]), :] (embedding gather), any dtype: rows are copied as bytes."""
+    table = np.ascontiguousarray(table)
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    nrows = table.shape[0]
+    row_bytes = table.nbytes // max(nrows, 1)
+    out = np.empty(idx.shape + table.shape[1:], dtype=table.dtype)
+    f = lib().orc_index_get
+    f.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+    _check(f(table.ctypes.data, nrows, row_bytes, idx.ctypes.data, idx.size, out.ctypes.data), "index_get")
+    return out
+
+
 def num_threads() -> int:
     return lib().orc_num_threads()
 

@@ -271,9 +271,33 @@ def sort():
     np.savez_compressed(OUT / "sort.npz", **d)
 
 
+def norms():
+    """rms_norm / layer_norm (README.md:28 roadmap item; no reference test exists): torch-CPU F.rms_norm / F.layer_norm in float64
+    on seeded f32 inputs, forward + autograd backward. Shapes: one wave per row (cols 64..1024), one block per row (4096), a
+    ragged row length (331: generic kernel) and a 3-D input (leading dims flatten into rows)."""
+    d = {}
+    for i, shp in enumerate(((37, 64), (5, 7, 256), (16, 1024), (5, 4096), (23, 331))):
+        rng = np.random.default_rng(130 + i)
+        x, g = uni(rng, shp, lo=-3, hi=3), uni(rng, shp, lo=-1, hi=1)
+        w, b = uni(rng, shp[-1:], lo=0.5, hi=1.5), uni(rng, shp[-1:], lo=-1, hi=1)
+        d[f"n{i}_x"], d[f"n{i}_g"], d[f"n{i}_w"], d[f"n{i}_b"] = x, g, w, b
+        for kind in ("rms", "layer"):
+            tx, tw, tb = (torch.from_numpy(a).double().requires_grad_() for a in (x, w, b))
+            if kind == "rms":
+                y = F.rms_norm(tx, (shp[-1],), tw, eps=1e-5)
+            else:
+                y = F.layer_norm(tx, (shp[-1],), tw, tb, eps=1e-5)
+            y.backward(torch.from_numpy(g).double())
+            f32 = lambda t: t.detach().numpy().astype(np.float32)  # noqa: E731  (evaluated in f64, stored in f32: 6e-8 relative)
+            d[f"n{i}_{kind}_y"], d[f"n{i}_{kind}_dx"], d[f"n{i}_{kind}_dw"] = f32(y), f32(tx.grad), f32(tw.grad)
+            if kind == "layer":
+                d[f"n{i}_layer_db"] = f32(tb.grad)
+    np.savez_compressed(OUT / "norms.npz", **d)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
-    for f in (elementwise, shape_ops, reductions, moments, gemm, attention, sort):
+    for f in (elementwise, shape_ops, reductions, moments, gemm, attention, sort, norms):
         if len(sys.argv) > 1 and f.__name__ not in sys.argv[1:]:
             continue
         f()

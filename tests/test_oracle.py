@@ -234,3 +234,30 @@ def test_sort_key_order_special_values():
     assert i[0].tolist() == [0, 1, 2, 3, 4, 5, 6, 7]
     with pytest.raises(ValueError):
         O.sort_key(np.zeros(3, np.bool_))
+
+
+def test_norms_vs_torch_fixtures():
+    """rms_norm / layer_norm forward + backward of the oracle against torch-CPU F.rms_norm / F.layer_norm + autograd (float64)
+    on the committed fixtures (tests/golden/gen_golden.py: norms)."""
+    g = golden("norms")
+    for i in range(5):
+        x, go, w, b = g[f"n{i}_x"], g[f"n{i}_g"], g[f"n{i}_w"], g[f"n{i}_b"]
+        for kind, name in ((O.RMS, "rms"), (O.LAYER, "layer")):
+            y, mean, rstd = O.norm_fwd(kind, x, w, b if kind == O.LAYER else None, eps=1e-5)
+            assert_close(y, g[f"n{i}_{name}_y"], rtol=1e-5, atol=1e-5, what=f"{name} fwd {i}")
+            dx, dw, db = O.norm_bwd(kind, x, w, go, eps=1e-5)
+            assert_close(dx, g[f"n{i}_{name}_dx"], rtol=1e-4, atol=1e-5, what=f"{name} dx {i}")
+            assert_close(dw, g[f"n{i}_{name}_dw"], rtol=1e-4, atol=1e-4, what=f"{name} dw {i}")
+            if kind == O.LAYER:
+                assert_close(db, g[f"n{i}_layer_db"], rtol=1e-4, atol=1e-4, what=f"db {i}")
+                x2 = x.reshape(-1, x.shape[-1]).astype(np.float64)
+                assert_close(mean, x2.mean(1), rtol=1e-5, atol=1e-6, what="mean")
+                assert_close(rstd, 1.0 / np.sqrt(x2.var(1) + 1e-5), rtol=1e-5, atol=1e-6, what="rstd")
+
+
+def test_index_get_is_numpy_take():
+    rng = np.random.default_rng(140)
+    for dt in (np.float32, np.uint16, np.int64, np.uint8):
+        table = rng.integers(0, 200, size=(50, 24)).astype(dt)
+        idx = rng.integers(-50, 50, size=(7, 9))
+        assert np.array_equal(O.index_get(table, idx), table[idx])
