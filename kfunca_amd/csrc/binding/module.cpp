@@ -51,6 +51,9 @@ py::array to_numpy(const Tensor &t) {
     case ScalarType::Half: np = "float16"; break;
     case ScalarType::Float: np = "float32"; break;
     case ScalarType::Double: np = "float64"; break;
+    // numpy has no bfloat16: the raw bits come back as uint16 (x.view(np.uint32) << 16 is the f32 value; ml_dtypes users can
+    // .view(ml_dtypes.bfloat16)). The reference's to_numpy rejects half and bfloat16 altogether (register.cpp:41-57).
+    case ScalarType::BFloat16: np = "uint16"; break;
     default: throw std::runtime_error("Unsupported dtype in to_numpy()");
     }
     py::array out(py::dtype(np), t.sizes());
@@ -255,6 +258,22 @@ PYBIND11_MODULE(_C, m) {
     m.def("to_numpy", &to_numpy);
     m.def("zeros", [](std::vector<int64_t> shape, ScalarType dtype, int device) { return zeros(shape, dtype, device); });
     m.def("causal_attention", &gpu::causal_attention);
+    // the reference's roadmap operators (README.md:28-30)
+    m.def("rms_norm", [](const Tensor &x, py::object w, double eps) { return gpu::rms_norm(x, w.is_none() ? Tensor() : w.cast<Tensor>(), eps); },
+          py::arg("x"), py::arg("weight") = py::none(), py::arg("eps") = 1e-5);
+    m.def("layer_norm", [](const Tensor &x, py::object w, py::object b, double eps) {
+        return gpu::layer_norm(x, w.is_none() ? Tensor() : w.cast<Tensor>(), b.is_none() ? Tensor() : b.cast<Tensor>(), eps);
+    }, py::arg("x"), py::arg("weight") = py::none(), py::arg("bias") = py::none(), py::arg("eps") = 1e-5);
+    m.def("embedding", &gpu::embedding, py::arg("table"), py::arg("indices"));
+    // from_numpy for bfloat16: uint16 bit patterns in, a BFloat16 tensor out (the inverse of to_numpy's uint16 view)
+    m.def("from_numpy_bf16", [](py::array array, int device) {
+        CHECK_FAIL(array.dtype().kind() == 'u' && array.dtype().itemsize() == 2, "from_numpy_bf16 expects uint16 bit patterns");
+        py::array c = py::array::ensure(array, py::array::c_style);
+        std::vector<int64_t> shape(c.shape(), c.shape() + c.ndim());
+        Tensor out = empty(shape, ScalarType::BFloat16, device);
+        if (out.numel() > 0) out.copy_from_cpu_ptr(const_cast<void *>(c.data()));
+        return out;
+    }, py::arg("array"), py::arg("device") = 0);
     m.def("gemm", &gpu::gemm);
     m.def("cat", &gpu::concat);
     m.def("_iter_geometry", &iter_geometry, py::arg("outputs"), py::arg("inputs"), py::arg("is_reduction") = false,

@@ -660,6 +660,120 @@ Tensor &index_put_(Tensor &self, const std::vector<Tensor> &indices, const Tenso
     return self;
 }
 
+// ---- rms_norm / layer_norm (README.md:28; statistics as norm_ops_kernel.cu:6-61 / welford_norm.h:170-187) ---------------------
+namespace {
+bool norm_dtype_ok(ScalarType t) { return t == ScalarType::Float || t == ScalarType::Half || t == ScalarType::BFloat16; }
+
+// saved for the backward: x, weight, and the forward's f32 statistics
+class NormGradFunction : public GradFunction {
+public:
+    NormGradFunction(int kind, const Tensor &x, const Tensor &w, const Tensor &b, const Tensor &mean, const Tensor &rstd)
+        : kind_(kind), has_w_(w.defined()), has_b_(b.defined()), mean_(mean), rstd_(rstd) {
+        inputs = {x};
+        if (has_w_) inputs.push_back(w);
+        if (has_b_) inputs.push_back(b);
+    }
+    std::vector<Tensor> backward(Tensor g) override {
+        const Tensor &x = inputs[0];
+        const int64_t cols = x.shape(-1), rows = x.numel() / cols;
+        Tensor gc = g.contiguous();
+        Tensor dx = empty(x.sizes(), x.dtype(), x.device());
+        Tensor dw, db;
+        const bool want_w = has_w_ && inputs[1].requires_grad(), want_b = has_b_ && inputs[has_w_ ? 2 : 1].requires_grad();
+        if (want_w || want_b) dw = empty({cols}, x.dtype(), x.device()); // the kernel produces both sums in one sweep
+        if (want_b) db = empty({cols}, x.dtype(), x.device());
+        size_t need = 0;
+        DEV_CALL(kf_norm_bwd_workspace_bytes(kind_, code(x.dtype()), rows, cols, cols, &need));
+        DataPtr scratch;
+        if (need && dw.defined()) scratch = DeviceAllocator::GetInstance()->allocate(need, x.device());
+        DEV_CALL(kf_norm_bwd(kind_, code(x.dtype()), rows, cols, cols, x.data_ptr(), has_w_ ? inputs[1].data_ptr() : nullptr,
+                             kind_ == KF_NORM_LAYER ? static_cast<const float *>(mean_.data_ptr()) : nullptr,
+                             static_cast<const float *>(rstd_.data_ptr()), gc.data_ptr(), dx.data_ptr(), dw.defined() ? dw.data_ptr() : nullptr,
+                             db.defined() ? db.data_ptr() : nullptr, scratch.get(), dw.defined() ? need : 0, dev::stream(x.device())));
+        std::vector<Tensor> out(inputs.size());
+        if (x.requires_grad()) out[0] = dx;
+        if (want_w) out[1] = dw;
+        if (want_b) out[has_w_ ? 2 : 1] = db;
+        return out;
+    }
+
+private:
+    int kind_;
+    bool has_w_, has_b_;
+    Tensor mean_, rstd_;
+};
+
+Tensor norm_impl(int kind, const Tensor &x, const Tensor &w, const Tensor &b, double eps) {
+    CHECK_FAIL(x.defined() && x.dim() >= 1 && x.is_contiguous(), "norm expects a contiguous tensor");
+    CHECK_FAIL(norm_dtype_ok(x.dtype()), "norm supports float, half and bfloat16");
+    const int64_t cols = x.shape(-1);
+    CHECK_FAIL(cols > 0);
+    const int64_t rows = x.numel() / cols;
+    for (const Tensor *p : {&w, &b})
+        if (p->defined()) CHECK_FAIL(p->dim() == 1 && p->shape(0) == cols && p->dtype() == x.dtype() && p->is_contiguous() && p->device() == x.device(),
+                                     "norm weight / bias must be contiguous 1-D tensors of the normalised length and of x's dtype");
+    Tensor y = empty(x.sizes(), x.dtype(), x.device());
+    const bool grad = x.requires_grad() || (w.defined() && w.requires_grad()) || (b.defined() && b.requires_grad());
+    Tensor mean, rstd;
+    if (grad) {
+        rstd = empty({rows}, ScalarType::Float, x.device());
+        if (kind == KF_NORM_LAYER) mean = empty({rows}, ScalarType::Float, x.device());
+    }
+    DEV_CALL(kf_norm_fwd(kind, code(x.dtype()), rows, cols, cols, x.data_ptr(), w.defined() ? w.data_ptr() : nullptr,
+                         b.defined() ? b.data_ptr() : nullptr, eps, y.data_ptr(), mean.defined() ? static_cast<float *>(mean.data_ptr()) : nullptr,
+                         rstd.defined() ? static_cast<float *>(rstd.data_ptr()) : nullptr, dev::stream(x.device())));
+    if (grad) {
+        y.set_requires_grad(true);
+        y.set_grad_fn(new NormGradFunction(kind, x, w, b, mean, rstd));
+    }
+    return y;
+}
+} // namespace
+
+Tensor rms_norm(const Tensor &x, const Tensor &weight, double eps) { return norm_impl(KF_NORM_RMS, x, weight, Tensor(), eps); }
+Tensor layer_norm(const Tensor &x, const Tensor &weight, const Tensor &bias, double eps) { return norm_impl(KF_NORM_LAYER, x, weight, bias, eps); }
+
+// ---- embedding (README.md:30; index arithmetic of tensor_index.h:56-104) -------------------------------------------------------
+namespace {
+class EmbeddingGradFunction : public GradFunction { // dTable[r] = sum of the gradient rows gathered from r, in input order
+public:
+    EmbeddingGradFunction(const Tensor &table, const Tensor &indices) : indices_(indices) { inputs = {table}; }
+    std::vector<Tensor> backward(Tensor g) override {
+        const Tensor &table = inputs[0];
+        const int64_t nrows = table.shape(0), cols = table.shape(1), n = indices_.numel();
+        Tensor gc = g.contiguous();
+        Tensor dt = zeros(table.sizes(), table.dtype(), table.device());
+        const size_t need = kf_index_add_workspace_bytes(n);
+        DataPtr scratch;
+        if (need) scratch = DeviceAllocator::GetInstance()->allocate(need, table.device());
+        DEV_CALL(kf_index_add(code(table.dtype()), static_cast<const int64_t *>(indices_.data_ptr()), n, gc.data_ptr(), cols, nrows,
+                              dt.data_ptr(), scratch.get(), need, dev::stream(table.device())));
+        return {dt};
+    }
+
+private:
+    Tensor indices_;
+};
+} // namespace
+
+Tensor embedding(const Tensor &table, const Tensor &indices) {
+    CHECK_FAIL(table.defined() && table.dim() == 2 && table.is_contiguous(), "embedding expects a contiguous 2-D table");
+    CHECK_FAIL(indices.defined() && indices.dtype() == ScalarType::Long, "Indices must be of type Long.");
+    CHECK_FAIL(indices.device() == table.device());
+    Tensor ix = indices.contiguous();
+    auto shape = ix.sizes();
+    shape.push_back(table.shape(1));
+    Tensor out = empty(shape, table.dtype(), table.device());
+    DEV_CALL(kf_index_get(table.data_ptr(), table.shape(0), table.shape(1) * table.element_size_in_bytes(),
+                          static_cast<const int64_t *>(ix.data_ptr()), ix.numel(), out.data_ptr(), dev::stream(table.device())));
+    if (table.requires_grad()) {
+        CHECK_FAIL(norm_dtype_ok(table.dtype()), "embedding backward supports float, half and bfloat16 tables");
+        out.set_requires_grad(true);
+        out.set_grad_fn(new EmbeddingGradFunction(table, ix));
+    }
+    return out;
+}
+
 // ---- shape ops (tensor_shape.cpp:41-89) ----------------------------------------------------------------------------
 namespace {
 class CatGradFunction : public GradFunction { // each input's gradient is its window of g

@@ -55,6 +55,13 @@ std::tuple<Tensor, Tensor> norm_stat(const Tensor &self, int64_t dim);
 std::tuple<Tensor, Tensor> sort(const Tensor &self, int64_t dim, bool descending);
 std::tuple<Tensor, Tensor> topk(const Tensor &self, int64_t k, int64_t dim, bool largest);
 
+// The reference's roadmap operators (README.md:28-32), finished on its building blocks; all carry autograd.
+//   rms_norm / layer_norm: normalise the LAST dim (weight / bias: 1-D of that length, may be undefined), statistics in f32
+//   embedding: out[..., :] = table[indices[...], :] (indices Long, negative ones wrap; table 2-D)
+Tensor rms_norm(const Tensor &x, const Tensor &weight, double eps);
+Tensor layer_norm(const Tensor &x, const Tensor &weight, const Tensor &bias, double eps);
+Tensor embedding(const Tensor &table, const Tensor &indices);
+
 // extensions used by the backward passes (no reference counterpart)
 Tensor gemm_ex(const Tensor &a, bool trans_a, const Tensor &b, bool trans_b, float alpha);
 std::tuple<Tensor, Tensor> causal_attention_fwd(const Tensor &q, const Tensor &k, const Tensor &v); // (out, lse)
