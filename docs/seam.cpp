@@ -1,0 +1,212 @@
+// docs/seam.cpp - the reference's device seam (src/device/include/*.h), implemented over include/kfunca_hip.h.
+//
+// This is the ONE translation unit a kfunca maintainer adds (as src/device_hip/seam.cpp) to put the MI355X device library
+// behind the unchanged host core: build src/core as before, compile this file with the host compiler, link -lkfunca_hip
+// instead of building src/device/*.cu. It includes ONLY reference headers + the C ABI, and every function below is the
+// definition of a declaration in src/device/include/ (cited per function).
+//
+// It is compiled - syntax and types, against the real reference headers - by tests/test_seam_compiles.py whenever the reference
+// tree is mounted (build container): g++ -std=c++20 -fsyntax-only -I src/core/include -I src/core/utils{,/memory}
+// -I src/device/include. Nothing from the reference is copied into this repository; the file is documentation that type-checks.
+#include <cmath>
+#include <tuple>
+#include <vector>
+
+#include "kfunca_hip.h" // the C ABI (this repository's include/)
+
+#include "tensor_iterator.h" // reference: src/core/include (Tensor, TensorIterator, DeviceAllocator, CHECK_FAIL, any_t)
+
+#include "binary_ops_kernel.h" // reference: src/device/include - the declarations defined below
+#include "causal_attention_kernel.h"
+#include "gemm_kernel.h"
+#include "index_ops_kernel.h"
+#include "memory_engine.h"
+#include "norm_ops_kernel.h"
+#include "nullary_ops_kernel.h"
+#include "reduce_ops_kernel.h"
+#include "sort_ops_kernel.h"
+#include "unary_ops_kernel.h"
+
+namespace {
+
+void check(int rc) { CHECK_FAIL(rc == KF_OK, kf_last_error()); } // status -> the reference's utils::Error (exception.h:123-131)
+
+// the reference launches on the legacy default stream (launcher_cuda.h:315-353); NULL = the device's null stream
+void *const kStream = nullptr;
+
+// post-build() TensorIterator state (tensor_iterator.h:27-47) -> the POD the C ABI takes
+kf_iter_desc to_desc(const TensorIterator &it) {
+    kf_iter_desc d{};
+    d.ndim = it.ndim();
+    d.ntensors = it.ntensors();
+    d.noutputs = it.noutputs();
+    for (int i = 0; i < it.ndim(); ++i) d.shape[i] = it.shape(i);
+    for (int t = 0; t < it.ntensors(); ++t) {
+        d.dtype[t] = static_cast<int>(it.dtype(t)); // ScalarType order == KF_* codes (scalar_type.h:9-27)
+        d.data[t] = it.data_ptr(t);
+        for (int i = 0; i < it.ndim(); ++i) d.stride_bytes[t][i] = it.stride_bytes(t, i);
+    }
+    return d;
+}
+
+// gpu_kernel's outer loop (tensor_loops.h:357-369): 32-bit-indexable pieces, one launch each
+template <typename F>
+void for_each_piece(TensorIterator &it, F &&launch) {
+    if (it.numel() == 0) return;
+    if (it.can_use_32bit_indexing()) {
+        launch(it);
+        return;
+    }
+    for (auto &sub : it.with_32bit_indexing()) launch(sub);
+}
+
+void elementwise(TensorIterator &it, int op, int compute_dtype, double scalar) {
+    for_each_piece(it, [&](TensorIterator &piece) {
+        kf_iter_desc d = to_desc(piece);
+        check(kf_elementwise(op, &d, compute_dtype, scalar, kStream));
+    });
+}
+
+// caller-owned scratch from the host allocator (the reference's device layer calls back into it, tensor_reduce.h:1057-1058)
+struct Scratch {
+    DataPtr block;
+    void *ptr = nullptr;
+    Scratch(size_t bytes, int device) {
+        if (bytes) {
+            block = DeviceAllocator::GetInstance()->allocate(bytes, device);
+            ptr = block.get();
+        }
+    }
+};
+
+void reduce(TensorIterator &it, int op) {
+    if (it.num_output_elements() == 0) return;
+    kf_iter_desc d = to_desc(it);
+    size_t need = 0;
+    check(kf_reduce_workspace_bytes(&d, &need));
+    Scratch ws(need, it.device(0));
+    check(kf_reduce(op, &d, ws.ptr, need, kStream));
+}
+
+} // namespace
+
+// ---- memory_engine.h:5-10 ------------------------------------------------------------------------------------------------
+void dset_device(const int device) { check(kf_set_device(device)); }
+void *dmalloc(const size_t size) {
+    void *p = nullptr;
+    check(kf_malloc(&p, size));
+    return p;
+}
+void dfree(void *ptr) { check(kf_free(ptr)); }
+void dmemcpy_h2d(void *dst, const void *src, const size_t size) { check(kf_memcpy_h2d(dst, src, size, kStream)); }
+void dmemcpy_d2h(void *dst, const void *src, const size_t size) { check(kf_memcpy_d2h(dst, src, size, kStream)); }
+void dmemset_zeros(void *ptr, const size_t size) {
+    check(kf_memset_zero(ptr, size, kStream));
+    check(kf_stream_sync(kStream)); // the reference's memset returns synchronised (launcher_cuda.h:196-202)
+}
+
+// ---- binary_ops_kernel.h:5-8: arithmetic runs in the common dtype's accumulate type (binary_ops_kernel.cu:34-60) ----------
+void add_kernel(TensorIterator &iter) { elementwise(iter, KF_EW_ADD, static_cast<int>(iter.common_dtype()), 0.0); }
+void sub_kernel(TensorIterator &iter) { elementwise(iter, KF_EW_SUB, static_cast<int>(iter.common_dtype()), 0.0); }
+void mul_kernel(TensorIterator &iter) { elementwise(iter, KF_EW_MUL, static_cast<int>(iter.common_dtype()), 0.0); }
+void div_kernel(TensorIterator &iter) { elementwise(iter, KF_EW_DIV, static_cast<int>(iter.common_dtype()), 0.0); }
+
+// ---- unary_ops_kernel.h:5, nullary_ops_kernel.h:5 -------------------------------------------------------------------------
+void copy_kernel(TensorIterator &iter) { elementwise(iter, KF_EW_COPY, 0, 0.0); }
+void fill_kernel(TensorIterator &iter, const any_t &value) { elementwise(iter, KF_EW_FILL, 0, static_cast<double>(value)); }
+
+// ---- reduce_ops_kernel.h:5-7 ----------------------------------------------------------------------------------------------
+void sum_kernel(TensorIterator &iter) { reduce(iter, KF_RED_SUM); }
+void mean_kernel(TensorIterator &iter) { reduce(iter, KF_RED_MEAN); }
+void mean_var_kernel(TensorIterator &iter, double correction, bool take_sqrt) {
+    if (iter.num_output_elements() == 0) return;
+    kf_iter_desc d = to_desc(iter); // outputs (var | std, mean), then the input: reduce_ops.cpp:24-25
+    size_t need = 0;
+    check(kf_reduce_moments_workspace_bytes(&d, &need));
+    Scratch ws(need, iter.device(0));
+    check(kf_reduce_moments(take_sqrt ? KF_MOM_STD : KF_MOM_VAR, &d, correction, 0.0, ws.ptr, need, kStream));
+}
+
+// ---- norm_ops_kernel.h:5: mean and invstd over dim 0 of a 2-D tensor, eps = 1e-12 (norm_ops_kernel.cu:6-61) ---------------
+std::tuple<Tensor, Tensor> norm_stat_kernel(const Tensor &self, const int dim) {
+    CHECK_FAIL(self.defined());
+    CHECK_FAIL(dim == 0 && self.dim() == 2);
+    Tensor invstd, mean;
+    auto iter = TensorIterator().add_output(invstd).add_output(mean).add_input(self).build_for_reduce(dim);
+    if (iter.num_output_elements() != 0) {
+        kf_iter_desc d = to_desc(iter);
+        size_t need = 0;
+        check(kf_reduce_moments_workspace_bytes(&d, &need));
+        Scratch ws(need, self.device());
+        check(kf_reduce_moments(KF_MOM_INVSTD, &d, 0.0, 1e-12, ws.ptr, need, kStream));
+    }
+    return std::make_tuple(mean, invstd);
+}
+
+// ---- index_ops_kernel.h:5 -------------------------------------------------------------------------------------------------
+void index_put_kernel(TensorIterator &iter, const std::vector<int64_t> index_size, const std::vector<int64_t> index_stride) {
+    for_each_piece(iter, [&](TensorIterator &piece) {
+        kf_iter_desc d = to_desc(piece);
+        check(kf_index_put(&d, static_cast<int>(index_size.size()), index_size.data(), index_stride.data(), kStream));
+    });
+}
+
+// ---- gemm_kernel.h:5 (argument checks as gemm_kernel.cu:8-25) -------------------------------------------------------------
+void gemm_kernel(Tensor &out, const Tensor &a, const Tensor &b, float alpha, float beta) {
+    CHECK_FAIL(out.is_contiguous() && a.is_contiguous() && b.is_contiguous());
+    CHECK_FAIL(b.dim() == 2 && a.dim() >= 1 && a.dtype() == b.dtype() && out.dtype() == a.dtype());
+    const int64_t k = a.shape(a.dim() - 1), m = a.numel() / k, n = b.shape(1);
+    CHECK_FAIL(b.shape(0) == k && out.numel() == m * n);
+    size_t need = 0;
+    check(kf_gemm_workspace_bytes(static_cast<int>(a.dtype()), 0, 0, m, n, k, &need));
+    Scratch ws(need, a.device());
+    check(kf_gemm(static_cast<int>(a.dtype()), 0, 0, m, n, k, alpha, a.data_ptr(), k, b.data_ptr(), n, beta, out.data_ptr(), n, KF_EPI_NONE,
+                  nullptr, ws.ptr, need, kStream));
+}
+
+// ---- causal_attention_kernel.h:5 (checks as causal_attention_kernel.cu:9-20; no S x S scratch, no discarded m / l) ----------
+Tensor causal_attention_kernel(const Tensor &q, const Tensor &k, const Tensor &v) {
+    CHECK_FAIL(q.dim() == 4 && k.dim() == 4 && v.dim() == 4);
+    CHECK_FAIL(q.is_contiguous() && k.is_contiguous() && v.is_contiguous());
+    CHECK_FAIL(q.dtype() == k.dtype() && q.dtype() == v.dtype());
+    Tensor out = empty_like(q);
+    check(kf_attn_fwd(static_cast<int>(q.dtype()), q.shape(0), q.shape(1), q.shape(2), k.shape(2), q.shape(3), q.data_ptr(), k.data_ptr(),
+                      v.data_ptr(), out.data_ptr(), /*lse*/ nullptr, kStream));
+    return out;
+}
+
+// ---- sort_ops_kernel.h:5-14: the device half is one stable segmented sort of dim-last rows; the dense dim-last copy and the
+//      copy back stay host logic, written here with the reference's own view ops -----------------------------------------------
+std::tuple<Tensor, Tensor> sort_stable_kernel(const Tensor &self, int64_t dim, bool descending) {
+    const int d = maybe_wrap_dim(static_cast<int>(dim), self.dim());
+    CHECK_FAIL(self.dtype() != ScalarType::Bool, "Sort currently does not support bool dtypes.");
+    const int64_t n = self.shape(d);
+    CHECK_FAIL(n <= std::numeric_limits<int>::max(), "The dimension being sorted can not have more than INT_MAX elements.");
+    // bring the sorted dim last, dense
+    std::vector<int64_t> perm, inverse(self.dim());
+    for (int i = 0; i < self.dim(); ++i)
+        if (i != d) perm.push_back(i);
+    perm.push_back(d);
+    for (int i = 0; i < self.dim(); ++i) inverse[perm[i]] = i;
+    Tensor keys = self.permute(perm).contiguous();
+    Tensor values = empty(keys.sizes(), self.dtype(), self.device());
+    Tensor positions = empty(keys.sizes(), ScalarType::Long, self.device());
+    if (self.numel() > 0) {
+        const int64_t nseg = self.numel() / n;
+        const size_t need = kf_sort_workspace_bytes(static_cast<int>(self.dtype()), nseg, n);
+        Scratch ws(need, self.device());
+        check(kf_sort(static_cast<int>(self.dtype()), keys.data_ptr(), values.data_ptr(), static_cast<int64_t *>(positions.data_ptr()), nseg, n,
+                      descending ? 1 : 0, ws.ptr, need, kStream));
+    }
+    // back to self's dim order (views; contiguous() materialises them like the reference's copy back)
+    return std::make_tuple(values.permute(inverse).contiguous(), positions.permute(inverse).contiguous());
+}
+
+std::tuple<Tensor, Tensor> topk_with_sort(const Tensor &self, int64_t k, int64_t dim, bool largest) {
+    const int d = maybe_wrap_dim(static_cast<int>(dim), self.dim());
+    auto sorted = sort_stable_kernel(self, d, largest);
+    return std::make_tuple(std::get<0>(sorted).narrow(d, 0, k).contiguous(), std::get<1>(sorted).narrow(d, 0, k).contiguous());
+}
+
+// device_info.h:5 (void device_info(): prints device properties and two microbenchmarks) is out of the hot path's scope
+// (SURVEY.md section 2 #27); its query half is kf_device_props_get.
