@@ -311,6 +311,29 @@ int kf_attn_bwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv,
                        const void *k, const void *v, const void *o, const float *lse, const void *d_o, void *dq,
                        void *dk, void *dv, void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * The same two entries for tensors that are NOT contiguous [B,H,S,D]: each operand comes with the ELEMENT strides of its batch,
+ * head and row dims (the head dim D itself is contiguous). This is what removes the layout copies around attention in a
+ * transformer block (the reference's roadmap item qkv_linear, README.md:32): q, k, v are read in place from the packed
+ * [B*S, 3*H*D] output of the QKV projection (batch = S*3*H*D, head = D, row = 3*H*D, bases offset by H*D), o is written
+ * as [B*S, H*D] - the layout the output projection consumes - and the backward writes dq, dk, dv straight into a packed
+ * [B*S, 3*H*D] gradient. Contiguous [B,H,S,D] is {H*S*D, S*D, D}. lse stays [B,H,Sq] contiguous f32.
+ * 16-bit matrix-core path only (dtype KF_BF16 / KF_F16, D = 128, Sq and Skv multiples of 128; KF_ERR_UNSUPPORTED otherwise:
+ * make contiguous copies and call the plain entries). Strides are multiples of 8 elements, operands 16-byte aligned.
+ * Workspace as kf_attn_bwd_workspace_bytes().
+ */
+typedef struct kf_attn_layout {
+    int64_t batch, head, row; /* element strides of dims B, H, S */
+} kf_attn_layout;
+int kf_attn_fwd_strided(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, float scale, const void *q,
+                        const kf_attn_layout *lq, const void *k, const kf_attn_layout *lk, const void *v, const kf_attn_layout *lv,
+                        void *o, const kf_attn_layout *lo, float *lse, void *stream);
+int kf_attn_bwd_strided(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, float scale, const void *q,
+                        const kf_attn_layout *lq, const void *k, const kf_attn_layout *lk, const void *v, const kf_attn_layout *lv,
+                        const void *o, const kf_attn_layout *lo, const float *lse, const void *d_o, const kf_attn_layout *ldo, void *dq,
+                        const kf_attn_layout *ldq, void *dk, const kf_attn_layout *ldk, void *dv, const kf_attn_layout *ldv,
+                        void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- collectives (RCCL over xGMI): the one exchange step of the batch-sharded path (§8e) ---- */
 #define KF_COMM_ID_BYTES 128
 int kf_comm_unique_id(char id[KF_COMM_ID_BYTES]);

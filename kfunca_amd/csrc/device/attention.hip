@@ -54,6 +54,9 @@ struct AttnArgs {
     float defer; // forward: adopt a new running maximum only beyond this many exponent units (kDeferMax; -inf: always)
     int persist;     // k > 0: a workgroup handles k pairs {block x, its causal mirror}: equal work per workgroup (k = 1 is used)
     int persist_rev; // the short block of a pair first
+    // global layouts of the 16-bit matrix-core path: byte strides of batch, head and row (the last dim is contiguous). Contiguous
+    // [B,H,S,D] tensors: {H S 256, S 256, 256}; q / k / v living inside one packed [B S, 3 H D] projection: {S 3 H D 2, 256, 3 H D 2}.
+    struct Lay { int64_t sb, sh, sr; } lq, lk, lv, lo, ldo, ldq, ldk, ldv;
     char *ds;        // backward: dS = P o (dP - delta) in 16 bits, written by the dK/dV kernel, read by the dQ kernel (null: not kept)
     int64_t ds_nqb, ds_nkwb; // its tile grid: 256-query blocks x 32-key blocks (DS_* below)
 };
@@ -75,6 +78,9 @@ __host__ __device__ inline size_t ds_bytes(int64_t nbh, int64_t Sq, int64_t Skv)
 // over the 8 XCDs, each with a private 4 MiB L2. All nx blocks of one (batch, head) re-read that head's K/V
 // (or Q/dO): 2 MiB at S = 4096. Dealing a head's blocks to ONE XCD keeps those re-reads in its L2 instead of
 // fetching every head into every L2. Speed only: any placement is correct.
+// base of (batch, head) bh = b * H + h under a layout
+__device__ __forceinline__ int64_t a_head(const AttnArgs::Lay &l, int64_t bh, int64_t H) { return (bh / H) * l.sb + (bh % H) * l.sh; }
+
 __device__ __forceinline__ void a_block_map(int nx, int nbh, int xcd_map, int &x, int64_t &bh) {
     const unsigned id = blockIdx.x;
     if (xcd_map) { // nbh % 8 == 0
@@ -142,7 +148,7 @@ __device__ __forceinline__ int a_row(int e, int h) { return (e & 3) + 8 * (e >> 
 struct Stage4 { uint4 a, b, c, d; }; // 64 rows
 struct Stage2 { uint4 a, b; };       // 32 rows
 // global [nrows][128] 16-bit rows -> swizzled LDS tile, 16 bytes per call
-__device__ __forceinline__ uint4 a_gld(const char *g, int id) { return *(const uint4 *)(g + (int64_t)(id >> 4) * AROW + (id & 15) * 16); }
+__device__ __forceinline__ uint4 a_gld(const char *g, int id, int64_t rs) { return *(const uint4 *)(g + (int64_t)(id >> 4) * rs + (id & 15) * 16); }
 __device__ __forceinline__ void a_lst(char *tile, int id, const uint4 &v) { *(uint4 *)(tile + a_off(id >> 4, id & 15)) = v; }
 
 template <bool BF>
@@ -151,7 +157,7 @@ __device__ __forceinline__ uint32_t a_cvt16(float v) { return BF ? f32_to_bf16(v
 // Write a wave's 32 x 128 result held as X^T accumulators (lane = row, registers = columns of
 // four 32-wide column blocks) as 16-bit rows of `dst` (row stride 256 B), via a per-wave LDS slab.
 template <bool BF>
-__device__ __forceinline__ void a_store_rows(char *slab, char *dst, const f32x16 (&acc)[4], float mul) {
+__device__ __forceinline__ void a_store_rows(char *slab, char *dst, const f32x16 (&acc)[4], float mul, int64_t rs) {
     const int lane = threadIdx.x & 63, xl = lane & 31, hl = lane >> 5;
 #pragma unroll
     for (int db = 0; db < 4; ++db)
@@ -171,7 +177,7 @@ __device__ __forceinline__ void a_store_rows(char *slab, char *dst, const f32x16
         const int id = lane + 64 * i; // 1024 pieces of 8 B: 32 rows x 32 pieces
         const int row = id >> 5, piece = id & 31;
         const uint2 w = *(const uint2 *)(slab + row * OPAD + piece * 8);
-        *(uint2 *)(dst + (int64_t)row * AROW + piece * 8) = w;
+        *(uint2 *)(dst + (int64_t)row * rs + piece * 8) = w;
     }
 }
 
@@ -239,15 +245,15 @@ __device__ __forceinline__ typename AFrag<BF>::type tr4_frag(const Tr4 &t, int d
 
 // LDS-DMA staging of one 64-key K tile and V tile (global_load_lds_dwordx4): 16 + 16 wave-instructions of
 // 1 KiB (4 rows), two of each per wave; the tile image's XOR swizzle goes on the per-lane SOURCE chunk.
-__device__ __forceinline__ void f_stage(const char *kg, const char *vg, char *buf) {
+__device__ __forceinline__ void f_stage(const char *kg, const char *vg, char *buf, int64_t krs, int64_t vrs) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row0 = (wid * 2 + i) * 4, row = row0 + (lane >> 4), pos = lane & 15;
         const int chunk = pos ^ (((row & 3) << 2) | ((row >> 2) & 3));
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kg + row * AROW + chunk * 16),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kg + row * krs + chunk * 16),
                                          (__attribute__((address_space(3))) void *)(buf + row0 * AROW), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vg + row * AROW + chunk * 16),
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vg + row * vrs + chunk * 16),
                                          (__attribute__((address_space(3))) void *)(buf + FTILE + row0 * AROW), 16, 0, 0);
     }
 }
@@ -371,8 +377,8 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
     a_block_map(nwx, (int)(a.B * a.H), a.xcd_map, xb0, bh);
     const int rgrp = ((wid & 3) << 1) | (wid >> 2);
     const bool late = __builtin_amdgcn_readfirstlane(wid) >= 4;
-    const char *Kg = a.k + bh * a.Skv * AROW;
-    const char *Vg = a.v + bh * a.Skv * AROW;
+    const char *Kg = a.k + a_head(a.lk, bh, a.H);
+    const char *Vg = a.v + a_head(a.lv, bh, a.H);
     int ko[8], vo[4][2];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) ko[kk] = a_off(xl, kk * 2 + hl);
@@ -394,7 +400,7 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
 
     frag_t qf[8];
     if (active) {
-        const char *Qg = a.q + (bh * a.Sq + m) * AROW;
+        const char *Qg = a.q + a_head(a.lq, bh, a.H) + m * a.lq.sr;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const frag_t *)(Qg + (kk * 16 + 8 * hl) * 2);
     } else {
@@ -417,7 +423,7 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
     const int nt = (int)((kv_end + ABK - 1) / ABK);
     auto stage = [&](int tile, char *buf) {
         const int64_t kv = (int64_t)(tile < nt ? tile : nt - 1) * ABK;
-        f_stage(Kg + kv * AROW, Vg + kv * AROW, buf);
+        f_stage(Kg + kv * a.lk.sr, Vg + kv * a.lv.sr, buf, a.lk.sr, a.lv.sr);
     };
     stage(0, smem);
     stage(1, smem + FBUF);
@@ -445,7 +451,7 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (active) {
-        a_store_rows<BF>(smem + wid * 32 * OPAD, a.out + (bh * a.Sq + qw) * AROW, o, 1.f / l_i);
+        a_store_rows<BF>(smem + wid * 32 * OPAD, a.out + a_head(a.lo, bh, a.H) + qw * a.lo.sr, o, 1.f / l_i, a.lo.sr);
         if (a.lse && hl == 0) a.lse[bh * a.Sq + m] = (m_i * c + __builtin_amdgcn_logf(l_i)) * kLn2;
     }
     if (a.persist) __syncthreads(); // the staging slabs overlap the ring the next block fills
@@ -456,14 +462,15 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
 // backward pre-pass: delta[q] = sum_d dO[q][d] * O[q][d]   (16 lanes per row, 16-B loads)
 // ------------------------------------------------------------------------------------------
 template <bool BF>
-__global__ __launch_bounds__(256) void attn_delta_kernel(const char *o, const char *d_o, float *delta, int64_t nrows, const float *lse = nullptr,
-                                                         float *nlse = nullptr, float *ndelta = nullptr, float rscale = 0.f) {
-    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+__global__ __launch_bounds__(256) void attn_delta_kernel(const char *o, const char *d_o, float *delta, int64_t nrows, const float *lse, float *nlse,
+                                                         float *ndelta, float rscale, AttnArgs::Lay lo, AttnArgs::Lay ldo, int64_t S, int64_t H) {
+    const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); // flat (b, h, s): the statistics stay [B, H, S] contiguous
     const int part = threadIdx.x & 15;
     float acc = 0.f;
     if (row < nrows) {
-        const uint4 a = *(const uint4 *)(o + row * AROW + part * 16);
-        const uint4 b = *(const uint4 *)(d_o + row * AROW + part * 16);
+        const int64_t bh = row / S, sq = row - bh * S;
+        const uint4 a = *(const uint4 *)(o + a_head(lo, bh, H) + sq * lo.sr + part * 16);
+        const uint4 b = *(const uint4 *)(d_o + a_head(ldo, bh, H) + sq * ldo.sr + part * 16);
         const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -554,8 +561,8 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a
     // a.persist: a workgroup takes query block x and its causal mirror nxb - 1 - x (equal work per workgroup, as in the forward)
     const int nwx = a.persist ? nxb / (2 * a.persist) : nxb;
     a_block_map(nwx, (int)(a.B * a.H), a.xcd_map, xb0, bh);
-    const char *Kg = a.k + bh * a.Skv * AROW;
-    const char *Vg = a.v + bh * a.Skv * AROW;
+    const char *Kg = a.k + a_head(a.lk, bh, a.H);
+    const char *Vg = a.v + a_head(a.lv, bh, a.H);
     char *doslab = smem + FRING * FBUF + wid * QSLAB; // this wave's dO rows, same swizzled image as a K tile (B operand of dP^T)
     int ko[8], vo[4][2];
 #pragma unroll
@@ -577,12 +584,12 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a
     frag_t qf[8];
     float lse2 = 0.f, dlt = 0.f;
     if (active) {
-        const char *Qg = a.q + (bh * a.Sq + m) * AROW;
+        const char *Qg = a.q + a_head(a.lq, bh, a.H) + m * a.lq.sr;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const frag_t *)(Qg + (kk * 16 + 8 * hl) * 2);
-        const char *dOw = a.d_o + (bh * a.Sq + qw) * AROW;
+        const char *dOw = a.d_o + a_head(a.ldo, bh, a.H) + qw * a.ldo.sr;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a_lst(doslab, lane + 64 * i, a_gld(dOw, lane + 64 * i));
+        for (int i = 0; i < 8; ++i) a_lst(doslab, lane + 64 * i, a_gld(dOw, lane + 64 * i, a.ldo.sr));
         lse2 = a.lse_r[bh * a.Sq + m] * kLog2e;
         dlt = a.delta[bh * a.Sq + m];
     } else {
@@ -602,7 +609,7 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a
     const int nt = (int)((kv_end + ABK - 1) / ABK);
     auto stage = [&](int tile, char *buf) { // 3-deep ring, counted vmcnt: see attn_fwd_v2_kernel
         const int64_t kv = (int64_t)(tile < nt ? tile : nt - 1) * ABK;
-        f_stage(Kg + kv * AROW, Vg + kv * AROW, buf);
+        f_stage(Kg + kv * a.lk.sr, Vg + kv * a.lv.sr, buf, a.lk.sr, a.lv.sr);
     };
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // Q fragments + the dO slab writes are done
     stage(0, smem);
@@ -623,7 +630,7 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (active) a_store_rows<BF>(smem + wid * 32 * OPAD, a.dq + (bh * a.Sq + qw) * AROW, dq, a.scale);
+    if (active) a_store_rows<BF>(smem + wid * 32 * OPAD, a.dq + a_head(a.ldq, bh, a.H) + qw * a.ldq.sr, dq, a.scale, a.ldq.sr);
     if (a.persist) __syncthreads(); // the staging slabs overlap the ring the next block fills
   }
 }
@@ -678,7 +685,7 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_ds_kernel(const AttnArgs a
     const int nxb = (int)((a.Sq + FQ - 1) / FQ);
     const int nwx = a.persist ? nxb / (2 * a.persist) : nxb;
     a_block_map(nwx, (int)(a.B * a.H), a.xcd_map, xb0, bh);
-    const char *Kg = a.k + bh * a.Skv * AROW;
+    const char *Kg = a.k + a_head(a.lk, bh, a.H);
     char *slab = smem + DQ_RING * FTILE + wid * DQ_RING * DQ_SLAB;
     int vo[4][2];
 #pragma unroll
@@ -718,12 +725,12 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_ds_kernel(const AttnArgs a
     const int kwb_last = (int)(a.ds_nkwb - 1);
     auto stage = [&](int tile, int slot) { // 2 K pieces (this wave's share of the tile) + 4 dS pieces (its own two tiles)
         const int tl = tile < nt ? tile : nt - 1;
-        const char *kg = Kg + (int64_t)tl * ABK * AROW;
+        const char *kg = Kg + (int64_t)tl * ABK * a.lk.sr;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row0 = (wid * 2 + i) * 4, row = row0 + krow;
             const int chunk = kpos ^ (((row & 3) << 2) | ((row >> 2) & 3));
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kg + row * AROW + chunk * 16),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kg + row * a.lk.sr + chunk * 16),
                                              (__attribute__((address_space(3))) void *)(smem + slot * FTILE + row0 * AROW), 16, 0, 0);
         }
 #pragma unroll
@@ -757,7 +764,7 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_ds_kernel(const AttnArgs a
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (active) a_store_rows<BF>(smem + wid * 32 * OPAD, a.dq + (bh * a.Sq + qw) * AROW, dq, a.scale);
+    if (active) a_store_rows<BF>(smem + wid * 32 * OPAD, a.dq + a_head(a.ldq, bh, a.H) + qw * a.ldq.sr, dq, a.scale, a.ldq.sr);
     if (a.persist) __syncthreads();
   }
 }
@@ -865,8 +872,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     // a.persist: a workgroup takes key block x and its causal mirror nkb - 1 - x (equal work per workgroup, as in the forward)
     const int nkb = (int)(a.Skv / K4B), nwx = a.persist ? nkb / (2 * a.persist) : nkb;
     a_block_map(nwx, (int)(a.B * a.H), a.xcd_map, xb0, bh);
-    const char *Qg = a.q + bh * a.Sq * AROW;
-    const char *dOg = a.d_o + bh * a.Sq * AROW;
+    const char *Qg = a.q + a_head(a.lq, bh, a.H);
+    const char *dOg = a.d_o + a_head(a.ldo, bh, a.H);
 #pragma nounroll
   for (int pass = 0; pass < (a.persist ? 2 * a.persist : 1); ++pass) {
     const int xp = xb0 + (pass >> 1) * nwx;
@@ -875,8 +882,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
 
     frag_t kf[8], vf[8]; // this wave's 32 keys: B operands of S = Q K^T and dP = dO V^T
     {
-        const char *Kg = a.k + (bh * a.Skv + n) * AROW;
-        const char *Vg = a.v + (bh * a.Skv + n) * AROW;
+        const char *Kg = a.k + a_head(a.lk, bh, a.H) + n * a.lk.sr;
+        const char *Vg = a.v + a_head(a.lv, bh, a.H) + n * a.lv.sr;
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
             kf[kk] = *(const frag_t *)(Kg + (kk * 16 + 8 * hl) * 2);
@@ -904,11 +911,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
 
     // ---- LDS-DMA: a 32-row tile is 8 wave-instructions of 1 KiB (8 rows x 128 B each); wave w moves rows 8 w .. 8 w + 7
     // of the Q tile and of the dO tile, and every wave fetches the 64 row constants (identical bytes: uniform counts).
-    int soff[2];
+    int64_t soffq[2], soffd[2]; // per-lane source offsets inside a slice: row * (row stride of Q | dO) + chunk
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int sub = 2 * i + (lane >> 5), r = (lane >> 2) & 7, slot = lane & 3, row = 8 * wid + r;
-        soff[i] = row * AROW + (4 * sub + (slot ^ ((row >> 2) & 3))) * 16;
+        const int ch = (4 * sub + (slot ^ ((row >> 2) & 3))) * 16;
+        soffq[i] = row * a.lq.sr + ch;
+        soffd[i] = row * a.ldo.sr + ch;
     }
     const float *rcg = lane < BQS ? a.nlse + bh * a.Sq + lane : a.ndelta + bh * a.Sq + lane - BQS;
     const int ns = (int)(a.Sq / BQS), np = ns / 2;
@@ -929,8 +938,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
                                              (__attribute__((address_space(3))) void *)(buf + 2 * BQS * AROW), 4, 0, 0);
         } else {
             constexpr int i = K >> 1;
-            const char *src = (K & 1) ? dOg : Qg;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + qs_ * AROW + soff[i]),
+            const char *src = (K & 1) ? dOg + qs_ * a.ldo.sr + soffd[i] : Qg + qs_ * a.lq.sr + soffq[i];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(buf + (K & 1) * BQS * AROW + 1024 * (2 * wid + i)), 16, 0, 0);
         }
     };
@@ -1148,8 +1157,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
 #undef K4_CVT2
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // drain the ring and the last prefetch before LDS is reused
     __syncthreads();
-    a_store_rows<BF>(smem + wid * 32 * OPAD, a.dv + (bh * a.Skv + kw) * AROW, dv, 1.f);
-    a_store_rows<BF>(smem + wid * 32 * OPAD, a.dk + (bh * a.Skv + kw) * AROW, dk, a.scale);
+    a_store_rows<BF>(smem + wid * 32 * OPAD, a.dv + a_head(a.ldv, bh, a.H) + kw * a.ldv.sr, dv, 1.f, a.ldv.sr);
+    a_store_rows<BF>(smem + wid * 32 * OPAD, a.dk + a_head(a.ldk, bh, a.H) + kw * a.ldk.sr, dk, a.scale, a.ldk.sr);
     if (a.persist) __syncthreads(); // the staging slabs overlap the ring the next block fills
   }
 }
@@ -1829,8 +1838,35 @@ extern "C" int kf_attn_fwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
     return kf_attn_fwd_scaled(dtype, B, H, Sq, Skv, D, D > 0 ? 1.0f / sqrtf((float)D) : 1.0f, q, k, v, o, lse, stream);
 }
 
+static AttnArgs::Lay lay_contig(int64_t H, int64_t S, int64_t D, int es) { return {H * S * D * es, S * D * es, D * es}; }
+static bool lay_from(const kf_attn_layout *l, int es, AttnArgs::Lay &out) {
+    if (!l || l->batch < 0 || l->head < 0 || l->row < 0) return false;
+    out = {l->batch * es, l->head * es, l->row * es};
+    return out.sb % 16 == 0 && out.sh % 16 == 0 && out.sr % 16 == 0; // 16-byte row pieces
+}
+
+static int attn_fwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, float scale, const void *q, const void *k,
+                         const void *v, void *o, float *lse, const AttnArgs::Lay *lays, void *stream);
+
 extern "C" int kf_attn_fwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, float scale, const void *q,
                                   const void *k, const void *v, void *o, float *lse, void *stream) {
+    return attn_fwd_impl(dtype, B, H, Sq, Skv, D, scale, q, k, v, o, lse, nullptr, stream);
+}
+
+extern "C" int kf_attn_fwd_strided(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, float scale, const void *q,
+                                   const kf_attn_layout *lq, const void *k, const kf_attn_layout *lk, const void *v, const kf_attn_layout *lv,
+                                   void *o, const kf_attn_layout *lo, float *lse, void *stream) {
+    KF_REQUIRE(mfma_ok(dtype, Sq, Skv, D), KF_ERR_UNSUPPORTED,
+               "kf_attn_fwd_strided: strided layouts are served by the 16-bit matrix-core kernels only (D = 128, Sq, Skv multiples of 128)");
+    AttnArgs::Lay lays[4];
+    KF_REQUIRE(lay_from(lq, 2, lays[0]) && lay_from(lk, 2, lays[1]) && lay_from(lv, 2, lays[2]) && lay_from(lo, 2, lays[3]), KF_ERR_INVALID,
+               "kf_attn_fwd_strided: strides must be non-negative multiples of 8 elements");
+    KF_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) % 16 == 0, KF_ERR_INVALID, "kf_attn_fwd_strided: operands must be 16-byte aligned");
+    return attn_fwd_impl(dtype, B, H, Sq, Skv, D, scale, q, k, v, o, lse, lays, stream);
+}
+
+static int attn_fwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, float scale, const void *q, const void *k,
+                         const void *v, void *o, float *lse, const AttnArgs::Lay *lays, void *stream) {
     int rc = check_common("kf_attn_fwd", dtype, B, H, Sq, Skv, D);
     if (rc != KF_OK) return rc;
     if (B * H == 0 || Sq == 0) return KF_OK;
@@ -1845,6 +1881,8 @@ extern "C" int kf_attn_fwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, i
     a.scale = scale;
     a.xcd_map = ((B * H) % 8 == 0) && !knob(KNOB_ATTN_NO_XCD);
     a.defer = knob(KNOB_ATTN_NO_DEFER) ? -INFINITY : kDeferMax; // A/B switch: rescale O at every tile
+    if (lays) { a.lq = lays[0]; a.lk = lays[1]; a.lv = lays[2]; a.lo = lays[3]; }
+    else { a.lq = a.lo = lay_contig(H, Sq, D, 2); a.lk = a.lv = lay_contig(H, Skv, D, 2); }
     if (mfma_ok(dtype, Sq, Skv, D)) {
         const size_t lds3 = SRING * FBUF;
         const int64_t nxb3 = (Sq + FQ - 1) / FQ;
@@ -1917,9 +1955,35 @@ extern "C" int kf_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t 
                               workspace_bytes, stream);
 }
 
+static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, float scale, const void *q, const void *k,
+                         const void *v, const void *o, const float *lse, const void *d_o, void *dq, void *dk, void *dv, const AttnArgs::Lay *lays,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
 extern "C" int kf_attn_bwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, float scale, const void *q,
                                   const void *k, const void *v, const void *o, const float *lse, const void *d_o, void *dq,
                                   void *dk, void *dv, void *workspace, size_t workspace_bytes, void *stream) {
+    return attn_bwd_impl(dtype, B, H, Sq, Skv, D, scale, q, k, v, o, lse, d_o, dq, dk, dv, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int kf_attn_bwd_strided(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, float scale, const void *q,
+                                   const kf_attn_layout *lq, const void *k, const kf_attn_layout *lk, const void *v, const kf_attn_layout *lv,
+                                   const void *o, const kf_attn_layout *lo, const float *lse, const void *d_o, const kf_attn_layout *ldo, void *dq,
+                                   const kf_attn_layout *ldq, void *dk, const kf_attn_layout *ldk, void *dv, const kf_attn_layout *ldv,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
+    KF_REQUIRE(mfma_ok(dtype, Sq, Skv, D), KF_ERR_UNSUPPORTED,
+               "kf_attn_bwd_strided: strided layouts are served by the 16-bit matrix-core kernels only (D = 128, Sq, Skv multiples of 128)");
+    AttnArgs::Lay lays[8];
+    const kf_attn_layout *in[8] = {lq, lk, lv, lo, ldo, ldq, ldk, ldv};
+    for (int i = 0; i < 8; ++i)
+        KF_REQUIRE(lay_from(in[i], 2, lays[i]), KF_ERR_INVALID, "kf_attn_bwd_strided: strides must be non-negative multiples of 8 elements");
+    KF_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 16 == 0,
+               KF_ERR_INVALID, "kf_attn_bwd_strided: operands must be 16-byte aligned");
+    return attn_bwd_impl(dtype, B, H, Sq, Skv, D, scale, q, k, v, o, lse, d_o, dq, dk, dv, lays, workspace, workspace_bytes, stream);
+}
+
+static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, float scale, const void *q, const void *k,
+                         const void *v, const void *o, const float *lse, const void *d_o, void *dq, void *dk, void *dv, const AttnArgs::Lay *lays,
+                         void *workspace, size_t workspace_bytes, void *stream) {
     int rc = check_common("kf_attn_bwd", dtype, B, H, Sq, Skv, D);
     if (rc != KF_OK) return rc;
     if (B * H == 0 || Sq == 0 || Skv == 0) return KF_OK;
@@ -1939,14 +2003,16 @@ extern "C" int kf_attn_bwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, i
     a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.D = D;
     KF_REQUIRE(scale > 0.f && scale < INFINITY, KF_ERR_INVALID, "attention: the softmax scale must be positive and finite");
     a.scale = scale;
+    if (lays) { a.lq = lays[0]; a.lk = lays[1]; a.lv = lays[2]; a.lo = lays[3]; a.ldo = lays[4]; a.ldq = lays[5]; a.ldk = lays[6]; a.ldv = lays[7]; }
+    else { a.lq = a.lo = a.ldo = a.ldq = lay_contig(H, Sq, D, 2); a.lk = a.lv = a.ldk = a.ldv = lay_contig(H, Skv, D, 2); }
     const int64_t nrows = B * H * Sq;
     if (mfma_ok(dtype, Sq, Skv, D)) {
         const unsigned gd = (unsigned)((nrows + 15) / 16);
         const bool bf = dtype == KF_BF16;
         {
             KF_PROF("attn_bwd_delta", st);
-            if (bf) attn_delta_kernel<true><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, 1.0f / a.scale);
-            else attn_delta_kernel<false><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, 1.0f / a.scale);
+            if (bf) attn_delta_kernel<true><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, 1.0f / a.scale, a.lo, a.ldo, Sq, H);
+            else attn_delta_kernel<false><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, 1.0f / a.scale, a.lo, a.ldo, Sq, H);
             KF_LAUNCH_CHECK();
         }
         const bool keep_ds = bwd_keeps_ds(dtype, B, H, Sq, Skv, D);

@@ -42,7 +42,7 @@ EXPORTS = [
     "kf_reduce_moments_workspace_bytes", "kf_reduce_moments",
     "kf_norm_fwd", "kf_norm_bwd_workspace_bytes", "kf_norm_bwd",
     "kf_index_put", "kf_index_get", "kf_index_add_workspace_bytes", "kf_index_add", "kf_sort_workspace_bytes", "kf_sort", "kf_gemm_workspace_bytes", "kf_gemm", "kf_attn_fwd", "kf_attn_fwd_scaled", "kf_attn_bwd_workspace_bytes",
-    "kf_attn_bwd", "kf_attn_bwd_scaled", "kf_comm_unique_id", "kf_comm_init", "kf_comm_destroy", "kf_allreduce_sum",
+    "kf_attn_bwd", "kf_attn_bwd_scaled", "kf_attn_fwd_strided", "kf_attn_bwd_strided", "kf_comm_unique_id", "kf_comm_init", "kf_comm_destroy", "kf_allreduce_sum",
 ]
 
 
@@ -57,6 +57,11 @@ class IterDesc(C.Structure):
     _fields_ = [("ndim", C.c_int32), ("ntensors", C.c_int32), ("noutputs", C.c_int32), ("reserved", C.c_int32),
                 ("dtype", C.c_int32 * MAX_TENSORS), ("shape", C.c_int64 * MAX_DIMS),
                 ("stride_bytes", (C.c_int64 * MAX_DIMS) * MAX_TENSORS), ("data", C.c_void_p * MAX_TENSORS)]
+
+
+class AttnLayout(C.Structure):
+    """kf_attn_layout: element strides of the batch, head and row dims of one attention operand."""
+    _fields_ = [("batch", C.c_int64), ("head", C.c_int64), ("row", C.c_int64)]
 
 
 class DeviceProps(C.Structure):
@@ -122,6 +127,10 @@ def lib():
         _lib.kf_attn_bwd.argtypes = [C.c_int, i64, i64, i64, i64, i64] + [vp] * 10 + [sz, vp]
         _lib.kf_attn_fwd_scaled.argtypes = [C.c_int, i64, i64, i64, i64, i64, C.c_float, vp, vp, vp, vp, vp, vp]
         _lib.kf_attn_bwd_scaled.argtypes = [C.c_int, i64, i64, i64, i64, i64, C.c_float] + [vp] * 10 + [sz, vp]
+        lp = C.POINTER(AttnLayout)
+        _lib.kf_attn_fwd_strided.argtypes = [C.c_int, i64, i64, i64, i64, i64, C.c_float, vp, lp, vp, lp, vp, lp, vp, lp, vp, vp]
+        _lib.kf_attn_bwd_strided.argtypes = [C.c_int, i64, i64, i64, i64, i64, C.c_float, vp, lp, vp, lp, vp, lp, vp, lp, vp, vp, lp, vp, lp, vp, lp,
+                                             vp, lp, vp, sz, vp]
         _lib.kf_comm_unique_id.argtypes = [C.c_char_p]
         _lib.kf_comm_init.argtypes = [C.POINTER(vp), C.c_char_p, C.c_int, C.c_int]
         _lib.kf_comm_destroy.argtypes = [vp]
@@ -455,6 +464,19 @@ def attn_bwd_workspace_bytes(dtype, B, H, Sq, Skv, D) -> int:
 def attn_bwd(dtype, B, H, Sq, Skv, D, q, k, v, o, lse, d_o, dq, dk, dv, workspace, workspace_bytes, stream=None):
     check(lib().kf_attn_bwd(dtype, B, H, Sq, Skv, D, q, k, v, o, lse, d_o, dq, dk, dv, workspace, workspace_bytes,
                             stream))
+
+
+def attn_fwd_strided(dtype, B, H, Sq, Skv, D, scale, q, lq, k, lk, v, lv, o, lo, lse=None, stream=None):
+    """lq.. are (batch, head, row) element-stride triples."""
+    L = [AttnLayout(*t) for t in (lq, lk, lv, lo)]
+    check(lib().kf_attn_fwd_strided(dtype, B, H, Sq, Skv, D, scale, q, C.byref(L[0]), k, C.byref(L[1]), v, C.byref(L[2]), o, C.byref(L[3]), lse, stream))
+
+
+def attn_bwd_strided(dtype, B, H, Sq, Skv, D, scale, q, lq, k, lk, v, lv, o, lo, lse, d_o, ldo, dq, ldq, dk, ldk, dv, ldv, workspace,
+                     workspace_bytes, stream=None):
+    L = [AttnLayout(*t) for t in (lq, lk, lv, lo, ldo, ldq, ldk, ldv)]
+    check(lib().kf_attn_bwd_strided(dtype, B, H, Sq, Skv, D, scale, q, C.byref(L[0]), k, C.byref(L[1]), v, C.byref(L[2]), o, C.byref(L[3]), lse,
+                                    d_o, C.byref(L[4]), dq, C.byref(L[5]), dk, C.byref(L[6]), dv, C.byref(L[7]), workspace, workspace_bytes, stream))
 
 
 def device_sync():

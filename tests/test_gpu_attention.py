@@ -322,3 +322,47 @@ def test_backward_forms_stored_ds_and_recomputing_split(code):
                 assert_close(f(got, code), f(ref, code), **TOL_BWD[code], what=f"{form} {nme} {Sq}x{Skv}")
         assert np.array_equal(res["ds"][1].view(np.uint16), res["split"][1].view(np.uint16))
         assert np.array_equal(res["ds"][2].view(np.uint16), res["split"][2].view(np.uint16))
+
+
+@pytest.mark.parametrize("code", [H.BF16, H.F16])
+def test_strided_layouts_packed_qkv_are_the_same_arithmetic(code):
+    """kf_attn_*_strided on q / k / v living inside one packed [B S, 3 H D] projection output, o as [B S, H D], and dq / dk / dv
+    written into a packed gradient: BIT-identical to the contiguous [B,H,S,D] entries on the same values (the layout changes
+    addresses, not arithmetic), the bytes between the strided outputs untouched."""
+    B, Hh, S, D = 2, 4, 512, 128
+    d = Hh * D
+    rng = np.random.default_rng(33 + code)
+    qkv = O.from_float(rng.uniform(-1, 1, (B * S, 3 * d)).astype(np.float32), code)
+    gout = O.from_float(rng.uniform(-1, 1, (B * S, d)).astype(np.float32), code)
+    heads = lambda x2: np.ascontiguousarray(x2.reshape(B, S, Hh, D).transpose(0, 2, 1, 3))  # noqa: E731  [B S, H D] -> [B, H, S, D]
+    q, k, v, go = heads(qkv[:, :d]), heads(qkv[:, d:2 * d]), heads(qkv[:, 2 * d:]), heads(gout)
+    o_ref, lse_ref = fwd(code, q, k, v)
+    dq_ref, dk_ref, dv_ref = bwd(code, q, k, v, o_ref, lse_ref, go)
+    es = 2
+    packed, flat = (S * 3 * d, D, 3 * d), (S * d, D, d)
+    bqkv, bgo = H.DevBuf.from_numpy(qkv), H.DevBuf.from_numpy(gout)
+    bo, blse = H.DevBuf(B * S * d * es), H.DevBuf(4 * B * Hh * S)
+    scale = 1.0 / np.sqrt(D)
+    H.attn_fwd_strided(code, B, Hh, S, S, D, scale, bqkv.ptr, packed, bqkv.ptr + d * es, packed, bqkv.ptr + 2 * d * es, packed, bo.ptr, flat, blse.ptr)
+    H.device_sync()
+    o2 = bo.to_numpy((B * S, d), qkv.dtype)
+    assert np.array_equal(heads(o2), o_ref)
+    assert np.array_equal(blse.to_numpy((B, Hh, S), np.float32).view(np.uint32), lse_ref.view(np.uint32))
+    dqkv = H.DevBuf.from_numpy(np.full((B * S, 3 * d + 8), 0x1234, dtype=np.uint16))  # a wider gradient buffer: 8 pad columns per row
+    wide = (S * (3 * d + 8), D, 3 * d + 8)
+    need = H.attn_bwd_workspace_bytes(code, B, Hh, S, S, D)
+    ws = H.DevBuf(need)
+    H.attn_bwd_strided(code, B, Hh, S, S, D, scale, bqkv.ptr, packed, bqkv.ptr + d * es, packed, bqkv.ptr + 2 * d * es, packed, bo.ptr, flat, blse.ptr,
+                       bgo.ptr, flat, dqkv.ptr, wide, dqkv.ptr + d * es, wide, dqkv.ptr + 2 * d * es, wide, ws.ptr, need)
+    H.device_sync()
+    g = dqkv.to_numpy((B * S, 3 * d + 8), np.uint16)
+    assert (g[:, 3 * d:] == 0x1234).all()
+    for name, got, ref in (("dq", g[:, :d], dq_ref), ("dk", g[:, d:2 * d], dk_ref), ("dv", g[:, 2 * d:3 * d], dv_ref)):
+        assert np.array_equal(heads(got).view(np.uint16), ref.view(np.uint16)), name
+    # refused off the matrix-core path (D = 64) and for misaligned strides
+    with pytest.raises(H.KfError) as e:
+        H.attn_fwd_strided(code, B, Hh, S, S, 64, scale, bqkv.ptr, packed, bqkv.ptr, packed, bqkv.ptr, packed, bo.ptr, flat, blse.ptr)
+    assert e.value.code == H.KF_ERR_UNSUPPORTED
+    with pytest.raises(H.KfError) as e:
+        H.attn_fwd_strided(code, B, Hh, S, S, D, scale, bqkv.ptr, (S * 3 * d, D, 3 * d + 1), bqkv.ptr, packed, bqkv.ptr, packed, bo.ptr, flat, blse.ptr)
+    assert e.value.code == H.KF_ERR_INVALID
