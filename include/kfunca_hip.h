@@ -277,6 +277,27 @@ int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K
             int64_t lda, const void *B, int64_t ldb, float beta, void *C, int64_t ldc, int epilogue,
             const void *bias, void *workspace, size_t workspace_bytes, void *stream);
 
+/*
+ * The same product with an element-wise tail fused into the store (the reference's roadmap: fused projections, README.md:32; its
+ * own API can only express these as separate add / mul kernels over the GEMM's output, binary_ops.cpp:6-91):
+ *     t = alpha * op(A) op(B) + beta * C + bias[n]        (bias NULL: none)
+ *     aux[m,n] = t                                        (aux NULL: not kept; the backward of a gating product needs it)
+ *     C[m,n]  = t * mul[m,n] + add[m,n]                   (mul NULL: 1; add NULL: 0)
+ * mul, add, aux: [M,N] row-major of the GEMM's dtype with their own leading dimensions. A residual connection is add = the
+ * residual stream; a gated MLP's h = (x Wg) o (x Wu) is mul = x Wu with aux = x Wg. Every kernel applies the tail.
+ */
+typedef struct kf_gemm_epilogue {
+    const void *bias; /* [N] or NULL */
+    const void *mul;  /* [M,N] or NULL */
+    int64_t ldmul;
+    const void *add;  /* [M,N] or NULL */
+    int64_t ldadd;
+    void *aux;        /* [M,N] or NULL */
+    int64_t ldaux;
+} kf_gemm_epilogue;
+int kf_gemm_ex(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const void *A, int64_t lda,
+               const void *B, int64_t ldb, float beta, void *C, int64_t ldc, const kf_gemm_epilogue *epi, void *stream);
+
 /* ---- causal attention: replaces causal_attention_kernel.h:5 (+ backward) ------------------- */
 /*
  * q:[B,H,Sq,D], k,v:[B,H,Skv,D], o:[B,H,Sq,D] contiguous; lse:[B,H,Sq] float32 (may be NULL for

@@ -265,6 +265,7 @@ PYBIND11_MODULE(_C, m) {
         return gpu::layer_norm(x, w.is_none() ? Tensor() : w.cast<Tensor>(), b.is_none() ? Tensor() : b.cast<Tensor>(), eps);
     }, py::arg("x"), py::arg("weight") = py::none(), py::arg("bias") = py::none(), py::arg("eps") = 1e-5);
     m.def("embedding", &gpu::embedding, py::arg("table"), py::arg("indices"));
+    m.def("causal_attention_qkv", &gpu::causal_attention_qkv, py::arg("qkv"), py::arg("B"), py::arg("S"), py::arg("H"));
     // from_numpy for bfloat16: uint16 bit patterns in, a BFloat16 tensor out (the inverse of to_numpy's uint16 view)
     m.def("from_numpy_bf16", [](py::array array, int device) {
         CHECK_FAIL(array.dtype().kind() == 'u' && array.dtype().itemsize() == 2, "from_numpy_bf16 expects uint16 bit patterns");

@@ -660,6 +660,73 @@ Tensor &index_put_(Tensor &self, const std::vector<Tensor> &indices, const Tenso
     return self;
 }
 
+// ---- attention on the packed QKV projection (README.md:32) ---------------------------------------------------------------------
+namespace {
+struct PackedLay { kf_attn_layout qkv, flat; };
+PackedLay packed_layouts(int64_t S, int64_t H, int64_t D) {
+    const int64_t d = H * D;
+    return {{S * 3 * d, D, 3 * d}, {S * d, D, d}};
+}
+bool packed_fast(const Tensor &qkv, int64_t S, int64_t D) {
+    return (qkv.dtype() == ScalarType::Half || qkv.dtype() == ScalarType::BFloat16) && D == 128 && S % 128 == 0 && S > 0;
+}
+
+class PackedAttentionGradFunction : public GradFunction {
+public:
+    PackedAttentionGradFunction(const Tensor &qkv, const Tensor &out, const Tensor &lse, int64_t B, int64_t S, int64_t H)
+        : out_(out), lse_(lse), B_(B), S_(S), H_(H) {
+        inputs = {qkv};
+    }
+    std::vector<Tensor> backward(Tensor g) override {
+        const Tensor &qkv = inputs[0];
+        const int64_t d = qkv.shape(1) / 3, D = d / H_;
+        const int es = (int)qkv.element_size_in_bytes();
+        Tensor gc = g.contiguous();
+        Tensor dqkv = empty(qkv.sizes(), qkv.dtype(), qkv.device());
+        const PackedLay L = packed_layouts(S_, H_, D);
+        size_t need = 0;
+        DEV_CALL(kf_attn_bwd_workspace_bytes(code(qkv.dtype()), B_, H_, S_, S_, D, &need));
+        DataPtr scratch = DeviceAllocator::GetInstance()->allocate(need, qkv.device());
+        const char *p = static_cast<const char *>(qkv.data_ptr());
+        char *gp = static_cast<char *>(dqkv.data_ptr());
+        DEV_CALL(kf_attn_bwd_strided(code(qkv.dtype()), B_, H_, S_, S_, D, 1.0f / std::sqrt((float)D), p, &L.qkv, p + d * es, &L.qkv, p + 2 * d * es,
+                                     &L.qkv, out_.data_ptr(), &L.flat, static_cast<const float *>(lse_.data_ptr()), gc.data_ptr(), &L.flat, gp, &L.qkv,
+                                     gp + d * es, &L.qkv, gp + 2 * d * es, &L.qkv, scratch.get(), need, dev::stream(qkv.device())));
+        return {dqkv};
+    }
+
+private:
+    Tensor out_, lse_;
+    int64_t B_, S_, H_;
+};
+} // namespace
+
+Tensor causal_attention_qkv(const Tensor &qkv, int64_t B, int64_t S, int64_t H) {
+    CHECK_FAIL(qkv.defined() && qkv.dim() == 2 && qkv.is_contiguous(), "causal_attention_qkv expects a contiguous [B*S, 3*H*D] tensor");
+    CHECK_FAIL(B > 0 && S > 0 && H > 0 && qkv.shape(0) == B * S && qkv.shape(1) % (3 * H) == 0, "causal_attention_qkv: shape does not match B, S, H");
+    const int64_t d = qkv.shape(1) / 3, D = d / H;
+    if (!packed_fast(qkv, S, D)) {
+        // off the strided kernels' shapes: the same result from the reference's own operators (which carry their own autograd)
+        auto parts = tensor_split(qkv, {d, d, d}, 1);
+        std::vector<Tensor> heads;
+        for (auto &t : parts) heads.push_back(t.contiguous().view({B, S, H, D}).permute({0, 2, 1, 3}).contiguous());
+        Tensor a = causal_attention(heads[0], heads[1], heads[2]);
+        return a.permute({0, 2, 1, 3}).contiguous().view({B * S, d});
+    }
+    const int es = (int)qkv.element_size_in_bytes();
+    Tensor out = empty({B * S, d}, qkv.dtype(), qkv.device());
+    Tensor lse = empty({B, H, S}, ScalarType::Float, qkv.device());
+    const PackedLay L = packed_layouts(S, H, D);
+    const char *p = static_cast<const char *>(qkv.data_ptr());
+    DEV_CALL(kf_attn_fwd_strided(code(qkv.dtype()), B, H, S, S, D, 1.0f / std::sqrt((float)D), p, &L.qkv, p + d * es, &L.qkv, p + 2 * d * es, &L.qkv,
+                                 out.data_ptr(), &L.flat, static_cast<float *>(lse.data_ptr()), dev::stream(qkv.device())));
+    if (qkv.requires_grad()) {
+        out.set_requires_grad(true);
+        out.set_grad_fn(new PackedAttentionGradFunction(qkv, out, lse, B, S, H));
+    }
+    return out;
+}
+
 // ---- rms_norm / layer_norm (README.md:28; statistics as norm_ops_kernel.cu:6-61 / welford_norm.h:170-187) ---------------------
 namespace {
 bool norm_dtype_ok(ScalarType t) { return t == ScalarType::Float || t == ScalarType::Half || t == ScalarType::BFloat16; }

@@ -61,6 +61,10 @@ std::tuple<Tensor, Tensor> topk(const Tensor &self, int64_t k, int64_t dim, bool
 Tensor rms_norm(const Tensor &x, const Tensor &weight, double eps);
 Tensor layer_norm(const Tensor &x, const Tensor &weight, const Tensor &bias, double eps);
 Tensor embedding(const Tensor &table, const Tensor &indices);
+//   causal_attention_qkv (the roadmap's qkv_linear, README.md:32, attention side): qkv is the packed output [B*S, 3*H*D] of the
+//   QKV projection (columns q | k | v, each H heads of D); q, k, v are read IN PLACE, the result is [B*S, H*D] - the layout
+//   the output projection takes - and the backward writes one packed gradient: no split / permute / contiguous copies
+Tensor causal_attention_qkv(const Tensor &qkv, int64_t B, int64_t S, int64_t H);
 
 // extensions used by the backward passes (no reference counterpart)
 Tensor gemm_ex(const Tensor &a, bool trans_a, const Tensor &b, bool trans_b, float alpha);

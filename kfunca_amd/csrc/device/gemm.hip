@@ -32,6 +32,10 @@ struct GemmArgs {
     float alpha, beta;
     int epilogue;
     int group_m; // tile rows per group of the grouped tile order (0: row-major)
+    // element-wise epilogue operands (kf_gemm_ex): C = (alpha AB + beta C + bias) o mul + add; aux receives the value in brackets
+    const void *mul, *add;
+    void *aux;
+    int64_t ldmul, ldadd, ldaux;
 };
 
 // XCD-aware remap: consecutive logical tile ids land on the same XCD (its own 4 MiB L2) so
@@ -68,6 +72,67 @@ template <> __device__ __forceinline__ float g_load<f16_t>(const f16_t *p) { ret
 template <typename T> __device__ __forceinline__ void g_store(T *p, typename GAcc<T>::type v) { *p = (T)v; }
 template <> __device__ __forceinline__ void g_store<bf16_t>(bf16_t *p, float v) { *p = f32_to_bf16(v); }
 template <> __device__ __forceinline__ void g_store<f16_t>(f16_t *p, float v) { *p = f32_to_f16(v); }
+
+// the element-wise tail of the epilogue for one output element (scalar sites: generic, f32, f64 and the 128-tile 16-bit kernel)
+template <typename T>
+__device__ __forceinline__ typename GAcc<T>::type g_epi(const GemmArgs &g, int64_t m, int64_t n, typename GAcc<T>::type v) {
+    if (g.aux) g_store<T>((T *)g.aux + m * g.ldaux + n, v);
+    if (g.mul) v *= g_load<T>((const T *)g.mul + m * g.ldmul + n);
+    if (g.add) v += g_load<T>((const T *)g.add + m * g.ldadd + n);
+    return v;
+}
+// ... and for eight consecutive columns of a 16-bit row (the 256-tile kernels): one 16-byte access per operand when its rows
+// are 16-byte aligned, element accesses otherwise
+template <bool BF>
+__device__ __forceinline__ void h_ld8(const void *base, int64_t ld, int64_t row, int64_t col, float (&f)[8]) {
+    const uint16_t *p = (const uint16_t *)base + row * ld + col;
+    uint32_t w[4];
+    if (ld % 8 == 0 && (uintptr_t)base % 16 == 0) {
+        const uint4 q = *(const uint4 *)p;
+        w[0] = q.x, w[1] = q.y, w[2] = q.z, w[3] = q.w;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (uint32_t)p[2 * e] | ((uint32_t)p[2 * e + 1] << 16);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint16_t o = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+        f[e] = BF ? bf16_to_f32(bf16_t{o}) : f16_to_f32(f16_t{o});
+    }
+}
+template <bool BF>
+__device__ __forceinline__ void h_st8(void *base, int64_t ld, int64_t row, int64_t col, const float (&f)[8]) {
+    uint16_t *p = (uint16_t *)base + row * ld + col;
+    uint32_t w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const uint16_t h0 = BF ? f32_to_bf16(f[2 * e]).x : f32_to_f16(f[2 * e]).x;
+        const uint16_t h1 = BF ? f32_to_bf16(f[2 * e + 1]).x : f32_to_f16(f[2 * e + 1]).x;
+        w[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+    }
+    if (ld % 8 == 0 && (uintptr_t)base % 16 == 0) {
+        *(uint4 *)p = uint4{w[0], w[1], w[2], w[3]};
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p[e] = (uint16_t)(w[e >> 1] >> ((e & 1) * 16));
+    }
+}
+template <bool BF>
+__device__ __forceinline__ void h_epi8(const GemmArgs &g, int64_t row, int64_t col, float (&v)[8]) {
+    if (g.aux) h_st8<BF>(g.aux, g.ldaux, row, col, v);
+    if (g.mul) {
+        float x[8];
+        h_ld8<BF>(g.mul, g.ldmul, row, col, x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= x[e];
+    }
+    if (g.add) {
+        float x[8];
+        h_ld8<BF>(g.add, g.ldadd, row, col, x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += x[e];
+    }
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_generic_kernel(const GemmArgs g, int ta, int tb) {
@@ -116,7 +181,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GemmArgs g, int
                 A_t v = (A_t)g.alpha * acc[i][j];
                 if (g.beta != 0.f) v += (A_t)g.beta * g_load<T>(C + m * g.ldc + n);
                 if (g.epilogue == KF_EPI_BIAS_ROW) v += g_load<T>((const T *)g.bias + n);
-                g_store<T>(C + m * g.ldc + n, v);
+                g_store<T>(C + m * g.ldc + n, g_epi<T>(g, m, n, v));
             }
         }
 }
@@ -240,7 +305,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmArgs g) {
                 const int64_t m = m0 + wr * (T / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kl;
                 float v = g.alpha * acc[i][j][e];
                 if (g.beta != 0.f) v += g.beta * C[m * g.ldc + n];
-                C[m * g.ldc + n] = v + bias;
+                C[m * g.ldc + n] = g_epi<float>(g, m, n, v + bias);
             }
         }
 }
@@ -349,7 +414,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const GemmArgs g) {
                 const int64_t m = m0 + wr * 32 + i * 16 + fk + 4 * e;
                 double v = (double)g.alpha * acc[i][j][e];
                 if (g.beta != 0.f) v += (double)g.beta * C[m * g.ldc + n];
-                C[m * g.ldc + n] = v + bias;
+                C[m * g.ldc + n] = g_epi<double>(g, m, n, v + bias);
             }
         }
 }
@@ -513,6 +578,7 @@ __global__ __launch_bounds__(256) void gemm_h_kernel(const GemmArgs g) {
                     v += g.beta * (BF ? bf16_to_f32(bf16_t{old}) : f16_to_f32(f16_t{old}));
                 }
                 v += bias;
+                if (BF) v = g_epi<bf16_t>(g, m, n, v); else v = g_epi<f16_t>(g, m, n, v);
                 C[m * g.ldc + n] = BF ? f32_to_bf16(v).x : f32_to_f16(v).x;
             }
         }
@@ -813,6 +879,7 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_h256_kernel(const GemmArgs g) {
                     v[e] += g.beta * (BF ? bf16_to_f32(bf16_t{o}) : f16_to_f32(f16_t{o}));
                 }
             }
+            h_epi8<BF>(g, row, col, v);
             uint32_t w[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1147,9 +1214,29 @@ extern "C" int kfdbg_gemm_clock(int64_t M, int64_t N, int64_t K, const void *A, 
 }
 #endif
 
+static int gemm_impl(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const void *A, int64_t lda, const void *B,
+                     int64_t ldb, float beta, void *C, int64_t ldc, int epilogue, const void *bias, const kf_gemm_epilogue *ex, void *stream);
+
 extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const void *A,
                        int64_t lda, const void *B, int64_t ldb, float beta, void *C, int64_t ldc, int epilogue,
                        const void *bias, void *workspace, size_t workspace_bytes, void *stream) {
+    (void)workspace; (void)workspace_bytes; // no kernel needs scratch (kf_gemm_workspace_bytes reports 0)
+    return gemm_impl(dtype, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, epilogue, bias, nullptr, stream);
+}
+
+extern "C" int kf_gemm_ex(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const void *A, int64_t lda,
+                          const void *B, int64_t ldb, float beta, void *C, int64_t ldc, const kf_gemm_epilogue *epi, void *stream) {
+    KF_REQUIRE(epi, KF_ERR_INVALID, "kf_gemm_ex: null epilogue");
+    KF_REQUIRE(!epi->mul || epi->ldmul >= N, KF_ERR_INVALID, "kf_gemm_ex: mul operand's leading dimension too small");
+    KF_REQUIRE(!epi->add || epi->ldadd >= N, KF_ERR_INVALID, "kf_gemm_ex: add operand's leading dimension too small");
+    KF_REQUIRE(!epi->aux || epi->ldaux >= N, KF_ERR_INVALID, "kf_gemm_ex: aux output's leading dimension too small");
+    KF_REQUIRE(!epi->aux || epi->aux != C, KF_ERR_INVALID, "kf_gemm_ex: aux must not alias C");
+    return gemm_impl(dtype, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, epi->bias ? KF_EPI_BIAS_ROW : KF_EPI_NONE, epi->bias, epi,
+                     stream);
+}
+
+static int gemm_impl(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const void *A, int64_t lda, const void *B,
+                     int64_t ldb, float beta, void *C, int64_t ldc, int epilogue, const void *bias, const kf_gemm_epilogue *ex, void *stream) {
     KF_REQUIRE(dtype == KF_F32 || dtype == KF_F64 || dtype == KF_F16 || dtype == KF_BF16, KF_ERR_UNSUPPORTED,
                "kf_gemm: dtype %d not supported (float, double, half, bfloat16)", dtype);
     KF_REQUIRE(M >= 0 && N >= 0 && K >= 0, KF_ERR_INVALID, "kf_gemm: negative extent");
@@ -1160,6 +1247,7 @@ extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N
     KF_REQUIRE((M + 63) / 64 * ((N + 63) / 64) <= 0x7fffffffLL, KF_ERR_INDEX_RANGE, "kf_gemm: too many output tiles for one launch");
     hipStream_t st = as_stream(stream);
     GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, beta, epilogue, 0};
+    if (ex) { g.mul = ex->mul; g.add = ex->add; g.aux = ex->aux; g.ldmul = ex->ldmul; g.ldadd = ex->ldadd; g.ldaux = ex->ldaux; }
     g.group_m = (int)knob_int(KNOB_GEMM_GROUP_M, 4);
 
     const bool al16 = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0);
@@ -1192,7 +1280,9 @@ extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N
     }
     if ((dtype == KF_BF16 || dtype == KF_F16) && h_fast_ok(M, N, K) && al16 && lda % 8 == 0 && ldb % 8 == 0) {
         if (h256_ok(M, N, K)) { // every operand layout is consumed in place
-            const bool w4 = h256_use_w4(M, N); // profile labels name the kernel that ran (tests assert them)
+            // the 4-wave kernel has no register to spare for the element-wise tail (its 512 are accumulators + fragments; the
+            // tail made it spill): products with mul / add / aux operands take the 8-wave kernel
+            const bool w4 = h256_use_w4(M, N) && !(g.mul || g.add || g.aux); // profile labels name the kernel that ran (tests assert them)
             KF_PROF(dtype == KF_BF16 ? (w4 ? "gemm_bf16_mfma" : "gemm_bf16_mfma_w8") : (w4 ? "gemm_f16_mfma" : "gemm_f16_mfma_w8"), st);
             return dtype == KF_BF16 ? launch_h256<true>(g, trans_a != 0, !trans_b, w4, st) : launch_h256<false>(g, trans_a != 0, !trans_b, w4, st);
         }

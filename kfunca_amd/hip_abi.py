@@ -41,7 +41,7 @@ EXPORTS = [
     "kf_device_props_get", "kf_elementwise", "kf_reduce_workspace_bytes", "kf_reduce",
     "kf_reduce_moments_workspace_bytes", "kf_reduce_moments",
     "kf_norm_fwd", "kf_norm_bwd_workspace_bytes", "kf_norm_bwd",
-    "kf_index_put", "kf_index_get", "kf_index_add_workspace_bytes", "kf_index_add", "kf_sort_workspace_bytes", "kf_sort", "kf_gemm_workspace_bytes", "kf_gemm", "kf_attn_fwd", "kf_attn_fwd_scaled", "kf_attn_bwd_workspace_bytes",
+    "kf_index_put", "kf_index_get", "kf_index_add_workspace_bytes", "kf_index_add", "kf_sort_workspace_bytes", "kf_sort", "kf_gemm_workspace_bytes", "kf_gemm", "kf_gemm_ex", "kf_attn_fwd", "kf_attn_fwd_scaled", "kf_attn_bwd_workspace_bytes",
     "kf_attn_bwd", "kf_attn_bwd_scaled", "kf_attn_fwd_strided", "kf_attn_bwd_strided", "kf_comm_unique_id", "kf_comm_init", "kf_comm_destroy", "kf_allreduce_sum",
 ]
 
@@ -57,6 +57,12 @@ class IterDesc(C.Structure):
     _fields_ = [("ndim", C.c_int32), ("ntensors", C.c_int32), ("noutputs", C.c_int32), ("reserved", C.c_int32),
                 ("dtype", C.c_int32 * MAX_TENSORS), ("shape", C.c_int64 * MAX_DIMS),
                 ("stride_bytes", (C.c_int64 * MAX_DIMS) * MAX_TENSORS), ("data", C.c_void_p * MAX_TENSORS)]
+
+
+class GemmEpilogue(C.Structure):
+    """kf_gemm_epilogue: C = (alpha AB + beta C + bias) o mul + add, aux = the value in brackets."""
+    _fields_ = [("bias", C.c_void_p), ("mul", C.c_void_p), ("ldmul", C.c_int64), ("add", C.c_void_p), ("ldadd", C.c_int64),
+                ("aux", C.c_void_p), ("ldaux", C.c_int64)]
 
 
 class AttnLayout(C.Structure):
@@ -122,6 +128,8 @@ def lib():
         _lib.kf_gemm_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int, i64, i64, i64, C.POINTER(sz)]
         _lib.kf_gemm.argtypes = [C.c_int, C.c_int, C.c_int, i64, i64, i64, C.c_float, vp, i64, vp, i64, C.c_float,
                                  vp, i64, C.c_int, vp, vp, sz, vp]
+        _lib.kf_gemm_ex.argtypes = [C.c_int, C.c_int, C.c_int, i64, i64, i64, C.c_float, vp, i64, vp, i64, C.c_float, vp, i64,
+                                    C.POINTER(GemmEpilogue), vp]
         _lib.kf_attn_fwd.argtypes = [C.c_int, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp]
         _lib.kf_attn_bwd_workspace_bytes.argtypes = [C.c_int, i64, i64, i64, i64, i64, C.POINTER(sz)]
         _lib.kf_attn_bwd.argtypes = [C.c_int, i64, i64, i64, i64, i64] + [vp] * 10 + [sz, vp]
@@ -449,6 +457,12 @@ def gemm(dtype, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, beta, Cptr, ld
          workspace=None, workspace_bytes=0, stream=None):
     check(lib().kf_gemm(dtype, int(trans_a), int(trans_b), M, N, K, alpha, A, lda, B, ldb, beta, Cptr, ldc,
                         epilogue, bias, workspace, workspace_bytes, stream))
+
+
+def gemm_ex(dtype, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, beta, Cptr, ldc, bias=None, mul=None, ldmul=0, add=None, ldadd=0,
+            aux=None, ldaux=0, stream=None):
+    e = GemmEpilogue(bias, mul, ldmul, add, ldadd, aux, ldaux)
+    check(lib().kf_gemm_ex(dtype, int(trans_a), int(trans_b), M, N, K, alpha, A, lda, B, ldb, beta, Cptr, ldc, C.byref(e), stream))
 
 
 def attn_fwd(dtype, B, H, Sq, Skv, D, q, k, v, o, lse=None, stream=None):

@@ -226,3 +226,48 @@ def test_errors():
             for tb in (False, True):
                 for (M, N, K) in ((128, 128, 64), (2048, 2048, 2048), (4096, 4096, 4096), (100, 130, 70)):
                     assert H.gemm_workspace_bytes(code, ta, tb, M, N, K) == 0
+
+
+@pytest.mark.parametrize("code,M,N,K,label", [
+    (H.F32, 256, 384, 64, "gemm_f32_mfma_t64"), (H.F32, 2048, 2048, 32, "gemm_f32_mfma"), (H.F64, 128, 192, 48, "gemm_f64_mfma"),
+    (H.BF16, 256, 384, 128, "gemm_bf16_mfma_128"), (H.F16, 384, 256, 64, "gemm_f16_mfma_128"),
+    (H.BF16, 2560, 4096, 128, "gemm_bf16_mfma_w8"), (H.F16, 2560, 4096, 64, "gemm_f16_mfma_w8"), (H.BF16, 100, 130, 70, "gemm_generic"),
+    (H.F32, 33, 65, 17, "gemm_generic")])
+def test_fused_elementwise_tail(code, M, N, K, label):
+    """kf_gemm_ex: C = (alpha A B + beta C + bias) o mul + add with aux = the bracket, on every kernel family (label asserted).
+    aux must equal what kf_gemm alone stores (bit for bit: same arithmetic, same rounding); C against f64 numpy on the
+    dtype-rounded inputs with the GEMM bound of this file plus one rounding of the result. A wide (ld > N) mul operand and a
+    tight add operand exercise both access forms of the 16-bit tail."""
+    eps = {H.BF16: 2.0 ** -8, H.F16: 2.0 ** -11, H.F32: 1e-6, H.F64: 1e-13}[code]
+    rng = np.random.default_rng(M + N + K + code)
+    mk = lambda shp: O.from_float(rng.uniform(-1, 1, shp).astype(np.float32), code) if code != H.F64 else rng.uniform(-1, 1, shp)  # noqa: E731
+    a, b, c, bias, mul_w, add = mk((M, K)), mk((K, N)), mk((M, N)), mk((N,)), mk((M, N + 8)), mk((M, N))
+    f = lambda x: (O.to_float(x, code) if code != H.F64 else x).astype(np.float64)  # noqa: E731
+    da, db, dbias, dmul, dadd = (H.DevBuf.from_numpy(x) for x in (a, b, bias, mul_w, add))
+    dc, daux, dplain = H.DevBuf.from_numpy(c), H.DevBuf(c.nbytes), H.DevBuf.from_numpy(c)
+    H.gemm(code, 0, 0, M, N, K, 0.5, da.ptr, K, db.ptr, N, 2.0, dplain.ptr, N, H.EPI_BIAS_ROW, dbias.ptr, None, 0)
+    H.profile_reset()
+    H.profile_enable(True)
+    H.gemm_ex(code, 0, 0, M, N, K, 0.5, da.ptr, K, db.ptr, N, 2.0, dc.ptr, N, bias=dbias.ptr, mul=dmul.ptr, ldmul=N + 8, add=dadd.ptr, ldadd=N,
+              aux=daux.ptr, ldaux=N)
+    H.device_sync()
+    H.profile_enable(False)
+    assert set(H.profile_results()) == {label}, H.profile_results()
+    plain, aux, got = dplain.to_numpy((M, N), a.dtype), daux.to_numpy((M, N), a.dtype), dc.to_numpy((M, N), a.dtype)
+    if label.endswith("_w8") or label.endswith("_128") or code in (H.F32, H.F64) or label == "gemm_generic":
+        # the plain product of the 2560 x 4096 shapes runs the 4-wave kernel (another accumulation order): compare through the bound there
+        same = not label.endswith("_w8")
+        if same:
+            assert np.array_equal(aux.view(np.uint8), plain.view(np.uint8)), "aux differs from the plain product"
+    raw = 0.5 * (f(a) @ f(b)) + 2.0 * f(c) + f(bias)[None, :]
+    mag = np.abs(f(a)) @ np.abs(f(b)) + 2.0 * np.abs(f(c)) + 1.0
+    assert (np.abs(f(aux) - raw) <= 2 * eps * np.abs(raw) + 2e-6 * mag * (1 if code != H.F64 else 1e-7) + 2 * eps).all(), "aux"
+    want = raw * f(mul_w)[:, :N] + f(add)
+    assert (np.abs(f(got) - want) <= 4 * eps * (np.abs(want) + np.abs(raw)) + 2e-6 * mag * (1 if code != H.F64 else 1e-7) + 4 * eps).all(), "C"
+    # each operand alone
+    for kw, expect in ((dict(mul=dmul.ptr, ldmul=N + 8), raw * f(mul_w)[:, :N]), (dict(add=dadd.ptr, ldadd=N), raw + f(add))):
+        H.check(H.lib().kf_memcpy_h2d(dc.ptr, c.ctypes.data, c.nbytes, None))
+        H.gemm_ex(code, 0, 0, M, N, K, 0.5, da.ptr, K, db.ptr, N, 2.0, dc.ptr, N, bias=dbias.ptr, **kw)
+        H.device_sync()
+        got1 = f(dc.to_numpy((M, N), a.dtype))
+        assert (np.abs(got1 - expect) <= 4 * eps * (np.abs(expect) + np.abs(raw)) + 2e-6 * mag * (1 if code != H.F64 else 1e-7) + 4 * eps).all(), kw.keys()
