@@ -265,6 +265,10 @@ PYBIND11_MODULE(_C, m) {
         return gpu::layer_norm(x, w.is_none() ? Tensor() : w.cast<Tensor>(), b.is_none() ? Tensor() : b.cast<Tensor>(), eps);
     }, py::arg("x"), py::arg("weight") = py::none(), py::arg("bias") = py::none(), py::arg("eps") = 1e-5);
     m.def("embedding", &gpu::embedding, py::arg("table"), py::arg("indices"));
+    m.def("gemm_fused", [](const Tensor &a, const Tensor &b, float alpha, py::object bias, py::object mul, py::object add) {
+        auto opt = [](py::object o) { return o.is_none() ? Tensor() : o.cast<Tensor>(); };
+        return gpu::gemm_fused(a, b, alpha, opt(bias), opt(mul), opt(add));
+    }, py::arg("a"), py::arg("b"), py::arg("alpha") = 1.0f, py::arg("bias") = py::none(), py::arg("mul") = py::none(), py::arg("add") = py::none());
     m.def("causal_attention_qkv", &gpu::causal_attention_qkv, py::arg("qkv"), py::arg("B"), py::arg("S"), py::arg("H"));
     // from_numpy for bfloat16: uint16 bit patterns in, a BFloat16 tensor out (the inverse of to_numpy's uint16 view)
     m.def("from_numpy_bf16", [](py::array array, int device) {

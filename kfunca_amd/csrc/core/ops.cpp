@@ -490,6 +490,87 @@ Tensor gemm(const Tensor &a, const Tensor &b, float alpha, float beta) {
     return out;
 }
 
+// ---- gemm with the fused element-wise tail ------------------------------------------------------------------------------------
+namespace {
+// y = (alpha a b + bias) o mul + add. With t = the bracket: d_add = g; d_mul = g o t (t kept only when mul wants a gradient);
+// d_t = g o mul; d_bias = column sums of d_t; da = alpha d_t b^T, db = alpha a^T d_t.
+class GemmFusedGradFunction : public GradFunction {
+public:
+    GemmFusedGradFunction(const Tensor &a, const Tensor &b, const Tensor &bias, const Tensor &mul, const Tensor &add, const Tensor &raw, float alpha)
+        : alpha_(alpha), raw_(raw) {
+        inputs = {a, b};
+        ibias_ = imul_ = iadd_ = -1;
+        if (bias.defined()) { ibias_ = (int)inputs.size(); inputs.push_back(bias); }
+        if (mul.defined()) { imul_ = (int)inputs.size(); inputs.push_back(mul); }
+        if (add.defined()) { iadd_ = (int)inputs.size(); inputs.push_back(add); }
+    }
+    std::vector<Tensor> backward(Tensor g) override {
+        const Tensor &a = inputs[0], &b = inputs[1];
+        const int64_t K = b.shape(0), N = b.shape(1), M = a.numel() / K;
+        Tensor g2 = g.contiguous().view({M, N});
+        std::vector<Tensor> out(inputs.size());
+        if (iadd_ >= 0 && inputs[iadd_].requires_grad()) out[iadd_] = g2.view(inputs[iadd_].sizes());
+        Tensor dt = g2;
+        if (imul_ >= 0) {
+            const Tensor m2 = inputs[imul_].view({M, N});
+            if (inputs[imul_].requires_grad()) out[imul_] = mul(g2, raw_.view({M, N})).view(inputs[imul_].sizes());
+            if (a.requires_grad() || b.requires_grad() || (ibias_ >= 0 && inputs[ibias_].requires_grad())) dt = mul(g2, m2);
+        }
+        if (ibias_ >= 0 && inputs[ibias_].requires_grad()) out[ibias_] = sum(dt, 0).view({N});
+        Tensor a2 = a.view({M, K});
+        if (a.requires_grad()) {
+            out[0] = empty(a.sizes(), a.dtype(), a.device());
+            Tensor c2 = out[0].view({M, K});
+            gemm_any(a.dtype(), false, true, M, K, N, alpha_, dt, b, 0.f, c2, a.device());
+        }
+        if (b.requires_grad()) {
+            out[1] = empty(b.sizes(), b.dtype(), b.device());
+            gemm_any(a.dtype(), true, false, K, N, M, alpha_, a2, dt, 0.f, out[1], b.device());
+        }
+        return out;
+    }
+
+private:
+    float alpha_;
+    Tensor raw_;
+    int ibias_, imul_, iadd_;
+};
+} // namespace
+
+Tensor gemm_fused(const Tensor &a, const Tensor &b, float alpha, const Tensor &bias, const Tensor &mul_t, const Tensor &add_t) {
+    CHECK_FAIL(a.defined() && b.defined() && a.is_contiguous() && b.is_contiguous() && a.dim() >= 1 && b.dim() == 2);
+    const int64_t k = a.shape(-1), n = b.shape(1);
+    CHECK_FAIL(k > 0 && b.shape(0) == k && n > 0 && a.dtype() == b.dtype() && a.device() == b.device());
+    CHECK_FAIL(gemm_dtype_ok(a.dtype()), "Unsupported ScalarType ", a.dtype());
+    const int64_t m = a.numel() / k;
+    auto out_size = a.sizes();
+    out_size.back() = n;
+    for (const Tensor *t : {&mul_t, &add_t})
+        if (t->defined()) CHECK_FAIL(t->is_contiguous() && t->dtype() == a.dtype() && t->device() == a.device() && t->numel() == m * n && t->shape(-1) == n,
+                                     "gemm_fused: mul / add must be contiguous tensors of the output's shape and dtype");
+    if (bias.defined()) CHECK_FAIL(bias.is_contiguous() && bias.dim() == 1 && bias.shape(0) == n && bias.dtype() == a.dtype() && bias.device() == a.device(),
+                                   "gemm_fused: bias must be a contiguous [N] tensor of the operands' dtype");
+    Tensor out = empty(out_size, a.dtype(), a.device());
+    const bool keep_raw = mul_t.defined() && mul_t.requires_grad();
+    Tensor raw = keep_raw ? empty({m, n}, a.dtype(), a.device()) : Tensor();
+    if (m > 0) {
+        kf_gemm_epilogue e{};
+        e.bias = bias.defined() ? bias.data_ptr() : nullptr;
+        e.mul = mul_t.defined() ? mul_t.data_ptr() : nullptr;
+        e.add = add_t.defined() ? add_t.data_ptr() : nullptr;
+        e.aux = keep_raw ? raw.data_ptr() : nullptr;
+        e.ldmul = e.ldadd = e.ldaux = n;
+        DEV_CALL(kf_gemm_ex(code(a.dtype()), 0, 0, m, n, k, alpha, a.data_ptr(), k, b.data_ptr(), n, 0.f, out.data_ptr(), n, &e, dev::stream(a.device())));
+    }
+    bool grad = a.requires_grad() || b.requires_grad();
+    for (const Tensor *t : {&bias, &mul_t, &add_t}) grad = grad || (t->defined() && t->requires_grad());
+    if (grad) {
+        out.set_requires_grad(true);
+        out.set_grad_fn(new GemmFusedGradFunction(a, b, bias, mul_t, add_t, raw, alpha));
+    }
+    return out;
+}
+
 Tensor gemm_ex(const Tensor &a, bool trans_a, const Tensor &b, bool trans_b, float alpha) {
     CHECK_FAIL(a.dim() == 2 && b.dim() == 2 && a.is_contiguous() && b.is_contiguous());
     CHECK_FAIL(a.dtype() == b.dtype() && gemm_dtype_ok(a.dtype()));

@@ -65,6 +65,10 @@ Tensor embedding(const Tensor &table, const Tensor &indices);
 //   QKV projection (columns q | k | v, each H heads of D); q, k, v are read IN PLACE, the result is [B*S, H*D] - the layout
 //   the output projection takes - and the backward writes one packed gradient: no split / permute / contiguous copies
 Tensor causal_attention_qkv(const Tensor &qkv, int64_t B, int64_t S, int64_t H);
+//   gemm_fused (fused projections, README.md:32): out = (alpha a b + bias) o mul + add in ONE kernel (kf_gemm_ex) - what the
+//   reference API spells gemm + add + mul + add over three extra passes of the output. bias [N]; mul, add shaped like the output;
+//   any of the three may be undefined. Residual connection: add = the stream; gated MLP: mul = the other projection.
+Tensor gemm_fused(const Tensor &a, const Tensor &b, float alpha, const Tensor &bias, const Tensor &mul, const Tensor &add);
 
 // extensions used by the backward passes (no reference counterpart)
 Tensor gemm_ex(const Tensor &a, bool trans_a, const Tensor &b, bool trans_b, float alpha);

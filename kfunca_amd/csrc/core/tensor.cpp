@@ -331,9 +331,20 @@ void Tensor::update_grad(Tensor grad) {
     if (impl->grad_) {
         *impl->grad_ += grad;
     } else {
-        Tensor g = empty_like(grad);
-        g.copy_(grad);
-        impl->grad_ = std::make_unique<Tensor>(g);
+        // First gradient of a leaf. The reference copies it (tensor.cpp:75-84); a gradient that nobody else can see - a fresh,
+        // dense tensor owning its whole storage, referenced only by the engine's own handles (the accumulator slot, the loop's
+        // local and this parameter) - is adopted instead: for a weight gradient that is one read + one write of the parameter's
+        // size saved per step. Anything shared (the SAME tensor handed to two inputs, as add's backward does; a view; the
+        // caller's own grad_output) is still copied.
+        const bool exclusive = grad.impl_ref_count() <= 3 && grad.storage_ref_count() == 1 && grad.is_contiguous() && grad.storage_offset() == 0 &&
+                               (size_t)grad.numel() * (size_t)grad.element_size_in_bytes() <= grad.storage_bytes() && !grad.has_grad_fn();
+        if (exclusive) {
+            impl->grad_ = std::make_unique<Tensor>(grad);
+        } else {
+            Tensor g = empty_like(grad);
+            g.copy_(grad);
+            impl->grad_ = std::make_unique<Tensor>(g);
+        }
     }
 }
 
