@@ -358,6 +358,9 @@ PYBIND11_MODULE(_C, m) {
         .def("requires_grad", &Tensor::requires_grad)
         .def("set_requires_grad", &Tensor::set_requires_grad)
         .def("backward", &Tensor::backward)
+        // extension: drop the accumulated gradient (an optimizer's zero_grad(set_to_none)); the next backward's first gradient is
+        // then taken over without a copy when nothing else refers to it
+        .def("zero_grad", [](Tensor &self) { self.impl()->grad_.reset(); })
         .def("grad", [](Tensor &self) {
             if (self.grad() && self.grad()->defined()) return *self.grad();
             return Tensor();

@@ -256,23 +256,45 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const NormArgs a) {
     }
 }
 
-// dw[c] = sum over blocks (in block order) of part[blk][0][c]; db likewise from part[blk][1][c]
+// dw[c] = sum over blocks of part[blk][0][c], db likewise from part[blk][1][c], in a FIXED order: a block owns 64 columns, its
+// four waves take the partial rows k = wave, wave + 4, ... (eight independent running sums per lane keep the loads in flight:
+// one thread walking all partial rows of a column serially took 0.26 ms for 1024 x 4096), and the four waves' sums are added in
+// wave order through LDS.
 template <typename T>
 __global__ __launch_bounds__(256) void norm_fold_kernel(const float *part, int nblk, int64_t cols, void *dw, void *db) {
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
-    float sw = 0.f, sb = 0.f;
-    for (int k = 0; k < nblk; ++k) {
-        sw += part[((int64_t)k * 2) * cols + c];
-        sb += part[((int64_t)k * 2 + 1) * cols + c];
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * 64 + cl;
+    float sw[8], sb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { sw[u] = 0.f; sb[u] = 0.f; }
+    if (c < cols) {
+        int k = kl;
+        for (; k + 28 < nblk; k += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                sw[u] += part[((int64_t)(k + 4 * u) * 2) * cols + c];
+                sb[u] += part[((int64_t)(k + 4 * u) * 2 + 1) * cols + c];
+            }
+        }
+        for (; k < nblk; k += 4) {
+            sw[0] += part[((int64_t)k * 2) * cols + c];
+            sb[0] += part[((int64_t)k * 2 + 1) * cols + c];
+        }
     }
+    red[0][kl][cl] = ((sw[0] + sw[1]) + (sw[2] + sw[3])) + ((sw[4] + sw[5]) + (sw[6] + sw[7]));
+    red[1][kl][cl] = ((sb[0] + sb[1]) + (sb[2] + sb[3])) + ((sb[4] + sb[5]) + (sb[6] + sb[7]));
+    __syncthreads();
+    if (kl != 0 || c >= cols) return;
+    const float tw = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+    const float tb = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
     auto st = [](void *p, int64_t i, float v) {
         if constexpr (sizeof(T) == 4) ((float *)p)[i] = v;
         else if constexpr (std::is_same<T, bf16_t>::value) ((bf16_t *)p)[i] = f32_to_bf16(v);
         else ((f16_t *)p)[i] = f32_to_f16(v);
     };
-    if (dw) st(dw, c, sw);
-    if (db) st(db, c, sb);
+    if (dw) st(dw, c, tw);
+    if (db) st(db, c, tb);
 }
 
 // ---- generic rows (any length, any alignment): one block per row, strided loops, x re-read from L2 -------------------
@@ -487,9 +509,10 @@ extern "C" int kf_norm_bwd(int kind, int dtype, int64_t rows, int64_t cols, int6
     }
     if (sums) {
         KF_PROF("norm_bwd_fold", st);
-        if (dtype == KF_F32) norm_fold_kernel<float><<<gc, 256, 0, st>>>(a.part, nblk, cols, dweight, dbias);
-        else if (dtype == KF_BF16) norm_fold_kernel<bf16_t><<<gc, 256, 0, st>>>(a.part, nblk, cols, dweight, dbias);
-        else norm_fold_kernel<f16_t><<<gc, 256, 0, st>>>(a.part, nblk, cols, dweight, dbias);
+        const unsigned gf = (unsigned)((cols + 63) / 64);
+        if (dtype == KF_F32) norm_fold_kernel<float><<<gf, 256, 0, st>>>(a.part, nblk, cols, dweight, dbias);
+        else if (dtype == KF_BF16) norm_fold_kernel<bf16_t><<<gf, 256, 0, st>>>(a.part, nblk, cols, dweight, dbias);
+        else norm_fold_kernel<f16_t><<<gf, 256, 0, st>>>(a.part, nblk, cols, dweight, dbias);
         KF_LAUNCH_CHECK();
     }
     return KF_OK;

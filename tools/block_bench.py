@@ -22,6 +22,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--json", default="")
     ap.add_argument("--graph", action="store_true", help="capture one step into a HIP graph and time its replays")
+    ap.add_argument("--form", choices=["reference", "fused", "fused-norm"], default="reference",
+                    help="reference: only operators the reference API has; fused: attention on the packed QKV projection + GEMM tails "
+                         "(same math); fused-norm: that plus the two rms_norms of a real pre-norm block")
     args = ap.parse_args()
     B, S, Hh, D, f = 1, 4096, 32, 128, 16384
     d, T = Hh * D, B * S
@@ -35,14 +38,31 @@ def main():
     x = param((T, d), 1.0)
     w = [param(s, 1.0 / np.sqrt(s[0])) for s in ((d, 3 * d), (d, d), (d, f), (d, f), (f, d))]
     g = kfunca.from_numpy(rng.uniform(-1, 1, (T, d)).astype(np.float32), 0).bfloat16()
+    gains = [param((d,), 1.0) for _ in range(2)]
 
-    def step():
+    def step_fused():
+        n1 = kfunca.rms_norm(x, gains[0], 1e-5) if args.form == "fused-norm" else x
+        a = kfunca.causal_attention_qkv(kfunca.gemm(n1, w[0], 1.0, 0.0), B, S, Hh)
+        h = kfunca.gemm_fused(a, w[1], 1.0, None, None, x)
+        n2 = kfunca.rms_norm(h, gains[1], 1e-5) if args.form == "fused-norm" else h
+        up = kfunca.gemm(n2, w[3], 1.0, 0.0)
+        y = kfunca.gemm_fused(kfunca.gemm_fused(n2, w[2], 1.0, None, up, None), w[4], 1.0, None, None, h)
+        y.backward(g)
+
+    def step_reference():
         qkv = kfunca.gemm(x, w[0], 1.0, 0.0)
         q, k, v = (t.contiguous().view(B, S, Hh, D).permute(0, 2, 1, 3).contiguous() for t in qkv.split([d, d, d], 1))
         a = kfunca.causal_attention(q, k, v).permute(0, 2, 1, 3).contiguous().view(T, d)
         h = x + kfunca.gemm(a, w[1], 1.0, 0.0)
         y = h + kfunca.gemm(kfunca.gemm(h, w[2], 1.0, 0.0) * kfunca.gemm(h, w[3], 1.0, 0.0), w[4], 1.0, 0.0)
         y.backward(g)
+
+    body = step_reference if args.form == "reference" else step_fused
+
+    def step():  # one training step's shape: gradients start empty (an optimizer's zero_grad), forward, backward
+        for t in [x] + w + gains:
+            t.zero_grad()
+        body()
 
     for _ in range(args.warmup):
         step()
@@ -68,7 +88,8 @@ def main():
     ms = (t1 - t0) / args.steps * 1e3
     flops = 6.0 * T * d * (4 * d + 3 * f) + 14.0 * B * S * S * d / 2
     prof = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps} for k, v in H.profile_results().items()}
-    out = {"mode": "hip graph replay" if args.graph else "eager", "config": "C5 shard: bf16 block fwd+bwd, B=1 S=4096 d=4096 H=32 D=128 f=16384, Python operator API + Tensor.backward",
+    ew = sum(v["launches_per_step"] for k, v in prof.items() if k.startswith("ew_"))
+    out = {"mode": "hip graph replay" if args.graph else "eager", "form": args.form, "elementwise_launches_per_step": ew, "config": "C5 shard: bf16 block fwd+bwd, B=1 S=4096 d=4096 H=32 D=128 f=16384, Python operator API + Tensor.backward",
            "ms_per_step": ms, "tokens_per_s": T / (ms * 1e-3), "matrix_tflops": flops / (ms * 1e-3) / 1e12,
            "device_ms_per_step": sum(v["ms_per_step"] for v in prof.values()), "kernels": prof}
     print(json.dumps(out, indent=1))
