@@ -113,6 +113,24 @@ def main():
         keep = []
         ms, k = timed(tag, lambda: keep.append(H.reduce_moments(H.MOM_INVSTD if dim == 0 else H.MOM_VAR, d, 1.0, 1e-12)), args.rounds)
         record(tag, ms, es * rows * cols + 8 * nout, k)
+    # rms_norm / layer_norm rows: forward reads x, writes y; backward reads x and dy, writes dx (+ dw, db)
+    for (rows, cols, code, tag) in ((1 << 16, 8192, H.BF16, "bf16 [65536, 8192]"), (1 << 16, 4096, H.F32, "f32 [65536, 4096]"),
+                                    (1 << 18, 1024, H.BF16, "bf16 [262144, 1024] (one wave per row)")):
+        es = 2 if code == H.BF16 else 4
+        wbuf, mean, rstd, dwb, dbb = H.DevBuf(cols * es), H.DevBuf(4 * rows), H.DevBuf(4 * rows), H.DevBuf(cols * es), H.DevBuf(cols * es)
+        H.elementwise(H.EW_FILL, H.make_desc([view(wbuf, (cols,), code)], []), 0, 1.0)
+        for kind, kname in ((H.NORM_RMS, "rms_norm"), (H.NORM_LAYER, "layer_norm")):
+            ms, k = timed(kname, lambda: H.norm_fwd(kind, code, rows, cols, a.ptr, wbuf.ptr, None, 1e-5, c.ptr, mean.ptr, rstd.ptr), args.rounds)
+            record(f"{kname} fwd {tag}", ms, 2 * es * rows * cols, k)
+            keep = []
+            ms, k = timed(kname, lambda: keep.append(H.norm_bwd(kind, code, rows, cols, a.ptr, wbuf.ptr, mean.ptr, rstd.ptr, b.ptr, c.ptr, dwb.ptr,
+                                                                 dbb.ptr if kind == H.NORM_LAYER else None)), args.rounds)
+            record(f"{kname} bwd {tag}", ms, 3 * es * rows * cols, k)
+    # embedding gather: 1 Mi rows of 4096 bf16 (8 KiB) out of a 64 Ki-row table
+    nidx, ecols = 1 << 17, 4096
+    eidx = H.DevBuf.from_numpy(np.random.default_rng(1).integers(0, 1 << 16, size=nidx).astype(np.int64))
+    ms, k = timed("gather", lambda: H.index_get(a.ptr, 1 << 16, ecols * 2, eidx.ptr, nidx, c.ptr), args.rounds)
+    record("embedding gather bf16 128Ki rows x 4096 (table 512 MiB)", ms, 2 * nidx * ecols * 2, k)
     # index_put_: 16 Mi scattered 4-byte values into a 256 Mi-element tensor (2 int64 indices each)
     m = 1 << 24
     rng = np.random.default_rng(0)
