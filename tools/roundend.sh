@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 R="${KF_ROUND:-r02}"
 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3
 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -1
-python bench.py > gpurun_out/bench_$R.json 2> gpurun_out/bench_$R.err; tail -c 600 gpurun_out/bench_$R.err | grep -v NCCL | tail -3
+python bench.py > gpurun_out/bench_$R.json 2> gpurun_out/bench_$R.err || true; tail -c 600 gpurun_out/bench_$R.err | grep -v NCCL | tail -3 || true
 rm -rf gpurun_out/prof_$R
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$R -o $R -- python3 bench.py --steps 10 --warmup 3 > gpurun_out/bench_$R_prof.json 2> gpurun_out/prof_$R.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$R -o $R -- python3 bench.py --steps 10 --warmup 3 --sustain-seconds 0 --no-cpu-baseline > gpurun_out/bench_${R}_prof.json 2> gpurun_out/prof_$R.err
 find gpurun_out/prof_$R -name "*kernel_stats.csv" | head
