@@ -881,6 +881,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     const int64_t k0 = (int64_t)xb * K4B, kw = k0 + wid * 32, n = kw + xl;
 
     frag_t kf[8], vf[8]; // this wave's 32 keys: B operands of S = Q K^T and dP = dO V^T
+    const float c = a.scale * kLog2e;
     {
         const char *Kg = a.k + a_head(a.lk, bh, a.H) + n * a.lk.sr;
         const char *Vg = a.v + a_head(a.lv, bh, a.H) + n * a.lv.sr;
@@ -889,13 +890,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
             kf[kk] = *(const frag_t *)(Kg + (kk * 16 + 8 * hl) * 2);
             vf[kk] = *(const frag_t *)(Vg + (kk * 16 + 8 * hl) * 2);
         }
+        // K pre-scaled by c = scale log2(e), once per block: S'' = Q (c K)^T - lse log2(e) leaves the MFMA chain as the exponent
+        // itself (p = exp2(S''), no multiply per score: 32 VALU instructions fewer per slice pair). The 16-bit rounding of c K moves
+        // an exponent by ~1e-3 (p by < 1e-3 relative, a quarter of P's own 16-bit rounding); dK = scale dS^T Q does not see it.
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (BF) kf[kk][j] = (__bf16)((float)kf[kk][j] * c);
+                else kf[kk][j] = (_Float16)((float)kf[kk][j] * c);
+            }
     }
     f32x16 dk[4], dv[4];
 #pragma unroll
     for (int d = 0; d < 4; ++d)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { dk[d][e] = 0.f; dv[d][e] = 0.f; }
-    const float c = a.scale * kLog2e;
 
     // ---- per-lane LDS read addresses inside a slice buffer (tile image (a): off(row, ch) =
     //      2048 (row >> 3) + 512 (ch >> 2) + 64 (row & 7) + 16 ((ch & 3) ^ ((row >> 2) & 3)))
@@ -923,8 +933,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     const int ns = (int)(a.Sq / BQS), np = ns / 2;
     // dS tiles of this wave's 32 keys: tile (qb, kwb, sl) of the workspace, lane (key xl, half hl) writes operand s at
     // s * 1024 + xl * 32 + hl * 16 (see DS_TILE)
-    const unsigned ds_lane = (unsigned)(xl * 32 + hl * 16);
-    const int64_t ds_wave = ((bh * a.ds_nqb * a.ds_nkwb + (kw >> 5)) * 8) * DS_TILE; // + (qb nkwb 8 + sl) 2 KiB per slice
+    unsigned ds_lane = (unsigned)(xl * 32 + hl * 16);
+    const char *ds_base = DS ? a.ds + ((bh * a.ds_nqb * a.ds_nkwb + (kw >> 5)) * 8) * DS_TILE : nullptr; // + (qb nkwb 8 + sl) tiles per slice
+    const int ds_qb_tiles = (int)(a.ds_nkwb * 8);
     // a pair is 10 DMA operations per wave (ids 0..9: slice id / 5; Q rows i, dO rows i for i = 0, 1, then the row
     // constants); they are issued ONE per quarter-phase (an LDS-DMA instruction holds the wave's issue for 60-180 cycles,
     // which a lone wave per SIMD can only hide under MFMAs already queued)
@@ -973,13 +984,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     //   q6  pack dS (k1)                                        q7  the next slice's S accumulator takes its row constants
     s16x8 g0[4], g1[4];
     f32x4 cs[4], cp[4];
-    f32x16 sv;
+    f32x16 svA, svB; // S accumulators of the even / odd slice of a pair: each slice fills the OTHER one's row constants (no copies)
     k4_rowc<0>(lr, cs);
     k4_rows4<0>(rb_e, rb_o, g0);
     k4_rows4<1024>(rb_e, rb_o, g1);
     k4_rowc<128>(lr, cp);
     asm volatile("s_waitcnt lgkmcnt(12)" : "+a"(cs[0]), "+a"(cs[1]), "+a"(cs[2]), "+a"(cs[3]) : : "memory");
-    sv = k4_acc(cs);
+    svA = k4_acc(cs);
 
 #define K4_MFMA4(ACC, FR, BOP, K0)                                                                                   \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) ACC = a_mfma<BF>(__builtin_bit_cast(frag_t, FR[kk]), BOP[K0 + kk], ACC);
@@ -989,11 +1000,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
 
     // SOFF: this slice's offset inside its pair buffer (bases e, o, t0, t1, l); the next slice's first groups are read off
     // (en, on, ln) + NOFF; LAST: the slice that ends a pair (barrier + DMA of the pair after next before its q6)
-    auto slice_body = [&](auto mask_c, auto soff_c, auto noff_c, auto last_c, unsigned e, unsigned o, unsigned t0, unsigned t1, unsigned l,
-                          unsigned en, unsigned on, unsigned ln, int64_t qs, int pr, int it) __attribute__((always_inline)) {
+    auto slice_body = [&, ds_lane, ds_base, ds_qb_tiles](auto mask_c, auto soff_c, auto noff_c, auto last_c, f32x16 &sv, f32x16 &svn, unsigned e, unsigned o, unsigned t0,
+                          unsigned t1, unsigned l, unsigned en, unsigned on, unsigned ln, int64_t qs, int pr, int it) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(mask_c)::value, LAST = decltype(last_c)::value;
         constexpr int SOFF = decltype(soff_c)::value, NOFF = decltype(noff_c)::value, DO = SOFF + BQS * AROW;
-        f32x16 dpv, svn;
+        f32x16 dpv;
         s16x8 g2[4], g3[4];
         K4Tr t4, t5, t6, t7;
         frag_t pf[2], df[2];
@@ -1018,7 +1029,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         k4_wait4<12>(g2);
 #define K4_EXP2(E)                                                                      \
     _Pragma("unroll") for (int e_ = (E); e_ < (E) + 2; ++e_) {                          \
-        float pv = __builtin_amdgcn_exp2f(sv[e_] * c);                                  \
+        float pv = __builtin_amdgcn_exp2f(sv[e_]);                                      \
         if (MASK && n > qs + a_row(e_, hl)) pv = 0.f;                                   \
         pe[e_] = pv;                                                                    \
     }
@@ -1125,7 +1136,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         }
         if constexpr (DS) { // the slice's dS, already packed as two MFMA operands: two 1 KiB stores per wave (behind the DMA: K4_VMCNT)
             const int sl_ = (int)(qs >> 5);
-            const char *tile = a.ds + ds_wave + ((int64_t)(sl_ >> 3) * a.ds_nkwb * 8 + (sl_ & 7)) * DS_TILE;
+            const char *tile = ds_base + ((int64_t)((sl_ >> 3) * ds_qb_tiles + (sl_ & 7)) << 11); // 32-bit tile index, DS_TILE = 2^11
             const uint64_t tb = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile) |
                                 ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)tile >> 32)) << 32);
             // write-through (sc0 sc1): the lines leave the XCD's L2 instead of evicting the Q / dO slices the workgroups of a head
@@ -1135,7 +1146,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
                          : "v"(ds_lane), "v"(df[0]), "v"(df[1]), "s"(tb)
                          : "memory");
         }
-        sv = svn;
     };
 
     using I0 = std::integral_constant<int, 0>;
@@ -1145,8 +1155,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         const unsigned bn = (unsigned)(((it + 1) & 3) * K4PAIR);     // the next pair's
         const int64_t qa = (int64_t)pr * 2 * BQS, qb = qa + BQS;
         const unsigned e = rb_e + bo, o = rb_o + bo, t0 = tb_0 + bo, t1 = tb_1 + bo, l = lr + bo;
-        slice_body(mask_c, I0{}, IS{}, std::false_type{}, e, o, t0, t1, l, e, o, l, qa, pr, it);
-        slice_body(mask_c, IS{}, I0{}, std::true_type{}, e, o, t0, t1, l, rb_e + bn, rb_o + bn, lr + bn, qb, pr, it);
+        slice_body(mask_c, I0{}, IS{}, std::false_type{}, svA, svB, e, o, t0, t1, l, e, o, l, qa, pr, it);
+        slice_body(mask_c, IS{}, I0{}, std::true_type{}, svB, svA, e, o, t0, t1, l, rb_e + bn, rb_o + bn, lr + bn, qb, pr, it);
     };
     // two loops, one body each (a loop that switches between the masked and the plain body makes the allocator shuttle
     // the dK / dV accumulators between the two register files at every iteration)
@@ -2011,8 +2021,8 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
         const bool bf = dtype == KF_BF16;
         {
             KF_PROF("attn_bwd_delta", st);
-            if (bf) attn_delta_kernel<true><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, 1.0f / a.scale, a.lo, a.ldo, Sq, H);
-            else attn_delta_kernel<false><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, 1.0f / a.scale, a.lo, a.ldo, Sq, H);
+            if (bf) attn_delta_kernel<true><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, kLog2e, a.lo, a.ldo, Sq, H);
+            else attn_delta_kernel<false><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, kLog2e, a.lo, a.ldo, Sq, H);
             KF_LAUNCH_CHECK();
         }
         const bool keep_ds = bwd_keeps_ds(dtype, B, H, Sq, Skv, D);
