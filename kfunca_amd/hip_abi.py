@@ -12,8 +12,11 @@ from pathlib import Path
 
 import numpy as np
 
+import os
+
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "libkfunca_hip.so"
+# KF_HIP_LIB: load another build of the same library (A/B runs of two kernel variants on one box, tools/ only)
+LIB_PATH = Path(os.environ["KF_HIP_LIB"]) if os.environ.get("KF_HIP_LIB") else PKG / "libkfunca_hip.so"
 
 # dtype codes == reference ScalarType order (src/core/include/scalar_type.h:9-27)
 BOOL, U8, I8, I16, I32, I64, F16, BF16, F32, F64 = range(10)
