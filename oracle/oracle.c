@@ -2,9 +2,11 @@
  * oracle.c — CPU restatement of the reference's tensor-kernel hot path.  TEST INFRASTRUCTURE ONLY
  * (see oracle.h: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it).
  *
- * Parity status: PINNED against the reference's own test oracle (numpy / torch-CPU expressions of
- * test/test_tensor.py, test_gemm.py, test_nn.py) via tests/golden/*.npz; the reference itself is
- * unbuildable here (every op bottoms out in nvcc-only .cu files and an un-vendored CUTLASS).
+ * Parity status: PARITY UNPINNED. No output of kfunca itself has been compared with this file: the reference is
+ * unbuildable here (every op bottoms out in nvcc-only .cu files and an un-vendored CUTLASS) and its tests hold no golden
+ * vectors. What this file IS checked against (tests/test_oracle.py, tests/golden/*.npz) is the reference's own TEST oracle:
+ * the numpy / torch-CPU expressions of test/test_tensor.py, test_gemm.py, test_nn.py evaluated on seeded inputs, and
+ * torch-CPU autograd / f64 numpy for everything the reference has no counterpart of (backward passes, bf16, norms, gather).
  * Citations are relative to /root/reference.
  */
 #include "oracle.h"

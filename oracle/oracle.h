@@ -6,11 +6,12 @@
  *
  * Every function restates reference semantics at TENSOR level (shapes, element strides, dtypes),
  * not at iterator level, so it checks the host TensorIterator as well as the kernels. The reference
- * has no CPU path and cannot be built here (nvcc + un-vendored CUTLASS); the oracle
- * is pinned instead against the reference's OWN test oracle — the numpy / torch-CPU expressions in
- * test/test_tensor.py, test/test_gemm.py and test/test_nn.py — through the committed fixtures in
- * tests/golden (tests/test_oracle.py). Backward of GEMM / attention has no reference counterpart
- * (SURVEY.md fact 2): those are pinned against torch-CPU autograd fixtures.
+ * has no CPU path and cannot be built here (nvcc + un-vendored CUTLASS): PARITY
+ * UNPINNED - nothing here has been compared with an output of kfunca itself. The oracle is checked
+ * against the reference's OWN test oracle — the numpy / torch-CPU expressions in test/test_tensor.py,
+ * test/test_gemm.py and test/test_nn.py — through the committed fixtures in tests/golden
+ * (tests/test_oracle.py). Backward of GEMM / attention, the norms and the gather have no reference
+ * counterpart (README.md:28-32): those are checked against torch-CPU autograd fixtures.
  */
 #ifndef KFUNCA_ORACLE_H_
 #define KFUNCA_ORACLE_H_
