@@ -36,6 +36,10 @@ struct GemmArgs {
     const void *mul, *add;
     void *aux;
     int64_t ldmul, ldadd, ldaux;
+    // split-K (128-tile 16-bit kernel on grids far below one round of CUs): slice s of `split` accumulates K tiles
+    // [s nt / split, (s + 1) nt / split) and stores its raw f32 tile to part[s][M][N]; gemm_splitk_fold_kernel finishes
+    int split;
+    float *part;
 };
 
 // XCD-aware remap: consecutive logical tile ids land on the same XCD (its own 4 MiB L2) so
@@ -504,7 +508,9 @@ __global__ __launch_bounds__(256) void gemm_h_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[]; // [2 buffers][A tile | B tile]
     const char *A = (const char *)g.A, *B = (const char *)g.B;
     const uint32_t tiles_n = (uint32_t)(g.N / H_BN);
-    const uint32_t tile = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t id = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t ntiles = g.split > 1 ? gridDim.x / (uint32_t)g.split : gridDim.x;
+    const uint32_t tile = g.split > 1 ? id % ntiles : id, slice = g.split > 1 ? id / ntiles : 0;
     const int64_t m0 = (int64_t)(tile / tiles_n) * H_BM, n0 = (int64_t)(tile % tiles_n) * H_BN;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int wr = wid >> 1, wc = wid & 1;
@@ -530,15 +536,17 @@ __global__ __launch_bounds__(256) void gemm_h_kernel(const GemmArgs g) {
     if constexpr (TRB) { h_tr_lane_off(wc * 64, toffB[0]); h_tr_lane_off(wc * 64 + 32, toffB[1]); }
     const unsigned smem_u = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)smem;
 
-    stage_tile(0, smem);
+    const int ntk = (int)(g.K / H_BK);
+    const int tk0 = g.split > 1 ? (int)((int64_t)slice * ntk / g.split) : 0;          // this block's K tiles: [tk0, tk0 + nt)
+    const int nt = (g.split > 1 ? (int)((int64_t)(slice + 1) * ntk / g.split) : ntk) - tk0;
+    stage_tile(tk0, smem);
     __syncthreads(); // emits s_waitcnt vmcnt(0) for the LDS-DMA in flight, then s_barrier
 
-    const int nt = (int)(g.K / H_BK);
     for (int t = 0; t < nt; ++t) {
         char *cur = smem + (t & 1) * 2 * H_TILE_BYTES;
         char *nxt = smem + ((t + 1) & 1) * 2 * H_TILE_BYTES;
         const unsigned cur_u = smem_u + (unsigned)((t & 1) * 2 * H_TILE_BYTES);
-        if (t + 1 < nt) stage_tile(t + 1, nxt);
+        if (t + 1 < nt) stage_tile(tk0 + t + 1, nxt);
 #define KF_H_STEP(KS)                                                                                                  \
         {                                                                                                              \
             frag_t a[2], b[2];                                                                                         \
@@ -558,6 +566,21 @@ __global__ __launch_bounds__(256) void gemm_h_kernel(const GemmArgs g) {
         __syncthreads();
     }
 
+    if (g.split > 1) { // the raw partial tile; alpha, beta, bias and the tail belong to the fold
+        float *P = g.part + (int64_t)slice * g.M * g.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int64_t n = n0 + wc * 64 + j * 32 + xl;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
+                    P[m * g.N + n] = acc[i][j][e];
+                }
+            }
+        return;
+    }
     uint16_t *C = (uint16_t *)g.C;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -582,6 +605,32 @@ __global__ __launch_bounds__(256) void gemm_h_kernel(const GemmArgs g) {
                 C[m * g.ldc + n] = BF ? f32_to_bf16(v).x : f32_to_f16(v).x;
             }
         }
+}
+
+// split-K fold: C = alpha sum_s part[s] + beta C + bias, then the element-wise tail; slices added in slice order (fixed: the result
+// does not depend on scheduling). Four consecutive columns per lane, float4 partial loads.
+template <bool BF>
+__global__ __launch_bounds__(256) void gemm_splitk_fold_kernel(const GemmArgs g) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x, per_row = g.N / 4;
+    if (q >= g.M * per_row) return;
+    const int64_t m = q / per_row, n = (q - m * per_row) * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < g.split; ++s) {
+        const float4 p = *(const float4 *)(g.part + ((int64_t)s * g.M + m) * g.N + n);
+        v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+    }
+    uint16_t *C = (uint16_t *)g.C + m * g.ldc + n;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float t = g.alpha * v[e];
+        if (g.beta != 0.f) t += g.beta * (BF ? bf16_to_f32(bf16_t{C[e]}) : f16_to_f32(f16_t{C[e]}));
+        if (g.epilogue == KF_EPI_BIAS_ROW) {
+            const uint16_t bb = ((const uint16_t *)g.bias)[n + e];
+            t += BF ? bf16_to_f32(bf16_t{bb}) : f16_to_f32(f16_t{bb});
+        }
+        if (BF) t = g_epi<bf16_t>(g, m, n + e, t); else t = g_epi<f16_t>(g, m, n + e, t);
+        C[e] = BF ? f32_to_bf16(t).x : f32_to_f16(t).x;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1154,11 +1203,27 @@ static bool h256_ok(int64_t M, int64_t N, int64_t K) {
            !knob(KNOB_GEMM_128);
 }
 
+// Split-K plan: only where the 128-tile 16-bit kernel would leave most of the chip idle (at most 128 tiles = half a round of 256 CUs)
+// AND the contraction is long enough to pay for the f32 partial round trip (at least 8 K tiles of 64 per slice). Slices = the largest
+// power of two that keeps tiles x slices within two rounds. A skinny product (M = 256, N = 4096, K = 16384: 64 tiles x 256 K tiles)
+// goes from 64 busy CUs to 512 workgroups.
+static int splitk_slices(int dtype, int64_t M, int64_t N, int64_t K) {
+    if (!(dtype == KF_BF16 || dtype == KF_F16) || !h_fast_ok(M, N, K) || h256_ok(M, N, K) || knob(KNOB_GEMM_NO_SPLITK)) return 1;
+    const int64_t tiles = (M / H_BM) * (N / H_BN), nt = K / H_BK;
+    if (tiles > 128) return 1;
+    int s = 1;
+    while (s < 16 && tiles * (s * 2) <= 512 && nt / (s * 2) >= 8) s *= 2;
+    return s;
+}
+
 extern "C" int kf_gemm_workspace_bytes(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, size_t *bytes) {
     KF_REQUIRE(bytes, KF_ERR_INVALID, "kf_gemm_workspace_bytes: null out pointer");
     *bytes = 0;
-    // every kernel reads every operand layout in place: no GEMM needs scratch (the entry stays for ABI stability)
-    (void)dtype; (void)trans_a; (void)trans_b; (void)M; (void)N; (void)K;
+    // every kernel reads every operand layout in place; the only scratch any GEMM takes is split-K's f32 partial tiles, and a call
+    // without it simply runs unsplit
+    (void)trans_a; (void)trans_b;
+    const int s = splitk_slices(dtype, M, N, K);
+    if (s > 1) *bytes = (size_t)s * (size_t)M * (size_t)N * sizeof(float);
     return KF_OK;
 }
 
@@ -1215,13 +1280,13 @@ extern "C" int kfdbg_gemm_clock(int64_t M, int64_t N, int64_t K, const void *A, 
 #endif
 
 static int gemm_impl(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const void *A, int64_t lda, const void *B,
-                     int64_t ldb, float beta, void *C, int64_t ldc, int epilogue, const void *bias, const kf_gemm_epilogue *ex, void *stream);
+                     int64_t ldb, float beta, void *C, int64_t ldc, int epilogue, const void *bias, const kf_gemm_epilogue *ex, void *stream,
+                     void *workspace = nullptr, size_t workspace_bytes = 0);
 
 extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const void *A,
                        int64_t lda, const void *B, int64_t ldb, float beta, void *C, int64_t ldc, int epilogue,
                        const void *bias, void *workspace, size_t workspace_bytes, void *stream) {
-    (void)workspace; (void)workspace_bytes; // no kernel needs scratch (kf_gemm_workspace_bytes reports 0)
-    return gemm_impl(dtype, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, epilogue, bias, nullptr, stream);
+    return gemm_impl(dtype, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, epilogue, bias, nullptr, stream, workspace, workspace_bytes);
 }
 
 extern "C" int kf_gemm_ex(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const void *A, int64_t lda,
@@ -1236,7 +1301,8 @@ extern "C" int kf_gemm_ex(int dtype, int trans_a, int trans_b, int64_t M, int64_
 }
 
 static int gemm_impl(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const void *A, int64_t lda, const void *B,
-                     int64_t ldb, float beta, void *C, int64_t ldc, int epilogue, const void *bias, const kf_gemm_epilogue *ex, void *stream) {
+                     int64_t ldb, float beta, void *C, int64_t ldc, int epilogue, const void *bias, const kf_gemm_epilogue *ex, void *stream,
+                     void *workspace, size_t workspace_bytes) {
     KF_REQUIRE(dtype == KF_F32 || dtype == KF_F64 || dtype == KF_F16 || dtype == KF_BF16, KF_ERR_UNSUPPORTED,
                "kf_gemm: dtype %d not supported (float, double, half, bfloat16)", dtype);
     KF_REQUIRE(M >= 0 && N >= 0 && K >= 0, KF_ERR_INVALID, "kf_gemm: negative extent");
@@ -1286,9 +1352,13 @@ static int gemm_impl(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, 
             KF_PROF(dtype == KF_BF16 ? (w4 ? "gemm_bf16_mfma" : "gemm_bf16_mfma_w8") : (w4 ? "gemm_f16_mfma" : "gemm_f16_mfma_w8"), st);
             return dtype == KF_BF16 ? launch_h256<true>(g, trans_a != 0, !trans_b, w4, st) : launch_h256<false>(g, trans_a != 0, !trans_b, w4, st);
         }
-        const unsigned grid = (unsigned)((M / H_BM) * (N / H_BN));
+        unsigned grid = (unsigned)((M / H_BM) * (N / H_BN));
         const size_t lds = 4 * H_TILE_BYTES;
-        KF_PROF(dtype == KF_BF16 ? "gemm_bf16_mfma_128" : "gemm_f16_mfma_128", st);
+        const int slices = splitk_slices(dtype, M, N, K);
+        const bool split = slices > 1 && workspace && workspace_bytes >= (size_t)slices * M * N * sizeof(float) && (uintptr_t)workspace % 16 == 0 &&
+                           N % 4 == 0;
+        if (split) { g.split = slices; g.part = (float *)workspace; grid *= (unsigned)slices; }
+        KF_PROF(dtype == KF_BF16 ? (split ? "gemm_bf16_mfma_128_splitk" : "gemm_bf16_mfma_128") : (split ? "gemm_f16_mfma_128_splitk" : "gemm_f16_mfma_128"), st);
         const bool tra = trans_a != 0, trb = !trans_b; // transposed-read operands: consumed as they lie in memory, no re-layout pass
 #define KF_H128(BF_, TA, TB)                                                                                                   \
     {                                                                                                                          \
@@ -1304,6 +1374,12 @@ static int gemm_impl(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, 
 #undef KF_H128_L
 #undef KF_H128
         KF_LAUNCH_CHECK();
+        if (split) {
+            const unsigned gf = (unsigned)((M * (N / 4) + 255) / 256);
+            if (dtype == KF_BF16) gemm_splitk_fold_kernel<true><<<gf, 256, 0, st>>>(g);
+            else gemm_splitk_fold_kernel<false><<<gf, 256, 0, st>>>(g);
+            KF_LAUNCH_CHECK();
+        }
         return KF_OK;
     }
     const int64_t gtiles = ((N + 31) / 32) * ((M + 31) / 32);

@@ -271,3 +271,53 @@ def test_fused_elementwise_tail(code, M, N, K, label):
         H.device_sync()
         got1 = f(dc.to_numpy((M, N), a.dtype))
         assert (np.abs(got1 - expect) <= 4 * eps * (np.abs(expect) + np.abs(raw)) + 2e-6 * mag * (1 if code != H.F64 else 1e-7) + 4 * eps).all(), kw.keys()
+
+
+@pytest.mark.parametrize("code,eps", [(H.BF16, 2.0 ** -8), (H.F16, 2.0 ** -11)])
+def test_split_k_skinny_products(code, eps):
+    """Split-K (kernel label ..._128_splitk): a skinny product - few output tiles, a long contraction - is cut into K slices whose f32
+    partial tiles a fold kernel adds in slice order. Every layout, alpha / beta / bias and the element-wise tail, against the oracle
+    and f64; bit-identical run to run; without the workspace the same call runs unsplit and agrees within the accumulation bound."""
+    rng = np.random.default_rng(99 + code)
+    M, N, K = 256, 384, 4096
+    need = H.gemm_workspace_bytes(code, False, False, M, N, K)
+    assert need == 8 * M * N * 4, need  # 6 tiles x 64 K tiles -> 8 slices of 8 K tiles
+    a = O.from_float(rng.uniform(-1, 1, (M, K)).astype(np.float32), code)
+    b = O.from_float(rng.uniform(-1, 1, (K, N)).astype(np.float32), code)
+    af, bf_ = f64(a, code), f64(b, code)
+    want, mag = af @ bf_, np.abs(af) @ np.abs(bf_)
+    label = "gemm_bf16_mfma_128_splitk" if code == H.BF16 else "gemm_f16_mfma_128_splitk"
+    for ta in (False, True):
+        for tb in (False, True):
+            sa, sb = (a.T.copy() if ta else a), (b.T.copy() if tb else b)
+            H.profile_reset()
+            H.profile_enable(True)
+            got = run_gemm(code, sa, sb, ta, tb)
+            H.profile_enable(False)
+            assert set(H.profile_results()) == {label}, H.profile_results()
+            assert np.array_equal(got, run_gemm(code, sa, sb, ta, tb)), "split-K result differs run to run"
+            gf = f64(got, code)
+            assert (np.abs(gf - want) <= eps * np.abs(want) + 1e-6 * mag + 1e-30).all(), (code, ta, tb)
+            orc = f64(O.gemm(sa, sb, trans_a=ta, trans_b=tb, code=code), code)
+            assert (np.abs(gf - orc) <= 2 * eps * np.abs(want) + 2e-6 * mag + 1e-30).all(), "vs oracle"
+    # epilogue + tail through the fold, and the unsplit form of the same call (no workspace passed)
+    bias = O.from_float(rng.uniform(-1, 1, (N,)).astype(np.float32), code)
+    c = O.from_float(rng.uniform(-1, 1, (M, N)).astype(np.float32), code)
+    x = O.from_float(rng.uniform(-1, 1, (M, N)).astype(np.float32), code)
+    da, db, dbias, dx = (H.DevBuf.from_numpy(t) for t in (a, b, bias, x))
+    ws = H.DevBuf(need)
+    outs = []
+    for wsp, wsb in ((ws.ptr, need), (None, 0)):
+        dc = H.DevBuf.from_numpy(c)
+        H.profile_reset()
+        H.profile_enable(True)
+        H.gemm(code, 0, 0, M, N, K, 0.5, da.ptr, K, db.ptr, N, 2.0, dc.ptr, N, H.EPI_BIAS_ROW, dbias.ptr, wsp, wsb)
+        H.device_sync()
+        H.profile_enable(False)
+        assert set(H.profile_results()) == {label if wsp else label[:-7]}, H.profile_results()
+        outs.append(f64(dc.to_numpy((M, N), a.dtype), code))
+    want_e = 0.5 * want + 2.0 * f64(c, code) + f64(bias, code)[None, :]
+    for o in outs:
+        assert (np.abs(o - want_e) <= 2 * eps * np.abs(want_e) + 2e-6 * mag + 2 * eps).all()
+    with H.knobs(KF_GEMM_NO_SPLITK="1"):
+        assert H.gemm_workspace_bytes(code, False, False, M, N, K) == 0
