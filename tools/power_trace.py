@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Board power and clocks beside a back-to-back bf16 GEMM loop (prove or drop the power-wall reading of the GEMM's
+clock). A sampler thread polls `amd-smi metric` (falls back to `rocm-smi`) every ~100 ms while 4096^3 GEMMs run for a few seconds, on
+uniform(-1, 1) operands and on all-zero operands; TFLOP/s comes from HIP events around the same loop. Writes one JSON object."""
+import argparse
+import json
+import re
+import subprocess
+import sys
+import threading
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from kfunca_amd import hip_abi as H  # noqa: E402
+
+
+def sample():
+    """One reading: {power_w, sclk_mhz, ...} from whichever CLI answers."""
+    out = {}
+    try:
+        r = subprocess.run(["amd-smi", "metric", "-g", "0", "--power", "--clock", "--json"], capture_output=True, text=True, timeout=5)
+        if r.returncode == 0 and r.stdout.strip():
+            j = json.loads(r.stdout)
+            j = j[0] if isinstance(j, list) else j
+            p = j.get("power", {})
+            for key in ("socket_power", "current_socket_power", "average_socket_power"):
+                v = p.get(key)
+                if isinstance(v, dict) and isinstance(v.get("value"), (int, float)):
+                    out["power_w"] = float(v["value"])
+                    break
+            clk = j.get("clock", {})
+            g = clk.get("gfx_0") or clk.get("gfx") or {}
+            v = g.get("clk") if isinstance(g, dict) else None
+            if isinstance(v, dict) and isinstance(v.get("value"), (int, float)):
+                out["sclk_mhz"] = float(v["value"])
+            if out:
+                return out
+    except Exception:
+        pass
+    try:
+        r = subprocess.run(["rocm-smi", "-d", "0", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=5)
+        m = re.search(r"Power \(W\):\s*([0-9.]+)", r.stdout)
+        if m:
+            out["power_w"] = float(m.group(1))
+        m = re.search(r"sclk clock level:.*\((\d+)Mhz\)", r.stdout)
+        if m:
+            out["sclk_mhz"] = float(m.group(1))
+    except Exception:
+        pass
+    return out
+
+
+def run(n, seconds, zeros):
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, size=(n, n)).astype(np.float32).view(np.uint32)
+    bits = ((x + 0x7FFF + ((x >> 16) & 1)) >> 16).astype(np.uint16)
+    if zeros:
+        bits[:] = 0
+    A, B, Cb = H.DevBuf.from_numpy(bits), H.DevBuf.from_numpy(bits[::-1].copy()), H.DevBuf(2 * n * n)
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            s = sample()
+            s["t"] = time.time()
+            samples.append(s)
+            time.sleep(0.1)
+
+    th = threading.Thread(target=poll, daemon=True)
+    th.start()
+    time.sleep(0.5)  # idle readings first
+    t_start = time.time()
+    e0, e1 = H.Event(), H.Event()
+    launches = 0
+    e0.record(None)
+    while time.time() < t_start + seconds:
+        for _ in range(100):
+            H.gemm(H.BF16, 0, 1, n, n, n, 1.0, A.ptr, n, B.ptr, n, 0.0, Cb.ptr, n)
+        launches += 100
+        H.device_sync()
+    e1.record(None)
+    e1.sync()
+    t_end = time.time()
+    stop.set()
+    th.join()
+    ms = e0.elapsed_ms(e1)
+    busy = [s for s in samples if t_start + 1.0 <= s["t"] <= t_end]
+    idle = [s for s in samples if s["t"] < t_start]
+    avg = lambda xs, k: float(np.mean([s[k] for s in xs if k in s])) if any(k in s for s in xs) else None  # noqa: E731
+    return {"operands": "zeros" if zeros else "uniform(-1,1)", "launches": launches, "tflops": 2.0 * n ** 3 * launches / (ms * 1e-3) / 1e12,
+            "power_w_idle": avg(idle, "power_w"), "power_w_loaded": avg(busy, "power_w"), "sclk_mhz_loaded": avg(busy, "sclk_mhz"),
+            "samples_loaded": len(busy)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--seconds", type=float, default=4.0)
+    ap.add_argument("--json", default="")
+    args = ap.parse_args()
+    H.set_device(0)
+    out = {"n": args.n, "first_sample": sample(), "runs": [run(args.n, args.seconds, False), run(args.n, args.seconds, True)]}
+    print(json.dumps(out, indent=1))
+    if args.json:
+        Path(args.json).write_text(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
