@@ -95,14 +95,78 @@ def run(n, seconds, zeros):
             "samples_loaded": len(busy)}
 
 
+def run_attention(seconds, zeros):
+    """The same measurement beside the C3 attention step (forward + backward, B 8, H 32, S 4096, D 128)."""
+    B, Hh, S, D = 8, 32, 4096, 128
+    rng = np.random.default_rng(1)
+    per = Hh * S * D * 2
+    bufs = {}
+    for name in ("q", "k", "v", "do"):
+        x = rng.uniform(-1, 1, size=(Hh, S, D)).astype(np.float32).view(np.uint32)
+        host = ((x + 0x7FFF + ((x >> 16) & 1)) >> 16).astype(np.uint16)
+        if zeros:
+            host[:] = 0
+        b = H.DevBuf(B * per)
+        for i in range(B):
+            H.check(H.lib().kf_memcpy_h2d(b.ptr + i * per, host.ctypes.data, per, None))
+        bufs[name] = b
+    for name in ("o", "dq", "dk", "dv"):
+        bufs[name] = H.DevBuf(B * per)
+    lse = H.DevBuf(4 * B * Hh * S)
+    need = H.attn_bwd_workspace_bytes(H.BF16, B, Hh, S, S, D)
+    ws = H.DevBuf(need)
+
+    def step():
+        H.attn_fwd(H.BF16, B, Hh, S, S, D, bufs["q"].ptr, bufs["k"].ptr, bufs["v"].ptr, bufs["o"].ptr, lse.ptr)
+        H.attn_bwd(H.BF16, B, Hh, S, S, D, bufs["q"].ptr, bufs["k"].ptr, bufs["v"].ptr, bufs["o"].ptr, lse.ptr, bufs["do"].ptr,
+                   bufs["dq"].ptr, bufs["dk"].ptr, bufs["dv"].ptr, ws.ptr, need)
+
+    samples, stop = [], threading.Event()
+
+    def poll():
+        while not stop.is_set():
+            s = sample()
+            s["t"] = time.time()
+            samples.append(s)
+            time.sleep(0.1)
+
+    th = threading.Thread(target=poll, daemon=True)
+    th.start()
+    for _ in range(3):
+        step()
+    H.device_sync()
+    t_start = time.time()
+    steps = 0
+    H.profile_reset()
+    H.profile_enable(True)
+    while time.time() < t_start + seconds:
+        for _ in range(20):
+            step()
+        steps += 20
+        H.device_sync()
+    H.profile_enable(False)
+    t_end = time.time()
+    stop.set()
+    th.join()
+    busy = [s for s in samples if t_start + 1.0 <= s["t"] <= t_end]
+    avg = lambda xs, k: float(np.mean([s[k] for s in xs if k in s])) if any(k in s for s in xs) else None  # noqa: E731
+    return {"operands": "zeros" if zeros else "uniform(-1,1)", "steps": steps, "kernel_ms": {k: v[0] / v[1] for k, v in H.profile_results().items()},
+            "power_w_loaded": avg(busy, "power_w"), "sclk_mhz_loaded": avg(busy, "sclk_mhz"), "samples_loaded": len(busy)}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--attention", action="store_true", help="trace the C3 attention step instead of the GEMM loop")
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--json", default="")
     args = ap.parse_args()
     H.set_device(0)
-    out = {"n": args.n, "first_sample": sample(), "runs": [run(args.n, args.seconds, False), run(args.n, args.seconds, True)]}
+    if args.attention:
+        out = {"workload": "attention fwd+bwd B8 H32 S4096 D128 bf16", "first_sample": sample(),
+               "runs": [run_attention(args.seconds, False), run_attention(args.seconds, True)]}
+    else:
+        out = {"n": args.n, "first_sample": sample(), "runs": [run(args.n, args.seconds, False), run(args.n, args.seconds, True)]}
     print(json.dumps(out, indent=1))
     if args.json:
         Path(args.json).write_text(json.dumps(out, indent=1))
