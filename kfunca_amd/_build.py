@@ -105,6 +105,36 @@ def build_oracle(force: bool = False) -> Path:
     return ORACLE_LIB
 
 
+def build_core_asan() -> Path:
+    """The host core + binding compiled with AddressSanitizer + UBSan into _build/asan/kfunca_amd/ (a shadow package beside copies of
+    the package's Python files): the CPU-side sanitizer build the GPU pool cannot offer (tests/test_host_asan.py runs the host-only
+    tests under it with libasan preloaded). Links the same libkfunca_hip.so."""
+    import pybind11
+
+    out_pkg = BUILD / "asan" / "kfunca_amd"
+    out_pkg.mkdir(parents=True, exist_ok=True)
+    build_device()
+    srcs = sorted((CSRC / "core").glob("*.cpp")) + sorted((CSRC / "binding").glob("*.cpp"))
+    py_inc = sysconfig.get_paths()["include"]
+    flags = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17", "-fPIC",
+             "-fvisibility=hidden", f"-I{INCLUDE}", f"-I{CSRC / 'core'}", f"-I{pybind11.get_include()}", f"-I{py_inc}"]
+    objs = []
+    jobs = []
+    for s in srcs:
+        o = BUILD / "asan" / ("core_" + s.stem + ".o")
+        objs.append(o)
+        jobs.append(["g++", *flags, "-c", s, "-o", o])
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        list(ex.map(_run, jobs))
+    mod = out_pkg / CORE_MODULE.name
+    _run(["g++", "-shared", "-fPIC", "-fsanitize=address,undefined", "-o", mod, *objs, f"-L{PKG}", "-lkfunca_hip", f"-Wl,-rpath,{PKG}",
+          f"-Wl,-rpath,{ROCM / 'lib'}"])
+    for f in PKG.glob("*.py"):
+        shutil.copy2(f, out_pkg / f.name)
+    shutil.copy2(DEVICE_LIB, out_pkg / DEVICE_LIB.name)
+    return out_pkg.parent
+
+
 def build_diag(force: bool = False) -> Path:
     """The diagnostic library tools/gemm_clock.py loads (clock-stamped GEMM kernel, -DKF_DIAG_BUILD): a separate .so under
     _build/, so that nothing diagnostic is exported from libkfunca_hip.so."""
