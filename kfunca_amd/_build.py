@@ -105,13 +105,14 @@ def build_oracle(force: bool = False) -> Path:
     return ORACLE_LIB
 
 
-def build_core_asan() -> Path:
-    """The host core + binding compiled with AddressSanitizer + UBSan into _build/asan/kfunca_amd/ (a shadow package beside copies of
-    the package's Python files): the CPU-side sanitizer build the GPU pool cannot offer (tests/test_host_asan.py runs the host-only
+def build_core_asan(out_root=None) -> Path:
+    """The host core + binding compiled with AddressSanitizer + UBSan into <out_root>/kfunca_amd/ (default _build/asan; a shadow package
+    beside copies of the package's Python files - 70 MB of instrumented objects, so tests build it in a temporary directory): the CPU-side sanitizer build the GPU pool cannot offer (tests/test_host_asan.py runs the host-only
     tests under it with libasan preloaded). Links the same libkfunca_hip.so."""
     import pybind11
 
-    out_pkg = BUILD / "asan" / "kfunca_amd"
+    root = Path(out_root) if out_root else BUILD / "asan"
+    out_pkg = root / "kfunca_amd"
     out_pkg.mkdir(parents=True, exist_ok=True)
     build_device()
     srcs = sorted((CSRC / "core").glob("*.cpp")) + sorted((CSRC / "binding").glob("*.cpp"))
@@ -121,7 +122,7 @@ def build_core_asan() -> Path:
     objs = []
     jobs = []
     for s in srcs:
-        o = BUILD / "asan" / ("core_" + s.stem + ".o")
+        o = root / ("core_" + s.stem + ".o")
         objs.append(o)
         jobs.append(["g++", *flags, "-c", s, "-o", o])
     with ThreadPoolExecutor(max_workers=6) as ex:

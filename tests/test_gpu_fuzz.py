@@ -84,3 +84,96 @@ def test_attention_random_shapes_dtypes_forward_backward():
         for t, r in zip((tq, tk, tv), O.attn_bwd(*ref_in)):
             gr = back(t.grad())
             assert np.isfinite(gr).all() and np.abs(gr - r).max() <= tolb * max(1.0, np.abs(r).max()), (dt, B, Hh, Sq, Skv, D)
+
+
+def test_round2_operators_random_shapes():
+    """rms_norm / layer_norm, gemm_fused, causal_attention_qkv and embedding over seeded random shapes and dtypes, forward + backward
+    through autograd, against f64 numpy on the dtype-rounded inputs (the kernels behind them are picked by shape: register-tile plans
+    and generic norm kernels, every GEMM family incl. split-K, strided attention or its fall-back composition)."""
+    rng = np.random.default_rng(2027)
+
+    def mk(shape, dt, scale=1.0):
+        x = (rng.uniform(-1, 1, shape) * scale).astype(np.float32)
+        if dt == "bf16":
+            x = O.bf16_to_f32(O.f32_to_bf16(x))
+        t = kfunca.from_numpy(x, 0)
+        t = t.bfloat16() if dt == "bf16" else t
+        t.set_requires_grad(True)
+        return t, x.astype(np.float64)
+
+    back = lambda t, dt: (t.float() if dt == "bf16" else t).numpy().astype(np.float64)  # noqa: E731
+    close = lambda got, want, tol: np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max())  # noqa: E731
+    for _ in range(16):  # norms
+        dt = ["f32", "bf16"][int(rng.integers(0, 2))]
+        rows, cols = int(rng.integers(1, 200)), int(rng.choice([8, 24, 100, 512, 1000, 2048, 4096, 8200, 12288]))
+        tol = 1e-4 if dt == "f32" else 4e-2
+        tx, x = mk((rows, cols), dt, 2.0)
+        tw, w = mk((cols,), dt)
+        tb, b = mk((cols,), dt)
+        tg, g = mk((rows, cols), dt)
+        layer = bool(rng.integers(0, 2))
+        y = kfunca.layer_norm(tx, tw, tb, 1e-5) if layer else kfunca.rms_norm(tx, tw, 1e-5)
+        y.backward(tg)
+        mean = x.mean(1, keepdims=True) if layer else 0.0
+        rstd = 1.0 / np.sqrt(((x - mean) ** 2).mean(1, keepdims=True) + 1e-5)
+        xh = (x - mean) * rstd
+        assert close(back(y, dt), xh * w + (b if layer else 0.0), tol), (dt, rows, cols, layer)
+        gg = g * w
+        dx = rstd * (gg - (gg.mean(1, keepdims=True) if layer else 0.0) - xh * (gg * xh).mean(1, keepdims=True))
+        assert close(back(tx.grad(), dt), dx, tol) and close(back(tw.grad(), dt), (g * xh).sum(0), tol * np.sqrt(rows)), (dt, rows, cols, layer)
+        if layer:
+            assert close(back(tb.grad(), dt), g.sum(0), tol * np.sqrt(rows))
+    for _ in range(12):  # gemm_fused
+        dt = ["f32", "bf16"][int(rng.integers(0, 2))]
+        M, N = (int(rng.choice([1, 7, 64, 128, 200, 256, 384])) for _ in range(2))
+        K = int(rng.choice([16, 64, 100, 512, 4096]))
+        tol = 1e-4 if dt == "f32" else 4e-2
+        ta, a = mk((M, K), dt)
+        tb, b = mk((K, N), dt, 1.0 / np.sqrt(K))
+        tbias, bias = mk((N,), dt)
+        tm, m = mk((M, N), dt)
+        tadd, add = mk((M, N), dt)
+        tg, g = mk((M, N), dt)
+        use = [bool(rng.integers(0, 2)) for _ in range(3)]
+        y = kfunca.gemm_fused(ta, tb, 0.5, tbias if use[0] else None, tm if use[1] else None, tadd if use[2] else None)
+        y.backward(tg)
+        raw = 0.5 * (a @ b) + (bias if use[0] else 0.0)
+        assert close(back(y, dt), raw * (m if use[1] else 1.0) + (add if use[2] else 0.0), tol), (dt, M, N, K, use)
+        draw = g * (m if use[1] else 1.0)
+        assert close(back(ta.grad(), dt), 0.5 * draw @ b.T, tol) and close(back(tb.grad(), dt), 0.5 * a.T @ draw, tol * np.sqrt(M)), (dt, M, N, K, use)
+        if use[0]:
+            assert close(back(tbias.grad(), dt), draw.sum(0), tol * np.sqrt(M))
+        if use[1]:
+            assert close(back(tm.grad(), dt), g * raw, tol)
+        if use[2]:
+            assert close(back(tadd.grad(), dt), g, tol)
+    for _ in range(8):  # causal_attention_qkv: strided kernels (bf16, D 128, S % 128 == 0) and the fall-back composition
+        dt = ["f32", "bf16"][int(rng.integers(0, 2))]
+        B, Hh, D = int(rng.integers(1, 3)), int(rng.integers(1, 4)), int(rng.choice([64, 128]))
+        S = int(rng.choice([128, 256, 96, 130]))
+        d = Hh * D
+        tol = 1e-4 if dt == "f32" else 4e-2
+        tqkv, qkv = mk((B * S, 3 * d), dt)
+        tg, g = mk((B * S, d), dt)
+        out = kfunca.causal_attention_qkv(tqkv, B, S, Hh)
+        out.backward(tg)
+        heads = lambda x2: np.ascontiguousarray(x2.reshape(B, S, Hh, D).transpose(0, 2, 1, 3)).astype(np.float32)  # noqa: E731
+        q, k, v, go = heads(qkv[:, :d]), heads(qkv[:, d:2 * d]), heads(qkv[:, 2 * d:]), heads(g)
+        o_ref, _ = O.attn_fwd(q, k, v)
+        flat = lambda x4: x4.transpose(0, 2, 1, 3).reshape(B * S, d).astype(np.float64)  # noqa: E731
+        assert close(back(out, dt), flat(o_ref), tol), (dt, B, Hh, S, D)
+        rq, rk, rv = O.attn_bwd(q, k, v, go)
+        want = np.concatenate([flat(rq), flat(rk), flat(rv)], axis=1)
+        assert close(back(tqkv.grad(), dt), want, tol), (dt, B, Hh, S, D)
+    for _ in range(6):  # embedding
+        dt = ["f32", "bf16"][int(rng.integers(0, 2))]
+        vocab, dim, n = int(rng.integers(1, 400)), int(rng.choice([1, 8, 33, 256])), int(rng.integers(1, 3000))
+        tt, table = mk((vocab, dim), dt)
+        idx = rng.integers(-vocab, vocab, size=(n,)).astype(np.int64)
+        tg, g = mk((n, dim), dt)
+        out = kfunca.embedding(tt, kfunca.from_numpy(idx, 0))
+        out.backward(tg)
+        assert np.array_equal(back(out, dt), table[idx])
+        want = np.zeros((vocab, dim))
+        np.add.at(want, np.where(idx < 0, idx + vocab, idx), g)
+        assert close(back(tt.grad(), dt), want, 1e-5 if dt == "f32" else 2e-2), (dt, vocab, dim, n)

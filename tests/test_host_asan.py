@@ -21,13 +21,22 @@ def _libasan():
 
 @pytest.mark.skipif(_libasan() is None, reason="no libasan")
 def test_host_geometry_and_promotion_under_asan_ubsan():
+    import tempfile
+
     from kfunca_amd import _build
-    shadow = _build.build_core_asan()  # .../_build/asan, holding a package `kfunca_amd` with the instrumented _C
+    tmp = tempfile.mkdtemp(prefix="kf_asan_")
+    try:
+        _run_under_asan(_build.build_core_asan(tmp))  # a shadow package `kfunca_amd` with the instrumented _C
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def _run_under_asan(shadow):
     # libstdc++ goes in with libasan: python itself does not link it, and ASan's __cxa_throw interceptor must find the real one
     stdcpp = subprocess.run(["gcc", "-print-file-name=libstdc++.so"], capture_output=True, text=True).stdout.strip()
     env = dict(os.environ, LD_PRELOAD=f"{_libasan()} {stdcpp}", ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
                PYTHONPATH=f"{shadow}{os.pathsep}{ROOT}")
-    code = ("import sys, kfunca_amd, pytest; assert '_build/asan' in kfunca_amd.__file__.replace(chr(92), '/'), kfunca_amd.__file__; "
+    code = (f"import sys, kfunca_amd, pytest; assert kfunca_amd.__file__.startswith(r'{shadow}'), kfunca_amd.__file__; "
             f"sys.exit(pytest.main(['-q', '-x', '-p', 'no:cacheprovider', r'{ROOT / 'tests' / 'test_host_geometry.py'}']))")
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=str(shadow), timeout=900)
     assert res.returncode == 0, (res.stdout[-3000:], res.stderr[-3000:])
