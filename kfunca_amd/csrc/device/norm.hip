@@ -156,7 +156,9 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormArgs a) {
 
 // ---- backward: a block walks rows blockIdx.x, + gridDim.x, ...; x and dy of a row in registers ------------------------
 //   g = dy * w;  layer: dx = rstd * (g - mean(g) - xhat * mean(g * xhat));  rms: dx = rstd * (g - xhat * mean(g * xhat))
-template <typename T, int TPR, int PACKS>
+// RMS is a compile-time flag here: without the mean, the mean(g) term and db the bf16 row costs ~9 instead of ~13 vector instructions
+// per element, and this kernel is VALU-limited on 16-bit rows (6 bytes per element)
+template <typename T, int TPR, int PACKS, bool RMS>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(const NormArgs a) {
     constexpr int V = NPack<T>::V, RPB = 256 / TPR;
     __shared__ float red[4];
@@ -179,7 +181,9 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const NormArgs a) {
         const bool live = row < a.rows;
         const int64_t rr = live ? row : 0;
         const T *x = (const T *)a.x + rr * a.ldx, *dy = (const T *)a.dy + rr * a.ldx;
-        const float rstd = live ? a.rstd[rr] : 0.f, mean = (live && !a.rms) ? a.mean[rr] : 0.f;
+        const float rstd = live ? a.rstd[rr] : 0.f;
+        float mean = 0.f;
+        if constexpr (!RMS) mean = live ? a.mean[rr] : 0.f;
         float xh[PACKS][V], g[PACKS][V];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -191,12 +195,12 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const NormArgs a) {
                 n_unpack<T, V>(*(const uint4 *)(dy + c), dv);
 #pragma unroll
                 for (int i = 0; i < V; ++i) {
-                    xh[p][i] = (xv[i] - mean) * rstd;
+                    xh[p][i] = RMS ? xv[i] * rstd : (xv[i] - mean) * rstd;
                     g[p][i] = dv[i] * wv[p][i];
-                    s1 += g[p][i];
+                    if constexpr (!RMS) s1 += g[p][i];
                     s2 += g[p][i] * xh[p][i];
                     dw[p][i] += dv[i] * xh[p][i];
-                    db[p][i] += dv[i];
+                    if constexpr (!RMS) db[p][i] += dv[i];
                 }
             } else {
 #pragma unroll
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const NormArgs a) {
             }
         }
         s2 = n_row_sum<TPR>(s2, red) * inv_n;
-        s1 = a.rms ? 0.f : n_row_sum<TPR>(s1, red) * inv_n;
+        if constexpr (!RMS) s1 = n_row_sum<TPR>(s1, red) * inv_n;
         if (live) {
             T *dx = (T *)a.dx + row * a.ldx;
 #pragma unroll
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const NormArgs a) {
                 if (c < a.cols) {
                     float o[V];
 #pragma unroll
-                    for (int i = 0; i < V; ++i) o[i] = rstd * (g[p][i] - s1 - xh[p][i] * s2);
+                    for (int i = 0; i < V; ++i) o[i] = RMS ? rstd * (g[p][i] - xh[p][i] * s2) : rstd * (g[p][i] - s1 - xh[p][i] * s2);
                     *(uint4 *)(dx + c) = n_pack<T, V>(o);
                 }
             }
@@ -391,9 +395,29 @@ static NormPlan norm_plan(int dtype, int64_t cols, int64_t ldx, const void *cons
         if (npk <= 256 * (int64_t)p) return {256, p};
     return {0, 0};
 }
-static int norm_bwd_blocks(const NormPlan &pl, int64_t rows) {
+constexpr int kNormMaxBlocks = 1024; // partial rows the backward's scratch is sized for
+static int norm_bwd_blocks(const NormPlan &pl, int64_t rows) { // upper bound (workspace sizing)
     const int64_t nrb = (rows + (256 / pl.tpr) - 1) / (256 / pl.tpr);
-    return (int)std::min<int64_t>(nrb, 1024); // 4 blocks per CU: enough waves in flight to stream HBM, few enough partial rows
+    return (int)std::min<int64_t>(nrb, kNormMaxBlocks);
+}
+// The backward is one persistent round: as many blocks as the chip holds at once for THIS instantiation (occupancy x CUs, at most
+// kNormMaxBlocks), each walking its share of the rows. A fixed 1024 blocks ran 1.33 rounds when the RMS form's register count
+// let three blocks share a CU (768 resident): its last third ran at a third of the bandwidth (3.83 -> 3.48 TB/s).
+template <typename T, int TPR, int PACKS, bool RMS>
+static int norm_bwd_launch(NormArgs &a, hipStream_t st, int &nblk) {
+    static int resident = 0;
+    if (resident == 0) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, norm_bwd_kernel<T, TPR, PACKS, RMS>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
+        resident = std::min(kNormMaxBlocks, per_cu * prop.multiProcessorCount);
+    }
+    constexpr int RPB = 256 / TPR;
+    const int64_t nrb = (a.rows + RPB - 1) / RPB;
+    nblk = (int)std::min<int64_t>(nrb, resident);
+    norm_bwd_kernel<T, TPR, PACKS, RMS><<<(unsigned)nblk, 256, 0, st>>>(a);
+    return KF_OK;
 }
 
 } // namespace kf
@@ -418,15 +442,15 @@ static int norm_check(const char *who, int kind, int dtype, int64_t rows, int64_
     case 25608: KERNEL<T, 256, 8> __VA_ARGS__; break;                                            \
     default: KERNEL<T, 256, 16> __VA_ARGS__; break;                                              \
     }
-#define KF_NORM_DISPATCH_BWD(KERNEL, T, PL, ...)                                                 \
+#define KF_NORM_DISPATCH_BWD(KERNEL, T, PL, RMS_, ...)                                           \
     switch ((PL).tpr * 100 + (PL).packs) {                                                       \
-    case 6401: KERNEL<T, 64, 1> __VA_ARGS__; break;                                              \
-    case 6402: KERNEL<T, 64, 2> __VA_ARGS__; break;                                              \
-    case 6404: KERNEL<T, 64, 4> __VA_ARGS__; break;                                              \
-    case 25602: KERNEL<T, 256, 2> __VA_ARGS__; break;                                            \
-    case 25604: KERNEL<T, 256, 4> __VA_ARGS__; break;                                            \
+    case 6401: KERNEL<T, 64, 1, RMS_> __VA_ARGS__; break;                                        \
+    case 6402: KERNEL<T, 64, 2, RMS_> __VA_ARGS__; break;                                        \
+    case 6404: KERNEL<T, 64, 4, RMS_> __VA_ARGS__; break;                                        \
+    case 25602: KERNEL<T, 256, 2, RMS_> __VA_ARGS__; break;                                      \
+    case 25604: KERNEL<T, 256, 4, RMS_> __VA_ARGS__; break;                                      \
     default:                                                                                     \
-        if constexpr (sizeof(T) == 4) { KERNEL<T, 256, 8> __VA_ARGS__; }                         \
+        if constexpr (sizeof(T) == 4) { KERNEL<T, 256, 8, RMS_> __VA_ARGS__; }                   \
         break;                                                                                   \
     }
 
@@ -494,7 +518,7 @@ extern "C" int kf_norm_bwd(int kind, int dtype, int64_t rows, int64_t cols, int6
         KF_LAUNCH_CHECK();
         return KF_OK;
     }
-    const int nblk = norm_bwd_blocks(pl, rows);
+    int nblk = norm_bwd_blocks(pl, rows);
     if (sums) {
         const size_t need = (size_t)nblk * 2 * (size_t)cols * sizeof(float);
         KF_REQUIRE(workspace && workspace_bytes >= need, KF_ERR_WORKSPACE, "kf_norm_bwd: workspace of %zu bytes required, got %zu", need, workspace_bytes);
@@ -502,9 +526,11 @@ extern "C" int kf_norm_bwd(int kind, int dtype, int64_t rows, int64_t cols, int6
     }
     {
         KF_PROF("norm_bwd", st);
-        if (dtype == KF_F32) { KF_NORM_DISPATCH_BWD(norm_bwd_kernel, float, pl, <<<(unsigned)nblk, 256, 0, st>>>(a)) }
-        else if (dtype == KF_BF16) { KF_NORM_DISPATCH_BWD(norm_bwd_kernel, bf16_t, pl, <<<(unsigned)nblk, 256, 0, st>>>(a)) }
-        else { KF_NORM_DISPATCH_BWD(norm_bwd_kernel, f16_t, pl, <<<(unsigned)nblk, 256, 0, st>>>(a)) }
+#define KF_NB(T_)                                                                          \
+    if (a.rms) { KF_NORM_DISPATCH_BWD(norm_bwd_launch, T_, pl, true, (a, st, nblk)) }      \
+    else { KF_NORM_DISPATCH_BWD(norm_bwd_launch, T_, pl, false, (a, st, nblk)) }
+        if (dtype == KF_F32) { KF_NB(float) } else if (dtype == KF_BF16) { KF_NB(bf16_t) } else { KF_NB(f16_t) }
+#undef KF_NB
         KF_LAUNCH_CHECK();
     }
     if (sums) {
