@@ -16,7 +16,7 @@ import importlib
 __all__ = ["device_info", "memstat", "dtype", "empty", "empty_like", "from_numpy", "to_numpy", "zeros",
            "causal_attention", "gemm", "cat", "tensor",
            # extensions over the reference surface
-           "rms_norm", "layer_norm", "embedding", "causal_attention_qkv", "gemm_fused", "from_numpy_bf16", "device_count", "synchronize", "memstat_dict", "graph_begin", "graph_end", "graph_launch", "graph_destroy"]
+           "rms_norm", "layer_norm", "embedding", "causal_attention_qkv", "gemm_fused", "qkv_linear", "from_numpy_bf16", "device_count", "synchronize", "memstat_dict", "graph_begin", "graph_end", "graph_launch", "graph_destroy"]
 
 _native = None
 

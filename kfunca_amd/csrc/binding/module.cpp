@@ -269,6 +269,11 @@ PYBIND11_MODULE(_C, m) {
         auto opt = [](py::object o) { return o.is_none() ? Tensor() : o.cast<Tensor>(); };
         return gpu::gemm_fused(a, b, alpha, opt(bias), opt(mul), opt(add));
     }, py::arg("a"), py::arg("b"), py::arg("alpha") = 1.0f, py::arg("bias") = py::none(), py::arg("mul") = py::none(), py::arg("add") = py::none());
+    // the roadmap's name (README.md:32): the fused QKV projection = one GEMM with the bias in its store; its packed [B*S, 3*H*D] output
+    // is what causal_attention_qkv reads in place
+    m.def("qkv_linear", [](const Tensor &x, const Tensor &w_qkv, py::object bias) {
+        return gpu::gemm_fused(x, w_qkv, 1.0f, bias.is_none() ? Tensor() : bias.cast<Tensor>(), Tensor(), Tensor());
+    }, py::arg("x"), py::arg("w_qkv"), py::arg("bias") = py::none());
     m.def("causal_attention_qkv", &gpu::causal_attention_qkv, py::arg("qkv"), py::arg("B"), py::arg("S"), py::arg("H"));
     // from_numpy for bfloat16: uint16 bit patterns in, a BFloat16 tensor out (the inverse of to_numpy's uint16 view)
     m.def("from_numpy_bf16", [](py::array array, int device) {

@@ -96,3 +96,30 @@ def test_bfloat16_numpy_bridge():
     back = kfunca.from_numpy_bf16(bits, 0)
     assert back.dtype() == kfunca.bfloat16 and np.array_equal(back.numpy(), bits)
     assert np.array_equal(back.float().numpy(), O.bf16_to_f32(bits))
+
+
+def test_qkv_linear_feeds_attention_in_place():
+    """README.md:32's qkv_linear: x W_qkv + b in one kernel, its packed output consumed in place by causal_attention_qkv; forward and
+    the gradients of x, W and b against f64 numpy / the oracle on the bf16-rounded inputs."""
+    rng = np.random.default_rng(183)
+    B, S, Hh, D = 1, 128, 2, 128
+    d = Hh * D
+    r = lambda shp, sc=1.0: O.bf16_to_f32(O.f32_to_bf16((rng.uniform(-1, 1, shp) * sc).astype(np.float32)))  # noqa: E731
+    x, w, b, g = r((B * S, d)), r((d, 3 * d), 1 / 16), r((3 * d,), 0.1), r((B * S, d))
+    tx, tw, tb = leaf(x, True), leaf(w, True), leaf(b, True)
+    qkv = kfunca.qkv_linear(tx, tw, tb)
+    out = kfunca.causal_attention_qkv(qkv, B, S, Hh)
+    out.backward(kfunca.from_numpy(g, 0).bfloat16())
+    qkv_ref = x.astype(np.float64) @ w.astype(np.float64) + b
+    assert_close(qkv.float().numpy(), qkv_ref, rtol=2e-2, atol=2e-2, what="qkv")
+    heads = lambda x2: np.ascontiguousarray(x2.reshape(B, S, Hh, D).transpose(0, 2, 1, 3)).astype(np.float32)  # noqa: E731
+    qb = O.bf16_to_f32(O.f32_to_bf16(qkv_ref.astype(np.float32)))
+    q, k, v = heads(qb[:, :d]), heads(qb[:, d:2 * d]), heads(qb[:, 2 * d:])
+    o_ref, _ = O.attn_fwd(q, k, v)
+    flat = lambda x4: x4.transpose(0, 2, 1, 3).reshape(B * S, d).astype(np.float64)  # noqa: E731
+    assert_close(out.float().numpy(), flat(o_ref), rtol=3e-2, atol=3e-2, what="attention on the packed projection")
+    dq, dk, dv = O.attn_bwd(q, k, v, heads(g))
+    dqkv = np.concatenate([flat(dq), flat(dk), flat(dv)], axis=1)
+    assert_close(tb.grad().float().numpy(), dqkv.sum(0), rtol=5e-2, atol=0.3, what="db")
+    assert_close(tx.grad().float().numpy(), dqkv @ w.astype(np.float64).T, rtol=5e-2, atol=5e-2, what="dx")
+    assert_close(tw.grad().float().numpy(), x.astype(np.float64).T @ dqkv, rtol=5e-2, atol=0.3, what="dW")
