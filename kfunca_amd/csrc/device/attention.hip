@@ -16,10 +16,11 @@
 //                        LDS tile), B = the S^T accumulator converted in place to bf16
 //    K/V tiles use one XOR-swizzled LDS image that is conflict-free for both the row reads and
 //    the transposed reads; causal tiles above the diagonal are skipped.
-//    Backward = delta pre-pass + a dQ kernel (same skeleton: S^T, dP^T, dQ^T += K^T dS^T) + a
-//    dK/dV kernel (key on the lane: S, dP, dV^T += dO^T P, dK^T += Q^T dS). Recomputing S/dP
-//    in both kernels costs 7 products instead of 5 but needs no atomics: dQ is bitwise
-//    reproducible and there is no global-atomic floor.
+//    Backward = delta pre-pass + a dK/dV kernel (key on the lane: S, dP, dV^T += dO^T P, dK^T += Q^T dS) that also STORES
+//    dS = P o (dP - delta) in 16 bits + a dQ kernel that streams it back (dQ^T += K^T dS^T): the 5 matrix products of the
+//    algorithm, no atomics (dQ, dK, dV bitwise reproducible), one 16-bit S x S / 2 round trip through HBM. A recomputing dQ
+//    kernel (S and dP again: 7 products, small workspace) remains behind KF_ATTN_SPLIT_BWD and for dS beyond 64 GiB.
+//    Operands may be strided (batch / head / row strides, kf_attn_*_strided): q, k, v in place inside a packed QKV projection.
 //    A workgroup takes a block and its causal mirror, so all workgroups carry the same work (a_block_map, `persist`).
 //  * f32 forward (the reference's own dtype and fast path, D = 64 | 128): exact-f32 MFMA kernel.
 //  * generic path (any other dtype / ragged shape / head size <= 256, and the f32 backward):
