@@ -9,7 +9,7 @@ processes itself (children, never an exec), relays rank 0's JSON line and exits 
 
 One "step" = one pass of the hot path over one batch of synthetic bf16 tensors, everything through the C ABI
 (include/kfunca_hip.h) with inputs already resident in HBM:
-    GEMM 4096^3 forward + backward   C = A W,  dA = dC W^T,  dW = A^T dC       (BASELINE target GEMM)
+    GEMM 4096^3 forward + backward   C = A W,  {dA = dC W^T, dW = A^T dC} as one grouped launch     (BASELINE target GEMM)
     causal attention forward + backward, B=8 H=32 S=4096 D=128               (BASELINE configs[2] / C3)
 At N > 1 the batch is sharded (weak scaling: every rank runs the per-GPU batch above) and the weight gradient dW is
 sum-all-reduced over RCCL/xGMI (kfunca_amd.parallel.ProcessGroup) on a second stream, overlapped with the attention pass.
@@ -47,6 +47,7 @@ XGMI_PEAK = 7 * 153.0    # GB/s per GPU, all links
 _PAIR = AB * AH * AS * AS * AD / 2.0
 KERNEL_FLOPS = {
     "gemm_bf16_mfma": 2.0 * GEMM_N ** 3,
+    "gemm_bf16_mfma_pair": 4.0 * GEMM_N ** 3,  # dA = dC W^T and dW = A^T dC in one grid (kf_gemm_grouped)
     "attn_fwd_mfma": 4.0 * _PAIR,       # QK^T + PV
     "attn_bwd_dkv_mfma": 8.0 * _PAIR,   # S, dP, dV, dK
     "attn_bwd_dq_mfma": 2.0 * _PAIR,    # dQ = dS K
@@ -106,8 +107,9 @@ class Workload:
         if pg is not None and ev_comm.recorded:  # dW of the previous step must be fully reduced before it is rewritten
             H.stream_wait_event(s, ev_comm)
         H.gemm(H.BF16, 0, 0, n, n, n, 1.0, self.A.ptr, n, self.W.ptr, n, 0.0, self.Cc.ptr, n, 0, None, None, 0, s)
-        H.gemm(H.BF16, 0, 1, n, n, n, 1.0, self.dC.ptr, n, self.W.ptr, n, 0.0, self.dA.ptr, n, 0, None, None, 0, s)
-        H.gemm(H.BF16, 1, 0, n, n, n, 1.0, self.A.ptr, n, self.dC.ptr, n, 0.0, self.dW.ptr, n, 0, None, None, 0, s)
+        # the backward pair dA = dC W^T, dW = A^T dC: one grid (the second product starts under the first one's last tiles)
+        H.gemm_grouped(H.BF16, [(0, 1, n, n, n, 1.0, 0.0, self.dC.ptr, n, self.W.ptr, n, self.dA.ptr, n),
+                                (1, 0, n, n, n, 1.0, 0.0, self.A.ptr, n, self.dC.ptr, n, self.dW.ptr, n)], s)
         if pg is not None:  # gradient all-reduce on its own stream, overlapped with the attention pass
             ev_grad.record(s)
             H.stream_wait_event(comm_stream, ev_grad)

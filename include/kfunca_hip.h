@@ -300,6 +300,26 @@ typedef struct kf_gemm_epilogue {
 int kf_gemm_ex(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const void *A, int64_t lda,
                const void *B, int64_t ldb, float beta, void *C, int64_t ldc, const kf_gemm_epilogue *epi, void *stream);
 
+/*
+ * Several independent products in one call (no element-wise tail). The backward pair of a linear layer - p[0] = dA = dC B^T
+ * (trans_a 0, trans_b 1), p[1] = dB = A^T dC (trans_a 1, trans_b 0) - in 16 bits on shapes of the 4-wave 256-tile kernel
+ * (M, N multiples of 256, K of 64, at most 512 tiles each, tile counts multiples of 8) runs as ONE grid: the second product's
+ * first tiles start under the first one's last tiles instead of behind a kernel boundary. Anything else is the same as calling
+ * kf_gemm once per problem, in order. KF_GEMM_NO_GROUP disables the single-grid form.
+ */
+typedef struct kf_gemm_problem {
+    int32_t trans_a, trans_b;
+    int64_t M, N, K;
+    float alpha, beta;
+    const void *A;
+    int64_t lda;
+    const void *B;
+    int64_t ldb;
+    void *C;
+    int64_t ldc;
+} kf_gemm_problem;
+int kf_gemm_grouped(int dtype, int count, const kf_gemm_problem *problems, void *stream);
+
 /* ---- causal attention: replaces causal_attention_kernel.h:5 (+ backward) ------------------- */
 /*
  * q:[B,H,Sq,D], k,v:[B,H,Skv,D], o:[B,H,Sq,D] contiguous; lse:[B,H,Sq] float32 (may be NULL for

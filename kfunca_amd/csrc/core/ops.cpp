@@ -440,6 +440,20 @@ public:
         Tensor gc = g.contiguous();
         std::vector<Tensor> out(2);
         Tensor g2 = gc.view({M, N}), a2 = a.view({M, K});
+        if (a.requires_grad() && b.requires_grad() && M % 256 == 0 && N % 256 == 0 && K % 256 == 0 &&
+            (a.dtype() == ScalarType::Half || a.dtype() == ScalarType::BFloat16)) {
+            // both gradients of a 16-bit layer on 256-tile shapes: one grouped call (a single grid where the shapes allow it,
+            // kf_gemm_grouped; the two ordinary launches otherwise)
+            out[0] = empty(a.sizes(), a.dtype(), a.device());
+            out[1] = empty(b.sizes(), b.dtype(), b.device());
+            kf_gemm_problem p[2] = {};
+            p[0].trans_a = 0; p[0].trans_b = 1; p[0].M = M; p[0].N = K; p[0].K = N; p[0].alpha = alpha_; p[0].beta = 0.f;
+            p[0].A = g2.data_ptr(); p[0].lda = N; p[0].B = b.data_ptr(); p[0].ldb = N; p[0].C = out[0].data_ptr(); p[0].ldc = K;
+            p[1].trans_a = 1; p[1].trans_b = 0; p[1].M = K; p[1].N = N; p[1].K = M; p[1].alpha = alpha_; p[1].beta = 0.f;
+            p[1].A = a2.data_ptr(); p[1].lda = K; p[1].B = g2.data_ptr(); p[1].ldb = N; p[1].C = out[1].data_ptr(); p[1].ldc = N;
+            DEV_CALL(kf_gemm_grouped(code(a.dtype()), 2, p, dev::stream(a.device())));
+            return out;
+        }
         if (a.requires_grad()) {
             out[0] = empty(a.sizes(), a.dtype(), a.device());
             Tensor c2 = out[0].view({M, K});

@@ -964,15 +964,17 @@ constexpr int W4_NT = 256;
 
 // DIAG (diagnostic build only, tools/gemm_clock.py): stamps s_memtime / s_memrealtime around the main loop and writes the
 // two differences to g.bias (a buffer nothing else reads) - the in-kernel clock is their ratio x 100 MHz.
-template <bool BF, bool TRA, bool TRB, bool DIAG = false>
-__global__ __launch_bounds__(W4_NT) void gemm_w4_kernel(const GemmArgs g) {
+// The body is a device function of (problem, workgroup id, workgroups of the problem): gemm_w4_kernel runs one problem per launch,
+// gemm_w4_pair_kernel two (the backward pair dA = dC B^T, dB = A^T dC) in ONE grid, so the second problem's first tiles start
+// under the first problem's last ones instead of behind a kernel boundary.
+template <bool BF, bool TRA, bool TRB, bool DIAG>
+__device__ __forceinline__ void gemm_w4_body(const GemmArgs &g, const uint32_t bid, const uint32_t nwg, char *smem) {
     using frag_t = typename HFrag<BF>::type;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wid >> 1, wc = wid & 1;
     const uint32_t tiles_n = (uint32_t)(g.N / G_BN);
     uint32_t tm, tn;
-    grouped_tile(xcd_remap(blockIdx.x, gridDim.x), (uint32_t)(g.M / G_BM), tiles_n, (uint32_t)g.group_m, tm, tn);
+    grouped_tile(xcd_remap(bid, nwg), (uint32_t)(g.M / G_BM), tiles_n, (uint32_t)g.group_m, tm, tn);
     const int64_t m0 = (int64_t)tm * G_BM, n0 = (int64_t)tn * G_BN;
     const int nt = (int)(g.K / G_BK);
 
@@ -1116,7 +1118,7 @@ __global__ __launch_bounds__(W4_NT) void gemm_w4_kernel(const GemmArgs g) {
     if constexpr (DIAG) {
         const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         if (threadIdx.x == 0) {
-            uint64_t *d = (uint64_t *)g.bias + 2 * (size_t)blockIdx.x;
+            uint64_t *d = (uint64_t *)g.bias + 2 * (size_t)bid;
             d[0] = t1 - t0;
             d[1] = r1 - r0;
         }
@@ -1186,6 +1188,23 @@ __global__ __launch_bounds__(W4_NT) void gemm_w4_kernel(const GemmArgs g) {
             }
         }
     }
+}
+
+template <bool BF, bool TRA, bool TRB, bool DIAG = false>
+__global__ __launch_bounds__(W4_NT) void gemm_w4_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_w4_body<BF, TRA, TRB, DIAG>(g, blockIdx.x, gridDim.x, smem);
+}
+
+// Two problems, one grid: g0 is an NT product (A [M,K], B stored [N,K]: dA = dC W^T), g1 a TN product (A stored [K,M], B [K,N]:
+// dW = A^T dC); n0, n1 = their tile counts, both multiples of 8. Workgroup ids are dealt to XCDs round-robin, so problem 0 takes
+// the first n0 / 8 ids of every XCD and problem 1 the rest: each problem keeps the XCD-major tile order xcd_remap gives it alone.
+template <bool BF>
+__global__ __launch_bounds__(W4_NT) void gemm_w4_pair_kernel(const GemmArgs g0, const GemmArgs g1, const uint32_t n0, const uint32_t n1) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, s0 = n0 >> 3;
+    if (slot < s0) gemm_w4_body<BF, false, false, false>(g0, slot * 8 + xcd, n0, smem); // TRB template flag = "B stored [K,N]": NT is <false, false>
+    else gemm_w4_body<BF, true, true, false>(g1, (slot - s0) * 8 + xcd, n1, smem);       // TN: A stored [K,M] (TRA), B stored [K,N] (TRB)
 }
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -1287,6 +1306,40 @@ extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N
                        int64_t lda, const void *B, int64_t ldb, float beta, void *C, int64_t ldc, int epilogue,
                        const void *bias, void *workspace, size_t workspace_bytes, void *stream) {
     return gemm_impl(dtype, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, epilogue, bias, nullptr, stream, workspace, workspace_bytes);
+}
+
+extern "C" int kf_gemm_grouped(int dtype, int count, const kf_gemm_problem *p, void *stream) {
+    KF_REQUIRE(count >= 0 && (p || count == 0), KF_ERR_INVALID, "kf_gemm_grouped: null problem list");
+    // the backward pair of one linear layer on the 4-wave 256-tile kernel: one grid, no kernel boundary between the two products
+    const bool half = dtype == KF_BF16 || dtype == KF_F16;
+    auto pair_ok = [&](const kf_gemm_problem &q) {
+        return q.A && q.B && q.C && h_fast_ok(q.M, q.N, q.K) && h256_ok(q.M, q.N, q.K) && h256_use_w4(q.M, q.N) && ((q.M / G_BM) * (q.N / G_BN)) % 8 == 0 &&
+               (uintptr_t)q.A % 16 == 0 && (uintptr_t)q.B % 16 == 0 && q.lda % 8 == 0 && q.ldb % 8 == 0 && q.ldc >= q.N &&
+               q.lda >= (q.trans_a ? q.M : q.K) && q.ldb >= (q.trans_b ? q.K : q.N);
+    };
+    if (half && count == 2 && !p[0].trans_a && p[0].trans_b && p[1].trans_a && !p[1].trans_b && pair_ok(p[0]) && pair_ok(p[1]) && !knob(KNOB_GEMM_NO_GROUP)) {
+        hipStream_t st = as_stream(stream);
+        GemmArgs g0{p[0].A, p[0].B, p[0].C, nullptr, p[0].M, p[0].N, p[0].K, p[0].lda, p[0].ldb, p[0].ldc, p[0].alpha, p[0].beta, KF_EPI_NONE, 0};
+        GemmArgs g1{p[1].A, p[1].B, p[1].C, nullptr, p[1].M, p[1].N, p[1].K, p[1].lda, p[1].ldb, p[1].ldc, p[1].alpha, p[1].beta, KF_EPI_NONE, 0};
+        g0.group_m = g1.group_m = (int)knob_int(KNOB_GEMM_GROUP_M, 4);
+        const unsigned n0 = (unsigned)((p[0].M / G_BM) * (p[0].N / G_BN)), n1 = (unsigned)((p[1].M / G_BM) * (p[1].N / G_BN));
+        KF_PROF(dtype == KF_BF16 ? "gemm_bf16_mfma_pair" : "gemm_f16_mfma_pair", st);
+        if (dtype == KF_BF16) {
+            KF_ENSURE_LDS((gemm_w4_pair_kernel<true>), G_LDS);
+            gemm_w4_pair_kernel<true><<<n0 + n1, W4_NT, G_LDS, st>>>(g0, g1, n0, n1);
+        } else {
+            KF_ENSURE_LDS((gemm_w4_pair_kernel<false>), G_LDS);
+            gemm_w4_pair_kernel<false><<<n0 + n1, W4_NT, G_LDS, st>>>(g0, g1, n0, n1);
+        }
+        KF_LAUNCH_CHECK();
+        return KF_OK;
+    }
+    for (int i = 0; i < count; ++i) {
+        const int rc = kf_gemm(dtype, p[i].trans_a, p[i].trans_b, p[i].M, p[i].N, p[i].K, p[i].alpha, p[i].A, p[i].lda, p[i].B, p[i].ldb, p[i].beta,
+                               p[i].C, p[i].ldc, KF_EPI_NONE, nullptr, nullptr, 0, stream);
+        if (rc != KF_OK) return rc;
+    }
+    return KF_OK;
 }
 
 extern "C" int kf_gemm_ex(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const void *A, int64_t lda,

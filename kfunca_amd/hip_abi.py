@@ -44,7 +44,7 @@ EXPORTS = [
     "kf_device_props_get", "kf_elementwise", "kf_reduce_workspace_bytes", "kf_reduce",
     "kf_reduce_moments_workspace_bytes", "kf_reduce_moments",
     "kf_norm_fwd", "kf_norm_bwd_workspace_bytes", "kf_norm_bwd",
-    "kf_index_put", "kf_index_get", "kf_index_add_workspace_bytes", "kf_index_add", "kf_sort_workspace_bytes", "kf_sort", "kf_gemm_workspace_bytes", "kf_gemm", "kf_gemm_ex", "kf_attn_fwd", "kf_attn_fwd_scaled", "kf_attn_bwd_workspace_bytes",
+    "kf_index_put", "kf_index_get", "kf_index_add_workspace_bytes", "kf_index_add", "kf_sort_workspace_bytes", "kf_sort", "kf_gemm_workspace_bytes", "kf_gemm", "kf_gemm_ex", "kf_gemm_grouped", "kf_attn_fwd", "kf_attn_fwd_scaled", "kf_attn_bwd_workspace_bytes",
     "kf_attn_bwd", "kf_attn_bwd_scaled", "kf_attn_fwd_strided", "kf_attn_bwd_strided", "kf_comm_unique_id", "kf_comm_init", "kf_comm_destroy", "kf_allreduce_sum",
 ]
 
@@ -66,6 +66,12 @@ class GemmEpilogue(C.Structure):
     """kf_gemm_epilogue: C = (alpha AB + beta C + bias) o mul + add, aux = the value in brackets."""
     _fields_ = [("bias", C.c_void_p), ("mul", C.c_void_p), ("ldmul", C.c_int64), ("add", C.c_void_p), ("ldadd", C.c_int64),
                 ("aux", C.c_void_p), ("ldaux", C.c_int64)]
+
+
+class GemmProblem(C.Structure):
+    """kf_gemm_problem: one product of a kf_gemm_grouped call."""
+    _fields_ = [("trans_a", C.c_int32), ("trans_b", C.c_int32), ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64), ("alpha", C.c_float),
+                ("beta", C.c_float), ("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64), ("C", C.c_void_p), ("ldc", C.c_int64)]
 
 
 class AttnLayout(C.Structure):
@@ -133,6 +139,7 @@ def lib():
                                  vp, i64, C.c_int, vp, vp, sz, vp]
         _lib.kf_gemm_ex.argtypes = [C.c_int, C.c_int, C.c_int, i64, i64, i64, C.c_float, vp, i64, vp, i64, C.c_float, vp, i64,
                                     C.POINTER(GemmEpilogue), vp]
+        _lib.kf_gemm_grouped.argtypes = [C.c_int, C.c_int, C.POINTER(GemmProblem), vp]
         _lib.kf_attn_fwd.argtypes = [C.c_int, i64, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp]
         _lib.kf_attn_bwd_workspace_bytes.argtypes = [C.c_int, i64, i64, i64, i64, i64, C.POINTER(sz)]
         _lib.kf_attn_bwd.argtypes = [C.c_int, i64, i64, i64, i64, i64] + [vp] * 10 + [sz, vp]
@@ -466,6 +473,12 @@ def gemm_ex(dtype, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, beta, Cptr,
             aux=None, ldaux=0, stream=None):
     e = GemmEpilogue(bias, mul, ldmul, add, ldadd, aux, ldaux)
     check(lib().kf_gemm_ex(dtype, int(trans_a), int(trans_b), M, N, K, alpha, A, lda, B, ldb, beta, Cptr, ldc, C.byref(e), stream))
+
+
+def gemm_grouped(dtype, problems, stream=None):
+    """problems: tuples (trans_a, trans_b, M, N, K, alpha, beta, A, lda, B, ldb, C, ldc)."""
+    arr = (GemmProblem * len(problems))(*[GemmProblem(*p) for p in problems])
+    check(lib().kf_gemm_grouped(dtype, len(problems), arr, stream))
 
 
 def attn_fwd(dtype, B, H, Sq, Skv, D, q, k, v, o, lse=None, stream=None):

