@@ -327,10 +327,11 @@ int kf_gemm_grouped(int dtype, int count, const kf_gemm_problem *problems, void 
  * O = softmax(mask(Q K^T / sqrt(D))) V, mask keeps key n for query m iff m >= n (absolute
  * indices, top-left aligned: causal_attention_ref.h:36-41).
  * dtype in {KF_F32, KF_BF16, KF_F16}, D <= 256, any Sq / Skv. Matrix-core kernels, forward and backward: 16-bit tensors
- * with D = 128 and Sq, Skv multiples of 128; f32 tensors (the reference's dtype: exact-f32 MFMA) with D = 64 or 128 and
- * Sq, Skv multiples of 32. Everything else runs the generic vector-ALU kernels (correct, 20-100x slower).
+ * with D = 64 or 128 (the reference's two fast head sizes, causal_attention_kernel.cu:25-60) and Sq, Skv multiples of 128; f32
+ * tensors (the reference's dtype: exact-f32 MFMA) with D = 64 or 128 and Sq, Skv multiples of 32. Everything else runs the generic
+ * vector-ALU kernels (correct, 20-100x slower).
  * The *_scaled forms take the softmax scale explicitly instead of 1 / sqrt(D): a host that zero-pads a smaller head
- * size up to 128 columns (zero columns change neither Q K^T nor P V) passes 1 / sqrt(its own D) and lands on the MFMA
+ * size up to 64 or 128 columns (zero columns change neither Q K^T nor P V) passes 1 / sqrt(its own D) and lands on the MFMA
  * kernels - kfunca_amd's causal_attention does exactly that.
  */
 int kf_attn_fwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, const void *q,
@@ -342,7 +343,8 @@ int kf_attn_fwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv,
  * dK/dV kernel reads and - on the matrix-core path for 16-bit tensors - dS = P o (dP - delta) in 16 bits, B*H*Sq*Skv*2 bytes
  * (Sq rounded up to 256): the dK/dV kernel writes it, the dQ kernel computes dQ = scale dS K from it, so the backward executes the
  * 5 matrix products of the algorithm instead of 7. kf_attn_bwd_workspace_bytes() says how much; no initialisation needed.
- * Beyond 64 GiB of dS, or with KF_ATTN_SPLIT_BWD set, the dQ kernel recomputes S and dP instead (small workspace).
+ * Beyond 64 GiB of dS, or with KF_ATTN_SPLIT_BWD set, the dQ kernel recomputes S and dP instead (small workspace; D = 128 only:
+ * D = 64 has the dS form alone and returns KF_ERR_UNSUPPORTED beyond 64 GiB).
  * No atomics in either form: dq, dk, dv are bitwise reproducible run to run.
  */
 int kf_attn_bwd_workspace_bytes(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D,
@@ -361,7 +363,7 @@ int kf_attn_bwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv,
  * [B*S, 3*H*D] output of the QKV projection (batch = S*3*H*D, head = D, row = 3*H*D, bases offset by H*D), o is written
  * as [B*S, H*D] - the layout the output projection consumes - and the backward writes dq, dk, dv straight into a packed
  * [B*S, 3*H*D] gradient. Contiguous [B,H,S,D] is {H*S*D, S*D, D}. lse stays [B,H,Sq] contiguous f32.
- * 16-bit matrix-core path only (dtype KF_BF16 / KF_F16, D = 128, Sq and Skv multiples of 128; KF_ERR_UNSUPPORTED otherwise:
+ * 16-bit matrix-core path only (dtype KF_BF16 / KF_F16, D = 64 or 128, Sq and Skv multiples of 128; KF_ERR_UNSUPPORTED otherwise:
  * make contiguous copies and call the plain entries). Strides are multiples of 8 elements, operands 16-byte aligned.
  * Workspace as kf_attn_bwd_workspace_bytes().
  */

@@ -155,13 +155,14 @@ __device__ __forceinline__ void a_lst(char *tile, int id, const uint4 &v) { *(ui
 template <bool BF>
 __device__ __forceinline__ uint32_t a_cvt16(float v) { return BF ? f32_to_bf16(v).x : f32_to_f16(v).x; }
 
-// Write a wave's 32 x 128 result held as X^T accumulators (lane = row, registers = columns of
-// four 32-wide column blocks) as 16-bit rows of `dst` (row stride 256 B), via a per-wave LDS slab.
-template <bool BF>
-__device__ __forceinline__ void a_store_rows(char *slab, char *dst, const f32x16 (&acc)[4], float mul, int64_t rs) {
+// Write a wave's 32 x D result held as X^T accumulators (lane = row, registers = columns of
+// DB = D / 32 column blocks of 32) as 16-bit rows of `dst` (row stride rs), via a per-wave LDS slab.
+template <bool BF, int DB, int N>
+__device__ __forceinline__ void a_store_rows(char *slab, char *dst, const f32x16 (&acc)[N], float mul, int64_t rs) {
+    static_assert(DB <= N, "column blocks");
     const int lane = threadIdx.x & 63, xl = lane & 31, hl = lane >> 5;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+    for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const uint32_t h0 = a_cvt16<BF>(acc[db][4 * gq + 0] * mul), h1 = a_cvt16<BF>(acc[db][4 * gq + 1] * mul);
@@ -174,9 +175,9 @@ __device__ __forceinline__ void a_store_rows(char *slab, char *dst, const f32x16
         }
     // same wave reads back what it wrote: LDS ops of one wave complete in order
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int id = lane + 64 * i; // 1024 pieces of 8 B: 32 rows x 32 pieces
-        const int row = id >> 5, piece = id & 31;
+    for (int i = 0; i < 4 * DB; ++i) {
+        const int id = lane + 64 * i; // 256 DB pieces of 8 B: 32 rows x 8 DB pieces
+        const int row = id / (8 * DB), piece = id % (8 * DB);
         const uint2 w = *(const uint2 *)(slab + row * OPAD + piece * 8);
         *(uint2 *)(dst + (int64_t)row * rs + piece * 8) = w;
     }
@@ -216,7 +217,21 @@ __device__ __forceinline__ typename AFrag<BF>::type a_tr_frag2(const char *p0, c
 // tr4_issue starts the eight reads of four fragments (column blocks d = 0..3 of one 16-row k-step) and
 // returns at once; tr4_wait is the matching lgkmcnt(0), naming every destination so no consumer can be
 // scheduled above it. ROFF = (first row of the k-step) * 256, a literal.
-struct Tr4 { s16x4 lo[4], hi[4]; };
+template <int DB> struct TrN { s16x4 lo[DB], hi[DB]; };
+using Tr4 = TrN<4>;
+using Tr2 = TrN<2>; // head size 64: two column blocks
+template <int ROFF>
+__device__ __forceinline__ void tr4_issue(const char *tile, const int (&vo)[2][2], Tr2 &t) {
+    const unsigned base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)tile;
+    asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%c8\n\tds_read_b64_tr_b16 %1, %5 offset:%c8\n\t"
+                 "ds_read_b64_tr_b16 %2, %6 offset:%c8\n\tds_read_b64_tr_b16 %3, %7 offset:%c8"
+                 : "=&v"(t.lo[0]), "=&v"(t.hi[0]), "=&v"(t.lo[1]), "=&v"(t.hi[1])
+                 : "v"(base + vo[0][0]), "v"(base + vo[0][1]), "v"(base + vo[1][0]), "v"(base + vo[1][1]), "i"(ROFF)
+                 : "memory");
+}
+__device__ __forceinline__ void tr4_wait1(Tr2 &a) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a.lo[0]), "+v"(a.hi[0]), "+v"(a.lo[1]), "+v"(a.hi[1]) : : "memory");
+}
 template <int ROFF>
 __device__ __forceinline__ void tr4_issue(const char *tile, const int (&vo)[4][2], Tr4 &t) {
     const unsigned base = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)tile;
@@ -235,8 +250,8 @@ __device__ __forceinline__ void tr4_wait1(Tr4 &a) {
                  :
                  : "memory");
 }
-template <bool BF>
-__device__ __forceinline__ typename AFrag<BF>::type tr4_frag(const Tr4 &t, int d) {
+template <bool BF, int DB>
+__device__ __forceinline__ typename AFrag<BF>::type tr4_frag(const TrN<DB> &t, int d) {
     s16x8 r;
     r[0] = t.lo[d][0]; r[1] = t.lo[d][1]; r[2] = t.lo[d][2]; r[3] = t.lo[d][3];
     r[4] = t.hi[d][0]; r[5] = t.hi[d][1]; r[6] = t.hi[d][2]; r[7] = t.hi[d][3];
@@ -246,16 +261,21 @@ __device__ __forceinline__ typename AFrag<BF>::type tr4_frag(const Tr4 &t, int d
 
 // LDS-DMA staging of one 64-key K tile and V tile (global_load_lds_dwordx4): 16 + 16 wave-instructions of
 // 1 KiB (4 rows), two of each per wave; the tile image's XOR swizzle goes on the per-lane SOURCE chunk.
+// Head size 64 keeps the 256-byte row pitch of the image (every offset below stays what it is); its rows hold 8 chunks, so the
+// lanes whose source chunk is 8..15 sit the instruction out (an LDS-DMA lane writes at base + 16 lane whatever the others do).
+template <int D>
 __device__ __forceinline__ void f_stage(const char *kg, const char *vg, char *buf, int64_t krs, int64_t vrs) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row0 = (wid * 2 + i) * 4, row = row0 + (lane >> 4), pos = lane & 15;
         const int chunk = pos ^ (((row & 3) << 2) | ((row >> 2) & 3));
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kg + row * krs + chunk * 16),
-                                         (__attribute__((address_space(3))) void *)(buf + row0 * AROW), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vg + row * vrs + chunk * 16),
-                                         (__attribute__((address_space(3))) void *)(buf + FTILE + row0 * AROW), 16, 0, 0);
+        if (D == AD || chunk < D / 8) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kg + row * krs + chunk * 16),
+                                             (__attribute__((address_space(3))) void *)(buf + row0 * AROW), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vg + row * vrs + chunk * 16),
+                                             (__attribute__((address_space(3))) void *)(buf + FTILE + row0 * AROW), 16, 0, 0);
+        }
     }
 }
 
@@ -282,8 +302,8 @@ __device__ __forceinline__ float a_half_sum(float x) {
 constexpr int SRING = 4;
 constexpr float kDeferMax = 8.0f;
 
-template <bool BF, bool MASK>
-__device__ __forceinline__ void s_qk_sm(const char *buf, const typename AFrag<BF>::type (&qf)[8], const int (&ko)[8], f32x16 (&o)[4],
+template <bool BF, bool MASK, int D>
+__device__ __forceinline__ void s_qk_sm(const char *buf, const typename AFrag<BF>::type (&qf)[D / 16], const int (&ko)[D / 16], f32x16 (&o)[D / 32],
                                         typename AFrag<BF>::type (&pf)[4], float &m_i, float &l_i, float c, int64_t kv0, int64_t m, int hl, float defer) {
     using frag_t = typename AFrag<BF>::type;
     f32x16 s[2];
@@ -292,7 +312,7 @@ __device__ __forceinline__ void s_qk_sm(const char *buf, const typename AFrag<BF
 #pragma unroll
         for (int e = 0; e < 16; ++e) s[sub][e] = 0.f;
 #pragma unroll
-        for (int kg = 0; kg < 2; ++kg) {
+        for (int kg = 0; kg < D / 64; ++kg) {
 #pragma unroll
             for (int kk = 4 * kg; kk < 4 * kg + 4; ++kk)
                 s[sub] = a_mfma<BF>(*(const frag_t *)(buf + sub * 32 * AROW + ko[kk]), qf[kk], s[sub]);
@@ -316,7 +336,7 @@ __device__ __forceinline__ void s_qk_sm(const char *buf, const typename AFrag<BF
         const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * c);
         l_i *= alpha;
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
+        for (int d = 0; d < D / 32; ++d)
 #pragma unroll
             for (int e = 0; e < 16; ++e) o[d][e] *= alpha;
         m_i = m_new;
@@ -339,34 +359,35 @@ __device__ __forceinline__ void s_qk_sm(const char *buf, const typename AFrag<BF
     pf[3] = a_pack<BF>(s[1], 1);
 }
 
-template <bool BF>
-__device__ __forceinline__ void s_pv(const char *vt, const int (&vo)[4][2], const typename AFrag<BF>::type (&pf)[4], f32x16 (&o)[4]) {
-    Tr4 ta; // one group of transposed V fragments at a time: the partner wave (in its softmax phase) covers the latency
+template <bool BF, int DB>
+__device__ __forceinline__ void s_pv(const char *vt, const int (&vo)[DB][2], const typename AFrag<BF>::type (&pf)[4], f32x16 (&o)[DB]) {
+    TrN<DB> ta; // one group of transposed V fragments at a time: the partner wave (in its softmax phase) covers the latency
     tr4_issue<0>(vt, vo, ta);
     tr4_wait1(ta);
 #pragma unroll
-    for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(tr4_frag<BF>(ta, d), pf[0], o[d]);
+    for (int d = 0; d < DB; ++d) o[d] = a_mfma<BF>(tr4_frag<BF, DB>(ta, d), pf[0], o[d]);
     __builtin_amdgcn_sched_barrier(0);
     tr4_issue<16 * AROW>(vt, vo, ta);
     tr4_wait1(ta);
 #pragma unroll
-    for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(tr4_frag<BF>(ta, d), pf[1], o[d]);
+    for (int d = 0; d < DB; ++d) o[d] = a_mfma<BF>(tr4_frag<BF, DB>(ta, d), pf[1], o[d]);
     __builtin_amdgcn_sched_barrier(0);
     tr4_issue<32 * AROW>(vt, vo, ta);
     tr4_wait1(ta);
 #pragma unroll
-    for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(tr4_frag<BF>(ta, d), pf[2], o[d]);
+    for (int d = 0; d < DB; ++d) o[d] = a_mfma<BF>(tr4_frag<BF, DB>(ta, d), pf[2], o[d]);
     __builtin_amdgcn_sched_barrier(0);
     tr4_issue<48 * AROW>(vt, vo, ta);
     tr4_wait1(ta);
 #pragma unroll
-    for (int d = 0; d < 4; ++d) o[d] = a_mfma<BF>(tr4_frag<BF>(ta, d), pf[3], o[d]);
+    for (int d = 0; d < DB; ++d) o[d] = a_mfma<BF>(tr4_frag<BF, DB>(ta, d), pf[3], o[d]);
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <bool BF>
+template <bool BF, int D>
 __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
     using frag_t = typename AFrag<BF>::type;
+    constexpr int KS = D / 16, DB = D / 32; // k-steps of a Q K^T chain, 32-wide column blocks of O
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
     int xb0;
@@ -380,11 +401,11 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
     const bool late = __builtin_amdgcn_readfirstlane(wid) >= 4;
     const char *Kg = a.k + a_head(a.lk, bh, a.H);
     const char *Vg = a.v + a_head(a.lv, bh, a.H);
-    int ko[8], vo[4][2];
+    int ko[KS], vo[DB][2];
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) ko[kk] = a_off(xl, kk * 2 + hl);
+    for (int kk = 0; kk < KS; ++kk) ko[kk] = a_off(xl, kk * 2 + hl);
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
+    for (int d = 0; d < DB; ++d) {
         vo[d][0] = a_tr_lane_off(d * 32, 0);
         vo[d][1] = a_tr_lane_off(d * 32, 1);
     }
@@ -399,20 +420,20 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
     const int64_t q0 = (int64_t)qblk * FQ, qw = q0 + rgrp * 32, m = qw + xl;
     const bool active = qw < a.Sq;
 
-    frag_t qf[8];
+    frag_t qf[KS];
     if (active) {
         const char *Qg = a.q + a_head(a.lq, bh, a.H) + m * a.lq.sr;
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const frag_t *)(Qg + (kk * 16 + 8 * hl) * 2);
+        for (int kk = 0; kk < KS; ++kk) qf[kk] = *(const frag_t *)(Qg + (kk * 16 + 8 * hl) * 2);
     } else {
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk)
+        for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
             for (int j = 0; j < 8; ++j) qf[kk][j] = 0;
     }
-    f32x16 o[4];
+    f32x16 o[DB];
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+    for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[d][e] = 0.f;
     float m_i = -INFINITY, l_i = 0.f;
@@ -424,7 +445,7 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
     const int nt = (int)((kv_end + ABK - 1) / ABK);
     auto stage = [&](int tile, char *buf) {
         const int64_t kv = (int64_t)(tile < nt ? tile : nt - 1) * ABK;
-        f_stage(Kg + kv * a.lk.sr, Vg + kv * a.lv.sr, buf, a.lk.sr, a.lv.sr);
+        f_stage<D>(Kg + kv * a.lk.sr, Vg + kv * a.lv.sr, buf, a.lk.sr, a.lv.sr);
     };
     stage(0, smem);
     stage(1, smem + FBUF);
@@ -439,20 +460,20 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
         const bool diag = kv0 + ABK - 1 > qw;
         // one copy of each phase in program order [PV(t-1) | QK+softmax(t) | PV(t)]: late waves take the first
         // two, early waves the last two
-        if (late && pending) s_pv<BF>(smem + ((t + SRING - 1) % SRING) * FBUF + FTILE, vo, pf, o);
+        if (late && pending) s_pv<BF, DB>(smem + ((t + SRING - 1) % SRING) * FBUF + FTILE, vo, pf, o);
         pending = false;
         if (!skip) {
-            if (diag) s_qk_sm<BF, true>(cur, qf, ko, o, pf, m_i, l_i, c, kv0, m, hl, a.defer);
-            else s_qk_sm<BF, false>(cur, qf, ko, o, pf, m_i, l_i, c, kv0, m, hl, a.defer);
+            if (diag) s_qk_sm<BF, true, D>(cur, qf, ko, o, pf, m_i, l_i, c, kv0, m, hl, a.defer);
+            else s_qk_sm<BF, false, D>(cur, qf, ko, o, pf, m_i, l_i, c, kv0, m, hl, a.defer);
             if (late) pending = true;
-            else s_pv<BF>(cur + FTILE, vo, pf, o);
+            else s_pv<BF, DB>(cur + FTILE, vo, pf, o);
         }
     }
-    if (late && pending) s_pv<BF>(smem + ((nt + SRING - 1) % SRING) * FBUF + FTILE, vo, pf, o);
+    if (late && pending) s_pv<BF, DB>(smem + ((nt + SRING - 1) % SRING) * FBUF + FTILE, vo, pf, o);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (active) {
-        a_store_rows<BF>(smem + wid * 32 * OPAD, a.out + a_head(a.lo, bh, a.H) + qw * a.lo.sr, o, 1.f / l_i, a.lo.sr);
+        a_store_rows<BF, DB>(smem + wid * 32 * OPAD, a.out + a_head(a.lo, bh, a.H) + qw * a.lo.sr, o, 1.f / l_i, a.lo.sr);
         if (a.lse && hl == 0) a.lse[bh * a.Sq + m] = (m_i * c + __builtin_amdgcn_logf(l_i)) * kLn2;
     }
     if (a.persist) __syncthreads(); // the staging slabs overlap the ring the next block fills
@@ -464,14 +485,17 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
 // ------------------------------------------------------------------------------------------
 template <bool BF>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const char *o, const char *d_o, float *delta, int64_t nrows, const float *lse, float *nlse,
-                                                         float *ndelta, float rscale, AttnArgs::Lay lo, AttnArgs::Lay ldo, int64_t S, int64_t H) {
+                                                         float *ndelta, float rscale, AttnArgs::Lay lo, AttnArgs::Lay ldo, int64_t S, int64_t H, int nparts) {
     const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); // flat (b, h, s): the statistics stay [B, H, S] contiguous
     const int part = threadIdx.x & 15;
     float acc = 0.f;
     if (row < nrows) {
         const int64_t bh = row / S, sq = row - bh * S;
-        const uint4 a = *(const uint4 *)(o + a_head(lo, bh, H) + sq * lo.sr + part * 16);
-        const uint4 b = *(const uint4 *)(d_o + a_head(ldo, bh, H) + sq * ldo.sr + part * 16);
+        uint4 a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
+        if (part < nparts) { // nparts = D / 8 (16 | 8): 16-byte pieces of a row
+            a = *(const uint4 *)(o + a_head(lo, bh, H) + sq * lo.sr + part * 16);
+            b = *(const uint4 *)(d_o + a_head(ldo, bh, H) + sq * ldo.sr + part * 16);
+        }
         const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -537,13 +561,13 @@ __device__ __forceinline__ void q_tile(const char *buf, const char *doslab, cons
         tr4_wait1(ta);
         { const frag_t df = a_pack<BF>(s, 0);
 #pragma unroll
-          for (int d = 0; d < 4; ++d) dq[d] = a_mfma<BF>(tr4_frag<BF>(ta, d), df, dq[d]); }
+          for (int d = 0; d < 4; ++d) dq[d] = a_mfma<BF>(tr4_frag<BF, 4>(ta, d), df, dq[d]); }
         __builtin_amdgcn_sched_barrier(0);
         if (sub == 0) tr4_issue<16 * AROW>(buf, vo, ta); else tr4_issue<48 * AROW>(buf, vo, ta);
         tr4_wait1(ta);
         { const frag_t df = a_pack<BF>(s, 1);
 #pragma unroll
-          for (int d = 0; d < 4; ++d) dq[d] = a_mfma<BF>(tr4_frag<BF>(ta, d), df, dq[d]); }
+          for (int d = 0; d < 4; ++d) dq[d] = a_mfma<BF>(tr4_frag<BF, 4>(ta, d), df, dq[d]); }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -610,7 +634,7 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a
     const int nt = (int)((kv_end + ABK - 1) / ABK);
     auto stage = [&](int tile, char *buf) { // 3-deep ring, counted vmcnt: see attn_fwd_v2_kernel
         const int64_t kv = (int64_t)(tile < nt ? tile : nt - 1) * ABK;
-        f_stage(Kg + kv * a.lk.sr, Vg + kv * a.lv.sr, buf, a.lk.sr, a.lv.sr);
+        f_stage<AD>(Kg + kv * a.lk.sr, Vg + kv * a.lv.sr, buf, a.lk.sr, a.lv.sr);
     };
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // Q fragments + the dO slab writes are done
     stage(0, smem);
@@ -631,7 +655,7 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (active) a_store_rows<BF>(smem + wid * 32 * OPAD, a.dq + a_head(a.ldq, bh, a.H) + qw * a.ldq.sr, dq, a.scale, a.ldq.sr);
+    if (active) a_store_rows<BF, 4>(smem + wid * 32 * OPAD, a.dq + a_head(a.ldq, bh, a.H) + qw * a.ldq.sr, dq, a.scale, a.ldq.sr);
     if (a.persist) __syncthreads(); // the staging slabs overlap the ring the next block fills
   }
 }
@@ -654,31 +678,28 @@ constexpr int DQ_SLAB = 2 * DS_TILE;                              // one wave's 
 constexpr int DQ_LDS = DQ_RING * FTILE + 8 * DQ_RING * DQ_SLAB;   // K ring 48 KiB + 8 private dS rings 96 KiB
 
 // one 16-key k-step of key block HF of the step: dS^T fragment (2 transposed reads of the private slab) + four K^T fragments
-template <bool BF, int HF, int KS>
-__device__ __forceinline__ void dq_step(const char *kt, const int (&vo)[4][2], unsigned dsb, f32x16 (&dq)[4]) {
+template <bool BF, int HF, int KS, int DB>
+__device__ __forceinline__ void dq_step(const char *kt, const int (&vo)[DB][2], unsigned dsb, f32x16 (&dq)[DB]) {
     s16x4 blo, bhi;
-    Tr4 ta;
+    TrN<DB> ta;
     asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%c3\n\tds_read_b64_tr_b16 %1, %2 offset:%c4"
                  : "=&v"(blo), "=&v"(bhi)
                  : "v"(dsb), "n"(HF * DS_TILE + KS * 512), "n"(HF * DS_TILE + KS * 512 + 256)
                  : "memory");
     tr4_issue<(32 * HF + 16 * KS) * AROW>(kt, vo, ta);
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(blo), "+v"(bhi), "+v"(ta.lo[0]), "+v"(ta.hi[0]), "+v"(ta.lo[1]), "+v"(ta.hi[1]), "+v"(ta.lo[2]), "+v"(ta.hi[2]),
-                   "+v"(ta.lo[3]), "+v"(ta.hi[3])
-                 :
-                 : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blo), "+v"(bhi) : : "memory");
+    tr4_wait1(ta);
     s16x8 r;
     r[0] = blo[0]; r[1] = blo[1]; r[2] = blo[2]; r[3] = blo[3];
     r[4] = bhi[0]; r[5] = bhi[1]; r[6] = bhi[2]; r[7] = bhi[3];
     const auto b = __builtin_bit_cast(typename AFrag<BF>::type, r);
 #pragma unroll
-    for (int d = 0; d < 4; ++d) dq[d] = a_mfma<BF>(tr4_frag<BF>(ta, d), b, dq[d]);
+    for (int d = 0; d < DB; ++d) dq[d] = a_mfma<BF>(tr4_frag<BF, DB>(ta, d), b, dq[d]);
 }
 
-template <bool BF>
+template <bool BF, int D>
 __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_ds_kernel(const AttnArgs a) {
-    using frag_t = typename AFrag<BF>::type;
+    constexpr int DB = D / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int xb0;
@@ -688,9 +709,9 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_ds_kernel(const AttnArgs a
     a_block_map(nwx, (int)(a.B * a.H), a.xcd_map, xb0, bh);
     const char *Kg = a.k + a_head(a.lk, bh, a.H);
     char *slab = smem + DQ_RING * FTILE + wid * DQ_RING * DQ_SLAB;
-    int vo[4][2];
+    int vo[DB][2];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
+    for (int d = 0; d < DB; ++d) {
         vo[d][0] = a_tr_lane_off(d * 32, 0);
         vo[d][1] = a_tr_lane_off(d * 32, 1);
     }
@@ -714,9 +735,9 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_ds_kernel(const AttnArgs a
     const int64_t q0 = (int64_t)qblk * FQ, qw = q0 + wid * 32;
     const bool active = qw < a.Sq;
     const int sl = (int)(qw >> 5); // this wave's slice: key blocks 0 .. sl contribute
-    f32x16 dq[4];
+    f32x16 dq[DB];
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+    for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int e = 0; e < 16; ++e) dq[d][e] = 0.f;
     const int64_t q_end = q0 + FQ < a.Sq ? q0 + FQ : a.Sq;
@@ -731,8 +752,9 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_ds_kernel(const AttnArgs a
         for (int i = 0; i < 2; ++i) {
             const int row0 = (wid * 2 + i) * 4, row = row0 + krow;
             const int chunk = kpos ^ (((row & 3) << 2) | ((row >> 2) & 3));
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kg + row * a.lk.sr + chunk * 16),
-                                             (__attribute__((address_space(3))) void *)(smem + slot * FTILE + row0 * AROW), 16, 0, 0);
+            if (D == AD || chunk < D / 8) // head size 64: see f_stage
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kg + row * a.lk.sr + chunk * 16),
+                                                 (__attribute__((address_space(3))) void *)(smem + slot * FTILE + row0 * AROW), 16, 0, 0);
         }
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
@@ -755,17 +777,17 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_ds_kernel(const AttnArgs a
         const char *kt = smem + (t % DQ_RING) * FTILE;
         const unsigned dsb = ds_rd + (unsigned)((t % DQ_RING) * DQ_SLAB);
         if (active && 2 * t <= sl) { // wave-uniform: key block 2 t lies at or below this slice's diagonal
-            dq_step<BF, 0, 0>(kt, vo, dsb, dq);
-            dq_step<BF, 0, 1>(kt, vo, dsb, dq);
+            dq_step<BF, 0, 0, DB>(kt, vo, dsb, dq);
+            dq_step<BF, 0, 1, DB>(kt, vo, dsb, dq);
             if (2 * t + 1 <= sl) {
-                dq_step<BF, 1, 0>(kt, vo, dsb, dq);
-                dq_step<BF, 1, 1>(kt, vo, dsb, dq);
+                dq_step<BF, 1, 0, DB>(kt, vo, dsb, dq);
+                dq_step<BF, 1, 1, DB>(kt, vo, dsb, dq);
             }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (active) a_store_rows<BF>(smem + wid * 32 * OPAD, a.dq + a_head(a.ldq, bh, a.H) + qw * a.ldq.sr, dq, a.scale, a.ldq.sr);
+    if (active) a_store_rows<BF, DB>(smem + wid * 32 * OPAD, a.dq + a_head(a.ldq, bh, a.H) + qw * a.ldq.sr, dq, a.scale, a.ldq.sr);
     if (a.persist) __syncthreads();
   }
 }
@@ -863,9 +885,24 @@ __device__ __forceinline__ f32x16 k4_acc(const f32x4 (&c)[4]) {
     return r;
 }
 
-template <bool BF, bool DS>
+// two column blocks of one 16-row k-step (head size 64)
+template <int OFF>
+__device__ __forceinline__ void k4_tr2(unsigned t0, unsigned t1, K4Tr &t) {
+    asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%c6\n\tds_read_b64_tr_b16 %1, %5 offset:%c6\n\t"
+                 "ds_read_b64_tr_b16 %2, %4 offset:%c7\n\tds_read_b64_tr_b16 %3, %5 offset:%c7"
+                 : "=&v"(t.lo[0]), "=&v"(t.hi[0]), "=&v"(t.lo[1]), "=&v"(t.hi[1])
+                 : "v"(t0), "v"(t1), "n"(OFF), "n"(OFF + 512)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void k4_wait_tr2(K4Tr &a) {
+    asm volatile("s_waitcnt lgkmcnt(%c4)" : "+v"(a.lo[0]), "+v"(a.hi[0]), "+v"(a.lo[1]), "+v"(a.hi[1]) : "n"(N) : "memory");
+}
+
+template <bool BF, bool DS, int D>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) {
     using frag_t = typename AFrag<BF>::type;
+    constexpr int KS = D / 16, DB = D / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), xl = lane & 31, hl = lane >> 5;
     int xb0;
@@ -887,7 +924,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         const char *Kg = a.k + a_head(a.lk, bh, a.H) + n * a.lk.sr;
         const char *Vg = a.v + a_head(a.lv, bh, a.H) + n * a.lv.sr;
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
+        for (int kk = 0; kk < KS; ++kk) {
             kf[kk] = *(const frag_t *)(Kg + (kk * 16 + 8 * hl) * 2);
             vf[kk] = *(const frag_t *)(Vg + (kk * 16 + 8 * hl) * 2);
         }
@@ -895,16 +932,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         // itself (p = exp2(S''), no multiply per score: 32 VALU instructions fewer per slice pair). The 16-bit rounding of c K moves
         // an exponent by ~1e-3 (p by < 1e-3 relative, a quarter of P's own 16-bit rounding); dK = scale dS^T Q does not see it.
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk)
+        for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 if constexpr (BF) kf[kk][j] = (__bf16)((float)kf[kk][j] * c);
                 else kf[kk][j] = (_Float16)((float)kf[kk][j] * c);
             }
     }
-    f32x16 dk[4], dv[4];
+    f32x16 dk[4], dv[4]; // head size 64 uses column blocks 0 and 1
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+    for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { dk[d][e] = 0.f; dv[d][e] = 0.f; }
 
@@ -942,6 +979,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     // which a lone wave per SIMD can only hide under MFMAs already queued)
     auto stage_piece = [&](auto id_c, int pr_, int slot4) __attribute__((always_inline)) {
         constexpr int ID = decltype(id_c)::value, SL = ID / 5, K = ID % 5;
+        if constexpr (D == 64 && (K == 2 || K == 3)) return; // head size 64: the rows end after column blocks 0 and 1 (pieces i = 0)
         const int prc = pr_ < np ? pr_ : np - 1; // past the end: re-fetch the last pair (keeps the counts uniform; never consumed)
         const int64_t qs_ = ((int64_t)prc * 2 + SL) * BQS;
         char *buf = smem + slot4 * K4PAIR + SL * K4SL;
@@ -988,9 +1026,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     f32x16 svA, svB; // S accumulators of the even / odd slice of a pair: each slice fills the OTHER one's row constants (no copies)
     k4_rowc<0>(lr, cs);
     k4_rows4<0>(rb_e, rb_o, g0);
-    k4_rows4<1024>(rb_e, rb_o, g1);
+    if constexpr (D == 128) k4_rows4<1024>(rb_e, rb_o, g1);
     k4_rowc<128>(lr, cp);
-    asm volatile("s_waitcnt lgkmcnt(12)" : "+a"(cs[0]), "+a"(cs[1]), "+a"(cs[2]), "+a"(cs[3]) : : "memory");
+    if constexpr (D == 128) asm volatile("s_waitcnt lgkmcnt(12)" : "+a"(cs[0]), "+a"(cs[1]), "+a"(cs[2]), "+a"(cs[3]) : : "memory");
+    else asm volatile("s_waitcnt lgkmcnt(8)" : "+a"(cs[0]), "+a"(cs[1]), "+a"(cs[2]), "+a"(cs[3]) : : "memory");
     svA = k4_acc(cs);
 
 #define K4_MFMA4(ACC, FR, BOP, K0)                                                                                   \
@@ -1149,6 +1188,112 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         }
     };
 
+    // Head size 64: the same slice with half the k-steps and half the column blocks - six phases of 4, 4, 2, 2, 2, 2 MFMAs
+    // (S | dP | dV k0 | dV k1 | dK k0 | dK k1), one row-read group per operand, transposed groups of 4 reads, 6 DMA operations per
+    // pair. The LDS images, offsets and the dS tiles are those of head size 128 (column blocks 2 and 3 of a tile simply stay
+    // unused). The arithmetic of a slice (the same 16 scores per lane) now weighs as much as its MFMAs, so it is left to the
+    // compiler's scheduler; LDS operations in issue order, with the counts the waits use (operations issued after the awaited one):
+    //   ... t7 4, cs 4 | g0 4 | cp 4 || p0: g2 4 (wait g0: 8) | p2: t4 4, t5 4 (wait g2, cp: 8) | p4: t6 4 (wait t4: 8)
+    //   | p5: t7 4, cs' 4 (wait t5: 12) | p6: g0' 4 (wait t6: 12) | p7: cp' 4 (wait t7, cs': 8)
+    auto slice_body64 = [&, ds_lane, ds_base, ds_qb_tiles](auto mask_c, auto soff_c, auto noff_c, auto last_c, f32x16 &sv, f32x16 &svn, unsigned e, unsigned o,
+                            unsigned t0, unsigned t1, unsigned l, unsigned en, unsigned on, unsigned ln, int64_t qs, int pr, int it) __attribute__((always_inline)) {
+        constexpr bool MASK = decltype(mask_c)::value, LAST = decltype(last_c)::value;
+        constexpr int SOFF = decltype(soff_c)::value, NOFF = decltype(noff_c)::value, DO = SOFF + BQS * AROW;
+        f32x16 dpv;
+        s16x8 g2[4];
+        K4Tr t4, t5, t6, t7;
+        frag_t pf[2], df[2];
+        float pe[16], de[16];
+        // p0: S
+        k4_rows4<DO>(e, o, g2);
+        k4_wait4<8>(g0);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) sv = a_mfma<BF>(__builtin_bit_cast(frag_t, g0[kk]), kf[kk], sv);
+        // p2: dP = dO V^T - delta; p = exp2(S'')
+        k4_tr2<DO>(t0, t1, t4);
+        k4_tr2<DO + 4096>(t0, t1, t5);
+        k4_wait4c<8>(g2, cp);
+        dpv = k4_acc(cp);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) dpv = a_mfma<BF>(__builtin_bit_cast(frag_t, g2[kk]), vf[kk], dpv);
+#pragma unroll
+        for (int e_ = 0; e_ < 16; ++e_) {
+            float pv = __builtin_amdgcn_exp2f(sv[e_]);
+            if (MASK && n > qs + a_row(e_, hl)) pv = 0.f;
+            pe[e_] = pv;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (BF) { pf[0][j] = (__bf16)pe[j]; pf[1][j] = (__bf16)pe[8 + j]; }
+            else { pf[0][j] = (_Float16)pe[j]; pf[1][j] = (_Float16)pe[8 + j]; }
+        }
+        // p4: dV k-step 0; dS = p dP'
+        k4_tr2<SOFF>(t0, t1, t6);
+        k4_wait_tr2<8>(t4);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) dv[d] = a_mfma<BF>(k4_frag<BF>(t4, d), pf[0], dv[d]);
+#pragma unroll
+        for (int e_ = 0; e_ < 16; ++e_) de[e_] = pe[e_] * dpv[e_];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if constexpr (BF) { df[0][j] = (__bf16)de[j]; df[1][j] = (__bf16)de[8 + j]; }
+            else { df[0][j] = (_Float16)de[j]; df[1][j] = (_Float16)de[8 + j]; }
+        }
+        // p5: dV k-step 1
+        k4_tr2<SOFF + 4096>(t0, t1, t7);
+        k4_rowc<NOFF>(ln, cs);
+        k4_wait_tr2<12>(t5);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) dv[d] = a_mfma<BF>(k4_frag<BF>(t5, d), pf[1], dv[d]);
+        // p6: dK k-step 0
+        if constexpr (LAST) {
+            // as for head size 128 (see there), with 6 DMA operations per pair: 2 + (2 + 6 + 2) + 2 = 14 younger operations
+            if constexpr (DS) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        k4_rows4<NOFF>(en, on, g0);
+        k4_wait_tr2<12>(t6);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            dk[d] = a_mfma<BF>(k4_frag<BF>(t6, d), df[0], dk[d]);
+            if constexpr (LAST) {
+                if (d == 0) stage_piece(std::integral_constant<int, 0>{}, pr + 3, (it + 3) & 3);
+                if (d == 1) stage_piece(std::integral_constant<int, 1>{}, pr + 3, (it + 3) & 3);
+            }
+        }
+        // p7: dK k-step 1; the next slice's S accumulator takes its row constants
+        k4_rowc<NOFF + 128>(ln, cp);
+        asm volatile("s_waitcnt lgkmcnt(8)"
+                     : "+v"(t7.lo[0]), "+v"(t7.hi[0]), "+v"(t7.lo[1]), "+v"(t7.hi[1]), "+a"(cs[0]), "+a"(cs[1]), "+a"(cs[2]), "+a"(cs[3])
+                     :
+                     : "memory");
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            dk[d] = a_mfma<BF>(k4_frag<BF>(t7, d), df[1], dk[d]);
+            if constexpr (LAST) {
+                if (d == 0) stage_piece(std::integral_constant<int, 4>{}, pr + 3, (it + 3) & 3);
+                if (d == 1) stage_piece(std::integral_constant<int, 5>{}, pr + 3, (it + 3) & 3);
+            }
+        }
+        svn = k4_acc(cs);
+        if constexpr (LAST) {
+            stage_piece(std::integral_constant<int, 6>{}, pr + 3, (it + 3) & 3);
+            stage_piece(std::integral_constant<int, 9>{}, pr + 3, (it + 3) & 3);
+        }
+        if constexpr (DS) {
+            const int sl_ = (int)(qs >> 5);
+            const char *tile = ds_base + ((int64_t)((sl_ >> 3) * ds_qb_tiles + (sl_ & 7)) << 11);
+            const uint64_t tb = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile) |
+                                ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)tile >> 32)) << 32);
+            asm volatile("global_store_dwordx4 %0, %1, %3 offset:0 sc0 sc1\n\tglobal_store_dwordx4 %0, %2, %3 offset:1024 sc0 sc1"
+                         :
+                         : "v"(ds_lane), "v"(df[0]), "v"(df[1]), "s"(tb)
+                         : "memory");
+        }
+    };
+
     using I0 = std::integral_constant<int, 0>;
     using IS = std::integral_constant<int, K4SL>;
     auto pair_body = [&](auto mask_c, int pr, int it) __attribute__((always_inline)) {
@@ -1156,8 +1301,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         const unsigned bn = (unsigned)(((it + 1) & 3) * K4PAIR);     // the next pair's
         const int64_t qa = (int64_t)pr * 2 * BQS, qb = qa + BQS;
         const unsigned e = rb_e + bo, o = rb_o + bo, t0 = tb_0 + bo, t1 = tb_1 + bo, l = lr + bo;
-        slice_body(mask_c, I0{}, IS{}, std::false_type{}, svA, svB, e, o, t0, t1, l, e, o, l, qa, pr, it);
-        slice_body(mask_c, IS{}, I0{}, std::true_type{}, svB, svA, e, o, t0, t1, l, rb_e + bn, rb_o + bn, lr + bn, qb, pr, it);
+        if constexpr (D == 128) {
+            slice_body(mask_c, I0{}, IS{}, std::false_type{}, svA, svB, e, o, t0, t1, l, e, o, l, qa, pr, it);
+            slice_body(mask_c, IS{}, I0{}, std::true_type{}, svB, svA, e, o, t0, t1, l, rb_e + bn, rb_o + bn, lr + bn, qb, pr, it);
+        } else {
+            slice_body64(mask_c, I0{}, IS{}, std::false_type{}, svA, svB, e, o, t0, t1, l, e, o, l, qa, pr, it);
+            slice_body64(mask_c, IS{}, I0{}, std::true_type{}, svB, svA, e, o, t0, t1, l, rb_e + bn, rb_o + bn, lr + bn, qb, pr, it);
+        }
     };
     // two loops, one body each (a loop that switches between the masked and the plain body makes the allocator shuttle
     // the dK / dV accumulators between the two register files at every iteration)
@@ -1168,8 +1318,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
 #undef K4_CVT2
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // drain the ring and the last prefetch before LDS is reused
     __syncthreads();
-    a_store_rows<BF>(smem + wid * 32 * OPAD, a.dv + a_head(a.ldv, bh, a.H) + kw * a.ldv.sr, dv, 1.f, a.ldv.sr);
-    a_store_rows<BF>(smem + wid * 32 * OPAD, a.dk + a_head(a.ldk, bh, a.H) + kw * a.ldk.sr, dk, a.scale, a.ldk.sr);
+    a_store_rows<BF, DB>(smem + wid * 32 * OPAD, a.dv + a_head(a.ldv, bh, a.H) + kw * a.ldv.sr, dv, 1.f, a.ldv.sr);
+    a_store_rows<BF, DB>(smem + wid * 32 * OPAD, a.dk + a_head(a.ldk, bh, a.H) + kw * a.ldk.sr, dk, a.scale, a.ldk.sr);
     if (a.persist) __syncthreads(); // the staging slabs overlap the ring the next block fills
   }
 }
@@ -1818,15 +1968,16 @@ __global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const AttnArgs a)
 }
 
 static bool mfma_ok(int dtype, int64_t Sq, int64_t Skv, int64_t D) {
-    return (dtype == KF_BF16 || dtype == KF_F16) && D == AD && Sq % 128 == 0 && Skv % 128 == 0 && Sq > 0 && Skv > 0;
+    return (dtype == KF_BF16 || dtype == KF_F16) && (D == AD || D == 64) && Sq % 128 == 0 && Skv % 128 == 0 && Sq > 0 && Skv > 0;
 }
 
 static inline size_t a_align(size_t v) { return (v + 255) / 256 * 256; }
 
 // the MFMA backward keeps dS (2 products for dQ instead of 6) while its workspace stays below 64 GiB; beyond that, and with
 // KF_ATTN_SPLIT_BWD, the dQ kernel recomputes S and dP (round 1's split: small workspace, 40 % more matrix work)
+// (head size 64 has the dS form only: the knob does not apply to it, and a dS beyond 64 GiB is refused)
 static bool bwd_keeps_ds(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D) {
-    return mfma_ok(dtype, Sq, Skv, D) && !knob(KNOB_ATTN_SPLIT_BWD) && ds_bytes(B * H, Sq, Skv) <= ((size_t)64 << 30);
+    return mfma_ok(dtype, Sq, Skv, D) && (D == 64 || !knob(KNOB_ATTN_SPLIT_BWD)) && ds_bytes(B * H, Sq, Skv) <= ((size_t)64 << 30);
 }
 
 template <typename K>
@@ -1868,7 +2019,7 @@ extern "C" int kf_attn_fwd_strided(int dtype, int64_t B, int64_t H, int64_t Sq, 
                                    const kf_attn_layout *lq, const void *k, const kf_attn_layout *lk, const void *v, const kf_attn_layout *lv,
                                    void *o, const kf_attn_layout *lo, float *lse, void *stream) {
     KF_REQUIRE(mfma_ok(dtype, Sq, Skv, D), KF_ERR_UNSUPPORTED,
-               "kf_attn_fwd_strided: strided layouts are served by the 16-bit matrix-core kernels only (D = 128, Sq, Skv multiples of 128)");
+               "kf_attn_fwd_strided: strided layouts are served by the 16-bit matrix-core kernels only (D = 64 or 128, Sq, Skv multiples of 128)");
     AttnArgs::Lay lays[4];
     KF_REQUIRE(lay_from(lq, 2, lays[0]) && lay_from(lk, 2, lays[1]) && lay_from(lv, 2, lays[2]) && lay_from(lo, 2, lays[3]), KF_ERR_INVALID,
                "kf_attn_fwd_strided: strides must be non-negative multiples of 8 elements");
@@ -1899,11 +2050,15 @@ static int attn_fwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
         const int64_t nxb3 = (Sq + FQ - 1) / FQ;
         a.persist = (nxb3 % 2 == 0 && nxb3 >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
         dim3 grid3((unsigned)((a.persist ? nxb3 / (2 * a.persist) : nxb3) * B * H));
-        KF_PROF("attn_fwd_mfma", st);
-        if ((rc = set_lds(attn_fwd_v3_kernel<true>, lds3)) != KF_OK) return rc;
-        if ((rc = set_lds(attn_fwd_v3_kernel<false>, lds3)) != KF_OK) return rc;
-        if (dtype == KF_BF16) attn_fwd_v3_kernel<true><<<grid3, FNT, lds3, st>>>(a);
-        else attn_fwd_v3_kernel<false><<<grid3, FNT, lds3, st>>>(a);
+        KF_PROF(D == 64 ? "attn_fwd_mfma_d64" : "attn_fwd_mfma", st);
+#define KF_FWD(BF_, D_)                                                                  \
+    {                                                                                    \
+        if ((rc = set_lds(attn_fwd_v3_kernel<BF_, D_>, lds3)) != KF_OK) return rc;       \
+        attn_fwd_v3_kernel<BF_, D_><<<grid3, FNT, lds3, st>>>(a);                         \
+    }
+        if (dtype == KF_BF16) { if (D == 64) KF_FWD(true, 64) else KF_FWD(true, 128) }
+        else { if (D == 64) KF_FWD(false, 64) else KF_FWD(false, 128) }
+#undef KF_FWD
         KF_LAUNCH_CHECK();
         return KF_OK;
     }
@@ -1982,7 +2137,7 @@ extern "C" int kf_attn_bwd_strided(int dtype, int64_t B, int64_t H, int64_t Sq, 
                                    const kf_attn_layout *ldq, void *dk, const kf_attn_layout *ldk, void *dv, const kf_attn_layout *ldv,
                                    void *workspace, size_t workspace_bytes, void *stream) {
     KF_REQUIRE(mfma_ok(dtype, Sq, Skv, D), KF_ERR_UNSUPPORTED,
-               "kf_attn_bwd_strided: strided layouts are served by the 16-bit matrix-core kernels only (D = 128, Sq, Skv multiples of 128)");
+               "kf_attn_bwd_strided: strided layouts are served by the 16-bit matrix-core kernels only (D = 64 or 128, Sq, Skv multiples of 128)");
     AttnArgs::Lay lays[8];
     const kf_attn_layout *in[8] = {lq, lk, lv, lo, ldo, ldq, ldk, ldv};
     for (int i = 0; i < 8; ++i)
@@ -2022,11 +2177,13 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
         const bool bf = dtype == KF_BF16;
         {
             KF_PROF("attn_bwd_delta", st);
-            if (bf) attn_delta_kernel<true><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, kLog2e, a.lo, a.ldo, Sq, H);
-            else attn_delta_kernel<false><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, kLog2e, a.lo, a.ldo, Sq, H);
+            if (bf) attn_delta_kernel<true><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, kLog2e, a.lo, a.ldo, Sq, H, (int)(D / 8));
+            else attn_delta_kernel<false><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, kLog2e, a.lo, a.ldo, Sq, H, (int)(D / 8));
             KF_LAUNCH_CHECK();
         }
         const bool keep_ds = bwd_keeps_ds(dtype, B, H, Sq, Skv, D);
+        KF_REQUIRE(keep_ds || D == AD, KF_ERR_UNSUPPORTED, "kf_attn_bwd: head size 64 keeps dS in the workspace, and %zu bytes of it exceed 64 GiB",
+                   ds_bytes(B * H, Sq, Skv));
         a.ds = keep_ds ? (char *)workspace + 3 * a_align((size_t)B * H * Sq * sizeof(float)) : nullptr;
         a.ds_nqb = (Sq + 255) / 256;
         a.ds_nkwb = Skv / 32;
@@ -2035,14 +2192,15 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
             a.persist = (nkb4 % 2 == 0 && nkb4 >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
             a.persist_rev = 1; // the short block of the pair first: 2.17 ms against 2.32 the other way round (2.22 unpaired)
             dim3 gk4((unsigned)((a.persist ? nkb4 / 2 : nkb4) * B * H));
-            KF_PROF("attn_bwd_dkv_mfma", st);
-#define KF_DKV(BF_, DS_)                                                                  \
-    {                                                                                     \
-        if ((rc = set_lds(attn_bwd_dkv_v4_kernel<BF_, DS_>, K4LDS)) != KF_OK) return rc;  \
-        attn_bwd_dkv_v4_kernel<BF_, DS_><<<gk4, 256, K4LDS, st>>>(a);                     \
+            KF_PROF(D == 64 ? "attn_bwd_dkv_mfma_d64" : "attn_bwd_dkv_mfma", st);
+#define KF_DKV(BF_, DS_, D_)                                                                  \
+    {                                                                                         \
+        if ((rc = set_lds(attn_bwd_dkv_v4_kernel<BF_, DS_, D_>, K4LDS)) != KF_OK) return rc;  \
+        attn_bwd_dkv_v4_kernel<BF_, DS_, D_><<<gk4, 256, K4LDS, st>>>(a);                     \
     }
-            if (bf) { if (keep_ds) KF_DKV(true, true) else KF_DKV(true, false) }
-            else { if (keep_ds) KF_DKV(false, true) else KF_DKV(false, false) }
+            if (D == 64) { if (bf) KF_DKV(true, true, 64) else KF_DKV(false, true, 64) }
+            else if (bf) { if (keep_ds) KF_DKV(true, true, 128) else KF_DKV(true, false, 128) }
+            else { if (keep_ds) KF_DKV(false, true, 128) else KF_DKV(false, false, 128) }
 #undef KF_DKV
             KF_LAUNCH_CHECK();
         }
@@ -2051,11 +2209,15 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
         a.persist_rev = 0;
         dim3 gq2((unsigned)((a.persist ? nxq / 2 : nxq) * B * H));
         if (keep_ds) { // dQ = scale dS K from the stored dS
-            if ((rc = set_lds(attn_bwd_dq_ds_kernel<true>, DQ_LDS)) != KF_OK) return rc;
-            if ((rc = set_lds(attn_bwd_dq_ds_kernel<false>, DQ_LDS)) != KF_OK) return rc;
-            KF_PROF("attn_bwd_dq_mfma", st);
-            if (bf) attn_bwd_dq_ds_kernel<true><<<gq2, FNT, DQ_LDS, st>>>(a);
-            else attn_bwd_dq_ds_kernel<false><<<gq2, FNT, DQ_LDS, st>>>(a);
+            KF_PROF(D == 64 ? "attn_bwd_dq_mfma_d64" : "attn_bwd_dq_mfma", st);
+#define KF_DQ(BF_, D_)                                                                      \
+    {                                                                                       \
+        if ((rc = set_lds(attn_bwd_dq_ds_kernel<BF_, D_>, DQ_LDS)) != KF_OK) return rc;     \
+        attn_bwd_dq_ds_kernel<BF_, D_><<<gq2, FNT, DQ_LDS, st>>>(a);                         \
+    }
+            if (bf) { if (D == 64) KF_DQ(true, 64) else KF_DQ(true, 128) }
+            else { if (D == 64) KF_DQ(false, 64) else KF_DQ(false, 128) }
+#undef KF_DQ
             KF_LAUNCH_CHECK();
         } else { // the recomputing dQ kernel
             if ((rc = set_lds(attn_bwd_dq_v2_kernel<true>, QLDS)) != KF_OK) return rc;

@@ -89,20 +89,45 @@ def test_uniform_scores_exact_structure(code):
 
 
 @pytest.mark.parametrize("code", [H.BF16, H.F16])
+@pytest.mark.parametrize("D", [128, 64])  # the reference's two fast head sizes (causal_attention_kernel.cu:25-60), each with native kernels
 @pytest.mark.parametrize("B,Hh,Sq,Skv", [(1, 2, 256, 256), (2, 3, 128, 384), (1, 2, 384, 128), (1, 1, 512, 512)])
-def test_mfma_path_vs_oracle(code, B, Hh, Sq, Skv):
-    D = 128
-    rng = np.random.default_rng(Sq + Skv + code)
+def test_mfma_path_vs_oracle(code, D, B, Hh, Sq, Skv):
+    rng = np.random.default_rng(Sq + Skv + code + D)
     q, k, v, go = (O.from_float(rng.uniform(-1, 1, s).astype(np.float32), code)
                    for s in ((B, Hh, Sq, D), (B, Hh, Skv, D), (B, Hh, Skv, D), (B, Hh, Sq, D)))
+    H.profile_reset()
+    H.profile_enable(True)
     o, lse = fwd(code, q, k, v)
     o_ref, lse_ref = O.attn_fwd(q, k, v, code=code)
     assert_close(f(o, code), f(o_ref, code), **TOL[code], what="fwd")
     assert_close(lse, lse_ref, rtol=1e-3, atol=2e-3, what="lse")
     dq, dk, dv = bwd(code, q, k, v, o, lse, go)
+    H.profile_enable(False)
+    sfx = "_d64" if D == 64 else ""
+    for label in ("attn_fwd_mfma", "attn_bwd_dkv_mfma", "attn_bwd_dq_mfma"):  # the matrix-core kernels of THIS head size ran, nothing padded
+        assert label + sfx in H.profile_results(), (label + sfx, sorted(H.profile_results()))
     rq, rk, rv = O.attn_bwd(q, k, v, go, code=code)
     for n, got, want in (("dq", dq, rq), ("dk", dk, rk), ("dv", dv, rv)):
         assert_close(f(got, code), f(want, code), **TOL_BWD[code], what=f"bwd {n}")
+
+
+def test_head_size_64_longer_sequences_and_batches():
+    """Native D = 64 kernels at sizes where every schedule feature is live: paired blocks (S >= 1024), heads pinned to XCDs
+    (B H % 8 == 0), many slice pairs per key block, Sq != Skv."""
+    code = H.BF16
+    for (B, Hh, Sq, Skv) in ((1, 8, 1024, 1024), (2, 1, 768, 1280), (1, 2, 2048, 2048)):
+        rng = np.random.default_rng(64 + Sq + Skv)
+        q, k, v, go = (O.from_float(rng.uniform(-1, 1, s).astype(np.float32), code)
+                       for s in ((B, Hh, Sq, 64), (B, Hh, Skv, 64), (B, Hh, Skv, 64), (B, Hh, Sq, 64)))
+        o, lse = fwd(code, q, k, v)
+        o_ref, lse_ref = O.attn_fwd(q, k, v, code=code)
+        assert_close(f(o, code), f(o_ref, code), **TOL[code], what=f"d64 fwd {Sq}x{Skv}")
+        assert_close(lse, lse_ref, rtol=1e-3, atol=2e-3, what="d64 lse")
+        got = bwd(code, q, k, v, o, lse, go)
+        again = bwd(code, q, k, v, o, lse, go)
+        for n, g_, g2, want in zip(("dq", "dk", "dv"), got, again, O.attn_bwd(q, k, v, go, code=code)):
+            assert_close(f(g_, code), f(want, code), **TOL_BWD[code], what=f"d64 bwd {n} {Sq}x{Skv}")
+            assert np.array_equal(g_.view(np.uint16), g2.view(np.uint16)), f"d64 {n} not reproducible"
 
 
 def test_rescale_branch_is_exercised():
@@ -325,13 +350,14 @@ def test_backward_forms_stored_ds_and_recomputing_split(code):
 
 
 @pytest.mark.parametrize("code", [H.BF16, H.F16])
-def test_strided_layouts_packed_qkv_are_the_same_arithmetic(code):
+@pytest.mark.parametrize("D", [128, 64])
+def test_strided_layouts_packed_qkv_are_the_same_arithmetic(code, D):
     """kf_attn_*_strided on q / k / v living inside one packed [B S, 3 H D] projection output, o as [B S, H D], and dq / dk / dv
     written into a packed gradient: BIT-identical to the contiguous [B,H,S,D] entries on the same values (the layout changes
     addresses, not arithmetic), the bytes between the strided outputs untouched."""
-    B, Hh, S, D = 2, 4, 512, 128
+    B, Hh, S = 2, 4, 512
     d = Hh * D
-    rng = np.random.default_rng(33 + code)
+    rng = np.random.default_rng(33 + code + D)
     qkv = O.from_float(rng.uniform(-1, 1, (B * S, 3 * d)).astype(np.float32), code)
     gout = O.from_float(rng.uniform(-1, 1, (B * S, d)).astype(np.float32), code)
     heads = lambda x2: np.ascontiguousarray(x2.reshape(B, S, Hh, D).transpose(0, 2, 1, 3))  # noqa: E731  [B S, H D] -> [B, H, S, D]
@@ -359,9 +385,9 @@ def test_strided_layouts_packed_qkv_are_the_same_arithmetic(code):
     assert (g[:, 3 * d:] == 0x1234).all()
     for name, got, ref in (("dq", g[:, :d], dq_ref), ("dk", g[:, d:2 * d], dk_ref), ("dv", g[:, 2 * d:3 * d], dv_ref)):
         assert np.array_equal(heads(got).view(np.uint16), ref.view(np.uint16)), name
-    # refused off the matrix-core path (D = 64) and for misaligned strides
+    # refused off the matrix-core path (D = 96) and for misaligned strides
     with pytest.raises(H.KfError) as e:
-        H.attn_fwd_strided(code, B, Hh, S, S, 64, scale, bqkv.ptr, packed, bqkv.ptr, packed, bqkv.ptr, packed, bo.ptr, flat, blse.ptr)
+        H.attn_fwd_strided(code, B, Hh, S, S, 96, scale, bqkv.ptr, packed, bqkv.ptr, packed, bqkv.ptr, packed, bo.ptr, flat, blse.ptr)
     assert e.value.code == H.KF_ERR_UNSUPPORTED
     with pytest.raises(H.KfError) as e:
         H.attn_fwd_strided(code, B, Hh, S, S, D, scale, bqkv.ptr, (S * 3 * d, D, 3 * d + 1), bqkv.ptr, packed, bqkv.ptr, packed, bo.ptr, flat, blse.ptr)

@@ -305,7 +305,7 @@ def test_ragged_16bit_attention_takes_the_mfma_kernels():
     run instead of the generic vector-ALU one."""
     from kfunca_amd import hip_abi as H
     rng = np.random.default_rng(16)
-    for (B, Hh, Sq, Skv, D) in ((2, 2, 200, 200, 128), (1, 2, 130, 300, 128), (1, 1, 1, 1, 128), (2, 3, 256, 256, 64), (1, 2, 100, 140, 80)):
+    for (B, Hh, Sq, Skv, D) in ((2, 2, 200, 200, 128), (1, 2, 130, 300, 128), (1, 1, 1, 1, 128), (2, 3, 256, 256, 64), (1, 2, 100, 140, 80), (1, 2, 90, 90, 40)):
         q, k, v, go = (rng.uniform(-1, 1, s).astype(np.float32) for s in ((B, Hh, Sq, D), (B, Hh, Skv, D), (B, Hh, Skv, D), (B, Hh, Sq, D)))
         tq, tk, tv = (kfunca.from_numpy(x, 0).bfloat16() for x in (q, k, v))
         for t in (tq, tk, tv):
@@ -317,7 +317,8 @@ def test_ragged_16bit_attention_takes_the_mfma_kernels():
         kfunca.synchronize()
         H.profile_enable(False)
         names = set(H.profile_results())
-        assert {"attn_fwd_mfma", "attn_bwd_dkv_mfma", "attn_bwd_dq_mfma"} <= names and not any("generic" in n for n in names), names
+        sfx = "_d64" if D <= 64 else ""  # head sizes up to 64 are padded to the native 64-wide kernels, the rest to 128
+        assert {"attn_fwd_mfma" + sfx, "attn_bwd_dkv_mfma" + sfx, "attn_bwd_dq_mfma" + sfx} <= names and not any("generic" in n for n in names), names
         assert out.sizes() == [B, Hh, Sq, D]
         qb, kb, vb, gb = (O.f32_to_bf16(x) for x in (q, k, v, go))
         o_ref, _ = O.attn_fwd(qb, kb, vb, code=O.BF16)

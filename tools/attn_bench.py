@@ -23,17 +23,21 @@ def main():
     ap.add_argument("--B", type=int, default=8)
     ap.add_argument("--H", type=int, default=32)
     ap.add_argument("--S", type=int, default=4096)
+    ap.add_argument("--D", type=int, default=128, help="head size: 128 or 64 (both have native matrix-core kernels)")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--variants", default="default")  # comma list of ENV=1 settings, e.g. default,KF_ATTN_DKV_V2
     ap.add_argument("--no-bwd", action="store_true")
+    ap.add_argument("--zeros", action="store_true", help="all-zero operands: the same instruction stream without the power limit (the schedule-bound time)")
     args = ap.parse_args()
-    B, Hh, S, D = args.B, args.H, args.S, 128
+    B, Hh, S, D = args.B, args.H, args.S, args.D
     H.set_device(0)
     rng = np.random.default_rng(0)
     per = Hh * S * D * 2
     bufs = {}
     for name in ("q", "k", "v", "do"):
         host = bf16(rng, (Hh, S, D))
+        if args.zeros:
+            host[:] = 0
         b = H.DevBuf(B * per)
         for i in range(B):
             H.check(H.lib().kf_memcpy_h2d(b.ptr + i * per, host.ctypes.data, per, None))
@@ -44,7 +48,7 @@ def main():
     need = H.attn_bwd_workspace_bytes(H.BF16, B, Hh, S, S, D)
     ws = H.DevBuf(need)
     pair = B * Hh * S * S * D / 2.0
-    flops = {"attn_fwd_mfma": 4 * pair, "attn_fwd_mfma_v2": 4 * pair, "attn_fwd_mfma_v1": 4 * pair, "attn_bwd_dkv_mfma": 8 * pair, "attn_bwd_dq_mfma": 2 * pair, "attn_bwd_dq_mfma_split": 6 * pair, "attn_bwd_dq_mfma_v1": 6 * pair, "attn_bwd_dkv_mfma_v1": 8 * pair, "attn_bwd_dkv_mfma_v3": 8 * pair, "attn_bwd_dkv_mfma_v2": 8 * pair}
+    flops = {"attn_fwd_mfma_d64": 4 * pair, "attn_bwd_dkv_mfma_d64": 8 * pair, "attn_bwd_dq_mfma_d64": 2 * pair, "attn_fwd_mfma": 4 * pair, "attn_fwd_mfma_v2": 4 * pair, "attn_fwd_mfma_v1": 4 * pair, "attn_bwd_dkv_mfma": 8 * pair, "attn_bwd_dq_mfma": 2 * pair, "attn_bwd_dq_mfma_split": 6 * pair, "attn_bwd_dq_mfma_v1": 6 * pair, "attn_bwd_dkv_mfma_v1": 8 * pair, "attn_bwd_dkv_mfma_v3": 8 * pair, "attn_bwd_dkv_mfma_v2": 8 * pair}
     variants = args.variants.split(",")
     results = {v: {} for v in variants}
     for r in range(args.rounds + 1):
