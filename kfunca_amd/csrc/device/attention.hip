@@ -9,7 +9,8 @@
 // recompute P, and nothing of size S^2 is ever materialised.
 //
 // Two implementations behind one ABI:
-//  * MFMA path (bf16/f16, D = 128, Sq % 128 == 0, Skv % 64 == 0): flash-style, everything kept in
+//  * MFMA path (bf16/f16, D = 64 or 128 - the reference's two fast head sizes, causal_attention_kernel.cu:25-60 -, Sq % 128 == 0,
+//    Skv % 128 == 0; every kernel of it is a template on the head size): flash-style, everything kept in
 //    the "query/key on the lane" orientation so softmax statistics are lane-local:
 //      S^T = K Q^T      A = K rows (LDS, ds_read_b128), B = Q fragments (registers)
 //      O^T += V^T P^T   A = V^T via ds_read_b64_tr_b16 (hardware transpose read of the row-major
@@ -98,9 +99,9 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
 // ==========================================================================================
-// MFMA path, D = 128
+// MFMA path, D = 128 | 64 (template parameter; the LDS images are those of D = 128 for both)
 // ==========================================================================================
-constexpr int AD = 128;              // head size
+constexpr int AD = 128;              // head size the LDS images are laid out for
 constexpr int AROW = AD * 2;         // bytes per row of a 16-bit tile
 constexpr int ABQ = 128, ABK = 64;   // forward / dQ: queries per block, keys per tile
 constexpr int OPAD = AROW + 8;       // epilogue staging row stride (bytes)
@@ -302,9 +303,35 @@ __device__ __forceinline__ float a_half_sum(float x) {
 constexpr int SRING = 4;
 constexpr float kDeferMax = 8.0f;
 
+// Diagnostic build only (-DKF_ATTN_TIMELINE, tools/attn_timeline.py; never in libkfunca_hip.so): every wave of the forward adds up the
+// shader-clock cycles it spends in each phase of its tile loop (s_memtime stamps at the phase boundaries) and writes the seven sums.
+#ifdef KF_ATTN_TIMELINE
+__device__ unsigned long long *g_attn_tl;
+#define TL_STAMP(I)                                                        \
+    {                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                 \
+        const unsigned long long n_ = __builtin_amdgcn_s_memtime();        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 \
+        tl_acc[I] += n_ - tl_t;                                            \
+        tl_t = n_;                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                 \
+    }
+// dK/dV slice: the stamps are only REQUESTED at the phase boundaries (a wait would drain the LDS prefetch the slice lives on) and
+// collected at the end of the slice; the counted LDS waits of the slice see up to ten more outstanding operations and get that much
+// more conservative.
+#define TLK_STAMP(I) asm volatile("s_memtime %0" : "=s"(tlk[I]) : : "memory");
+#define TL_PARAMS , unsigned long long &tl_t, unsigned long long (&tl_acc)[7]
+#define TL_ARGS , tl_t, tl_acc
+#else
+#define TL_STAMP(I)
+#define TLK_STAMP(I)
+#define TL_PARAMS
+#define TL_ARGS
+#endif
+
 template <bool BF, bool MASK, int D>
 __device__ __forceinline__ void s_qk_sm(const char *buf, const typename AFrag<BF>::type (&qf)[D / 16], const int (&ko)[D / 16], f32x16 (&o)[D / 32],
-                                        typename AFrag<BF>::type (&pf)[4], float &m_i, float &l_i, float c, int64_t kv0, int64_t m, int hl, float defer) {
+                                        typename AFrag<BF>::type (&pf)[4], float &m_i, float &l_i, float c, int64_t kv0, int64_t m, int hl, float defer TL_PARAMS) {
     using frag_t = typename AFrag<BF>::type;
     f32x16 s[2];
 #pragma unroll
@@ -319,6 +346,7 @@ __device__ __forceinline__ void s_qk_sm(const char *buf, const typename AFrag<BF
             __builtin_amdgcn_sched_barrier(0); // bounds the K fragments in flight (register budget)
         }
     }
+    TL_STAMP(3)
     float mx = -INFINITY;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub)
@@ -449,12 +477,19 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
     };
     stage(0, smem);
     stage(1, smem + FBUF);
+#ifdef KF_ATTN_TIMELINE
+    unsigned long long tl_t = __builtin_amdgcn_s_memtime(), tl_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int t = 0; t < nt; ++t) {
         const int64_t kv0 = (int64_t)t * ABK;
+        TL_STAMP(6) // loop overhead
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        TL_STAMP(0) // this wave's part of tile t has landed
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        TL_STAMP(1) // everyone's
         stage(t + 2, smem + ((t + 2) % SRING) * FBUF); // slot of tile t-2: nobody reads it any more
+        TL_STAMP(2) // four LDS-DMA instructions issued
         const char *cur = smem + (t % SRING) * FBUF;
         const bool skip = !active || kv0 > qw + 31;
         const bool diag = kv0 + ABK - 1 > qw;
@@ -462,13 +497,23 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
         // two, early waves the last two
         if (late && pending) s_pv<BF, DB>(smem + ((t + SRING - 1) % SRING) * FBUF + FTILE, vo, pf, o);
         pending = false;
+        TL_STAMP(5) // a late wave's P V of the previous tile
         if (!skip) {
-            if (diag) s_qk_sm<BF, true, D>(cur, qf, ko, o, pf, m_i, l_i, c, kv0, m, hl, a.defer);
-            else s_qk_sm<BF, false, D>(cur, qf, ko, o, pf, m_i, l_i, c, kv0, m, hl, a.defer);
+            if (diag) s_qk_sm<BF, true, D>(cur, qf, ko, o, pf, m_i, l_i, c, kv0, m, hl, a.defer TL_ARGS); // stamps 3 after Q K^T
+            else s_qk_sm<BF, false, D>(cur, qf, ko, o, pf, m_i, l_i, c, kv0, m, hl, a.defer TL_ARGS);
+            TL_STAMP(4) // softmax
             if (late) pending = true;
             else s_pv<BF, DB>(cur + FTILE, vo, pf, o);
+            TL_STAMP(5) // an early wave's P V
         }
     }
+#ifdef KF_ATTN_TIMELINE
+    if (lane == 0 && g_attn_tl) {
+        unsigned long long *dst = g_attn_tl + ((size_t)blockIdx.x * 2 + (pass & 1)) * 64 + wid * 8;
+        for (int i = 0; i < 7; ++i) dst[i] = tl_acc[i];
+        dst[7] = (unsigned long long)nt;
+    }
+#endif
     if (late && pending) s_pv<BF, DB>(smem + ((nt + SRING - 1) % SRING) * FBUF + FTILE, vo, pf, o);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -899,6 +944,13 @@ __device__ __forceinline__ void k4_wait_tr2(K4Tr &a) {
     asm volatile("s_waitcnt lgkmcnt(%c4)" : "+v"(a.lo[0]), "+v"(a.hi[0]), "+v"(a.lo[1]), "+v"(a.hi[1]) : "n"(N) : "memory");
 }
 
+#ifdef KF_ABL_DKV_NOVALU // ablation (scratch builds only): the slice without its exp2 and its dS multiplies
+#define KF_ABL_EXP(x) (x)
+#define KF_ABL_MUL(a, b) (b)
+#else
+#define KF_ABL_EXP(x) __builtin_amdgcn_exp2f(x)
+#define KF_ABL_MUL(a, b) ((a) * (b))
+#endif
 template <bool BF, bool DS, int D>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) {
     using frag_t = typename AFrag<BF>::type;
@@ -1021,6 +1073,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     //   q1  the dP accumulator takes its row constants        q2, q3  p = exp2(c S'), two elements per MFMA; pack p (k0)
     //   q4  dS = p dP' (k0 elements); pack p (k1)               q5  dS (k1 elements); pack dS (k0)
     //   q6  pack dS (k1)                                        q7  the next slice's S accumulator takes its row constants
+#ifdef KF_ATTN_TIMELINE
+    unsigned long long tlk[10], tlk_acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlk_prev = __builtin_amdgcn_s_memtime();
+#endif
     s16x8 g0[4], g1[4];
     f32x4 cs[4], cp[4];
     f32x16 svA, svB; // S accumulators of the even / odd slice of a pair: each slice fills the OTHER one's row constants (no copies)
@@ -1049,10 +1104,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         K4Tr t4, t5, t6, t7;
         frag_t pf[2], df[2];
         float pe[16], de[16];
+        TLK_STAMP(0)
         // q0: S k-steps 0..3
         k4_rows4<DO>(e, o, g2);
         k4_wait4<12>(g0);
         K4_MFMA4(sv, g0, kf, 0)
+        TLK_STAMP(1)
         // q1: S k-steps 4..7; the dP accumulator takes its row constants (- delta)
         k4_rows4<DO + 1024>(e, o, g3);
         k4_wait4c<8>(g1, cp);
@@ -1064,12 +1121,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
             for (int j = 0; j < 4; ++j) dpv[4 * kk + j] = cp[kk][j];
             asm volatile("" : "+a"(sv), "+a"(dpv));
         }
+        TLK_STAMP(2)
         // q2: dP k-steps 0..3; p = exp2(c S') for elements 0..7
         k4_tr4<DO>(t0, t1, t4);
         k4_wait4<12>(g2);
 #define K4_EXP2(E)                                                                      \
     _Pragma("unroll") for (int e_ = (E); e_ < (E) + 2; ++e_) {                          \
-        float pv = __builtin_amdgcn_exp2f(sv[e_]);                                      \
+        float pv = KF_ABL_EXP(sv[e_]);                                                  \
         if (MASK && n > qs + a_row(e_, hl)) pv = 0.f;                                   \
         pe[e_] = pv;                                                                    \
     }
@@ -1080,6 +1138,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
             K4_EXP2(2 * kk)
             asm volatile("" : "+a"(dpv), "+v"(pe[2 * kk]), "+v"(pe[2 * kk + 1]));
         }
+        TLK_STAMP(3)
         // q3: dP k-steps 4..7; elements 8..15; pack p of k-step 0
         k4_tr4<DO + 4096>(t0, t1, t5);
         k4_wait4<15>(g3);
@@ -1092,6 +1151,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
             asm volatile("" : "+a"(dpv), "+v"(pe[8 + 2 * kk]), "+v"(pe[9 + 2 * kk]), "+v"(pf[0]));
         }
 #undef K4_EXP2
+        TLK_STAMP(4)
         // q4: dV k-step 0; dS = p dP' for elements 0..7; pack p of k-step 1
         k4_tr4<SOFF>(t0, t1, t6);
         k4_wait_tr<15>(t4);
@@ -1099,10 +1159,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         for (int d = 0; d < 4; ++d) {
             dv[d] = a_mfma<BF>(k4_frag<BF>(t4, d), pf[0], dv[d]);
             asm volatile("" : "+a"(dv[d]), "+a"(dpv), "+v"(pe[8 + 2 * d]), "+v"(pe[9 + 2 * d]));
-            de[2 * d] = pe[2 * d] * dpv[2 * d]; de[2 * d + 1] = pe[2 * d + 1] * dpv[2 * d + 1];
+            de[2 * d] = KF_ABL_MUL(pe[2 * d], dpv[2 * d]); de[2 * d + 1] = KF_ABL_MUL(pe[2 * d + 1], dpv[2 * d + 1]);
             K4_CVT2(pf[1], 2 * d, pe[8 + 2 * d], pe[9 + 2 * d])
             asm volatile("" : "+a"(dv[(d + 1) & 3]), "+v"(de[2 * d]), "+v"(de[2 * d + 1]), "+v"(pf[1]));
         }
+        TLK_STAMP(5)
         // q5: dV k-step 1; dS for elements 8..15; pack dS of k-step 0
         k4_tr4<SOFF + 4096>(t0, t1, t7);
         k4_rowc<NOFF>(ln, cs); // the next slice's S constants (q7 moves them into its accumulator)
@@ -1111,24 +1172,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         for (int d = 0; d < 4; ++d) {
             dv[d] = a_mfma<BF>(k4_frag<BF>(t5, d), pf[1], dv[d]);
             asm volatile("" : "+a"(dv[d]), "+a"(dpv), "+v"(de[2 * d]), "+v"(de[2 * d + 1]));
-            de[8 + 2 * d] = pe[8 + 2 * d] * dpv[8 + 2 * d]; de[9 + 2 * d] = pe[9 + 2 * d] * dpv[9 + 2 * d];
+            de[8 + 2 * d] = KF_ABL_MUL(pe[8 + 2 * d], dpv[8 + 2 * d]); de[9 + 2 * d] = KF_ABL_MUL(pe[9 + 2 * d], dpv[9 + 2 * d]);
             K4_CVT2(df[0], 2 * d, de[2 * d], de[2 * d + 1])
             asm volatile("" : "+a"(dv[(d + 1) & 3]), "+v"(de[8 + 2 * d]), "+v"(de[9 + 2 * d]), "+v"(df[0]));
         }
+        TLK_STAMP(6)
         // q6: dK k-step 0; pack dS of k-step 1
         if constexpr (LAST) {
             // the next pair has landed - this wave's part, then everyone's - and every wave is past its reads of the
             // previous pair, whose buffer takes pair pr + 3. vmcnt(0), not a counted wait: register spills are VMEM
             // operations too and would be counted among "the youngest"; the pair after next was issued a pair ago.
-            // With the dS stores in the stream (two per slice, at its end) the wait is COUNTED: the pair being waited for (pr + 1)
-            // was issued in pair pr - 2's last slice; younger than it are that slice's 2 stores, pair pr - 1's 2 + 10 + 2 and this
-            // pair's first slice's 2 = 18 operations (a store that has just been issued takes ~1 us to retire: vmcnt(0) here would
-            // stall every pair on it). The kernel must stay spill-free for this to hold (tools/kernel_resources.py).
-            if constexpr (DS) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            // With the dS stores in the stream (two per slice, one in q6 and one in q7) the wait is COUNTED: the pair being waited
+            // for (pr + 1) was issued in pair pr - 2's last slice, whose last operation is its last DMA piece; younger than that are
+            // pair pr - 1's 2 + (10 + 2) and this pair's first slice's 2 = 16 operations (a store that has just been issued takes
+            // ~1 us to retire: vmcnt(0) here would stall every pair on it). The kernel must stay spill-free for this to hold
+            // (tools/kernel_resources.py).
+            if constexpr (DS) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if constexpr (!K4_SPREAD) stage_pair(pr + 3, (it + 3) & 3);
+        }
+        TLK_STAMP(8) // (LAST slices: after the counted vmcnt wait and the barrier)
+        // the slice's dS, already packed as two MFMA operands (df[0]: complete; df[1]: packed under the MFMAs of q6): two 1 KiB stores
+        // per wave, each issued behind an MFMA (at the end of the slice their issue - ~100 cycles apiece with nothing queued in the
+        // matrix pipe - was dead time: tools/attn_timeline.py --dkv)
+        uint64_t tb = 0;
+        if constexpr (DS) {
+            const int sl_ = (int)(qs >> 5);
+            const char *tile = ds_base + ((int64_t)((sl_ >> 3) * ds_qb_tiles + (sl_ & 7)) << 11); // 32-bit tile index, DS_TILE = 2^11
+            tb = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile) |
+                 ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)tile >> 32)) << 32);
         }
         k4_rows4<NOFF>(en, on, g0);
         k4_wait_tr<15>(t6);
@@ -1143,8 +1217,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
                 if (d == 2) stage_piece(std::integral_constant<int, 2>{}, pr + 3, (it + 3) & 3);
                 if (d == 3) stage_piece(std::integral_constant<int, 3>{}, pr + 3, (it + 3) & 3);
             }
+            // write-through (sc0 sc1): the lines leave the XCD's L2 instead of evicting the Q / dO slices the workgroups of a head
+            // share through it (measured at C3: 2.476 ms against 2.516 plain and 2.528 nt; 2.455 without the stores)
+            if (DS && d == 1) asm volatile("global_store_dwordx4 %0, %1, %2 offset:0 sc0 sc1" : : "v"(ds_lane), "v"(df[0]), "s"(tb) : "memory");
             asm volatile("" : "+a"(dk[(d + 1) & 3]), "+v"(df[1]) : : "memory");
         }
+        TLK_STAMP(7)
         // q7: dK k-step 1; the next slice's S accumulator takes its row constants (- lse sqrt(D))
         k4_rows4<NOFF + 1024>(en, on, g1);
         k4_rowc<NOFF + 128>(ln, cp);
@@ -1168,24 +1246,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
                 if (d == 2) stage_piece(std::integral_constant<int, 6>{}, pr + 3, (it + 3) & 3);
                 if (d == 3) stage_piece(std::integral_constant<int, 7>{}, pr + 3, (it + 3) & 3);
             }
+            if (DS && d == 1) asm volatile("global_store_dwordx4 %0, %1, %2 offset:1024 sc0 sc1" : : "v"(ds_lane), "v"(df[1]), "s"(tb) : "memory");
             asm volatile("" : "+a"(dk[(d + 1) & 3]), "+a"(svn) : : "memory");
         }
         if constexpr (LAST && K4_SPREAD) {
             stage_piece(std::integral_constant<int, 8>{}, pr + 3, (it + 3) & 3);
             stage_piece(std::integral_constant<int, 9>{}, pr + 3, (it + 3) & 3);
         }
-        if constexpr (DS) { // the slice's dS, already packed as two MFMA operands: two 1 KiB stores per wave (behind the DMA: K4_VMCNT)
-            const int sl_ = (int)(qs >> 5);
-            const char *tile = ds_base + ((int64_t)((sl_ >> 3) * ds_qb_tiles + (sl_ & 7)) << 11); // 32-bit tile index, DS_TILE = 2^11
-            const uint64_t tb = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile) |
-                                ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)tile >> 32)) << 32);
-            // write-through (sc0 sc1): the lines leave the XCD's L2 instead of evicting the Q / dO slices the workgroups of a head
-            // share through it (measured at C3: 2.476 ms against 2.516 plain and 2.528 nt; 2.455 without the stores)
-            asm volatile("global_store_dwordx4 %0, %1, %3 offset:0 sc0 sc1\n\tglobal_store_dwordx4 %0, %2, %3 offset:1024 sc0 sc1"
-                         :
-                         : "v"(ds_lane), "v"(df[0]), "v"(df[1]), "s"(tb)
-                         : "memory");
-        }
+        TLK_STAMP(9)
+#ifdef KF_ATTN_TIMELINE
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(tlk[0]), "+s"(tlk[1]), "+s"(tlk[2]), "+s"(tlk[3]), "+s"(tlk[4]), "+s"(tlk[5]), "+s"(tlk[6]), "+s"(tlk[7]),
+                                              "+s"(tlk[8]), "+s"(tlk[9]) : : "memory");
+        tlk_acc[0] += tlk[1] - tlk[0]; tlk_acc[1] += tlk[2] - tlk[1]; tlk_acc[2] += tlk[3] - tlk[2]; tlk_acc[3] += tlk[4] - tlk[3];
+        tlk_acc[4] += tlk[5] - tlk[4]; tlk_acc[5] += tlk[6] - tlk[5]; tlk_acc[6] += tlk[8] - tlk[6]; tlk_acc[7] += tlk[7] - tlk[8];
+        tlk_acc[8] += tlk[9] - tlk[7]; tlk_acc[9] += tlk[0] - tlk_prev; tlk_prev = tlk[9]; tlk_acc[10] += 1;
+#endif
     };
 
     // Head size 64: the same slice with half the k-steps and half the column blocks - six phases of 4, 4, 2, 2, 2, 2 MFMAs
@@ -1314,6 +1389,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     int pr = p0, it = 0;
     for (; pr < np && (int64_t)pr * 2 * BQS < kw + 31; ++pr, ++it) pair_body(std::true_type{}, pr, it);
     for (; pr < np; ++pr, ++it) pair_body(std::false_type{}, pr, it);
+#ifdef KF_ATTN_TIMELINE
+    if (lane == 0 && g_attn_tl && D == 128) { // q0..q5, q6's wait + barrier, q6, q7, between slices (dS stores, loop edge), slices
+        unsigned long long *dst = g_attn_tl + ((size_t)blockIdx.x * 2 + (pass & 1)) * 64 + wid * 16;
+        for (int i = 0; i < 11; ++i) dst[i] = tlk_acc[i];
+    }
+#endif
 #undef K4_MFMA4
 #undef K4_CVT2
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // drain the ring and the last prefetch before LDS is reused
@@ -2289,3 +2370,10 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
 #undef KF_GENERIC_BWD
     return KF_OK;
 }
+
+#ifdef KF_ATTN_TIMELINE
+extern "C" int kfdbg_attn_timeline(void *buf) { // buf: grid x 2 passes x 8 waves x 8 counters of 8 bytes, zero-filled by the caller
+    unsigned long long *p = (unsigned long long *)buf;
+    return hipMemcpyToSymbol(HIP_SYMBOL(kf::g_attn_tl), &p, sizeof(p)) == hipSuccess ? KF_OK : KF_ERR_HIP;
+}
+#endif
