@@ -1386,8 +1386,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     };
     // two loops, one body each (a loop that switches between the masked and the plain body makes the allocator shuttle
     // the dK / dV accumulators between the two register files at every iteration)
+    // pairs p0 .. pm - 1 touch this wave's diagonal (pair pr holds queries 64 pr .. 64 pr + 63; masked while 64 pr < kw + 31): a
+    // plain scalar trip count (with the 64-bit compare in the loop condition a variant of this kernel had three accumulator tuples
+    // parked in scratch at every iteration of the masked loop)
+    int pm = (int)((kw + 31 + 2 * BQS - 1) / (2 * BQS));
+    pm = __builtin_amdgcn_readfirstlane(pm < np ? pm : np);
     int pr = p0, it = 0;
-    for (; pr < np && (int64_t)pr * 2 * BQS < kw + 31; ++pr, ++it) pair_body(std::true_type{}, pr, it);
+    for (; pr < pm; ++pr, ++it) pair_body(std::true_type{}, pr, it);
     for (; pr < np; ++pr, ++it) pair_body(std::false_type{}, pr, it);
 #ifdef KF_ATTN_TIMELINE
     if (lane == 0 && g_attn_tl && D == 128) { // q0..q5, q6's wait + barrier, q6, q7, between slices (dS stores, loop edge), slices
