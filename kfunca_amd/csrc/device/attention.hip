@@ -930,6 +930,105 @@ __device__ __forceinline__ f32x16 k4_acc(const f32x4 (&c)[4]) {
     return r;
 }
 
+// ---- head size 128: the S and dP chains as inline-asm MFMAs whose accumulator is a VGPR tuple ----------------------------------
+// hipcc gives every MFMA *builtin* of a kernel that uses accumulator registers an AGPR destination, and the VALU cannot read an
+// AGPR: each exp2 / multiply of a score then costs a v_accvgpr_read on top, and the row constants reach the accumulators through
+// v_accvgpr_mov (136 of the 274 VALU instructions of a slice pair; with one wave per SIMD a wave's VALU instructions do not run
+// under its own MFMAs - tools/scratch/mfma_valu_overlap.hip - so they are time). Written as asm the chains keep S and dP in VGPRs
+// (read in place), start from the row constants as the C operand of their first MFMA (no copies), and take the K / V operands
+// from AGPRs, which is where the 64 registers of those fragments now live (only MFMAs read them).
+// Hazards the compiler cannot see inside asm: an 8-pass MFMA's VGPR result may be read by the VALU 11 wait states later
+// (GFX940 XDL write -> VALU read); every first read below sits behind >= 8 LDS instructions, a wait and an MFMA, plus the s_nop
+// of the pin that follows; the first MFMA of a chain carries an s_nop 1 in front for a C operand the compiler might have just moved.
+// And the other direction: to the compiler an asm statement is done with its inputs when it is issued, so it would hand an A or C
+// operand's registers to the very next VALU result (it did: v_exp_f32 into the first register of the fragment an MFMA two
+// instructions earlier was still reading - NaNs in one accumulator element of the masked loop only). The VGPR operands are
+// therefore in-out operands of the MFMA statements and stay live until k4_keep() names them, a quarter-phase later.
+template <int OFF>
+__device__ __forceinline__ void k4_rows4a(unsigned e, unsigned o, s16x8 (&f)[4]) { // k4_rows4 into accumulator registers
+    asm volatile("ds_read_b128 %0, %4 offset:%c6\n\tds_read_b128 %1, %5 offset:%c6\n\t"
+                 "ds_read_b128 %2, %4 offset:%c7\n\tds_read_b128 %3, %5 offset:%c7"
+                 : "=&a"(f[0]), "=&a"(f[1]), "=&a"(f[2]), "=&a"(f[3])
+                 : "v"(e), "v"(o), "n"(OFF), "n"(OFF + 512)
+                 : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void k4_rowcv(unsigned lr, f32x4 (&c)[4]) { // k4_rowc into VGPR quads
+    asm volatile("ds_read_b128 %0, %4 offset:%c5\n\tds_read_b128 %1, %4 offset:%c6\n\t"
+                 "ds_read_b128 %2, %4 offset:%c7\n\tds_read_b128 %3, %4 offset:%c8"
+                 : "=&v"(c[0]), "=&v"(c[1]), "=&v"(c[2]), "=&v"(c[3])
+                 : "v"(lr), "n"(OFF), "n"(OFF + 32), "n"(OFF + 64), "n"(OFF + 96)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void k4_wait4a_cv(s16x8 (&f)[4], f32x4 (&c)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%c8)"
+                 : "+a"(f[0]), "+a"(f[1]), "+a"(f[2]), "+a"(f[3]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+                 : "n"(N)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void k4_wait4a(s16x8 (&f)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%c4)" : "+a"(f[0]), "+a"(f[1]), "+a"(f[2]), "+a"(f[3]) : "n"(N) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void k4_wait4_cv(s16x8 (&f)[4], f32x4 (&c)[4]) {
+    asm volatile("s_waitcnt lgkmcnt(%c8)"
+                 : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3])
+                 : "n"(N)
+                 : "memory");
+}
+// The slice's LDS reads one or two per MFMA gap instead of four to twelve at the head of a quarter-phase (a lone wave hides about
+// five single-issue instructions behind an MFMA; a burst of reads in one gap is paid in full: MI355X_MICROARCH.md, "one wave per
+// SIMD ... HIDDEN per MFMA gap"). Pieces of k4_rows4 / k4_rowc / k4_tr4:
+template <int OFF>
+__device__ __forceinline__ void k4_row1(unsigned a, s16x8 &f) { asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=&v"(f) : "v"(a), "n"(OFF) : "memory"); }
+template <int OFF>
+__device__ __forceinline__ void k4_row1a(unsigned a, s16x8 &f) { asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=&a"(f) : "v"(a), "n"(OFF) : "memory"); }
+template <int OFF>
+__device__ __forceinline__ void k4_rowc1(unsigned lr, f32x4 &c) { asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=&v"(c) : "v"(lr), "n"(OFF) : "memory"); }
+template <int OFF>
+__device__ __forceinline__ void k4_trp(unsigned t0, unsigned t1, s16x4 &lo, s16x4 &hi) { // one column block of a 16-row k-step
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%c4\n\tds_read_b64_tr_b16 %1, %3 offset:%c4" : "=&v"(lo), "=&v"(hi) : "v"(t0), "v"(t1), "n"(OFF) : "memory");
+}
+// acc = A B + C (first MFMA of a chain; A fragment in AGPRs (AA) or VGPRs), acc += A B (the rest)
+template <bool BF, bool AA>
+__device__ __forceinline__ void k4_mfma_first(f32x16 &acc, s16x8 &a, const typename AFrag<BF>::type &b, f32x16 &c) {
+    if constexpr (BF) {
+        if constexpr (AA) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %3, %2" : "=&v"(acc), "+a"(a), "+v"(c) : "a"(b));
+        else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %3, %2" : "=&v"(acc), "+v"(a), "+v"(c) : "a"(b));
+    } else {
+        if constexpr (AA) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %3, %2" : "=&v"(acc), "+a"(a), "+v"(c) : "a"(b));
+        else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %3, %2" : "=&v"(acc), "+v"(a), "+v"(c) : "a"(b));
+    }
+}
+template <bool BF, bool AA>
+__device__ __forceinline__ void k4_mfma_acc(f32x16 &acc, s16x8 &a, const typename AFrag<BF>::type &b) {
+    if constexpr (BF) {
+        if constexpr (AA) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc), "+a"(a) : "a"(b));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc), "+v"(a) : "a"(b));
+    } else {
+        if constexpr (AA) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc), "+a"(a) : "a"(b));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc), "+v"(a) : "a"(b));
+    }
+}
+// the same with a second VGPR tuple as an in-out operand that the instruction does not touch: the arithmetic on `tag` (exp2 of S
+// beside the dP chain) then stays between two MFMAs of the chain without separate ordering statements (hipcc pads every inline
+// asm whose registers a neighbouring instruction touches with a wait state: three s_nop per MFMA gap with the pins, one without)
+template <bool BF>
+__device__ __forceinline__ void k4_mfma_first_t(f32x16 &acc, s16x8 &a, const typename AFrag<BF>::type &b, f32x16 &c, f32x16 &tag) {
+    if constexpr (BF) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %4, %2\n\ts_nop 1" : "=&v"(acc), "+v"(a), "+v"(c), "+v"(tag) : "a"(b));
+    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %4, %2\n\ts_nop 1" : "=&v"(acc), "+v"(a), "+v"(c), "+v"(tag) : "a"(b));
+}
+template <bool BF>
+__device__ __forceinline__ void k4_mfma_acc_t(f32x16 &acc, s16x8 &a, const typename AFrag<BF>::type &b, f32x16 &tag) {
+    if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %3, %0" : "+v"(acc), "+v"(a), "+v"(tag) : "a"(b));
+    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %3, %0" : "+v"(acc), "+v"(a), "+v"(tag) : "a"(b));
+}
+// the registers of these operands may be reused only after this point
+__device__ __forceinline__ void k4_keep(s16x8 (&f)[4]) { asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3])); }
+__device__ __forceinline__ void k4_keep(f32x16 &c) { asm volatile("" : "+v"(c)); }
+
 // two column blocks of one 16-row k-step (head size 64)
 template <int OFF>
 __device__ __forceinline__ void k4_tr2(unsigned t0, unsigned t1, K4Tr &t) {
@@ -944,12 +1043,20 @@ __device__ __forceinline__ void k4_wait_tr2(K4Tr &a) {
     asm volatile("s_waitcnt lgkmcnt(%c4)" : "+v"(a.lo[0]), "+v"(a.hi[0]), "+v"(a.lo[1]), "+v"(a.hi[1]) : "n"(N) : "memory");
 }
 
+// one v_mul_f32, opaque to the vectoriser: beside MFMAs a v_pk_mul_f32 costs more than the two multiplies it replaces
+// (MI355X_MICROARCH.md, "packed f32 VALU ... an anti-lever beside MFMAs"), and -O3 packs adjacent tuple elements on its own
+// (the odd element of a pair as a x b + 0: a v_fma_f32 beside a v_mul_f32 is not a pair the vectoriser packs, and neither is inline
+// asm, around which hipcc would put wait states)
+__device__ __forceinline__ float k4_mul(float a, float b) { return a * b; }
+__device__ __forceinline__ float k4_mul_odd(float a, float b) { return __builtin_fmaf(a, b, 0.f); }
 #ifdef KF_ABL_DKV_NOVALU // ablation (scratch builds only): the slice without its exp2 and its dS multiplies
 #define KF_ABL_EXP(x) (x)
 #define KF_ABL_MUL(a, b) (b)
+#define KF_ABL_MUL_ODD(a, b) (b)
 #else
 #define KF_ABL_EXP(x) __builtin_amdgcn_exp2f(x)
-#define KF_ABL_MUL(a, b) ((a) * (b))
+#define KF_ABL_MUL(a, b) k4_mul(a, b)
+#define KF_ABL_MUL_ODD(a, b) k4_mul_odd(a, b)
 #endif
 template <bool BF, bool DS, int D>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) {
@@ -990,6 +1097,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
                 if constexpr (BF) kf[kk][j] = (__bf16)((float)kf[kk][j] * c);
                 else kf[kk][j] = (_Float16)((float)kf[kk][j] * c);
             }
+        if constexpr (D == 128) { // only MFMAs read them from here on: accumulator registers
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) asm volatile("" : "+a"(kf[kk]), "+a"(vf[kk]));
+        }
     }
     f32x16 dk[4], dv[4]; // head size 64 uses column blocks 0 and 1
 #pragma unroll
@@ -1079,13 +1190,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     s16x8 g0[4], g1[4];
     f32x4 cs[4], cp[4];
     f32x16 svA, svB; // S accumulators of the even / odd slice of a pair: each slice fills the OTHER one's row constants (no copies)
-    k4_rowc<0>(lr, cs);
-    k4_rows4<0>(rb_e, rb_o, g0);
-    if constexpr (D == 128) k4_rows4<1024>(rb_e, rb_o, g1);
-    k4_rowc<128>(lr, cp);
-    if constexpr (D == 128) asm volatile("s_waitcnt lgkmcnt(12)" : "+a"(cs[0]), "+a"(cs[1]), "+a"(cs[2]), "+a"(cs[3]) : : "memory");
-    else asm volatile("s_waitcnt lgkmcnt(8)" : "+a"(cs[0]), "+a"(cs[1]), "+a"(cs[2]), "+a"(cs[3]) : : "memory");
-    svA = k4_acc(cs);
+    if constexpr (D == 128) { // the first slice's first groups: constants into VGPR quads, Q rows into accumulator registers
+        k4_rowcv<0>(lr, cs);
+        k4_rows4a<0>(rb_e, rb_o, g0);
+        k4_rows4a<1024>(rb_e, rb_o, g1);
+        k4_rowcv<128>(lr, cp);
+    } else {
+        k4_rowc<0>(lr, cs);
+        k4_rows4<0>(rb_e, rb_o, g0);
+        k4_rowc<128>(lr, cp);
+        asm volatile("s_waitcnt lgkmcnt(8)" : "+a"(cs[0]), "+a"(cs[1]), "+a"(cs[2]), "+a"(cs[3]) : : "memory");
+        svA = k4_acc(cs);
+    }
 
 #define K4_MFMA4(ACC, FR, BOP, K0)                                                                                   \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) ACC = a_mfma<BF>(__builtin_bit_cast(frag_t, FR[kk]), BOP[K0 + kk], ACC);
@@ -1095,87 +1211,102 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
 
     // SOFF: this slice's offset inside its pair buffer (bases e, o, t0, t1, l); the next slice's first groups are read off
     // (en, on, ln) + NOFF; LAST: the slice that ends a pair (barrier + DMA of the pair after next before its q6)
-    auto slice_body = [&, ds_lane, ds_base, ds_qb_tiles](auto mask_c, auto soff_c, auto noff_c, auto last_c, f32x16 &sv, f32x16 &svn, unsigned e, unsigned o, unsigned t0,
+    auto slice_body = [&, ds_lane, ds_base, ds_qb_tiles](auto mask_c, auto soff_c, auto noff_c, auto last_c, unsigned e, unsigned o, unsigned t0,
                           unsigned t1, unsigned l, unsigned en, unsigned on, unsigned ln, int64_t qs, int pr, int it) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(mask_c)::value, LAST = decltype(last_c)::value;
         constexpr int SOFF = decltype(soff_c)::value, NOFF = decltype(noff_c)::value, DO = SOFF + BQS * AROW;
-        f32x16 dpv;
+        // LDS reads, one or two behind every MFMA, each group requested during the quarter-phase TWO before the one that consumes it:
+        //   q0: g2 (dO rows k 0..3)   q1: g3 (dO rows k 4..7)   q2: t4 (dO^T k-step 0)   q3: t5 (dO^T k-step 1)   q4: t6 (Q^T 0)   q5: t7 (Q^T 1)
+        //   q6: the next slice's S constants + its Q rows k 0..3 (after the pair barrier)   q7: its Q rows k 4..7 + its dP constants
+        // so a quarter-phase opens with one counted wait that leaves exactly the previous quarter-phase's group in flight
+        // (lgkmcnt 8, 4, 4, 8, 8, 8, 8, 8 for q0 .. q7).
+        f32x16 sv, dpv; // VGPR tuples: written by the asm MFMA chains; p = exp2(S'') replaces S in place and dS = p dP' replaces dP
+        const int nd = (int)(n - qs) - 4 * hl; // key - query of accumulator element e is nd - a_row(e, 0): masked when positive
         s16x8 g2[4], g3[4];
         K4Tr t4, t5, t6, t7;
         frag_t pf[2], df[2];
-        float pe[16], de[16];
         TLK_STAMP(0)
         // q0: S k-steps 0..3
-        k4_rows4<DO>(e, o, g2);
-        k4_wait4<12>(g0);
-        K4_MFMA4(sv, g0, kf, 0)
+        k4_wait4a_cv<8>(g0, cs);
+        f32x16 c_s = k4_acc(cs), c_p;
+        k4_mfma_first<BF, true>(sv, g0[0], kf[0], c_s); // C = - lse log2(e): the chain starts from the row constants
+        k4_row1<DO>(e, g2[0]);
+        k4_mfma_acc<BF, true>(sv, g0[1], kf[1]);
+        k4_row1<DO>(o, g2[1]);
+        k4_mfma_acc<BF, true>(sv, g0[2], kf[2]);
+        k4_row1<DO + 512>(e, g2[2]);
+        k4_mfma_acc<BF, true>(sv, g0[3], kf[3]);
+        k4_row1<DO + 512>(o, g2[3]);
         TLK_STAMP(1)
-        // q1: S k-steps 4..7; the dP accumulator takes its row constants (- delta)
-        k4_rows4<DO + 1024>(e, o, g3);
-        k4_wait4c<8>(g1, cp);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            sv = a_mfma<BF>(__builtin_bit_cast(frag_t, g1[kk]), kf[4 + kk], sv);
-            asm volatile("" : "+a"(sv), "+a"(cp[kk]));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) dpv[4 * kk + j] = cp[kk][j];
-            asm volatile("" : "+a"(sv), "+a"(dpv));
-        }
+        // q1: S k-steps 4..7
+        k4_wait4a<4>(g1);
+        k4_mfma_acc<BF, true>(sv, g1[0], kf[4]);
+        k4_row1<DO + 1024>(e, g3[0]);
+        k4_mfma_acc<BF, true>(sv, g1[1], kf[5]);
+        k4_row1<DO + 1024>(o, g3[1]);
+        k4_mfma_acc<BF, true>(sv, g1[2], kf[6]);
+        k4_row1<DO + 1536>(e, g3[2]);
+        k4_mfma_acc<BF, true>(sv, g1[3], kf[7]);
+        k4_row1<DO + 1536>(o, g3[3]);
+        k4_keep(c_s);
         TLK_STAMP(2)
-        // q2: dP k-steps 0..3; p = exp2(c S') for elements 0..7
-        k4_tr4<DO>(t0, t1, t4);
-        k4_wait4<12>(g2);
+        // q2: dP k-steps 0..3; p = exp2(S'') for elements 0..7
+        k4_wait4_cv<4>(g2, cp);
 #define K4_EXP2(E)                                                                      \
     _Pragma("unroll") for (int e_ = (E); e_ < (E) + 2; ++e_) {                          \
         float pv = KF_ABL_EXP(sv[e_]);                                                  \
-        if (MASK && n > qs + a_row(e_, hl)) pv = 0.f;                                   \
-        pe[e_] = pv;                                                                    \
+        if (MASK && nd > a_row(e_, 0)) pv = 0.f;                                        \
+        sv[e_] = pv;                                                                    \
     }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            dpv = a_mfma<BF>(__builtin_bit_cast(frag_t, g2[kk]), vf[kk], dpv);
-            asm volatile("" : "+a"(dpv), "+a"(sv));
-            K4_EXP2(2 * kk)
-            asm volatile("" : "+a"(dpv), "+v"(pe[2 * kk]), "+v"(pe[2 * kk + 1]));
-        }
+#define K4_Q2(KK)                                                                                       \
+    if constexpr ((KK) == 0) {                                                                          \
+        c_p = k4_acc(cp);                                                                               \
+        k4_mfma_first_t<BF>(dpv, g2[0], vf[0], c_p, sv); /* C = - delta; S is read from here on: hazard note */ \
+    } else {                                                                                            \
+        k4_mfma_acc_t<BF>(dpv, g2[KK], vf[KK], sv);                                                     \
+    }                                                                                                   \
+    K4_EXP2(2 * (KK))                                                                                   \
+    k4_trp<DO + 512 * (KK)>(t0, t1, t4.lo[KK], t4.hi[KK]);
+        K4_Q2(0) K4_Q2(1) K4_Q2(2) K4_Q2(3)
+#undef K4_Q2
         TLK_STAMP(3)
         // q3: dP k-steps 4..7; elements 8..15; pack p of k-step 0
-        k4_tr4<DO + 4096>(t0, t1, t5);
-        k4_wait4<15>(g3);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            dpv = a_mfma<BF>(__builtin_bit_cast(frag_t, g3[kk]), vf[4 + kk], dpv);
-            asm volatile("" : "+a"(dpv), "+a"(sv), "+v"(pe[2 * kk]), "+v"(pe[2 * kk + 1]));
-            K4_EXP2(8 + 2 * kk)
-            K4_CVT2(pf[0], 2 * kk, pe[2 * kk], pe[2 * kk + 1])
-            asm volatile("" : "+a"(dpv), "+v"(pe[8 + 2 * kk]), "+v"(pe[9 + 2 * kk]), "+v"(pf[0]));
-        }
+        k4_wait4<8>(g3);
+#define K4_Q3(KK)                                                                                       \
+    k4_mfma_acc_t<BF>(dpv, g3[KK], vf[4 + (KK)], sv);                                                   \
+    K4_EXP2(8 + 2 * (KK))                                                                               \
+    K4_CVT2(pf[0], 2 * (KK), sv[2 * (KK)], sv[2 * (KK) + 1])                                            \
+    k4_trp<DO + 4096 + 512 * (KK)>(t0, t1, t5.lo[KK], t5.hi[KK]);
+        K4_Q3(0) K4_Q3(1) K4_Q3(2) K4_Q3(3)
+#undef K4_Q3
 #undef K4_EXP2
+        k4_keep(c_p);
+        k4_keep(g2);
         TLK_STAMP(4)
         // q4: dV k-step 0; dS = p dP' for elements 0..7; pack p of k-step 1
-        k4_tr4<SOFF>(t0, t1, t6);
-        k4_wait_tr<15>(t4);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            dv[d] = a_mfma<BF>(k4_frag<BF>(t4, d), pf[0], dv[d]);
-            asm volatile("" : "+a"(dv[d]), "+a"(dpv), "+v"(pe[8 + 2 * d]), "+v"(pe[9 + 2 * d]));
-            de[2 * d] = KF_ABL_MUL(pe[2 * d], dpv[2 * d]); de[2 * d + 1] = KF_ABL_MUL(pe[2 * d + 1], dpv[2 * d + 1]);
-            K4_CVT2(pf[1], 2 * d, pe[8 + 2 * d], pe[9 + 2 * d])
-            asm volatile("" : "+a"(dv[(d + 1) & 3]), "+v"(de[2 * d]), "+v"(de[2 * d + 1]), "+v"(pf[1]));
-        }
+        k4_wait_tr<8>(t4);
+#define K4_Q4(DD)                                                                                                       \
+    dv[DD] = a_mfma<BF>(k4_frag<BF>(t4, DD), pf[0], dv[DD]);                                                            \
+    asm volatile("" : "+a"(dv[DD]), "+v"(dpv), "+v"(sv));                                                               \
+    dpv[2 * (DD)] = KF_ABL_MUL(sv[2 * (DD)], dpv[2 * (DD)]); dpv[2 * (DD) + 1] = KF_ABL_MUL_ODD(sv[2 * (DD) + 1], dpv[2 * (DD) + 1]); \
+    K4_CVT2(pf[1], 2 * (DD), sv[8 + 2 * (DD)], sv[9 + 2 * (DD)])                                                        \
+    asm volatile("" : "+a"(dv[((DD) + 1) & 3]), "+v"(dpv), "+v"(pf[1]));                                                \
+    k4_trp<SOFF + 512 * (DD)>(t0, t1, t6.lo[DD], t6.hi[DD]);
+        K4_Q4(0) K4_Q4(1) K4_Q4(2) K4_Q4(3)
+#undef K4_Q4
+        k4_keep(g3);
         TLK_STAMP(5)
         // q5: dV k-step 1; dS for elements 8..15; pack dS of k-step 0
-        k4_tr4<SOFF + 4096>(t0, t1, t7);
-        k4_rowc<NOFF>(ln, cs); // the next slice's S constants (q7 moves them into its accumulator)
-        k4_wait_tr<15>(t5);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            dv[d] = a_mfma<BF>(k4_frag<BF>(t5, d), pf[1], dv[d]);
-            asm volatile("" : "+a"(dv[d]), "+a"(dpv), "+v"(de[2 * d]), "+v"(de[2 * d + 1]));
-            de[8 + 2 * d] = KF_ABL_MUL(pe[8 + 2 * d], dpv[8 + 2 * d]); de[9 + 2 * d] = KF_ABL_MUL(pe[9 + 2 * d], dpv[9 + 2 * d]);
-            K4_CVT2(df[0], 2 * d, de[2 * d], de[2 * d + 1])
-            asm volatile("" : "+a"(dv[(d + 1) & 3]), "+v"(de[8 + 2 * d]), "+v"(de[9 + 2 * d]), "+v"(df[0]));
-        }
+        k4_wait_tr<8>(t5);
+#define K4_Q5(DD)                                                                                                       \
+    dv[DD] = a_mfma<BF>(k4_frag<BF>(t5, DD), pf[1], dv[DD]);                                                            \
+    asm volatile("" : "+a"(dv[DD]), "+v"(dpv));                                                                         \
+    dpv[8 + 2 * (DD)] = KF_ABL_MUL(sv[8 + 2 * (DD)], dpv[8 + 2 * (DD)]); dpv[9 + 2 * (DD)] = KF_ABL_MUL_ODD(sv[9 + 2 * (DD)], dpv[9 + 2 * (DD)]); \
+    K4_CVT2(df[0], 2 * (DD), dpv[2 * (DD)], dpv[2 * (DD) + 1])                                                          \
+    asm volatile("" : "+a"(dv[((DD) + 1) & 3]), "+v"(dpv), "+v"(df[0]));                                                \
+    k4_trp<SOFF + 4096 + 512 * (DD)>(t0, t1, t7.lo[DD], t7.hi[DD]);
+        K4_Q5(0) K4_Q5(1) K4_Q5(2) K4_Q5(3)
+#undef K4_Q5
         TLK_STAMP(6)
         // q6: dK k-step 0; pack dS of k-step 1
         if constexpr (LAST) {
@@ -1186,7 +1317,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
             // for (pr + 1) was issued in pair pr - 2's last slice, whose last operation is its last DMA piece; younger than that are
             // pair pr - 1's 2 + (10 + 2) and this pair's first slice's 2 = 16 operations (a store that has just been issued takes
             // ~1 us to retire: vmcnt(0) here would stall every pair on it). The kernel must stay spill-free for this to hold
-            // (tools/kernel_resources.py).
+            // (tools/kernel_resources.py). Every read of the NEXT pair's buffer (the constants and Q rows below) comes after this barrier.
             if constexpr (DS) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -1195,8 +1326,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         }
         TLK_STAMP(8) // (LAST slices: after the counted vmcnt wait and the barrier)
         // the slice's dS, already packed as two MFMA operands (df[0]: complete; df[1]: packed under the MFMAs of q6): two 1 KiB stores
-        // per wave, each issued behind an MFMA (at the end of the slice their issue - ~100 cycles apiece with nothing queued in the
-        // matrix pipe - was dead time: tools/attn_timeline.py --dkv)
+        // per wave, each issued behind an MFMA
         uint64_t tb = 0;
         if constexpr (DS) {
             const int sl_ = (int)(qs >> 5);
@@ -1204,51 +1334,31 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
             tb = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile) |
                  ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)tile >> 32)) << 32);
         }
-        k4_rows4<NOFF>(en, on, g0);
-        k4_wait_tr<15>(t6);
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            dk[d] = a_mfma<BF>(k4_frag<BF>(t6, d), df[0], dk[d]);
-            asm volatile("" : "+a"(dk[d]), "+v"(de[8 + 2 * d]), "+v"(de[9 + 2 * d]));
-            K4_CVT2(df[1], 2 * d, de[8 + 2 * d], de[9 + 2 * d])
-            if constexpr (LAST && K4_SPREAD) { // one DMA operation behind each MFMA: its issue (60-180 cycles) hides in the pipe time
-                if (d == 0) stage_piece(std::integral_constant<int, 0>{}, pr + 3, (it + 3) & 3);
-                if (d == 1) stage_piece(std::integral_constant<int, 1>{}, pr + 3, (it + 3) & 3);
-                if (d == 2) stage_piece(std::integral_constant<int, 2>{}, pr + 3, (it + 3) & 3);
-                if (d == 3) stage_piece(std::integral_constant<int, 3>{}, pr + 3, (it + 3) & 3);
-            }
-            // write-through (sc0 sc1): the lines leave the XCD's L2 instead of evicting the Q / dO slices the workgroups of a head
-            // share through it (measured at C3: 2.476 ms against 2.516 plain and 2.528 nt; 2.455 without the stores)
-            if (DS && d == 1) asm volatile("global_store_dwordx4 %0, %1, %2 offset:0 sc0 sc1" : : "v"(ds_lane), "v"(df[0]), "s"(tb) : "memory");
-            asm volatile("" : "+a"(dk[(d + 1) & 3]), "+v"(df[1]) : : "memory");
-        }
+        k4_wait_tr<8>(t6);
+#define K4_Q6(DD, ID)                                                                                                   \
+    dk[DD] = a_mfma<BF>(k4_frag<BF>(t6, DD), df[0], dk[DD]);                                                            \
+    asm volatile("" : "+a"(dk[DD]), "+v"(dpv));                                                                         \
+    K4_CVT2(df[1], 2 * (DD), dpv[8 + 2 * (DD)], dpv[9 + 2 * (DD)])                                                      \
+    if constexpr (LAST && K4_SPREAD) stage_piece(std::integral_constant<int, ID>{}, pr + 3, (it + 3) & 3);              \
+    /* write-through (sc0 sc1): the lines leave the XCD's L2 instead of evicting the Q / dO slices the workgroups of a head share */ \
+    if (DS && (DD) == 1) asm volatile("global_store_dwordx4 %0, %1, %2 offset:0 sc0 sc1" : : "v"(ds_lane), "v"(df[0]), "s"(tb) : "memory"); \
+    asm volatile("" : "+a"(dk[((DD) + 1) & 3]), "+v"(df[1]) : : "memory");                                              \
+    k4_rowc1<NOFF + 32 * (DD)>(ln, cs[DD]);                                                                             \
+    k4_row1a<NOFF + 512 * ((DD) >> 1)>(((DD) & 1) ? on : en, g0[DD]);
+        K4_Q6(0, 0) K4_Q6(1, 1) K4_Q6(2, 2) K4_Q6(3, 3)
+#undef K4_Q6
         TLK_STAMP(7)
-        // q7: dK k-step 1; the next slice's S accumulator takes its row constants (- lse sqrt(D))
-        k4_rows4<NOFF + 1024>(en, on, g1);
-        k4_rowc<NOFF + 128>(ln, cp);
-        {
-            K4Tr &t = t7;
-            asm volatile("s_waitcnt lgkmcnt(12)"
-                         : "+v"(t.lo[0]), "+v"(t.hi[0]), "+v"(t.lo[1]), "+v"(t.hi[1]), "+v"(t.lo[2]), "+v"(t.hi[2]), "+v"(t.lo[3]), "+v"(t.hi[3]),
-                           "+a"(cs[0]), "+a"(cs[1]), "+a"(cs[2]), "+a"(cs[3])
-                         :
-                         : "memory");
-        }
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            dk[d] = a_mfma<BF>(k4_frag<BF>(t7, d), df[1], dk[d]);
-            asm volatile("" : "+a"(dk[d]), "+a"(cs[d]));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) svn[4 * d + j] = cs[d][j];
-            if constexpr (LAST && K4_SPREAD) {
-                if (d == 0) stage_piece(std::integral_constant<int, 4>{}, pr + 3, (it + 3) & 3);
-                if (d == 1) stage_piece(std::integral_constant<int, 5>{}, pr + 3, (it + 3) & 3);
-                if (d == 2) stage_piece(std::integral_constant<int, 6>{}, pr + 3, (it + 3) & 3);
-                if (d == 3) stage_piece(std::integral_constant<int, 7>{}, pr + 3, (it + 3) & 3);
-            }
-            if (DS && d == 1) asm volatile("global_store_dwordx4 %0, %1, %2 offset:1024 sc0 sc1" : : "v"(ds_lane), "v"(df[1]), "s"(tb) : "memory");
-            asm volatile("" : "+a"(dk[(d + 1) & 3]), "+a"(svn) : : "memory");
-        }
+        // q7: dK k-step 1
+        k4_wait_tr<8>(t7);
+#define K4_Q7(DD, ID)                                                                                                   \
+    dk[DD] = a_mfma<BF>(k4_frag<BF>(t7, DD), df[1], dk[DD]);                                                            \
+    if constexpr (LAST && K4_SPREAD) stage_piece(std::integral_constant<int, ID>{}, pr + 3, (it + 3) & 3);              \
+    if (DS && (DD) == 1) asm volatile("global_store_dwordx4 %0, %1, %2 offset:1024 sc0 sc1" : : "v"(ds_lane), "v"(df[1]), "s"(tb) : "memory"); \
+    asm volatile("" : "+a"(dk[((DD) + 1) & 3]) : : "memory");                                                           \
+    k4_row1a<NOFF + 1024 + 512 * ((DD) >> 1)>(((DD) & 1) ? on : en, g1[DD]);                                            \
+    k4_rowc1<NOFF + 128 + 32 * (DD)>(ln, cp[DD]);
+        K4_Q7(0, 4) K4_Q7(1, 5) K4_Q7(2, 6) K4_Q7(3, 7)
+#undef K4_Q7
         if constexpr (LAST && K4_SPREAD) {
             stage_piece(std::integral_constant<int, 8>{}, pr + 3, (it + 3) & 3);
             stage_piece(std::integral_constant<int, 9>{}, pr + 3, (it + 3) & 3);
@@ -1377,8 +1487,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         const int64_t qa = (int64_t)pr * 2 * BQS, qb = qa + BQS;
         const unsigned e = rb_e + bo, o = rb_o + bo, t0 = tb_0 + bo, t1 = tb_1 + bo, l = lr + bo;
         if constexpr (D == 128) {
-            slice_body(mask_c, I0{}, IS{}, std::false_type{}, svA, svB, e, o, t0, t1, l, e, o, l, qa, pr, it);
-            slice_body(mask_c, IS{}, I0{}, std::true_type{}, svB, svA, e, o, t0, t1, l, rb_e + bn, rb_o + bn, lr + bn, qb, pr, it);
+            slice_body(mask_c, I0{}, IS{}, std::false_type{}, e, o, t0, t1, l, e, o, l, qa, pr, it);
+            slice_body(mask_c, IS{}, I0{}, std::true_type{}, e, o, t0, t1, l, rb_e + bn, rb_o + bn, lr + bn, qb, pr, it);
         } else {
             slice_body64(mask_c, I0{}, IS{}, std::false_type{}, svA, svB, e, o, t0, t1, l, e, o, l, qa, pr, it);
             slice_body64(mask_c, IS{}, I0{}, std::true_type{}, svB, svA, e, o, t0, t1, l, rb_e + bn, rb_o + bn, lr + bn, qb, pr, it);
