@@ -1076,6 +1076,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     const int xp = xb0 + (pass >> 1) * nwx;
     const int xb = ((pass & 1) != (a.persist_rev != 0)) ? nkb - 1 - xp : xp;
     const int64_t k0 = (int64_t)xb * K4B, kw = k0 + wid * 32, n = kw + xl;
+#ifdef KF_ATTN_TIMELINE
+    const unsigned long long tl_pass0 = __builtin_amdgcn_s_memtime();
+#endif
 
     frag_t kf[8], vf[8]; // this wave's 32 keys: B operands of S = Q K^T and dP = dO V^T
     const float c = a.scale * kLog2e;
@@ -1086,20 +1089,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         for (int kk = 0; kk < KS; ++kk) {
             kf[kk] = *(const frag_t *)(Kg + (kk * 16 + 8 * hl) * 2);
             vf[kk] = *(const frag_t *)(Vg + (kk * 16 + 8 * hl) * 2);
-        }
-        // K pre-scaled by c = scale log2(e), once per block: S'' = Q (c K)^T - lse log2(e) leaves the MFMA chain as the exponent
-        // itself (p = exp2(S''), no multiply per score: 32 VALU instructions fewer per slice pair). The 16-bit rounding of c K moves
-        // an exponent by ~1e-3 (p by < 1e-3 relative, a quarter of P's own 16-bit rounding); dK = scale dS^T Q does not see it.
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if constexpr (BF) kf[kk][j] = (__bf16)((float)kf[kk][j] * c);
-                else kf[kk][j] = (_Float16)((float)kf[kk][j] * c);
-            }
-        if constexpr (D == 128) { // only MFMAs read them from here on: accumulator registers
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) asm volatile("" : "+a"(kf[kk]), "+a"(vf[kk]));
         }
     }
     f32x16 dk[4], dv[4]; // head size 64 uses column blocks 0 and 1
@@ -1168,7 +1157,26 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     stage_pair(p0, 0);
     stage_pair(p0 + 1, 1);
     stage_pair(p0 + 2, 2);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // pair p0 has landed (this wave's part) ...
+    { // (after the first three slice pairs are on their way: their latency runs under this arithmetic)
+        // K pre-scaled by c = scale log2(e), once per block: S'' = Q (c K)^T - lse log2(e) leaves the MFMA chain as the exponent
+        // itself (p = exp2(S''), no multiply per score: 32 VALU instructions fewer per slice pair). The 16-bit rounding of c K moves
+        // an exponent by ~1e-3 (p by < 1e-3 relative, a quarter of P's own 16-bit rounding); dK = scale dS^T Q does not see it.
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if constexpr (BF) kf[kk][j] = (__bf16)((float)kf[kk][j] * c);
+                else kf[kk][j] = (_Float16)((float)kf[kk][j] * c);
+            }
+        if constexpr (D == 128) { // only MFMAs read them from here on: accumulator registers
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk) asm volatile("" : "+a"(kf[kk]), "+a"(vf[kk]));
+        }
+    }
+    // pairs p0 and p0 + 1 have landed (this wave's part: everything but the DMA operations of the third pair; the counted wait of
+    // the loop assumes a pair's predecessor-but-one complete, which the first iteration gets from here) ...
+    if constexpr (D == 128) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // ... and everyone else's
     asm volatile("" ::: "memory");
 
@@ -1502,13 +1510,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     int pm = (int)((kw + 31 + 2 * BQS - 1) / (2 * BQS));
     pm = __builtin_amdgcn_readfirstlane(pm < np ? pm : np);
     int pr = p0, it = 0;
+#ifdef KF_ATTN_TIMELINE
+    const unsigned long long tl_loop0 = __builtin_amdgcn_s_memtime();
+#endif
     for (; pr < pm; ++pr, ++it) pair_body(std::true_type{}, pr, it);
     for (; pr < np; ++pr, ++it) pair_body(std::false_type{}, pr, it);
 #ifdef KF_ATTN_TIMELINE
-    if (lane == 0 && g_attn_tl && D == 128) { // q0..q5, q6's wait + barrier, q6, q7, between slices (dS stores, loop edge), slices
-        unsigned long long *dst = g_attn_tl + ((size_t)blockIdx.x * 2 + (pass & 1)) * 64 + wid * 16;
-        for (int i = 0; i < 11; ++i) dst[i] = tlk_acc[i];
-    }
+    const unsigned long long tl_loop1 = __builtin_amdgcn_s_memtime();
 #endif
 #undef K4_MFMA4
 #undef K4_CVT2
@@ -1517,6 +1525,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     a_store_rows<BF, DB>(smem + wid * 32 * OPAD, a.dv + a_head(a.ldv, bh, a.H) + kw * a.ldv.sr, dv, 1.f, a.ldv.sr);
     a_store_rows<BF, DB>(smem + wid * 32 * OPAD, a.dk + a_head(a.ldk, bh, a.H) + kw * a.ldk.sr, dk, a.scale, a.ldk.sr);
     if (a.persist) __syncthreads(); // the staging slabs overlap the ring the next block fills
+#ifdef KF_ATTN_TIMELINE
+    if (lane == 0 && g_attn_tl && D == 128) { // q0..q5, q6's wait + barrier, q6, q7, between slices, slices, prologue, epilogue
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long tl_end = __builtin_amdgcn_s_memtime();
+        unsigned long long *dst = g_attn_tl + ((size_t)blockIdx.x * 2 + (pass & 1)) * 64 + wid * 16;
+        for (int i = 0; i < 11; ++i) dst[i] = tlk_acc[i];
+        dst[11] = tl_loop0 - tl_pass0;
+        dst[12] = tl_end - tl_loop1;
+    }
+#endif
   }
 }
 

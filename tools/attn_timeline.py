@@ -106,6 +106,8 @@ def dkv_timeline(H, args, bufs, o, lse, fn):
     print(f"dK/dV, B {B} H {Hh} S {S} D {D}: {len(t)} wave passes, {slices:.0f} slices, {tot / slices:.0f} cycles per slice of a wave (32 MFMAs = 1024 cycles of pipe time)")
     for i, name in enumerate(DKV_PHASES):
         print(f"  {name:48s} {100 * t[:, i].sum() / tot:5.1f} %   {t[:, i].sum() / slices:6.0f} cycles / slice")
+    print(f"  per pass (one key block of a workgroup): slice loop {tot / len(t):.0f} cycles, before it (K / V fragments, three slice pairs staged, "
+          f"first wait + barrier) {t[:, 11].mean():.0f}, after it (drain, dK / dV through LDS to memory) {t[:, 12].mean():.0f}")
 
 
 if __name__ == "__main__":
