@@ -852,8 +852,11 @@ constexpr int BQS = 32;  // queries per slice
 // (inline-asm reads, counted lgkmcnt waits that name their destinations). The arithmetic hides under MFMAs of the
 // SAME slice: p = exp2(c S') needs only S, so it runs under the dP chain; dV needs only p, so dS = p dP' runs under
 // the dV MFMAs. K and V fragments stay in registers (B operands of S and dP).
-// Row constants as initial accumulators: the pre-pass stores -lse sqrt(D) and -delta, a slice's 2 x 32 of them come
-// into LDS with its tiles and are read straight into the S and dP accumulators, so p = exp2(c S') and dS = p dP'.
+// Row constants as initial accumulators: the pre-pass stores -lse log2(e) and -delta, a slice's 2 x 32 of them come
+// into LDS with its tiles and start the S and dP chains (head size 128: as the C operand of a chain's first MFMA; head size 64:
+// read into the accumulator), so p = exp2(S'') and dS = p dP'.
+// Head size 128 runs the S and dP chains as inline-asm MFMAs on VGPR accumulators (k4_mfma_first / k4_mfma_acc below: what that
+// buys, and the hazards it makes ours); its LDS reads go one or two behind every MFMA. Head size 64 keeps the builtin form.
 // LDS image of a 32-row tile: 8-row x 32-column subtiles of 512 B with the chunk XOR inside a subtile (guide T10,
 // image (a)) - two base VGPRs serve the 8 row reads of a tile and two the 16 transposed reads, the rest are
 // immediates. Q / dO slices stream through a ring of four slice PAIRS by LDS-DMA, one DMA operation per quarter-phase;
