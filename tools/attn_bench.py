@@ -53,7 +53,7 @@ def main():
     results = {v: {} for v in variants}
     for r in range(args.rounds + 1):
         for v in variants:
-            for e in [x for x in os.environ if x.startswith("KF_ATTN") and x != "KF_ATTN_FWD_V3"]:
+            for e in [x for x in os.environ if x.startswith("KF_ATTN")]:
                 del os.environ[e]
             if v != "default":
                 for kv in v.split("+"):
