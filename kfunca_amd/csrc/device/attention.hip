@@ -1020,8 +1020,8 @@ __device__ __forceinline__ void k4_mfma_acc(f32x16 &acc, s16x8 &a, const typenam
 // asm whose registers a neighbouring instruction touches with a wait state: three s_nop per MFMA gap with the pins, one without)
 template <bool BF>
 __device__ __forceinline__ void k4_mfma_first_t(f32x16 &acc, s16x8 &a, const typename AFrag<BF>::type &b, f32x16 &c, f32x16 &tag) {
-    if constexpr (BF) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %4, %2\n\ts_nop 1" : "=&v"(acc), "+v"(a), "+v"(c), "+v"(tag) : "a"(b));
-    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %4, %2\n\ts_nop 1" : "=&v"(acc), "+v"(a), "+v"(c), "+v"(tag) : "a"(b));
+    if constexpr (BF) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %4, %2\n\ts_nop 3" : "=&v"(acc), "+v"(a), "+v"(c), "+v"(tag) : "a"(b));
+    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %4, %2\n\ts_nop 3" : "=&v"(acc), "+v"(a), "+v"(c), "+v"(tag) : "a"(b));
 }
 template <bool BF>
 __device__ __forceinline__ void k4_mfma_acc_t(f32x16 &acc, s16x8 &a, const typename AFrag<BF>::type &b, f32x16 &tag) {
@@ -1294,8 +1294,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         k4_keep(c_p);
         k4_keep(g2);
         TLK_STAMP(4)
-        // q4: dV k-step 0; dS = p dP' for elements 0..7; pack p of k-step 1
+        // q4: dV k-step 0; dS = p dP' for elements 0..7; pack p of k-step 1 (s_nop: the dP chain's result is read three instructions on;
+        // tools/kernel_hazards.py counts the wait states of every such pair in the compiled kernel)
         k4_wait_tr<8>(t4);
+        asm volatile("s_nop 2" : "+v"(dpv));
 #define K4_Q4(DD)                                                                                                       \
     dv[DD] = a_mfma<BF>(k4_frag<BF>(t4, DD), pf[0], dv[DD]);                                                            \
     asm volatile("" : "+a"(dv[DD]), "+v"(dpv), "+v"(sv));                                                               \
