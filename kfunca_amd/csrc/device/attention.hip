@@ -1171,10 +1171,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
                 if constexpr (BF) kf[kk][j] = (__bf16)((float)kf[kk][j] * c);
                 else kf[kk][j] = (_Float16)((float)kf[kk][j] * c);
             }
-        if constexpr (D == 128) { // only MFMAs read them from here on: accumulator registers
+        // only MFMAs read them from here on: accumulator registers
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk) asm volatile("" : "+a"(kf[kk]), "+a"(vf[kk]));
-        }
+        for (int kk = 0; kk < KS; ++kk) asm volatile("" : "+a"(kf[kk]), "+a"(vf[kk]));
     }
     // pairs p0 and p0 + 1 have landed (this wave's part: everything but the DMA operations of the third pair; the counted wait of
     // the loop assumes a pair's predecessor-but-one complete, which the first iteration gets from here) ...
@@ -1200,18 +1199,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
 #endif
     s16x8 g0[4], g1[4];
     f32x4 cs[4], cp[4];
-    f32x16 svA, svB; // S accumulators of the even / odd slice of a pair: each slice fills the OTHER one's row constants (no copies)
     if constexpr (D == 128) { // the first slice's first groups: constants into VGPR quads, Q rows into accumulator registers
         k4_rowcv<0>(lr, cs);
         k4_rows4a<0>(rb_e, rb_o, g0);
         k4_rows4a<1024>(rb_e, rb_o, g1);
         k4_rowcv<128>(lr, cp);
-    } else {
-        k4_rowc<0>(lr, cs);
-        k4_rows4<0>(rb_e, rb_o, g0);
-        k4_rowc<128>(lr, cp);
-        asm volatile("s_waitcnt lgkmcnt(8)" : "+a"(cs[0]), "+a"(cs[1]), "+a"(cs[2]), "+a"(cs[3]) : : "memory");
-        svA = k4_acc(cs);
+    } else { // head size 64: constants, Q rows (accumulator registers), dP constants, dO rows (carried in g1)
+        k4_rowcv<0>(lr, cs);
+        k4_rows4a<0>(rb_e, rb_o, g0);
+        k4_rowcv<128>(lr, cp);
+        k4_rows4<BQS * AROW>(rb_e, rb_o, g1);
     }
 
 #define K4_MFMA4(ACC, FR, BOP, K0)                                                                                   \
@@ -1387,109 +1384,134 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     };
 
     // Head size 64: the same slice with half the k-steps and half the column blocks - six phases of 4, 4, 2, 2, 2, 2 MFMAs
-    // (S | dP | dV k0 | dV k1 | dK k0 | dK k1), one row-read group per operand, transposed groups of 4 reads, 6 DMA operations per
-    // pair. The LDS images, offsets and the dS tiles are those of head size 128 (column blocks 2 and 3 of a tile simply stay
-    // unused). The arithmetic of a slice (the same 16 scores per lane) now weighs as much as its MFMAs, so it is left to the
-    // compiler's scheduler; LDS operations in issue order, with the counts the waits use (operations issued after the awaited one):
-    //   ... t7 4, cs 4 | g0 4 | cp 4 || p0: g2 4 (wait g0: 8) | p2: t4 4, t5 4 (wait g2, cp: 8) | p4: t6 4 (wait t4: 8)
-    //   | p5: t7 4, cs' 4 (wait t5: 12) | p6: g0' 4 (wait t6: 12) | p7: cp' 4 (wait t7, cs': 8)
-    auto slice_body64 = [&, ds_lane, ds_base, ds_qb_tiles](auto mask_c, auto soff_c, auto noff_c, auto last_c, f32x16 &sv, f32x16 &svn, unsigned e, unsigned o,
-                            unsigned t0, unsigned t1, unsigned l, unsigned en, unsigned on, unsigned ln, int64_t qs, int pr, int it) __attribute__((always_inline)) {
+    // (S | dP | dV k0 | dV k1 | dK k0 | dK k1), written like the head-size-128 slice: asm score chains on VGPR accumulators that start
+    // from the row constants, P and dS in place, two LDS reads behind every MFMA. The LDS images, offsets and the dS tiles are those of
+    // head size 128 (column blocks 2 and 3 of a tile simply stay unused); 6 DMA operations per pair. A slice's 16 MFMAs carry the same
+    // 16 scores per lane as 32 do at head size 128, so it is bound by its arithmetic: about 7 instructions per MFMA gap.
+    // LDS reads in issue order (each group 4 reads, two per gap), and the quarter-phase that consumes them:
+    //   p0: t4 (dO^T k0 -> p4), t5 (dO^T k1 -> p5) | p2: t6 (Q^T k0 -> p6), t7 (Q^T k1 -> p7) | p4: the next slice's S constants (-> its p0)
+    //   | p5: its Q rows (-> p0) | p6: its dP constants (-> p2) | p7: its dO rows (-> p2; carried in g1)
+    // counted waits (reads issued after the awaited group): p0 8, p2 8, p4 12, p5 12, p6 12, p7 12. The pair barrier sits in front of
+    // p4: everything read after it belongs to the next pair's buffer when the slice is a pair's last.
+    auto slice_body64 = [&, ds_lane, ds_base, ds_qb_tiles](auto mask_c, auto soff_c, auto noff_c, auto last_c, unsigned e, unsigned o, unsigned t0,
+                            unsigned t1, unsigned l, unsigned en, unsigned on, unsigned ln, int64_t qs, int pr, int it) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(mask_c)::value, LAST = decltype(last_c)::value;
-        constexpr int SOFF = decltype(soff_c)::value, NOFF = decltype(noff_c)::value, DO = SOFF + BQS * AROW;
-        f32x16 dpv;
-        s16x8 g2[4];
+        constexpr int SOFF = decltype(soff_c)::value, NOFF = decltype(noff_c)::value, DO = SOFF + BQS * AROW, NDO = NOFF + BQS * AROW;
+        f32x16 sv, dpv;
+        const int nd = (int)(n - qs) - 4 * hl; // key - query of accumulator element e is nd - a_row(e, 0): masked when positive
         K4Tr t4, t5, t6, t7;
         frag_t pf[2], df[2];
-        float pe[16], de[16];
-        // p0: S
-        k4_rows4<DO>(e, o, g2);
-        k4_wait4<8>(g0);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) sv = a_mfma<BF>(__builtin_bit_cast(frag_t, g0[kk]), kf[kk], sv);
-        // p2: dP = dO V^T - delta; p = exp2(S'')
-        k4_tr2<DO>(t0, t1, t4);
-        k4_tr2<DO + 4096>(t0, t1, t5);
-        k4_wait4c<8>(g2, cp);
-        dpv = k4_acc(cp);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) dpv = a_mfma<BF>(__builtin_bit_cast(frag_t, g2[kk]), vf[kk], dpv);
-#pragma unroll
-        for (int e_ = 0; e_ < 16; ++e_) {
-            float pv = __builtin_amdgcn_exp2f(sv[e_]);
-            if (MASK && n > qs + a_row(e_, hl)) pv = 0.f;
-            pe[e_] = pv;
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if constexpr (BF) { pf[0][j] = (__bf16)pe[j]; pf[1][j] = (__bf16)pe[8 + j]; }
-            else { pf[0][j] = (_Float16)pe[j]; pf[1][j] = (_Float16)pe[8 + j]; }
-        }
-        // p4: dV k-step 0; dS = p dP'
-        k4_tr2<SOFF>(t0, t1, t6);
-        k4_wait_tr2<8>(t4);
-#pragma unroll
-        for (int d = 0; d < 2; ++d) dv[d] = a_mfma<BF>(k4_frag<BF>(t4, d), pf[0], dv[d]);
-#pragma unroll
-        for (int e_ = 0; e_ < 16; ++e_) de[e_] = pe[e_] * dpv[e_];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if constexpr (BF) { df[0][j] = (__bf16)de[j]; df[1][j] = (__bf16)de[8 + j]; }
-            else { df[0][j] = (_Float16)de[j]; df[1][j] = (_Float16)de[8 + j]; }
-        }
-        // p5: dV k-step 1
-        k4_tr2<SOFF + 4096>(t0, t1, t7);
-        k4_rowc<NOFF>(ln, cs);
-        k4_wait_tr2<12>(t5);
-#pragma unroll
-        for (int d = 0; d < 2; ++d) dv[d] = a_mfma<BF>(k4_frag<BF>(t5, d), pf[1], dv[d]);
-        // p6: dK k-step 0
+#define K6_EXP(E)                                                        \
+    {                                                                    \
+        float pv = __builtin_amdgcn_exp2f(sv[E]);                        \
+        if (MASK && nd > a_row(E, 0)) pv = 0.f;                          \
+        sv[E] = pv;                                                      \
+    }
+#define K6_MUL2(E) dpv[E] = k4_mul(sv[E], dpv[E]); dpv[(E) + 1] = k4_mul_odd(sv[(E) + 1], dpv[(E) + 1]);
+        // p0: S (4 MFMAs)
+        k4_wait4a_cv<8>(g0, cs);
+        f32x16 c_s = k4_acc(cs), c_p;
+        k4_mfma_first<BF, true>(sv, g0[0], kf[0], c_s);
+        k4_trp<DO>(t0, t1, t4.lo[0], t4.hi[0]);
+        k4_mfma_acc<BF, true>(sv, g0[1], kf[1]);
+        k4_trp<DO + 512>(t0, t1, t4.lo[1], t4.hi[1]);
+        k4_mfma_acc<BF, true>(sv, g0[2], kf[2]);
+        k4_trp<DO + 4096>(t0, t1, t5.lo[0], t5.hi[0]);
+        k4_mfma_acc<BF, true>(sv, g0[3], kf[3]);
+        k4_trp<DO + 4096 + 512>(t0, t1, t5.lo[1], t5.hi[1]);
+        // p2: dP (4 MFMAs); p = exp2(S'') for elements 0..11, P of k-step 0 packed
+        k4_wait4_cv<8>(g1, cp);
+        c_p = k4_acc(cp);
+        asm volatile("s_nop 3" : "+v"(sv)); // (S is read three instructions on: tools/kernel_hazards.py)
+        k4_mfma_first_t<BF>(dpv, g1[0], vf[0], c_p, sv);
+        K6_EXP(0) K6_EXP(1) K6_EXP(2)
+        k4_trp<SOFF>(t0, t1, t6.lo[0], t6.hi[0]);
+        k4_mfma_acc_t<BF>(dpv, g1[1], vf[1], sv);
+        K6_EXP(3) K6_EXP(4) K6_EXP(5) K4_CVT2(pf[0], 0, sv[0], sv[1]) K4_CVT2(pf[0], 2, sv[2], sv[3])
+        k4_trp<SOFF + 512>(t0, t1, t6.lo[1], t6.hi[1]);
+        k4_mfma_acc_t<BF>(dpv, g1[2], vf[2], sv);
+        K6_EXP(6) K6_EXP(7) K6_EXP(8) K4_CVT2(pf[0], 4, sv[4], sv[5])
+        k4_trp<SOFF + 4096>(t0, t1, t7.lo[0], t7.hi[0]);
+        k4_mfma_acc_t<BF>(dpv, g1[3], vf[3], sv);
+        K6_EXP(9) K6_EXP(10) K6_EXP(11) K4_CVT2(pf[0], 6, sv[6], sv[7])
+        k4_trp<SOFF + 4096 + 512>(t0, t1, t7.lo[1], t7.hi[1]);
+        k4_keep(c_s);
+        // p4: dV k-step 0 (2 MFMAs); the last exponentials; dS = p dP' for elements 0..7; P of k-step 1 packed
         if constexpr (LAST) {
-            // as for head size 128 (see there), with 6 DMA operations per pair: 2 + (2 + 6 + 2) + 2 = 14 younger operations
-            if constexpr (DS) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+            // as for head size 128 (see there): the next pair has landed, the previous pair's buffer is free for pair pr + 3. With 6 DMA
+            // operations per pair and the two dS stores behind MFMAs of p6 / p7: 2 + (6 + 2) + 2 = 12 younger operations.
+            if constexpr (DS) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
-        k4_rows4<NOFF>(en, on, g0);
+        uint64_t tb = 0;
+        if constexpr (DS) {
+            const int sl_ = (int)(qs >> 5);
+            const char *tile = ds_base + ((int64_t)((sl_ >> 3) * ds_qb_tiles + (sl_ & 7)) << 11);
+            tb = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile) |
+                 ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)tile >> 32)) << 32);
+        }
+        k4_wait_tr2<12>(t4);
+        asm volatile("s_nop 2" : "+v"(dpv)); // (the dP chain's result is read a few instructions on)
+        dv[0] = a_mfma<BF>(k4_frag<BF>(t4, 0), pf[0], dv[0]);
+        asm volatile("" : "+a"(dv[0]), "+v"(dpv), "+v"(sv));
+        K6_EXP(12) K6_EXP(13) K6_MUL2(0) K6_MUL2(2) K4_CVT2(pf[1], 0, sv[8], sv[9]) K4_CVT2(pf[1], 2, sv[10], sv[11])
+        asm volatile("" : "+a"(dv[1]), "+v"(dpv), "+v"(sv));
+        k4_rowc1<NOFF>(ln, cs[0]); k4_rowc1<NOFF + 32>(ln, cs[1]);
+        dv[1] = a_mfma<BF>(k4_frag<BF>(t4, 1), pf[0], dv[1]);
+        asm volatile("" : "+a"(dv[1]), "+v"(dpv), "+v"(sv));
+        K6_EXP(14) K6_EXP(15) K6_MUL2(4) K6_MUL2(6) K4_CVT2(pf[1], 4, sv[12], sv[13]) K4_CVT2(pf[1], 6, sv[14], sv[15])
+        asm volatile("" : "+a"(dv[0]), "+v"(dpv), "+v"(pf[1]));
+        k4_rowc1<NOFF + 64>(ln, cs[2]); k4_rowc1<NOFF + 96>(ln, cs[3]);
+        k4_keep(c_p);
+        k4_keep(g1);
+        // p5: dV k-step 1; dS for elements 8..15; dS of k-step 0 packed
+        k4_wait_tr2<12>(t5);
+        dv[0] = a_mfma<BF>(k4_frag<BF>(t5, 0), pf[1], dv[0]);
+        asm volatile("" : "+a"(dv[0]), "+v"(dpv));
+        K6_MUL2(8) K6_MUL2(10) K4_CVT2(df[0], 0, dpv[0], dpv[1]) K4_CVT2(df[0], 2, dpv[2], dpv[3])
+        asm volatile("" : "+a"(dv[1]), "+v"(dpv), "+v"(df[0]));
+        k4_row1a<NOFF>(en, g0[0]); k4_row1a<NOFF>(on, g0[1]);
+        dv[1] = a_mfma<BF>(k4_frag<BF>(t5, 1), pf[1], dv[1]);
+        asm volatile("" : "+a"(dv[1]), "+v"(dpv));
+        K6_MUL2(12) K6_MUL2(14) K4_CVT2(df[0], 4, dpv[4], dpv[5]) K4_CVT2(df[0], 6, dpv[6], dpv[7])
+        asm volatile("" : "+a"(dk[0]), "+v"(dpv), "+v"(df[0]));
+        k4_row1a<NOFF + 512>(en, g0[2]); k4_row1a<NOFF + 512>(on, g0[3]);
+        // p6: dK k-step 0; dS of k-step 1 packed; first dS store
         k4_wait_tr2<12>(t6);
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            dk[d] = a_mfma<BF>(k4_frag<BF>(t6, d), df[0], dk[d]);
-            if constexpr (LAST) {
-                if (d == 0) stage_piece(std::integral_constant<int, 0>{}, pr + 3, (it + 3) & 3);
-                if (d == 1) stage_piece(std::integral_constant<int, 1>{}, pr + 3, (it + 3) & 3);
-            }
-        }
-        // p7: dK k-step 1; the next slice's S accumulator takes its row constants
-        k4_rowc<NOFF + 128>(ln, cp);
-        asm volatile("s_waitcnt lgkmcnt(8)"
-                     : "+v"(t7.lo[0]), "+v"(t7.hi[0]), "+v"(t7.lo[1]), "+v"(t7.hi[1]), "+a"(cs[0]), "+a"(cs[1]), "+a"(cs[2]), "+a"(cs[3])
-                     :
-                     : "memory");
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            dk[d] = a_mfma<BF>(k4_frag<BF>(t7, d), df[1], dk[d]);
-            if constexpr (LAST) {
-                if (d == 0) stage_piece(std::integral_constant<int, 4>{}, pr + 3, (it + 3) & 3);
-                if (d == 1) stage_piece(std::integral_constant<int, 5>{}, pr + 3, (it + 3) & 3);
-            }
-        }
-        svn = k4_acc(cs);
+        dk[0] = a_mfma<BF>(k4_frag<BF>(t6, 0), df[0], dk[0]);
+        asm volatile("" : "+a"(dk[0]), "+v"(dpv));
+        K4_CVT2(df[1], 0, dpv[8], dpv[9]) K4_CVT2(df[1], 2, dpv[10], dpv[11])
+        if constexpr (LAST) stage_piece(std::integral_constant<int, 0>{}, pr + 3, (it + 3) & 3);
+        asm volatile("" : "+a"(dk[1]), "+v"(df[1]) : : "memory");
+        k4_rowc1<NOFF + 128>(ln, cp[0]); k4_rowc1<NOFF + 160>(ln, cp[1]);
+        dk[1] = a_mfma<BF>(k4_frag<BF>(t6, 1), df[0], dk[1]);
+        asm volatile("" : "+a"(dk[1]), "+v"(dpv));
+        K4_CVT2(df[1], 4, dpv[12], dpv[13]) K4_CVT2(df[1], 6, dpv[14], dpv[15])
+        if constexpr (LAST) stage_piece(std::integral_constant<int, 1>{}, pr + 3, (it + 3) & 3);
+        if constexpr (DS) asm volatile("global_store_dwordx4 %0, %1, %2 offset:0 sc0 sc1" : : "v"(ds_lane), "v"(df[0]), "s"(tb) : "memory");
+        asm volatile("" : "+a"(dk[0]), "+v"(df[1]) : : "memory");
+        k4_rowc1<NOFF + 192>(ln, cp[2]); k4_rowc1<NOFF + 224>(ln, cp[3]);
+        // p7: dK k-step 1; second dS store; the next slice's dO rows
+        k4_wait_tr2<12>(t7);
+        dk[0] = a_mfma<BF>(k4_frag<BF>(t7, 0), df[1], dk[0]);
+        asm volatile("" : "+a"(dk[0]));
+        if constexpr (LAST) stage_piece(std::integral_constant<int, 4>{}, pr + 3, (it + 3) & 3);
+        asm volatile("" : "+a"(dk[1]) : : "memory");
+        k4_row1<NDO>(en, g1[0]); k4_row1<NDO>(on, g1[1]);
+        dk[1] = a_mfma<BF>(k4_frag<BF>(t7, 1), df[1], dk[1]);
+        asm volatile("" : "+a"(dk[1]));
+        if constexpr (LAST) stage_piece(std::integral_constant<int, 5>{}, pr + 3, (it + 3) & 3);
+        if constexpr (DS) asm volatile("global_store_dwordx4 %0, %1, %2 offset:1024 sc0 sc1" : : "v"(ds_lane), "v"(df[1]), "s"(tb) : "memory");
+        asm volatile("" : "+a"(dk[0]) : : "memory");
+        k4_row1<NDO + 512>(en, g1[2]); k4_row1<NDO + 512>(on, g1[3]);
         if constexpr (LAST) {
             stage_piece(std::integral_constant<int, 6>{}, pr + 3, (it + 3) & 3);
             stage_piece(std::integral_constant<int, 9>{}, pr + 3, (it + 3) & 3);
         }
-        if constexpr (DS) {
-            const int sl_ = (int)(qs >> 5);
-            const char *tile = ds_base + ((int64_t)((sl_ >> 3) * ds_qb_tiles + (sl_ & 7)) << 11);
-            const uint64_t tb = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile) |
-                                ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)tile >> 32)) << 32);
-            asm volatile("global_store_dwordx4 %0, %1, %3 offset:0 sc0 sc1\n\tglobal_store_dwordx4 %0, %2, %3 offset:1024 sc0 sc1"
-                         :
-                         : "v"(ds_lane), "v"(df[0]), "v"(df[1]), "s"(tb)
-                         : "memory");
-        }
+#undef K6_EXP
+#undef K6_MUL2
     };
 
     using I0 = std::integral_constant<int, 0>;
@@ -1503,8 +1525,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
             slice_body(mask_c, I0{}, IS{}, std::false_type{}, e, o, t0, t1, l, e, o, l, qa, pr, it);
             slice_body(mask_c, IS{}, I0{}, std::true_type{}, e, o, t0, t1, l, rb_e + bn, rb_o + bn, lr + bn, qb, pr, it);
         } else {
-            slice_body64(mask_c, I0{}, IS{}, std::false_type{}, svA, svB, e, o, t0, t1, l, e, o, l, qa, pr, it);
-            slice_body64(mask_c, IS{}, I0{}, std::true_type{}, svB, svA, e, o, t0, t1, l, rb_e + bn, rb_o + bn, lr + bn, qb, pr, it);
+            slice_body64(mask_c, I0{}, IS{}, std::false_type{}, e, o, t0, t1, l, e, o, l, qa, pr, it);
+            slice_body64(mask_c, IS{}, I0{}, std::true_type{}, e, o, t0, t1, l, rb_e + bn, rb_o + bn, lr + bn, qb, pr, it);
         }
     };
     // two loops, one body each (a loop that switches between the masked and the plain body makes the allocator shuttle

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Static check of the hazards hipcc cannot see inside inline-asm MFMAs (dK/dV kernel, head size 128: S and dP chains on VGPR
-accumulators). Compiles kfunca_amd/csrc/device/attention.hip to ISA and, in every attn_bwd_dkv_v4_kernel<*, *, 128>, verifies for each
+"""Static check of the hazards hipcc cannot see inside inline-asm MFMAs (dK/dV kernel, both head sizes: S and dP chains on VGPR
+accumulators). Compiles kfunca_amd/csrc/device/attention.hip to ISA and, in every attn_bwd_dkv_v4_kernel<*, *, 64 | 128>, verifies for each
 `v_mfma_f32_32x32x16_* v[D], A, B, C` (a VGPR destination marks an asm MFMA: the builtin ones write AGPRs there):
 
   RAW / WAW  the first non-MFMA instruction that reads or writes a register of v[D] after the LAST MFMA of its chain comes at least
@@ -101,7 +101,7 @@ def main():
             B._run([B._hipcc(), *B.HIP_FLAGS, "-S", "--cuda-device-only", "-o", out, B.CSRC / "device" / "attention.hip"])
             text = out.read_text()
     total_bad, total = [], 0
-    for m in re.finditer(r"^(_ZN2kf22attn_bwd_dkv_v4_kernelILb[01]ELb[01]ELi128EEEvNS_8AttnArgsE):\s", text, re.M):
+    for m in re.finditer(r"^(_ZN2kf22attn_bwd_dkv_v4_kernelILb[01]ELb[01]ELi(?:64|128)EEEvNS_8AttnArgsE):\s", text, re.M):
         body = text[m.end():]
         body = body[:body.index("s_endpgm")].split("\n")
         bad, n = check(m.group(1), body)
