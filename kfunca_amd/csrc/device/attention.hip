@@ -1566,506 +1566,6 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
 }
 
 // ==========================================================================================
-// forward, v5 (head size 128): 4 waves x 64 queries, ONE wave per SIMD with the whole register file, written the way the dK/dV
-// kernel is (what tools/attn_timeline.py showed about v3: 4990 cycles per tile iteration of a wave for 1024 of matrix-pipe time;
-// phases of two waves that collide on the pipe or wait on each other's softmax; a barrier the early waves spend a quarter of
-// their time in). Here a wave owns TWO 32-query blocks, A and B, and staggers them inside its own instruction stream, so every
-// 16-MFMA phase of one block has the other block's arithmetic to hide (B runs half a tile behind A):
-//     phase 1: S_A(t) = Q_A K(t)^T        | p = exp2(S_B(t-1)) in place, pack P_B(t-1)
-//     phase 2: O_B += P_B(t-1) V(t-1)     | row sums of P_B(t-1), row maxima of S_A(t) (+ the lazy adoption of a new maximum)
-//     phase 3: S_B(t) = Q_B K(t)^T        | p = exp2(S_A(t)), pack P_A(t)
-//     phase 4: O_A += P_A(t) V(t)         | row sums of P_A(t), row maxima of S_B(t)
-// The score chains are inline-asm MFMAs on VGPR accumulators that start from C = -M (the running maximum in exponent units,
-// kept replicated in a 16-register tuple per block): the accumulator IS the exponent, no subtraction per score; Q is pre-scaled by
-// scale log2(e). O (128 registers) and Q (64) live in AGPRs; P V is asm MFMAs on AGPR accumulators;
-// LDS reads go one (K rows) or two (V^T pair) per MFMA, three fragments ahead, with counted lgkmcnt waits. K / V tiles: the v3
-// ring (LDS-DMA, 4 slots; V(t-1) stays for phase 2), 8 DMA instructions per wave and tile.
-// ==========================================================================================
-constexpr int V5NT = 256;
-
-template <int OFF>
-__device__ __forceinline__ void v5_kread(unsigned a, s16x8 &f) { asm volatile("ds_read_b128 %0, %1 offset:%c2" : "=&v"(f) : "v"(a), "n"(OFF) : "memory"); }
-template <int ROFF>
-__device__ __forceinline__ void v5_vread(unsigned a0, unsigned a1, s16x4 &lo, s16x4 &hi) {
-    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%c4\n\tds_read_b64_tr_b16 %1, %3 offset:%c4" : "=&v"(lo), "=&v"(hi) : "v"(a0), "v"(a1), "n"(ROFF) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void v5_waitk(s16x8 &f) { asm volatile("s_waitcnt lgkmcnt(%c1)" : "+v"(f) : "n"(N) : "memory"); }
-template <int N>
-__device__ __forceinline__ void v5_waitv(s16x4 &lo, s16x4 &hi) { asm volatile("s_waitcnt lgkmcnt(%c2)" : "+v"(lo), "+v"(hi) : "n"(N) : "memory"); }
-// S chain: acc = K_frag x Q_frag + C (first) / += (rest); tag: the tuple the surrounding arithmetic works on (ordering only)
-template <bool BF>
-__device__ __forceinline__ void v5_qk_first(f32x16 &acc, s16x8 &k, const typename AFrag<BF>::type &q, f32x16 &c, f32x16 &tag) {
-    if constexpr (BF) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %3, %2" : "=&v"(acc), "+v"(k), "+v"(c) : "a"(q));
-    else asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %3, %2" : "=&v"(acc), "+v"(k), "+v"(c) : "a"(q));
-}
-template <bool BF>
-__device__ __forceinline__ void v5_qk(f32x16 &acc, s16x8 &k, const typename AFrag<BF>::type &q, f32x16 &tag) {
-    if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc), "+v"(k) : "a"(q));
-    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc), "+v"(k) : "a"(q));
-}
-// O^T += V^T_frag x P_frag on an AGPR accumulator
-template <bool BF>
-__device__ __forceinline__ void v5_pv(f32x16 &o, s16x8 &v, typename AFrag<BF>::type &p, f32x16 &tag) {
-    if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o), "+v"(v), "+v"(p));
-    else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(o), "+v"(v), "+v"(p));
-}
-
-// O is "asm-owned": block QB's column block d lives in a[64 QB + 16 d .. + 15] at every statement that touches it, so the (rare)
-// rescale can be one asm block on literal registers instead of 64 values the allocator routes through other registers - with
-// allocator-chosen homes it copied whole 64-register blocks between the two sides of every branch around an adoption.
-// V5_OR_<QB>_<I>: the constraint of the tuple P V step I (column block I & 3) accumulates into.
-#define V5_OR_0_0 "{a[0:15]}"
-#define V5_OR_0_1 "{a[16:31]}"
-#define V5_OR_0_2 "{a[32:47]}"
-#define V5_OR_0_3 "{a[48:63]}"
-#define V5_OR_0_4 "{a[0:15]}"
-#define V5_OR_0_5 "{a[16:31]}"
-#define V5_OR_0_6 "{a[32:47]}"
-#define V5_OR_0_7 "{a[48:63]}"
-#define V5_OR_0_8 "{a[0:15]}"
-#define V5_OR_0_9 "{a[16:31]}"
-#define V5_OR_0_10 "{a[32:47]}"
-#define V5_OR_0_11 "{a[48:63]}"
-#define V5_OR_0_12 "{a[0:15]}"
-#define V5_OR_0_13 "{a[16:31]}"
-#define V5_OR_0_14 "{a[32:47]}"
-#define V5_OR_0_15 "{a[48:63]}"
-#define V5_OR_1_0 "{a[64:79]}"
-#define V5_OR_1_1 "{a[80:95]}"
-#define V5_OR_1_2 "{a[96:111]}"
-#define V5_OR_1_3 "{a[112:127]}"
-#define V5_OR_1_4 "{a[64:79]}"
-#define V5_OR_1_5 "{a[80:95]}"
-#define V5_OR_1_6 "{a[96:111]}"
-#define V5_OR_1_7 "{a[112:127]}"
-#define V5_OR_1_8 "{a[64:79]}"
-#define V5_OR_1_9 "{a[80:95]}"
-#define V5_OR_1_10 "{a[96:111]}"
-#define V5_OR_1_11 "{a[112:127]}"
-#define V5_OR_1_12 "{a[64:79]}"
-#define V5_OR_1_13 "{a[80:95]}"
-#define V5_OR_1_14 "{a[96:111]}"
-#define V5_OR_1_15 "{a[112:127]}"
-#define V5_RESCALE_0(AL, T)                                                           \
-    asm volatile("s_nop 7\n\ts_nop 7\n\t" \
-                 "v_accvgpr_read_b32 %0, a0\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a0, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a1\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a1, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a2\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a2, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a3\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a3, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a4\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a4, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a5\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a5, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a6\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a6, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a7\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a7, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a8\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a8, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a9\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a9, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a10\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a10, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a11\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a11, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a12\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a12, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a13\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a13, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a14\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a14, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a15\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a15, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a16\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a16, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a17\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a17, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a18\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a18, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a19\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a19, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a20\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a20, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a21\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a21, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a22\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a22, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a23\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a23, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a24\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a24, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a25\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a25, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a26\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a26, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a27\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a27, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a28\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a28, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a29\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a29, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a30\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a30, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a31\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a31, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a32\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a32, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a33\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a33, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a34\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a34, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a35\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a35, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a36\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a36, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a37\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a37, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a38\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a38, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a39\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a39, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a40\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a40, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a41\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a41, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a42\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a42, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a43\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a43, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a44\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a44, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a45\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a45, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a46\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a46, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a47\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a47, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a48\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a48, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a49\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a49, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a50\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a50, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a51\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a51, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a52\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a52, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a53\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a53, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a54\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a54, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a55\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a55, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a56\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a56, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a57\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a57, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a58\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a58, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a59\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a59, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a60\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a60, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a61\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a61, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a62\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a62, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a63\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a63, %0\n\t" \
-                 "s_nop 1"                                                   \
-                 : "=&v"(T), "+v"(AL), "+" V5_OR_0_0(o[0][0]), "+" V5_OR_0_1(o[0][1]), "+" V5_OR_0_2(o[0][2]), "+" V5_OR_0_3(o[0][3]));
-#define V5_RESCALE_1(AL, T)                                                           \
-    asm volatile("s_nop 7\n\ts_nop 7\n\t" \
-                 "v_accvgpr_read_b32 %0, a64\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a64, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a65\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a65, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a66\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a66, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a67\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a67, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a68\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a68, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a69\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a69, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a70\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a70, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a71\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a71, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a72\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a72, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a73\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a73, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a74\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a74, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a75\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a75, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a76\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a76, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a77\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a77, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a78\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a78, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a79\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a79, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a80\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a80, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a81\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a81, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a82\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a82, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a83\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a83, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a84\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a84, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a85\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a85, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a86\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a86, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a87\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a87, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a88\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a88, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a89\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a89, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a90\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a90, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a91\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a91, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a92\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a92, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a93\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a93, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a94\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a94, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a95\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a95, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a96\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a96, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a97\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a97, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a98\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a98, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a99\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a99, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a100\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a100, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a101\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a101, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a102\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a102, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a103\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a103, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a104\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a104, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a105\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a105, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a106\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a106, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a107\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a107, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a108\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a108, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a109\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a109, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a110\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a110, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a111\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a111, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a112\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a112, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a113\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a113, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a114\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a114, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a115\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a115, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a116\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a116, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a117\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a117, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a118\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a118, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a119\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a119, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a120\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a120, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a121\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a121, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a122\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a122, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a123\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a123, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a124\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a124, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a125\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a125, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a126\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a126, %0\n\t" \
-                 "v_accvgpr_read_b32 %0, a127\n\tv_mul_f32 %0, %0, %1\n\tv_accvgpr_write_b32 a127, %0\n\t" \
-                 "s_nop 1"                                                   \
-                 : "=&v"(T), "+v"(AL), "+" V5_OR_1_0(o[1][0]), "+" V5_OR_1_1(o[1][1]), "+" V5_OR_1_2(o[1][2]), "+" V5_OR_1_3(o[1][3]));
-
-template <bool BF>
-__global__ __launch_bounds__(V5NT) void attn_fwd_v5_kernel(const AttnArgs a) {
-    using frag_t = typename AFrag<BF>::type;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), xl = lane & 31, hl = lane >> 5;
-    int xb0;
-    int64_t bh;
-    const int nxb = (int)((a.Sq + FQ - 1) / FQ);
-    const int nwx = a.persist ? nxb / (2 * a.persist) : nxb;
-    a_block_map(nwx, (int)(a.B * a.H), a.xcd_map, xb0, bh);
-    const char *Kg = a.k + a_head(a.lk, bh, a.H);
-    const char *Vg = a.v + a_head(a.lv, bh, a.H);
-    const unsigned smem_u = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)smem;
-    unsigned ko[8], vo[4][2];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) ko[kk] = (unsigned)a_off(xl, kk * 2 + hl);
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        vo[d][0] = (unsigned)a_tr_lane_off(d * 32, 0);
-        vo[d][1] = (unsigned)a_tr_lane_off(d * 32, 1);
-    }
-    const float c = a.scale * kLog2e;
-    // LDS-DMA: wave w moves rows (4 w + i) * 4 .. + 3 (i = 0..3) of the K tile and of the V tile: 8 instructions per tile
-    // (per lane only 32-bit offsets inside a tile stay live: row * stride < 2^31 is the strided entry's own limit for 64 rows)
-    uint32_t sko[4], svo[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wid * 4 + i) * 4 + (lane >> 4), pos = lane & 15;
-        const int chunk = pos ^ (((row & 3) << 2) | ((row >> 2) & 3));
-        sko[i] = (uint32_t)(row * a.lk.sr + chunk * 16);
-        svo[i] = (uint32_t)(row * a.lv.sr + chunk * 16);
-    }
-    auto stage = [&](int tile, int nt_, char *buf) __attribute__((always_inline)) {
-        const int64_t kv = (int64_t)(tile < nt_ ? tile : nt_ - 1) * ABK;
-        const char *kg = Kg + kv * a.lk.sr, *vg = Vg + kv * a.lv.sr;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row0 = (wid * 4 + i) * 4;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kg + sko[i]),
-                                             (__attribute__((address_space(3))) void *)(buf + row0 * AROW), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(vg + svo[i]),
-                                             (__attribute__((address_space(3))) void *)(buf + FTILE + row0 * AROW), 16, 0, 0);
-        }
-    };
-#pragma nounroll
-  for (int pass = 0; pass < (a.persist ? 2 * a.persist : 1); ++pass) {
-    const int xp = xb0 + (pass >> 1) * nwx;
-    const int xb = ((pass & 1) != (a.persist_rev != 0)) ? nxb - 1 - xp : xp;
-    const int qblk = nxb - 1 - xb; // longest blocks first
-    const int64_t q0 = (int64_t)qblk * FQ, qw = q0 + wid * 64;
-    const bool active = qw < a.Sq;
-    const int64_t q_end = q0 + FQ < a.Sq ? q0 + FQ : a.Sq;
-    const int64_t kv_end = a.Skv < q_end ? a.Skv : q_end;
-    const int nt = (int)((kv_end + ABK - 1) / ABK);
-    int my_nt = active ? (int)(qw / ABK) + 1 : 0; // tiles 0 .. qw / 64 hold keys this wave's 64 queries see; the last one is its diagonal
-    my_nt = __builtin_amdgcn_readfirstlane(my_nt < nt ? my_nt : nt);
-    const int diag_t = (int)(qw / ABK); // (>= nt when Skv ends above the wave's rows: then no tile is masked)
-
-    // Q fragments of both blocks, pre-scaled by scale log2(e), parked in AGPRs (B operands of the score chains)
-    frag_t qf[2][8];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        const int64_t m = qw + 32 * qb + xl;
-        if (m < a.Sq) {
-            const char *Qg = a.q + a_head(a.lq, bh, a.H) + m * a.lq.sr;
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) qf[qb][kk] = *(const frag_t *)(Qg + (kk * 16 + 8 * hl) * 2);
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) qf[qb][kk][j] = 0;
-        }
-    }
-    stage(0, nt, smem);
-    stage(1, nt, smem + FBUF);
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if constexpr (BF) qf[qb][kk][j] = (__bf16)((float)qf[qb][kk][j] * c);
-                else qf[qb][kk][j] = (_Float16)((float)qf[qb][kk][j] * c);
-            }
-            asm volatile("" : "+a"(qf[qb][kk]));
-        }
-    f32x16 o[2][4], negm[2];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) negm[qb][e] = 0.f;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) o[qb][d][e] = 0.f;
-        }
-    }
-    asm volatile("" : "+" V5_OR_0_0(o[0][0]), "+" V5_OR_0_1(o[0][1]), "+" V5_OR_0_2(o[0][2]), "+" V5_OR_0_3(o[0][3]), "+" V5_OR_1_0(o[1][0]),
-                      "+" V5_OR_1_1(o[1][1]), "+" V5_OR_1_2(o[1][2]), "+" V5_OR_1_3(o[1][3]));
-    float M[2] = {0.f, 0.f}, lp[2] = {0.f, 0.f}; // running maximum (exponent units) and this lane's part of the row sum
-    f32x16 s00, s01, s10, s11;                    // scores, then probabilities in place: s<block><32-key half>
-#define V5_H_0 0
-#define V5_H_1 0
-#define V5_H_2 0
-#define V5_H_3 0
-#define V5_H_4 0
-#define V5_H_5 0
-#define V5_H_6 0
-#define V5_H_7 0
-#define V5_H_8 1
-#define V5_H_9 1
-#define V5_H_10 1
-#define V5_H_11 1
-#define V5_H_12 1
-#define V5_H_13 1
-#define V5_H_14 1
-#define V5_H_15 1
-#define V5_S(QB, H) V5_S_(QB, H)
-#define V5_SH(QB, N) V5_SH_(QB, V5_H_##N)
-#define V5_SH_(QB, H) V5_S_(QB, H)
-#define V5_S_(QB, H) s##QB##H
-    frag_t pf[2][4];                              // packed P
-    s16x8 kr[4];
-    s16x4 vlo[4], vhi[4];
-
-    // S of block QB for one K tile (fragment J = 8 half + kk, three fragments ahead); VA: the other block's arithmetic, one piece per MFMA
-#define V5_QKSTEP(QB, KTU, J, TAG, VA)                                                                                      \
-    if constexpr ((J) + 3 < 16) v5_kread<(((J) + 3) >> 3) * 32 * AROW>((KTU) + ko[((J) + 3) & 7], kr[((J) + 3) & 3]);       \
-    v5_waitk<((J) + 3 < 16 ? 3 : 15 - (J))>(kr[(J) & 3]);                                                                   \
-    if constexpr (((J) & 7) == 0) v5_qk_first<BF>(V5_SH(QB, J), kr[(J) & 3], qf[QB][0], negm[QB], TAG);                  \
-    else v5_qk<BF>(V5_SH(QB, J), kr[(J) & 3], qf[QB][(J) & 7], TAG);                                                     \
-    VA
-#define V5_QK_PRE(KTU)                                                                                                      \
-    v5_kread<0>((KTU) + ko[0], kr[0]); v5_kread<0>((KTU) + ko[1], kr[1]); v5_kread<0>((KTU) + ko[2], kr[2]);
-    // piece C (0..15) of block QB's softmax tail: p = exp2(S) in place for elements 2 (C & 7), + 1 of half C >> 3, packed into P
-#define V5_SOFT(QB, C)                                                                                                      \
-    V5_SH(QB, C)[2 * ((C) & 7)] = __builtin_amdgcn_exp2f(V5_SH(QB, C)[2 * ((C) & 7)]);                                \
-    V5_SH(QB, C)[2 * ((C) & 7) + 1] = __builtin_amdgcn_exp2f(V5_SH(QB, C)[2 * ((C) & 7) + 1]);                        \
-    if constexpr (BF) {                                                                                                     \
-        pf[QB][((C) >> 3) * 2 + (((C) & 7) >> 2)][2 * ((C) & 3)] = (__bf16)V5_SH(QB, C)[2 * ((C) & 7)];                  \
-        pf[QB][((C) >> 3) * 2 + (((C) & 7) >> 2)][2 * ((C) & 3) + 1] = (__bf16)V5_SH(QB, C)[2 * ((C) & 7) + 1];          \
-    } else {                                                                                                                \
-        pf[QB][((C) >> 3) * 2 + (((C) & 7) >> 2)][2 * ((C) & 3)] = (_Float16)V5_SH(QB, C)[2 * ((C) & 7)];                \
-        pf[QB][((C) >> 3) * 2 + (((C) & 7) >> 2)][2 * ((C) & 3) + 1] = (_Float16)V5_SH(QB, C)[2 * ((C) & 7) + 1];        \
-    }
-    // O of block QB += P V of one tile (V^T fragment I = 4 kstep + d, three fragments ahead)
-#define V5_PVSTEP(QB, VTU, I, TAG, VA)                                                                                      \
-    if constexpr ((I) + 3 < 16)                                                                                             \
-        v5_vread<16 * (((I) + 3) >> 2) * AROW>((VTU) + vo[((I) + 3) & 3][0], (VTU) + vo[((I) + 3) & 3][1], vlo[((I) + 3) & 3], vhi[((I) + 3) & 3]); \
-    v5_waitv<2 * ((I) + 3 < 16 ? 3 : 15 - (I))>(vlo[(I) & 3], vhi[(I) & 3]);                                                \
-    {                                                                                                                       \
-        s16x8 vf_;                                                                                                          \
-        vf_[0] = vlo[(I) & 3][0]; vf_[1] = vlo[(I) & 3][1]; vf_[2] = vlo[(I) & 3][2]; vf_[3] = vlo[(I) & 3][3];             \
-        vf_[4] = vhi[(I) & 3][0]; vf_[5] = vhi[(I) & 3][1]; vf_[6] = vhi[(I) & 3][2]; vf_[7] = vhi[(I) & 3][3];             \
-        if constexpr (BF) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+" V5_OR_##QB##_##I(o[QB][(I) & 3]), "+v"(vf_), "+v"(pf[QB][(I) >> 2])); \
-        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+" V5_OR_##QB##_##I(o[QB][(I) & 3]), "+v"(vf_), "+v"(pf[QB][(I) >> 2]));         \
-    }                                                                                                                       \
-    VA
-#define V5_PV_PRE(VTU)                                                                                                      \
-    v5_vread<0>((VTU) + vo[0][0], (VTU) + vo[0][1], vlo[0], vhi[0]); v5_vread<0>((VTU) + vo[1][0], (VTU) + vo[1][1], vlo[1], vhi[1]); \
-    v5_vread<0>((VTU) + vo[2][0], (VTU) + vo[2][1], vlo[2], vhi[2]);
-    // piece C (0..15) under a P V phase: two elements of block QS's row sums (its P is final) and of block QM's row maxima
-#define V5_SUM(QS, C) lp[QS] += V5_SH(QS, C)[2 * ((C) & 7)] + V5_SH(QS, C)[2 * ((C) & 7) + 1];
-#define V5_MAX(QM, C) mxr = fmaxf(mxr, fmaxf(V5_SH(QM, C)[2 * ((C) & 7)], V5_SH(QM, C)[2 * ((C) & 7) + 1]));
-#define V5_SUMMAX(QS, QM, C) V5_SUM(QS, C) V5_MAX(QM, C)
-#define V5_16(M_, ...) M_(0, __VA_ARGS__) M_(1, __VA_ARGS__) M_(2, __VA_ARGS__) M_(3, __VA_ARGS__) M_(4, __VA_ARGS__) M_(5, __VA_ARGS__) M_(6, __VA_ARGS__)          \
-    M_(7, __VA_ARGS__) M_(8, __VA_ARGS__) M_(9, __VA_ARGS__) M_(10, __VA_ARGS__) M_(11, __VA_ARGS__) M_(12, __VA_ARGS__) M_(13, __VA_ARGS__) M_(14, __VA_ARGS__)   \
-    M_(15, __VA_ARGS__)
-
-    // causal mask of the wave's diagonal tile (keys kv0 = qw ..): block A sees nothing of the second key half and the lower triangle
-    // of the first; block B sees the whole first half and the lower triangle of the second
-    // (a tile past the diagonal - the extra iteration that only finishes block B - is masked whole)
-    // block A (0): second key half entirely, first half above the diagonal; block B (1): second half above the diagonal
-#define V5_MASK(NAME, QB, SD, SO)                                                                                           \
-    auto NAME = [&](bool whole) __attribute__((always_inline)) {                                                            \
-        const int nd = whole ? -1 : xl - 4 * hl; /* query - key of element e in a diagonal 32 x 32 block: nd - a_row(e, 0) */ \
-        asm volatile("s_nop 7\n\ts_nop 7" : "+v"(SD), "+v"(SO)); /* (the chains' results are read here) */                 \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) {                                                                    \
-            if ((QB) == 0 || whole) SO[e] = -INFINITY;                                                                      \
-            if (a_row(e, 0) > nd) SD[e] = -INFINITY;                                                                        \
-        }                                                                                                                   \
-    };
-    V5_MASK(maskA, 0, s00, s01)
-    V5_MASK(maskB, 1, s11, s10)
-#undef V5_MASK
-    // adopt a new maximum for block QB: its rows exceed the one in use by dl (exponent units; the first tile: the signed distance from
-    // the provisional 0) - O, the row sum and the pending scores move with it. After block QB's scores of tile t: adopt if some row
-    // exceeds the maximum in use by more than kDeferMax (wave-uniform, rare after the first tiles; always on the first tile).
-    // (two plain lambdas, not one generic one: a generic lambda does not capture a variable that appears only as an asm operand)
-#define V5_SETTLE(NAME, QB)                                                                              \
-    auto NAME = [&](int t, float mxr_) __attribute__((always_inline)) {                                  \
-        const float m = a_half_max(mxr_);                                                                \
-        const bool first = t == 0;                                                                       \
-        if (!first && __builtin_amdgcn_ballot_w64(m > a.defer) == 0) return;                             \
-        const float dl = first ? m : fmaxf(m, 0.f);                                                      \
-        M[QB] += dl;                                                                                     \
-        _Pragma("unroll") for (int e = 0; e < 16; ++e) { V5_S(QB, 0)[e] -= dl; V5_S(QB, 1)[e] -= dl; negm[QB][e] = -M[QB]; } \
-        if (!first) { /* (on the first tile O and the row sum are still zero) */                         \
-            float al = __builtin_amdgcn_exp2f(-dl), tmp_;                                                \
-            lp[QB] *= al;                                                                                \
-            V5_RESCALE_##QB(al, tmp_)                                                                    \
-        }                                                                                                \
-    };
-    V5_SETTLE(settleA, 0)
-    V5_SETTLE(settleB, 1)
-#undef V5_SETTLE
-    using QA = std::integral_constant<int, 0>;
-    using QB_ = std::integral_constant<int, 1>;
-
-    // block B runs half a tile behind: its "previous tile" of the first iteration is an all-zero P against an all-zero V tile
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { s10[e] = -INFINITY; s11[e] = -INFINITY; }
-    for (int i = threadIdx.x; i < FTILE / 16; i += V5NT) *(uint4 *)(smem + 3 * FBUF + FTILE + i * 16) = uint4{0, 0, 0, 0};
-    // one body for every tile 0 .. my_nt (the last one only finishes block B; its scores lie above the diagonal and are masked away)
-    for (int t = 0; t <= nt; ++t) {
-        // tile t has landed (this wave's part, then everyone's); every wave is past tile t - 1's second phase, so tile t - 2's slot is free
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        stage(t + 2, nt, smem + ((t + 2) & 3) * FBUF);
-        if (t > my_nt) continue;
-        const unsigned ktu = smem_u + (unsigned)((t & 3) * FBUF), vtu = ktu + FTILE, vtp = smem_u + (unsigned)(((t + 3) & 3) * FBUF + FTILE);
-        float mxr;
-        // phase 1: S_A(t) | exp2 / pack of S_B(t - 1)
-        V5_QK_PRE(ktu)
-#define V5_P1(C, X) V5_QKSTEP(0, ktu, C, V5_SH(1, C), V5_SOFT(1, C))
-        V5_16(V5_P1, 0)
-#undef V5_P1
-        if (t >= diag_t || t == my_nt) maskA(t > diag_t || t == my_nt);
-        // phase 2: O_B += P_B(t - 1) V(t - 1) | row sums of P_B(t - 1), row maxima of S_A(t)
-        mxr = -INFINITY;
-        V5_PV_PRE(vtp)
-#define V5_P2(C, X) V5_PVSTEP(1, vtp, C, V5_SH(1, C), V5_SUMMAX(1, 0, C))
-        V5_16(V5_P2, 0)
-#undef V5_P2
-        settleA(t, mxr);
-        // phase 3: S_B(t) | exp2 / pack of S_A(t)
-        V5_QK_PRE(ktu)
-#define V5_P3(C, X) V5_QKSTEP(1, ktu, C, V5_SH(0, C), V5_SOFT(0, C))
-        V5_16(V5_P3, 0)
-#undef V5_P3
-        if (t >= diag_t || t == my_nt) maskB(t > diag_t || t == my_nt);
-        // phase 4: O_A += P_A(t) V(t) | row sums of P_A(t), row maxima of S_B(t)
-        mxr = -INFINITY;
-        V5_PV_PRE(vtu)
-#define V5_P4(C, X) V5_PVSTEP(0, vtu, C, V5_SH(0, C), V5_SUMMAX(0, 1, C))
-        V5_16(V5_P4, 0)
-#undef V5_P4
-        settleB(t, mxr);
-    }
-#undef V5_QKSTEP
-#undef V5_QK_PRE
-#undef V5_SOFT
-#undef V5_PVSTEP
-#undef V5_PV_PRE
-#undef V5_SUM
-#undef V5_MAX
-#undef V5_SUMMAX
-#undef V5_16
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (active) {
-        // (the store addresses are computed HERE: left alone hipcc hoists 32 row pointers above the tile loop and keeps them in scratch)
-        int64_t rs_o = a.lo.sr;
-        char *out_o = a.out + a_head(a.lo, bh, a.H);
-        asm volatile("" : "+s"(rs_o), "+s"(out_o));
-#pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            const int64_t qr = qw + 32 * qb;
-            if (qr < a.Sq) {
-                const float l = a_half_sum(lp[qb]);
-                a_store_rows<BF, 4>(smem + wid * 32 * OPAD, out_o + qr * rs_o, o[qb], 1.f / l, rs_o);
-                if (a.lse && hl == 0) a.lse[bh * a.Sq + qr + xl] = (M[qb] + __builtin_amdgcn_logf(l)) * kLn2;
-            }
-        }
-    }
-    if (a.persist) __syncthreads();
-  }
-}
-
-// ==========================================================================================
 // forward, f32 (the reference's dtype: CausalAttentionForwardFN<float, 64 | 128>, causal_attention.h:66-258), on the
 // exact-f32 matrix instruction v_mfma_f32_32x32x2_f32 (a k-ordered fma chain, 157 TFLOP/s dense, 1/16 of the bf16 rate -
 // so this kernel is matrix-pipe bound by a wide margin and needs no scheduling tricks). Query on the lane, 4 waves x 32
@@ -2791,15 +2291,6 @@ static int attn_fwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
         const int64_t nxb3 = (Sq + FQ - 1) / FQ;
         a.persist = (nxb3 % 2 == 0 && nxb3 >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
         dim3 grid3((unsigned)((a.persist ? nxb3 / (2 * a.persist) : nxb3) * B * H));
-        if (D == 128 && !knob(KNOB_ATTN_FWD_V3)) { // 4 waves x 64 queries, one wave per SIMD (KF_ATTN_FWD_V3: the 8-wave kernel)
-            KF_PROF("attn_fwd_mfma", st);
-            if ((rc = set_lds(attn_fwd_v5_kernel<true>, lds3)) != KF_OK) return rc;
-            if ((rc = set_lds(attn_fwd_v5_kernel<false>, lds3)) != KF_OK) return rc;
-            if (dtype == KF_BF16) attn_fwd_v5_kernel<true><<<grid3, V5NT, lds3, st>>>(a);
-            else attn_fwd_v5_kernel<false><<<grid3, V5NT, lds3, st>>>(a);
-            KF_LAUNCH_CHECK();
-            return KF_OK;
-        }
         KF_PROF(D == 64 ? "attn_fwd_mfma_d64" : "attn_fwd_mfma", st);
 #define KF_FWD(BF_, D_)                                                                  \
     {                                                                                    \
