@@ -127,10 +127,13 @@ class Workload:
                    self.dq.ptr, self.dk.ptr, self.dv.ptr, self.aws.ptr, self.aws_bytes, s)
 
 
+CHECK_NOTES = {}
+
+
 def spot_check(H, wl):
     """After timing: outputs left in the timed buffers against the oracle (the checker; never inside the timed region).
-    GEMM: 8 rows of C = A W (bf16 inputs, f32 accumulation, one rounding). Attention, head (0, 0): the causal prefix - the
-    first 256 rows of O and LSE equal attention over the first 256 tokens - and the checksum sum_n dV[n] = sum_m dO[m]."""
+    GEMM: 8 rows of C = A W (bf16 inputs, f32 accumulation, one rounding). Attention: all of head (0, 0) under the scale-aware
+    bounds (see below) and the checksum sum_n dV[n] = sum_m dO[m]."""
     from oracle import oracle as O
     n = GEMM_N
     rows = [0, 1, 127, 128, 2047, 3000, 4094, 4095]
@@ -141,20 +144,32 @@ def spot_check(H, wl):
     mag = np.abs(O.bf16_to_f32(wl.A_host[rows]).astype(np.float64)) @ np.abs(O.bf16_to_f32(wl.W_host).astype(np.float64))
     g = O.bf16_to_f32(got).astype(np.float64)
     gemm_ok = bool((np.abs(g - want) <= 2.0 ** -7 * np.abs(want) + 2e-6 * mag + 1e-6).all())
-    P = 256
-    q, k, v = (wl.host[x][None, None, :P] for x in ("q", "k", "v"))
-    o_ref, lse_ref = O.attn_fwd(q, k, v, code=O.BF16)
-    o_got = np.empty((P, AD), dtype=np.uint16)
-    H.check(H.lib().kf_memcpy_d2h(o_got.ctypes.data, wl.o.ptr, o_got.nbytes, None))
-    lse_got = np.empty((P,), dtype=np.float32)
-    H.check(H.lib().kf_memcpy_d2h(lse_got.ctypes.data, wl.lse.ptr, lse_got.nbytes, None))
-    attn_ok = bool(np.allclose(O.bf16_to_f32(o_got), O.bf16_to_f32(o_ref)[0, 0], rtol=2e-2, atol=2e-2)
-                   and np.allclose(lse_got, lse_ref[0, 0], rtol=1e-3, atol=2e-3))
-    dv = np.empty((AS, AD), dtype=np.uint16)
-    H.check(H.lib().kf_memcpy_d2h(dv.ctypes.data, wl.dv.ptr, dv.nbytes, None))
-    dv_sum, do_sum = O.bf16_to_f32(dv).astype(np.float64).sum(0), O.bf16_to_f32(wl.host["do"]).astype(np.float64).sum(0)
-    bwd_ok = bool(np.allclose(dv_sum, do_sum, rtol=2e-2, atol=0.5))
-    return {"gemm_rows_vs_oracle": gemm_ok, "attn_prefix_vs_oracle": attn_ok, "attn_dv_checksum": bwd_ok}
+    # attention: EVERY element of head (0, 0) - O, LSE, dQ, dK, dV at S = 4096 - against the double-precision oracle under the
+    # scale-aware bounds of oracle/checks.py (per element, per row, per head; no absolute tolerance), and the same head of the last
+    # batch element (the batch is one element replicated) bit-identical to it
+    from oracle import checks as K
+    q, k, v, go = (wl.host[x][None, None] for x in ("q", "k", "v", "do"))
+    per_b = AH * AS * AD * 2
+
+    def head(buf, b, shape=(1, 1, AS, AD), dt=np.uint16, per_batch=per_b):
+        out = np.empty(shape, dtype=dt)
+        H.check(H.lib().kf_memcpy_d2h(out.ctypes.data, buf.ptr + b * per_batch, out.nbytes, None))
+        return out
+
+    got = {n: head(b, 0) for n, b in (("o", wl.o), ("dq", wl.dq), ("dk", wl.dk), ("dv", wl.dv))}
+    lse_got = head(wl.lse, 0, (1, 1, AS), np.float32, AH * AS * 4)
+    try:
+        margins = K.attn_check(q, k, v, O.BF16, o=got["o"], lse=lse_got, d_o=go, dq=got["dq"], dk=got["dk"], dv=got["dv"], what="bench head (0,0)")
+        attn_ok, attn_note = True, {n: round(max(m.get("element", 0), m.get("row", 0), m.get("head", 0)), 3) for n, m in margins.items() if n != "lse"}
+    except AssertionError as e:
+        attn_ok, attn_note = False, str(e)
+    same = all(np.array_equal(got[n], head(b, AB - 1)) for n, b in (("o", wl.o), ("dq", wl.dq), ("dk", wl.dk), ("dv", wl.dv)))
+    dv_sum, do_sum = O.bf16_to_f32(got["dv"][0, 0]).astype(np.float64).sum(0), O.bf16_to_f32(wl.host["do"]).astype(np.float64).sum(0)
+    bound = 2.0 ** -8 * (np.abs(O.bf16_to_f32(got["dv"][0, 0]).astype(np.float64)).sum(0) + np.abs(O.bf16_to_f32(wl.host["do"]).astype(np.float64)).sum(0) / math.sqrt(AS))
+    bwd_ok = bool((np.abs(dv_sum - do_sum) <= bound).all())
+    CHECK_NOTES["attn_head00_worst_fraction_of_bound"] = attn_note  # per output: max of the element / row / head figures (1 = at the bound)
+    return {"gemm_rows_vs_oracle": gemm_ok, "attn_head00_vs_oracle_scale_aware": attn_ok,
+            "attn_last_batch_bit_identical": bool(same), "attn_dv_checksum": bwd_ok}
 
 
 def check_allreduce(H, wl, pg, stream):
@@ -368,6 +383,7 @@ def main():
                          "algorithmic_flops_per_launch": KERNEL_FLOPS[dom]},
             "device_src_sha": device_src_sha(),
             "checks": checks,
+            "check_notes": CHECK_NOTES,
         }
         if sustained:
             out["ms_per_step_sustained"] = sustained[1] / sustained[0] * 1e3

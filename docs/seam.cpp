@@ -9,6 +9,7 @@
 // tree is mounted (build container): g++ -std=c++20 -fsyntax-only -I src/core/include -I src/core/utils{,/memory}
 // -I src/device/include. Nothing from the reference is copied into this repository; the file is documentation that type-checks.
 #include <cmath>
+#include <iostream>
 #include <tuple>
 #include <vector>
 
@@ -18,6 +19,7 @@
 
 #include "binary_ops_kernel.h" // reference: src/device/include - the declarations defined below
 #include "causal_attention_kernel.h"
+#include "device_info.h"
 #include "gemm_kernel.h"
 #include "index_ops_kernel.h"
 #include "memory_engine.h"
@@ -208,5 +210,51 @@ std::tuple<Tensor, Tensor> topk_with_sort(const Tensor &self, int64_t k, int64_t
     return std::make_tuple(std::get<0>(sorted).narrow(d, 0, k).contiguous(), std::get<1>(sorted).narrow(d, 0, k).contiguous());
 }
 
-// device_info.h:5 (void device_info(): prints device properties and two microbenchmarks) is out of the hot path's scope
-// (SURVEY.md section 2 #27); its query half is kf_device_props_get.
+// device_info.h:5 - void device_info(): the device's properties, a 1 GB copy-bandwidth test and a matrix throughput test
+// (device_info.cu:191-216 prints cudaDeviceProp, times a vectorised float copy and an FP32 MAD loop). Over the C ABI: the properties
+// from kf_device_props_get, the copy as the seam's own copy kernel on a 1 GB float buffer, the arithmetic test as the f32 GEMM the
+// path replaces CUTLASS with - both timed with kf_event_*.
+void device_info() {
+    int ndev = 0;
+    check(kf_device_count(&ndev));
+    for (int i = 0; i < ndev; ++i) {
+        kf_device_props p;
+        check(kf_device_props_get(i, &p));
+        std::cout << "[" << i << "] " << p.name << " (" << p.arch << "), " << p.compute_units << " CUs, wavefront " << p.wavefront_size << ", "
+                  << p.clock_khz / 1000 << " MHz, LDS per block " << p.lds_per_block << " B, L2 " << p.l2_bytes << " B, memory "
+                  << p.total_mem / (1ull << 30) << " GiB (" << p.memory_bus_bits << "-bit bus at " << p.memory_clock_khz / 1000 << " MHz)\n";
+    }
+    if (ndev == 0) return;
+    void *e0 = nullptr, *e1 = nullptr;
+    check(kf_event_create(&e0));
+    check(kf_event_create(&e1));
+    float ms = 0.f;
+    {
+        std::cout << "\n1GB copy test ... ";
+        const int64_t n = 1024 * 1024 * 256;
+        Tensor a = zeros({n}, ScalarType::Float, 0), b = empty({n}, ScalarType::Float, 0);
+        for (int rep = 0; rep < 4; ++rep) {
+            if (rep == 1) check(kf_event_record(e0, kStream));
+            b.copy_(a);
+        }
+        check(kf_event_record(e1, kStream));
+        check(kf_event_sync(e1));
+        check(kf_event_elapsed_ms(e0, e1, &ms));
+        std::cout << 3.0 * 2.0 * n * sizeof(float) / 1e6 / ms << " GBPS\n";
+    }
+    {
+        std::cout << "FP32 GEMM 4096^3 test ... ";
+        const int64_t n = 4096;
+        Tensor a = zeros({n, n}, ScalarType::Float, 0), b = zeros({n, n}, ScalarType::Float, 0), c = empty({n, n}, ScalarType::Float, 0);
+        for (int rep = 0; rep < 4; ++rep) {
+            if (rep == 1) check(kf_event_record(e0, kStream));
+            gemm_kernel(c, a, b, 1.0f, 0.0f);
+        }
+        check(kf_event_record(e1, kStream));
+        check(kf_event_sync(e1));
+        check(kf_event_elapsed_ms(e0, e1, &ms));
+        std::cout << 3.0 * 2.0 * n * n * n / (ms / 1000) * 1e-12 << " TFLOPS" << std::endl;
+    }
+    check(kf_event_destroy(e0));
+    check(kf_event_destroy(e1));
+}

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KF_ABI_VERSION 4 /* 2: + kf_reduce_moments*, KF_EW_*_SCALAR, kf_graph_*, kf_attn_*_scaled; 3: + kf_sort*; 4: + kf_knobs_reload, kf_norm_*, kf_index_get, kf_gemm_ex, KF_EPI_* (all additive) */
+#define KF_ABI_VERSION 5 /* 2: + kf_reduce_moments*, KF_EW_*_SCALAR, kf_graph_*, kf_attn_*_scaled; 3: + kf_sort*; 4: + kf_knobs_reload, kf_norm_*, kf_index_get, kf_gemm_ex, KF_EPI_*; 5: + kf_gemm_grouped_single_grid, kf_allreduce_sum_multi, kf_attn_bwd accepts any workspace >= the statistics (all additive) */
 
 /* ---- status ------------------------------------------------------------------------------ */
 enum {
@@ -319,6 +319,10 @@ typedef struct kf_gemm_problem {
     int64_t ldc;
 } kf_gemm_problem;
 int kf_gemm_grouped(int dtype, int count, const kf_gemm_problem *problems, void *stream);
+/* 1 when kf_gemm_grouped would run these problems as ONE grid (the backward pair of a 16-bit linear layer on 256-tile shapes with
+ * few enough tiles), 0 when it would fall back to one kf_gemm per problem WITHOUT a workspace - a caller that owns split-K scratch
+ * (kf_gemm_workspace_bytes) should then issue the kf_gemm calls itself so that skinny products are still split. */
+int kf_gemm_grouped_single_grid(int dtype, int count, const kf_gemm_problem *p);
 
 /* ---- causal attention: replaces causal_attention_kernel.h:5 (+ backward) ------------------- */
 /*
@@ -339,12 +343,15 @@ int kf_attn_fwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_
 int kf_attn_fwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, float scale, const void *q,
                        const void *k, const void *v, void *o, float *lse, void *stream);
 /*
- * dq,dk,dv from d_o. Needs o and lse from the forward. workspace holds delta[B,H,Sq] f32, the two row-constant arrays the
- * dK/dV kernel reads and - on the matrix-core path for 16-bit tensors - dS = P o (dP - delta) in 16 bits, B*H*Sq*Skv*2 bytes
- * (Sq rounded up to 256): the dK/dV kernel writes it, the dQ kernel computes dQ = scale dS K from it, so the backward executes the
- * 5 matrix products of the algorithm instead of 7. kf_attn_bwd_workspace_bytes() says how much; no initialisation needed.
- * Beyond 64 GiB of dS, or with KF_ATTN_SPLIT_BWD set, the dQ kernel recomputes S and dP instead (small workspace; D = 128 only:
- * D = 64 has the dS form alone and returns KF_ERR_UNSUPPORTED beyond 64 GiB).
+ * dq,dk,dv from d_o. Needs o and lse from the forward. The workspace holds three f32 rows of statistics (delta[B,H,Sq] and the two
+ * row-constant arrays the dK/dV kernel reads: 3 x B*H*Sq*4 bytes, each rounded up to 256 - the MINIMUM, O(B H S)) and, on the
+ * matrix-core path for 16-bit tensors, whatever lies beyond them holds dS = P o (dP - delta) in 16 bits (Sq rounded up to 256, x Skv
+ * x 2 bytes per (batch, head) pair): the dK/dV kernel writes it, the dQ kernel computes dQ = scale dS K from it, so the backward
+ * executes the 5 matrix products of the algorithm instead of 7. The pairs are processed in GROUPS of as many as the workspace holds
+ * dS for, so ANY workspace_bytes >= the minimum is accepted, for both head sizes and every S: with room for less than one pair's dS
+ * (or with KF_ATTN_SPLIT_BWD set) the dQ kernel recomputes S and dP instead (minimum workspace, 7 products).
+ * kf_attn_bwd_workspace_bytes() RECOMMENDS minimum + min(dS of all pairs, KF_ATTN_DS_CAP_MB MiB (default 16384)): bounded whatever
+ * the problem size. No initialisation needed. Results do not depend on the group size (bit-identical).
  * No atomics in either form: dq, dk, dv are bitwise reproducible run to run.
  */
 int kf_attn_bwd_workspace_bytes(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D,
@@ -386,6 +393,8 @@ int kf_comm_init(void **comm, const char id[KF_COMM_ID_BYTES], int rank, int wor
 int kf_comm_destroy(void *comm);
 /* in-place sum all-reduce of `count` elements of dtype (KF_F32, KF_BF16, KF_F16, KF_F64, ints) */
 int kf_allreduce_sum(void *comm, void *buf, size_t count, int dtype, void *stream);
+/* the same over n buffers as ONE collective launch (an RCCL group): the tensors of all_reduce_(list) that are not one flat range */
+int kf_allreduce_sum_multi(void *comm, int n, void *const *bufs, const size_t *counts, int dtype, void *stream);
 
 #ifdef __cplusplus
 }

@@ -148,12 +148,29 @@ def build_diag(force: bool = False) -> Path:
     return out
 
 
+def build_mutant(force: bool = False) -> Path:
+    """The mutation library tests/test_gpu_attention_mutants.py loads beside the real one (-DKF_MUTANT: attention kernels with
+    deliberate single-tile defects behind a run-time selector): a separate .so under _build/, nothing of it in libkfunca_hip.so."""
+    BUILD.mkdir(exist_ok=True)
+    out = BUILD / "libkfunca_hip_mutant.so"
+    srcs = [CSRC / "device" / "attention.hip", CSRC / "device" / "runtime.hip"]
+    hdrs = sorted((CSRC / "device").glob("*.h")) + sorted(INCLUDE.glob("*.h"))
+    if force or not _newer(out, srcs + hdrs):
+        _run([_hipcc(), *HIP_FLAGS, "-DKF_MUTANT", "-shared", "-o", out, *srcs])
+    return out
+
+
 def build_all(force: bool = False):
     build_device(force)
     if (CSRC / "core").exists() and any((CSRC / "core").glob("*.cpp")):
         build_core(force)
     if (ROOT / "oracle" / "oracle.c").exists():
         build_oracle(force)
+    build_mutant(force)
+    if Path("/root/reference/src/core/tensor.cpp").exists():  # build container only: the reference's host half on our device library
+        sys.path.insert(0, str(ROOT))
+        from oracle import build_ref_host
+        build_ref_host.build(with_module=True)
 
 
 if __name__ == "__main__":

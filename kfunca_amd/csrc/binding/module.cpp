@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "allocator.h"
+#include "comm.h"
 #include "device_api.h"
 #include "ops.h"
 #include "tensor.h"
@@ -239,7 +240,7 @@ PYBIND11_MODULE(_C, m) {
         return d;
     }, py::arg("device") = -1);
 
-    py::enum_<ScalarType>(m, "dtype")
+    py::enum_<ScalarType>(m, "dtype", py::module_local()) // module-local: the reference's own module (oracle/_ref) binds the same C++ names
         .value("byte", ScalarType::Byte)
         .value("char", ScalarType::Char)
         .value("short", ScalarType::Short)
@@ -259,6 +260,46 @@ PYBIND11_MODULE(_C, m) {
     m.def("zeros", [](std::vector<int64_t> shape, ScalarType dtype, int device) { return zeros(shape, dtype, device); });
     m.def("causal_attention", &gpu::causal_attention);
     // the reference's roadmap operators (README.md:28-30)
+    // ---- collectives (extension: the reference has no distributed code): one process per GPU, one RCCL communicator
+    // per process through the C ABI; the 128-byte id travels out of band (kfunca_amd.parallel uses torch.distributed / gloo for that)
+    m.def("comm_unique_id", []() { return py::bytes(gpu::comm_unique_id()); });
+    m.def("comm_init", [](py::bytes id, int rank, int world_size, int device) { gpu::comm_init(std::string(id), rank, world_size, device); },
+          py::arg("unique_id"), py::arg("rank"), py::arg("world_size"), py::arg("device") = 0);
+    m.def("comm_destroy", &gpu::comm_destroy);
+    m.def("comm_initialized", &gpu::comm_initialized);
+    m.def("comm_rank", &gpu::comm_rank);
+    m.def("comm_world_size", &gpu::comm_world_size);
+    m.def("all_reduce_", [](py::object x) { // a tensor, or a list of tensors reduced as ONE collective launch; in place, returns its argument
+        if (py::isinstance<py::list>(x) || py::isinstance<py::tuple>(x)) {
+            std::vector<Tensor> ts = x.cast<std::vector<Tensor>>();
+            gpu::all_reduce_(ts);
+        } else {
+            Tensor t = x.cast<Tensor>();
+            gpu::all_reduce_(t);
+        }
+        return x;
+    });
+    py::class_<gpu::GradBucket, std::shared_ptr<gpu::GradBucket>>(m, "GradBucket", py::module_local())
+        .def(py::init([](const std::vector<Tensor> &params, double cap_mb) { return gpu::GradBucket::create(params, (int64_t)(cap_mb * 1048576.0)); }),
+             py::arg("params"), py::arg("cap_mb") = 256.0)
+        .def("attach", &gpu::GradBucket::attach)
+        .def("detach", &gpu::GradBucket::detach)
+        .def("wait", &gpu::GradBucket::wait)
+        .def("flat", &gpu::GradBucket::flat)
+        .def("reduced_bytes", &gpu::GradBucket::reduced_bytes)
+        .def("fired_order", [](const gpu::GradBucket &b) { return b.fired_order(); })
+        .def("chunks", [](const gpu::GradBucket &b) {
+            py::list out;
+            for (const auto &c : b.chunks()) out.append(py::make_tuple(c.first, c.last, c.offset, c.numel));
+            return out;
+        })
+        // the layout arithmetic alone (no device): [(first, last, offset, numel)], chunk 0 = the LAST parameters
+        .def_static("plan", [](const std::vector<int64_t> &numels, int64_t cap_elements) {
+            py::list out;
+            for (const auto &c : gpu::GradBucket::plan(numels, cap_elements)) out.append(py::make_tuple(c.first, c.last, c.offset, c.numel));
+            return out;
+        });
+
     m.def("rms_norm", [](const Tensor &x, py::object w, double eps) { return gpu::rms_norm(x, w.is_none() ? Tensor() : w.cast<Tensor>(), eps); },
           py::arg("x"), py::arg("weight") = py::none(), py::arg("eps") = 1e-5);
     m.def("layer_norm", [](const Tensor &x, py::object w, py::object b, double eps) {
@@ -291,7 +332,7 @@ PYBIND11_MODULE(_C, m) {
     m.def("_promote_types", &promote_types);
     m.def("_pool_index", &utils::memory::DeviceAllocator::pool_index);
 
-    py::class_<Tensor>(m, "tensor")
+    py::class_<Tensor>(m, "tensor", py::module_local())
         .def("__copy__", [](const Tensor &self) { return Tensor(self); })
         .def("__deepcopy__", [](const Tensor &self, py::dict) { return Tensor(self); })
         .def("__repr__", &Tensor::to_string)

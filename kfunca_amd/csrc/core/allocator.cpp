@@ -70,7 +70,11 @@ void DeviceAllocator::free(void *ptr) {
     if (it == by_ptr_.end() || !it->second->in_use) return;
     Block *b = it->second;
     b->in_use = false;
-    if (capturing_ != 0 && capture_device_ == b->device) b->graph = capturing_; // freed while recording: the graph may still touch it
+    // freed while recording: the graph being captured may still touch it. A block that already belongs to ANOTHER live graph (say an
+    // output that graph's replays still write) keeps its owner: re-tagging it would hand it back to the shared cache when the
+    // capturing graph is destroyed, while the first graph can still be replayed.
+    if (capturing_ != 0 && capture_device_ == b->device && !(b->graph != 0 && b->graph != capturing_ && graph_free_.count(b->graph)))
+        b->graph = capturing_;
     if (b->graph != 0) {
         auto g = graph_free_.find(b->graph);
         if (g != graph_free_.end()) {

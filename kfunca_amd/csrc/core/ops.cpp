@@ -442,17 +442,24 @@ public:
         Tensor g2 = gc.view({M, N}), a2 = a.view({M, K});
         if (a.requires_grad() && b.requires_grad() && M % 256 == 0 && N % 256 == 0 && K % 256 == 0 &&
             (a.dtype() == ScalarType::Half || a.dtype() == ScalarType::BFloat16)) {
-            // both gradients of a 16-bit layer on 256-tile shapes: one grouped call (a single grid where the shapes allow it,
-            // kf_gemm_grouped; the two ordinary launches otherwise)
-            out[0] = empty(a.sizes(), a.dtype(), a.device());
-            out[1] = empty(b.sizes(), b.dtype(), b.device());
+            // both gradients of a 16-bit layer on 256-tile shapes: ONE grid where the device library can fuse the pair
+            // (kf_gemm_grouped_single_grid). Where it cannot - too many tiles, or a skinny product such as dA of x[256, 4096] W[4096, 16384] -
+            // the two ordinary calls below run, which carry the split-K scratch kf_gemm_grouped's fall-back would not have.
+            // a bucketed weight whose gradient starts empty takes dW straight into its bucket slot (update_grad then has nothing to copy)
+            TensorImpl *bi = b.impl();
+            const bool to_slot = !b.has_grad_fn() && bi->sink_ && !bi->grad_;
+            Tensor da = empty(a.sizes(), a.dtype(), a.device()), db = to_slot ? bi->sink_->slot(bi) : empty(b.sizes(), b.dtype(), b.device());
             kf_gemm_problem p[2] = {};
             p[0].trans_a = 0; p[0].trans_b = 1; p[0].M = M; p[0].N = K; p[0].K = N; p[0].alpha = alpha_; p[0].beta = 0.f;
-            p[0].A = g2.data_ptr(); p[0].lda = N; p[0].B = b.data_ptr(); p[0].ldb = N; p[0].C = out[0].data_ptr(); p[0].ldc = K;
+            p[0].A = g2.data_ptr(); p[0].lda = N; p[0].B = b.data_ptr(); p[0].ldb = N; p[0].C = da.data_ptr(); p[0].ldc = K;
             p[1].trans_a = 1; p[1].trans_b = 0; p[1].M = K; p[1].N = N; p[1].K = M; p[1].alpha = alpha_; p[1].beta = 0.f;
-            p[1].A = a2.data_ptr(); p[1].lda = K; p[1].B = g2.data_ptr(); p[1].ldb = N; p[1].C = out[1].data_ptr(); p[1].ldc = N;
-            DEV_CALL(kf_gemm_grouped(code(a.dtype()), 2, p, dev::stream(a.device())));
-            return out;
+            p[1].A = a2.data_ptr(); p[1].lda = K; p[1].B = g2.data_ptr(); p[1].ldb = N; p[1].C = db.data_ptr(); p[1].ldc = N;
+            if (kf_gemm_grouped_single_grid(code(a.dtype()), 2, p)) {
+                DEV_CALL(kf_gemm_grouped(code(a.dtype()), 2, p, dev::stream(a.device())));
+                out[0] = da;
+                out[1] = db;
+                return out;
+            }
         }
         if (a.requires_grad()) {
             out[0] = empty(a.sizes(), a.dtype(), a.device());
@@ -460,7 +467,8 @@ public:
             gemm_any(a.dtype(), false, true, M, K, N, alpha_, g2, b, 0.f, c2, a.device());
         }
         if (b.requires_grad()) {
-            out[1] = empty(b.sizes(), b.dtype(), b.device());
+            TensorImpl *bi = b.impl();
+            out[1] = (!b.has_grad_fn() && bi->sink_ && !bi->grad_) ? bi->sink_->slot(bi) : empty(b.sizes(), b.dtype(), b.device());
             gemm_any(a.dtype(), true, false, K, N, M, alpha_, a2, g2, 0.f, out[1], b.device());
         }
         return out;
@@ -538,7 +546,8 @@ public:
             gemm_any(a.dtype(), false, true, M, K, N, alpha_, dt, b, 0.f, c2, a.device());
         }
         if (b.requires_grad()) {
-            out[1] = empty(b.sizes(), b.dtype(), b.device());
+            TensorImpl *bi = b.impl(); // (a bucketed weight: dW straight into its bucket slot, as in GemmGradFunction)
+            out[1] = (!b.has_grad_fn() && bi->sink_ && !bi->grad_) ? bi->sink_->slot(bi) : empty(b.sizes(), b.dtype(), b.device());
             gemm_any(a.dtype(), true, false, K, N, M, alpha_, a2, dt, 0.f, out[1], b.device());
         }
         return out;
@@ -685,6 +694,25 @@ std::tuple<Tensor, Tensor> causal_attention_fwd(const Tensor &q, const Tensor &k
     return {out, lse};
 }
 
+// Backward scratch: the size the device library recommends (statistics + dS of as many (batch, head) pairs as its cap allows); when
+// the allocator cannot supply that, halve the dS part until it can - the library accepts anything down to the statistics alone
+// (then the recomputing dQ kernel runs: kf_attn_bwd, include/kfunca_hip.h).
+static DataPtr attn_bwd_scratch(int dt, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, int device, size_t &bytes) {
+    size_t need = 0, floor_ = 0;
+    DEV_CALL(kf_attn_bwd_workspace_bytes(dt, B, H, Sq, Skv, D, &need));
+    floor_ = 3 * (((size_t)B * H * Sq * sizeof(float) + 255) / 256 * 256);
+    for (;;) {
+        try {
+            bytes = need;
+            return DeviceAllocator::GetInstance()->allocate(need, device);
+        } catch (const utils::Error &) {
+            if (need <= floor_) throw;
+            need = floor_ + (need - floor_) / 2;
+            if (need - floor_ < ((size_t)1 << 20)) need = floor_;
+        }
+    }
+}
+
 std::tuple<Tensor, Tensor, Tensor> causal_attention_bwd(const Tensor &q, const Tensor &k, const Tensor &v, const Tensor &out,
                                                         const Tensor &lse, const Tensor &grad_out) {
     check_attention(q, k, v);
@@ -696,8 +724,7 @@ std::tuple<Tensor, Tensor, Tensor> causal_attention_bwd(const Tensor &q, const T
         Tensor lp = pad_to(lse, Sqp, 0), gp = pad_to(grad_out.contiguous(), Sqp, Dp);
         Tensor dqp = empty_like(qp), dkp = empty_like(kp), dvp = empty_like(vp);
         size_t need = 0;
-        DEV_CALL(kf_attn_bwd_workspace_bytes(code(q.dtype()), B, H, Sqp, Skp, Dp, &need));
-        DataPtr scratch = DeviceAllocator::GetInstance()->allocate(need, q.device());
+        DataPtr scratch = attn_bwd_scratch(code(q.dtype()), B, H, Sqp, Skp, Dp, q.device(), need);
         DEV_CALL(kf_attn_bwd_scaled(code(q.dtype()), B, H, Sqp, Skp, Dp, 1.0f / std::sqrt((float)D), qp.data_ptr(), kp.data_ptr(), vp.data_ptr(),
                                     op.data_ptr(), static_cast<const float *>(lp.data_ptr()), gp.data_ptr(), dqp.data_ptr(), dkp.data_ptr(),
                                     dvp.data_ptr(), scratch.get(), need, dev::stream(q.device())));
@@ -706,8 +733,7 @@ std::tuple<Tensor, Tensor, Tensor> causal_attention_bwd(const Tensor &q, const T
     Tensor go = grad_out.contiguous();
     Tensor dq = empty_like(q), dk = empty_like(k), dv = empty_like(v);
     size_t need = 0;
-    DEV_CALL(kf_attn_bwd_workspace_bytes(code(q.dtype()), B, H, Sq, Skv, D, &need));
-    DataPtr scratch = DeviceAllocator::GetInstance()->allocate(need, q.device());
+    DataPtr scratch = attn_bwd_scratch(code(q.dtype()), B, H, Sq, Skv, D, q.device(), need);
     DEV_CALL(kf_attn_bwd(code(q.dtype()), B, H, Sq, Skv, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(),
                          static_cast<const float *>(lse.data_ptr()), go.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
                          scratch.get(), need, dev::stream(q.device())));
@@ -780,8 +806,7 @@ public:
         Tensor dqkv = empty(qkv.sizes(), qkv.dtype(), qkv.device());
         const PackedLay L = packed_layouts(S_, H_, D);
         size_t need = 0;
-        DEV_CALL(kf_attn_bwd_workspace_bytes(code(qkv.dtype()), B_, H_, S_, S_, D, &need));
-        DataPtr scratch = DeviceAllocator::GetInstance()->allocate(need, qkv.device());
+        DataPtr scratch = attn_bwd_scratch(code(qkv.dtype()), B_, H_, S_, S_, D, qkv.device(), need);
         const char *p = static_cast<const char *>(qkv.data_ptr());
         char *gp = static_cast<char *>(dqkv.data_ptr());
         DEV_CALL(kf_attn_bwd_strided(code(qkv.dtype()), B_, H_, S_, S_, D, 1.0f / std::sqrt((float)D), p, &L.qkv, p + d * es, &L.qkv, p + 2 * d * es,

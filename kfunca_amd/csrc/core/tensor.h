@@ -68,6 +68,17 @@ private:
 };
 
 class Tensor;
+class TensorImpl;
+
+// Where a leaf's gradient lands when the leaf belongs to a gradient bucket (gpu::GradBucket, comm.h): the bucket hands out the leaf's
+// slot - a view into ONE flat buffer - and is told when the leaf's gradient of this backward pass is complete, which is what lets it
+// start the all-reduce of a finished chunk while the rest of the backward is still running. No reference counterpart (the reference
+// has no distributed code: SURVEY.md fact 5).
+struct GradSink {
+    virtual ~GradSink() = default;
+    virtual Tensor slot(TensorImpl *leaf) = 0;     // the leaf's gradient storage inside the bucket
+    virtual void arrived(TensorImpl *leaf) = 0;    // the leaf's gradient of this pass is in its slot
+};
 
 class TensorImpl : public intrusive_ptr_target {
 public:
@@ -102,6 +113,7 @@ public:
     void as_strided_(const std::vector<int64_t> &sizes, const std::vector<int64_t> &strides, int64_t storage_offset);
 
     std::unique_ptr<Tensor> grad_; // accumulated gradient of a leaf
+    std::shared_ptr<GradSink> sink_; // set by GradBucket::attach: gradients are written into the bucket
 
 private:
     void refresh_();

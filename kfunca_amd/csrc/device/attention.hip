@@ -59,6 +59,11 @@ struct AttnArgs {
     // global layouts of the 16-bit matrix-core path: byte strides of batch, head and row (the last dim is contiguous). Contiguous
     // [B,H,S,D] tensors: {H S 256, S 256, 256}; q / k / v living inside one packed [B S, 3 H D] projection: {S 3 H D 2, 256, 3 H D 2}.
     struct Lay { int64_t sb, sh, sr; } lq, lk, lv, lo, ldo, ldq, ldk, ldv;
+#ifdef KF_MUTANT
+    int mutant;      // mutation build only (tests/test_gpu_attention_mutants.py): which deliberate defect is switched on
+#endif
+    int64_t bh0;     // backward, dS form: this launch covers the (batch, head) pairs bh0 .. bh0 + nbh - 1 (one group of the workspace cap)
+    int nbh;         // pairs in this launch (forward and the other forms: B H, bh0 = 0)
     char *ds;        // backward: dS = P o (dP - delta) in 16 bits, written by the dK/dV kernel, read by the dQ kernel (null: not kept)
     int64_t ds_nqb, ds_nkwb; // its tile grid: 256-query blocks x 32-key blocks (DS_* below)
 };
@@ -97,6 +102,19 @@ __device__ __forceinline__ void a_block_map(int nx, int nbh, int xcd_map, int &x
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
+
+// Mutation build (-DKF_MUTANT, kfunca_amd/_build.py: build_mutant; never in libkfunca_hip.so): deliberate single-tile defects, switched on at
+// run time by kfmut_select(), that the parity tests must REJECT (tests/test_gpu_attention_mutants.py) - the proof that their bounds can fail.
+//   1  forward: the last 256-query block of every head skips its key tile 1 (64 keys dropped from O and LSE)
+//   2  dK/dV: the last 32-query slice contributes nothing to the first 128-key block (P = 0 there: dK, dV of those keys and, through
+//      the stored dS, dQ of those queries lose one slice x block)
+//   3  dQ (stored-dS form): the last 256-query block skips its key step 0 (64 keys dropped from dQ)
+//   4  dQ (recomputing form): the same
+#ifdef KF_MUTANT
+#define KF_MUT(N, COND) (a.mutant == (N) && (COND))
+#else
+#define KF_MUT(N, COND) false
+#endif
 
 // ==========================================================================================
 // MFMA path, D = 128 | 64 (template parameter; the LDS images are those of D = 128 for both)
@@ -424,7 +442,7 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
     // a.persist (nxb even): a workgroup takes query block x AND its mirror nxb - 1 - x of the same (batch, head), so every
     // workgroup has the same causal work (nxb + 1 key tiles' worth) and half as many workgroups are dispatched
     const int nwx = a.persist ? nxb / (2 * a.persist) : nxb; // workgroups per (batch, head)
-    a_block_map(nwx, (int)(a.B * a.H), a.xcd_map, xb0, bh);
+    a_block_map(nwx, a.nbh, a.xcd_map, xb0, bh);
     const int rgrp = ((wid & 3) << 1) | (wid >> 2);
     const bool late = __builtin_amdgcn_readfirstlane(wid) >= 4;
     const char *Kg = a.k + a_head(a.lk, bh, a.H);
@@ -491,7 +509,7 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
         stage(t + 2, smem + ((t + 2) % SRING) * FBUF); // slot of tile t-2: nobody reads it any more
         TL_STAMP(2) // four LDS-DMA instructions issued
         const char *cur = smem + (t % SRING) * FBUF;
-        const bool skip = !active || kv0 > qw + 31;
+        const bool skip = !active || kv0 > qw + 31 || KF_MUT(1, t == 1 && qblk == nxb - 1);
         const bool diag = kv0 + ABK - 1 > qw;
         // one copy of each phase in program order [PV(t-1) | QK+softmax(t) | PV(t)]: late waves take the first
         // two, early waves the last two
@@ -570,10 +588,11 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const char *o, const ch
 // double-buffered, one barrier per tile). Per 32-key sub-tile: S^T = K Q^T, dP^T = V dO^T,
 // dS^T = P^T o (dP^T - delta), dQ^T += K^T dS^T (K^T through transposed reads of the same K image).
 // ------------------------------------------------------------------------------------------
-template <bool BF, bool MASK>
-__device__ __forceinline__ void q_tile(const char *buf, const char *doslab, const typename AFrag<BF>::type (&qf)[8], const int (&ko)[8],
-                                       const int (&vo)[4][2], f32x16 (&dq)[4], float c, float lse2, float dlt, int64_t kv0, int64_t m, int hl) {
+template <bool BF, bool MASK, int D>
+__device__ __forceinline__ void q_tile(const char *buf, const char *doslab, const typename AFrag<BF>::type (&qf)[D / 16], const int (&ko)[D / 16],
+                                       const int (&vo)[D / 32][2], f32x16 (&dq)[D / 32], float c, float lse2, float dlt, int64_t kv0, int64_t m, int hl) {
     using frag_t = typename AFrag<BF>::type;
+    constexpr int DB = D / 32;
     const char *vt = buf + FTILE;
 #pragma unroll
     for (int sub = 0; sub < 2; ++sub) {
@@ -583,13 +602,13 @@ __device__ __forceinline__ void q_tile(const char *buf, const char *doslab, cons
         // groups of four k-steps fenced for the scheduler: hoisting every fragment load of the tile to the
         // top costs > 90 VGPRs and spills at two waves per SIMD; the partner wave hides the LDS latency instead
 #pragma unroll
-        for (int kg = 0; kg < 2; ++kg) {
+        for (int kg = 0; kg < D / 64; ++kg) {
 #pragma unroll
             for (int kk = 4 * kg; kk < 4 * kg + 4; ++kk) s = a_mfma<BF>(*(const frag_t *)(buf + sub * 32 * AROW + ko[kk]), qf[kk], s);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int kg = 0; kg < 2; ++kg) {
+        for (int kg = 0; kg < D / 64; ++kg) {
 #pragma unroll
             for (int kk = 4 * kg; kk < 4 * kg + 4; ++kk)
                 dp = a_mfma<BF>(*(const frag_t *)(vt + sub * 32 * AROW + ko[kk]), *(const frag_t *)(doslab + ko[kk]), dp);
@@ -601,18 +620,18 @@ __device__ __forceinline__ void q_tile(const char *buf, const char *doslab, cons
             if (MASK && kv0 + sub * 32 + a_row(e, hl) > m) p = 0.f;
             s[e] = p * (dp[e] - dlt);
         }
-        Tr4 ta; // one group of transposed K fragments at a time (register budget); the partner wave covers the LDS latency
+        TrN<DB> ta; // one group of transposed K fragments at a time (register budget); the partner wave covers the LDS latency
         if (sub == 0) tr4_issue<0>(buf, vo, ta); else tr4_issue<32 * AROW>(buf, vo, ta);
         tr4_wait1(ta);
         { const frag_t df = a_pack<BF>(s, 0);
 #pragma unroll
-          for (int d = 0; d < 4; ++d) dq[d] = a_mfma<BF>(tr4_frag<BF, 4>(ta, d), df, dq[d]); }
+          for (int d = 0; d < DB; ++d) dq[d] = a_mfma<BF>(tr4_frag<BF, DB>(ta, d), df, dq[d]); }
         __builtin_amdgcn_sched_barrier(0);
         if (sub == 0) tr4_issue<16 * AROW>(buf, vo, ta); else tr4_issue<48 * AROW>(buf, vo, ta);
         tr4_wait1(ta);
         { const frag_t df = a_pack<BF>(s, 1);
 #pragma unroll
-          for (int d = 0; d < 4; ++d) dq[d] = a_mfma<BF>(tr4_frag<BF, 4>(ta, d), df, dq[d]); }
+          for (int d = 0; d < DB; ++d) dq[d] = a_mfma<BF>(tr4_frag<BF, DB>(ta, d), df, dq[d]); }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -620,9 +639,10 @@ __device__ __forceinline__ void q_tile(const char *buf, const char *doslab, cons
 constexpr int QSLAB = 32 * AROW;                 // one wave's dO rows (8 KiB)
 constexpr int QLDS = FRING * FBUF + 8 * QSLAB;   // K/V ring + 8 dO slabs = 160 KiB (the whole LDS of a CU)
 
-template <bool BF>
+template <bool BF, int D>
 __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a) {
     using frag_t = typename AFrag<BF>::type;
+    constexpr int KS = D / 16, DB = D / 32; // head size 64: half the k-steps and column blocks, the LDS images keep their 256-byte rows
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, xl = lane & 31, hl = lane >> 5;
     int xb0;
@@ -630,15 +650,15 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a
     const int nxb = (int)((a.Sq + FQ - 1) / FQ);
     // a.persist: a workgroup takes query block x and its causal mirror nxb - 1 - x (equal work per workgroup, as in the forward)
     const int nwx = a.persist ? nxb / (2 * a.persist) : nxb;
-    a_block_map(nwx, (int)(a.B * a.H), a.xcd_map, xb0, bh);
+    a_block_map(nwx, a.nbh, a.xcd_map, xb0, bh);
     const char *Kg = a.k + a_head(a.lk, bh, a.H);
     const char *Vg = a.v + a_head(a.lv, bh, a.H);
     char *doslab = smem + FRING * FBUF + wid * QSLAB; // this wave's dO rows, same swizzled image as a K tile (B operand of dP^T)
-    int ko[8], vo[4][2];
+    int ko[KS], vo[DB][2];
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) ko[kk] = a_off(xl, kk * 2 + hl);
+    for (int kk = 0; kk < KS; ++kk) ko[kk] = a_off(xl, kk * 2 + hl);
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
+    for (int d = 0; d < DB; ++d) {
         vo[d][0] = a_tr_lane_off(d * 32, 0);
         vo[d][1] = a_tr_lane_off(d * 32, 1);
     }
@@ -651,26 +671,27 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a
     const int64_t q0 = (int64_t)qblk * FQ, qw = q0 + wid * 32, m = qw + xl;
     const bool active = qw < a.Sq;
 
-    frag_t qf[8];
+    frag_t qf[KS];
     float lse2 = 0.f, dlt = 0.f;
     if (active) {
         const char *Qg = a.q + a_head(a.lq, bh, a.H) + m * a.lq.sr;
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const frag_t *)(Qg + (kk * 16 + 8 * hl) * 2);
+        for (int kk = 0; kk < KS; ++kk) qf[kk] = *(const frag_t *)(Qg + (kk * 16 + 8 * hl) * 2);
         const char *dOw = a.d_o + a_head(a.ldo, bh, a.H) + qw * a.ldo.sr;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a_lst(doslab, lane + 64 * i, a_gld(dOw, lane + 64 * i, a.ldo.sr));
+        for (int i = 0; i < 8; ++i) // 512 pieces of 16 B = 32 rows x 16 chunks; head size 64: chunks 8..15 lie beyond the row
+            if (D == AD || ((lane + 64 * i) & 15) < D / 8) a_lst(doslab, lane + 64 * i, a_gld(dOw, lane + 64 * i, a.ldo.sr));
         lse2 = a.lse_r[bh * a.Sq + m] * kLog2e;
         dlt = a.delta[bh * a.Sq + m];
     } else {
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk)
+        for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
             for (int j = 0; j < 8; ++j) qf[kk][j] = 0;
     }
-    f32x16 dq[4];
+    f32x16 dq[DB];
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+    for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int e = 0; e < 16; ++e) dq[d][e] = 0.f;
 
@@ -679,7 +700,7 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a
     const int nt = (int)((kv_end + ABK - 1) / ABK);
     auto stage = [&](int tile, char *buf) { // 3-deep ring, counted vmcnt: see attn_fwd_v2_kernel
         const int64_t kv = (int64_t)(tile < nt ? tile : nt - 1) * ABK;
-        f_stage<AD>(Kg + kv * a.lk.sr, Vg + kv * a.lv.sr, buf, a.lk.sr, a.lv.sr);
+        f_stage<D>(Kg + kv * a.lk.sr, Vg + kv * a.lv.sr, buf, a.lk.sr, a.lv.sr);
     };
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // Q fragments + the dO slab writes are done
     stage(0, smem);
@@ -691,16 +712,16 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_v2_kernel(const AttnArgs a
         asm volatile("" ::: "memory");
         stage(t + 2, smem + ((t + 2) % FRING) * FBUF);
         const char *cur = smem + (t % FRING) * FBUF;
-        const bool skip = !active || kv0 > qw + 31;
+        const bool skip = !active || kv0 > qw + 31 || KF_MUT(4, t == 0 && qblk == nxb - 1);
         const bool diag = kv0 + ABK - 1 > qw;
         if (!skip) {
-            if (diag) q_tile<BF, true>(cur, doslab, qf, ko, vo, dq, c, lse2, dlt, kv0, m, hl);
-            else q_tile<BF, false>(cur, doslab, qf, ko, vo, dq, c, lse2, dlt, kv0, m, hl);
+            if (diag) q_tile<BF, true, D>(cur, doslab, qf, ko, vo, dq, c, lse2, dlt, kv0, m, hl);
+            else q_tile<BF, false, D>(cur, doslab, qf, ko, vo, dq, c, lse2, dlt, kv0, m, hl);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (active) a_store_rows<BF, 4>(smem + wid * 32 * OPAD, a.dq + a_head(a.ldq, bh, a.H) + qw * a.ldq.sr, dq, a.scale, a.ldq.sr);
+    if (active) a_store_rows<BF, DB>(smem + wid * 32 * OPAD, a.dq + a_head(a.ldq, bh, a.H) + qw * a.ldq.sr, dq, a.scale, a.ldq.sr);
     if (a.persist) __syncthreads(); // the staging slabs overlap the ring the next block fills
   }
 }
@@ -751,7 +772,8 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_ds_kernel(const AttnArgs a
     int64_t bh;
     const int nxb = (int)((a.Sq + FQ - 1) / FQ);
     const int nwx = a.persist ? nxb / (2 * a.persist) : nxb;
-    a_block_map(nwx, (int)(a.B * a.H), a.xcd_map, xb0, bh);
+    a_block_map(nwx, a.nbh, a.xcd_map, xb0, bh);
+    bh += a.bh0;
     const char *Kg = a.k + a_head(a.lk, bh, a.H);
     char *slab = smem + DQ_RING * FTILE + wid * DQ_RING * DQ_SLAB;
     int vo[DB][2];
@@ -788,7 +810,7 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_ds_kernel(const AttnArgs a
     const int64_t q_end = q0 + FQ < a.Sq ? q0 + FQ : a.Sq;
     const int64_t kv_end = a.Skv < q_end ? a.Skv : q_end;
     const int nt = (int)((kv_end + ABK - 1) / ABK);
-    const char *dsg = a.ds + ((bh * a.ds_nqb + qblk) * a.ds_nkwb * 8 + wid) * DS_TILE; // + kwb * 8 tiles
+    const char *dsg = a.ds + (((bh - a.bh0) * a.ds_nqb + qblk) * a.ds_nkwb * 8 + wid) * DS_TILE; // + kwb * 8 tiles (the workspace holds this launch's heads)
     const int kwb_last = (int)(a.ds_nkwb - 1);
     auto stage = [&](int tile, int slot) { // 2 K pieces (this wave's share of the tile) + 4 dS pieces (its own two tiles)
         const int tl = tile < nt ? tile : nt - 1;
@@ -821,7 +843,7 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_ds_kernel(const AttnArgs a
         stage(t + 2, (t + 2) % DQ_RING);
         const char *kt = smem + (t % DQ_RING) * FTILE;
         const unsigned dsb = ds_rd + (unsigned)((t % DQ_RING) * DQ_SLAB);
-        if (active && 2 * t <= sl) { // wave-uniform: key block 2 t lies at or below this slice's diagonal
+        if (active && 2 * t <= sl && !KF_MUT(3, t == 0 && qblk == nxb - 1)) { // wave-uniform: key block 2 t lies at or below this slice's diagonal
             dq_step<BF, 0, 0, DB>(kt, vo, dsb, dq);
             dq_step<BF, 0, 1, DB>(kt, vo, dsb, dq);
             if (2 * t + 1 <= sl) {
@@ -1071,7 +1093,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     int64_t bh;
     // a.persist: a workgroup takes key block x and its causal mirror nkb - 1 - x (equal work per workgroup, as in the forward)
     const int nkb = (int)(a.Skv / K4B), nwx = a.persist ? nkb / (2 * a.persist) : nkb;
-    a_block_map(nwx, (int)(a.B * a.H), a.xcd_map, xb0, bh);
+    a_block_map(nwx, a.nbh, a.xcd_map, xb0, bh);
+    bh += a.bh0;
     const char *Qg = a.q + a_head(a.lq, bh, a.H);
     const char *dOg = a.d_o + a_head(a.ldo, bh, a.H);
 #pragma nounroll
@@ -1127,7 +1150,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     // dS tiles of this wave's 32 keys: tile (qb, kwb, sl) of the workspace, lane (key xl, half hl) writes operand s at
     // s * 1024 + xl * 32 + hl * 16 (see DS_TILE)
     unsigned ds_lane = (unsigned)(xl * 32 + hl * 16);
-    const char *ds_base = DS ? a.ds + ((bh * a.ds_nqb * a.ds_nkwb + (kw >> 5)) * 8) * DS_TILE : nullptr; // + (qb nkwb 8 + sl) tiles per slice
+    const char *ds_base = DS ? a.ds + (((bh - a.bh0) * a.ds_nqb * a.ds_nkwb + (kw >> 5)) * 8) * DS_TILE : nullptr; // + (qb nkwb 8 + sl) tiles per slice
     const int ds_qb_tiles = (int)(a.ds_nkwb * 8);
     // a pair is 10 DMA operations per wave (ids 0..9: slice id / 5; Q rows i, dO rows i for i = 0, 1, then the row
     // constants); they are issued ONE per quarter-phase (an LDS-DMA instruction holds the wave's issue for 60-180 cycles,
@@ -1264,6 +1287,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     _Pragma("unroll") for (int e_ = (E); e_ < (E) + 2; ++e_) {                          \
         float pv = KF_ABL_EXP(sv[e_]);                                                  \
         if (MASK && nd > a_row(e_, 0)) pv = 0.f;                                        \
+        if (KF_MUT(2, xb == 0 && qs == a.Sq - BQS)) pv = 0.f;                           \
         sv[e_] = pv;                                                                    \
     }
 #define K4_Q2(KK)                                                                                       \
@@ -1405,6 +1429,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     {                                                                    \
         float pv = __builtin_amdgcn_exp2f(sv[E]);                        \
         if (MASK && nd > a_row(E, 0)) pv = 0.f;                          \
+        if (KF_MUT(2, xb == 0 && qs == a.Sq - BQS)) pv = 0.f;            \
         sv[E] = pv;                                                      \
     }
 #define K6_MUL2(E) dpv[E] = k4_mul(sv[E], dpv[E]); dpv[(E) + 1] = k4_mul_odd(sv[(E) + 1], dpv[(E) + 1]);
@@ -1587,7 +1612,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_f32_mfma_kernel(const AttnArg
     int64_t bh;
     const int nxb = (int)((a.Sq + XQ - 1) / XQ);
     const int nwx = a.persist ? nxb / (2 * a.persist) : nxb; // a.persist: a block and its causal mirror per workgroup (see attn_fwd_v3_kernel)
-    a_block_map(nwx, (int)(a.B * a.H), a.xcd_map, xb0, bh);
+    a_block_map(nwx, a.nbh, a.xcd_map, xb0, bh);
     const float *Kg = (const float *)a.k + bh * a.Skv * D;
     const float *Vg = (const float *)a.v + bh * a.Skv * D;
   for (int pass = 0; pass < (a.persist ? 2 * a.persist : 1); ++pass) {
@@ -1756,7 +1781,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_f32_mfma_kernel(const AttnArg
     int64_t bh;
     const int nxb = (int)((a.Sq + XQ - 1) / XQ);
     const int nwx = a.persist ? nxb / (2 * a.persist) : nxb;
-    a_block_map(nwx, (int)(a.B * a.H), a.xcd_map, xb0, bh);
+    a_block_map(nwx, a.nbh, a.xcd_map, xb0, bh);
     const float *Kg = (const float *)a.k + bh * a.Skv * D;
     const float *Vg = (const float *)a.v + bh * a.Skv * D;
     const float c = a.scale * kLog2e;
@@ -1868,7 +1893,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_f32_mfma_kernel(const AttnAr
     int64_t bh;
     const int nkb = (int)((a.Skv + XQ - 1) / XQ);
     const int nwx = a.persist ? nkb / (2 * a.persist) : nkb;
-    a_block_map(nwx, (int)(a.B * a.H), a.xcd_map, xb0, bh);
+    a_block_map(nwx, a.nbh, a.xcd_map, xb0, bh);
     const float *Qg = (const float *)a.q + bh * a.Sq * D;
     const float *Og = (const float *)a.d_o + bh * a.Sq * D;
     const float c = a.scale * kLog2e;
@@ -2214,12 +2239,21 @@ static bool mfma_ok(int dtype, int64_t Sq, int64_t Skv, int64_t D) {
 
 static inline size_t a_align(size_t v) { return (v + 255) / 256 * 256; }
 
-// the MFMA backward keeps dS (2 products for dQ instead of 6) while its workspace stays below 64 GiB; beyond that, and with
-// KF_ATTN_SPLIT_BWD, the dQ kernel recomputes S and dP (round 1's split: small workspace, 40 % more matrix work)
-// (head size 64 has the dS form only: the knob does not apply to it, and a dS beyond 64 GiB is refused)
-static bool bwd_keeps_ds(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D) {
-    return mfma_ok(dtype, Sq, Skv, D) && (D == 64 || !knob(KNOB_ATTN_SPLIT_BWD)) && ds_bytes(B * H, Sq, Skv) <= ((size_t)64 << 30);
+// Backward workspace of the 16-bit matrix-core path: three rows of statistics (O(B H S), always) + as much of dS as the caller gives.
+// The dS form (2 products for dQ instead of the 6 a recomputing kernel executes) processes the (batch, head) pairs in GROUPS of as
+// many pairs as the workspace holds dS for (multiples of 8 when it can, so a group's heads still pin to XCDs); a workspace that
+// cannot hold one pair's dS - or KF_ATTN_SPLIT_BWD - selects the recomputing dQ kernel, whose workspace is the statistics alone.
+// kf_attn_bwd_workspace_bytes recommends statistics + min(all of dS, KF_ATTN_DS_CAP_MB (default 16 GiB)): the workspace is bounded
+// whatever B, H and S are, and ANY size >= the statistics is accepted (both head sizes, every S).
+static size_t bwd_stats_bytes(int64_t nbh, int64_t Sq) { return 3 * a_align((size_t)nbh * Sq * sizeof(float)); }
+static int64_t ds_group(int64_t nbh, int64_t Sq, int64_t Skv, size_t budget) { // pairs whose dS fit into `budget` bytes
+    const size_t one = ds_bytes(1, Sq, Skv);
+    int64_t g = (int64_t)(budget / one);
+    if (g >= nbh) return nbh;
+    if (g >= 8) g -= g % 8;
+    return g;
 }
+static size_t ds_cap() { return (size_t)knob_int(KNOB_ATTN_DS_CAP_MB, 16384) << 20; }
 
 template <typename K>
 static int set_lds(K kernel, size_t bytes) { return ensure_dynamic_lds((const void *)kernel, (int)bytes); }
@@ -2227,6 +2261,11 @@ static int set_lds(K kernel, size_t bytes) { return ensure_dynamic_lds((const vo
 } // namespace kf
 
 using namespace kf;
+
+#ifdef KF_MUTANT
+static int g_mutant = 0; // see KF_MUT above
+extern "C" int kfmut_select(int which) { g_mutant = which; return KF_OK; }
+#endif
 
 static int check_common(const char *who, int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D) {
     KF_REQUIRE(dtype == KF_F32 || dtype == KF_BF16 || dtype == KF_F16, KF_ERR_UNSUPPORTED, "%s: dtype %d not supported", who, dtype);
@@ -2280,10 +2319,14 @@ static int attn_fwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
     memset(&a, 0, sizeof(a));
     a.q = (const char *)q; a.k = (const char *)k; a.v = (const char *)v; a.out = (char *)o; a.lse = lse;
     a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.D = D;
+    a.nbh = (int)(B * H);
     KF_REQUIRE(scale > 0.f && scale < INFINITY, KF_ERR_INVALID, "attention: the softmax scale must be positive and finite");
     a.scale = scale;
     a.xcd_map = ((B * H) % 8 == 0) && !knob(KNOB_ATTN_NO_XCD);
     a.defer = knob(KNOB_ATTN_NO_DEFER) ? -INFINITY : kDeferMax; // A/B switch: rescale O at every tile
+#ifdef KF_MUTANT
+    a.mutant = g_mutant;
+#endif
     if (lays) { a.lq = lays[0]; a.lk = lays[1]; a.lv = lays[2]; a.lo = lays[3]; }
     else { a.lq = a.lo = lay_contig(H, Sq, D, 2); a.lk = a.lv = lay_contig(H, Skv, D, 2); }
     if (mfma_ok(dtype, Sq, Skv, D)) {
@@ -2350,8 +2393,9 @@ extern "C" int kf_attn_bwd_workspace_bytes(int dtype, int64_t B, int64_t H, int6
     KF_REQUIRE(bytes, KF_ERR_INVALID, "kf_attn_bwd_workspace_bytes: null out pointer");
     int rc = check_common("kf_attn_bwd_workspace_bytes", dtype, B, H, Sq, Skv, D);
     if (rc != KF_OK) return rc;
-    *bytes = 3 * a_align((size_t)B * H * Sq * sizeof(float)); // delta | -lse sqrt(D) | -delta
-    if (bwd_keeps_ds(dtype, B, H, Sq, Skv, D)) *bytes += ds_bytes(B * H, Sq, Skv); // + dS in 16 bits (DS_TILE)
+    *bytes = bwd_stats_bytes(B * H, Sq); // delta | -lse log2(e) | -delta
+    if (mfma_ok(dtype, Sq, Skv, D) && !knob(KNOB_ATTN_SPLIT_BWD) && B * H > 0)
+        *bytes += ds_bytes(ds_group(B * H, Sq, Skv, ds_cap()), Sq, Skv); // + dS in 16 bits (DS_TILE) of one group of pairs
     return KF_OK;
 }
 
@@ -2395,9 +2439,8 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
     if (rc != KF_OK) return rc;
     if (B * H == 0 || Sq == 0 || Skv == 0) return KF_OK;
     KF_REQUIRE(q && k && v && o && lse && d_o && dq && dk && dv, KF_ERR_INVALID, "kf_attn_bwd: null operand");
-    size_t need = 0;
-    kf_attn_bwd_workspace_bytes(dtype, B, H, Sq, Skv, D, &need);
-    KF_REQUIRE(workspace && workspace_bytes >= need, KF_ERR_WORKSPACE, "kf_attn_bwd: workspace of %zu bytes required, got %zu", need, workspace_bytes);
+    const size_t need = bwd_stats_bytes(B * H, Sq); // the minimum; what lies beyond it holds dS (see ds_group)
+    KF_REQUIRE(workspace && workspace_bytes >= need, KF_ERR_WORKSPACE, "kf_attn_bwd: workspace of at least %zu bytes required, got %zu", need, workspace_bytes);
     hipStream_t st = as_stream(stream);
     AttnArgs a;
     memset(&a, 0, sizeof(a));
@@ -2408,8 +2451,12 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
     a.ndelta = (float *)((char *)workspace + 2 * a_align((size_t)B * H * Sq * sizeof(float)));
     a.xcd_map = ((B * H) % 8 == 0) && !knob(KNOB_ATTN_NO_XCD);
     a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.D = D;
+    a.nbh = (int)(B * H);
     KF_REQUIRE(scale > 0.f && scale < INFINITY, KF_ERR_INVALID, "attention: the softmax scale must be positive and finite");
     a.scale = scale;
+#ifdef KF_MUTANT
+    a.mutant = g_mutant;
+#endif
     if (lays) { a.lq = lays[0]; a.lk = lays[1]; a.lv = lays[2]; a.lo = lays[3]; a.ldo = lays[4]; a.ldq = lays[5]; a.ldk = lays[6]; a.ldv = lays[7]; }
     else { a.lq = a.lo = a.ldo = a.ldq = lay_contig(H, Sq, D, 2); a.lk = a.lv = a.ldk = a.ldv = lay_contig(H, Skv, D, 2); }
     const int64_t nrows = B * H * Sq;
@@ -2422,52 +2469,65 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
             else attn_delta_kernel<false><<<gd, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, kLog2e, a.lo, a.ldo, Sq, H, (int)(D / 8));
             KF_LAUNCH_CHECK();
         }
-        const bool keep_ds = bwd_keeps_ds(dtype, B, H, Sq, Skv, D);
-        KF_REQUIRE(keep_ds || D == AD, KF_ERR_UNSUPPORTED, "kf_attn_bwd: head size 64 keeps dS in the workspace, and %zu bytes of it exceed 64 GiB",
-                   ds_bytes(B * H, Sq, Skv));
-        a.ds = keep_ds ? (char *)workspace + 3 * a_align((size_t)B * H * Sq * sizeof(float)) : nullptr;
+        const int64_t nbh = B * H;
+        const int64_t group = knob(KNOB_ATTN_SPLIT_BWD) ? 0 : ds_group(nbh, Sq, Skv, workspace_bytes - need);
+        const bool keep_ds = group > 0;
+        a.ds = keep_ds ? (char *)workspace + need : nullptr;
         a.ds_nqb = (Sq + 255) / 256;
         a.ds_nkwb = Skv / 32;
-        { // one wave per SIMD, pinned MFMA / VALU interleave
-            const int64_t nkb4 = Skv / K4B;
-            a.persist = (nkb4 % 2 == 0 && nkb4 >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
-            a.persist_rev = 1; // the short block of the pair first: 2.17 ms against 2.32 the other way round (2.22 unpaired)
-            dim3 gk4((unsigned)((a.persist ? nkb4 / 2 : nkb4) * B * H));
-            KF_PROF(D == 64 ? "attn_bwd_dkv_mfma_d64" : "attn_bwd_dkv_mfma", st);
+        const int64_t nkb4 = Skv / K4B, nxq = (Sq + FQ - 1) / FQ;
+        const int pair_kv = (nkb4 % 2 == 0 && nkb4 >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
+        const int pair_q = (nxq % 2 == 0 && nxq >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
 #define KF_DKV(BF_, DS_, D_)                                                                  \
     {                                                                                         \
         if ((rc = set_lds(attn_bwd_dkv_v4_kernel<BF_, DS_, D_>, K4LDS)) != KF_OK) return rc;  \
         attn_bwd_dkv_v4_kernel<BF_, DS_, D_><<<gk4, 256, K4LDS, st>>>(a);                     \
     }
-            if (D == 64) { if (bf) KF_DKV(true, true, 64) else KF_DKV(false, true, 64) }
-            else if (bf) { if (keep_ds) KF_DKV(true, true, 128) else KF_DKV(true, false, 128) }
-            else { if (keep_ds) KF_DKV(false, true, 128) else KF_DKV(false, false, 128) }
-#undef KF_DKV
-            KF_LAUNCH_CHECK();
-        }
-        const int64_t nxq = (Sq + FQ - 1) / FQ;
-        a.persist = (nxq % 2 == 0 && nxq >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
-        a.persist_rev = 0;
-        dim3 gq2((unsigned)((a.persist ? nxq / 2 : nxq) * B * H));
-        if (keep_ds) { // dQ = scale dS K from the stored dS
-            KF_PROF(D == 64 ? "attn_bwd_dq_mfma_d64" : "attn_bwd_dq_mfma", st);
 #define KF_DQ(BF_, D_)                                                                      \
     {                                                                                       \
         if ((rc = set_lds(attn_bwd_dq_ds_kernel<BF_, D_>, DQ_LDS)) != KF_OK) return rc;     \
         attn_bwd_dq_ds_kernel<BF_, D_><<<gq2, FNT, DQ_LDS, st>>>(a);                         \
     }
-            if (bf) { if (D == 64) KF_DQ(true, 64) else KF_DQ(true, 128) }
-            else { if (D == 64) KF_DQ(false, 64) else KF_DQ(false, 128) }
-#undef KF_DQ
-            KF_LAUNCH_CHECK();
-        } else { // the recomputing dQ kernel
-            if ((rc = set_lds(attn_bwd_dq_v2_kernel<true>, QLDS)) != KF_OK) return rc;
-            if ((rc = set_lds(attn_bwd_dq_v2_kernel<false>, QLDS)) != KF_OK) return rc;
-            KF_PROF("attn_bwd_dq_mfma_split", st);
-            if (bf) attn_bwd_dq_v2_kernel<true><<<gq2, FNT, QLDS, st>>>(a);
-            else attn_bwd_dq_v2_kernel<false><<<gq2, FNT, QLDS, st>>>(a);
-            KF_LAUNCH_CHECK();
+#define KF_DQ2(BF_, D_)                                                                     \
+    {                                                                                       \
+        if ((rc = set_lds(attn_bwd_dq_v2_kernel<BF_, D_>, QLDS)) != KF_OK) return rc;       \
+        attn_bwd_dq_v2_kernel<BF_, D_><<<gq2, FNT, QLDS, st>>>(a);                           \
+    }
+        // one group of (batch, head) pairs at a time: dK/dV (stores the group's dS), then dQ from it. Without dS: one group, all pairs.
+        for (int64_t bh0 = 0; bh0 < nbh; bh0 += keep_ds ? group : nbh) {
+            a.bh0 = bh0;
+            a.nbh = (int)std::min<int64_t>(keep_ds ? group : nbh, nbh - bh0);
+            a.xcd_map = (a.nbh % 8 == 0) && !knob(KNOB_ATTN_NO_XCD);
+            { // dK / dV: one wave per SIMD, pinned MFMA / VALU interleave
+                a.persist = pair_kv;
+                a.persist_rev = 1; // the short block of the pair first: 2.17 ms against 2.32 the other way round (2.22 unpaired)
+                dim3 gk4((unsigned)((a.persist ? nkb4 / 2 : nkb4) * a.nbh));
+                KF_PROF(D == 64 ? "attn_bwd_dkv_mfma_d64" : "attn_bwd_dkv_mfma", st);
+                if (D == 64) {
+                    if (bf) { if (keep_ds) KF_DKV(true, true, 64) else KF_DKV(true, false, 64) }
+                    else { if (keep_ds) KF_DKV(false, true, 64) else KF_DKV(false, false, 64) }
+                } else if (bf) { if (keep_ds) KF_DKV(true, true, 128) else KF_DKV(true, false, 128) }
+                else { if (keep_ds) KF_DKV(false, true, 128) else KF_DKV(false, false, 128) }
+                KF_LAUNCH_CHECK();
+            }
+            a.persist = pair_q;
+            a.persist_rev = 0;
+            dim3 gq2((unsigned)((a.persist ? nxq / 2 : nxq) * a.nbh));
+            if (keep_ds) { // dQ = scale dS K from the stored dS
+                KF_PROF(D == 64 ? "attn_bwd_dq_mfma_d64" : "attn_bwd_dq_mfma", st);
+                if (bf) { if (D == 64) KF_DQ(true, 64) else KF_DQ(true, 128) }
+                else { if (D == 64) KF_DQ(false, 64) else KF_DQ(false, 128) }
+                KF_LAUNCH_CHECK();
+            } else { // the recomputing dQ kernel (S and dP again)
+                KF_PROF(D == 64 ? "attn_bwd_dq_mfma_split_d64" : "attn_bwd_dq_mfma_split", st);
+                if (bf) { if (D == 64) KF_DQ2(true, 64) else KF_DQ2(true, 128) }
+                else { if (D == 64) KF_DQ2(false, 64) else KF_DQ2(false, 128) }
+                KF_LAUNCH_CHECK();
+            }
         }
+#undef KF_DKV
+#undef KF_DQ
+#undef KF_DQ2
         return KF_OK;
     }
     const unsigned gd = (unsigned)((nrows + 3) / 4);

@@ -63,3 +63,15 @@ extern "C" int kf_allreduce_sum(void *comm, void *buf, size_t count, int dtype, 
     KF_NCCL_TRY(ncclAllReduce(buf, buf, count, dt, ncclSum, (ncclComm_t)comm, as_stream(stream)));
     return KF_OK;
 }
+
+// several buffers, ONE collective launch (ncclGroupStart / End): the pieces of a gradient bucket that are not contiguous
+extern "C" int kf_allreduce_sum_multi(void *comm, int n, void *const *bufs, const size_t *counts, int dtype, void *stream) {
+    KF_REQUIRE(comm && n >= 0 && (n == 0 || (bufs && counts)), KF_ERR_INVALID, "kf_allreduce_sum_multi: null argument");
+    if (n == 0) return KF_OK;
+    if (n == 1) return kf_allreduce_sum(comm, bufs[0], counts[0], dtype, stream);
+    KF_NCCL_TRY(ncclGroupStart());
+    int rc = KF_OK;
+    for (int i = 0; i < n && rc == KF_OK; ++i) rc = kf_allreduce_sum(comm, bufs[i], counts[i], dtype, stream);
+    KF_NCCL_TRY(ncclGroupEnd());
+    return rc;
+}

@@ -1308,16 +1308,23 @@ extern "C" int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N
     return gemm_impl(dtype, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, epilogue, bias, nullptr, stream, workspace, workspace_bytes);
 }
 
-extern "C" int kf_gemm_grouped(int dtype, int count, const kf_gemm_problem *p, void *stream) {
-    KF_REQUIRE(count >= 0 && (p || count == 0), KF_ERR_INVALID, "kf_gemm_grouped: null problem list");
-    // the backward pair of one linear layer on the 4-wave 256-tile kernel: one grid, no kernel boundary between the two products
+// the backward pair of one linear layer (dA = dC W^T: NT, dW = A^T dC: TN) on the 4-wave 256-tile kernel as ONE grid
+static bool grouped_single_grid(int dtype, int count, const kf_gemm_problem *p) {
     const bool half = dtype == KF_BF16 || dtype == KF_F16;
     auto pair_ok = [&](const kf_gemm_problem &q) {
         return q.A && q.B && q.C && h_fast_ok(q.M, q.N, q.K) && h256_ok(q.M, q.N, q.K) && h256_use_w4(q.M, q.N) && ((q.M / G_BM) * (q.N / G_BN)) % 8 == 0 &&
                (uintptr_t)q.A % 16 == 0 && (uintptr_t)q.B % 16 == 0 && q.lda % 8 == 0 && q.ldb % 8 == 0 && q.ldc >= q.N &&
                q.lda >= (q.trans_a ? q.M : q.K) && q.ldb >= (q.trans_b ? q.K : q.N);
     };
-    if (half && count == 2 && !p[0].trans_a && p[0].trans_b && p[1].trans_a && !p[1].trans_b && pair_ok(p[0]) && pair_ok(p[1]) && !knob(KNOB_GEMM_NO_GROUP)) {
+    return half && count == 2 && p && !p[0].trans_a && p[0].trans_b && p[1].trans_a && !p[1].trans_b && pair_ok(p[0]) && pair_ok(p[1]) && !knob(KNOB_GEMM_NO_GROUP);
+}
+
+extern "C" int kf_gemm_grouped_single_grid(int dtype, int count, const kf_gemm_problem *p) { return grouped_single_grid(dtype, count, p) ? 1 : 0; }
+
+extern "C" int kf_gemm_grouped(int dtype, int count, const kf_gemm_problem *p, void *stream) {
+    KF_REQUIRE(count >= 0 && (p || count == 0), KF_ERR_INVALID, "kf_gemm_grouped: null problem list");
+    // one grid, no kernel boundary between the two products
+    if (grouped_single_grid(dtype, count, p)) {
         hipStream_t st = as_stream(stream);
         GemmArgs g0{p[0].A, p[0].B, p[0].C, nullptr, p[0].M, p[0].N, p[0].K, p[0].lda, p[0].ldb, p[0].ldc, p[0].alpha, p[0].beta, KF_EPI_NONE, 0};
         GemmArgs g1{p[1].A, p[1].B, p[1].C, nullptr, p[1].M, p[1].N, p[1].K, p[1].lda, p[1].ldb, p[1].ldc, p[1].alpha, p[1].beta, KF_EPI_NONE, 0};

@@ -44,8 +44,8 @@ EXPORTS = [
     "kf_device_props_get", "kf_elementwise", "kf_reduce_workspace_bytes", "kf_reduce",
     "kf_reduce_moments_workspace_bytes", "kf_reduce_moments",
     "kf_norm_fwd", "kf_norm_bwd_workspace_bytes", "kf_norm_bwd",
-    "kf_index_put", "kf_index_get", "kf_index_add_workspace_bytes", "kf_index_add", "kf_sort_workspace_bytes", "kf_sort", "kf_gemm_workspace_bytes", "kf_gemm", "kf_gemm_ex", "kf_gemm_grouped", "kf_attn_fwd", "kf_attn_fwd_scaled", "kf_attn_bwd_workspace_bytes",
-    "kf_attn_bwd", "kf_attn_bwd_scaled", "kf_attn_fwd_strided", "kf_attn_bwd_strided", "kf_comm_unique_id", "kf_comm_init", "kf_comm_destroy", "kf_allreduce_sum",
+    "kf_index_put", "kf_index_get", "kf_index_add_workspace_bytes", "kf_index_add", "kf_sort_workspace_bytes", "kf_sort", "kf_gemm_workspace_bytes", "kf_gemm", "kf_gemm_ex", "kf_gemm_grouped", "kf_gemm_grouped_single_grid", "kf_attn_fwd", "kf_attn_fwd_scaled", "kf_attn_bwd_workspace_bytes",
+    "kf_attn_bwd", "kf_attn_bwd_scaled", "kf_attn_fwd_strided", "kf_attn_bwd_strided", "kf_comm_unique_id", "kf_comm_init", "kf_comm_destroy", "kf_allreduce_sum", "kf_allreduce_sum_multi",
 ]
 
 

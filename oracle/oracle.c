@@ -498,6 +498,111 @@ int orc_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64
     return 0;
 }
 
+/* The same two functions in DOUBLE on the dtype-rounded inputs, nothing rounded on the way or at the end, plus the error SCALE of every
+ * output element: the sum of the absolute values of the terms it is a sum of. A 16-bit kernel rounds P and dS to 8 (bf16) or 11 (f16)
+ * significant bits before the second contraction, so its error in an element is bounded by eps * that element's scale (plus one output
+ * rounding) whatever the element's own size is - the bound tests/helpers.py: attn_check holds the kernels to.
+ * Semantics: causal_attention_ref.h:25-64 (scale 1/sqrt(D) :33, mask keeps m >= n :36-41, max-subtracted softmax :43-58).
+ *   o[m,d]  = sum_n p[m,n] v[n,d]                     mo[m,d]  = sum_n p[m,n] |v[n,d]|
+ *   dv[n,d] = sum_m p[m,n] dO[m,d]                    mdv[n,d] = sum_m p[m,n] |dO[m,d]|
+ *   dq[m,d] = scale sum_n ds[m,n] k[n,d]              mdq[m,d] = scale sum_n |ds[m,n]| |k[n,d]|
+ *                                                     bdq[m,d] = da[m] scale |sum_n p[m,n] k[n,d]|
+ *   dk[n,d] = scale sum_m ds[m,n] q[m,d]              mdk[n,d] = scale sum_m (|ds[m,n]| + p[m,n] da[m]) |q[m,d]|
+ *   ds = p (dp - delta), delta[m] = sum_n p dp = sum_d dO O;  da[m] = sum_d |dO[m,d] O[m,d]|: a 16-bit backward forms delta from the
+ *   ROUNDED O, so delta carries an error up to eps da[m]; it moves every dS of row m the same way (coherent in dq: the separate,
+ *   signed-sum scale bdq; independent from row to row in dk: inside mdk)
+ * Every output pointer is double[B,H,S,D] (lse: double[B,H,Sq]); d_o == NULL computes the forward half only. Rows in parallel. */
+int orc_attn_ref64(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, const void *q, const void *k, const void *v,
+                   const void *d_o, double *o, double *lse, double *mo, double *dq, double *dk, double *dv, double *mdq, double *mdk,
+                   double *mdv, double *bdq) {
+    if (!(dtype == ORC_F32 || dtype == ORC_F16 || dtype == ORC_BF16)) return 1;
+    const int es = dt_size(dtype);
+    const double scale = 1.0 / sqrt((double)D);
+    for (int64_t bh = 0; bh < B * H; ++bh) {
+        double *qf = (double *)malloc(sizeof(double) * (size_t)(Sq * D)), *kf = (double *)malloc(sizeof(double) * (size_t)(Skv * D));
+        double *vf = (double *)malloc(sizeof(double) * (size_t)(Skv * D)), *gf = d_o ? (double *)malloc(sizeof(double) * (size_t)(Sq * D)) : NULL;
+        double *rmx = (double *)malloc(sizeof(double) * (size_t)Sq), *rl = (double *)malloc(sizeof(double) * (size_t)Sq);
+        double *rdelta = (double *)malloc(sizeof(double) * (size_t)Sq), *rdabs = (double *)malloc(sizeof(double) * (size_t)Sq);
+        for (int64_t i = 0; i < Sq * D; ++i) qf[i] = ld_d(dtype, (const char *)q + (bh * Sq * D + i) * es);
+        for (int64_t i = 0; i < Skv * D; ++i) kf[i] = ld_d(dtype, (const char *)k + (bh * Skv * D + i) * es);
+        for (int64_t i = 0; i < Skv * D; ++i) vf[i] = ld_d(dtype, (const char *)v + (bh * Skv * D + i) * es);
+        if (d_o) for (int64_t i = 0; i < Sq * D; ++i) gf[i] = ld_d(dtype, (const char *)d_o + (bh * Sq * D + i) * es);
+#pragma omp parallel
+        {
+            double *p = (double *)malloc(sizeof(double) * (size_t)Skv), *dp = (double *)malloc(sizeof(double) * (size_t)Skv);
+#pragma omp for schedule(dynamic, 8)
+            for (int64_t m = 0; m < Sq; ++m) { /* pass 1, a query row at a time: statistics, o, dq */
+                const int64_t nvis = m + 1 < Skv ? m + 1 : Skv;
+                const double *qr = qf + m * D;
+                double mx = -INFINITY;
+                for (int64_t n = 0; n < nvis; ++n) {
+                    double sum = 0.0;
+                    for (int64_t d = 0; d < D; ++d) sum += qr[d] * kf[n * D + d];
+                    p[n] = sum * scale;
+                    if (p[n] > mx) mx = p[n];
+                }
+                double l = 0.0;
+                for (int64_t n = 0; n < nvis; ++n) { p[n] = exp(p[n] - mx); l += p[n]; }
+                for (int64_t n = 0; n < nvis; ++n) p[n] /= l;
+                rmx[m] = mx; rl[m] = l;
+                if (lse) lse[bh * Sq + m] = mx + log(l);
+                double *orow = o + (bh * Sq + m) * D, *morow = mo ? mo + (bh * Sq + m) * D : NULL;
+                for (int64_t d = 0; d < D; ++d) { orow[d] = 0.0; if (morow) morow[d] = 0.0; }
+                for (int64_t n = 0; n < nvis; ++n)
+                    for (int64_t d = 0; d < D; ++d) {
+                        orow[d] += p[n] * vf[n * D + d];
+                        if (morow) morow[d] += p[n] * fabs(vf[n * D + d]);
+                    }
+                if (!d_o) continue;
+                double delta = 0.0;
+                for (int64_t n = 0; n < nvis; ++n) {
+                    double sum = 0.0;
+                    for (int64_t d = 0; d < D; ++d) sum += gf[m * D + d] * vf[n * D + d];
+                    dp[n] = sum;
+                    delta += p[n] * sum;
+                }
+                rdelta[m] = delta;
+                double dabs = 0.0; /* delta = rowsum(dO o O) is formed from the ROUNDED O by a 16-bit backward: its error scale */
+                for (int64_t d = 0; d < D; ++d) dabs += fabs(gf[m * D + d] * orow[d]);
+                rdabs[m] = dabs;
+                double *dqr = dq + (bh * Sq + m) * D, *mdqr = mdq ? mdq + (bh * Sq + m) * D : NULL, *bdqr = bdq ? bdq + (bh * Sq + m) * D : NULL;
+                for (int64_t d = 0; d < D; ++d) { dqr[d] = 0.0; if (mdqr) mdqr[d] = 0.0; if (bdqr) bdqr[d] = 0.0; }
+                for (int64_t n = 0; n < nvis; ++n) {
+                    const double ds = p[n] * (dp[n] - delta) * scale;
+                    for (int64_t d = 0; d < D; ++d) {
+                        dqr[d] += ds * kf[n * D + d];
+                        if (mdqr) mdqr[d] += fabs(ds) * fabs(kf[n * D + d]);
+                        if (bdqr) bdqr[d] += p[n] * kf[n * D + d]; /* signed: one delta error moves every dS of the row the same way */
+                    }
+                }
+                if (bdqr) for (int64_t d = 0; d < D; ++d) bdqr[d] = fabs(bdqr[d]) * dabs * scale;
+            }
+            if (d_o) {
+#pragma omp for schedule(dynamic, 8)
+                for (int64_t n = 0; n < Skv; ++n) { /* pass 2, a key row at a time (p, dp recomputed from the saved statistics): dk, dv */
+                    double *dkr = dk + (bh * Skv + n) * D, *dvr = dv + (bh * Skv + n) * D;
+                    double *mdkr = mdk ? mdk + (bh * Skv + n) * D : NULL, *mdvr = mdv ? mdv + (bh * Skv + n) * D : NULL;
+                    for (int64_t d = 0; d < D; ++d) { dkr[d] = dvr[d] = 0.0; if (mdkr) mdkr[d] = 0.0; if (mdvr) mdvr[d] = 0.0; }
+                    for (int64_t m = n; m < Sq; ++m) {
+                        double s = 0.0, g = 0.0;
+                        for (int64_t d = 0; d < D; ++d) { s += qf[m * D + d] * kf[n * D + d]; g += gf[m * D + d] * vf[n * D + d]; }
+                        const double pp = exp(s * scale - rmx[m]) / rl[m], ds = pp * (g - rdelta[m]) * scale;
+                        for (int64_t d = 0; d < D; ++d) {
+                            dkr[d] += ds * qf[m * D + d];
+                            dvr[d] += pp * gf[m * D + d];
+                            if (mdkr) mdkr[d] += (fabs(ds) + pp * rdabs[m] * scale) * fabs(qf[m * D + d]);
+                            if (mdvr) mdvr[d] += pp * fabs(gf[m * D + d]);
+                        }
+                    }
+                }
+            }
+            free(p); free(dp);
+        }
+        free(qf); free(kf); free(vf); free(gf); free(rmx); free(rl); free(rdelta); free(rdabs);
+    }
+    return 0;
+}
+
 /* ---- row normalisations (README.md:28 roadmap rms_norm; invstd as welford_norm.h:170-187: 1 / sqrt(M2 / n + eps)) --------
  * kind 0 = rms (y = x rstd w, rstd = 1 / sqrt(mean(x^2) + eps)), 1 = layer (y = (x - mean) rstd w + b). Statistics and the
  * whole evaluation in double on the dtype-rounded inputs; outputs rounded once. */

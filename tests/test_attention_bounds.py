@@ -1,0 +1,124 @@
+"""not gpu: the scale-aware attention bounds (oracle/checks.py) CAN FAIL.
+
+The round-2 tests compared the 16-bit attention kernels with absolute tolerances larger than the data (atol 3e-2 against a median
+|dQ| of 0.003 at S = 4096): an all-zero gradient passed 99 % of the comparisons. Here the replacement bounds are shown, on CPU, to
+  * accept the f32 oracle's own 16-bit outputs (its error is one output rounding) and a simulated matrix-core kernel (P and dS rounded
+    to the 16-bit type before the second contraction, outputs rounded once - the arithmetic of kfunca_amd/csrc/device/attention.hip),
+  * reject every structural defect a tiled kernel can have: a dropped 64-key tile, a 32-query slice that contributes nothing, a mask
+    row that lets one future key through, a stale running maximum (one tile scaled wrongly), an all-zero output.
+The same defects are injected into the real kernels by tests/test_gpu_attention_mutants.py (-m gpu)."""
+import numpy as np
+import pytest
+
+from oracle import checks as K
+from oracle import oracle as O
+
+S, D = 4096, 128  # config C3's sequence length and head size, one head
+
+
+def rnd(x, code):
+    return O.to_float(O.from_float(np.asarray(x, dtype=np.float32), code), code).astype(np.float64)
+
+
+@pytest.fixture(scope="module")
+def case():
+    rng = np.random.default_rng(4096)
+    code = O.BF16
+    q, k, v, go = (O.from_float(rng.uniform(-1, 1, (1, 1, S, D)).astype(np.float32), code) for _ in range(4))
+    ref = O.attn_ref64(q, k, v, go, code=code)
+    qf, kf, vf, gf = (K.to_f64(x, code)[0, 0] for x in (q, k, v, go))
+    return dict(code=code, q=q, k=k, v=v, go=go, ref=ref, qf=qf, kf=kf, vf=vf, gf=gf)
+
+
+def rows(c, m0, m1):
+    """P, dP, dS (f64) of query rows m0..m1-1 against all keys (zeros above the diagonal)."""
+    s = c["qf"][m0:m1] @ c["kf"].T / np.sqrt(D)
+    mask = np.arange(S)[None, :] <= np.arange(m0, m1)[:, None]
+    s = np.where(mask, s, -np.inf)
+    p = np.exp(s - s.max(axis=1, keepdims=True))
+    p /= p.sum(axis=1, keepdims=True)
+    dp = c["gf"][m0:m1] @ c["vf"].T
+    ds = p * (dp - (p * dp).sum(axis=1, keepdims=True)) / np.sqrt(D)
+    return p, dp, ds
+
+
+def to16(x, code):
+    return O.from_float(np.asarray(x, dtype=np.float32), code)
+
+
+def test_accepts_the_oracle_and_a_simulated_matrix_core_kernel(case):
+    c = case
+    code = c["code"]
+    o, lse = O.attn_fwd(c["q"], c["k"], c["v"], code=code)
+    dq, dk, dv = O.attn_bwd(c["q"], c["k"], c["v"], c["go"], code=code)
+    m = K.attn_check(c["q"], c["k"], c["v"], code, o=o, lse=lse, d_o=c["go"], dq=dq, dk=dk, dv=dv, ref=c["ref"], what="oracle")
+    assert max(m[n]["row"] for n in K.NAMES) < 0.3  # one output rounding sits well inside the row bound
+    # the kernels' arithmetic on the last 256 query rows: P, dS rounded to bf16 before the second product, f32-ish sums, one rounding
+    m0 = S - 256
+    p, dp, ds = rows(c, m0, S)
+    o_sim = rnd(rnd(p, code) @ c["vf"], code)
+    dq_sim = rnd(rnd(ds * np.sqrt(D), code) @ c["kf"] / np.sqrt(D), code)
+    sl = (slice(None), slice(None), slice(m0, S))
+    for name, sim in (("o", o_sim), ("dq", dq_sim)):
+        mm = K.margins(sim[None, None], c["ref"][name][sl], c["ref"]["m" + name][sl], K.EPS[code], coh=c["ref"]["bdq"][sl] if name == "dq" else None)
+        assert mm["element"] < 1 and mm["row"] < 1 and mm["head"] < 1, (name, mm)
+
+
+def reject(c, name, bad, sl=None):
+    ref, mag, coh = c["ref"][name], c["ref"]["m" + name], c["ref"]["bdq"] if name == "dq" else None
+    if sl is not None:
+        ref, mag, coh = ref[sl], mag[sl], None if coh is None else coh[sl]
+    with pytest.raises(AssertionError, match="scale-aware bound"):
+        K.check_one(name, to16(bad, c["code"]), ref, mag, c["code"], what="defect", coh=coh)
+
+
+def test_rejects_a_dropped_key_tile_in_the_last_query_block(case):
+    c = case
+    m0 = S - 256
+    p, dp, ds = rows(c, m0, S)
+    sl = (slice(None), slice(None), slice(m0, S))
+    for t0 in (64, 2048, 3840):  # the forward skips one 64-key tile: its P never reaches O or the row sum
+        pd = p.copy()
+        pd[:, t0:t0 + 64] = 0
+        pd /= pd.sum(axis=1, keepdims=True)
+        reject(c, "o", (pd @ c["vf"])[None, None], sl)
+        dsd = ds.copy()
+        dsd[:, t0:t0 + 64] = 0  # the dQ kernel skips one 64-key step
+        reject(c, "dq", (dsd @ c["kf"])[None, None], sl)
+
+
+def test_rejects_a_slice_that_contributes_nothing_to_a_key_block(case):
+    c = case
+    p, dp, ds = rows(c, S - 32, S)  # the last 32-query slice
+    for n0 in (0, 1920):            # ... dropped from the sums of one 128-key block
+        sl = (slice(None), slice(None), slice(n0, n0 + 128))
+        dv_bad = c["ref"]["dv"][0, 0, n0:n0 + 128] - p[:, n0:n0 + 128].T @ c["gf"][S - 32:]
+        dk_bad = c["ref"]["dk"][0, 0, n0:n0 + 128] - ds[:, n0:n0 + 128].T @ c["qf"][S - 32:]
+        reject(c, "dv", dv_bad[None, None], sl)
+        reject(c, "dk", dk_bad[None, None], sl)
+
+
+def test_rejects_a_leaky_mask_a_stale_maximum_and_zeros(case):
+    c = case
+    code = c["code"]
+    # one query row sees the next key (mask off by one on a single row of the diagonal tile)
+    m = 1000
+    s = c["qf"][m] @ c["kf"][:m + 2].T / np.sqrt(D)
+    p = np.exp(s - s.max())
+    p /= p.sum()
+    o_bad = c["ref"]["o"].copy()
+    o_bad[0, 0, m] = p @ c["vf"][:m + 2]
+    reject(c, "o", o_bad)
+    # a rescale applied to one 64-key tile only: its P carries a stray factor 2 (the hazard of guide T13)
+    p, dp, ds = rows(c, S - 32, S)
+    pd = p.copy()
+    pd[:, 1024:1088] *= 2
+    pd /= pd.sum(axis=1, keepdims=True)
+    reject(c, "o", (pd @ c["vf"])[None, None], (slice(None), slice(None), slice(S - 32, S)))
+    # all zeros: what the round-2 tolerances accepted in 99 % of the entries
+    for name in ("dq", "dk", "dv", "o"):
+        reject(c, name, np.zeros_like(c["ref"][name]))
+    # and the f16 bounds are 8x tighter: bf16-rounded outputs of the right values fail them
+    o, _ = O.attn_fwd(c["q"], c["k"], c["v"], code=code)
+    with pytest.raises(AssertionError):
+        K.check_one("o", K.to_f64(o, code).astype(np.float16), c["ref"]["o"], c["ref"]["mo"], O.F16)

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import kfunca_amd as kfunca
+from oracle import checks as K
 from oracle import oracle as O
 from tests.helpers import assert_close, golden
 
@@ -110,16 +111,24 @@ def test_qkv_linear_feeds_attention_in_place():
     qkv = kfunca.qkv_linear(tx, tw, tb)
     out = kfunca.causal_attention_qkv(qkv, B, S, Hh)
     out.backward(kfunca.from_numpy(g, 0).bfloat16())
-    qkv_ref = x.astype(np.float64) @ w.astype(np.float64) + b
-    assert_close(qkv.float().numpy(), qkv_ref, rtol=2e-2, atol=2e-2, what="qkv")
-    heads = lambda x2: np.ascontiguousarray(x2.reshape(B, S, Hh, D).transpose(0, 2, 1, 3)).astype(np.float32)  # noqa: E731
-    qb = O.bf16_to_f32(O.f32_to_bf16(qkv_ref.astype(np.float32)))
-    q, k, v = heads(qb[:, :d]), heads(qb[:, d:2 * d]), heads(qb[:, 2 * d:])
-    o_ref, _ = O.attn_fwd(q, k, v)
-    flat = lambda x4: x4.transpose(0, 2, 1, 3).reshape(B * S, d).astype(np.float64)  # noqa: E731
-    assert_close(out.float().numpy(), flat(o_ref), rtol=3e-2, atol=3e-2, what="attention on the packed projection")
-    dq, dk, dv = O.attn_bwd(q, k, v, heads(g))
-    dqkv = np.concatenate([flat(dq), flat(dk), flat(dv)], axis=1)
-    assert_close(tb.grad().float().numpy(), dqkv.sum(0), rtol=5e-2, atol=0.3, what="db")
-    assert_close(tx.grad().float().numpy(), dqkv @ w.astype(np.float64).T, rtol=5e-2, atol=5e-2, what="dx")
-    assert_close(tw.grad().float().numpy(), x.astype(np.float64).T @ dqkv, rtol=5e-2, atol=0.3, what="dW")
+    eps = 2.0 ** -8
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    qkv_ref = x64 @ w64 + b
+    got = qkv.float().numpy().astype(np.float64)
+    assert (np.abs(got - qkv_ref) <= eps * np.abs(qkv_ref) + 1e-6 * (np.abs(x64) @ np.abs(w64) + np.abs(b))).all(), "qkv"  # the GEMM bound of test_gpu_gemm.py
+    # attention is checked on the projection the device produced (its bits), under the scale-aware bounds of oracle/checks.py
+    heads = lambda x2: np.ascontiguousarray(x2.reshape(B, S, Hh, D).transpose(0, 2, 1, 3))  # noqa: E731
+    flat = lambda x4: x4.transpose(0, 2, 1, 3).reshape(B * S, d)  # noqa: E731
+    qkv_bits, g_bits = qkv.numpy(), O.f32_to_bf16(g)
+    q, k, v = heads(qkv_bits[:, :d]), heads(qkv_bits[:, d:2 * d]), heads(qkv_bits[:, 2 * d:])
+    ref = O.attn_ref64(q, k, v, heads(g_bits), code=O.BF16)
+    K.attn_check(q, k, v, O.BF16, o=heads(out.numpy()), ref=ref, what="attention on the packed projection")
+    # the gradients behind it: d(qkv) = [dq | dk | dv] reaches the projection rounded to bf16 once; sums of it bounded by eps x sum |terms|
+    dqkv = np.concatenate([flat(ref["dq"]), flat(ref["dk"]), flat(ref["dv"])], axis=1)
+    mqkv = np.concatenate([flat(ref["mdq"]), flat(ref["mdk"]), flat(ref["mdv"])], axis=1)  # the error scale of every d(qkv) element
+    edqkv = eps * (1.5 * np.abs(dqkv) + 0.75 * mqkv)                                         # ... and its bound (oracle/checks.py, element form)
+    for name, t, want, err in (("db", tb, dqkv.sum(0), edqkv.sum(0)), ("dx", tx, dqkv @ w64.T, edqkv @ np.abs(w64).T),
+                               ("dW", tw, x64.T @ dqkv, np.abs(x64).T @ edqkv)):
+        gotg = t.grad().float().numpy().astype(np.float64)
+        assert np.isfinite(gotg).all() and (np.abs(gotg - want) <= err + eps * np.abs(want)).all(), name
+        assert np.linalg.norm(gotg - want) <= 3 * eps * np.linalg.norm(want), name  # and 1 % of the whole gradient's norm

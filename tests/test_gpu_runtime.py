@@ -168,7 +168,8 @@ def test_bench_collective_path_and_checks_on_one_gpu():
     """`KF_BENCH_FORCE_COMM=1 python bench.py --gpus 1 --check`: the whole N > 1 code path of bench.py on one GPU — gloo rendezvous
     + RCCL communicator through kfunca_amd.parallel.ProcessGroup, the all-reduce of dW on its own stream behind an event, and
     after timing the checks: all-reduced dW == sum over ranks of each rank's own dW (here: bit-identical, one rank), sampled GEMM
-    rows and the attention prefix against the oracle, sum dV == sum dO."""
+    rows against the oracle, every element of attention head (0, 0) - O, LSE, dQ, dK, dV at S = 4096 - under the scale-aware bounds,
+    sum dV == sum dO."""
     import json
     import os
     import subprocess
@@ -179,7 +180,9 @@ def test_bench_collective_path_and_checks_on_one_gpu():
                           "--warmup", "1", "--sustain-seconds", "0.2", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
     assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-1500:])
     line = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][-1])
-    assert line["checks"] == {"allreduce_dw_vs_gloo_sum": True, "gemm_rows_vs_oracle": True, "attn_prefix_vs_oracle": True,
-                              "attn_dv_checksum": True}, line["checks"]
+    assert line["checks"] == {"allreduce_dw_vs_gloo_sum": True, "gemm_rows_vs_oracle": True, "attn_head00_vs_oracle_scale_aware": True,
+                              "attn_last_batch_bit_identical": True, "attn_dv_checksum": True}, line["checks"]
+    worst = line["check_notes"]["attn_head00_worst_fraction_of_bound"]
+    assert set(worst) == {"o", "dq", "dk", "dv"} and all(0 < v < 1 for v in worst.values()), worst
     assert line["allreduce"]["message_bytes"] == 4096 * 4096 * 2 and line["allreduce"]["ms"] > 0
     assert line["n_gpus"] == 1 and line["ms_per_step_sustained"] > 0 and line["roofline"]["frac"] > 0

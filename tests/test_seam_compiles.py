@@ -28,5 +28,5 @@ def test_seam_defines_every_declaration_of_the_reference_seam():
     text = (ROOT / "docs" / "seam.cpp").read_text()
     for name in ("dset_device", "dmalloc", "dfree", "dmemcpy_h2d", "dmemcpy_d2h", "dmemset_zeros", "add_kernel", "sub_kernel", "mul_kernel",
                  "div_kernel", "copy_kernel", "fill_kernel", "sum_kernel", "mean_kernel", "mean_var_kernel", "norm_stat_kernel",
-                 "index_put_kernel", "gemm_kernel", "causal_attention_kernel", "sort_stable_kernel", "topk_with_sort"):
+                 "index_put_kernel", "gemm_kernel", "causal_attention_kernel", "sort_stable_kernel", "topk_with_sort", "device_info"):
         assert re.search(r"\b" + name + r"\(", text), name

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Measured margins of the 16-bit attention kernels under the scale-aware bounds of oracle/checks.py (GPU box):
+
+    python tools/attn_parity_margins.py [--out gpurun_out/r03_attn_parity_margins.json]
+
+For every shape / dtype / head size below: the worst element, row and head figures (fractions of the bound: 1 = at the bound) and the worst
+row-relative L2 error of O, dQ, dK, dV against the double-precision oracle, plus the LSE error. The constants in oracle/checks.py are set
+at >= 2x the largest figures this prints; DESIGN.md section 2 quotes them."""
+import argparse
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+from kfunca_amd import hip_abi as H  # noqa: E402
+from oracle import checks as K  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from tests.test_gpu_attention import bwd, fwd  # noqa: E402
+
+SHAPES = [(1, 2, 256, 256, 128), (2, 3, 128, 384, 128), (1, 2, 384, 128, 128), (1, 2, 1024, 1024, 128), (1, 2, 2048, 2048, 64),
+          (1, 2, 4096, 4096, 128), (1, 2, 4096, 4096, 64), (1, 1, 8192, 8192, 128), (2, 2, 65, 33, 64), (1, 3, 40, 72, 80)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "r03_attn_parity_margins.json"))
+    args = ap.parse_args()
+    H.set_device(0)
+    rows, worst = [], {}
+    for code, cname in ((H.BF16, "bf16"), (H.F16, "f16")):
+        for (B, Hh, Sq, Skv, D) in SHAPES:
+            for dist in ("uniform(-1,1)", "normal(0,1)"):
+                rng = np.random.default_rng(Sq * 31 + Skv + D + code)
+                draw = (lambda s: rng.uniform(-1, 1, s)) if dist.startswith("u") else (lambda s: rng.standard_normal(s))
+                q, k, v, go = (O.from_float(draw(s).astype(np.float32), code) for s in ((B, Hh, Sq, D), (B, Hh, Skv, D), (B, Hh, Skv, D), (B, Hh, Sq, D)))
+                o, lse = fwd(code, q, k, v)
+                dq, dk, dv = bwd(code, q, k, v, o, lse, go)
+                ref = O.attn_ref64(q, k, v, go, code=code)
+                rec = {"dtype": cname, "B": B, "H": Hh, "Sq": Sq, "Skv": Skv, "D": D, "inputs": dist}
+                for n, g in (("o", o), ("dq", dq), ("dk", dk), ("dv", dv)):
+                    m = K.margins(K.to_f64(g, code), ref[n], ref["m" + n], K.EPS[code], K.ABS_ULP[code], ref["bdq"] if n == "dq" else None)
+                    rec[n] = {a: round(b, 4) for a, b in m.items()}
+                    for a, b in m.items():
+                        worst[(cname, a)] = max(worst.get((cname, a), 0.0), b)
+                rec["lse_max_abs"] = float(np.abs(lse.astype(np.float64) - ref["lse"]).max())
+                rec["lse_max_rel"] = float((np.abs(lse.astype(np.float64) - ref["lse"]) / (1 + np.abs(ref["lse"]))).max())
+                worst[(cname, "lse_rel")] = max(worst.get((cname, "lse_rel"), 0.0), rec["lse_max_rel"])
+                rows.append(rec)
+                print(json.dumps(rec), flush=True)
+    out = {"constants": {"C_OUT": K.C_OUT, "C_SUM": K.C_SUM, "C_ROW": K.C_ROW, "C_FLOOR": K.C_FLOOR, "C_HEAD": K.C_HEAD, "eps": {"bf16": 2.0 ** -8, "f16": 2.0 ** -11}},
+           "worst": {f"{a}:{b}": round(v, 5) for (a, b), v in sorted(worst.items())}, "cases": rows}
+    Path(args.out).parent.mkdir(parents=True, exist_ok=True)
+    Path(args.out).write_text(json.dumps(out, indent=1))
+    print("worst:", out["worst"])
+
+
+if __name__ == "__main__":
+    main()

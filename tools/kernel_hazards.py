@@ -9,6 +9,8 @@ accumulators). Compiles kfunca_amd/csrc/device/attention.hip to ISA and, in ever
   WAR        no instruction writes a VGPR of the MFMA's A or C operand within 8 wait states after it (the MFMA reads them over its passes;
              the compiler thinks an asm statement is done with its inputs when it is issued).
 
+Every check follows ALL paths out of the MFMA: straight on and through each branch to its label (loop back edges included), and an LDS
+load's destination and address registers count like any other write / read.
 Exit status 0 = clean; prints every violation otherwise.   usage: python tools/kernel_hazards.py [--asm FILE.s]"""
 import argparse
 import re
@@ -55,35 +57,66 @@ def dst_src(op, toks):
 
 
 def check(name, body):
-    ins = [p for p in (parse(l) for l in body) if p]
+    """Walks forward from every asm MFMA along EVERY path: straight on, and through each s_branch / s_cbranch_* to its label (loop
+    back edges included: a chain-ending MFMA near the bottom of the slice-pair loop is followed into the top of the next iteration)."""
+    ins, labels = [], {}
+    for l in body:
+        t = l.split(";")[0].strip()
+        if t.endswith(":"):  # a label (.LBBn_m:): where a branch lands
+            labels[t[:-1]] = len(ins)
+            continue
+        p = parse(l)
+        if p:
+            ins.append(p)
     bad = []
+
+    def paths(i, budget, visit):
+        """Yield (op, toks, wait states so far) along all paths from instruction i, up to `budget` wait states."""
+        stack = [(i, 0)]
+        seen = set()
+        while stack:
+            j, w = stack.pop()
+            while j < len(ins) and w < budget:
+                if (j, w) in seen:
+                    break
+                seen.add((j, w))
+                op2, t2 = ins[j]
+                if visit(op2, t2, w) is False:
+                    break
+                if op2 in ("s_branch",) or op2.startswith("s_cbranch"):
+                    tgt = labels.get(t2[0]) if t2 else None
+                    if tgt is not None:
+                        stack.append((tgt, w + 1))
+                    if op2 == "s_branch":
+                        break
+                w += states(op2, t2)
+                j += 1
+
     for i, (op, toks) in enumerate(ins):
         if not op.startswith("v_mfma_f32_32x32x16") or not toks[0].startswith("v["):
             continue
         d, a_c = regs(toks[0]), regs(toks[1]) | regs(toks[3])
-        # WAR on A / C operands
-        w = 0
-        for op2, t2 in ins[i + 1:]:
+        desc = f"`{op} {', '.join(toks)}`"
+
+        def war(op2, t2, w):  # WAR on A / C operands (an LDS load returning into them counts: its destination is written)
             wr, _ = dst_src(op2, t2)
             if not op2.startswith("v_mfma") and wr & (a_c - d):
-                bad.append(f"{name}: WAR {op2} {' '.join(t2)} {w} wait states after `{op} {', '.join(toks)}`")
-                break
-            w += states(op2, t2)
-            if w >= WAR_STATES:
-                break
-        # RAW / WAW on the destination: only from the last MFMA of a chain (the next instruction touching d is not an MFMA accumulating into it)
-        w = 0
-        for op2, t2 in ins[i + 1:]:
+                bad.append(f"{name}: WAR {op2} {' '.join(t2)} {w} wait states after {desc}")
+                return False
+            return True
+        paths(i + 1, WAR_STATES, war)
+
+        def raw(op2, t2, w):  # RAW / WAW on the destination: only from the last MFMA of a chain
             wr, rd = dst_src(op2, t2)
             if op2.startswith("v_mfma") and regs(t2[0]) == d:
-                break  # the chain continues: the hardware forwards the accumulator
-            if (wr | rd) & d and not op2.startswith(("ds_read", "s_waitcnt")):
+                return False  # the chain continues: the hardware forwards the accumulator
+            if (wr | rd) & d and not op2.startswith("s_waitcnt"):  # ds_read destinations and address registers included
                 if w < RAW_STATES:
-                    bad.append(f"{name}: RAW/WAW {op2} {' '.join(t2)} only {w} wait states after `{op} {', '.join(toks)}`")
-                break
-            w += states(op2, t2)
-            if w >= 4 * RAW_STATES:
-                break
+                    bad.append(f"{name}: RAW/WAW {op2} {' '.join(t2)} only {w} wait states after {desc}")
+                return False
+            return True
+        paths(i + 1, 4 * RAW_STATES, raw)
+    bad = sorted(set(bad))
     return bad, sum(1 for op, t in ins if op.startswith("v_mfma_f32_32x32x16") and t[0].startswith("v["))
 
 
