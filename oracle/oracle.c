@@ -498,23 +498,24 @@ int orc_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64
     return 0;
 }
 
-/* The same two functions in DOUBLE on the dtype-rounded inputs, nothing rounded on the way or at the end, plus the error SCALE of every
- * output element: the sum of the absolute values of the terms it is a sum of. A 16-bit kernel rounds P and dS to 8 (bf16) or 11 (f16)
- * significant bits before the second contraction, so its error in an element is bounded by eps * that element's scale (plus one output
- * rounding) whatever the element's own size is - the bound tests/helpers.py: attn_check holds the kernels to.
+/* The same two functions in DOUBLE on the dtype-rounded inputs, nothing rounded on the way or at the end, plus, for every output element,
+ * the two SCALES of the error a 16-bit kernel may make in it - such a kernel rounds P and dS to 8 (bf16) or 11 (f16) significant bits
+ * before the second contraction, forms delta = rowsum(dO o O) from the ROUNDED O, and rounds each output once:
+ *   m*  worst case: the sum of the absolute values of the terms the element is a sum of (every rounding pushing the same way);
+ *   q*  statistical: the same terms in QUADRATURE (independent roundings add like a random walk; one term: q = m) - the scale of a row's
+ *       or a head's error NORM. A row with few terms (the last keys of dK / dV, the first queries of O / dQ) has q close to m, a long
+ *       row has q close to |ref| itself: the bound follows the data instead of assuming either.
  * Semantics: causal_attention_ref.h:25-64 (scale 1/sqrt(D) :33, mask keeps m >= n :36-41, max-subtracted softmax :43-58).
- *   o[m,d]  = sum_n p[m,n] v[n,d]                     mo[m,d]  = sum_n p[m,n] |v[n,d]|
- *   dv[n,d] = sum_m p[m,n] dO[m,d]                    mdv[n,d] = sum_m p[m,n] |dO[m,d]|
- *   dq[m,d] = scale sum_n ds[m,n] k[n,d]              mdq[m,d] = scale sum_n |ds[m,n]| |k[n,d]|
- *                                                     bdq[m,d] = da[m] scale |sum_n p[m,n] k[n,d]|
- *   dk[n,d] = scale sum_m ds[m,n] q[m,d]              mdk[n,d] = scale sum_m (|ds[m,n]| + p[m,n] da[m]) |q[m,d]|
- *   ds = p (dp - delta), delta[m] = sum_n p dp = sum_d dO O;  da[m] = sum_d |dO[m,d] O[m,d]|: a 16-bit backward forms delta from the
- *   ROUNDED O, so delta carries an error up to eps da[m]; it moves every dS of row m the same way (coherent in dq: the separate,
- *   signed-sum scale bdq; independent from row to row in dk: inside mdk)
- * Every output pointer is double[B,H,S,D] (lse: double[B,H,Sq]); d_o == NULL computes the forward half only. Rows in parallel. */
+ *   o[m,d]  = sum_n p[m,n] v[n,d]            terms p v                  dv[n,d] = sum_m p[m,n] dO[m,d]          terms p dO
+ *   dq[m,d] = scale sum_n ds[m,n] k[n,d]     terms ds k, and the delta error e[m] through scale (sum_n p k) e[m]: ONE term (coherent over n);
+ *             its worst case is returned apart as bdq[m,d] = da[m] scale |sum_n p[m,n] k[n,d]| (not inside mdq)
+ *   dk[n,d] = scale sum_m ds[m,n] q[m,d]     terms (ds + p e[m]) q: the delta errors of different query rows are independent
+ *   ds = p (dp - delta), delta[m] = sum_n p dp = sum_d dO O;  |e[m]| <= eps da[m], da[m] = sum_d |dO[m,d] O[m,d]| (worst case),
+ *   da2[m] = sqrt(sum_d (dO O)^2) (statistical)
+ * Every output pointer is double[B,H,S,D] (lse: double[B,H,Sq]) and may be NULL; d_o == NULL computes the forward half only. */
 int orc_attn_ref64(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, const void *q, const void *k, const void *v,
                    const void *d_o, double *o, double *lse, double *mo, double *dq, double *dk, double *dv, double *mdq, double *mdk,
-                   double *mdv, double *bdq) {
+                   double *mdv, double *bdq, double *qo, double *qdq, double *qdk, double *qdv) {
     if (!(dtype == ORC_F32 || dtype == ORC_F16 || dtype == ORC_BF16)) return 1;
     const int es = dt_size(dtype);
     const double scale = 1.0 / sqrt((double)D);
@@ -523,6 +524,7 @@ int orc_attn_ref64(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int
         double *vf = (double *)malloc(sizeof(double) * (size_t)(Skv * D)), *gf = d_o ? (double *)malloc(sizeof(double) * (size_t)(Sq * D)) : NULL;
         double *rmx = (double *)malloc(sizeof(double) * (size_t)Sq), *rl = (double *)malloc(sizeof(double) * (size_t)Sq);
         double *rdelta = (double *)malloc(sizeof(double) * (size_t)Sq), *rdabs = (double *)malloc(sizeof(double) * (size_t)Sq);
+        double *rda2 = (double *)malloc(sizeof(double) * (size_t)Sq);
         for (int64_t i = 0; i < Sq * D; ++i) qf[i] = ld_d(dtype, (const char *)q + (bh * Sq * D + i) * es);
         for (int64_t i = 0; i < Skv * D; ++i) kf[i] = ld_d(dtype, (const char *)k + (bh * Skv * D + i) * es);
         for (int64_t i = 0; i < Skv * D; ++i) vf[i] = ld_d(dtype, (const char *)v + (bh * Skv * D + i) * es);
@@ -530,6 +532,7 @@ int orc_attn_ref64(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int
 #pragma omp parallel
         {
             double *p = (double *)malloc(sizeof(double) * (size_t)Skv), *dp = (double *)malloc(sizeof(double) * (size_t)Skv);
+            double *t0 = (double *)malloc(sizeof(double) * (size_t)D * 4), *t1 = t0 + D, *t2 = t1 + D, *t3 = t2 + D;
 #pragma omp for schedule(dynamic, 8)
             for (int64_t m = 0; m < Sq; ++m) { /* pass 1, a query row at a time: statistics, o, dq */
                 const int64_t nvis = m + 1 < Skv ? m + 1 : Skv;
@@ -546,13 +549,19 @@ int orc_attn_ref64(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int
                 for (int64_t n = 0; n < nvis; ++n) p[n] /= l;
                 rmx[m] = mx; rl[m] = l;
                 if (lse) lse[bh * Sq + m] = mx + log(l);
-                double *orow = o + (bh * Sq + m) * D, *morow = mo ? mo + (bh * Sq + m) * D : NULL;
-                for (int64_t d = 0; d < D; ++d) { orow[d] = 0.0; if (morow) morow[d] = 0.0; }
+                double *orow = t0, *morow = t1, *qorow = t2;
+                for (int64_t d = 0; d < D; ++d) orow[d] = morow[d] = qorow[d] = 0.0;
                 for (int64_t n = 0; n < nvis; ++n)
                     for (int64_t d = 0; d < D; ++d) {
-                        orow[d] += p[n] * vf[n * D + d];
-                        if (morow) morow[d] += p[n] * fabs(vf[n * D + d]);
+                        const double t = p[n] * vf[n * D + d];
+                        orow[d] += t; morow[d] += fabs(t); qorow[d] += t * t;
                     }
+                for (int64_t d = 0; d < D; ++d) {
+                    const int64_t at = (bh * Sq + m) * D + d;
+                    if (o) o[at] = orow[d];
+                    if (mo) mo[at] = morow[d];
+                    if (qo) qo[at] = sqrt(qorow[d]);
+                }
                 if (!d_o) continue;
                 double delta = 0.0;
                 for (int64_t n = 0; n < nvis; ++n) {
@@ -562,43 +571,65 @@ int orc_attn_ref64(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int
                     delta += p[n] * sum;
                 }
                 rdelta[m] = delta;
-                double dabs = 0.0; /* delta = rowsum(dO o O) is formed from the ROUNDED O by a 16-bit backward: its error scale */
-                for (int64_t d = 0; d < D; ++d) dabs += fabs(gf[m * D + d] * orow[d]);
-                rdabs[m] = dabs;
-                double *dqr = dq + (bh * Sq + m) * D, *mdqr = mdq ? mdq + (bh * Sq + m) * D : NULL, *bdqr = bdq ? bdq + (bh * Sq + m) * D : NULL;
-                for (int64_t d = 0; d < D; ++d) { dqr[d] = 0.0; if (mdqr) mdqr[d] = 0.0; if (bdqr) bdqr[d] = 0.0; }
+                double dabs = 0.0, da2 = 0.0;
+                for (int64_t d = 0; d < D; ++d) { const double t = gf[m * D + d] * orow[d]; dabs += fabs(t); da2 += t * t; }
+                da2 = sqrt(da2);
+                rdabs[m] = dabs; rda2[m] = da2;
+                double *dqr = t0, *mdqr = t1, *pk = t2, *qq = t3; /* (orow is no longer needed) */
+                for (int64_t d = 0; d < D; ++d) dqr[d] = mdqr[d] = pk[d] = qq[d] = 0.0;
                 for (int64_t n = 0; n < nvis; ++n) {
                     const double ds = p[n] * (dp[n] - delta) * scale;
                     for (int64_t d = 0; d < D; ++d) {
-                        dqr[d] += ds * kf[n * D + d];
-                        if (mdqr) mdqr[d] += fabs(ds) * fabs(kf[n * D + d]);
-                        if (bdqr) bdqr[d] += p[n] * kf[n * D + d]; /* signed: one delta error moves every dS of the row the same way */
+                        const double t = ds * kf[n * D + d];
+                        dqr[d] += t; mdqr[d] += fabs(t); qq[d] += t * t;
+                        pk[d] += p[n] * kf[n * D + d]; /* signed: one delta error moves every dS of the row the same way */
                     }
                 }
-                if (bdqr) for (int64_t d = 0; d < D; ++d) bdqr[d] = fabs(bdqr[d]) * dabs * scale;
+                for (int64_t d = 0; d < D; ++d) {
+                    const int64_t at = (bh * Sq + m) * D + d;
+                    const double c = fabs(pk[d]) * scale;
+                    if (dq) dq[at] = dqr[d];
+                    if (mdq) mdq[at] = mdqr[d];
+                    if (bdq) bdq[at] = c * dabs;
+                    if (qdq) qdq[at] = sqrt(qq[d] + c * da2 * c * da2);
+                }
             }
             if (d_o) {
 #pragma omp for schedule(dynamic, 8)
                 for (int64_t n = 0; n < Skv; ++n) { /* pass 2, a key row at a time (p, dp recomputed from the saved statistics): dk, dv */
-                    double *dkr = dk + (bh * Skv + n) * D, *dvr = dv + (bh * Skv + n) * D;
-                    double *mdkr = mdk ? mdk + (bh * Skv + n) * D : NULL, *mdvr = mdv ? mdv + (bh * Skv + n) * D : NULL;
-                    for (int64_t d = 0; d < D; ++d) { dkr[d] = dvr[d] = 0.0; if (mdkr) mdkr[d] = 0.0; if (mdvr) mdvr[d] = 0.0; }
+                    double *dkr = t0, *dvr = t1, *ak = t2, *av = t3;
+                    for (int64_t d = 0; d < D; ++d) dkr[d] = dvr[d] = ak[d] = av[d] = 0.0;
+                    double *mkr = (double *)calloc((size_t)D * 2, sizeof(double)), *mvr = mkr + D;
                     for (int64_t m = n; m < Sq; ++m) {
                         double s = 0.0, g = 0.0;
                         for (int64_t d = 0; d < D; ++d) { s += qf[m * D + d] * kf[n * D + d]; g += gf[m * D + d] * vf[n * D + d]; }
                         const double pp = exp(s * scale - rmx[m]) / rl[m], ds = pp * (g - rdelta[m]) * scale;
+                        const double wk = fabs(ds) + pp * rdabs[m] * scale, w2 = ds * ds + pp * rda2[m] * scale * pp * rda2[m] * scale;
                         for (int64_t d = 0; d < D; ++d) {
-                            dkr[d] += ds * qf[m * D + d];
-                            dvr[d] += pp * gf[m * D + d];
-                            if (mdkr) mdkr[d] += (fabs(ds) + pp * rdabs[m] * scale) * fabs(qf[m * D + d]);
-                            if (mdvr) mdvr[d] += pp * fabs(gf[m * D + d]);
+                            const double qd = qf[m * D + d], gd = gf[m * D + d];
+                            dkr[d] += ds * qd;
+                            dvr[d] += pp * gd;
+                            mkr[d] += wk * fabs(qd);
+                            mvr[d] += pp * fabs(gd);
+                            ak[d] += w2 * qd * qd;
+                            av[d] += pp * gd * pp * gd;
                         }
                     }
+                    for (int64_t d = 0; d < D; ++d) {
+                        const int64_t at = (bh * Skv + n) * D + d;
+                        if (dk) dk[at] = dkr[d];
+                        if (dv) dv[at] = dvr[d];
+                        if (mdk) mdk[at] = mkr[d];
+                        if (mdv) mdv[at] = mvr[d];
+                        if (qdk) qdk[at] = sqrt(ak[d]);
+                        if (qdv) qdv[at] = sqrt(av[d]);
+                    }
+                    free(mkr);
                 }
             }
-            free(p); free(dp);
+            free(p); free(dp); free(t0);
         }
-        free(qf); free(kf); free(vf); free(gf); free(rmx); free(rl); free(rdelta); free(rdabs);
+        free(qf); free(kf); free(vf); free(gf); free(rmx); free(rl); free(rdelta); free(rdabs); free(rda2);
     }
     return 0;
 }

@@ -58,11 +58,12 @@ int orc_attn_fwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64
 /* closed-form softmax-Jacobian backward of the above (no reference counterpart) */
 int orc_attn_bwd(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, const void *q, const void *k,
                  const void *v, const void *d_o, void *dq, void *dk, void *dv);
-/* the same in double with nothing rounded, plus each output element's error scale (sum of |terms|): the reference the 16-bit
- * kernels' scale-aware bounds are taken against (tests/helpers.py: attn_check). d_o == NULL: forward half only */
+/* the same in double with nothing rounded, plus each output element's error scales - m*: sum of |terms| (worst case), q*: the terms in
+ * quadrature (statistical), bdq: the worst case of a rounded delta through dq (oracle.c) - the reference the 16-bit kernels' scale-aware
+ * bounds are taken against (oracle/checks.py). Output pointers may be NULL; d_o == NULL: forward half only */
 int orc_attn_ref64(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, const void *q, const void *k, const void *v,
                    const void *d_o, double *o, double *lse, double *mo, double *dq, double *dk, double *dv, double *mdq, double *mdk,
-                   double *mdv, double *bdq);
+                   double *mdv, double *bdq, double *qo, double *qdq, double *qdk, double *qdv);
 /* rms_norm / layer_norm rows (README.md:28 roadmap item; invstd = 1 / sqrt(M2 / n + eps) as welford_norm.h:170-187); double
  * arithmetic on the dtype-rounded inputs, x / y / dy / dx contiguous [rows, cols]; kind 0 = rms, 1 = layer */
 int orc_norm_fwd(int kind, int dtype, int64_t rows, int64_t cols, const void *x, const void *w, const void *b, double eps, void *y,

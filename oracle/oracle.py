@@ -222,23 +222,25 @@ def attn_bwd(q, k, v, d_o, code=None):
 
 
 def attn_ref64(q, k, v, d_o=None, code=None):
-    """The double-precision evaluation (nothing rounded) on the dtype-rounded inputs + every output element's error scale.
-    Returns a dict: o, lse, mo and, with d_o, dq, dk, dv, mdq, mdk, mdv (float64 arrays; m* = sum of |terms|) and bdq (the scale of
-    the coherent error a rounded delta puts into dq; oracle.c: orc_attn_ref64)."""
+    """The double-precision evaluation (nothing rounded) on the dtype-rounded inputs + every output element's error scales.
+    Returns a dict of float64 arrays: o, lse, mo, qo and, with d_o, dq, dk, dv, mdq, mdk, mdv, qdq, qdk, qdv, bdq
+    (m* = sum of |terms|: worst case; q* = terms in quadrature: statistical; bdq = worst case of a rounded delta through dq;
+    oracle.c: orc_attn_ref64)."""
     cd = code_of(q, code)
     B, H, Sq, D = q.shape
     Skv = k.shape[2]
     q, k, v = map(np.ascontiguousarray, (q, k, v))
-    r = {"o": np.empty(q.shape, np.float64), "lse": np.empty((B, H, Sq), np.float64), "mo": np.empty(q.shape, np.float64)}
+    r = {"o": np.empty(q.shape, np.float64), "lse": np.empty((B, H, Sq), np.float64), "mo": np.empty(q.shape, np.float64), "qo": np.empty(q.shape, np.float64)}
     if d_o is not None:
         d_o = np.ascontiguousarray(d_o)
-        for n, like in (("dq", q), ("dk", k), ("dv", v), ("mdq", q), ("mdk", k), ("mdv", v), ("bdq", q)):
+        for n, like in (("dq", q), ("dk", k), ("dv", v), ("mdq", q), ("mdk", k), ("mdv", v), ("bdq", q), ("qdq", q), ("qdk", k), ("qdv", v)):
             r[n] = np.empty(like.shape, np.float64)
     f = lib().orc_attn_ref64
-    f.argtypes = [C.c_int] + [C.c_int64] * 5 + [C.c_void_p] * 14
+    f.argtypes = [C.c_int] + [C.c_int64] * 5 + [C.c_void_p] * 18
     ptr = lambda n: r[n].ctypes.data if n in r else None  # noqa: E731
     _check(f(cd, B, H, Sq, Skv, D, q.ctypes.data, k.ctypes.data, v.ctypes.data, None if d_o is None else d_o.ctypes.data,
-             ptr("o"), ptr("lse"), ptr("mo"), ptr("dq"), ptr("dk"), ptr("dv"), ptr("mdq"), ptr("mdk"), ptr("mdv"), ptr("bdq")), "attn_ref64")
+             ptr("o"), ptr("lse"), ptr("mo"), ptr("dq"), ptr("dk"), ptr("dv"), ptr("mdq"), ptr("mdk"), ptr("mdv"), ptr("bdq"),
+             ptr("qo"), ptr("qdq"), ptr("qdk"), ptr("qdv")), "attn_ref64")
     return r
 
 

@@ -58,25 +58,21 @@ def test_accepts_the_oracle_and_a_simulated_matrix_core_kernel(case):
     p, dp, ds = rows(c, m0, S)
     o_sim = rnd(rnd(p, code) @ c["vf"], code)
     dq_sim = rnd(rnd(ds * np.sqrt(D), code) @ c["kf"] / np.sqrt(D), code)
-    sl = (slice(None), slice(None), slice(m0, S))
     for name, sim in (("o", o_sim), ("dq", dq_sim)):
-        mm = K.margins(sim[None, None], c["ref"][name][sl], c["ref"]["m" + name][sl], K.EPS[code], coh=c["ref"]["bdq"][sl] if name == "dq" else None)
-        assert mm["element"] < 1 and mm["row"] < 1 and mm["head"] < 1, (name, mm)
+        mm = K.check_one(name, to16(sim[None, None], code), c["ref"], code, what="simulated kernel", rows=slice(m0, S))
+        assert mm["row"] < 0.6 and mm["head"] < 0.6, (name, mm)
 
 
-def reject(c, name, bad, sl=None):
-    ref, mag, coh = c["ref"][name], c["ref"]["m" + name], c["ref"]["bdq"] if name == "dq" else None
-    if sl is not None:
-        ref, mag, coh = ref[sl], mag[sl], None if coh is None else coh[sl]
+def reject(c, name, bad, rows=None):
     with pytest.raises(AssertionError, match="scale-aware bound"):
-        K.check_one(name, to16(bad, c["code"]), ref, mag, c["code"], what="defect", coh=coh)
+        K.check_one(name, to16(bad, c["code"]), c["ref"], c["code"], what="defect", rows=rows)
 
 
 def test_rejects_a_dropped_key_tile_in_the_last_query_block(case):
     c = case
     m0 = S - 256
     p, dp, ds = rows(c, m0, S)
-    sl = (slice(None), slice(None), slice(m0, S))
+    sl = slice(m0, S)
     for t0 in (64, 2048, 3840):  # the forward skips one 64-key tile: its P never reaches O or the row sum
         pd = p.copy()
         pd[:, t0:t0 + 64] = 0
@@ -91,7 +87,7 @@ def test_rejects_a_slice_that_contributes_nothing_to_a_key_block(case):
     c = case
     p, dp, ds = rows(c, S - 32, S)  # the last 32-query slice
     for n0 in (0, 1920):            # ... dropped from the sums of one 128-key block
-        sl = (slice(None), slice(None), slice(n0, n0 + 128))
+        sl = slice(n0, n0 + 128)
         dv_bad = c["ref"]["dv"][0, 0, n0:n0 + 128] - p[:, n0:n0 + 128].T @ c["gf"][S - 32:]
         dk_bad = c["ref"]["dk"][0, 0, n0:n0 + 128] - ds[:, n0:n0 + 128].T @ c["qf"][S - 32:]
         reject(c, "dv", dv_bad[None, None], sl)
@@ -114,11 +110,11 @@ def test_rejects_a_leaky_mask_a_stale_maximum_and_zeros(case):
     pd = p.copy()
     pd[:, 1024:1088] *= 2
     pd /= pd.sum(axis=1, keepdims=True)
-    reject(c, "o", (pd @ c["vf"])[None, None], (slice(None), slice(None), slice(S - 32, S)))
+    reject(c, "o", (pd @ c["vf"])[None, None], slice(S - 32, S))
     # all zeros: what the round-2 tolerances accepted in 99 % of the entries
     for name in ("dq", "dk", "dv", "o"):
         reject(c, name, np.zeros_like(c["ref"][name]))
     # and the f16 bounds are 8x tighter: bf16-rounded outputs of the right values fail them
     o, _ = O.attn_fwd(c["q"], c["k"], c["v"], code=code)
     with pytest.raises(AssertionError):
-        K.check_one("o", K.to_f64(o, code).astype(np.float16), c["ref"]["o"], c["ref"]["mo"], O.F16)
+        K.check_one("o", K.to_f64(o, code).astype(np.float16), c["ref"], O.F16)

@@ -59,7 +59,7 @@ def verdicts(code, q, k, v, go, ref, r):
     out = {}
     for n in K.NAMES:
         try:
-            K.check_one(n, r[n], ref[n], ref["m" + n], code, what="mutant", coh=ref["bdq"] if n == "dq" else None)
+            K.check_one(n, r[n], ref, code, what="mutant")
             out[n] = True
         except AssertionError:
             out[n] = False
@@ -101,4 +101,4 @@ def test_round2_tolerances_would_have_passed_the_defects(mut):
     assert np.allclose(K.to_f64(bad["dq"], code), K.to_f64(want, code), rtol=2e-2, atol=3e-2)  # the old test: green on a wrong gradient
     ref = O.attn_ref64(q, k, v, go, code=code)
     with pytest.raises(AssertionError):
-        K.check_one("dq", bad["dq"], ref["dq"], ref["mdq"], code, coh=ref["bdq"])
+        K.check_one("dq", bad["dq"], ref, code)

@@ -82,3 +82,37 @@ def test_bench_launches_its_own_ranks_cpu_dry_run():
     assert len(lines) == 1, res.stdout
     line = json.loads(lines[0])
     assert line == {"dry_run": True, "n_gpus": 2, "allreduce_check": True, "elapsed_s": line["elapsed_s"]}
+
+
+def test_gradient_bucket_plan_is_pure_arithmetic_and_cuts_from_the_end():
+    """kfunca.GradBucket.plan (C++ core, csrc/core/comm.cpp): slots 64-element aligned in parameter order, chunks of at most `cap`
+    elements cut from the END of the list (the last parameters' gradients arrive first), every parameter in exactly one chunk, an
+    oversized parameter alone in its chunk. No device needed."""
+    import kfunca_amd as kfunca
+    plan = kfunca.GradBucket.plan([100, 7, 4096, 64, 1], 4200)
+    assert plan == [(3, 4, 4288, 128), (1, 2, 128, 4160), (0, 0, 0, 128)]  # slots 128 | 64 | 4096 | 64 | 64 elements at 0, 128, 192, 4288, 4352
+    assert kfunca.GradBucket.plan([10, 20, 30], 1) == [(2, 2, 128, 64), (1, 1, 64, 64), (0, 0, 0, 64)]  # smaller than any slot: one chunk each
+    assert kfunca.GradBucket.plan([10, 20, 30], 10 ** 9) == [(0, 2, 0, 192)]
+    d, f = 4096, 16384  # config C5's block with the default 136 MiB cap of tools/block_bench.py: [down] [up] [gate] [out-proj + qkv]
+    numels = [d * 3 * d, d * d, d * f, d * f, f * d]
+    chunks = kfunca.GradBucket.plan(numels, 136 * 1048576 // 2)
+    assert [(c[0], c[1]) for c in chunks] == [(4, 4), (3, 3), (2, 2), (0, 1)]
+    assert sum(c[3] for c in chunks) == sum(numels) and all(c[2] % 64 == 0 for c in chunks)
+
+
+def test_block_bench_launches_its_own_ranks_cpu_dry_run():
+    """`python tools/block_bench.py --gpus 2` (config C5's multi-rank runner) with no torchrun environment: the parent starts both
+    ranks, they rendezvous over gloo, agree on the gradient bucket's plan and the parent relays rank 0's one line."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, str(Path(__file__).resolve().parent.parent / "tools" / "block_bench.py"), "--gpus", "2", "--dry-run-cpu"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["dry_run"] and line["n_gpus"] == 2 and line["allreduce_check"] is True
+    assert [c[:2] for c in line["bucket_chunks"]] == [[4, 4], [3, 3], [2, 2], [0, 1]]

@@ -21,7 +21,7 @@ from oracle import checks as K  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 from tests.test_gpu_attention import bwd, fwd  # noqa: E402
 
-SHAPES = [(1, 2, 256, 256, 128), (2, 3, 128, 384, 128), (1, 2, 384, 128, 128), (1, 2, 1024, 1024, 128), (1, 2, 2048, 2048, 64),
+SHAPES = [(1, 2, 256, 256, 128), (2, 3, 128, 384, 128), (1, 2, 384, 128, 128), (1, 3, 768, 768, 128), (1, 2, 1024, 1024, 128), (1, 2, 2048, 2048, 64),
           (1, 2, 4096, 4096, 128), (1, 2, 4096, 4096, 64), (1, 1, 8192, 8192, 128), (2, 2, 65, 33, 64), (1, 3, 40, 72, 80)]
 
 
@@ -42,7 +42,7 @@ def main():
                 ref = O.attn_ref64(q, k, v, go, code=code)
                 rec = {"dtype": cname, "B": B, "H": Hh, "Sq": Sq, "Skv": Skv, "D": D, "inputs": dist}
                 for n, g in (("o", o), ("dq", dq), ("dk", dk), ("dv", dv)):
-                    m = K.margins(K.to_f64(g, code), ref[n], ref["m" + n], K.EPS[code], K.ABS_ULP[code], ref["bdq"] if n == "dq" else None)
+                    m = K.margins(K.to_f64(g, code), *K.scales(ref, n)[:3], K.EPS[code], K.ABS_ULP[code], K.scales(ref, n)[3])
                     rec[n] = {a: round(b, 4) for a, b in m.items()}
                     for a, b in m.items():
                         worst[(cname, a)] = max(worst.get((cname, a), 0.0), b)
@@ -51,7 +51,7 @@ def main():
                 worst[(cname, "lse_rel")] = max(worst.get((cname, "lse_rel"), 0.0), rec["lse_max_rel"])
                 rows.append(rec)
                 print(json.dumps(rec), flush=True)
-    out = {"constants": {"C_OUT": K.C_OUT, "C_SUM": K.C_SUM, "C_ROW": K.C_ROW, "C_FLOOR": K.C_FLOOR, "C_HEAD": K.C_HEAD, "eps": {"bf16": 2.0 ** -8, "f16": 2.0 ** -11}},
+    out = {"constants": {"C_OUT": K.C_OUT, "C_SUM": K.C_SUM, "C_ROW": K.C_ROW, "C_Q": K.C_Q, "C_HEAD": K.C_HEAD, "C_QH": K.C_QH, "eps": {"bf16": 2.0 ** -8, "f16": 2.0 ** -11}},
            "worst": {f"{a}:{b}": round(v, 5) for (a, b), v in sorted(worst.items())}, "cases": rows}
     Path(args.out).parent.mkdir(parents=True, exist_ok=True)
     Path(args.out).write_text(json.dumps(out, indent=1))
