@@ -324,6 +324,7 @@ def main():
     if pg is not None:
         elapsed = pg.max_over_ranks(elapsed)
     prof = H.profile_results()
+    samples = H.profile_samples()  # every launch's own HIP-event duration: percentiles, run-to-run spread
 
     # sustained loop: the chip settles its clock only after ~2 s of back-to-back work (profiles/r01_gemm_clock.json)
     sustained = None
@@ -349,8 +350,13 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         kern = {k: {"avg_ms": ms / max(cnt, 1), "launches": cnt} for k, (ms, cnt) in prof.items()}
         for k, v in kern.items():
+            if k in samples and len(samples[k]):
+                a = np.sort(samples[k].astype(np.float64))
+                v.update({"p50_ms": float(np.percentile(a, 50)), "p95_ms": float(np.percentile(a, 95)), "min_ms": float(a[0]), "max_ms": float(a[-1])})
             if k in KERNEL_FLOPS:
                 v["tflops"] = KERNEL_FLOPS[k] / (v["avg_ms"] * 1e-3) / 1e12
+                if "p50_ms" in v:
+                    v["tflops_p50"] = KERNEL_FLOPS[k] / (v["p50_ms"] * 1e-3) / 1e12
         per_step = {k: ms / args.steps for k, (ms, cnt) in prof.items()}
         gemm_ms = sum(v for k, v in per_step.items() if k.startswith("gemm"))
         attn_ms = sum(v for k, v in per_step.items() if k.startswith("attn"))

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KF_ABI_VERSION 5 /* 2: + kf_reduce_moments*, KF_EW_*_SCALAR, kf_graph_*, kf_attn_*_scaled; 3: + kf_sort*; 4: + kf_knobs_reload, kf_norm_*, kf_index_get, kf_gemm_ex, KF_EPI_*; 5: + kf_gemm_grouped_single_grid, kf_allreduce_sum_multi, kf_attn_bwd accepts any workspace >= the statistics (all additive) */
+#define KF_ABI_VERSION 5 /* 2: + kf_reduce_moments*, KF_EW_*_SCALAR, kf_graph_*, kf_attn_*_scaled; 3: + kf_sort*; 4: + kf_knobs_reload, kf_norm_*, kf_index_get, kf_gemm_ex, KF_EPI_*; 5: + kf_gemm_grouped_single_grid, kf_allreduce_sum_multi, kf_profile_samples, kf_attn_bwd accepts any workspace >= the statistics (all additive) */
 
 /* ---- status ------------------------------------------------------------------------------ */
 enum {
@@ -114,6 +114,8 @@ int kf_profile_enable(int on);
 int kf_profile_reset(void);
 int kf_profile_count(int *n);
 int kf_profile_get(int i, char name[64], double *total_ms, int64_t *launches);
+/* the durations of entry i's individual launches, in launch order (at most the first 65536 are kept): percentiles, run-to-run spread */
+int kf_profile_samples(int i, float *ms, int capacity, int *written);
 
 /* A/B switches (KF_* environment variables: kernel-selection knobs for benchmarks and parity tests, the counterpart of
  * the reference's compile-time constants, SURVEY.md section 5 "Config / flags") are read once per process; this re-reads them. */

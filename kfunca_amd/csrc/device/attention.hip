@@ -2493,10 +2493,15 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
         if ((rc = set_lds(attn_bwd_dq_v2_kernel<BF_, D_>, QLDS)) != KF_OK) return rc;       \
         attn_bwd_dq_v2_kernel<BF_, D_><<<gq2, FNT, QLDS, st>>>(a);                           \
     }
+        // (Tried in round 3 and removed: the dS workspace as two half-group slots with group g's dQ - HBM-bound, it streams dS - on a second
+        // stream beside group g + 1's matrix-bound dK/dV. At C3 the backward took 3.39-3.78 ms against 3.32-3.36 in sequence
+        // (profiles/r03_attn_bwd_overlap_experiment.txt): both kernels fill every CU, so the dispatcher interleaves them instead of
+        // running them side by side, and each group boundary adds a tail.)
+        const int64_t grp = keep_ds ? group : nbh;
         // one group of (batch, head) pairs at a time: dK/dV (stores the group's dS), then dQ from it. Without dS: one group, all pairs.
-        for (int64_t bh0 = 0; bh0 < nbh; bh0 += keep_ds ? group : nbh) {
+        for (int64_t bh0 = 0; bh0 < nbh; bh0 += grp) {
             a.bh0 = bh0;
-            a.nbh = (int)std::min<int64_t>(keep_ds ? group : nbh, nbh - bh0);
+            a.nbh = (int)std::min<int64_t>(grp, nbh - bh0);
             a.xcd_map = (a.nbh % 8 == 0) && !knob(KNOB_ATTN_NO_XCD);
             { // dK / dV: one wave per SIMD, pinned MFMA / VALU interleave
                 a.persist = pair_kv;

@@ -18,6 +18,7 @@ void set_error(const char *fmt, ...) {
 } // namespace kf
 
 // ---- per-launch timing registry -------------------------------------------------------------
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -42,7 +43,7 @@ ProfScope::~ProfScope() {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_recs.push_back(r);
 }
-struct ProfSum { std::string name; double ms; int64_t n; };
+struct ProfSum { std::string name; double ms; int64_t n; std::vector<float> each; }; // each: the launches' own durations (for percentiles)
 static std::vector<ProfSum> g_prof_sums;
 static void prof_collect() { // folds finished records into per-name sums
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -54,8 +55,8 @@ static void prof_collect() { // folds finished records into per-name sums
         hipEventDestroy(r->e1);
         bool found = false;
         for (auto &s : g_prof_sums)
-            if (s.name == r->name) { s.ms += ms; s.n += 1; found = true; break; }
-        if (!found) g_prof_sums.push_back({r->name, (double)ms, 1});
+            if (s.name == r->name) { s.ms += ms; s.n += 1; if (s.each.size() < 65536) s.each.push_back(ms); found = true; break; }
+        if (!found) g_prof_sums.push_back({r->name, (double)ms, 1, {ms}});
         delete r;
     }
     g_prof_recs.clear();
@@ -67,8 +68,7 @@ static void prof_collect() { // folds finished records into per-name sums
 namespace kf {
 static const char *const g_knob_names[KNOB_COUNT] = {
     "KF_ATTN_NO_XCD", "KF_ATTN_NO_DEFER", "KF_ATTN_NO_PAIR", "KF_ATTN_F32_GENERIC", "KF_ATTN_SPLIT_BWD", "KF_GEMM_128", "KF_GEMM_W4",
-    "KF_GEMM_W8", "KF_GEMM_GROUP_M", "KF_GEMM_F64_GENERIC", "KF_REDUCE_NO_TALL", "KF_GEMM_NO_SPLITK", "KF_GEMM_NO_GROUP", "KF_ATTN_DS_CAP_MB",
-    "KF_ATTN_OVERLAP"};
+    "KF_GEMM_W8", "KF_GEMM_GROUP_M", "KF_GEMM_F64_GENERIC", "KF_REDUCE_NO_TALL", "KF_GEMM_NO_SPLITK", "KF_GEMM_NO_GROUP", "KF_ATTN_DS_CAP_MB"};
 static std::mutex g_knob_mu;
 static bool g_knob_loaded = false;
 static bool g_knob_set[KNOB_COUNT];
@@ -144,6 +144,16 @@ int kf_profile_get(int i, char name[64], double *total_ms, int64_t *launches) {
     snprintf(name, 64, "%s", g_prof_sums[i].name.c_str());
     *total_ms = g_prof_sums[i].ms;
     *launches = g_prof_sums[i].n;
+    return KF_OK;
+}
+
+int kf_profile_samples(int i, float *ms, int capacity, int *written) {
+    KF_REQUIRE(ms && written && capacity >= 0, KF_ERR_INVALID, "kf_profile_samples: null out pointer");
+    prof_collect();
+    KF_REQUIRE(i >= 0 && i < (int)g_prof_sums.size(), KF_ERR_INVALID, "kf_profile_samples: index %d out of range", i);
+    const int n = std::min<int>(capacity, (int)g_prof_sums[i].each.size());
+    for (int j = 0; j < n; ++j) ms[j] = g_prof_sums[i].each[j];
+    *written = n;
     return KF_OK;
 }
 

@@ -40,7 +40,7 @@ EXPORTS = [
     "kf_last_error", "kf_abi_version", "kf_device_count", "kf_set_device", "kf_get_device", "kf_malloc", "kf_free",
     "kf_memcpy_h2d", "kf_memcpy_d2h", "kf_memcpy_d2d", "kf_memset_zero", "kf_stream_create", "kf_stream_destroy",
     "kf_stream_sync", "kf_stream_wait_event", "kf_device_sync", "kf_event_create", "kf_event_destroy", "kf_event_record", "kf_event_sync",
-    "kf_event_elapsed_ms", "kf_graph_begin_capture", "kf_graph_end_capture", "kf_graph_launch", "kf_graph_destroy", "kf_profile_enable", "kf_profile_reset", "kf_profile_count", "kf_profile_get", "kf_knobs_reload",
+    "kf_event_elapsed_ms", "kf_graph_begin_capture", "kf_graph_end_capture", "kf_graph_launch", "kf_graph_destroy", "kf_profile_enable", "kf_profile_reset", "kf_profile_count", "kf_profile_get", "kf_profile_samples", "kf_knobs_reload",
     "kf_device_props_get", "kf_elementwise", "kf_reduce_workspace_bytes", "kf_reduce",
     "kf_reduce_moments_workspace_bytes", "kf_reduce_moments",
     "kf_norm_fwd", "kf_norm_bwd_workspace_bytes", "kf_norm_bwd",
@@ -556,6 +556,22 @@ def profile_enable(on: bool):
 
 def profile_reset():
     check(lib().kf_profile_reset())
+
+
+def profile_samples() -> dict:
+    """{kernel name: float32 array of its launches' durations in ms, in launch order} (synchronises)."""
+    n = C.c_int(0)
+    check(lib().kf_profile_count(C.byref(n)))
+    out = {}
+    for i in range(n.value):
+        name = C.create_string_buffer(64)
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        check(lib().kf_profile_get(i, name, C.byref(ms), C.byref(cnt)))
+        buf = np.empty(min(cnt.value, 65536), dtype=np.float32)
+        w = C.c_int(0)
+        check(lib().kf_profile_samples(i, buf.ctypes.data_as(C.POINTER(C.c_float)), buf.size, C.byref(w)))
+        out[name.value.decode()] = buf[:w.value]
+    return out
 
 
 def profile_results() -> dict:

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--variants", default="default")  # comma list of ENV=1 settings, e.g. default,KF_ATTN_DKV_V2
     ap.add_argument("--no-bwd", action="store_true")
+    ap.add_argument("--wall", type=int, default=0, help="also time N back-to-back backward calls per variant with one event pair (no per-kernel events)")
     ap.add_argument("--zeros", action="store_true", help="all-zero operands: the same instruction stream without the power limit (the schedule-bound time)")
     args = ap.parse_args()
     B, Hh, S, D = args.B, args.H, args.S, args.D
@@ -72,6 +73,28 @@ def main():
                 continue  # warm-up
             for k, (ms, n) in H.profile_results().items():
                 results[v].setdefault(k, []).append(ms / n)
+    if args.wall:
+        for rep in range(2):
+            for v in variants:
+                for e in [x for x in os.environ if x.startswith("KF_ATTN")]:
+                    del os.environ[e]
+                if v != "default":
+                    for kv in v.split("+"):
+                        k, _, val = kv.partition("=")
+                        os.environ[k] = val or "1"
+                H.knobs_reload()
+                nd = H.attn_bwd_workspace_bytes(H.BF16, B, Hh, S, S, D)
+                call = lambda: H.attn_bwd(H.BF16, B, Hh, S, S, D, bufs["q"].ptr, bufs["k"].ptr, bufs["v"].ptr, bufs["o"].ptr, lse.ptr, bufs["do"].ptr,  # noqa: E731
+                                          bufs["dq"].ptr, bufs["dk"].ptr, bufs["dv"].ptr, ws.ptr, min(nd, need))
+                call()
+                H.device_sync()
+                e0, e1 = H.Event(), H.Event()
+                e0.record(None)
+                for _ in range(args.wall):
+                    call()
+                e1.record(None)
+                H.device_sync()
+                print(f"wall[{rep}] {v:60s} {e0.elapsed_ms(e1) / args.wall:8.3f} ms per backward (workspace {min(nd, need) / 2 ** 20:.0f} MiB)", flush=True)
     for v in variants:
         print(f"== {v}  (B={B} H={Hh} S={S} D={D})")
         for k, xs in results[v].items():

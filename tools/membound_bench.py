@@ -16,7 +16,15 @@ from kfunca_amd import hip_abi as H  # noqa: E402
 PEAK = 8000.0  # GB/s, HBM3E spec (MI355X_MICROARCH.md); 6.3 TB/s is the measured float4-copy ceiling
 
 
+MARK = {"on": False, "buf": None, "order": []}
+
+
 def timed(name, fn, rounds):
+    if MARK["on"]:  # a one-workgroup f64 fill in front of every case: tools/membound_prof.py cuts the rocprofv3 dispatch list at these
+        if MARK["buf"] is None:
+            MARK["buf"] = H.DevBuf(512)
+        H.elementwise(H.EW_FILL, H.make_desc([H.View(MARK["buf"].ptr, (64,), (1,), H.F64)], []), 0, float(len(MARK["order"])))
+        MARK["order"].append(name)
     fn()
     H.device_sync()
     H.profile_reset()
@@ -34,7 +42,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=10)
     ap.add_argument("--json", default="")
+    ap.add_argument("--markers", action="store_true", help="a one-workgroup f64 fill before every case (for tools/membound_prof.py)")
     args = ap.parse_args()
+    MARK["on"] = args.markers
     H.set_device(0)
     out = {}
 
@@ -49,7 +59,7 @@ def main():
 
     def record(name, ms, nbytes, kernels):
         gbs = nbytes / (ms * 1e-3) / 1e9
-        out[name] = {"ms": ms, "algorithmic_bytes": nbytes, "GB/s": gbs, "frac_of_8TB/s": gbs / PEAK, "kernels": kernels}
+        out[name] = {"case_index": len(out), "rounds": args.rounds, "ms": ms, "algorithmic_bytes": nbytes, "GB/s": gbs, "frac_of_8TB/s": gbs / PEAK, "kernels": kernels}
         print(f"{name:44s} {ms:8.4f} ms  {gbs:9.1f} GB/s  {gbs / PEAK * 100:5.1f}% of HBM peak  {kernels}", flush=True)
 
     big = 1 << 28  # 256 Mi elements
