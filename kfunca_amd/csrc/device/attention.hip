@@ -106,8 +106,10 @@ constexpr float kLn2 = 0.6931471805599453f;
 // Mutation build (-DKF_MUTANT, kfunca_amd/_build.py: build_mutant; never in libkfunca_hip.so): deliberate single-tile defects, switched on at
 // run time by kfmut_select(), that the parity tests must REJECT (tests/test_gpu_attention_mutants.py) - the proof that their bounds can fail.
 //   1  forward: the last 256-query block of every head skips its key tile 1 (64 keys dropped from O and LSE)
-//   2  dK/dV: the last 32-query slice contributes nothing to the first 128-key block (P = 0 there: dK, dV of those keys and, through
-//      the stored dS, dQ of those queries lose one slice x block)
+//   2  dK/dV: the fifth 32-query slice (queries 128..159, the first one below the first key block's diagonal) contributes nothing to
+//      that 128-key block (P = 0 there: dK, dV of those keys and, through the stored dS, dQ of those queries lose one slice x block).
+//      (The LAST slice instead is a defect of ~1 % of those rows' norms - softmax weights of ~1/4096 beside ~1/n - which no bound
+//      that tolerates 16-bit rounding can see: the bounds' resolution is a few eps of a row's norm.)
 //   3  dQ (stored-dS form): the last 256-query block skips its key step 0 (64 keys dropped from dQ)
 //   4  dQ (recomputing form): the same
 #ifdef KF_MUTANT
@@ -1287,7 +1289,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     _Pragma("unroll") for (int e_ = (E); e_ < (E) + 2; ++e_) {                          \
         float pv = KF_ABL_EXP(sv[e_]);                                                  \
         if (MASK && nd > a_row(e_, 0)) pv = 0.f;                                        \
-        if (KF_MUT(2, xb == 0 && qs == a.Sq - BQS)) pv = 0.f;                           \
+        if (KF_MUT(2, xb == 0 && qs == 4 * BQS)) pv = 0.f;                              \
         sv[e_] = pv;                                                                    \
     }
 #define K4_Q2(KK)                                                                                       \
@@ -1429,7 +1431,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     {                                                                    \
         float pv = __builtin_amdgcn_exp2f(sv[E]);                        \
         if (MASK && nd > a_row(E, 0)) pv = 0.f;                          \
-        if (KF_MUT(2, xb == 0 && qs == a.Sq - BQS)) pv = 0.f;            \
+        if (KF_MUT(2, xb == 0 && qs == 4 * BQS)) pv = 0.f;               \
         sv[E] = pv;                                                      \
     }
 #define K6_MUL2(E) dpv[E] = k4_mul(sv[E], dpv[E]); dpv[(E) + 1] = k4_mul_odd(sv[(E) + 1], dpv[(E) + 1]);
@@ -1574,6 +1576,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
 #undef K4_CVT2
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // drain the ring and the last prefetch before LDS is reused
     __syncthreads();
+    // (Round 3, tried and dropped: requesting the NEXT pass's K / V fragments and first three slice pairs here, in front of this
+    // epilogue - slabs moved to the ring's fourth slot - so that their latency runs under it: 2.32-2.35 ms against 2.29-2.31 on the
+    // same box (tools/scratch/ab_attn.sh): thirty LDS-DMA issues in front of the stores delay the epilogue by more than the next
+    // pass's prologue gains.)
     a_store_rows<BF, DB>(smem + wid * 32 * OPAD, a.dv + a_head(a.ldv, bh, a.H) + kw * a.ldv.sr, dv, 1.f, a.ldv.sr);
     a_store_rows<BF, DB>(smem + wid * 32 * OPAD, a.dk + a_head(a.ldk, bh, a.H) + kw * a.ldk.sr, dk, a.scale, a.ldk.sr);
     if (a.persist) __syncthreads(); // the staging slabs overlap the ring the next block fills

@@ -62,6 +62,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     r.x = (uint16_t)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
     return r;
 }
+// two floats -> two bf16 in one word (lo in the low half) with the hardware's converter: round-to-nearest-even like f32_to_bf16; a NaN
+// keeps its payload's top bits instead of becoming 0x7FC0, so the bit-exact conversion paths (copy / convert kernels) do not use it -
+// the floating-point kernels, whose results are held to tolerances, do (one instruction instead of ~16 for the pair)
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2_hw(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
 __device__ __forceinline__ float f16_to_f32(f16_t v) {
     _Float16 h;
     __builtin_memcpy(&h, &v.x, 2);
@@ -92,7 +100,7 @@ static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream
 // kf_knobs_reload() re-reads them (tests and tools that flip a switch between two calls).
 enum Knob {
     KNOB_ATTN_NO_XCD, KNOB_ATTN_NO_DEFER, KNOB_ATTN_NO_PAIR, KNOB_ATTN_F32_GENERIC, KNOB_ATTN_SPLIT_BWD, KNOB_GEMM_128, KNOB_GEMM_W4,
-    KNOB_GEMM_W8, KNOB_GEMM_GROUP_M, KNOB_GEMM_F64_GENERIC, KNOB_REDUCE_NO_TALL, KNOB_GEMM_NO_SPLITK, KNOB_GEMM_NO_GROUP, KNOB_ATTN_DS_CAP_MB, KNOB_COUNT
+    KNOB_GEMM_W8, KNOB_GEMM_GROUP_M, KNOB_GEMM_F64_GENERIC, KNOB_REDUCE_NO_TALL, KNOB_GEMM_NO_SPLITK, KNOB_GEMM_NO_GROUP, KNOB_ATTN_DS_CAP_MB, KNOB_NORM_BWD_TPR, KNOB_COUNT
 };
 bool knob(Knob k);              // the variable is set
 long knob_int(Knob k, long dflt); // its integer value, dflt when unset

@@ -62,27 +62,39 @@ __device__ __forceinline__ uint4 n_pack(const float (&f)[V]) {
         uint32_t w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            uint32_t lo, hi;
-            if constexpr (std::is_same<T, bf16_t>::value) { lo = f32_to_bf16(f[2 * i]).x; hi = f32_to_bf16(f[2 * i + 1]).x; }
-            else { lo = f32_to_f16(f[2 * i]).x; hi = f32_to_f16(f[2 * i + 1]).x; }
-            w[i] = lo | (hi << 16);
+            if constexpr (std::is_same<T, bf16_t>::value) {
+                w[i] = f32x2_to_bf16x2_hw(f[2 * i], f[2 * i + 1]);
+            } else {
+                const uint32_t lo = f32_to_f16(f[2 * i]).x, hi = f32_to_f16(f[2 * i + 1]).x;
+                w[i] = lo | (hi << 16);
+            }
         }
         p.x = w[0]; p.y = w[1]; p.z = w[2]; p.w = w[3];
     }
     return p;
 }
 
-// sum over the TPR lanes that share a row (TPR = 64: one wave; 256: the block, through LDS). Every lane gets the total.
+// sum over the TPR lanes that share a row (TPR = 64: one wave; 256 / 512 / 1024: the whole block, through LDS). Every lane gets the total.
 template <int TPR>
 __device__ __forceinline__ float n_row_sum(float v, float *red) {
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
-    if constexpr (TPR == 256) {
+    if constexpr (TPR > 64) {
+        constexpr int NW = TPR / 64;
         const int wid = threadIdx.x >> 6;
         __syncthreads(); // the previous use of red[] is over
         if ((threadIdx.x & 63) == 0) red[wid] = v;
         __syncthreads();
-        v = (red[0] + red[1]) + (red[2] + red[3]); // fixed order
+        if constexpr (NW == 4) {
+            v = (red[0] + red[1]) + (red[2] + red[3]); // fixed order
+        } else {
+            float t[NW / 4];
+#pragma unroll
+            for (int i = 0; i < NW / 4; ++i) t[i] = (red[4 * i] + red[4 * i + 1]) + (red[4 * i + 2] + red[4 * i + 3]);
+            v = t[0];
+#pragma unroll
+            for (int i = 1; i < NW / 4; ++i) v += t[i];
+        }
     }
     return v;
 }
@@ -157,70 +169,132 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormArgs a) {
 // ---- backward: a block walks rows blockIdx.x, + gridDim.x, ...; x and dy of a row in registers ------------------------
 //   g = dy * w;  layer: dx = rstd * (g - mean(g) - xhat * mean(g * xhat));  rms: dx = rstd * (g - xhat * mean(g * xhat))
 // RMS is a compile-time flag here: without the mean, the mean(g) term and db the bf16 row costs ~9 instead of ~13 vector instructions
-// per element, and this kernel is VALU-limited on 16-bit rows (6 bytes per element)
-template <typename T, int TPR, int PACKS, bool RMS>
-__global__ __launch_bounds__(256) void norm_bwd_kernel(const NormArgs a) {
-    constexpr int V = NPack<T>::V, RPB = 256 / TPR;
-    __shared__ float red[4];
+// per element. A lane owns at most TWO packs of a row (16 elements of a 16-bit row): long rows spread over 512 or 1024 threads instead
+// of deepening the per-lane tile, which keeps the register count near 100 and four or more waves per SIMD in flight.
+// the two row sums of the backward with ONE barrier per row: the partial sums of the block's waves go through an LDS buffer that
+// alternates with the row's parity (the buffer written for row r + 1 was last read for row r - 1, before row r's barrier)
+template <int TPR>
+__device__ __forceinline__ void n_row_sum2(float &s1, float &s2, float (*red)[2][16], int parity) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+    if constexpr (TPR > 64) {
+        constexpr int NW = TPR / 64;
+        const int wid = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { red[parity][0][wid] = s1; red[parity][1][wid] = s2; }
+        __syncthreads();
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NW; i += 4) { // fixed order
+            t1 += (red[parity][0][i] + red[parity][0][i + 1]) + (red[parity][0][i + 2] + red[parity][0][i + 3]);
+            t2 += (red[parity][1][i] + red[parity][1][i + 1]) + (red[parity][1][i + 2] + red[parity][1][i + 3]);
+        }
+        s1 = t1; s2 = t2;
+    }
+}
+
+// PF = rows requested ahead of the one being worked on (0: none - wave-per-row blocks, whose four rows and many resident blocks
+// already keep the memory system busy; 2: a row spread over a whole block, where the row sums' barrier would otherwise expose a
+// full memory latency per row: with one pack per lane a row ahead costs 8 registers)
+template <typename T, int TPR, int PACKS, bool RMS, int PF>
+__global__ __launch_bounds__(TPR < 256 ? 256 : TPR) void norm_bwd_kernel(const NormArgs a) {
+    constexpr int NT = TPR < 256 ? 256 : TPR; // threads per block: four wave-rows, or ONE row across 4 / 8 / 16 waves
+    constexpr int V = NPack<T>::V, RPB = NT / TPR;
+    __shared__ float red[2][2][16];
     const int tr = threadIdx.x % TPR, sub = threadIdx.x / TPR;
-    float dw[PACKS][V], db[PACKS][V], wv[PACKS][V];
+    // Registers hold the row as it was LOADED (16-byte packs of x and dy: half the registers of their f32 images for 16-bit rows);
+    // x-hat and g = dy w are recomputed for the store.
+    uint4 wr[PACKS];
+    float dw[PACKS][V], db[RMS ? 1 : PACKS][V];
+    bool okc[PACKS];
 #pragma unroll
     for (int p = 0; p < PACKS; ++p) {
         const int64_t c = ((int64_t)p * TPR + tr) * V;
-        if (a.w && c < a.cols) n_unpack<T, V>(*(const uint4 *)((const T *)a.w + c), wv[p]);
+        okc[p] = c < a.cols;
+        wr[p] = (a.w && okc[p]) ? *(const uint4 *)((const T *)a.w + c) : uint4{0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < V; ++i) {
-            dw[p][i] = 0.f; db[p][i] = 0.f;
-            if (!(a.w && c < a.cols)) wv[p][i] = 1.f;
+            dw[p][i] = 0.f;
+            if constexpr (!RMS) db[p][i] = 0.f;
         }
     }
+    const bool has_w = a.w != nullptr;
     const float inv_n = 1.0f / (float)a.cols;
     const int64_t nrb = (a.rows + RPB - 1) / RPB; // row groups
-    for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x) {
+    constexpr int NS = PF + 1;
+    uint4 xq[NS][PACKS], dq[NS][PACKS]; // slot 0: the row being worked on; slots 1..PF: the rows after it
+    auto fetch = [&](int64_t rb, uint4 (&xo)[PACKS], uint4 (&dO)[PACKS]) __attribute__((always_inline)) {
         const int64_t row = rb * RPB + sub;
-        const bool live = row < a.rows;
-        const int64_t rr = live ? row : 0;
-        const T *x = (const T *)a.x + rr * a.ldx, *dy = (const T *)a.dy + rr * a.ldx;
-        const float rstd = live ? a.rstd[rr] : 0.f;
-        float mean = 0.f;
-        if constexpr (!RMS) mean = live ? a.mean[rr] : 0.f;
-        float xh[PACKS][V], g[PACKS][V];
-        float s1 = 0.f, s2 = 0.f;
+        const bool live = rb < nrb && row < a.rows;
+        const T *x = (const T *)a.x + (live ? row : 0) * a.ldx, *dy = (const T *)a.dy + (live ? row : 0) * a.ldx;
 #pragma unroll
         for (int p = 0; p < PACKS; ++p) {
             const int64_t c = ((int64_t)p * TPR + tr) * V;
-            if (live && c < a.cols) {
-                float xv[V], dv[V];
-                n_unpack<T, V>(*(const uint4 *)(x + c), xv);
-                n_unpack<T, V>(*(const uint4 *)(dy + c), dv);
+            if (live && okc[p]) { xo[p] = *(const uint4 *)(x + c); dO[p] = *(const uint4 *)(dy + c); }
+            else { xo[p] = uint4{0, 0, 0, 0}; dO[p] = uint4{0, 0, 0, 0}; }
+        }
+    };
 #pragma unroll
-                for (int i = 0; i < V; ++i) {
-                    xh[p][i] = RMS ? xv[i] * rstd : (xv[i] - mean) * rstd;
-                    g[p][i] = dv[i] * wv[p][i];
-                    if constexpr (!RMS) s1 += g[p][i];
-                    s2 += g[p][i] * xh[p][i];
-                    dw[p][i] += dv[i] * xh[p][i];
-                    if constexpr (!RMS) db[p][i] += dv[i];
-                }
-            } else {
+    for (int k = 0; k < PF; ++k) fetch((int64_t)blockIdx.x + (int64_t)k * gridDim.x, xq[k], dq[k]);
+    int parity = 0;
+    for (int64_t rb = blockIdx.x; rb < nrb; rb += gridDim.x, parity ^= 1) {
+        fetch(rb + (int64_t)PF * gridDim.x, xq[PF], dq[PF]); // PF row groups ahead (PF = 0: this one)
+        const int64_t row = rb * RPB + sub;
+        const bool live = row < a.rows;
+        const int64_t rr = live ? row : 0;
+        const float rstd = live ? a.rstd[rr] : 0.f;
+        float mean = 0.f;
+        if constexpr (!RMS) mean = live ? a.mean[rr] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int i = 0; i < V; ++i) { xh[p][i] = 0.f; g[p][i] = 0.f; }
+        for (int p = 0; p < PACKS; ++p) {
+            float xv[V], dv[V], wv[V];
+            n_unpack<T, V>(xq[0][p], xv);
+            n_unpack<T, V>(dq[0][p], dv);
+            if (has_w) n_unpack<T, V>(wr[p], wv);
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                const float xh = RMS ? xv[i] * rstd : (xv[i] - mean) * rstd;
+                const float g = has_w ? dv[i] * wv[i] : dv[i];
+                if constexpr (!RMS) s1 += g;
+                s2 += g * xh;
+                dw[p][i] += dv[i] * xh; // (zero packs of dead rows / columns add zero)
+                if constexpr (!RMS) db[p][i] += dv[i];
             }
         }
-        s2 = n_row_sum<TPR>(s2, red) * inv_n;
-        if constexpr (!RMS) s1 = n_row_sum<TPR>(s1, red) * inv_n;
+        n_row_sum2<TPR>(s1, s2, red, parity);
+        s1 *= inv_n;
+        s2 *= inv_n;
+        // the packs are unpacked AGAIN for the store (opaque to the optimiser, which would otherwise keep the first pass's f32 images
+        // alive across the row sums)
+#pragma unroll
+        for (int p = 0; p < PACKS; ++p)
+            asm volatile("" : "+v"(xq[0][p].x), "+v"(xq[0][p].y), "+v"(xq[0][p].z), "+v"(xq[0][p].w), "+v"(dq[0][p].x), "+v"(dq[0][p].y), "+v"(dq[0][p].z),
+                         "+v"(dq[0][p].w));
         if (live) {
             T *dx = (T *)a.dx + row * a.ldx;
 #pragma unroll
             for (int p = 0; p < PACKS; ++p) {
                 const int64_t c = ((int64_t)p * TPR + tr) * V;
-                if (c < a.cols) {
-                    float o[V];
+                if (okc[p]) {
+                    float xv[V], dv[V], wv[V], o[V];
+                    n_unpack<T, V>(xq[0][p], xv);
+                    n_unpack<T, V>(dq[0][p], dv);
+                    if (has_w) n_unpack<T, V>(wr[p], wv);
 #pragma unroll
-                    for (int i = 0; i < V; ++i) o[i] = RMS ? rstd * (g[p][i] - xh[p][i] * s2) : rstd * (g[p][i] - s1 - xh[p][i] * s2);
+                    for (int i = 0; i < V; ++i) {
+                        const float xh = RMS ? xv[i] * rstd : (xv[i] - mean) * rstd;
+                        const float g = has_w ? dv[i] * wv[i] : dv[i];
+                        o[i] = RMS ? rstd * (g - xh * s2) : rstd * (g - s1 - xh * s2);
+                    }
                     *(uint4 *)(dx + c) = n_pack<T, V>(o);
                 }
             }
+        }
+        if constexpr (PF > 0) {
+#pragma unroll
+            for (int k = 0; k < PF; ++k)
+#pragma unroll
+                for (int p = 0; p < PACKS; ++p) { xq[k][p] = xq[k + 1][p]; dq[k][p] = dq[k + 1][p]; }
         }
     }
     if (!a.part) return;
@@ -232,7 +306,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const NormArgs a) {
             const int64_t c = ((int64_t)p * TPR + tr) * V;
             if (c < a.cols) {
 #pragma unroll
-                for (int i = 0; i < V; ++i) { part[c + i] = dw[p][i]; part[a.cols + c + i] = db[p][i]; }
+                for (int i = 0; i < V; ++i) { part[c + i] = dw[p][i]; part[a.cols + c + i] = RMS ? 0.f : db[RMS ? 0 : p][i]; }
             }
         }
     } else {
@@ -244,7 +318,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const NormArgs a) {
             for (int which = 0; which < 2; ++which) {
                 __syncthreads();
 #pragma unroll
-                for (int i = 0; i < V; ++i) slab[sub][tr * V + i] = which ? db[p][i] : dw[p][i];
+                for (int i = 0; i < V; ++i) slab[sub][tr * V + i] = which ? (RMS ? 0.f : db[RMS ? 0 : p][i]) : dw[p][i];
                 __syncthreads();
                 if (sub == 0 && c < a.cols) {
 #pragma unroll
@@ -377,27 +451,37 @@ __global__ __launch_bounds__(256) void norm_colsum_generic_kernel(const NormArgs
 }
 
 // the register-tile plan of a row: threads per row and packs per thread (0: generic kernel)
-// The backward keeps five register arrays of packs * V floats (dw, db, w, xhat, g): its tile stops at packs * V = 32
-// (8192-element rows with 256 threads); the forward keeps one (up to 128 floats: 32768-element 16-bit rows).
+// The forward keeps one register array of packs * V floats (up to 128: 32768-element 16-bit rows, 256 threads per row). The backward
+// keeps the packs of two rows (current + prefetched, x and dy) and the dw / db accumulators: at most two packs per lane, rows up to
+// 1024 threads x 2 packs (16384 16-bit elements, 8192 f32 ones).
 struct NormPlan { int tpr, packs; };
 static NormPlan norm_plan(int dtype, int64_t cols, int64_t ldx, const void *const *ptrs, int nptr, bool bwd) {
     const int es = dtype_size(dtype), V = 16 / es;
-    const int maxp = bwd ? 32 / V : 16;
     if (cols % V != 0 || ldx % V != 0) return {0, 0};
     for (int i = 0; i < nptr; ++i)
         if (ptrs[i] && (uintptr_t)ptrs[i] % 16 != 0) return {0, 0};
     const int64_t npk = cols / V;
+    if (bwd) {
+        const long forced = knob_int(KNOB_NORM_BWD_TPR, 0); // A/B switch: threads per row (64 | 256 | 512 | 1024)
+        for (int p = 1; p <= 4; p *= 2) // short rows: one wave per row (no barrier), up to 4 packs per lane
+            if (npk <= 64 * p && (forced == 0 || forced == 64)) return {64, p};
+        for (int p = 1; p <= 2; ++p) // longer ones: one pack per lane wherever 1024 threads reach (the fewest registers), two beyond
+            for (int t = 256; t <= 1024; t *= 2)
+                if (npk <= (int64_t)t * p && (forced == 0 || forced == t || (p == 2 && t == 1024))) return {t, p};
+        return {0, 0};
+    }
     if (npk <= 64 * 4) { // one wave per row, up to 4 packs per lane (4 KiB rows)
         for (int p = 1; p <= 4; p *= 2)
             if (npk <= 64 * p) return {64, p};
     }
-    for (int p = 2; p <= maxp; p *= 2)
+    for (int p = 2; p <= 16; p *= 2)
         if (npk <= 256 * (int64_t)p) return {256, p};
     return {0, 0};
 }
 constexpr int kNormMaxBlocks = 1024; // partial rows the backward's scratch is sized for
 static int norm_bwd_blocks(const NormPlan &pl, int64_t rows) { // upper bound (workspace sizing)
-    const int64_t nrb = (rows + (256 / pl.tpr) - 1) / (256 / pl.tpr);
+    const int rpb = pl.tpr < 256 ? 256 / pl.tpr : 1;
+    const int64_t nrb = (rows + rpb - 1) / rpb;
     return (int)std::min<int64_t>(nrb, kNormMaxBlocks);
 }
 // The backward is one persistent round: as many blocks as the chip holds at once for THIS instantiation (occupancy x CUs, at most
@@ -405,18 +489,19 @@ static int norm_bwd_blocks(const NormPlan &pl, int64_t rows) { // upper bound (w
 // let three blocks share a CU (768 resident): its last third ran at a third of the bandwidth (3.83 -> 3.48 TB/s).
 template <typename T, int TPR, int PACKS, bool RMS>
 static int norm_bwd_launch(NormArgs &a, hipStream_t st, int &nblk) {
+    constexpr int PF = TPR > 64 ? ((!RMS && sizeof(T) == 2 && TPR == 1024) ? 1 : 2) : 0; // (the 16-bit layer form at 1024 threads has 128 registers: one row ahead fits, two spill)
     static int resident = 0;
     if (resident == 0) {
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, norm_bwd_kernel<T, TPR, PACKS, RMS>, 256, 0) != hipSuccess || per_cu < 1) per_cu = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, norm_bwd_kernel<T, TPR, PACKS, RMS, PF>, TPR < 256 ? 256 : TPR, 0) != hipSuccess || per_cu < 1) per_cu = 1;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) prop.multiProcessorCount = 256;
         resident = std::min(kNormMaxBlocks, per_cu * prop.multiProcessorCount);
     }
-    constexpr int RPB = 256 / TPR;
+    constexpr int NT = TPR < 256 ? 256 : TPR, RPB = NT / TPR;
     const int64_t nrb = (a.rows + RPB - 1) / RPB;
     nblk = (int)std::min<int64_t>(nrb, resident);
-    norm_bwd_kernel<T, TPR, PACKS, RMS><<<(unsigned)nblk, 256, 0, st>>>(a);
+    norm_bwd_kernel<T, TPR, PACKS, RMS, PF><<<(unsigned)nblk, NT, 0, st>>>(a);
     return KF_OK;
 }
 
@@ -447,11 +532,12 @@ static int norm_check(const char *who, int kind, int dtype, int64_t rows, int64_
     case 6401: KERNEL<T, 64, 1, RMS_> __VA_ARGS__; break;                                        \
     case 6402: KERNEL<T, 64, 2, RMS_> __VA_ARGS__; break;                                        \
     case 6404: KERNEL<T, 64, 4, RMS_> __VA_ARGS__; break;                                        \
+    case 25601: KERNEL<T, 256, 1, RMS_> __VA_ARGS__; break;                                      \
     case 25602: KERNEL<T, 256, 2, RMS_> __VA_ARGS__; break;                                      \
-    case 25604: KERNEL<T, 256, 4, RMS_> __VA_ARGS__; break;                                      \
-    default:                                                                                     \
-        if constexpr (sizeof(T) == 4) { KERNEL<T, 256, 8, RMS_> __VA_ARGS__; }                   \
-        break;                                                                                   \
+    case 51201: KERNEL<T, 512, 1, RMS_> __VA_ARGS__; break;                                      \
+    case 51202: KERNEL<T, 512, 2, RMS_> __VA_ARGS__; break;                                      \
+    case 102401: KERNEL<T, 1024, 1, RMS_> __VA_ARGS__; break;                                    \
+    default: KERNEL<T, 1024, 2, RMS_> __VA_ARGS__; break;                                        \
     }
 
 extern "C" int kf_norm_fwd(int kind, int dtype, int64_t rows, int64_t cols, int64_t ld, const void *x, const void *weight, const void *bias,

@@ -80,6 +80,7 @@ struct RedArgs {
 // engine fixes the order, so results are reproducible), Ops::Fin is the projection + store.
 template <typename T>
 struct SumOps {
+    static constexpr bool kPackRows = false; // (sums keep one running sum per row group: the summation order tests and fixtures know)
     using X = typename RAcc<T>::type;
     using A = X;
     struct Fin {
@@ -103,6 +104,7 @@ template <> __device__ __forceinline__ float fast_rcp<float>(float v) { return _
 
 template <typename T>
 struct MomentOps {
+    static constexpr bool kPackRows = true; // reduce_outer_kernel folds four rows of a column as one pack
     using X = typename RAcc<T>::type; // float | double
     struct A { X mean, m2, n; };
     struct Fin {
@@ -245,13 +247,25 @@ __global__ __launch_bounds__(kRB) void reduce_outer_kernel(const RedArgs a, cons
                 RPack<T, VEC> p[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) p[u] = *(const RPack<T, VEC> *)(col + (r + 4 * u) * a.r_stride);
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
+                if constexpr (Ops::kPackRows) {
+                    // moments: the four rows of a column fold as ONE pack (Chan's pairwise update: one reciprocal and one dependent
+                    // mean / M2 step per four elements instead of per element - the column statistics ran at 4.8 TB/s against the
+                    // column sums' 5.5 on the per-element form)
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) {
-                        const X x[1] = {r_load<T>((const char *)&p[u].v[e])};
-                        Ops::template add_pack<1>(acc[u][e], x);
+                        const X x[4] = {r_load<T>((const char *)&p[0].v[e]), r_load<T>((const char *)&p[1].v[e]), r_load<T>((const char *)&p[2].v[e]),
+                                        r_load<T>((const char *)&p[3].v[e])};
+                        Ops::template add_pack<4>(acc[0][e], x);
                     }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int e = 0; e < VEC; ++e) {
+                            const X x[1] = {r_load<T>((const char *)&p[u].v[e])};
+                            Ops::template add_pack<1>(acc[u][e], x);
+                        }
+                }
             }
             for (; r < r1; r += 4) {
                 RPack<T, VEC> p0 = *(const RPack<T, VEC> *)(col + r * a.r_stride);

@@ -2,7 +2,7 @@
 
 kfunca_amd/_build/libkfunca_hip_mutant.so is attention.hip compiled with -DKF_MUTANT (kfunca_amd/_build.py: build_mutant; never part
 of libkfunca_hip.so): the production kernels plus four deliberate single-tile defects behind kfmut_select() (KF_MUT in attention.hip):
-  1  the forward's last 256-query block skips key tile 1          2  the last 32-query slice gives nothing to the first 128-key block
+  1  the forward's last 256-query block skips key tile 1          2  queries 128-159 give nothing to the first 128-key block
   3  the stored-dS dQ kernel's last block skips key step 0        4  the recomputing dQ kernel's last block skips key step 0
 With the selector at 0 the mutant library must PASS the same scale-aware bounds as the product (and agree with it bit for bit);
 with a defect switched on the bounds must FAIL on exactly the outputs that defect reaches - at config C3's own sequence length,
