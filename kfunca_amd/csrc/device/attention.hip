@@ -284,6 +284,10 @@ __device__ __forceinline__ typename AFrag<BF>::type tr4_frag(const TrN<DB> &t, i
 // 1 KiB (4 rows), two of each per wave; the tile image's XOR swizzle goes on the per-lane SOURCE chunk.
 // Head size 64 keeps the 256-byte row pitch of the image (every offset below stays what it is); its rows hold 8 chunks, so the
 // lanes whose source chunk is 8..15 sit the instruction out (an LDS-DMA lane writes at base + 16 lane whatever the others do).
+// (Round 3, tried and dropped: the BUFFER form - buffer_load_dwordx4 ... offen lds with a per-tile scalar descriptor and a loop-invariant
+// 32-bit lane offset instead of a 64-bit address per lane: the forward ran 1.58-1.61 ms against 1.53-1.56 on the same box. The ~108
+// cycles an LDS-DMA instruction holds a wave's issue here are not address arithmetic: all eight waves issue their four pieces right
+// behind the tile barrier, 32 KiB in one burst through a 64 B / clock vector-memory path.)
 template <int D>
 __device__ __forceinline__ void f_stage(const char *kg, const char *vg, char *buf, int64_t krs, int64_t vrs) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
