@@ -1046,26 +1046,52 @@ __device__ __forceinline__ void gemm_w4_body(const GemmArgs &g, const uint32_t b
         if constexpr (BF) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(b), "v"(a));
         else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(b), "v"(a));
     };
-    // read number r (0..15) of a k-step: A tiles 0..7, then B tiles 0..7
-#define W4_READ1(SET, KS, BUFU, R)                                                                             \
+    // read number r (0..15) of a k-step: A tiles 0..7, then B tiles 0..7, in two halves that go behind DIFFERENT MFMAs of a group.
+    // A K-contiguous operand's fragment is one ds_read_b128 (first half; the second is empty). A transposed-read operand's is two
+    // ds_read_b64_tr_b16, one per half, off ONE address per PAIR of tiles: tile t sits at byte (t >> 1) << 6 XORed into the lane's
+    // chunk swizzle (four per-lane bases xbA / xbB, set up once) plus the immediate (t & 1) * 32, so the loop's only address
+    // arithmetic is base + buffer. (Both operands transposed - the TN product dW = A^T dC - used to spend 56 v_add_u32 and both
+    // reads of a fragment in the single gap behind a group's first MFMA; a lone wave fits about two instructions into a 16-cycle
+    // MFMA: TN ran 8 % behind NT.)
+    unsigned xbA[4], xbB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        xbA[j] = (unsigned)((lbT ^ (j << 6)) + pbT) + (2 * wr) * G_HALF;
+        xbB[j] = (unsigned)((lbT ^ (j << 6)) + pbT) + (2 * wc + 1) * G_HALF;
+    }
+    g_s16x4 trlo, trhi;
+    auto trd = [&](g_s16x4 &dst, unsigned addr, auto off) __attribute__((always_inline)) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%c2" : "=v"(dst) : "v"(addr), "n"(decltype(off)::value) : "memory");
+    };
+    auto trjoin = [&]() __attribute__((always_inline)) {
+        g_s16x8 r;
+        r[0] = trlo[0]; r[1] = trlo[1]; r[2] = trlo[2]; r[3] = trlo[3];
+        r[4] = trhi[0]; r[5] = trhi[1]; r[6] = trhi[2]; r[7] = trhi[3];
+        return __builtin_bit_cast(frag_t, r);
+    };
+#define W4_READ_A(SET, KS, BUFU, R)                                                                            \
     {                                                                                                          \
         constexpr int t = (R) & 7;                                                                             \
+        constexpr int toff = ((KS) == 0 ? 0 : 8192 + 128) + (t & 1) * 32;                                      \
         if constexpr ((R) < 8) {                                                                               \
-            if constexpr (TRA) {                                                                               \
-                const unsigned x = (unsigned)((lbT ^ (t * 32)) + pbT) + (BUFU) + (2 * wr) * G_HALF;            \
-                if constexpr ((KS) == 0) fa[SET][t] = g_tr_frag<BF, 0>(x); else fa[SET][t] = g_tr_frag<BF, 8192 + 128>(x); \
-            } else {                                                                                           \
-                rd(fa[SET][t], (BUFU) + (2 * wr) * G_HALF + offk[KS], std::integral_constant<int, t * 2048>{}); \
-            }                                                                                                  \
+            if constexpr (TRA) trd(trlo, xbA[t >> 1] + (BUFU), std::integral_constant<int, toff>{});           \
+            else rd(fa[SET][t], (BUFU) + (2 * wr) * G_HALF + offk[KS], std::integral_constant<int, t * 2048>{}); \
         } else {                                                                                               \
-            if constexpr (TRB) {                                                                               \
-                const unsigned x = (unsigned)((lbT ^ (t * 32)) + pbT) + (BUFU) + (2 * wc + 1) * G_HALF;        \
-                if constexpr ((KS) == 0) fb[SET][t] = g_tr_frag<BF, 0>(x); else fb[SET][t] = g_tr_frag<BF, 8192 + 128>(x); \
-            } else {                                                                                           \
-                rd(fb[SET][t], (BUFU) + (2 * wc + 1) * G_HALF + offk[KS], std::integral_constant<int, t * 2048>{}); \
-            }                                                                                                  \
+            if constexpr (TRB) trd(trlo, xbB[t >> 1] + (BUFU), std::integral_constant<int, toff>{});           \
+            else rd(fb[SET][t], (BUFU) + (2 * wc + 1) * G_HALF + offk[KS], std::integral_constant<int, t * 2048>{}); \
         }                                                                                                      \
     }
+#define W4_READ_B(SET, KS, BUFU, R)                                                                            \
+    {                                                                                                          \
+        constexpr int t = (R) & 7;                                                                             \
+        constexpr int toff = ((KS) == 0 ? 0 : 8192 + 128) + (t & 1) * 32 + 1024;                               \
+        if constexpr ((R) < 8) {                                                                               \
+            if constexpr (TRA) { trd(trhi, xbA[t >> 1] + (BUFU), std::integral_constant<int, toff>{}); fa[SET][t] = trjoin(); } \
+        } else {                                                                                               \
+            if constexpr (TRB) { trd(trhi, xbB[t >> 1] + (BUFU), std::integral_constant<int, toff>{}); fb[SET][t] = trjoin(); } \
+        }                                                                                                      \
+    }
+#define W4_READ1(SET, KS, BUFU, R) W4_READ_A(SET, KS, BUFU, R) W4_READ_B(SET, KS, BUFU, R)
     // one k-step: 64 MFMAs on fragment set SET; after every fourth one, read R of the next fragment set and (DMA) one
     // LDS-DMA operation of tile kt + 2
 #define W4_STEP(SET, NKS, NBUFU, DMA)                                                                          \
@@ -1078,10 +1104,11 @@ __device__ __forceinline__ void gemm_w4_body(const GemmArgs &g, const uint32_t b
         constexpr int n = (G) >> 1, mb = ((G) & 1) * 4;                                                        \
         mm(acc[n][mb + 0], fb[SET][n], fa[SET][mb + 0]);                                                       \
         if constexpr (DMA && (G) < W4_DMA_GROUPS) stage_op((G) * (16 / W4_DMA_GROUPS) / 4, (G) * (16 / W4_DMA_GROUPS) % 4, kt + 2); \
-        W4_READ1(1 - (SET), NKS, NBUFU, G)                                                                     \
         mm(acc[n][mb + 1], fb[SET][n], fa[SET][mb + 1]);                                                       \
         if constexpr (DMA && (G) < W4_DMA_GROUPS && W4_DMA_GROUPS <= 8) stage_op(((G) * (16 / W4_DMA_GROUPS) + 1) / 4, ((G) * (16 / W4_DMA_GROUPS) + 1) % 4, kt + 2); \
+        W4_READ_A(1 - (SET), NKS, NBUFU, G)                                                                    \
         mm(acc[n][mb + 2], fb[SET][n], fa[SET][mb + 2]);                                                       \
+        W4_READ_B(1 - (SET), NKS, NBUFU, G)                                                                    \
         if constexpr (DMA && (G) < W4_DMA_GROUPS && W4_DMA_GROUPS <= 4) stage_op(((G) * 4 + 2) / 4, ((G) * 4 + 2) % 4, kt + 2); \
         mm(acc[n][mb + 3], fb[SET][n], fa[SET][mb + 3]);                                                       \
         if constexpr (DMA && (G) < W4_DMA_GROUPS && W4_DMA_GROUPS <= 4) stage_op(((G) * 4 + 3) / 4, ((G) * 4 + 3) % 4, kt + 2); \
@@ -1115,6 +1142,8 @@ __device__ __forceinline__ void gemm_w4_body(const GemmArgs &g, const uint32_t b
 #undef W4_STEP
 #undef W4_GROUP
 #undef W4_READ1
+#undef W4_READ_A
+#undef W4_READ_B
     if constexpr (DIAG) {
         const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         if (threadIdx.x == 0) {
@@ -1226,6 +1255,12 @@ static bool h256_ok(int64_t M, int64_t N, int64_t K) {
 // AND the contraction is long enough to pay for the f32 partial round trip (at least 8 K tiles of 64 per slice). Slices = the largest
 // power of two that keeps tiles x slices within two rounds. A skinny product (M = 256, N = 4096, K = 16384: 64 tiles x 256 K tiles)
 // goes from 64 busy CUs to 512 workgroups.
+// (Round 3, tried and dropped - tools/scratch/gemm_splitk_reduce_scatter_experiment.patch: 2048^3 as 64 tiles of 256^2 x 4 K slices in the
+// 4-wave kernel, the slices of a tile finishing it by a reduce-scatter through the workspace inside the launch (flags, no fold kernel).
+// Correct, and 67 us against this path's 33: the bare 8-K-tile loop + prologue + a quarter epilogue is already 20 us, the 48 MB of f32
+// pieces cost 19 us to write and 14 us to read back (2.5-3.4 TB/s: they do not stay in the 8 x 4 MiB of L2), and the agent-scope
+// release / acquire another 12 us (L2 write-back + invalidate on every workgroup). A 128^2 tile per CU is LDS-bound instead: 512 B of
+// LDS-DMA writes + 1024 B of fragment reads per unit of k against 8 MFMA cycles = 12 cycles per k, a ceiling of 0.67 of peak.)
 static int splitk_slices(int dtype, int64_t M, int64_t N, int64_t K) {
     if (!(dtype == KF_BF16 || dtype == KF_F16) || !h_fast_ok(M, N, K) || h256_ok(M, N, K) || knob(KNOB_GEMM_NO_SPLITK)) return 1;
     const int64_t tiles = (M / H_BM) * (N / H_BN), nt = K / H_BK;

@@ -33,15 +33,33 @@ def timed(fn, rounds):
     return sum(v[0] for v in res.values()) / rounds, sorted(res)
 
 
+def timed_b2b(fn, n):
+    """n launches behind each other between ONE event pair: what a caller that queues work sees (launch latency hidden behind the
+    previous kernel, the clock settled) - the per-launch event times above carry ~10 us of dispatch gap each."""
+    fn()
+    H.device_sync()
+    e0, e1 = H.Event(), H.Event()
+    e0.record(None)
+    for _ in range(n):
+        fn()
+    e1.record(None)
+    H.device_sync()
+    return e0.elapsed_ms(e1) / n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=10)
+    ap.add_argument("--b2b", type=int, default=50, help="launches per back-to-back measurement (0 = skip)")
+    ap.add_argument("--sizes", default="1024,2048,4096,8192")
+    ap.add_argument("--no-f32", action="store_true")
     ap.add_argument("--json", default="")
     args = ap.parse_args()
     H.set_device(0)
     rng = np.random.default_rng(1004)  # seed = 1000 + config number (C4)
     out = {}
-    for dt, code, sizes in (("bf16", H.BF16, (1024, 2048, 4096, 8192)), ("f32", H.F32, (1024, 2048, 4096))):
+    bsizes = tuple(int(x) for x in args.sizes.split(","))
+    for dt, code, sizes in (("bf16", H.BF16, bsizes), ("f32", H.F32, () if args.no_f32 else tuple(x for x in bsizes if x <= 4096))):
         for n in sizes:
             mk = (lambda: bf16(rng, (n, n))) if code == H.BF16 else (lambda: rng.uniform(-1, 1, size=(n, n)).astype(np.float32))
             A, B, G = (H.DevBuf.from_numpy(mk()) for _ in range(3))
@@ -62,9 +80,17 @@ def main():
                 ms, kernels = timed(fn, rounds)
                 tf = 2.0 * n ** 3 / (ms * 1e-3) / 1e12
                 out[f"{dt} {n}^3 {tag}"] = {"ms": ms, "TFLOP/s": tf, "frac_of_mfma_peak": tf / PEAK[dt], "kernels": kernels}
-                print(f"{dt} {n:5d}^3 {tag:48s} {ms:9.4f} ms {tf:8.1f} TF/s  {tf / PEAK[dt] * 100:5.1f}% of {PEAK[dt]:.0f}  {kernels}", flush=True)
+                b2b = ""
+                if args.b2b:
+                    mb = timed_b2b(fn, args.b2b if n <= 4096 else max(5, args.b2b // 5))
+                    out[f"{dt} {n}^3 {tag}"].update({"ms_back_to_back": mb, "TFLOP/s_back_to_back": 2.0 * n ** 3 / (mb * 1e-3) / 1e12})
+                    b2b = f"| back to back {mb:9.4f} ms {2.0 * n ** 3 / (mb * 1e-3) / 1e12:8.1f} TF/s"
+                print(f"{dt} {n:5d}^3 {tag:48s} {ms:9.4f} ms {tf:8.1f} TF/s  {tf / PEAK[dt] * 100:5.1f}% of {PEAK[dt]:.0f} {b2b} {kernels}", flush=True)
             fb = sum(out[f"{dt} {n}^3 {t}"]["ms"] for t in ("NN fwd", "NT dA", "TN dB"))
             out[f"{dt} {n}^3 fwd+bwd"] = {"ms": fb, "TFLOP/s": 6.0 * n ** 3 / (fb * 1e-3) / 1e12, "frac_of_mfma_peak": 6.0 * n ** 3 / (fb * 1e-3) / 1e12 / PEAK[dt]}
+            if args.b2b:
+                fbb = sum(out[f"{dt} {n}^3 {t}"]["ms_back_to_back"] for t in ("NN fwd", "NT dA", "TN dB"))
+                out[f"{dt} {n}^3 fwd+bwd"].update({"ms_back_to_back": fbb, "TFLOP/s_back_to_back": 6.0 * n ** 3 / (fbb * 1e-3) / 1e12})
             print(f"{dt} {n:5d}^3 fwd+bwd {fb:9.4f} ms {out[f'{dt} {n}^3 fwd+bwd']['TFLOP/s']:8.1f} TF/s", flush=True)
     if args.json:
         Path(args.json).write_text(json.dumps(out, indent=1))
