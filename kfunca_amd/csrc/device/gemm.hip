@@ -68,6 +68,14 @@ __device__ __forceinline__ void grouped_tile(uint32_t id, uint32_t tiles_m, uint
 // ------------------------------------------------------------------------------------------
 // generic fallback: any shape, any layout, f32/f64/bf16/f16; 32x32 tile, 256 threads (2x2 per lane)
 // ------------------------------------------------------------------------------------------
+// two f32 -> one word of two 16-bit values, round-to-nearest-even: bf16 with the hardware's packed converter (one instruction; the
+// software form is ~10 per value, and the 4-wave kernel's epilogue converts 256 values per lane - 5 us of a 105 us launch at 4096^3)
+template <bool BF>
+__device__ __forceinline__ uint32_t g_pack2(float lo, float hi) {
+    if constexpr (BF) return f32x2_to_bf16x2_hw(lo, hi);
+    else return (uint32_t)f32_to_f16(lo).x | ((uint32_t)f32_to_f16(hi).x << 16);
+}
+
 template <typename T> struct GAcc { using type = float; };
 template <> struct GAcc<double> { using type = double; };
 template <typename T> __device__ __forceinline__ typename GAcc<T>::type g_load(const T *p) { return (typename GAcc<T>::type)(*p); }
@@ -110,9 +118,7 @@ __device__ __forceinline__ void h_st8(void *base, int64_t ld, int64_t row, int64
     uint32_t w[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const uint16_t h0 = BF ? f32_to_bf16(f[2 * e]).x : f32_to_f16(f[2 * e]).x;
-        const uint16_t h1 = BF ? f32_to_bf16(f[2 * e + 1]).x : f32_to_f16(f[2 * e + 1]).x;
-        w[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        w[e] = g_pack2<BF>(f[2 * e], f[2 * e + 1]);
     }
     if (ld % 8 == 0 && (uintptr_t)base % 16 == 0) {
         *(uint4 *)p = uint4{w[0], w[1], w[2], w[3]};
@@ -932,9 +938,7 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_h256_kernel(const GemmArgs g) {
             uint32_t w[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const uint16_t h0 = BF ? f32_to_bf16(v[2 * e]).x : f32_to_f16(v[2 * e]).x;
-                const uint16_t h1 = BF ? f32_to_bf16(v[2 * e + 1]).x : f32_to_f16(v[2 * e + 1]).x;
-                w[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                w[e] = g_pack2<BF>(v[2 * e], v[2 * e + 1]);
             }
             if (wide) {
                 *(uint4 *)dst = uint4{w[0], w[1], w[2], w[3]};
@@ -1121,6 +1125,12 @@ __device__ __forceinline__ void gemm_w4_body(const GemmArgs &g, const uint32_t b
         for (int which = 0; which < 4; ++which)
 #pragma unroll
             for (int i = 0; i < 4; ++i) stage_op(which, i, kt);
+    // the 256 accumulator registers are zeroed HERE, under the first tiles' flight (left alone the compiler sinks the ~500 writes
+    // behind the barrier: 1 us between the data landing and the first MFMA)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(acc[i][j]));
     asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
 #define W4_R(R) W4_READ1(0, 0, smem_u, R)
     W4_R(0) W4_R(1) W4_R(2) W4_R(3) W4_R(4) W4_R(5) W4_R(6) W4_R(7) W4_R(8) W4_R(9) W4_R(10) W4_R(11) W4_R(12) W4_R(13) W4_R(14) W4_R(15)
@@ -1205,9 +1215,7 @@ __device__ __forceinline__ void gemm_w4_body(const GemmArgs &g, const uint32_t b
             uint32_t w[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const uint16_t h0 = BF ? f32_to_bf16(v[2 * e]).x : f32_to_f16(v[2 * e]).x;
-                const uint16_t h1 = BF ? f32_to_bf16(v[2 * e + 1]).x : f32_to_f16(v[2 * e + 1]).x;
-                w[e] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+                w[e] = g_pack2<BF>(v[2 * e], v[2 * e + 1]);
             }
             if (wide) {
                 *(uint4 *)dst = uint4{w[0], w[1], w[2], w[3]};
