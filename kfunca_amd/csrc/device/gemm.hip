@@ -434,6 +434,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(const GemmArgs g) {
 // ------------------------------------------------------------------------------------------
 constexpr int H_BM = 128, H_BN = 128, H_BK = 64;
 constexpr int H_TILE_BYTES = H_BM * H_BK * 2; // 16 KiB per operand tile
+constexpr int H_STAGES = 4;                   // ring of [A tile | B tile] buffers: 128 KiB
 
 template <bool BF> struct HFrag { using type = f16x8; };
 template <> struct HFrag<true> { using type = bf16x8; };
@@ -511,7 +512,7 @@ __device__ __forceinline__ typename HFrag<BF>::type h_tr_frag(unsigned a0, unsig
 template <bool BF, bool TRA, bool TRB>
 __global__ __launch_bounds__(256) void gemm_h_kernel(const GemmArgs g) {
     using frag_t = typename HFrag<BF>::type;
-    extern __shared__ __attribute__((aligned(16))) char smem[]; // [2 buffers][A tile | B tile]
+    extern __shared__ __attribute__((aligned(16))) char smem[]; // [H_STAGES buffers][A tile | B tile]
     const char *A = (const char *)g.A, *B = (const char *)g.B;
     const uint32_t tiles_n = (uint32_t)(g.N / H_BN);
     const uint32_t id = xcd_remap(blockIdx.x, gridDim.x);
@@ -545,32 +546,59 @@ __global__ __launch_bounds__(256) void gemm_h_kernel(const GemmArgs g) {
     const int ntk = (int)(g.K / H_BK);
     const int tk0 = g.split > 1 ? (int)((int64_t)slice * ntk / g.split) : 0;          // this block's K tiles: [tk0, tk0 + nt)
     const int nt = (g.split > 1 ? (int)((int64_t)(slice + 1) * ntk / g.split) : ntk) - tk0;
-    stage_tile(tk0, smem);
-    __syncthreads(); // emits s_waitcnt vmcnt(0) for the LDS-DMA in flight, then s_barrier
-
-    for (int t = 0; t < nt; ++t) {
-        char *cur = smem + (t & 1) * 2 * H_TILE_BYTES;
-        char *nxt = smem + ((t + 1) & 1) * 2 * H_TILE_BYTES;
-        const unsigned cur_u = smem_u + (unsigned)((t & 1) * 2 * H_TILE_BYTES);
-        if (t + 1 < nt) stage_tile(tk0 + t + 1, nxt);
-#define KF_H_STEP(KS)                                                                                                  \
-        {                                                                                                              \
-            frag_t a[2], b[2];                                                                                         \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                            \
-                if constexpr (TRA) a[i] = h_tr_frag<BF, (KS) * 16 * 256>(cur_u + toffA[i][0], cur_u + toffA[i][1]);     \
-                else a[i] = *(const frag_t *)(cur + h_lds_off(wr * 64 + i * 32 + xl, (KS) * 2 + hl));                  \
-                if constexpr (TRB) b[i] = h_tr_frag<BF, (KS) * 16 * 256>(cur_u + H_TILE_BYTES + toffB[i][0], cur_u + H_TILE_BYTES + toffB[i][1]); \
-                else b[i] = *(const frag_t *)(cur + H_TILE_BYTES + h_lds_off(wc * 64 + i * 32 + xl, (KS) * 2 + hl));   \
-            }                                                                                                          \
-            if constexpr (TRA || TRB) /* the asm-issued reads are invisible to the compiler's wait insertion */        \
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : : "memory");     \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                              \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j) acc[i][j] = h_mfma<BF>(a[i], b[j], acc[i][j]);           \
+    // A ring of H_STAGES tile buffers, three tiles in flight: one tile is 16 MFMAs of 32 cycles per wave - a quarter of a microsecond,
+    // far less than an L2 / HBM round trip, and with the tile t + 1 requested only at the top of iteration t every iteration sat out most
+    // of that latency (0.72 us per K tile at 2048^3, twice the kernel's LDS bound). A wave issues 8 LDS-DMA operations per tile, so
+    // s_waitcnt vmcnt(16) = "everything but the two youngest tiles has landed"; past the end the last tile is fetched again (never
+    // read), which keeps that count constant. Every LDS read is inline asm: the compiler would put a vmcnt(0) in front of a read it
+    // can see (it cannot tell the ring slots apart). Measured at 2048^3: 34.2 -> 31.7 us (500 -> 540 TFLOP/s). What is left is the
+    // operand stream itself: 32 KiB per K tile per CU at 0.65 us = 49 GB/s per CU, 12.6 TB/s over the chip, against the 66-73 GB/s per CU
+    // the guide measures as the most LDS-DMA delivers from L2 (MI355X_MICROARCH.md, indexed rows) - a 128^2 tile per CU is bound by its
+    // 64 FLOP per staged byte at about 750 TFLOP/s, which is why the large shapes take 256^2 tiles.
+    auto clampt = [&](int t) { return tk0 + (t < nt ? t : nt - 1); };
+#pragma unroll
+    for (int t = 0; t < H_STAGES - 1; ++t) stage_tile(clampt(t), smem + t * 2 * H_TILE_BYTES);
+    const int offA[2] = {h_lds_off(wr * 64 + xl, hl), h_lds_off(wr * 64 + 32 + xl, hl)};      // K-contiguous operands: k-step ks flips chunk bits
+    const int offB[2] = {h_lds_off(wc * 64 + xl, hl), h_lds_off(wc * 64 + 32 + xl, hl)};      // (ks * 2 + hl) ^ sw = (hl ^ sw) ^ (ks * 2): XOR 32 * ks
+    auto rd = [&](frag_t &dst, unsigned addr) __attribute__((always_inline)) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory"); };
+    auto read_step = [&](auto ks_c, unsigned cur_u, frag_t (&a)[2], frag_t (&b)[2]) __attribute__((always_inline)) {
+        constexpr int KS = decltype(ks_c)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            if constexpr (TRA) a[i] = h_tr_frag<BF, KS * 16 * 256>(cur_u + toffA[i][0], cur_u + toffA[i][1]);
+            else rd(a[i], cur_u + (unsigned)(offA[i] ^ (KS * 32)));
+            if constexpr (TRB) b[i] = h_tr_frag<BF, KS * 16 * 256>(cur_u + H_TILE_BYTES + toffB[i][0], cur_u + H_TILE_BYTES + toffB[i][1]);
+            else rd(b[i], cur_u + H_TILE_BYTES + (unsigned)(offB[i] ^ (KS * 32)));
         }
-        KF_H_STEP(0) KF_H_STEP(1) KF_H_STEP(2) KF_H_STEP(3)
-#undef KF_H_STEP
-        __syncthreads();
+    };
+    auto landed = [&](frag_t (&a)[2], frag_t (&b)[2]) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[0]), "+v"(a[1]), "+v"(b[0]), "+v"(b[1]) : : "memory");
+    };
+    auto mma = [&](frag_t (&a)[2], frag_t (&b)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = h_mfma<BF>(a[i], b[j], acc[i][j]);
+    };
+    frag_t fa[2][2], fb[2][2]; // two fragment sets: k-step ks + 1 is read under the MFMAs of k-step ks
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory"); // tile t has landed for everyone; everyone is done reading tile t - 1
+        stage_tile(clampt(t + H_STAGES - 1), smem + ((t + H_STAGES - 1) % H_STAGES) * 2 * H_TILE_BYTES);
+        const unsigned cur_u = smem_u + (unsigned)((t % H_STAGES) * 2 * H_TILE_BYTES);
+        read_step(std::integral_constant<int, 0>{}, cur_u, fa[0], fb[0]);
+        landed(fa[0], fb[0]);
+        read_step(std::integral_constant<int, 1>{}, cur_u, fa[1], fb[1]);
+        mma(fa[0], fb[0]);
+        landed(fa[1], fb[1]);
+        read_step(std::integral_constant<int, 2>{}, cur_u, fa[0], fb[0]);
+        mma(fa[1], fb[1]);
+        landed(fa[0], fb[0]);
+        read_step(std::integral_constant<int, 3>{}, cur_u, fa[1], fb[1]);
+        mma(fa[0], fb[0]);
+        landed(fa[1], fb[1]);
+        mma(fa[1], fb[1]);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the re-fetched tail tiles: nothing may still be writing LDS when the workgroup retires
 
     if (g.split > 1) { // the raw partial tile; alpha, beta, bias and the tail belong to the fold
         float *P = g.part + (int64_t)slice * g.M * g.N;
@@ -608,7 +636,7 @@ __global__ __launch_bounds__(256) void gemm_h_kernel(const GemmArgs g) {
                 }
                 v += bias;
                 if (BF) v = g_epi<bf16_t>(g, m, n, v); else v = g_epi<f16_t>(g, m, n, v);
-                C[m * g.ldc + n] = BF ? f32_to_bf16(v).x : f32_to_f16(v).x;
+                C[m * g.ldc + n] = (uint16_t)g_pack2<BF>(v, 0.f);
             }
         }
 }
@@ -635,7 +663,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_fold_kernel(const GemmArgs g)
             t += BF ? bf16_to_f32(bf16_t{bb}) : f16_to_f32(f16_t{bb});
         }
         if (BF) t = g_epi<bf16_t>(g, m, n + e, t); else t = g_epi<f16_t>(g, m, n + e, t);
-        C[e] = BF ? f32_to_bf16(t).x : f32_to_f16(t).x;
+        C[e] = (uint16_t)g_pack2<BF>(t, 0.f);
     }
 }
 
@@ -1456,7 +1484,7 @@ static int gemm_impl(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, 
             return dtype == KF_BF16 ? launch_h256<true>(g, trans_a != 0, !trans_b, w4, st) : launch_h256<false>(g, trans_a != 0, !trans_b, w4, st);
         }
         unsigned grid = (unsigned)((M / H_BM) * (N / H_BN));
-        const size_t lds = 4 * H_TILE_BYTES;
+        const size_t lds = (size_t)H_STAGES * 2 * H_TILE_BYTES;
         const int slices = splitk_slices(dtype, M, N, K);
         const bool split = slices > 1 && workspace && workspace_bytes >= (size_t)slices * M * N * sizeof(float) && (uintptr_t)workspace % 16 == 0 &&
                            N % 4 == 0;
