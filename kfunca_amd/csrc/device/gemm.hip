@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256) void gemm_h_kernel(const GemmArgs g) {
     const int ntk = (int)(g.K / H_BK);
     const int tk0 = g.split > 1 ? (int)((int64_t)slice * ntk / g.split) : 0;          // this block's K tiles: [tk0, tk0 + nt)
     const int nt = (g.split > 1 ? (int)((int64_t)(slice + 1) * ntk / g.split) : ntk) - tk0;
-    // A ring of H_STAGES tile buffers, three tiles in flight: one tile is 16 MFMAs of 32 cycles per wave - a quarter of a microsecond,
+    // A ring of H_STAGES tile buffers, three to four tiles in flight: one tile is 16 MFMAs of 32 cycles per wave - a quarter of a microsecond,
     // far less than an L2 / HBM round trip, and with the tile t + 1 requested only at the top of iteration t every iteration sat out most
     // of that latency (0.72 us per K tile at 2048^3, twice the kernel's LDS bound). A wave issues 8 LDS-DMA operations per tile, so
     // s_waitcnt vmcnt(16) = "everything but the two youngest tiles has landed"; past the end the last tile is fetched again (never
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void gemm_h_kernel(const GemmArgs g) {
     // 64 FLOP per staged byte at about 750 TFLOP/s, which is why the large shapes take 256^2 tiles.
     auto clampt = [&](int t) { return tk0 + (t < nt ? t : nt - 1); };
 #pragma unroll
-    for (int t = 0; t < H_STAGES - 1; ++t) stage_tile(clampt(t), smem + t * 2 * H_TILE_BYTES);
+    for (int t = 0; t < H_STAGES; ++t) stage_tile(clampt(t), smem + t * 2 * H_TILE_BYTES);
     const int offA[2] = {h_lds_off(wr * 64 + xl, hl), h_lds_off(wr * 64 + 32 + xl, hl)};      // K-contiguous operands: k-step ks flips chunk bits
     const int offB[2] = {h_lds_off(wc * 64 + xl, hl), h_lds_off(wc * 64 + 32 + xl, hl)};      // (ks * 2 + hl) ^ sw = (hl ^ sw) ^ (ks * 2): XOR 32 * ks
     auto rd = [&](frag_t &dst, unsigned addr) __attribute__((always_inline)) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr) : "memory"); };
@@ -581,12 +581,14 @@ __global__ __launch_bounds__(256) void gemm_h_kernel(const GemmArgs g) {
             for (int j = 0; j < 2; ++j) acc[i][j] = h_mfma<BF>(a[i], b[j], acc[i][j]);
     };
     frag_t fa[2][2], fb[2][2]; // two fragment sets: k-step ks + 1 is read under the MFMAs of k-step ks
+    // The barrier sits in front of a tile's LAST k-step, not its first: by then every wave has received (not just issued) its reads of the
+    // tile, so the slot can be handed to tile t + 4 at once, and the next tile's first fragments are read under the four MFMAs that are
+    // left - no wave stands at a barrier with an empty MFMA queue, no first read of a tile is waited for in the open.
+    asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory"); // tile 0 has landed for everyone
+    read_step(std::integral_constant<int, 0>{}, smem_u, fa[0], fb[0]);
+    landed(fa[0], fb[0]);
     for (int t = 0; t < nt; ++t) {
-        asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory"); // tile t has landed for everyone; everyone is done reading tile t - 1
-        stage_tile(clampt(t + H_STAGES - 1), smem + ((t + H_STAGES - 1) % H_STAGES) * 2 * H_TILE_BYTES);
-        const unsigned cur_u = smem_u + (unsigned)((t % H_STAGES) * 2 * H_TILE_BYTES);
-        read_step(std::integral_constant<int, 0>{}, cur_u, fa[0], fb[0]);
-        landed(fa[0], fb[0]);
+        const unsigned cur_u = smem_u + (unsigned)((t % H_STAGES) * 2 * H_TILE_BYTES), nxt_u = smem_u + (unsigned)(((t + 1) % H_STAGES) * 2 * H_TILE_BYTES);
         read_step(std::integral_constant<int, 1>{}, cur_u, fa[1], fb[1]);
         mma(fa[0], fb[0]);
         landed(fa[1], fb[1]);
@@ -596,7 +598,11 @@ __global__ __launch_bounds__(256) void gemm_h_kernel(const GemmArgs g) {
         read_step(std::integral_constant<int, 3>{}, cur_u, fa[1], fb[1]);
         mma(fa[0], fb[0]);
         landed(fa[1], fb[1]);
+        asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory"); // tile t + 1 has landed for everyone; nobody reads tile t any more
+        stage_tile(clampt(t + H_STAGES), smem + (t % H_STAGES) * 2 * H_TILE_BYTES);
+        read_step(std::integral_constant<int, 0>{}, nxt_u, fa[0], fb[0]);
         mma(fa[1], fb[1]);
+        landed(fa[0], fb[0]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the re-fetched tail tiles: nothing may still be writing LDS when the workgroup retires
 
@@ -988,6 +994,10 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_h256_kernel(const GemmArgs g) {
 //     P : s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier   - tile t + 1 has landed for everyone, tile t's buffer is free
 //     S1: 64 MFMAs of (t, k-step 1)      | under them: 16 DMA operations of tile t + 2, read fragments (t + 1, k-step 0)
 // Half-tiles: HA0 / HA1 = rows 0..127 / 128..255 of the A tile, HB0 / HB1 likewise for B; wave (wr, wc) reads HA[wr], HB[wc].
+// Where a 4096^3 launch's 110 us go (round 3, random operands, back to back; each row = the kernel with parts compiled out): MFMAs alone
+// 71 us (2048 cycles per K tile at 2.2 GHz + 12 us of launch, prologue and epilogue), + the LDS-DMA stream 83, + the fragment reads 94,
+// everything 110; the data movement without the MFMAs 67. No single unit is the bound - every activity added lowers the clock the power
+// limit leaves (1.87 GHz with all of them, profiles/r01_gemm_clock.json) and the loop's MFMA issue sits at 84 % of that clock.
 // ------------------------------------------------------------------------------------------
 constexpr int W4_NT = 256;
 #ifndef W4_DMA_GROUPS

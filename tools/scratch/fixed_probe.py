@@ -14,6 +14,7 @@ def b2b(fn, reps=50):
     for _ in range(reps): fn()
     e1.record(None); H.device_sync()
     return e0.elapsed_ms(e1)/reps*1e3
-for K in (64,128,256,4096):
-    f=lambda: H.gemm(H.BF16,0,1,n,n,K,1.0,A.ptr,4096,B.ptr,4096,0.0,C.ptr,n,0,None,None,0)
-    print('gemm NT K',K,'b2b us %.2f'%b2b(f), flush=True)
+for tb,tag in ((1,'NT'),(0,'NN')):
+    for K in (4096,):
+        f=lambda: H.gemm(H.BF16,0,tb,n,n,K,1.0,A.ptr,4096,B.ptr,4096,0.0,C.ptr,n,0,None,None,0)
+        print('gemm',tag,'K',K,'b2b us %.2f'%b2b(f), flush=True)
