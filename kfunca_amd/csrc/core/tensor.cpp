@@ -345,14 +345,15 @@ void Tensor::update_grad(Tensor grad) {
         *impl->grad_ += grad;
     } else {
         // First gradient of a leaf. The reference copies it (tensor.cpp:75-84); a gradient that nobody else can see - a fresh,
-        // dense tensor owning its whole storage, referenced only by the engine's own handles (the accumulator slot, the loop's
-        // local and this parameter) - is adopted instead: for a weight gradient that is one read + one write of the parameter's
-        // size saved per step. Anything shared (the SAME tensor handed to two inputs, as add's backward does; a view; the
-        // caller's own grad_output) is still copied.
-        const bool exclusive = grad.impl_ref_count() <= 3 && grad.storage_ref_count() == 1 && grad.is_contiguous() && grad.storage_offset() == 0 &&
+        // dense tensor owning its whole storage, whose ONLY handle is this parameter (the engine moves its accumulator slot in;
+        // round 3: the count is exactly one, not "at most the three handles the engine happens to hold") - is adopted instead:
+        // for a weight gradient that is one read + one write of the parameter's size saved per step. Anything shared (the SAME
+        // tensor handed to two inputs, as add's backward does; a view; the caller's own grad_output; a tensor a GradFunction
+        // keeps) is still copied.
+        const bool exclusive = grad.impl_ref_count() == 1 && grad.storage_ref_count() == 1 && grad.is_contiguous() && grad.storage_offset() == 0 &&
                                (size_t)grad.numel() * (size_t)grad.element_size_in_bytes() <= grad.storage_bytes() && !grad.has_grad_fn();
         if (exclusive) {
-            impl->grad_ = std::make_unique<Tensor>(grad);
+            impl->grad_ = std::make_unique<Tensor>(std::move(grad));
         } else {
             Tensor g = empty_like(grad);
             g.copy_(grad);
@@ -385,7 +386,11 @@ void Tensor::backward(Tensor grad_output) {
     while (!work.empty()) {
         Tensor *t = work.front();
         work.pop();
-        Tensor g = acc[t->impl()];
+        // the slot is MOVED out: every consumer of t has reported (pending == 0), nobody adds to it again, and a leaf can see that the
+        // handle it receives is the only one
+        auto slot_it = acc.find(t->impl());
+        Tensor g = std::move(slot_it->second);
+        acc.erase(slot_it);
         if (t->has_grad_fn()) {
             GradFunction *fn = t->grad_fn_.get();
             std::vector<Tensor> gin = fn->backward(g);
@@ -397,7 +402,7 @@ void Tensor::backward(Tensor grad_output) {
                 if (--pending[in.impl()] == 0) work.push(&in);
             }
         } else if (t->requires_grad()) {
-            t->update_grad(g);
+            t->update_grad(std::move(g));
         }
     }
 }

@@ -242,6 +242,36 @@ def test_basic_backward_add_dag():  # test_tensor.py:286-309
     assert not c.grad().defined()
 
 
+def test_one_gradient_tensor_for_two_leaves_is_shared_by_neither():
+    """add's backward hands the SAME tensor to both inputs (binary_ops.cpp:16-33). The engine adopts a first gradient without a copy only
+    when the handle it holds is the tensor's only one (update_grad: impl_ref_count() == 1 - it moves its accumulator slot in), so two
+    leaves fed by one tensor end up with gradients of their own: a second backward adds into each in place and must not be seen by
+    the other; the caller's grad_output is never adopted either; a fresh weight gradient (gemm's dW) still is, without a copy."""
+    rng = np.random.default_rng(11)
+    a, b = (kfunca.from_numpy(uni(rng, (4, 8)), 0) for _ in range(2))
+    a.set_requires_grad(True)
+    b.set_requires_grad(True)
+    g1 = kfunca.from_numpy(uni(rng, (4, 8)), 0)
+    (a + b).backward(g1)
+    assert len({a.grad().data_ptr(), b.grad().data_ptr(), g1.data_ptr()}) == 3
+    # only a is in the second graph: its gradient doubles in place, b's stays, the caller's tensor is untouched
+    g1_host = g1.numpy().copy()
+    (a + kfunca.from_numpy(uni(rng, (4, 8)), 0)).backward(g1)
+    assert np.array_equal(a.grad().numpy(), g1_host + g1_host)
+    assert np.array_equal(b.grad().numpy(), g1_host)
+    assert np.array_equal(g1.numpy(), g1_host)
+    # a leaf that is its own root: the caller's grad_output is copied, not adopted
+    c = kfunca.from_numpy(uni(rng, (4, 8)), 0)
+    c.set_requires_grad(True)
+    c.backward(g1)
+    assert c.grad().data_ptr() != g1.data_ptr() and np.array_equal(c.grad().numpy(), g1_host)
+    # the same leaf twice in one node: one gradient, the sum of both
+    d = kfunca.from_numpy(uni(rng, (4, 8)), 0)
+    d.set_requires_grad(True)
+    (d + d).backward(g1)
+    assert np.array_equal(d.grad().numpy(), g1_host + g1_host) and np.array_equal(g1.numpy(), g1_host)
+
+
 def test_gemm_golden_and_backward():  # test_gemm.py:9-17 + backward (no reference counterpart)
     g = golden("gemm")
     a, b = regen(g["f64_seed"][0], [(123, 457), (457, 234)], g["f64_sha"], dtype=np.float64)
