@@ -1009,7 +1009,7 @@ constexpr int W4_NT = 256;
 // The body is a device function of (problem, workgroup id, workgroups of the problem): gemm_w4_kernel runs one problem per launch,
 // gemm_w4_pair_kernel two (the backward pair dA = dC B^T, dB = A^T dC) in ONE grid, so the second problem's first tiles start
 // under the first problem's last ones instead of behind a kernel boundary.
-template <bool BF, bool TRA, bool TRB, bool DIAG>
+template <bool BF, bool TRA, bool TRB, bool DIAG, bool TAIL = false>
 __device__ __forceinline__ void gemm_w4_body(const GemmArgs &g, const uint32_t bid, const uint32_t nwg, char *smem) {
     using frag_t = typename HFrag<BF>::type;
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1250,6 +1250,7 @@ __device__ __forceinline__ void gemm_w4_body(const GemmArgs &g, const uint32_t b
                     v[e] += g.beta * (BF ? bf16_to_f32(bf16_t{o}) : f16_to_f32(f16_t{o}));
                 }
             }
+            if constexpr (TAIL) h_epi8<BF>(g, row, col, v);
             uint32_t w[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -1269,6 +1270,13 @@ template <bool BF, bool TRA, bool TRB, bool DIAG = false>
 __global__ __launch_bounds__(W4_NT) void gemm_w4_kernel(const GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     gemm_w4_body<BF, TRA, TRB, DIAG>(g, blockIdx.x, gridDim.x, smem);
+}
+// the same kernel with the element-wise tail (mul / add / aux operands) in its epilogue: its own instantiation, so the plain product
+// carries none of the tail's pointers through its loop
+template <bool BF, bool TRA, bool TRB>
+__global__ __launch_bounds__(W4_NT) void gemm_w4_tail_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm_w4_body<BF, TRA, TRB, false, true>(g, blockIdx.x, gridDim.x, smem);
 }
 
 // Two problems, one grid: g0 is an NT product (A [M,K], B stored [N,K]: dA = dC W^T), g1 a TN product (A stored [K,M], B [K,N]:
@@ -1327,16 +1335,19 @@ extern "C" int kf_gemm_workspace_bytes(int dtype, int trans_a, int trans_b, int6
     return KF_OK;
 }
 
-// both 256-tile forms run at the clock the chip holds under the load (tools/gemm_clock.py) and end up within a few % of each
-// other; the 4-wave form is ahead while the grid is at most two rounds of tiles, the 8-wave form on larger grids
+// Round 3: the 4-wave form on every grid. It used to win only up to two rounds of tiles; with its transposed reads spread over the MFMA
+// gaps and the shorter epilogue it is ahead of the 8-wave form everywhere measured (tools/scratch/w4_vs_w8.py, same process, interleaved):
+// 4096 x 12288 x 4096 NN 1258 vs 1120 TFLOP/s, TN 1234 vs 1091; 4096 x 4096 x 16384 TN 1315 vs 1130; 8192^3 NN 1396 vs 1264, NT 1454
+// vs 1390; 5120^3 TN 1058 vs 934. KF_GEMM_W8 still selects the 8-wave kernel (tests keep it covered).
 static bool h256_use_w4(int64_t M, int64_t N) {
-    const int64_t grid = (M / G_BM) * (N / G_BN);
-    return knob(KNOB_GEMM_W4) ? true : (knob(KNOB_GEMM_W8) ? false : grid <= 512);
+    (void)M; (void)N;
+    return !knob(KNOB_GEMM_W8);
 }
 
 template <bool BF>
 static int launch_h256(const GemmArgs &g, bool tra, bool trb, bool w4, hipStream_t st) {
     const unsigned grid = (unsigned)((g.M / G_BM) * (g.N / G_BN));
+    const bool tail = g.mul || g.add || g.aux;
 #define KF_H256(TA, TB)                                                                                                   \
     {                                                                                                                     \
         KF_ENSURE_LDS((gemm_h256_kernel<BF, TA, TB>), G_LDS); \
@@ -1344,8 +1355,13 @@ static int launch_h256(const GemmArgs &g, bool tra, bool trb, bool w4, hipStream
     }
 #define KF_W4(TA, TB)                                                                                                     \
     {                                                                                                                     \
-        KF_ENSURE_LDS((gemm_w4_kernel<BF, TA, TB>), G_LDS); \
-        gemm_w4_kernel<BF, TA, TB><<<grid, W4_NT, G_LDS, st>>>(g);                                                        \
+        if (tail) {                                                                                                       \
+            KF_ENSURE_LDS((gemm_w4_tail_kernel<BF, TA, TB>), G_LDS);                                                      \
+            gemm_w4_tail_kernel<BF, TA, TB><<<grid, W4_NT, G_LDS, st>>>(g);                                               \
+        } else {                                                                                                          \
+            KF_ENSURE_LDS((gemm_w4_kernel<BF, TA, TB>), G_LDS);                                                           \
+            gemm_w4_kernel<BF, TA, TB><<<grid, W4_NT, G_LDS, st>>>(g);                                                    \
+        }                                                                                                                 \
     }
     if (w4) {
         if (!tra && !trb) KF_W4(false, false)
@@ -1487,9 +1503,9 @@ static int gemm_impl(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, 
     }
     if ((dtype == KF_BF16 || dtype == KF_F16) && h_fast_ok(M, N, K) && al16 && lda % 8 == 0 && ldb % 8 == 0) {
         if (h256_ok(M, N, K)) { // every operand layout is consumed in place
-            // the 4-wave kernel has no register to spare for the element-wise tail (its 512 are accumulators + fragments; the
-            // tail made it spill): products with mul / add / aux operands take the 8-wave kernel
-            const bool w4 = h256_use_w4(M, N) && !(g.mul || g.add || g.aux); // profile labels name the kernel that ran (tests assert them)
+            // products with mul / add / aux operands take the 4-wave kernel's tail instantiation (round 3; same loop, same accumulation
+            // order, so aux is bit-identical to the plain product)
+            const bool w4 = h256_use_w4(M, N); // profile labels name the kernel that ran (tests assert them)
             KF_PROF(dtype == KF_BF16 ? (w4 ? "gemm_bf16_mfma" : "gemm_bf16_mfma_w8") : (w4 ? "gemm_f16_mfma" : "gemm_f16_mfma_w8"), st);
             return dtype == KF_BF16 ? launch_h256<true>(g, trans_a != 0, !trans_b, w4, st) : launch_h256<false>(g, trans_a != 0, !trans_b, w4, st);
         }

@@ -6,7 +6,7 @@ sampled output rows / sampled (batch, head) pairs with the CPU oracle — the or
 subset of attention, so the check costs seconds while the launch is the real one.
 
   C2  fp32 4096^3 fwd + bwd            -> gemm_f32_mfma (the 128-tile form of gemm_f32_kernel), bit-exact vs the fma chain
-  C4  bf16 8192 x 8192 x K + epilogue  -> gemm_bf16_mfma_w8 (the 8-wave 256-tile kernel), all four layouts, alpha / beta / bias
+  C4  bf16 8192 x 8192 x K + epilogue  -> gemm_bf16_mfma (the 4-wave 256-tile kernel: every grid since round 3) and, forced, gemm_bf16_mfma_w8; all four layouts, alpha / beta / bias
   C3  bf16 attention B8 H32 S4096 D128 -> forward and the backward kernels with the XCD block map on
 Reference bars: test/test_gemm.py:9-17, test/test_nn.py:11-33, test/common.py:6-11.
 """
@@ -69,11 +69,17 @@ def _bf16_rows_check(got, want64, mag, eps=2.0 ** -8, scale=1.0):
     assert (np.abs(got - want64) <= scale * eps * np.abs(want64) + scale * 1e-6 * mag + scale * eps * 1e-3).all()
 
 
-@pytest.mark.parametrize("K", [512, 8192])
-def test_c4_bf16_8192_epilogue_runs_the_8_wave_kernel(K):
-    """8192 x 8192 x K bf16 with alpha / beta and the fused bias row: 1024 tiles of 256^2 -> the 8-wave kernel. K = 512 sweeps
+@pytest.mark.parametrize("K,w8", [(512, False), (8192, False), (512, True)])
+def test_c4_bf16_8192_epilogue_on_both_256_tile_kernels(K, w8):
+    """8192 x 8192 x K bf16 with alpha / beta and the fused bias row: 1024 tiles of 256^2 -> the 4-wave kernel (every grid since
+    round 3: it is ahead of the 8-wave form at every size measured), and the 8-wave kernel forced with KF_GEMM_W8. K = 512 sweeps
     all four layouts; K = 8192 is config C4 itself (NN and NT). Sampled rows against the oracle (bf16 inputs, f32
     accumulation, one rounding) and against f64 numpy with the bound of tests/test_gpu_gemm.py."""
+    with H.knobs(KF_GEMM_W8="1" if w8 else None, KF_GEMM_W4=None):
+        _c4_case(K, "gemm_bf16_mfma_w8" if w8 else "gemm_bf16_mfma")
+
+
+def _c4_case(K, label):
     M = N = 8192
     rng = np.random.default_rng(1004 + K)
     bits = lambda shape: O.f32_to_bf16(rng.uniform(-1, 1, shape).astype(np.float32))
@@ -91,7 +97,7 @@ def test_c4_bf16_8192_epilogue_runs_the_8_wave_kernel(K):
         da, db = H.DevBuf.from_numpy(sa), H.DevBuf.from_numpy(sb)
         dc.zero()
         ran = gemm_dev(H.BF16, da, db, dc, M, N, K, ta, tb, sa.shape[1], sb.shape[1])
-        assert ran == {"gemm_bf16_mfma_w8"}, (ta, tb, ran)
+        assert ran == {label}, (ta, tb, ran)
         got = O.bf16_to_f32(rows_of(dc, rows, N, np.uint16)).astype(np.float64)
         _bf16_rows_check(got, want_plain, mag)
         orc_a = np.ascontiguousarray(sa[:, rows]) if ta else sa[rows]
@@ -100,7 +106,7 @@ def test_c4_bf16_8192_epilogue_runs_the_8_wave_kernel(K):
         # alpha / beta / bias row epilogue on the same launch shape
         H.check(H.lib().kf_memcpy_h2d(dc.ptr, c.ctypes.data, c.nbytes, None))
         ran = gemm_dev(H.BF16, da, db, dc, M, N, K, ta, tb, sa.shape[1], sb.shape[1], alpha=0.5, beta=2.0, bias=dbias)
-        assert ran == {"gemm_bf16_mfma_w8"}, (ta, tb, ran)
+        assert ran == {label}, (ta, tb, ran)
         got = O.bf16_to_f32(rows_of(dc, rows, N, np.uint16)).astype(np.float64)
         assert (np.abs(got - want_epi) <= 2 * 2.0 ** -8 * np.abs(want_epi) + 2e-6 * mag + 2 * 2.0 ** -8).all(), ("epilogue", ta, tb)
         orc = O.bf16_to_f32(O.gemm(orc_a, sb, alpha=0.5, beta=2.0, trans_a=bool(ta), trans_b=bool(tb), c=c[rows], bias=bias,

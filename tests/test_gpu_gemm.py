@@ -231,9 +231,15 @@ def test_errors():
 @pytest.mark.parametrize("code,M,N,K,label", [
     (H.F32, 256, 384, 64, "gemm_f32_mfma_t64"), (H.F32, 2048, 2048, 32, "gemm_f32_mfma"), (H.F64, 128, 192, 48, "gemm_f64_mfma"),
     (H.BF16, 256, 384, 128, "gemm_bf16_mfma_128"), (H.F16, 384, 256, 64, "gemm_f16_mfma_128"),
+    (H.BF16, 2560, 4096, 128, "gemm_bf16_mfma"), (H.F16, 2560, 4096, 64, "gemm_f16_mfma"),
     (H.BF16, 2560, 4096, 128, "gemm_bf16_mfma_w8"), (H.F16, 2560, 4096, 64, "gemm_f16_mfma_w8"), (H.BF16, 100, 130, 70, "gemm_generic"),
     (H.F32, 33, 65, 17, "gemm_generic")])
 def test_fused_elementwise_tail(code, M, N, K, label):
+    with H.knobs(KF_GEMM_W8="1" if label.endswith("_w8") else None):  # the 8-wave 256-tile kernel runs only when asked for (round 3)
+        _fused_tail_case(code, M, N, K, label)
+
+
+def _fused_tail_case(code, M, N, K, label):
     """kf_gemm_ex: C = (alpha A B + beta C + bias) o mul + add with aux = the bracket, on every kernel family (label asserted).
     aux must equal what kf_gemm alone stores (bit for bit: same arithmetic, same rounding); C against f64 numpy on the
     dtype-rounded inputs with the GEMM bound of this file plus one rounding of the result. A wide (ld > N) mul operand and a
@@ -254,11 +260,9 @@ def test_fused_elementwise_tail(code, M, N, K, label):
     H.profile_enable(False)
     assert set(H.profile_results()) == {label}, H.profile_results()
     plain, aux, got = dplain.to_numpy((M, N), a.dtype), daux.to_numpy((M, N), a.dtype), dc.to_numpy((M, N), a.dtype)
-    if label.endswith("_w8") or label.endswith("_128") or code in (H.F32, H.F64) or label == "gemm_generic":
-        # the plain product of the 2560 x 4096 shapes runs the 4-wave kernel (another accumulation order): compare through the bound there
-        same = not label.endswith("_w8")
-        if same:
-            assert np.array_equal(aux.view(np.uint8), plain.view(np.uint8)), "aux differs from the plain product"
+    # aux = what kf_gemm alone stores, bit for bit: the tail runs in the same kernel's epilogue (the 4-wave 256-tile kernel's tail form is
+    # the same loop; under KF_GEMM_W8 the plain product above ran the 8-wave kernel too)
+    assert np.array_equal(aux.view(np.uint8), plain.view(np.uint8)), "aux differs from the plain product"
     raw = 0.5 * (f(a) @ f(b)) + 2.0 * f(c) + f(bias)[None, :]
     mag = np.abs(f(a)) @ np.abs(f(b)) + 2.0 * np.abs(f(c)) + 1.0
     assert (np.abs(f(aux) - raw) <= 2 * eps * np.abs(raw) + 2e-6 * mag * (1 if code != H.F64 else 1e-7) + 2 * eps).all(), "aux"
