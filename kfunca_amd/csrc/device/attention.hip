@@ -512,6 +512,9 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         TL_STAMP(1) // everyone's
+        // (round 3, tried: the four LDS-DMA instructions under the first four MFMAs of the score chain instead of here in the open, where
+        // they cost the wave 433 cycles per tile - 1.41 ms against 1.28 on the same box and run: with two waves per SIMD a wave stuck
+        // issuing DMA costs the SIMD nothing, its partner has the pipes, while the same instructions inside the chain delay the chain)
         stage(t + 2, smem + ((t + 2) % SRING) * FBUF); // slot of tile t-2: nobody reads it any more
         TL_STAMP(2) // four LDS-DMA instructions issued
         const char *cur = smem + (t % SRING) * FBUF;
