@@ -1,6 +1,8 @@
 """-m gpu: seeded random-shape sweeps through the operator API against the oracle - the paths that pick kernels by shape
 (sort: LDS / radix, views; GEMM: matrix-core kernels behind zero-padding; attention: MFMA kernels behind zero-padding or the
 generic kernels) over shapes nobody wrote down by hand."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,10 +11,11 @@ from oracle import checks as K
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
+SEED = int(os.environ.get("KF_FUZZ_SEED", "0"))  # `KF_FUZZ_SEED=n pytest tests/test_gpu_fuzz.py`: other shapes (0 = the committed sweep)
 
 
 def test_sort_topk_random_shapes_views_dtypes():
-    rng = np.random.default_rng(2025)
+    rng = np.random.default_rng(2025 + 1000 * SEED)
     dts = [np.float32, np.float64, np.int32, np.int64, np.int16, np.uint8, np.int8, np.float16]
     for _ in range(60):
         nd = int(rng.integers(1, 4))
@@ -36,7 +39,7 @@ def test_sort_topk_random_shapes_views_dtypes():
 
 
 def test_gemm_random_ragged_shapes():
-    rng = np.random.default_rng(2026)
+    rng = np.random.default_rng(2026 + 1000 * SEED)
     for _ in range(30):
         M, N, K = (int(rng.integers(1, 700)) for _ in range(3))
         dt = ["f32", "f64", "bf16"][int(rng.integers(0, 3))]
@@ -61,7 +64,7 @@ def test_attention_random_shapes_dtypes_forward_backward():
     """Random shapes and dtypes through the operator API (matrix-core kernels with operator padding, generic kernels for the rest).
     f32: 3e-5 / 1e-4 of the output's scale against the f32 oracle; bf16 / f16: the scale-aware bounds of oracle/checks.py against the
     double-precision oracle (per element, per row, per head; nothing absolute)."""
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(77 + 1000 * SEED)
     for _ in range(24):
         B, Hh = int(rng.integers(1, 3)), int(rng.integers(1, 4))
         Sq = int(rng.choice([1, 7, 31, 32, 33, 64, 100, 128, 129, 256, 300, 512]))
@@ -95,7 +98,7 @@ def test_round2_operators_random_shapes():
     """rms_norm / layer_norm, gemm_fused, causal_attention_qkv and embedding over seeded random shapes and dtypes, forward + backward
     through autograd, against f64 numpy on the dtype-rounded inputs (the kernels behind them are picked by shape: register-tile plans
     and generic norm kernels, every GEMM family incl. split-K, strided attention or its fall-back composition)."""
-    rng = np.random.default_rng(2027)
+    rng = np.random.default_rng(2027 + 1000 * SEED)
 
     def mk(shape, dt, scale=1.0):
         x = (rng.uniform(-1, 1, shape) * scale).astype(np.float32)
