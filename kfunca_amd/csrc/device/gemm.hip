@@ -998,6 +998,10 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_h256_kernel(const GemmArgs g) {
 // 71 us (2048 cycles per K tile at 2.2 GHz + 12 us of launch, prologue and epilogue), + the LDS-DMA stream 83, + the fragment reads 94,
 // everything 110; the data movement without the MFMAs 67. No single unit is the bound - every activity added lowers the clock the power
 // limit leaves (1.87 GHz with all of them, profiles/r01_gemm_clock.json) and the loop's MFMA issue sits at 84 % of that clock.
+// (Round 3, tried and dropped - tools/scratch/gemm_persistent_tiles_experiment.patch: one workgroup per CU walking the tiles of a
+// multi-round grid, the LDS-DMA a K loop issues past its end fetching the NEXT tile's first K tiles, the epilogue's stores draining under
+// the next tile's first MFMAs behind a counted wait. Bit-identical, and within +-3 % of one tile per workgroup on every shape measured in
+// one process (4096 x 12288 x 4096 ... 8192^3): the dispatcher already starts the next workgroup as fast as a tile loop does.)
 // ------------------------------------------------------------------------------------------
 constexpr int W4_NT = 256;
 #ifndef W4_DMA_GROUPS
@@ -1068,13 +1072,7 @@ __device__ __forceinline__ void gemm_w4_body(const GemmArgs &g, const uint32_t b
     const int pbT = 32 * fg;
     const unsigned smem_u = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)smem;
 
-    f32x4 acc[8][8]; // [n-tile][m-tile]: D = B_frag x A_frag, i.e. C^T tiles
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    f32x4 acc[8][8]; // [n-tile][m-tile]: D = B_frag x A_frag, i.e. C^T tiles (first written by K tile 0's first k-step)
     frag_t fa[2][8], fb[2][8]; // [set][tile]
 
     // Everything in the loop is volatile inline asm, i.e. issued exactly in source order: MFMAs with "+a" accumulators (all
@@ -1087,6 +1085,12 @@ __device__ __forceinline__ void gemm_w4_body(const GemmArgs &g, const uint32_t b
     auto mm = [&](f32x4 &c, const frag_t &b, const frag_t &a) __attribute__((always_inline)) {
         if constexpr (BF) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(b), "v"(a));
         else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(c) : "v"(b), "v"(a));
+    };
+    // the first k-step of the output tile starts its 64 accumulators from the inline constant 0: nothing to zero (the ~500
+    // v_accvgpr_write the zero-initialisation used to cost stood between the first data landing and the first MFMA)
+    auto mmz = [&](f32x4 &c, const frag_t &b, const frag_t &a) __attribute__((always_inline)) {
+        if constexpr (BF) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(c) : "v"(b), "v"(a));
+        else asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(c) : "v"(b), "v"(a));
     };
     // read number r (0..15) of a k-step: A tiles 0..7, then B tiles 0..7, in two halves that go behind DIFFERENT MFMAs of a group.
     // A K-contiguous operand's fragment is one ds_read_b128 (first half; the second is empty). A transposed-read operand's is two
@@ -1136,23 +1140,24 @@ __device__ __forceinline__ void gemm_w4_body(const GemmArgs &g, const uint32_t b
 #define W4_READ1(SET, KS, BUFU, R) W4_READ_A(SET, KS, BUFU, R) W4_READ_B(SET, KS, BUFU, R)
     // one k-step: 64 MFMAs on fragment set SET; after every fourth one, read R of the next fragment set and (DMA) one
     // LDS-DMA operation of tile kt + 2
-#define W4_STEP(SET, NKS, NBUFU, DMA)                                                                          \
-    W4_GROUP(SET, NKS, NBUFU, DMA, 0) W4_GROUP(SET, NKS, NBUFU, DMA, 1) W4_GROUP(SET, NKS, NBUFU, DMA, 2) W4_GROUP(SET, NKS, NBUFU, DMA, 3) \
-    W4_GROUP(SET, NKS, NBUFU, DMA, 4) W4_GROUP(SET, NKS, NBUFU, DMA, 5) W4_GROUP(SET, NKS, NBUFU, DMA, 6) W4_GROUP(SET, NKS, NBUFU, DMA, 7) \
-    W4_GROUP(SET, NKS, NBUFU, DMA, 8) W4_GROUP(SET, NKS, NBUFU, DMA, 9) W4_GROUP(SET, NKS, NBUFU, DMA, 10) W4_GROUP(SET, NKS, NBUFU, DMA, 11) \
-    W4_GROUP(SET, NKS, NBUFU, DMA, 12) W4_GROUP(SET, NKS, NBUFU, DMA, 13) W4_GROUP(SET, NKS, NBUFU, DMA, 14) W4_GROUP(SET, NKS, NBUFU, DMA, 15)
-#define W4_GROUP(SET, NKS, NBUFU, DMA, G)                                                                      \
+#define W4_STEP(SET, NKS, NBUFU, DMA) W4_STEPM(mm, SET, NKS, NBUFU, DMA)
+#define W4_STEPM(MM, SET, NKS, NBUFU, DMA)                                                                          \
+    W4_GROUP(MM, SET, NKS, NBUFU, DMA, 0) W4_GROUP(MM, SET, NKS, NBUFU, DMA, 1) W4_GROUP(MM, SET, NKS, NBUFU, DMA, 2) W4_GROUP(MM, SET, NKS, NBUFU, DMA, 3) \
+    W4_GROUP(MM, SET, NKS, NBUFU, DMA, 4) W4_GROUP(MM, SET, NKS, NBUFU, DMA, 5) W4_GROUP(MM, SET, NKS, NBUFU, DMA, 6) W4_GROUP(MM, SET, NKS, NBUFU, DMA, 7) \
+    W4_GROUP(MM, SET, NKS, NBUFU, DMA, 8) W4_GROUP(MM, SET, NKS, NBUFU, DMA, 9) W4_GROUP(MM, SET, NKS, NBUFU, DMA, 10) W4_GROUP(MM, SET, NKS, NBUFU, DMA, 11) \
+    W4_GROUP(MM, SET, NKS, NBUFU, DMA, 12) W4_GROUP(MM, SET, NKS, NBUFU, DMA, 13) W4_GROUP(MM, SET, NKS, NBUFU, DMA, 14) W4_GROUP(MM, SET, NKS, NBUFU, DMA, 15)
+#define W4_GROUP(MM, SET, NKS, NBUFU, DMA, G)                                                                      \
     {                                                                                                          \
         constexpr int n = (G) >> 1, mb = ((G) & 1) * 4;                                                        \
-        mm(acc[n][mb + 0], fb[SET][n], fa[SET][mb + 0]);                                                       \
+        MM(acc[n][mb + 0], fb[SET][n], fa[SET][mb + 0]);                                                       \
         if constexpr (DMA && (G) < W4_DMA_GROUPS) stage_op((G) * (16 / W4_DMA_GROUPS) / 4, (G) * (16 / W4_DMA_GROUPS) % 4, kt + 2); \
-        mm(acc[n][mb + 1], fb[SET][n], fa[SET][mb + 1]);                                                       \
+        MM(acc[n][mb + 1], fb[SET][n], fa[SET][mb + 1]);                                                       \
         if constexpr (DMA && (G) < W4_DMA_GROUPS && W4_DMA_GROUPS <= 8) stage_op(((G) * (16 / W4_DMA_GROUPS) + 1) / 4, ((G) * (16 / W4_DMA_GROUPS) + 1) % 4, kt + 2); \
         W4_READ_A(1 - (SET), NKS, NBUFU, G)                                                                    \
-        mm(acc[n][mb + 2], fb[SET][n], fa[SET][mb + 2]);                                                       \
+        MM(acc[n][mb + 2], fb[SET][n], fa[SET][mb + 2]);                                                       \
         W4_READ_B(1 - (SET), NKS, NBUFU, G)                                                                    \
         if constexpr (DMA && (G) < W4_DMA_GROUPS && W4_DMA_GROUPS <= 4) stage_op(((G) * 4 + 2) / 4, ((G) * 4 + 2) % 4, kt + 2); \
-        mm(acc[n][mb + 3], fb[SET][n], fa[SET][mb + 3]);                                                       \
+        MM(acc[n][mb + 3], fb[SET][n], fa[SET][mb + 3]);                                                       \
         if constexpr (DMA && (G) < W4_DMA_GROUPS && W4_DMA_GROUPS <= 4) stage_op(((G) * 4 + 3) / 4, ((G) * 4 + 3) % 4, kt + 2); \
     }
 
@@ -1163,12 +1168,6 @@ __device__ __forceinline__ void gemm_w4_body(const GemmArgs &g, const uint32_t b
         for (int which = 0; which < 4; ++which)
 #pragma unroll
             for (int i = 0; i < 4; ++i) stage_op(which, i, kt);
-    // the 256 accumulator registers are zeroed HERE, under the first tiles' flight (left alone the compiler sinks the ~500 writes
-    // behind the barrier: 1 us between the data landing and the first MFMA)
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(acc[i][j]));
     asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
 #define W4_R(R) W4_READ1(0, 0, smem_u, R)
     W4_R(0) W4_R(1) W4_R(2) W4_R(3) W4_R(4) W4_R(5) W4_R(6) W4_R(7) W4_R(8) W4_R(9) W4_R(10) W4_R(11) W4_R(12) W4_R(13) W4_R(14) W4_R(15)
@@ -1180,7 +1179,15 @@ __device__ __forceinline__ void gemm_w4_body(const GemmArgs &g, const uint32_t b
         t0 = __builtin_amdgcn_s_memtime();
         r0 = __builtin_amdgcn_s_memrealtime();
     }
-    for (int kt = 0; kt < nt; ++kt) {
+    { // K tile 0: the accumulators start from 0 in its first k-step
+        const int kt = 0;
+        const unsigned bufu = smem_u, nbufu = smem_u + G_TILE;
+        W4_STEPM(mmz, 0, 1, bufu, false)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        W4_STEP(1, 0, nbufu, true)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    for (int kt = 1; kt < nt; ++kt) {
         const unsigned bufu = smem_u + (kt & 1) * G_TILE, nbufu = smem_u + ((kt + 1) & 1) * G_TILE;
         W4_STEP(0, 1, bufu, false)                                                        // S0
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");          // P
@@ -1188,6 +1195,7 @@ __device__ __forceinline__ void gemm_w4_body(const GemmArgs &g, const uint32_t b
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 #undef W4_STEP
+#undef W4_STEPM
 #undef W4_GROUP
 #undef W4_READ1
 #undef W4_READ_A
