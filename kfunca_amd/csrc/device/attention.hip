@@ -512,6 +512,8 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         TL_STAMP(1) // everyone's
+        // (round 3, tried: a five-slot ring (all 160 KiB) with ONE barrier per TWO tiles - 1.54 ms against 1.41-1.47 on the same box: the
+        // per-tile barrier is what keeps the early / late waves of a SIMD in their complementary phases.)
         // (round 3, tried: the four LDS-DMA instructions under the first four MFMAs of the score chain instead of here in the open, where
         // they cost the wave 433 cycles per tile - 1.41 ms against 1.28 on the same box and run: with two waves per SIMD a wave stuck
         // issuing DMA costs the SIMD nothing, its partner has the pipes, while the same instructions inside the chain delay the chain)
