@@ -467,6 +467,9 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
     const int xp = xb0 + (pass >> 1) * nwx;           // pair index: blocks xp and nxb - 1 - xp
     const int xb = ((pass & 1) != (a.persist_rev != 0)) ? nxb - 1 - xp : xp;
     const int qblk = nxb - 1 - xb; // longest blocks first
+#ifdef KF_ATTN_TIMELINE
+    const unsigned long long tl_pass0 = __builtin_amdgcn_s_memtime();
+#endif
     // query rows are dealt so that each SIMD's early wave (w) and late wave (w + 4) own ADJACENT 32-row groups:
     // their causal work differs by at most one tile
     const int64_t q0 = (int64_t)qblk * FQ, qw = q0 + rgrp * 32, m = qw + xl;
@@ -503,6 +506,7 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
     stage(1, smem + FBUF);
 #ifdef KF_ATTN_TIMELINE
     unsigned long long tl_t = __builtin_amdgcn_s_memtime(), tl_acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long tl_loop0 = tl_t;
 #endif
     for (int t = 0; t < nt; ++t) {
         const int64_t kv0 = (int64_t)t * ABK;
@@ -536,12 +540,15 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
             TL_STAMP(5) // an early wave's P V
         }
     }
-#ifdef KF_ATTN_TIMELINE
+#if defined(KF_ATTN_TIMELINE) && KF_ATTN_TIMELINE != 2
     if (lane == 0 && g_attn_tl) {
         unsigned long long *dst = g_attn_tl + ((size_t)blockIdx.x * 2 + (pass & 1)) * 64 + wid * 8;
         for (int i = 0; i < 7; ++i) dst[i] = tl_acc[i];
         dst[7] = (unsigned long long)nt;
     }
+#endif
+#ifdef KF_ATTN_TIMELINE
+    const unsigned long long tl_loop1 = __builtin_amdgcn_s_memtime();
 #endif
     if (late && pending) s_pv<BF, DB>(smem + ((nt + SRING - 1) % SRING) * FBUF + FTILE, vo, pf, o);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -551,6 +558,15 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
         if (a.lse && hl == 0) a.lse[bh * a.Sq + m] = (m_i * c + __builtin_amdgcn_logf(l_i)) * kLn2;
     }
     if (a.persist) __syncthreads(); // the staging slabs overlap the ring the next block fills
+#if defined(KF_ATTN_TIMELINE) && KF_ATTN_TIMELINE == 2 // per pass: before the tile loop | the loop | behind it (tools/attn_timeline.py --outside)
+    if (lane == 0 && g_attn_tl) {
+        unsigned long long *dst = g_attn_tl + ((size_t)blockIdx.x * 2 + (pass & 1)) * 64 + wid * 8;
+        const unsigned long long tl_end = __builtin_amdgcn_s_memtime();
+        dst[0] = tl_loop0 - tl_pass0, dst[1] = tl_loop1 - tl_loop0, dst[2] = tl_end - tl_loop1;
+        dst[3] = dst[4] = dst[5] = dst[6] = 0;
+        dst[7] = (unsigned long long)nt;
+    }
+#endif
   }
 }
 

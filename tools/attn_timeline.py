@@ -27,10 +27,15 @@ def main():
     ap.add_argument("--D", type=int, default=128)
     ap.add_argument("--zeros", action="store_true")
     ap.add_argument("--build-only", action="store_true")
+    ap.add_argument("--outside", action="store_true", help="forward: cycles of a pass before / in / behind the tile loop (build -DKF_ATTN_TIMELINE=2)")
     ap.add_argument("--dkv", action="store_true", help="the dK/dV kernel's slice phases instead of the forward's tile loop (D = 128)")
     args = ap.parse_args()
+    global LIB
+    if args.outside:
+        LIB = ROOT / "tools" / "scratch" / "lib_timeline2.so"
     if not LIB.exists() or args.build_only:
-        subprocess.run([sys.executable, str(ROOT / "tools" / "scratch" / "build_variant.py"), "timeline", "attention.hip", "-DKF_ATTN_TIMELINE"], check=True)
+        subprocess.run([sys.executable, str(ROOT / "tools" / "scratch" / "build_variant.py"), "timeline2" if args.outside else "timeline", "attention.hip",
+                        "-DKF_ATTN_TIMELINE=2" if args.outside else "-DKF_ATTN_TIMELINE"], check=True)
         if args.build_only:
             return
     os.environ["KF_HIP_LIB"] = str(LIB)
@@ -67,6 +72,20 @@ def main():
     H.device_sync()
     H.check(fn(None))
     t = tl.to_numpy((nblk, 2, 8, 8), np.uint64).astype(np.float64)
+    if args.outside:
+        blocks = t[t[..., 7].max(axis=-1) > 0]  # [passes, 8 waves, 8]
+        per = blocks.max(axis=1)                # the slowest wave of a pass sets its length
+        nt = per[:, 7]
+        tot = per[:, 0] + per[:, 1] + per[:, 2]
+        print(f"forward passes {len(per)}: mean cycles before the tile loop {per[:, 0].mean():.0f}, in it {per[:, 1].mean():.0f} ({(per[:, 1] / nt).mean():.0f} per tile), "
+              f"behind it {per[:, 2].mean():.0f}; outside the loop {100 * (per[:, 0] + per[:, 2]).sum() / tot.sum():.1f} % of a pass")
+        a_, b_ = np.polyfit(nt, per[:, 1], 1)
+        print(f"  loop cycles = {a_:.0f} x tiles + {b_:.0f}  (the intercept is the diagonal tiles' excess)")
+        for lo in (4, 16, 32, 64):
+            sel = (nt >= lo) & (nt < lo * 2)
+            if sel.any():
+                print(f"  passes of {lo}..{2 * lo - 1} tiles: before {per[sel, 0].mean():.0f}, loop {per[sel, 1].mean():.0f}, behind {per[sel, 2].mean():.0f}")
+        return
     t = t[t[..., 7] > 0]  # (passes x waves) that ran: [n, 8]
     tiles = t[:, 7].sum()
     tot = t[:, :7].sum()
