@@ -998,7 +998,7 @@ __global__ __launch_bounds__(G_NT, 2) void gemm_h256_kernel(const GemmArgs g) {
 // 71 us (2048 cycles per K tile at 2.2 GHz + 12 us of launch, prologue and epilogue), + the LDS-DMA stream 83, + the fragment reads 94,
 // everything 110; the data movement without the MFMAs 67. No single unit is the bound - every activity added lowers the clock the power
 // limit leaves (1.87 GHz with all of them, profiles/r01_gemm_clock.json) and the loop's MFMA issue sits at 84 % of that clock.
-// (Round 3, tried and dropped - tools/scratch/gemm_persistent_tiles_experiment.patch: one workgroup per CU walking the tiles of a
+// (Round 3, tried and dropped - a patch of it sits in the git history beside the commit that introduced the constant-0 first k-step: one workgroup per CU walking the tiles of a
 // multi-round grid, the LDS-DMA a K loop issues past its end fetching the NEXT tile's first K tiles, the epilogue's stores draining under
 // the next tile's first MFMAs behind a counted wait. Bit-identical, and within +-3 % of one tile per workgroup on every shape measured in
 // one process (4096 x 12288 x 4096 ... 8192^3): the dispatcher already starts the next workgroup as fast as a tile loop does.)
@@ -1317,7 +1317,7 @@ static bool h256_ok(int64_t M, int64_t N, int64_t K) {
 // AND the contraction is long enough to pay for the f32 partial round trip (at least 8 K tiles of 64 per slice). Slices = the largest
 // power of two that keeps tiles x slices within two rounds. A skinny product (M = 256, N = 4096, K = 16384: 64 tiles x 256 K tiles)
 // goes from 64 busy CUs to 512 workgroups.
-// (Round 3, tried and dropped - tools/scratch/gemm_splitk_reduce_scatter_experiment.patch: 2048^3 as 64 tiles of 256^2 x 4 K slices in the
+// (Round 3, tried and dropped; the measurements are what is kept: 2048^3 as 64 tiles of 256^2 x 4 K slices in the
 // 4-wave kernel, the slices of a tile finishing it by a reduce-scatter through the workspace inside the launch (flags, no fold kernel).
 // Correct, and 67 us against this path's 33: the bare 8-K-tile loop + prologue + a quarter epilogue is already 20 us, the 48 MB of f32
 // pieces cost 19 us to write and 14 us to read back (2.5-3.4 TB/s: they do not stay in the 8 x 4 MiB of L2), and the agent-scope
