@@ -15,6 +15,10 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+
+# the pool's host driver only supports dmabuf IPC: without this RCCL's cross-process buffer sharing fails (hipIpcGetMemHandle: invalid argument).
+# Must be in the environment before HIP initialises; children inherit it.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 from dataclasses import dataclass
 from typing import List, Sequence, Tuple
 

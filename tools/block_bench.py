@@ -24,6 +24,10 @@ all-reduce bytes per step and - with --check - the verdicts:
 import argparse
 import json
 import os
+
+# the pool's host driver only supports dmabuf IPC: without this RCCL's cross-process buffer sharing fails (hipIpcGetMemHandle: invalid argument).
+# Must be in the environment before HIP initialises; children inherit it.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import socket
 import subprocess
 import sys
