@@ -854,6 +854,11 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_ds_kernel(const AttnArgs a
         for (int hf = 0; hf < 2; ++hf) {
             int kwb = 2 * tl + hf;
             kwb = kwb < kwb_last ? kwb : kwb_last; // Skv % 64 == 32: the odd last key block has no partner (never consumed)
+#ifndef KF_DQ_FETCH_ALL
+            // key blocks above this wave's slice are never consumed (and were never written): fetch the slice's own last tile again instead -
+            // it came through a few steps ago, the bytes come from cache, not from HBM (this kernel is bound by its 4.3 GB of dS)
+            kwb = kwb <= sl ? kwb : (sl < kwb_last ? sl : kwb_last);
+#endif
             const char *tg = dsg + (int64_t)kwb * 8 * DS_TILE;
 #pragma unroll
             for (int pc = 0; pc < 2; ++pc)
