@@ -10,12 +10,13 @@ namespace kf {
 struct FastDivU32 {
     uint32_t d = 1, magic = 1, shift = 0;
     FastDivU32() = default;
+    // n / d = (mulhi(n, magic) + n) >> shift for every n < 2^31, with shift = ceil(log2 d) and magic = ceil(2^(32 + shift) / d) - 2^32
+    // (the round-up reciprocal with its implicit leading one split off, so it fits 32 bits; a power of two gets magic 0). Divisors here
+    // are dim sizes <= 2^31 - 1, so shift <= 31 and 2^(32 + shift) fits 64 bits.
     explicit FastDivU32(uint32_t divisor) : d(divisor) {
-        // smallest s with 2^s >= d, magic = floor(2^32 * (2^s - d) / d) + 1
-        for (shift = 0; shift < 32; ++shift)
-            if ((1ull << shift) >= d) break;
-        uint64_t one = 1;
-        magic = (uint32_t)(((one << 32) * ((one << shift) - d)) / d + 1);
+        shift = divisor <= 1 ? 0u : 32u - (uint32_t)__builtin_clz(divisor - 1);
+        const uint64_t pow = 1ull << (32 + shift);
+        magic = (uint32_t)((pow + divisor - 1) / divisor - (1ull << 32));
     }
     __device__ __forceinline__ uint32_t div(uint32_t n) const { return (__umulhi(n, magic) + n) >> shift; }
 };
