@@ -53,7 +53,8 @@ def sample():
     return out
 
 
-def run(n, seconds, zeros):
+def run(n, seconds, zeros, layout="NT"):
+    ta, tb = {"NN": (0, 0), "NT": (0, 1), "TN": (1, 0)}[layout]
     rng = np.random.default_rng(0)
     x = rng.uniform(-1, 1, size=(n, n)).astype(np.float32).view(np.uint32)
     bits = ((x + 0x7FFF + ((x >> 16) & 1)) >> 16).astype(np.uint16)
@@ -78,7 +79,7 @@ def run(n, seconds, zeros):
     e0.record(None)
     while time.time() < t_start + seconds:
         for _ in range(100):
-            H.gemm(H.BF16, 0, 1, n, n, n, 1.0, A.ptr, n, B.ptr, n, 0.0, Cb.ptr, n)
+            H.gemm(H.BF16, ta, tb, n, n, n, 1.0, A.ptr, n, B.ptr, n, 0.0, Cb.ptr, n)
         launches += 100
         H.device_sync()
     e1.record(None)
@@ -158,6 +159,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--attention", action="store_true", help="trace the C3 attention step instead of the GEMM loop")
     ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--layout", default="NT", choices=["NN", "NT", "TN"], help="operand layout of the GEMM loop (NT = the round-1/2 traces)")
     ap.add_argument("--seconds", type=float, default=4.0)
     ap.add_argument("--json", default="")
     args = ap.parse_args()
@@ -166,7 +168,8 @@ def main():
         out = {"workload": "attention fwd+bwd B8 H32 S4096 D128 bf16", "first_sample": sample(),
                "runs": [run_attention(args.seconds, False), run_attention(args.seconds, True)]}
     else:
-        out = {"n": args.n, "first_sample": sample(), "runs": [run(args.n, args.seconds, False), run(args.n, args.seconds, True)]}
+        out = {"n": args.n, "layout": args.layout, "first_sample": sample(),
+               "runs": [run(args.n, args.seconds, False, args.layout), run(args.n, args.seconds, True, args.layout)]}
     print(json.dumps(out, indent=1))
     if args.json:
         Path(args.json).write_text(json.dumps(out, indent=1))
