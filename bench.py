@@ -33,7 +33,9 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import socket
 import subprocess
 import sys
+import threading
 import time
+from contextlib import contextmanager
 from pathlib import Path
 
 import numpy as np
@@ -61,6 +63,31 @@ ATTN_FLOPS_STEP = 14.0 * _PAIR
 TOKENS_STEP = AB * AS
 
 
+RANK_TIMEOUT_S = float(os.environ.get("KF_BENCH_RANK_TIMEOUT_S", "600"))   # the parent's patience with its rank processes
+PHASE_TIMEOUT_S = float(os.environ.get("KF_BENCH_PHASE_TIMEOUT_S", "180"))  # a rank's own patience with one collective phase
+
+
+@contextmanager
+def deadline(what: str, seconds: float = None):
+    """Bounds a phase that can wait on OTHER ranks (communicator construction, a barrier, a timed loop with collectives): if it has not
+    ended after `seconds`, this process says so on stderr and exits with status 124 - a fresh exit, never a re-exec - so that a rank stuck in
+    ncclCommInitRank or in a collective takes the job down (torch.distributed.run and launch_ranks both end the other ranks when one
+    fails) instead of holding the GPUs until somebody else's limit fires."""
+    seconds = PHASE_TIMEOUT_S if seconds is None else seconds
+    done = threading.Event()
+
+    def watch():
+        if not done.wait(seconds):
+            print(f"[bench.py] rank {os.environ.get('RANK', '0')}: '{what}' did not finish within {seconds:.0f} s - giving up", file=sys.stderr, flush=True)
+            os._exit(124)
+    t = threading.Thread(target=watch, daemon=True)
+    t.start()
+    try:
+        yield
+    finally:
+        done.set()
+
+
 def bf16_random(rng, shape):
     x = rng.uniform(-1.0, 1.0, size=shape).astype(np.float32)
     u = x.view(np.uint32)
@@ -76,6 +103,35 @@ def device_src_sha() -> str:
             h.update(p.name.encode())
             h.update(p.read_bytes())
     return h.hexdigest()[:16]
+
+
+# which device sources each kind of committed profile depends on (tests/test_profiles_fresh.py): a profile is STALE - and must be
+# re-collected before it is quoted - when any of its files has changed since it was taken
+BENCH_SOURCES = ("attention.hip", "gemm.hip", "common.h", "runtime.hip")
+MEMBOUND_SOURCES = ("elementwise.hip", "reduce.hip", "norm.hip", "index.hip", "sort.hip", "common.h", "offset_calc.h", "runtime.hip")
+
+
+def device_src_shas(names=None) -> dict:
+    """Per-file content hashes of the device sources (all of them, or the `names` subset)."""
+    out = {}
+    for p in sorted((ROOT / "kfunca_amd" / "csrc" / "device").glob("*")):
+        if p.suffix in (".hip", ".h") and (names is None or p.name in names):
+            out[p.name] = hashlib.sha256(p.read_bytes()).hexdigest()[:16]
+    return out
+
+
+def stamp(names) -> dict:
+    """What a profile-writing tool puts into its output: the tree-wide hash (as before) and the per-file hashes it depends on."""
+    return {"device_src_sha": device_src_sha(), "device_src_files": device_src_shas(names)}
+
+
+def stamp_is_current(obj: dict, names) -> bool:
+    """True when a profile's stamp matches THIS tree on the files it depends on (an old stamp without per-file hashes must match tree-wide)."""
+    files = obj.get("device_src_files")
+    if files:
+        now = device_src_shas(names)
+        return all(files.get(n) == h for n, h in now.items())
+    return obj.get("device_src_sha") == device_src_sha()
 
 
 class Workload:
@@ -106,8 +162,10 @@ class Workload:
         self.aws = H.DevBuf(self.aws_bytes)
         H.device_sync()
 
-    def step(self, stream, pg=None, comm_stream=None, ev_grad=None, ev_comm=None, comm_events=None):
+    def step(self, stream, pg=None, comm_stream=None, ev_grad=None, ev_comm=None, comm_events=None, no_comm=False):
         H, n, s = self.H, GEMM_N, stream
+        if no_comm:  # the same step with the collective left out (the "off" arm of exposed_comm_ms)
+            pg = None
         if pg is not None and ev_comm.recorded:  # dW of the previous step must be fully reduced before it is rewritten
             H.stream_wait_event(s, ev_comm)
         H.gemm(H.BF16, 0, 0, n, n, n, 1.0, self.A.ptr, n, self.W.ptr, n, 0.0, self.Cc.ptr, n, 0, None, None, 0, s)
@@ -134,20 +192,30 @@ class Workload:
 CHECK_NOTES = {}
 
 
-def spot_check(H, wl):
+def spot_check(H, wl, check_dw=True):
     """After timing: outputs left in the timed buffers against the oracle (the checker; never inside the timed region).
-    GEMM: 8 rows of C = A W (bf16 inputs, f32 accumulation, one rounding). Attention: all of head (0, 0) under the scale-aware
+    GEMM: 8 rows of C = A W and of both products of the backward pair, dA = dC W^T and dW = A^T dC (bf16 inputs, f32 accumulation,
+    one rounding). Attention: all of head (0, 0) under the scale-aware
     bounds (see below) and the checksum sum_n dV[n] = sum_m dO[m]."""
     from oracle import oracle as O
     n = GEMM_N
     rows = [0, 1, 127, 128, 2047, 3000, 4094, 4095]
-    got = np.empty((len(rows), n), dtype=np.uint16)
-    for i, r in enumerate(rows):
-        H.check(H.lib().kf_memcpy_d2h(got[i].ctypes.data, wl.Cc.ptr + r * n * 2, n * 2, None))
-    want = O.bf16_to_f32(O.gemm(wl.A_host[rows], wl.W_host, code=O.BF16)).astype(np.float64)
-    mag = np.abs(O.bf16_to_f32(wl.A_host[rows]).astype(np.float64)) @ np.abs(O.bf16_to_f32(wl.W_host).astype(np.float64))
-    g = O.bf16_to_f32(got).astype(np.float64)
-    gemm_ok = bool((np.abs(g - want) <= 2.0 ** -7 * np.abs(want) + 2e-6 * mag + 1e-6).all())
+    f64 = lambda x: O.bf16_to_f32(x).astype(np.float64)
+
+    def rows_ok(buf, want_bits, mag):
+        got = np.empty((len(rows), n), dtype=np.uint16)
+        for i, r in enumerate(rows):
+            H.check(H.lib().kf_memcpy_d2h(got[i].ctypes.data, buf.ptr + r * n * 2, n * 2, None))
+        want = f64(want_bits)
+        return bool((np.abs(f64(got) - want) <= 2.0 ** -7 * np.abs(want) + 2e-6 * mag + 1e-6).all())
+
+    dC_host = wl.dC.to_numpy((n, n), np.uint16)
+    gemm_ok = rows_ok(wl.Cc, O.gemm(wl.A_host[rows], wl.W_host, code=O.BF16), np.abs(f64(wl.A_host[rows])) @ np.abs(f64(wl.W_host)))
+    # the backward pair of the same launch (gemm_bf16_mfma_pair): rows of dA = dC W^T and of dW = A^T dC under the same bound
+    # (bar: the reference's own GEMM test, test/test_gemm.py:9-17, is a forward-only f64 case; the backward is this repository's)
+    da_ok = rows_ok(wl.dA, O.gemm(dC_host[rows], wl.W_host, trans_b=True, code=O.BF16), np.abs(f64(dC_host[rows])) @ np.abs(f64(wl.W_host)).T)
+    a_cols = np.ascontiguousarray(wl.A_host[:, rows])
+    dw_ok = rows_ok(wl.dW, O.gemm(a_cols, dC_host, trans_a=True, code=O.BF16), np.abs(f64(a_cols)).T @ np.abs(f64(dC_host))) if check_dw else None
     # attention: EVERY element of head (0, 0) - O, LSE, dQ, dK, dV at S = 4096 - against the double-precision oracle under the
     # scale-aware bounds of oracle/checks.py (per element, per row, per head; no absolute tolerance), and the same head of the last
     # batch element (the batch is one element replicated) bit-identical to it
@@ -172,8 +240,11 @@ def spot_check(H, wl):
     bound = 2.0 ** -8 * (np.abs(O.bf16_to_f32(got["dv"][0, 0]).astype(np.float64)).sum(0) + np.abs(O.bf16_to_f32(wl.host["do"]).astype(np.float64)).sum(0) / math.sqrt(AS))
     bwd_ok = bool((np.abs(dv_sum - do_sum) <= bound).all())
     CHECK_NOTES["attn_head00_worst_fraction_of_bound"] = attn_note  # per output: max of the element / row / head figures (1 = at the bound)
-    return {"gemm_rows_vs_oracle": gemm_ok, "attn_head00_vs_oracle_scale_aware": attn_ok,
-            "attn_last_batch_bit_identical": bool(same), "attn_dv_checksum": bwd_ok}
+    out = {"gemm_rows_vs_oracle": gemm_ok, "gemm_dA_rows_vs_oracle": da_ok, "attn_head00_vs_oracle_scale_aware": attn_ok,
+           "attn_last_batch_bit_identical": bool(same), "attn_dv_checksum": bwd_ok}
+    if dw_ok is not None:  # with a communicator dW holds the SUM over ranks: that is check_allreduce's business
+        out["gemm_dW_rows_vs_oracle"] = dw_ok
+    return out
 
 
 def check_allreduce(H, wl, pg, stream):
@@ -237,14 +308,41 @@ def launch_ranks(args) -> int:
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [p.wait() for p in procs]
+    out0, codes = supervise(procs, RANK_TIMEOUT_S)
     lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
     for ln in lines[:-1]:
         print(ln, file=sys.stderr)  # library banners etc.: THE line is the last one
-    if lines:
+    if lines and all(c == 0 for c in codes):
         print(lines[-1], flush=True)
     return max(abs(c) for c in codes)
+
+
+def supervise(procs, timeout_s):
+    """Waits for the rank processes: returns (rank 0's stdout, exit codes). When one of them fails, or the whole job outlives
+    `timeout_s`, the OTHERS are ended (these exact children, by handle) - one rank's hang must not keep the rest, and their GPUs, waiting."""
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read() if procs[0].stdout else ""), daemon=True)
+    reader.start()
+    t_end = time.monotonic() + timeout_s
+    why = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if any(c not in (None, 0) for c in codes):
+            why = f"rank {next(i for i, c in enumerate(codes) if c not in (None, 0))} exited with status {next(c for c in codes if c not in (None, 0))}"
+        elif time.monotonic() > t_end:
+            why = f"the job did not finish within {timeout_s:.0f} s"
+        if why:
+            print(f"[bench.py] {why}: ending the remaining ranks", file=sys.stderr, flush=True)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            codes = [p.wait() for p in procs]  # the killed ones report -9: the job's status is non-zero
+            break
+        time.sleep(0.05)
+    reader.join(timeout=5)
+    return (out0[0] if out0 else ""), [c if c is not None else 1 for c in codes]
 
 
 def dry_run_cpu(args, rank, world):
@@ -294,7 +392,11 @@ def main():
     pg = None
     force_comm = bool(os.environ.get("KF_BENCH_FORCE_COMM"))  # exercises the collective path on one GPU
     if world > 1 or force_comm:
-        pg = parallel.ProcessGroup(backend="rccl")  # gloo rendezvous (plumbing) + RCCL communicator through the C ABI
+        if rank == 0:  # RCCL's own warnings of rank 0 go to stderr (stdout carries THE line)
+            os.environ.setdefault("NCCL_DEBUG", "WARN")
+            os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+        with deadline("rendezvous + ncclCommInitRank"):
+            pg = parallel.ProcessGroup(backend="rccl")  # gloo rendezvous (plumbing) + RCCL communicator through the C ABI
         C.CDLL(None).fflush(None)  # RCCL leaves its version banner in the C stdout buffer: out with it now
 
     wl = Workload(H, rank)
@@ -304,29 +406,41 @@ def main():
     if pg:
         ev_comm.recorded = False
 
-    def barrier():
-        H.device_sync()
-        if pg is not None:
-            pg.barrier()
+    no_comm_env = bool(os.environ.get("KF_BENCH_NO_COMM"))  # A/B by hand: the main loop without the collective
 
-    def run_step(comm_events=None):
-        wl.step(stream.handle, pg, comm_stream.handle if pg else None, ev_grad, ev_comm, comm_events)
+    def barrier():
+        with deadline("device sync + barrier"):
+            H.device_sync()
+            if pg is not None:
+                pg.barrier()
+
+    def run_step(comm_events=None, no_comm=no_comm_env):
+        wl.step(stream.handle, pg, comm_stream.handle if pg else None, ev_grad, ev_comm, comm_events, no_comm=no_comm)
+
+    def timed(steps, comm_events=None, no_comm=no_comm_env):
+        """EXACTLY `steps` steps between two barrier + device-sync brackets; the maximum over ranks."""
+        barrier()
+        t0 = time.perf_counter()
+        with deadline(f"{steps} timed steps", PHASE_TIMEOUT_S + 0.05 * steps):
+            for _ in range(steps):
+                run_step(comm_events, no_comm)
+        barrier()
+        dt = time.perf_counter() - t0
+        return pg.max_over_ranks(dt) if pg is not None else dt
 
     for _ in range(args.warmup):
         run_step()
     barrier()
     H.profile_reset()
     H.profile_enable(True)
-    comm_events = [] if pg else None
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run_step(comm_events)
-    barrier()
-    t1 = time.perf_counter()
+    comm_events = [] if (pg and not no_comm_env) else None
+    elapsed = timed(args.steps, comm_events)
     H.profile_enable(False)
-    elapsed = t1 - t0
-    if pg is not None:
-        elapsed = pg.max_over_ranks(elapsed)
+    # attribution at N > 1 (VERDICT round 3 #6): the SAME loop once more with the collective left out. The difference is the
+    # communication time the step could not hide (exposed); what the all-reduce took on its own stream is `allreduce.ms`.
+    elapsed_off = None
+    if pg is not None and not no_comm_env:
+        elapsed_off = timed(args.steps, None, no_comm=True)
     prof = H.profile_results()
     samples = H.profile_samples()  # every launch's own HIP-event duration: percentiles, run-to-run spread
 
@@ -334,15 +448,7 @@ def main():
     sustained = None
     if args.sustain_seconds > 0:
         n_sus = max(args.steps, int(math.ceil(args.sustain_seconds / max(elapsed / args.steps, 1e-6))))
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(n_sus):
-            run_step()
-        barrier()
-        t_sus = time.perf_counter() - t0
-        if pg is not None:
-            t_sus = pg.max_over_ranks(t_sus)
-        sustained = (n_sus, t_sus)
+        sustained = (n_sus, timed(n_sus))
 
     checks = {}
     if pg is not None and (args.check or force_comm):
@@ -350,7 +456,7 @@ def main():
     rc = 0
     if rank == 0:
         if world == 1 or args.check:
-            checks.update(spot_check(H, wl))
+            checks.update(spot_check(H, wl, check_dw=(pg is None or world == 1)))
         ms_step = elapsed / args.steps * 1e3
         kern = {k: {"avg_ms": ms / max(cnt, 1), "launches": cnt} for k, (ms, cnt) in prof.items()}
         for k, v in kern.items():
@@ -371,7 +477,7 @@ def main():
         traffic, traffic_src = None, None
         for tfile in sorted((ROOT / "profiles").glob("r*_pmc_traffic.json"), reverse=True):
             tj = json.loads(tfile.read_text())
-            if tj.get("device_src_sha") == device_src_sha():
+            if stamp_is_current(tj, BENCH_SOURCES):
                 traffic, traffic_src = tj.get(dom, {}).get("bytes_per_launch"), tfile.name
                 break
         out = {
@@ -403,9 +509,16 @@ def main():
             ms = [e0.elapsed_ms(e1) for e0, e1 in comm_events]
             nbytes = GEMM_N * GEMM_N * 2
             t = sum(ms) / len(ms) * 1e-3
-            out["allreduce"] = {"ms": t * 1e3, "message_bytes": nbytes, "dtype": "bf16",
+            out["allreduce"] = {"ms": t * 1e3, "ms_p50": float(np.percentile(ms, 50)), "ms_max": float(max(ms)), "message_bytes": nbytes, "dtype": "bf16",
                                 "busbw_GBps": 2.0 * (world - 1) / world * nbytes / t / 1e9 if world > 1 else 0.0,
                                 "xgmi_peak_GBps": XGMI_PEAK, "overlapped_with": "attention forward + backward"}
+        if elapsed_off is not None:  # where the step time of an N-GPU job goes: compute alone, compute + collective, the collective alone
+            ms_off = elapsed_off / args.steps * 1e3
+            exposed = ms_step - ms_off
+            ar = out.get("allreduce", {}).get("ms")
+            out["ms_per_step_no_comm"] = ms_off
+            out["exposed_comm_ms"] = exposed
+            out["overlap_efficiency"] = (max(0.0, min(1.0, 1.0 - exposed / ar)) if ar else None)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         if not all(checks.values()):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KF_ABI_VERSION 5 /* 2: + kf_reduce_moments*, KF_EW_*_SCALAR, kf_graph_*, kf_attn_*_scaled; 3: + kf_sort*; 4: + kf_knobs_reload, kf_norm_*, kf_index_get, kf_gemm_ex, KF_EPI_*; 5: + kf_gemm_grouped_single_grid, kf_allreduce_sum_multi, kf_profile_samples, kf_attn_bwd accepts any workspace >= the statistics (all additive) */
+#define KF_ABI_VERSION 6 /* 6: + KF_ERR_OOM from kf_malloc; 2: + kf_reduce_moments*, KF_EW_*_SCALAR, kf_graph_*, kf_attn_*_scaled; 3: + kf_sort*; 4: + kf_knobs_reload, kf_norm_*, kf_index_get, kf_gemm_ex, KF_EPI_*; 5: + kf_gemm_grouped_single_grid, kf_allreduce_sum_multi, kf_profile_samples, kf_attn_bwd accepts any workspace >= the statistics (all additive) */
 
 /* ---- status ------------------------------------------------------------------------------ */
 enum {
@@ -36,7 +36,8 @@ enum {
     KF_ERR_UNSUPPORTED = 3, /* valid request the device layer has no kernel for              */
     KF_ERR_INDEX_RANGE = 4, /* descriptor not 32-bit indexable; caller must split (a6)       */
     KF_ERR_WORKSPACE = 5,   /* workspace missing or too small                                */
-    KF_ERR_COMM = 6         /* RCCL failure                                                  */
+    KF_ERR_COMM = 6,        /* RCCL failure                                                  */
+    KF_ERR_OOM = 7          /* kf_malloc: the device has no room for this allocation; nothing else is affected (HIP's sticky last-error is cleared), the caller may free and retry */
 };
 
 /* ---- dtypes: reference ScalarType order (scalar_type.h:9-27) ------------------------------ */

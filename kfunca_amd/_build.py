@@ -166,11 +166,18 @@ def build_all(force: bool = False):
         build_core(force)
     if (ROOT / "oracle" / "oracle.c").exists():
         build_oracle(force)
-    build_mutant(force)
+    # test-only extras: a failure here must not take the product build down with it (the tests that need them say so)
+    try:
+        build_mutant(force)
+    except Exception as e:  # noqa: BLE001
+        print(f"[kfunca_amd._build] mutation library NOT built (tests/test_gpu_attention_mutants.py will fail): {e}", file=sys.stderr)
     if Path("/root/reference/src/core/tensor.cpp").exists():  # build container only: the reference's host half on our device library
-        sys.path.insert(0, str(ROOT))
-        from oracle import build_ref_host
-        build_ref_host.build(with_module=True)
+        try:
+            sys.path.insert(0, str(ROOT))
+            from oracle import build_ref_host
+            build_ref_host.build(with_module=True)
+        except Exception as e:  # noqa: BLE001
+            print(f"[kfunca_amd._build] oracle/_ref NOT built (tests/test_seam_links.py, test_gpu_reference_host.py will fail): {e}", file=sys.stderr)
 
 
 if __name__ == "__main__":

@@ -331,6 +331,9 @@ PYBIND11_MODULE(_C, m) {
           py::arg("reduce_dim") = 0, py::arg("resize_outputs") = true, py::arg("aliases") = std::vector<int>(), py::arg("check_mem_overlap") = true);
     m.def("_promote_types", &promote_types);
     m.def("_pool_index", &utils::memory::DeviceAllocator::pool_index);
+    m.def("release_cached", [](int device) { return utils::memory::DeviceAllocator::GetInstance()->release_cached(device); }, py::arg("device") = 0);
+    m.def("_alloc_fail_above", [](size_t bytes) { utils::memory::DeviceAllocator::GetInstance()->debug_fail_above(bytes); });
+    m.def("_alloc_oom_retries", []() { return utils::memory::DeviceAllocator::GetInstance()->oom_retries(); });
 
     py::class_<Tensor>(m, "tensor", py::module_local())
         .def("__copy__", [](const Tensor &self) { return Tensor(self); })

@@ -53,7 +53,18 @@ DataPtr DeviceAllocator::allocate(size_t size, int device) {
             pool.erase(it);
         } else {
             void *p = nullptr;
-            DEV_CALL(kf_malloc(&p, rounded));
+            int st = (fail_above_ && rounded > fail_above_) ? (int)KF_ERR_OOM : kf_malloc(&p, rounded);
+            if (st == KF_ERR_OOM) {
+                // the driver is out of room while this cache may sit on gigabytes nobody uses: hand every idle block of the device back
+                // (the reference never returns memory: device_allocator.cpp:37-72, `dfree` is never called) and try once more
+                ++oom_retries_;
+                if (capturing_ == 0) release_cached_locked(device); // (hipFree is not a capturable operation)
+                st = (fail_above_ && rounded > fail_above_) ? (int)KF_ERR_OOM : kf_malloc(&p, rounded);
+            }
+            if (st == KF_ERR_OOM)
+                throw utils::OutOfMemory(utils::concat("[device error in kf_malloc, status ", st, "] "),
+                                         utils::concat("out of device memory: ", rounded, " bytes requested on device ", device));
+            dev::check(st, "kf_malloc(&p, rounded)");
             b = new Block{p, rounded, device, next_id_++, false, 0};
             by_ptr_[p] = b;
             ++driver_allocs_;
@@ -87,6 +98,39 @@ void DeviceAllocator::free(void *ptr) {
     auto &pools = free_[b->device];
     if (pools.empty()) pools.resize(kNumPools);
     pools[pool_index(b->size)].insert(b);
+}
+
+size_t DeviceAllocator::release_cached_locked(int device) {
+    size_t freed = 0;
+    auto dv = free_.find(device);
+    if (dv == free_.end()) return 0;
+    for (Pool &pool : dv->second) {
+        for (Block *b : pool) { // idle, owned by no graph (graph-held blocks live in graph_free_)
+            if (kf_free(b->ptr) != KF_OK) continue;
+            freed += b->size;
+            by_ptr_.erase(b->ptr);
+            delete b;
+        }
+        pool.clear();
+    }
+    return freed;
+}
+
+size_t DeviceAllocator::release_cached(int device) {
+    dev::set_device(device);
+    dev::synchronize(device); // nothing queued may still touch a block that was freed to the cache a moment ago
+    std::lock_guard<std::mutex> lk(mu_);
+    return release_cached_locked(device);
+}
+
+void DeviceAllocator::debug_fail_above(size_t bytes) {
+    std::lock_guard<std::mutex> lk(mu_);
+    fail_above_ = bytes;
+}
+
+uint64_t DeviceAllocator::oom_retries() {
+    std::lock_guard<std::mutex> lk(mu_);
+    return oom_retries_;
 }
 
 uint64_t DeviceAllocator::begin_capture(int device) {

@@ -65,6 +65,12 @@ public:
     void end_capture(uint64_t graph_id);
     void release_graph(uint64_t graph_id);
 
+    // Hands every idle cached block of `device` (owned by no live graph) back to the driver; returns the bytes released. allocate()
+    // does this by itself, once, when the driver reports out-of-memory (KF_ERR_OOM), before it gives up with utils::OutOfMemory.
+    size_t release_cached(int device);
+    uint64_t oom_retries();               // how often allocate() took that path
+    void debug_fail_above(size_t bytes);  // test hook (tests/test_gpu_host_api.py): driver allocations larger than this fail as out-of-memory; 0 = off
+
     struct Stats { size_t active_blocks, cached_blocks, active_bytes, cached_bytes, driver_allocs, graph_blocks, graph_bytes; };
     Stats stats(int device = -1);
     static int pool_index(size_t size);
@@ -88,6 +94,9 @@ private:
     uint64_t next_graph_ = 0;
     uint32_t next_id_ = 0;
     size_t driver_allocs_ = 0;
+    size_t fail_above_ = 0;
+    uint64_t oom_retries_ = 0;
+    size_t release_cached_locked(int device);
 };
 
 } // namespace memory

@@ -22,6 +22,12 @@ private:
     std::string where_, msg_, text_;
 };
 
+// the device has no room for an allocation (KF_ERR_OOM): the one device error a caller can sensibly recover from
+class OutOfMemory : public Error {
+public:
+    using Error::Error;
+};
+
 template <typename... Args>
 inline std::string concat(const Args &...args) {
     std::ostringstream os;

@@ -48,20 +48,28 @@ void comm_destroy() {
     g_comm = CommState{};
 }
 
-bool comm_initialized() { return g_comm.comm != nullptr; }
-int comm_rank() { return g_comm.rank; }
-int comm_world_size() { return g_comm.world; }
+namespace {
+CommState comm_snapshot() { // the communicator as of now, read under the lock that comm_init / comm_destroy write it under
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    return g_comm;
+}
+} // namespace
+bool comm_initialized() { return comm_snapshot().comm != nullptr; }
+int comm_rank() { return comm_snapshot().rank; }
+int comm_world_size() { return comm_snapshot().world; }
 
 Tensor &all_reduce_(Tensor &t) {
     check_dense(t, "all_reduce_");
-    CHECK_FAIL(comm_initialized(), "all_reduce_: no communicator (comm_init)");
-    DEV_CALL(kf_allreduce_sum(g_comm.comm, t.data_ptr(), (size_t)t.numel(), code(t.dtype()), dev::stream(t.device())));
+    const CommState cs = comm_snapshot();
+    CHECK_FAIL(cs.comm != nullptr, "all_reduce_: no communicator (comm_init)");
+    DEV_CALL(kf_allreduce_sum(cs.comm, t.data_ptr(), (size_t)t.numel(), code(t.dtype()), dev::stream(t.device())));
     return t;
 }
 
 void all_reduce_(std::vector<Tensor> &ts) {
     if (ts.empty()) return;
-    CHECK_FAIL(comm_initialized(), "all_reduce_: no communicator (comm_init)");
+    const CommState cs = comm_snapshot();
+    CHECK_FAIL(cs.comm != nullptr, "all_reduce_: no communicator (comm_init)");
     std::vector<void *> bufs;
     std::vector<size_t> counts;
     for (auto &t : ts) {
@@ -70,7 +78,7 @@ void all_reduce_(std::vector<Tensor> &ts) {
         bufs.push_back(t.data_ptr());
         counts.push_back((size_t)t.numel());
     }
-    DEV_CALL(kf_allreduce_sum_multi(g_comm.comm, (int)ts.size(), bufs.data(), counts.data(), code(ts[0].dtype()), dev::stream(ts[0].device())));
+    DEV_CALL(kf_allreduce_sum_multi(cs.comm, (int)ts.size(), bufs.data(), counts.data(), code(ts[0].dtype()), dev::stream(ts[0].device())));
 }
 
 // ---- GradBucket ---------------------------------------------------------------------------------------------------------------
@@ -123,6 +131,7 @@ std::shared_ptr<GradBucket> GradBucket::create(const std::vector<Tensor> &params
         for (int i = b->chunks_[c].first; i <= b->chunks_[c].last; ++i) b->chunk_of_[i] = (int)c;
     for (size_t i = 0; i < params.size(); ++i) b->slots_.push_back(b->flat_.narrow(0, b->offsets_[i], numels[i]).view(params[i].sizes()));
     b->have_.assign(params.size(), 0);
+    b->taken_.assign(params.size(), 0);
     b->fired_.assign(b->chunks_.size(), 0);
     b->missing_.resize(b->chunks_.size());
     for (size_t c = 0; c < b->chunks_.size(); ++c) b->missing_[c] = b->chunks_[c].last - b->chunks_[c].first + 1;
@@ -138,12 +147,12 @@ std::shared_ptr<GradBucket> GradBucket::create(const std::vector<Tensor> &params
 }
 
 GradBucket::~GradBucket() {
+    // nothing may still be queued behind these events when they go: drain the communication stream first. The parameters hold the
+    // bucket weakly (TensorImpl::sink_), so dropping the last handle lands here without a detach().
+    if (comm_stream_) kf_stream_sync(comm_stream_);
     for (void *e : ev_ready_) if (e) kf_event_destroy(e);
     for (void *e : ev_done_) if (e) kf_event_destroy(e);
-    if (comm_stream_) {
-        kf_stream_sync(comm_stream_);
-        kf_stream_destroy(comm_stream_);
-    }
+    if (comm_stream_) kf_stream_destroy(comm_stream_);
 }
 
 void GradBucket::attach() {
@@ -157,13 +166,21 @@ void GradBucket::attach() {
 
 void GradBucket::detach() {
     for (auto &p : params_)
-        if (p.impl()->sink_.get() == this) p.impl()->sink_.reset();
+        if (p.impl()->sink_.lock().get() == this) p.impl()->sink_.reset();
     attached_ = false;
 }
 
 Tensor GradBucket::slot(TensorImpl *leaf) {
     auto it = index_.find(leaf);
     CHECK_FAIL(it != index_.end(), "GradBucket: this tensor is not one of the bucket's parameters");
+    return slots_[it->second];
+}
+
+Tensor GradBucket::take_slot(TensorImpl *leaf) {
+    auto it = index_.find(leaf);
+    CHECK_FAIL(it != index_.end(), "GradBucket: this tensor is not one of the bucket's parameters");
+    if (taken_[it->second]) return Tensor(); // a second producer in this pass: it allocates its own and the engine adds
+    taken_[it->second] = 1;
     return slots_[it->second];
 }
 
@@ -181,13 +198,14 @@ void GradBucket::arrived(TensorImpl *leaf) {
 void GradBucket::fire(int c) {
     fired_[c] = 1;
     fired_order_.push_back(c);
-    if (!comm_initialized()) return; // a single process without a communicator: the sum over one rank is the gradient itself
+    const CommState cs = comm_snapshot();
+    if (!cs.comm) return; // a single process without a communicator: the sum over one rank is the gradient itself
     void *compute = dev::stream(device_);
     // the chunk's last gradient has been ENQUEUED on the compute stream: the collective waits for it there, not on the host
     DEV_CALL(kf_event_record(ev_ready_[c], compute));
     DEV_CALL(kf_stream_wait_event(comm_stream_, ev_ready_[c]));
     char *base = static_cast<char *>(flat_.data_ptr()) + chunks_[c].offset * flat_.element_size_in_bytes();
-    DEV_CALL(kf_allreduce_sum(g_comm.comm, base, (size_t)chunks_[c].numel, code(flat_.dtype()), comm_stream_));
+    DEV_CALL(kf_allreduce_sum(cs.comm, base, (size_t)chunks_[c].numel, code(flat_.dtype()), comm_stream_));
     DEV_CALL(kf_event_record(ev_done_[c], comm_stream_));
 }
 
@@ -200,6 +218,7 @@ void GradBucket::wait() {
     }
     pass_open_ = false;
     std::fill(have_.begin(), have_.end(), 0);
+    std::fill(taken_.begin(), taken_.end(), 0);
     std::fill(fired_.begin(), fired_.end(), 0);
     for (size_t c = 0; c < chunks_.size(); ++c) missing_[c] = chunks_[c].last - chunks_[c].first + 1;
 }

@@ -52,6 +52,7 @@ public:
     int64_t reduced_bytes() const;
 
     Tensor slot(TensorImpl *leaf) override;
+    Tensor take_slot(TensorImpl *leaf) override;
     void arrived(TensorImpl *leaf) override;
 
 private:
@@ -62,7 +63,7 @@ private:
     std::vector<int64_t> offsets_;
     std::vector<Chunk> chunks_;
     std::vector<int> chunk_of_, missing_, fired_order_;
-    std::vector<char> have_, fired_;
+    std::vector<char> have_, fired_, taken_;
     std::vector<void *> ev_ready_, ev_done_;
     void *comm_stream_ = nullptr;
     Tensor flat_;

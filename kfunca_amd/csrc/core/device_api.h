@@ -12,6 +12,7 @@
 namespace dev {
 
 inline void check(int status, const char *what) {
+    if (status == KF_ERR_OOM) throw utils::OutOfMemory(utils::concat("[device error in ", what, ", status ", status, "] "), kf_last_error());
     if (status != KF_OK) {
         throw utils::Error(utils::concat("[device error in ", what, ", status ", status, "] "), kf_last_error());
     }

@@ -430,6 +430,17 @@ void gemm_any(ScalarType dt, bool ta, bool tb, int64_t M, int64_t N, int64_t K, 
     }
 }
 
+// Where a weight gradient is written: a bucketed leaf whose gradient starts empty takes it straight into its bucket slot (update_grad then
+// has nothing to copy) - but only the FIRST product of a backward pass that asks (GradSink::take_slot): a weight used by two products gets
+// a fresh tensor for the second, and the engine sums the two.
+Tensor grad_target(const Tensor &b) {
+    TensorImpl *bi = b.impl();
+    if (!b.has_grad_fn() && !bi->grad_)
+        if (std::shared_ptr<GradSink> sink = bi->sink_.lock())
+            if (Tensor s = sink->take_slot(bi); s.defined()) return s;
+    return empty(b.sizes(), b.dtype(), b.device());
+}
+
 // dA = alpha * dC B^T, dB = alpha * A^T dC with A flattened to [M,K] (no reference counterpart)
 class GemmGradFunction : public GradFunction {
 public:
@@ -446,9 +457,7 @@ public:
             // (kf_gemm_grouped_single_grid). Where it cannot - too many tiles, or a skinny product such as dA of x[256, 4096] W[4096, 16384] -
             // the two ordinary calls below run, which carry the split-K scratch kf_gemm_grouped's fall-back would not have.
             // a bucketed weight whose gradient starts empty takes dW straight into its bucket slot (update_grad then has nothing to copy)
-            TensorImpl *bi = b.impl();
-            const bool to_slot = !b.has_grad_fn() && bi->sink_ && !bi->grad_;
-            Tensor da = empty(a.sizes(), a.dtype(), a.device()), db = to_slot ? bi->sink_->slot(bi) : empty(b.sizes(), b.dtype(), b.device());
+            Tensor da = empty(a.sizes(), a.dtype(), a.device()), db = grad_target(b);
             kf_gemm_problem p[2] = {};
             p[0].trans_a = 0; p[0].trans_b = 1; p[0].M = M; p[0].N = K; p[0].K = N; p[0].alpha = alpha_; p[0].beta = 0.f;
             p[0].A = g2.data_ptr(); p[0].lda = N; p[0].B = b.data_ptr(); p[0].ldb = N; p[0].C = da.data_ptr(); p[0].ldc = K;
@@ -467,8 +476,7 @@ public:
             gemm_any(a.dtype(), false, true, M, K, N, alpha_, g2, b, 0.f, c2, a.device());
         }
         if (b.requires_grad()) {
-            TensorImpl *bi = b.impl();
-            out[1] = (!b.has_grad_fn() && bi->sink_ && !bi->grad_) ? bi->sink_->slot(bi) : empty(b.sizes(), b.dtype(), b.device());
+            out[1] = grad_target(b);
             gemm_any(a.dtype(), true, false, K, N, M, alpha_, a2, g2, 0.f, out[1], b.device());
         }
         return out;
@@ -546,8 +554,7 @@ public:
             gemm_any(a.dtype(), false, true, M, K, N, alpha_, dt, b, 0.f, c2, a.device());
         }
         if (b.requires_grad()) {
-            TensorImpl *bi = b.impl(); // (a bucketed weight: dW straight into its bucket slot, as in GemmGradFunction)
-            out[1] = (!b.has_grad_fn() && bi->sink_ && !bi->grad_) ? bi->sink_->slot(bi) : empty(b.sizes(), b.dtype(), b.device());
+            out[1] = grad_target(b); // (a bucketed weight: dW straight into its bucket slot, as in GemmGradFunction)
             gemm_any(a.dtype(), true, false, K, N, M, alpha_, a2, dt, 0.f, out[1], b.device());
         }
         return out;
@@ -705,7 +712,7 @@ static DataPtr attn_bwd_scratch(int dt, int64_t B, int64_t H, int64_t Sq, int64_
         try {
             bytes = need;
             return DeviceAllocator::GetInstance()->allocate(need, device);
-        } catch (const utils::Error &) {
+        } catch (const utils::OutOfMemory &) { // only that: any other failure is not cured by asking for less
             if (need <= floor_) throw;
             need = floor_ + (need - floor_) / 2;
             if (need - floor_ < ((size_t)1 << 20)) need = floor_;

@@ -328,17 +328,17 @@ Tensor &Tensor::index_put_(const std::vector<Tensor> &idx, const Tensor &v) { re
 // ---- autograd (reference tensor.cpp:75-126) ------------------------------------------------------
 void Tensor::update_grad(Tensor grad) {
     auto *impl = impl_.get();
-    if (impl->sink_) {
+    if (std::shared_ptr<GradSink> sink = impl->sink_.lock()) {
         // a bucketed leaf: its gradient lives in the bucket's flat buffer. A backward function that knew the slot (GemmGradFunction
         // writes dW straight into it) hands the slot back - nothing to copy; anything else is copied in (first gradient) or added.
-        Tensor slot = impl->sink_->slot(impl);
+        Tensor slot = sink->slot(impl);
         if (!impl->grad_) {
             if (grad.data_ptr() != slot.data_ptr()) slot.copy_(grad);
             impl->grad_ = std::make_unique<Tensor>(slot);
         } else {
             *impl->grad_ += grad;
         }
-        impl->sink_->arrived(impl);
+        sink->arrived(impl);
         return;
     }
     if (impl->grad_) {

@@ -77,6 +77,11 @@ class TensorImpl;
 struct GradSink {
     virtual ~GradSink() = default;
     virtual Tensor slot(TensorImpl *leaf) = 0;     // the leaf's gradient storage inside the bucket
+    // The slot for a backward function to WRITE its gradient into directly (beta = 0), handed out at most ONCE per backward pass: a
+    // weight that feeds two products of one graph (weight tying) gets the slot for the first of them and an undefined tensor - "allocate
+    // your own" - for the second, so the engine's fan-in sum sees two different tensors (two beta = 0 writes into the
+    // same slot left 2 dW_last instead of dW_1 + dW_2).
+    virtual Tensor take_slot(TensorImpl *leaf) = 0;
     virtual void arrived(TensorImpl *leaf) = 0;    // the leaf's gradient of this pass is in its slot
 };
 
@@ -113,7 +118,7 @@ public:
     void as_strided_(const std::vector<int64_t> &sizes, const std::vector<int64_t> &strides, int64_t storage_offset);
 
     std::unique_ptr<Tensor> grad_; // accumulated gradient of a leaf
-    std::shared_ptr<GradSink> sink_; // set by GradBucket::attach: gradients are written into the bucket
+    std::weak_ptr<GradSink> sink_;   // set by GradBucket::attach: gradients are written into the bucket (weak: the bucket owns its parameters, not the reverse)
 
 private:
     void refresh_();

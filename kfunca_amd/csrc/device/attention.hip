@@ -2301,7 +2301,10 @@ static int64_t ds_group(int64_t nbh, int64_t Sq, int64_t Skv, size_t budget) { /
     if (g >= 8) g -= g % 8;
     return g;
 }
-static size_t ds_cap() { return (size_t)knob_int(KNOB_ATTN_DS_CAP_MB, 16384) << 20; }
+static size_t ds_cap() { // KF_ATTN_DS_CAP_MB, clamped to [0, 4 Ti MB): a negative or absurd value must not wrap the shift
+    const long long mb = knob_int(KNOB_ATTN_DS_CAP_MB, 16384);
+    return (size_t)std::min<long long>(std::max<long long>(mb, 0), 4ll << 20) << 20;
+}
 
 template <typename K>
 static int set_lds(K kernel, size_t bytes) { return ensure_dynamic_lds((const void *)kernel, (int)bytes); }

@@ -17,6 +17,7 @@ void set_error(const char *fmt, ...);
         hipError_t e_ = (expr);                                                                       \
         if (e_ != hipSuccess) {                                                                       \
             ::kf::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (void)hipGetLastError(); /* since ROCm 7.0 the last error is STICKY: reported here, it must not surface again at the next launch check */ \
             return KF_ERR_HIP;                                                                        \
         }                                                                                             \
     } while (0)

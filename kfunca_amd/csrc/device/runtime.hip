@@ -182,7 +182,17 @@ int kf_malloc(void **ptr, size_t bytes) {
     KF_REQUIRE(ptr, KF_ERR_INVALID, "kf_malloc: null out pointer");
     *ptr = nullptr;
     if (bytes == 0) return KF_OK;
-    KF_HIP_TRY(hipMalloc(ptr, bytes));
+    const hipError_t e = hipMalloc(ptr, bytes);
+    if (e == hipErrorOutOfMemory) {
+        // a recoverable condition with a status of its own: the caller may release cached memory and retry, or ask for less.
+        // hipGetLastError() keeps the last REAL error until read (ROCm >= 7.0; successful calls no longer reset it): unread, the next
+        // KF_LAUNCH_CHECK would report "out of memory" for a kernel that launched fine.
+        (void)hipGetLastError();
+        *ptr = nullptr;
+        set_error("kf_malloc: out of device memory (%zu bytes requested)", bytes);
+        return KF_ERR_OOM;
+    }
+    KF_HIP_TRY(e);
     return KF_OK;
 }
 

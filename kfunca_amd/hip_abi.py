@@ -27,7 +27,7 @@ MOM_VAR, MOM_STD, MOM_INVSTD = range(3)
 EPI_NONE, EPI_BIAS_ROW = range(2)
 NORM_RMS, NORM_LAYER = range(2)
 MAX_DIMS, MAX_TENSORS = 12, 8
-KF_OK, KF_ERR_HIP, KF_ERR_INVALID, KF_ERR_UNSUPPORTED, KF_ERR_INDEX_RANGE, KF_ERR_WORKSPACE, KF_ERR_COMM = range(7)
+KF_OK, KF_ERR_HIP, KF_ERR_INVALID, KF_ERR_UNSUPPORTED, KF_ERR_INDEX_RANGE, KF_ERR_WORKSPACE, KF_ERR_COMM, KF_ERR_OOM = range(8)
 COMM_ID_BYTES = 128
 
 NP2CODE = {np.dtype(np.bool_): BOOL, np.dtype(np.uint8): U8, np.dtype(np.int8): I8, np.dtype(np.int16): I16,

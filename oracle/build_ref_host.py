@@ -53,8 +53,11 @@ def build(with_module: bool = True) -> Path:
     srcs = sorted((REF / "core").glob("*.cpp")) + [ROOT / "docs" / "seam.cpp"] + ([REF / "register.cpp"] if with_module else [])
     py = [f"-I{pybind11.get_include()}", f"-I{sysconfig.get_paths()['include']}"]
     objs = [obj / (s.stem + ".o") for s in srcs]
+    # an object is stale when its source OR any header it may include is newer: the reference's headers, the seam's, the C ABI
+    hdrs = [h for d in (REF / "core", REF / "device" / "include", ROOT / "include", ROOT / "docs") for h in d.rglob("*.h")]
+    newest_hdr = max((h.stat().st_mtime for h in hdrs), default=0.0)
     jobs = [["g++", "-std=c++20", "-O2", "-fPIC", "-w", *includes(), *py, "-c", s, "-o", o] for s, o in zip(srcs, objs)
-            if not o.exists() or o.stat().st_mtime < s.stat().st_mtime]
+            if not o.exists() or o.stat().st_mtime < max(s.stat().st_mtime, newest_hdr)]
     with ThreadPoolExecutor(max_workers=6) as ex:
         list(ex.map(run, jobs))
     core = OUT / "libkfunca_core_on_hip.so"

@@ -421,3 +421,66 @@ def test_c5_full_size_shard_and_the_multi_rank_runner_on_one_gpu():
     assert line["bucket"]["collective"] == "RCCL" and [ch[:2] for ch in line["bucket"]["chunks_first_last_offset_numel"]] == [[4, 4], [3, 3], [2, 2], [0, 1]]
     assert sorted(line["bucket"]["fired_order_last_step"]) == [0, 1, 2, 3] and line["bucket"]["fired_order_last_step"][-1] == 3
     assert set(c["shard_figures"]) == {"y", "dx", "dWqkv", "dWo", "dWgate", "dWup", "dWdown"}
+
+
+def test_bucketed_weight_used_by_two_products_gets_the_sum():
+    """one bucketed W feeding TWO matmuls of a graph (weight tying). Both backward products used to write their
+    dW with beta = 0 straight into the same bucket slot - the gradient came out as 2 dW_last. The sink now hands the slot to the first
+    product of a pass only (GradSink::take_slot); the second allocates, the engine sums. Checked against plain autograd (no bucket)
+    bit for bit and against numpy, for the pair-launch shape (256 multiples, both inputs need gradients) and for the two-call shape."""
+    rng = np.random.default_rng(77)
+    for n, fused in ((256, False), (256, True), (192, False)):
+        x1, x2, w, g = (rng.uniform(-1, 1, (n, n)).astype(np.float32) for _ in range(4))
+
+        def up(a, grad=True):
+            t = kfunca.from_numpy(a, 0).bfloat16()
+            t.set_requires_grad(grad)
+            return t
+        t1, t2, tw, tg = up(x1), up(x2), up(w), kfunca.from_numpy(g, 0).bfloat16()
+
+        def step():
+            for t in (t1, t2, tw):
+                t.zero_grad()
+            if fused:
+                y = kfunca.gemm_fused(t1, tw, 1.0, None, None, None) + kfunca.gemm_fused(t2, tw, 1.0, None, None, None)
+            else:
+                y = kfunca.gemm(t1, tw, 1.0, 0.0) + kfunca.gemm(t2, tw, 1.0, 0.0)
+            y.backward(tg)
+        step()
+        plain = tw.grad().numpy().copy()
+        f = lambda t: t.float().numpy().astype(np.float64)
+        want = f(t1).T @ f(tg) + f(t2).T @ f(tg)
+        got = (plain.astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+        assert np.abs(got - want).max() <= 2.0 ** -6 * np.abs(want).max(), "plain autograd itself"
+        bucket = kfunca.GradBucket([tw], 64.0)
+        bucket.attach()
+        for rep in range(2):
+            step()
+            bucket.wait()
+            assert np.array_equal(tw.grad().numpy(), plain), (n, fused, rep)  # dW_1 + dW_2, not 2 dW_2
+        assert tw.grad().data_ptr() == bucket.flat().data_ptr()
+        bucket.detach()
+
+
+def test_dropping_a_bucket_frees_it_without_detach():
+    """attach() used to store the bucket in every parameter's TensorImpl (bucket -> params -> impl -> bucket): a
+    dropped bucket was never freed. Parameters now hold it weakly: after `del bucket` the flat buffer returns to the allocator's
+    cache and the parameters get ordinary gradients again."""
+    import gc
+    rng = np.random.default_rng(5)
+    w = kfunca.from_numpy(rng.uniform(-1, 1, (256, 256)).astype(np.float32), 0).bfloat16()
+    w.set_requires_grad(True)
+    x = kfunca.from_numpy(rng.uniform(-1, 1, (256, 256)).astype(np.float32), 0).bfloat16()
+    g = kfunca.from_numpy(rng.uniform(-1, 1, (256, 256)).astype(np.float32), 0).bfloat16()
+    before = kfunca.memstat_dict(0)["active_blocks"]
+    bucket = kfunca.GradBucket([w], 64.0)
+    bucket.attach()
+    assert kfunca.memstat_dict(0)["active_blocks"] == before + 1  # the flat buffer
+    del bucket
+    gc.collect()
+    assert kfunca.memstat_dict(0)["active_blocks"] == before
+    kfunca.gemm(x, w, 1.0, 0.0).backward(g)
+    want = kfunca.gemm_ex(x, True, g, False, 1.0) if hasattr(kfunca, "gemm_ex") else None
+    assert w.grad().defined()
+    if want is not None:
+        assert np.array_equal(w.grad().numpy(), want.numpy())

@@ -367,3 +367,37 @@ def test_grouped_backward_pair_is_the_two_products(code):
     H.profile_enable(False)
     assert sum(v[1] for v in H.profile_results().values()) == 2 and label not in H.profile_results()
     assert np.array_equal(o0.to_numpy((M, N), a.dtype), o1.to_numpy((M, N), a.dtype))
+
+
+@pytest.mark.parametrize("code,eps", [(H.BF16, 2.0 ** -8), (H.F16, 2.0 ** -11)])
+def test_headline_backward_pair_vs_oracle_at_4096(code, eps):
+    """The headline GEMM's BACKWARD at its own size: the one-grid pair launch dA = dC W^T, dW = A^T dC at
+    4096^3 (label gemm_*_mfma_pair, what bench.py times) against the oracle on sampled rows of both outputs, under the bound the
+    forward rows are held to. Bar: test/test_gemm.py:9-17 (the reference's only GEMM test: forward, f64); the backward has no
+    reference counterpart (binary_ops.cpp:16-33 is its only GradFunction)."""
+    rng = np.random.default_rng(4096 + code)
+    n = 4096
+    a, w, g = (O.from_float(rng.uniform(-1, 1, (n, n)).astype(np.float32), code) for _ in range(3))
+    da, dw, dg = H.DevBuf.from_numpy(a), H.DevBuf.from_numpy(w), H.DevBuf.from_numpy(g)
+    o_da, o_dw = H.DevBuf(2 * n * n), H.DevBuf(2 * n * n)
+    H.profile_reset()
+    H.profile_enable(True)
+    H.gemm_grouped(code, [(0, 1, n, n, n, 1.0, 0.0, dg.ptr, n, dw.ptr, n, o_da.ptr, n),
+                          (1, 0, n, n, n, 1.0, 0.0, da.ptr, n, dg.ptr, n, o_dw.ptr, n)])
+    H.device_sync()
+    H.profile_enable(False)
+    label = "gemm_bf16_mfma_pair" if code == H.BF16 else "gemm_f16_mfma_pair"
+    assert set(H.profile_results()) == {label}, H.profile_results()
+    rows = [0, 1, 127, 128, 255, 256, 2047, 3000, 4094, 4095]
+    got_da = f64(o_da.to_numpy((n, n), a.dtype)[rows], code)
+    got_dw = f64(o_dw.to_numpy((n, n), a.dtype)[rows], code)
+    want_da = f64(O.gemm(g[rows], w, trans_b=True, code=code), code)
+    a_cols = np.ascontiguousarray(a[:, rows])
+    want_dw = f64(O.gemm(a_cols, g, trans_a=True, code=code), code)
+    mag_da = np.abs(f64(g[rows], code)) @ np.abs(f64(w, code)).T
+    mag_dw = np.abs(f64(a_cols, code)).T @ np.abs(f64(g, code))
+    assert (np.abs(got_da - want_da) <= 2 * eps * np.abs(want_da) + 2e-6 * mag_da + 1e-6).all(), "dA"
+    assert (np.abs(got_dw - want_dw) <= 2 * eps * np.abs(want_dw) + 2e-6 * mag_dw + 1e-6).all(), "dW"
+    # and against f64 mathematics (the oracle's f32 chain differs from the tile order by accumulation noise only)
+    assert (np.abs(got_da - f64(g[rows], code) @ f64(w, code).T) <= 2 * eps * np.abs(want_da) + 2e-6 * mag_da + 1e-6).all()
+    assert (np.abs(got_dw - f64(a_cols, code).T @ f64(g, code)) <= 2 * eps * np.abs(want_dw) + 2e-6 * mag_dw + 1e-6).all()

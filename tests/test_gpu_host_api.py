@@ -482,3 +482,45 @@ def test_ragged_gemm_runs_on_the_matrix_cores():
         wa, wb = g.astype(np.float64) @ b.astype(np.float64).T, a.astype(np.float64).T @ g.astype(np.float64)
         assert np.abs(out(ta.grad()) - wa).max() <= tol * np.abs(wa).max()
         assert np.abs(out(tb.grad()) - wb).max() <= tol * np.abs(wb).max()
+
+
+def test_out_of_memory_is_recoverable_and_the_attention_backward_falls_back():
+    """ADVICE round 3 (medium). (1) kf_malloc reports out-of-memory as KF_ERR_OOM -> utils::OutOfMemory, having read HIP's sticky
+    last-error (ROCm >= 7.0 keeps it until read): the next kernel launch check is clean. (2) The allocator hands its idle cache back to
+    the driver and retries once before giving up. (3) causal_attention's backward scratch asks for less when - and only when - the failure
+    is out-of-memory, down to the statistics alone (the recomputing dQ kernel): forced here with the allocator's test hook, results
+    checked against the ordinary run (dK / dV the same bits, dQ under the oracle's bounds)."""
+    rng = np.random.default_rng(61)
+    # (1) a real out-of-memory through the allocator, then a kernel: the launch check must not see a stale error
+    with pytest.raises(RuntimeError, match="out of device memory"):
+        kfunca.empty([1 << 40], kfunca.byte, 0)  # 1 TiB on a 288 GB device
+    a = rng.uniform(-1, 1, (300, 7)).astype(np.float32)
+    assert np.array_equal((kfunca.from_numpy(a, 0) + kfunca.from_numpy(a, 0)).numpy(), a + a)
+    # (2) that attempt took the release-and-retry path (the idle cache went back to the driver before the second try)
+    assert kfunca._alloc_oom_retries() >= 1
+    # (3) the attention backward under a simulated shortage
+    q, k, v, go = (rng.uniform(-1, 1, (1, 2, 512, 128)).astype(np.float32) for _ in range(4))
+    qb, kb, vb, gb = (O.f32_to_bf16(x) for x in (q, k, v, go))
+
+    def run():
+        tq, tk, tv = (kfunca.from_numpy(x, 0).bfloat16() for x in (q, k, v))
+        for t in (tq, tk, tv):
+            t.set_requires_grad(True)
+        out = kfunca.causal_attention(tq, tk, tv)
+        out.backward(kfunca.from_numpy(go, 0).bfloat16())
+        return out.numpy(), tq.grad().numpy(), tk.grad().numpy(), tv.grad().numpy()
+    ref = run()
+    kfunca.synchronize(0)
+    kfunca.release_cached(0)  # so that the scratch request reaches the driver (and the hook) instead of a cached block
+    before = kfunca._alloc_oom_retries()
+    kfunca._alloc_fail_above(600 << 10)  # dS of the two heads is 1 MiB, every tensor of this problem 256 KiB
+    try:
+        got = run()
+    finally:
+        kfunca._alloc_fail_above(0)
+    assert kfunca._alloc_oom_retries() > before
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
+    K.attn_check(qb, kb, vb, O.BF16, o=got[0], d_o=gb, dq=got[1], dk=got[2], dv=got[3], what="backward after the out-of-memory fallback")
+    # anything that is not out-of-memory still propagates (the fallback catches utils::OutOfMemory only): a bad device index
+    with pytest.raises(RuntimeError, match="out of range"):
+        kfunca.empty([4], kfunca.float, 99)

@@ -12,7 +12,10 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+sys.path.insert(0, str(ROOT))
+from bench import MEMBOUND_SOURCES, stamp  # noqa: E402
+
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 OUT = ROOT / "gpurun_out"
 
 
@@ -64,10 +67,12 @@ def main():
                      "frac_of_8TBps": bench[name]["algorithmic_bytes"] / (ms * 1e-3) / 1e9 / 8000.0,
                      "traffic_over_algorithmic": traffic / bench[name]["algorithmic_bytes"], "kernels": kern}
         print(f"{name:60s} {ms:8.4f} ms  alg {out[name]['GBps_algorithmic']:8.1f} GB/s  counters {out[name]['GBps_counters']:8.1f} GB/s  x{out[name]['traffic_over_algorithmic']:.2f}")
+    out.update(stamp(MEMBOUND_SOURCES))  # tests/test_profiles_fresh.py: a profile is quoted only for the device sources it was measured on
     (OUT / f"{R}_membound_rocprof.json").write_text(json.dumps(out, indent=1))
     stats = glob.glob(str(OUT / "mbT" / "**" / "*kernel_stats.csv"), recursive=True)
     if stats:
         shutil.copy(stats[0], OUT / f"{R}_membound_kernel_stats.csv")
+        (OUT / f"{R}_membound_kernel_stats.stamp.json").write_text(json.dumps(stamp(MEMBOUND_SOURCES), indent=1))
 
 
 if __name__ == "__main__":

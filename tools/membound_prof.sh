@@ -5,7 +5,7 @@
 set -euo pipefail
 cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run under gpurun)}"
 export TMPDIR=/tmp
-R="${KF_ROUND:-r03}"
+R="${KF_ROUND:-r04}"
 rm -rf gpurun_out/mbT gpurun_out/mbF gpurun_out/mbW
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/mbT -o r -- python3 tools/membound_bench.py --markers --rounds 5 --json gpurun_out/${R}_membound.json > gpurun_out/mbT.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/mbF -o r -- python3 tools/membound_bench.py --markers --rounds 5 > gpurun_out/mbF.log 2>&1

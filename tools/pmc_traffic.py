@@ -8,9 +8,9 @@ import sys
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from bench import device_src_sha  # noqa: E402
+from bench import BENCH_SOURCES, stamp  # noqa: E402
 
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 NAMES = {"gemm_h256_kernel": "gemm_bf16_mfma", "gemm_w4_pair_kernel": "gemm_bf16_mfma_pair", "gemm_w4_kernel": "gemm_bf16_mfma", "attn_fwd_v3_kernel": "attn_fwd_mfma", "attn_delta_kernel": "attn_bwd_delta",
          "attn_bwd_dkv_v4_kernel": "attn_bwd_dkv_mfma", "attn_bwd_dq_v2_kernel": "attn_bwd_dq_mfma", "attn_bwd_dq_ds_kernel": "attn_bwd_dq_mfma"}
@@ -37,6 +37,6 @@ for k in NAMES.values():
     if k in fetch and k in write:
         fk, wk = sum(fetch[k]) / len(fetch[k]), sum(write[k]) / len(write[k])
         out[k] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "bytes_per_launch": (2 * fk + wk) * 1024, "launches_sampled": len(fetch[k])}
-out["device_src_sha"] = device_src_sha()  # bench.py quotes this file only for the device sources it was measured on
+out.update(stamp(BENCH_SOURCES))  # bench.py quotes this file only for the device sources it was measured on
 json.dump(out, open(f"profiles/{ROUND}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: v["bytes_per_launch"] for k, v in out.items() if isinstance(v, dict)}, indent=1))

@@ -8,9 +8,9 @@ import sys
 from pathlib import Path
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
-from bench import device_src_sha  # noqa: E402
+from bench import BENCH_SOURCES, stamp  # noqa: E402
 
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 NAMES = {"gemm_h256_kernel": "gemm_bf16_mfma", "gemm_w4_pair_kernel": "gemm_bf16_mfma_pair", "gemm_w4_kernel": "gemm_bf16_mfma", "attn_fwd_v3_kernel": "attn_fwd_mfma", "attn_bwd_dkv_v4_kernel": "attn_bwd_dkv_mfma",
          "attn_bwd_dq_v2_kernel": "attn_bwd_dq_mfma", "attn_bwd_dq_ds_kernel": "attn_bwd_dq_mfma"}
@@ -51,6 +51,6 @@ for k, d in acc.items():
     if "SQ_INSTS_MFMA" in m and "SQ_INSTS_VALU" in m:
         o["valu_per_mfma"] = (m["SQ_INSTS_VALU"] - m["SQ_INSTS_MFMA"]) / m["SQ_INSTS_MFMA"]
     out[k] = o
-out["device_src_sha"] = device_src_sha()  # bench.py quotes this file only for the device sources it was measured on
+out.update(stamp(BENCH_SOURCES))  # bench.py quotes this file only for the device sources it was measured on
 json.dump(out, open(f"profiles/{ROUND}_pmc_util.json", "w"), indent=1)
 print(json.dumps({k: {a: b for a, b in v.items() if a != "counters"} for k, v in out.items() if isinstance(v, dict)}, indent=1))
