@@ -287,6 +287,8 @@ PYBIND11_MODULE(_C, m) {
         .def("wait", &gpu::GradBucket::wait)
         .def("flat", &gpu::GradBucket::flat)
         .def("reduced_bytes", &gpu::GradBucket::reduced_bytes)
+        .def("set_collectives", &gpu::GradBucket::set_collectives)
+        .def("chunk_ms", &gpu::GradBucket::chunk_ms)
         .def("fired_order", [](const gpu::GradBucket &b) { return b.fired_order(); })
         .def("chunks", [](const gpu::GradBucket &b) {
             py::list out;

@@ -139,9 +139,12 @@ std::shared_ptr<GradBucket> GradBucket::create(const std::vector<Tensor> &params
     DEV_CALL(kf_stream_create(&b->comm_stream_));
     b->ev_ready_.resize(b->chunks_.size(), nullptr);
     b->ev_done_.resize(b->chunks_.size(), nullptr);
+    b->ev_start_.resize(b->chunks_.size(), nullptr);
+    b->timed_.assign(b->chunks_.size(), 0);
     for (size_t c = 0; c < b->chunks_.size(); ++c) {
         DEV_CALL(kf_event_create(&b->ev_ready_[c]));
         DEV_CALL(kf_event_create(&b->ev_done_[c]));
+        DEV_CALL(kf_event_create(&b->ev_start_[c]));
     }
     return b;
 }
@@ -152,6 +155,7 @@ GradBucket::~GradBucket() {
     if (comm_stream_) kf_stream_sync(comm_stream_);
     for (void *e : ev_ready_) if (e) kf_event_destroy(e);
     for (void *e : ev_done_) if (e) kf_event_destroy(e);
+    for (void *e : ev_start_) if (e) kf_event_destroy(e);
     if (comm_stream_) kf_stream_destroy(comm_stream_);
 }
 
@@ -198,12 +202,15 @@ void GradBucket::arrived(TensorImpl *leaf) {
 void GradBucket::fire(int c) {
     fired_[c] = 1;
     fired_order_.push_back(c);
+    timed_[c] = 0;
     const CommState cs = comm_snapshot();
-    if (!cs.comm) return; // a single process without a communicator: the sum over one rank is the gradient itself
+    if (!cs.comm || !collectives_) return; // a single process without a communicator: the sum over one rank is the gradient itself
     void *compute = dev::stream(device_);
     // the chunk's last gradient has been ENQUEUED on the compute stream: the collective waits for it there, not on the host
     DEV_CALL(kf_event_record(ev_ready_[c], compute));
     DEV_CALL(kf_stream_wait_event(comm_stream_, ev_ready_[c]));
+    DEV_CALL(kf_event_record(ev_start_[c], comm_stream_));
+    timed_[c] = 1;
     char *base = static_cast<char *>(flat_.data_ptr()) + chunks_[c].offset * flat_.element_size_in_bytes();
     DEV_CALL(kf_allreduce_sum(cs.comm, base, (size_t)chunks_[c].numel, code(flat_.dtype()), comm_stream_));
     DEV_CALL(kf_event_record(ev_done_[c], comm_stream_));
@@ -214,13 +221,25 @@ void GradBucket::wait() {
     for (size_t c = 0; c < chunks_.size(); ++c) {
         // a chunk whose parameters got no gradient this pass (unused in the graph) is still reduced: every rank must issue the same collectives
         if (!fired_[c]) fire((int)c);
-        if (comm_initialized()) DEV_CALL(kf_stream_wait_event(compute, ev_done_[c]));
+        if (timed_[c]) DEV_CALL(kf_stream_wait_event(compute, ev_done_[c]));
     }
     pass_open_ = false;
     std::fill(have_.begin(), have_.end(), 0);
     std::fill(taken_.begin(), taken_.end(), 0);
     std::fill(fired_.begin(), fired_.end(), 0);
     for (size_t c = 0; c < chunks_.size(); ++c) missing_[c] = chunks_[c].last - chunks_[c].first + 1;
+}
+
+std::vector<double> GradBucket::chunk_ms() {
+    std::vector<double> out(chunks_.size(), 0.0);
+    if (comm_stream_) DEV_CALL(kf_stream_sync(comm_stream_));
+    for (size_t c = 0; c < chunks_.size(); ++c) {
+        if (!timed_[c]) continue;
+        float ms = 0.f;
+        DEV_CALL(kf_event_elapsed_ms(ev_start_[c], ev_done_[c], &ms));
+        out[c] = ms;
+    }
+    return out;
 }
 
 } // namespace gpu

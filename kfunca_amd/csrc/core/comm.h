@@ -50,6 +50,11 @@ public:
     const std::vector<Chunk> &chunks() const { return chunks_; }
     const std::vector<int> &fired_order() const { return fired_order_; }  // chunk indices in the order their collectives were issued (last pass)
     int64_t reduced_bytes() const;
+    // attribution (tools/block_bench.py): with collectives off the bucket still collects the gradients but issues nothing (the "off" arm
+    // of exposed-communication timing); chunk_ms() = what each chunk's collective of the LAST pass took on the communication stream,
+    // from the moment its gradients were ready to its end (0 for a chunk that issued none). Synchronises the communication stream.
+    void set_collectives(bool on) { collectives_ = on; }
+    std::vector<double> chunk_ms();
 
     Tensor slot(TensorImpl *leaf) override;
     Tensor take_slot(TensorImpl *leaf) override;
@@ -64,7 +69,9 @@ private:
     std::vector<Chunk> chunks_;
     std::vector<int> chunk_of_, missing_, fired_order_;
     std::vector<char> have_, fired_, taken_;
-    std::vector<void *> ev_ready_, ev_done_;
+    std::vector<void *> ev_ready_, ev_done_, ev_start_;
+    std::vector<char> timed_;
+    bool collectives_ = true;
     void *comm_stream_ = nullptr;
     Tensor flat_;
     int device_ = 0;

@@ -116,3 +116,56 @@ def test_block_bench_launches_its_own_ranks_cpu_dry_run():
     line = json.loads(lines[0])
     assert line["dry_run"] and line["n_gpus"] == 2 and line["allreduce_check"] is True
     assert [c[:2] for c in line["bucket_chunks"]] == [[4, 4], [3, 3], [2, 2], [0, 1]]
+
+
+def _block_worker(rank, world, port, out):
+    """Config C5's exchange step, numerically: every rank runs ITS batch element of the block restatement (oracle/block_ref.py),
+    lays the five dW (and the two norm gains) into the flat gradient bucket and all-reduces it over gloo."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from oracle import block_ref as R
+    pg = parallel.ProcessGroup(backend="gloo")
+    B, S, H, D, f = world, 64, 2, 32, 128
+    d = H * D
+    rng = np.random.default_rng(505)             # identical on every rank: the full batch + the replicated weights
+    x = R.r16(rng.uniform(-1, 1, (B * S, d)).astype(np.float32))
+    g = R.r16(rng.uniform(-1, 1, (B * S, d)).astype(np.float32))
+    shapes = ((d, 3 * d), (d, d), (d, f), (d, f), (f, d))
+    w = [R.r16((rng.uniform(-1, 1, s) / np.sqrt(s[0])).astype(np.float32)) for s in shapes]
+    gains = [R.r16(np.ones(d, np.float32) + 0.1 * rng.uniform(-1, 1, d).astype(np.float32)) for _ in range(2)]
+    lo, hi = parallel.shard_range(B, rank, world)   # batch elements of this rank
+    rows = slice(lo * S, hi * S)
+    _, dx_r, dw_r, dg_r = R.block_fwd_bwd(x[rows], w, g[rows], hi - lo, S, H, D, gains=gains)
+    bucket = parallel.GradBucket([*shapes, (d,), (d,)], dtype=np.float32)
+    flat = np.zeros(bucket.numel, dtype=np.float32)
+    for i, a in enumerate([*dw_r, *dg_r]):
+        bucket.view(flat, i)[...] = a
+    mag = np.abs(flat)
+    pg.allreduce_sum_host(flat)
+    pg.allreduce_sum_host(mag)                    # sum_r |dW_r|: the scale the per-rank roundings are relative to
+    ok = True
+    if rank == 0:  # the full batch in ONE process: its gradients are the sum of the shards' (attention and norms are per row / per batch element)
+        _, dx_full, dw_full, dg_full = R.block_fwd_bwd(x, w, g, B, S, H, D, gains=gains)
+        for i, a in enumerate([*dw_full, *dg_full]):
+            got = bucket.view(flat, i)
+            # every rank rounds ITS dW to bf16 once (the device path stores 16-bit gradients) and the full batch rounds the sum once:
+            # |difference| <= 2^-9 (sum_r |dW_r| + |dW|) elementwise (+ f32 BLAS blocking noise), nothing that grows with the
+            # number of additions: the all-reduce itself adds in f32
+            bound = 2.0 ** -8 * (bucket.view(mag, i) + np.abs(a)) + 1e-6
+            ok = ok and bool((np.abs(got - a) <= bound).all()) and bool(np.isfinite(got).all()) and float(np.abs(a).max()) > 0
+        # activations' gradients need no exchange at all: the shard's rows ARE the full batch's rows (up to BLAS blocking at another M:
+        # an occasional bf16 rounding flip)
+        ok = ok and bool((np.abs(dx_full[rows] - dx_r) <= 2.0 ** -7 * np.abs(dx_full[rows]) + 1e-6).all())
+    out[rank] = bool(ok)
+    pg.close()
+
+
+def test_block_gradients_of_two_batch_shards_sum_to_the_full_batch():
+    """a world-2 gloo NUMERICAL test of config C5 - two ranks each run half the batch of oracle/block_ref.py, the
+    all-reduced bucket equals the full-batch gradients (SURVEY.md section 8e's parity sentence, on CPU)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_block_worker, args=(2, port, out), nprocs=2, join=True)
+    assert dict(out) == {0: True, 1: True}

@@ -55,12 +55,12 @@ def launch_ranks(n: int) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [p.wait() for p in procs]
+    from bench import RANK_TIMEOUT_S, supervise  # bounded: a rank that fails or hangs ends the others (bench.py)
+    out0, codes = supervise(procs, RANK_TIMEOUT_S)
     lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
     for ln in lines[:-1]:
         print(ln, file=sys.stderr)
-    if lines:
+    if lines and all(c == 0 for c in codes):
         print(lines[-1], flush=True)
     return max(abs(c) for c in codes)
 
@@ -122,12 +122,17 @@ def main():
         raise SystemExit("block_bench.py needs a GPU: the HIP path has no CPU fallback")
     dev = local_rank
     H.set_device(dev)
+    from bench import deadline
     pg = None
     if world > 1 or args.force_comm:
-        pg = parallel.ProcessGroup(backend="gloo")  # rendezvous + host-side sums for --check; the data path is the C++ core's communicator
-        ident = [kfunca.comm_unique_id() if rank == 0 else None]
-        pg.dist.broadcast_object_list(ident, src=0)
-        kfunca.comm_init(ident[0], rank, world, dev)
+        if rank == 0:  # RCCL's own warnings of rank 0 go to stderr (stdout carries THE line)
+            os.environ.setdefault("NCCL_DEBUG", "WARN")
+            os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+        with deadline("rendezvous + ncclCommInitRank"):
+            pg = parallel.ProcessGroup(backend="gloo")  # rendezvous + host-side sums for --check; the data path is the C++ core's communicator
+            ident = [kfunca.comm_unique_id() if rank == 0 else None]
+            pg.dist.broadcast_object_list(ident, src=0)
+            kfunca.comm_init(ident[0], rank, world, dev)
         import ctypes
         ctypes.CDLL(None).fflush(None)  # RCCL's version banner
 
@@ -178,9 +183,10 @@ def main():
         return y
 
     def barrier():
-        kfunca.synchronize(dev)
-        if pg is not None:
-            pg.barrier()
+        with deadline("device sync + barrier"):
+            kfunca.synchronize(dev)
+            if pg is not None:
+                pg.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -194,21 +200,31 @@ def main():
         kfunca.synchronize(dev)
     H.profile_reset()
     H.profile_enable(graph is None)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if graph is not None:
-            kfunca.graph_launch(graph, dev)
-        else:
-            step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def timed():
+        barrier()
+        t0 = time.perf_counter()
+        with deadline(f"{args.steps} timed steps"):
+            for _ in range(args.steps):
+                if graph is not None:
+                    kfunca.graph_launch(graph, dev)
+                else:
+                    step()
+        barrier()
+        dt = time.perf_counter() - t0
+        return pg.max_over_ranks(dt) if pg is not None else dt
+    elapsed = timed()
     H.profile_enable(False)
-    if pg is not None:
-        elapsed = pg.max_over_ranks(elapsed)
     ms = elapsed / args.steps * 1e3
     prof = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps} for k, v in H.profile_results().items()}
     fired = list(bucket.fired_order())
+    # attribution: what each chunk's collective took on the communication stream (last step), and the same timed
+    # loop with the collectives left out - the difference is the communication the backward could not hide
+    chunk_ms = [float(v) for v in bucket.chunk_ms()]
+    ms_off = None
+    if kfunca.comm_initialized() and graph is None:
+        bucket.set_collectives(False)
+        ms_off = timed() / args.steps * 1e3
+        bucket.set_collectives(True)
 
     checks = {}
     if args.check:
@@ -234,6 +250,11 @@ def main():
                "scaling": "weak", "bucket": {"chunks_first_last_offset_numel": [list(c) for c in bucket.chunks()], "fired_order_last_step": fired,
                                                "bytes_reduced_per_step": nbytes, "collective": "RCCL" if kfunca.comm_initialized() else "none (one rank)"},
                "allreduce_busbw_lower_bound_GBps": (2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9) if world > 1 else 0.0,
+               "allreduce_chunk_ms": chunk_ms,
+               "allreduce_chunk_busbw_GBps": [(2.0 * (world - 1) / world * c[3] * 2 / (t * 1e-3) / 1e9) if (world > 1 and t > 0) else 0.0
+                                              for c, t in zip(bucket.chunks(), chunk_ms)],
+               "ms_per_step_no_comm": ms_off, "exposed_comm_ms": (ms - ms_off) if ms_off is not None else None,
+               "overlap_efficiency": (max(0.0, min(1.0, 1.0 - (ms - ms_off) / sum(chunk_ms))) if (ms_off is not None and sum(chunk_ms) > 0) else None),
                "device_ms_per_step": sum(v["ms_per_step"] for v in prof.values()),
                "elementwise_launches_per_step": sum(v["launches_per_step"] for k, v in prof.items() if k.startswith("ew_")),
                "kernels": prof, "checks": checks}
