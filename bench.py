@@ -99,7 +99,7 @@ def device_src_sha() -> str:
     differs from the tree being benchmarked is not quoted (the GPU box has no .git, so a commit id is not available)."""
     h = hashlib.sha256()
     for p in sorted((ROOT / "kfunca_amd" / "csrc" / "device").glob("*")):
-        if p.suffix in (".hip", ".h"):
+        if p.suffix in (".hip", ".h", ".inc"):
             h.update(p.name.encode())
             h.update(p.read_bytes())
     return h.hexdigest()[:16]
@@ -107,7 +107,7 @@ def device_src_sha() -> str:
 
 # which device sources each kind of committed profile depends on (tests/test_profiles_fresh.py): a profile is STALE - and must be
 # re-collected before it is quoted - when any of its files has changed since it was taken
-BENCH_SOURCES = ("attention.hip", "gemm.hip", "common.h", "runtime.hip")
+BENCH_SOURCES = ("attention.hip", "attn_fwd_w4.inc", "gemm.hip", "common.h", "runtime.hip")
 MEMBOUND_SOURCES = ("elementwise.hip", "reduce.hip", "norm.hip", "index.hip", "sort.hip", "common.h", "offset_calc.h", "runtime.hip")
 
 
@@ -115,7 +115,7 @@ def device_src_shas(names=None) -> dict:
     """Per-file content hashes of the device sources (all of them, or the `names` subset)."""
     out = {}
     for p in sorted((ROOT / "kfunca_amd" / "csrc" / "device").glob("*")):
-        if p.suffix in (".hip", ".h") and (names is None or p.name in names):
+        if p.suffix in (".hip", ".h", ".inc") and (names is None or p.name in names):
             out[p.name] = hashlib.sha256(p.read_bytes()).hexdigest()[:16]
     return out
 

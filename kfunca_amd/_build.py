@@ -56,7 +56,7 @@ def build_device(force: bool = False) -> Path:
     """hipcc --offload-arch=gfx950: kfunca_amd/csrc/device/*.hip -> kfunca_amd/libkfunca_hip.so"""
     BUILD.mkdir(exist_ok=True)
     srcs = sorted((CSRC / "device").glob("*.hip"))
-    hdrs = sorted((CSRC / "device").glob("*.h")) + sorted(INCLUDE.glob("*.h"))
+    hdrs = sorted((CSRC / "device").glob("*.h")) + sorted((CSRC / "device").glob("*.inc")) + sorted(INCLUDE.glob("*.h"))
     objs = []
     jobs = []
     for s in srcs:
@@ -142,7 +142,7 @@ def build_diag(force: bool = False) -> Path:
     BUILD.mkdir(exist_ok=True)
     out = BUILD / "libkfunca_hip_diag.so"
     srcs = [CSRC / "device" / "gemm.hip", CSRC / "device" / "runtime.hip"]
-    hdrs = sorted((CSRC / "device").glob("*.h")) + sorted(INCLUDE.glob("*.h"))
+    hdrs = sorted((CSRC / "device").glob("*.h")) + sorted((CSRC / "device").glob("*.inc")) + sorted(INCLUDE.glob("*.h"))
     if force or not _newer(out, srcs + hdrs):
         _run([_hipcc(), *HIP_FLAGS, "-DKF_DIAG_BUILD", "-shared", "-o", out, *srcs])
     return out
@@ -154,7 +154,7 @@ def build_mutant(force: bool = False) -> Path:
     BUILD.mkdir(exist_ok=True)
     out = BUILD / "libkfunca_hip_mutant.so"
     srcs = [CSRC / "device" / "attention.hip", CSRC / "device" / "runtime.hip"]
-    hdrs = sorted((CSRC / "device").glob("*.h")) + sorted(INCLUDE.glob("*.h"))
+    hdrs = sorted((CSRC / "device").glob("*.h")) + sorted((CSRC / "device").glob("*.inc")) + sorted(INCLUDE.glob("*.h"))
     if force or not _newer(out, srcs + hdrs):
         _run([_hipcc(), *HIP_FLAGS, "-DKF_MUTANT", "-shared", "-o", out, *srcs])
     return out

@@ -52,6 +52,7 @@ struct AttnArgs {
     float *nlse, *ndelta; // backward, dK/dV v4: -lse * sqrt(D) and -delta (initial accumulators of S and dP)
     int64_t B, H, Sq, Skv, D;
     float scale;
+    float scale_log2e; // scale * log2(e), formed on the host (attn_fwd_w4_kernel hands it to its instruction stream as a scalar)
     int xcd_map; // 1: nbh % 8 == 0, heads are pinned to XCDs (a_block_map)
     float defer; // forward: adopt a new running maximum only beyond this many exponent units (kDeferMax; -inf: always)
     int persist;     // k > 0: a workgroup handles k pairs {block x, its causal mirror}: equal work per workgroup (k = 1 is used)
@@ -580,6 +581,57 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
     }
 #endif
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward, round 4: 4 waves x 64 query rows, ONE wave per SIMD, the whole 512-register file asm-owned, the query block's pass (prologue,
+// tile loop in six variants, epilogue) as ONE generated instruction stream: tools/gen_attn_fwd.py -> attn_fwd_w4.inc (structure, register
+// map and the placement tables are documented there). This wrapper only maps the workgroup to its two query blocks (a block and its
+// causal mirror, as the other kernels) and hands the stream its scalars; every lane-dependent value is formed inside.
+// Head size 128, Sq a multiple of 256, Skv >= Sq, K and V with the same row stride; everything else keeps attn_fwd_v3_kernel.
+// ------------------------------------------------------------------------------------------
+#include "attn_fwd_w4.inc"
+template <bool BF>
+__global__ __launch_bounds__(256) void attn_fwd_w4_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int xb0;
+    int64_t bh;
+    const int nxb = (int)(a.Sq / FQ);
+    const int nwx = a.persist ? nxb / 2 : nxb;
+    a_block_map(nwx, a.nbh, a.xcd_map, xb0, bh);
+    const unsigned lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)smem;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const char *kp = a.k + a_head(a.lk, bh, a.H), *vp = a.v + a_head(a.lv, bh, a.H);
+    const char *qh = a.q + a_head(a.lq, bh, a.H);
+    char *oh = a.out + a_head(a.lo, bh, a.H);
+    const float c = a.scale_log2e, defer = a.defer; // (kernel arguments are scalar registers; a float product formed here would be a vector one)
+    const int qsr = (int)a.lq.sr, kvsr = (int)a.lk.sr, osr = (int)a.lo.sr;
+#pragma nounroll
+    for (int pass = 0; pass < (a.persist ? 2 : 1); ++pass) {
+        const int xb = ((pass & 1) != (a.persist_rev != 0)) ? nxb - 1 - xb0 : xb0;
+        const int qblk = nxb - 1 - xb; // longest blocks first
+        const int64_t q0 = (int64_t)qblk * FQ;
+        const char *qp = qh + q0 * a.lq.sr;
+        char *op = oh + q0 * a.lo.sr;
+        float *lsep = a.lse ? a.lse + bh * a.Sq + q0 : nullptr;
+        const int T = (int)((q0 + FQ) / ABK); // key tiles of this block: up to its last query's diagonal
+        int mut = -1;
+#ifdef KF_MUTANT
+        if (a.mutant == 1 && qblk == nxb - 1) mut = 1; // defect 1: the head's last block drops key tile 1
+#endif
+        if constexpr (BF)
+            asm volatile(KF_FWD_W4_ASM_BF16
+                         :
+                         : [qp] "s"(qp), [kp] "s"(kp), [vp] "s"(vp), [op] "s"(op), [lsep] "s"(lsep), [qsr] "s"(qsr), [kvsr] "s"(kvsr), [osr] "s"(osr),
+                           [T] "s"(T), [wid] "s"(wid), [c] "s"(c), [defer] "s"(defer), [lds] "s"(lds), [mut] "s"(mut)
+                         : KF_FWD_W4_CLOBBERS);
+        else
+            asm volatile(KF_FWD_W4_ASM_F16
+                         :
+                         : [qp] "s"(qp), [kp] "s"(kp), [vp] "s"(vp), [op] "s"(op), [lsep] "s"(lsep), [qsr] "s"(qsr), [kvsr] "s"(kvsr), [osr] "s"(osr),
+                           [T] "s"(T), [wid] "s"(wid), [c] "s"(c), [defer] "s"(defer), [lds] "s"(lds), [mut] "s"(mut)
+                         : KF_FWD_W4_CLOBBERS);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2373,6 +2425,7 @@ static int attn_fwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
     a.nbh = (int)(B * H);
     KF_REQUIRE(scale > 0.f && scale < INFINITY, KF_ERR_INVALID, "attention: the softmax scale must be positive and finite");
     a.scale = scale;
+    a.scale_log2e = scale * kLog2e;
     a.xcd_map = ((B * H) % 8 == 0) && !knob(KNOB_ATTN_NO_XCD);
     a.defer = knob(KNOB_ATTN_NO_DEFER) ? -INFINITY : kDeferMax; // A/B switch: rescale O at every tile
 #ifdef KF_MUTANT
@@ -2386,6 +2439,19 @@ static int attn_fwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
         a.persist = (nxb3 % 2 == 0 && nxb3 >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
         dim3 grid3((unsigned)((a.persist ? nxb3 / (2 * a.persist) : nxb3) * B * H));
         KF_PROF(D == 64 ? "attn_fwd_mfma_d64" : "attn_fwd_mfma", st);
+        // round 4: the one-wave-per-SIMD stream (attn_fwd_w4_kernel) wherever its shape conditions hold; KF_ATTN_FWD_V3 keeps the 8-wave kernel (A/B)
+        if (D == AD && Sq % FQ == 0 && Skv >= Sq && a.lk.sr == a.lv.sr && (uint64_t)Skv * (uint64_t)a.lk.sr < (1ull << 32) &&
+            (uint64_t)FQ * (uint64_t)std::max(a.lq.sr, a.lo.sr) < (1ull << 31) && !knob(KNOB_ATTN_FWD_V3)) {
+            if (dtype == KF_BF16) {
+                if ((rc = set_lds(attn_fwd_w4_kernel<true>, KF_FWD_W4_LDS_BYTES)) != KF_OK) return rc;
+                attn_fwd_w4_kernel<true><<<grid3, 256, KF_FWD_W4_LDS_BYTES, st>>>(a);
+            } else {
+                if ((rc = set_lds(attn_fwd_w4_kernel<false>, KF_FWD_W4_LDS_BYTES)) != KF_OK) return rc;
+                attn_fwd_w4_kernel<false><<<grid3, 256, KF_FWD_W4_LDS_BYTES, st>>>(a);
+            }
+            KF_LAUNCH_CHECK();
+            return KF_OK;
+        }
 #define KF_FWD(BF_, D_)                                                                  \
     {                                                                                    \
         if ((rc = set_lds(attn_fwd_v3_kernel<BF_, D_>, lds3)) != KF_OK) return rc;       \

@@ -1,0 +1,748 @@
+#!/usr/bin/env python3
+"""Generator of the 16-bit causal-attention FORWARD for gfx950 as ONE hand-placed instruction stream
+(kfunca_amd/csrc/device/attn_fwd_w4.inc, included by attention.hip; replaces the hot loop of the reference's
+CausalAttentionForwardFN, src/device/utils/causal_attention.h:66-258, for D = 128).
+
+Structure (cdna_hip_programming.md, "4-wave, one-wave-per-SIMD, persistent structure"):
+  * a workgroup = 4 waves = one 256-row query block; a wave = 64 query rows = two 32-row blocks b0, b1 and the WHOLE 512-register file:
+      a[0:127]   O^T accumulators  [b][db]            (32 d x 32 queries each)
+      a[128:191] Q fragments       [b][kk]            (B operand of S^T = K Q^T)
+      a[192:255] K fragments       [sub][kk]          (A operand; one 64-key tile, re-read per tile)
+      v[0:63]    S^T accumulators  [b][sub] -> exponentiated in place
+      v[64:95]   P (16-bit pairs)  [b][ks]            (B operand of O^T += V^T P^T)
+      v[96:159]  V^T fragments     [ks][db]           (A operand, ds_read_b64_tr_b16)
+      v[160:..]  addresses, running maxima, row sums, temporaries
+  * per 64-key tile a wave issues 64 MFMAs in four slots of 16:  A: S(b0)   B: PV(b1, previous tile)   C: S(b1)   D: PV(b0).
+    The two query blocks run HALF A TILE APART, so each block's softmax (16 max3, 32 fma, 32 exp, 32 add, 16 cvt_pk) has the 32
+    MFMA gaps between its S slot and its PV slot to itself: one v_exp_f32 per gap, everywhere. A rescale of O (deferred running
+    maximum) happens at the decision point of a block, when that block's previous P V has long finished: the textbook order.
+  * K / V tiles arrive by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB pieces, 8 per wave and tile) into two-slot rings, K two tiles
+    ahead, V one; ONE barrier per tile (end of slot A) behind an s_waitcnt vmcnt(0) that the DMA issued a whole tile earlier has
+    long satisfied. LDS image: 8-row x 32-column subtiles with the chunk XOR inside (cdna_hip_programming.md T10 image (a)): two
+    base registers for the row reads, two for the transposed reads, everything else immediates.
+  * every filler (VALU, LDS read, DMA piece, wait) is ASSIGNED to an MFMA gap by the tables below; `check()` walks the emitted
+    stream and enforces the distances the hardware does not interlock (MFMA result -> VALU, VALU -> MFMA operand, LDS read -> use).
+
+The file written is a C++ header with one string literal per element type (bf16 / f16) and the clobber list."""
+import argparse
+import re
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+OUT = ROOT / "kfunca_amd" / "csrc" / "device" / "attn_fwd_w4.inc"
+
+# ------------------------------------------------------------------ register map
+def S(b, n): return 32 * b + n                  # score / probability n (0..31 = sub * 16 + register) of block b
+def P(b, ks): return 64 + 16 * b + 4 * ks        # packed 16-bit P fragment of k-step ks (4 VGPRs)
+def VF(ks, db): return 96 + 16 * ks + 4 * db     # V^T fragment (4 VGPRs)
+KB = (160, 161)          # K row-read bases (even / odd k-step)
+VB = (162, 163)          # V transposed-read bases (first / second read of a fragment)
+DMA = (164, 165)         # LDS-DMA source offsets (even / odd row group)
+MC = (166, 167)          # running maximum in use, exponent units (score * scale * log2 e), per block
+LA, LB = (168, 170), (169, 171)   # row sums, two partial chains per block
+MXA, MXB = (172, 174), (173, 175)  # per-lane tile maxima (two chains)
+NEGINF, RM, DV = 176, 177, 178
+T = list(range(180, 196))  # temporaries (slow path, prologue, epilogue)
+def OA(b, db): return 64 * b + 16 * db           # AGPRs
+def QF(b, kk): return 128 + 32 * b + 4 * kk
+def KF(sub, kk): return 192 + 32 * sub + 4 * kk
+
+# scalar registers (all clobbered; inputs are copied in)
+# (s32 .. s35 are the ABI's stack / frame registers: not ours to clobber)
+K_SRD, V_SRD, Q_SRD, O_SRD = 36, 40, 44, 48
+S_C, S_DEFER, S_T, S_DT, S_IT, S_KVSR, S_TSTEP, S_RB0 = 52, 53, 54, 55, 56, 57, 58, 59
+S_KOFF0, S_KOFF1, S_VOFF0, S_VOFF1, S_M0K, S_M0V = 60, 61, 62, 63, 64, 65
+S_TMP, S_TMP2, S_QSR, S_OSR, S_WID, S_TM1 = 66, 67, 68, 69, 70, 71
+S_LSE = 72  # pair
+S_LDS, S_STAGE, S_X0, S_X1, S_X2 = 74, 75, 76, 77, 78
+S_MUT = 79  # mutation build: the tile whose probabilities are dropped (-1: none)
+N_VGPR = 200  # v0 .. v199 are the stream's; the rest of the arch file stays the compiler's (it has nowhere else to keep a scalar it cannot hold in SGPRs)
+
+KSLOT = 16384
+VSLOT0 = 32768
+STAGE0 = 65536
+STAGE_ROW = 272
+LDS_BYTES = STAGE0 + 4 * 64 * STAGE_ROW
+
+
+def vr(i, n=1): return f"v{i}" if n == 1 else f"v[{i}:{i + n - 1}]"
+def ar(i, n=1): return f"a{i}" if n == 1 else f"a[{i}:{i + n - 1}]"
+def sr(i, n=1): return f"s{i}" if n == 1 else f"s[{i}:{i + n - 1}]"
+
+
+class Ins:
+    """One instruction with what the checker needs to know about it."""
+    def __init__(self, text, kind, reads=(), writes=(), tag=""):
+        self.text, self.kind, self.reads, self.writes, self.tag = text, kind, tuple(reads), tuple(writes), tag
+
+
+def V(i, n=1): return [("v", j) for j in range(i, i + n)]
+def A(i, n=1): return [("a", j) for j in range(i, i + n)]
+
+
+class Gen:
+    def __init__(self, f16=False, mutant=False):
+        self.mutant = mutant
+        self.mfma = "v_mfma_f32_32x32x16_f16" if f16 else "v_mfma_f32_32x32x16_bf16"
+        self.cvt = "v_cvt_pk_f16_f32" if f16 else "v_cvt_pk_bf16_f32"
+        self.out = []   # list of Ins (and labels / comments as kind "raw")
+        self.uid = 0
+
+    # -------------------------------------------------------------- emit helpers
+    def raw(self, text): self.out.append(Ins(text, "raw"))
+    def label(self, name): self.out.append(Ins(f"{name}:", "label"))
+    def salu(self, text): self.out.append(Ins(text, "salu"))
+
+    def valu(self, text, reads=(), writes=(), trans=False):
+        self.out.append(Ins(text, "trans" if trans else "valu", reads, writes))
+
+    def qk(self, b, sub, kk):
+        d = S(b, 16 * sub)
+        c = "0" if kk == 0 else vr(d, 16)
+        self.out.append(Ins(f"{self.mfma} {vr(d, 16)}, {ar(KF(sub, kk), 4)}, {ar(QF(b, kk), 4)}, {c}", "mfma",
+                            A(KF(sub, kk), 4) + A(QF(b, kk), 4) + (V(d, 16) if kk else []), V(d, 16), tag=f"qk b{b} sub{sub} kk{kk}"))
+
+    def pv(self, b, ks, db):
+        o = OA(b, db)
+        self.out.append(Ins(f"{self.mfma} {ar(o, 16)}, {vr(VF(ks, db), 4)}, {vr(P(b, ks), 4)}, {ar(o, 16)}", "mfma",
+                            V(VF(ks, db), 4) + V(P(b, ks), 4) + A(o, 16), A(o, 16), tag=f"pv b{b} ks{ks} db{db}"))
+
+    def lds_k(self, sub, kk):   # K fragment (sub, kk) of the tile at the K bases
+        imm = 8192 * sub + 512 * (kk >> 1)
+        self.out.append(Ins(f"ds_read_b128 {ar(KF(sub, kk), 4)}, {vr(KB[kk & 1])} offset:{imm}", "lds", V(KB[kk & 1]), A(KF(sub, kk), 4)))
+
+    def lds_v(self, ks, db, second):  # half of V^T fragment (ks, db): keys 16 ks + 4 h + {0..3} (+ 8 for the second half)
+        sub, s = ks >> 1, ks & 1
+        imm = 2048 * (4 * sub + 2 * s + second) + 512 * db
+        self.out.append(Ins(f"ds_read_b64_tr_b16 {vr(VF(ks, db) + 2 * second, 2)}, {vr(VB[second])} offset:{imm}", "lds",
+                            V(VB[second]), V(VF(ks, db) + 2 * second, 2)))
+
+    def wait(self, vm=None, lgkm=None):
+        parts = ([f"vmcnt({vm})"] if vm is not None else []) + ([f"lgkmcnt({lgkm})"] if lgkm is not None else [])
+        self.out.append(Ins("s_waitcnt " + " ".join(parts), "wait", tag=f"{'vm' if vm is not None else ''}{'lgkm' if lgkm is not None else ''}"))
+
+    def barrier(self): self.out.append(Ins("s_barrier", "barrier"))
+
+    def dma(self, srd, voff, soff, m0_from, m0_add, inst_off):
+        self.salu(f"s_add_u32 m0, {sr(m0_from)}, {m0_add}" if m0_add else f"s_mov_b32 m0, {sr(m0_from)}")
+        self.salu("s_nop 0")
+        o = f" offset:{inst_off}" if inst_off else ""
+        self.out.append(Ins(f"buffer_load_dwordx4 {vr(voff)}, {sr(srd, 4)}, {sr(soff)} offen{o} lds", "dma", V(voff)))
+
+    # -------------------------------------------------------------- the filler streams of one iteration
+    def softmax_ops(self, b, cur, masked, drop):
+        """All VALU ops of block b's softmax of one tile as (gap, order, emit) tuples; gaps are relative to the block's S slot
+        (0 = behind the slot's first MFMA) and run to 57; the caller shifts block 1 by 32 and folds modulo 64."""
+        ops = []
+        s_c = sr(S_C)
+        def add(g, fn): ops.append((g, len(ops), fn))
+        # ---- masking of the diagonal tile (this wave's own diagonal): key (e & 3) + 8 (e >> 2) + 4 h > query r
+        # (this variant runs once per wave and block: its gaps may be as full as they need to be; the chain's timing stays the steady one)
+        if masked:
+            sub = 0 if b == 0 else 1   # b0: sub 0 is the diagonal, sub 1 lies wholly above it; b1: sub 0 is visible, sub 1 is the diagonal
+            if b == 0:
+                for e in range(16):  # sub 1 of block 0: all of it (its 8 MFMAs are not issued)
+                    add(2 + e // 3, lambda e=e: self.valu(f"v_mov_b32 {vr(S(0, 16 + e))}, {vr(NEGINF)}", V(NEGINF), V(S(0, 16 + e))))
+                add(8, lambda: self.valu(f"v_mov_b32 {vr(MXB[0])}, {vr(NEGINF)}", V(NEGINF), V(MXB[0])))
+                add(8, lambda: self.salu("s_nop 15"))   # no MFMAs follow the diagonal sub-tile's chain in this slot: give its last one its time
+                add(8, lambda: self.salu("s_nop 7"))
+            for e in range(16):
+                kc = (e & 3) + 8 * (e >> 2)
+                g = (9 if sub == 0 else 17) + e // 8
+                def m(e=e, kc=kc, sub=sub):
+                    self.valu(f"v_cmp_gt_i32 vcc, {kc}, {vr(RM)}", V(RM), [("vcc", 0)])
+                    self.valu(f"v_cndmask_b32 {vr(S(b, 16 * sub + e))}, {vr(S(b, 16 * sub + e))}, {vr(NEGINF)}, vcc",
+                              V(S(b, 16 * sub + e)) + V(NEGINF) + [("vcc", 0)], V(S(b, 16 * sub + e)))
+                add(g, m)
+        # ---- tile maximum per lane: two chains (sub 0 -> MXA, sub 1 -> MXB), v_max3 takes two new values per instruction
+        shift = 0
+        chains = ((0, MXA[b], 9, 1.2), (1, MXB[b], 17, 2.0))
+        if masked:
+            chains = ((0, MXA[0], 11, 2.0),) if b == 0 else ((0, MXA[1], 9, 1.2), (1, MXB[1], 19, 4.0))
+        for sub, mx, g0, per in chains:
+            base = S(b, 16 * sub)
+            seq = [(base, base + 1, base + 2)] + [(mx, base + 3 + 2 * j, min(base + 4 + 2 * j, base + 15)) for j in range(7)]
+            for j, (x, y, z) in enumerate(seq):
+                add(g0 + int(j / per), lambda x=x, y=y, z=z, mx=mx: self.valu(f"v_max3_f32 {vr(mx)}, {vr(x)}, {vr(y)}, {vr(z)}", V(x) + V(y) + V(z), V(mx)))
+        # ---- decision: does any query of the wave exceed the maximum in use by more than `defer` exponent units?
+        gd = 21 + shift
+        add(gd, lambda: self.valu(f"v_max_f32 {vr(MXA[b])}, {vr(MXA[b])}, {vr(MXB[b])}", V(MXA[b]) + V(MXB[b]), V(MXA[b])))
+        add(gd, lambda: self.valu(f"v_fma_f32 {vr(DV)}, {vr(MXA[b])}, {s_c}, -{vr(MC[b])}", V(MXA[b]) + V(MC[b]), V(DV)))
+        add(gd + 1, lambda: self.valu(f"v_cmp_lt_f32 vcc, {sr(S_DEFER)}, {vr(DV)}", V(DV), [("vcc", 0)]))
+        add(gd + 1, lambda: self.rescale(b))
+        # ---- the exponent chain, one value per gap: fma (scale, subtract the maximum) | exp2 | row sum | pack pairs
+        g0 = gd + 2
+        src2 = vr(MC[b])
+        for n in range(32):
+            x = S(b, n)
+            if drop:  # mutation build: this tile's probabilities are dropped (p = exp2(-inf) = 0)
+                add(g0 + n, lambda x=x: self.valu(f"v_mov_b32 {vr(x)}, {vr(NEGINF)}", V(NEGINF), V(x)))
+            else:
+                add(g0 + n, lambda x=x: self.valu(f"v_fma_f32 {vr(x)}, {vr(x)}, {s_c}, -{src2}", V(x) + V(MC[b]), V(x)))
+            add(g0 + n + 1, lambda x=x: self.valu(f"v_exp_f32 {vr(x)}, {vr(x)}", V(x), V(x), trans=True))
+            l = (LA if n % 2 == 0 else LB)[b]
+            add(g0 + n + 2, lambda x=x, l=l: self.valu(f"v_add_f32 {vr(l)}, {vr(l)}, {vr(x)}", V(l) + V(x), V(l)))
+            if n % 2 == 1:
+                d = P(b, n // 8) + (n % 8) // 2
+                add(g0 + n + 3, lambda x=x, d=d: self.valu(f"{self.cvt} {vr(d)}, {vr(x - 1)}, {vr(x)}", V(x - 1) + V(x), V(d)))
+        return ops
+
+    def rescale(self, b):
+        """The rare path, inline behind the decision: adopt the new maximum (the same for the two lanes of a query), scale the row
+        sums and the O accumulators of block b. The block's last P V finished at least 20 MFMAs ago."""
+        self.uid += 1
+        skip = f"L_norescale_{self.uid}_%="
+        self.salu(f"s_cbranch_vccz {skip}")
+        n_before = len(self.out)
+        t0, t1, t2 = T[0], T[1], T[2]
+        self.valu(f"v_mov_b32 {vr(t0)}, {vr(MXA[b])}", V(MXA[b]), V(t0))
+        self.valu(f"v_mov_b32 {vr(t1)}, {vr(MXA[b])}", V(MXA[b]), V(t1))
+        self.salu("s_nop 1")
+        self.valu(f"v_permlane32_swap_b32 {vr(t0)}, {vr(t1)}", V(t0) + V(t1), V(t0) + V(t1))
+        self.valu(f"v_max_f32 {vr(t0)}, {vr(t0)}, {vr(t1)}", V(t0) + V(t1), V(t0))
+        self.valu(f"v_mul_f32 {vr(t0)}, {sr(S_C)}, {vr(t0)}", V(t0), V(t0))
+        self.valu(f"v_max_f32 {vr(t0)}, {vr(t0)}, {vr(MC[b])}", V(t0) + V(MC[b]), V(t0))           # new maximum
+        self.valu(f"v_sub_f32 {vr(t1)}, {vr(MC[b])}, {vr(t0)}", V(t0) + V(MC[b]), V(t1))
+        self.valu(f"v_mov_b32 {vr(MC[b])}, {vr(t0)}", V(t0), V(MC[b]))
+        self.valu(f"v_exp_f32 {vr(t1)}, {vr(t1)}", V(t1), V(t1), trans=True)                           # alpha = 2^(old - new), 0 at the first tile
+        self.salu("s_nop 0")
+        self.valu(f"v_mul_f32 {vr(LA[b])}, {vr(LA[b])}, {vr(t1)}", V(LA[b]) + V(t1), V(LA[b]))
+        self.valu(f"v_mul_f32 {vr(LB[b])}, {vr(LB[b])}, {vr(t1)}", V(LB[b]) + V(t1), V(LB[b]))
+        for base in range(OA(b, 0), OA(b, 0) + 64, 8):
+            for j in range(8):
+                self.valu(f"v_accvgpr_read_b32 {vr(T[4 + j])}, {ar(base + j)}", A(base + j), V(T[4 + j]))
+            for j in range(8):
+                self.valu(f"v_mul_f32 {vr(T[4 + j])}, {vr(T[4 + j])}, {vr(t1)}", V(T[4 + j]) + V(t1), V(T[4 + j]))
+            for j in range(8):
+                self.valu(f"v_accvgpr_write_b32 {ar(base + j)}, {vr(T[4 + j])}", V(T[4 + j]), A(base + j))
+        for x in self.out[n_before:]:
+            x.tag = "rare"
+        self.label(skip)
+
+    # -------------------------------------------------------------- one iteration (tile `it`) of one variant
+    def iteration(self, name, has_prev, has_cur, masked=False, drop=False):
+        """has_cur: this wave computes tile `it` (S of both blocks, block 0's softmax and P V, the head of block 1's softmax);
+        has_prev: it owes tile it - 1 its second half (block 1's softmax tail and P V). Neither: only the DMA and the barrier."""
+        G = [[] for _ in range(64)]   # fillers per gap, (order key, emit function)
+        def put(g, key, fn): G[g % 64].append((key, fn))
+        if has_cur:
+            for (g, k, fn) in self.softmax_ops(0, True, masked, drop):
+                put(g, (0, k), fn)
+            for (g, k, fn) in self.softmax_ops(1, True, masked, drop):
+                if 32 + g < 64:
+                    put(32 + g, (1, k), fn)
+        if has_prev:
+            for (g, k, fn) in self.softmax_ops(1, False, False, False):   # the tail of the PREVIOUS tile's block 1 (never the diagonal tile's mask: that sits in the head)
+                if 32 + g >= 64:
+                    put(32 + g - 64, (1, k), fn)
+        # V^T fragments: tile it - 1 for slot B (read in A), tile it for slot D (read in C); in consumption order, 3 per gap
+        def vreads(g0):
+            seq = [(ks, db, sec) for ks in range(4) for db in range(4) for sec in (0, 1)]
+            for i, (ks, db, sec) in enumerate(seq):
+                put(g0 + i // 3, (2, i), lambda ks=ks, db=db, sec=sec: self.lds_v(ks, db, sec))
+        if has_prev: vreads(0)
+        if has_cur: vreads(32)
+        # K fragments of tile it + 1 (slot D; its own tiles only)
+        if has_cur and not masked:
+            seq = [(sub, kk) for sub in range(2) for kk in range(8)]
+            for i, (sub, kk) in enumerate(seq):
+                put(48 + (i * 3) // 4, (2, i), lambda sub=sub, kk=kk: self.lds_k(sub, kk))
+        # LDS-DMA of K(it + 2) and V(it + 1): this wave's 4 + 4 pieces, behind the barrier, one per gap from gap 23
+        pieces = [(K_SRD, DMA[0], S_KOFF0, S_M0K, 0, 0), (K_SRD, DMA[0], S_KOFF0, S_M0K, 896, 128),
+                  (K_SRD, DMA[1], S_KOFF1, S_M0K, 2048, 0), (K_SRD, DMA[1], S_KOFF1, S_M0K, 2048 + 896, 128),
+                  (V_SRD, DMA[0], S_VOFF0, S_M0V, 0, 0), (V_SRD, DMA[0], S_VOFF0, S_M0V, 896, 128),
+                  (V_SRD, DMA[1], S_VOFF1, S_M0V, 2048, 0), (V_SRD, DMA[1], S_VOFF1, S_M0V, 2048 + 896, 128)]
+        for i, p in enumerate(pieces):
+            put(23 + i, (3, i), lambda p=p: self.dma(*p))
+        # loop bookkeeping (slot B, behind the DMA): ring toggles, next source offsets
+        def book():
+            for r in (KB[0], KB[1], VB[0], VB[1]):
+                self.valu(f"v_xor_b32 {vr(r)}, {KSLOT}, {vr(r)}", V(r), V(r))
+            self.salu(f"s_xor_b32 {sr(S_M0K)}, {sr(S_M0K)}, {KSLOT}")
+            self.salu(f"s_xor_b32 {sr(S_M0V)}, {sr(S_M0V)}, {KSLOT}")
+            # K(it + 3) and V(it + 2) for the next iteration, clamped to the last tile (a clamped piece is fetched again and never read)
+            for (dst0, dst1, ahead) in ((S_KOFF0, S_KOFF1, 3), (S_VOFF0, S_VOFF1, 2)):
+                self.salu(f"s_add_u32 {sr(S_TMP)}, {sr(S_IT)}, {ahead}")
+                self.salu(f"s_min_u32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_TM1)}")
+                self.salu(f"s_mul_i32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_TSTEP)}")
+                self.salu(f"s_add_u32 {sr(dst0)}, {sr(S_TMP)}, {sr(S_RB0)}")
+                self.salu(f"s_lshl_b32 {sr(S_TMP2)}, {sr(S_KVSR)}, 3")
+                self.salu(f"s_add_u32 {sr(dst1)}, {sr(dst0)}, {sr(S_TMP2)}")
+        put(31, (4, 0), book)
+
+        self.label(f"L_{name}_%=")
+        for g in range(64):
+            slot, j = g // 16, g % 16
+            # ---- waits in front of the slot's first MFMA
+            if g == 0 and has_cur:
+                self.wait(lgkm=0)          # K fragments (read in slot D of the previous iteration / the prologue)
+            if g == 16 and has_cur and not has_prev:
+                self.salu("s_nop 15")   # no MFMAs in this slot of the first tile: the S chain that has just been issued gets its time
+                self.salu("s_nop 7")
+            if g == 16:
+                self.wait(vm=0, lgkm=0)    # this wave's DMA pieces of the previous iteration have landed; V^T fragments of slot A
+                self.barrier()             # everyone's: K(it + 1), V(it) are in LDS, V(it - 1) and K(it) are no longer read
+            if g == 48 and has_cur:
+                self.wait(lgkm=0)          # V^T fragments (read in slot C)
+            # ---- the MFMA of this gap
+            if slot == 0 and has_cur and not (masked and j >= 8):
+                self.qk(0, j // 8, j % 8)
+            elif slot == 1 and has_prev:
+                self.pv(1, j // 4, j % 4)
+            elif slot == 2 and has_cur:
+                self.qk(1, j // 8, j % 8)
+            elif slot == 3 and has_cur:
+                self.pv(0, j // 4, j % 4)
+            else:
+                self.out.append(Ins("", "nomfma"))
+            for _, fn in sorted(G[g], key=lambda t: t[0]):
+                fn()
+
+    # -------------------------------------------------------------- whole pass of one query block
+    def prologue(self):
+        e = self
+        e.raw("; ---- inputs into fixed registers")
+        e.salu(f"s_mov_b64 {sr(K_SRD, 2)}, %[kp]")
+        e.salu(f"s_mov_b64 {sr(V_SRD, 2)}, %[vp]")
+        e.salu(f"s_mov_b64 {sr(Q_SRD, 2)}, %[qp]")
+        e.salu(f"s_mov_b64 {sr(O_SRD, 2)}, %[op]")
+        for srd in (K_SRD, V_SRD, Q_SRD, O_SRD):
+            e.salu(f"s_mov_b32 {sr(srd + 2)}, 0xffffffff")
+            e.salu(f"s_mov_b32 {sr(srd + 3)}, 0x00020000")
+        e.salu(f"s_mov_b64 {sr(S_LSE, 2)}, %[lsep]")
+        for dst, src in ((S_C, "c"), (S_DEFER, "defer"), (S_T, "T"), (S_KVSR, "kvsr"), (S_QSR, "qsr"), (S_OSR, "osr"), (S_WID, "wid"), (S_LDS, "lds"), (S_MUT, "mut")):
+            e.salu(f"s_mov_b32 {sr(dst)}, %[{src}]")
+        e.salu(f"s_sub_u32 {sr(S_TM1)}, {sr(S_T)}, 1")
+        e.salu(f"s_sub_u32 {sr(S_DT)}, {sr(S_T)}, 4")
+        e.salu(f"s_add_u32 {sr(S_DT)}, {sr(S_DT)}, {sr(S_WID)}")            # this wave's diagonal tile
+        e.salu(f"s_lshl_b32 {sr(S_TSTEP)}, {sr(S_KVSR)}, 6")                  # bytes per 64-key tile
+        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 4")
+        e.salu(f"s_mul_i32 {sr(S_RB0)}, {sr(S_TMP)}, {sr(S_KVSR)}")          # rows 16 w .. of a tile: this wave's two row groups
+        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 12")
+        e.salu(f"s_add_u32 {sr(S_M0K)}, {sr(S_LDS)}, {sr(S_TMP)}")           # DMA destination of this wave inside a K slot ...
+        e.salu(f"s_add_u32 {sr(S_M0V)}, {sr(S_M0K)}, {VSLOT0}")              # ... and a V slot
+        e.salu(f"s_mul_i32 {sr(S_TMP)}, {sr(S_WID)}, {64 * STAGE_ROW}")
+        e.salu(f"s_add_u32 {sr(S_STAGE)}, {sr(S_LDS)}, {STAGE0}")
+        e.salu(f"s_add_u32 {sr(S_STAGE)}, {sr(S_STAGE)}, {sr(S_TMP)}")
+        # ---- lane constants
+        lane, r, h, t0, t1, t2, t3 = T[0], T[1], T[2], T[3], T[4], T[5], T[6]
+        e.raw("; ---- lane constants")
+        e.valu(f"v_mbcnt_lo_u32_b32 {vr(lane)}, -1, 0")
+        e.valu(f"v_mbcnt_hi_u32_b32 {vr(lane)}, -1, {vr(lane)}")
+        e.valu(f"v_and_b32 {vr(r)}, 31, {vr(lane)}")
+        e.valu(f"v_lshrrev_b32 {vr(h)}, 5, {vr(lane)}")
+        e.valu(f"v_mov_b32 {vr(NEGINF)}, 0xff800000")
+        e.valu(f"v_lshlrev_b32 {vr(t0)}, 2, {vr(h)}")
+        e.valu(f"v_sub_u32 {vr(RM)}, {vr(r)}, {vr(t0)}")                     # r - 4 h: key register e is masked where (e & 3) + 8 (e >> 2) > r - 4 h
+        # K row-read bases: 2048 (r >> 3) + 64 (r & 7) + 16 (h ^ ((r >> 2) & 3)), slot 0
+        e.valu(f"v_lshrrev_b32 {vr(t0)}, 3, {vr(r)}")
+        e.valu(f"v_lshlrev_b32 {vr(t0)}, 11, {vr(t0)}")
+        e.valu(f"v_and_b32 {vr(t1)}, 7, {vr(r)}")
+        e.valu(f"v_lshlrev_b32 {vr(t1)}, 6, {vr(t1)}")
+        e.valu(f"v_bfe_u32 {vr(t2)}, {vr(r)}, 2, 2")
+        e.valu(f"v_xor_b32 {vr(t2)}, {vr(t2)}, {vr(h)}")
+        e.valu(f"v_lshlrev_b32 {vr(t2)}, 4, {vr(t2)}")
+        e.valu(f"v_add3_u32 {vr(KB[0])}, {vr(t0)}, {vr(t1)}, {vr(t2)}")
+        e.valu(f"v_add_u32 {vr(KB[0])}, {sr(S_LDS)}, {vr(KB[0])}")
+        e.valu(f"v_xor_b32 {vr(KB[1])}, 32, {vr(KB[0])}")
+        # V transposed-read bases: i = lane & 15, q = i >> 2, p = i & 3, g = lane >> 4:  64 (4 h + q) + 16 ((2 (g & 1) + (p >> 1)) ^ h) + 8 (p & 1), V slot 1
+        e.valu(f"v_bfe_u32 {vr(t0)}, {vr(lane)}, 2, 2")                      # q
+        e.valu(f"v_lshl_add_u32 {vr(t0)}, {vr(h)}, 2, {vr(t0)}")             # 4 h + q
+        e.valu(f"v_lshlrev_b32 {vr(t0)}, 6, {vr(t0)}")
+        e.valu(f"v_bfe_u32 {vr(t1)}, {vr(lane)}, 4, 1")                      # g & 1
+        e.valu(f"v_bfe_u32 {vr(t2)}, {vr(lane)}, 1, 1")                      # p >> 1
+        e.valu(f"v_lshl_add_u32 {vr(t1)}, {vr(t1)}, 1, {vr(t2)}")
+        e.valu(f"v_xor_b32 {vr(t1)}, {vr(t1)}, {vr(h)}")
+        e.valu(f"v_lshlrev_b32 {vr(t1)}, 4, {vr(t1)}")
+        e.valu(f"v_and_b32 {vr(t2)}, 1, {vr(lane)}")
+        e.valu(f"v_lshlrev_b32 {vr(t2)}, 3, {vr(t2)}")
+        e.valu(f"v_add3_u32 {vr(VB[0])}, {vr(t0)}, {vr(t1)}, {vr(t2)}")
+        e.valu(f"v_add_u32 {vr(VB[0])}, {sr(S_LDS)}, {vr(VB[0])}")
+        e.valu(f"v_add_u32 {vr(VB[0])}, {VSLOT0 + KSLOT}, {vr(VB[0])}")
+        e.valu(f"v_xor_b32 {vr(VB[1])}, 32, {vr(VB[0])}")
+        # LDS-DMA source offsets: row7 = (lane >> 2) & 7, sub32 = lane >> 5, slot = lane & 3, b4 = (lane >> 4) & 1
+        #   even row group: row7 sr + 64 sub32 + 16 (slot ^ b4); odd: ... 16 (slot ^ (2 | b4))
+        e.valu(f"v_bfe_u32 {vr(t0)}, {vr(lane)}, 2, 3")
+        e.valu(f"v_mul_lo_u32 {vr(t0)}, {vr(t0)}, {sr(S_KVSR)}")
+        e.valu(f"v_lshl_add_u32 {vr(t0)}, {vr(h)}, 6, {vr(t0)}")
+        e.valu(f"v_and_b32 {vr(t1)}, 3, {vr(lane)}")
+        e.valu(f"v_bfe_u32 {vr(t2)}, {vr(lane)}, 4, 1")
+        e.valu(f"v_xor_b32 {vr(t1)}, {vr(t1)}, {vr(t2)}")
+        e.valu(f"v_lshl_add_u32 {vr(DMA[0])}, {vr(t1)}, 4, {vr(t0)}")
+        e.valu(f"v_xor_b32 {vr(t1)}, 2, {vr(t1)}")
+        e.valu(f"v_lshl_add_u32 {vr(DMA[1])}, {vr(t1)}, 4, {vr(t0)}")
+        # ---- Q fragments first (the first MFMA needs them and K(0)): query 64 w + 32 b + r, k = 16 kk + 8 h .. + 7  ->  a[128 ..]
+        e.valu(f"v_mul_lo_u32 {vr(t3)}, {vr(r)}, {sr(S_QSR)}")
+        e.valu(f"v_lshl_add_u32 {vr(t3)}, {vr(h)}, 4, {vr(t3)}")
+        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 6")
+        e.salu(f"s_mul_i32 {sr(S_X0)}, {sr(S_TMP)}, {sr(S_QSR)}")
+        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_QSR)}, 5")
+        e.salu(f"s_add_u32 {sr(S_X1)}, {sr(S_X0)}, {sr(S_TMP)}")
+        for b in range(2):
+            for kk in range(8):
+                e.out.append(Ins(f"buffer_load_dwordx4 {ar(QF(b, kk), 4)}, {vr(t3)}, {sr(Q_SRD, 4)}, {sr(S_X0 + b)} offen offset:{32 * kk}", "vmem", V(t3), A(QF(b, kk), 4)))
+        # ---- tile 0 of K into slot 0
+        e.raw("; ---- K(0) -> slot 0; then K(1) -> slot 1 and V(0) -> slot 0")
+        e.salu(f"s_mov_b32 {sr(S_KOFF0)}, {sr(S_RB0)}")
+        e.salu(f"s_lshl_b32 {sr(S_TMP2)}, {sr(S_KVSR)}, 3")
+        e.salu(f"s_add_u32 {sr(S_KOFF1)}, {sr(S_KOFF0)}, {sr(S_TMP2)}")
+        for i in range(4):
+            self.dma(K_SRD, DMA[i >> 1], S_KOFF0 + (i >> 1), S_M0K, 2048 * (i >> 1) + 896 * (i & 1), 128 * (i & 1))
+        # K(1) (clamped) and V(0)
+        e.salu(f"s_min_u32 {sr(S_TMP)}, 1, {sr(S_TM1)}")
+        e.salu(f"s_mul_i32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_TSTEP)}")
+        e.salu(f"s_add_u32 {sr(S_KOFF0)}, {sr(S_TMP)}, {sr(S_RB0)}")
+        e.salu(f"s_add_u32 {sr(S_KOFF1)}, {sr(S_KOFF0)}, {sr(S_TMP2)}")
+        e.salu(f"s_mov_b32 {sr(S_VOFF0)}, {sr(S_RB0)}")
+        e.salu(f"s_add_u32 {sr(S_VOFF1)}, {sr(S_VOFF0)}, {sr(S_TMP2)}")
+        e.salu(f"s_xor_b32 {sr(S_M0K)}, {sr(S_M0K)}, {KSLOT}")
+        for i in range(4):
+            self.dma(K_SRD, DMA[i >> 1], S_KOFF0 + (i >> 1), S_M0K, 2048 * (i >> 1) + 896 * (i & 1), 128 * (i & 1))
+        for i in range(4):
+            self.dma(V_SRD, DMA[i >> 1], S_VOFF0 + (i >> 1), S_M0V, 2048 * (i >> 1) + 896 * (i & 1), 128 * (i & 1))
+        e.salu(f"s_xor_b32 {sr(S_M0K)}, {sr(S_M0K)}, {KSLOT}")                # iteration 0 stages K(2) into slot 0 ...
+        e.salu(f"s_xor_b32 {sr(S_M0V)}, {sr(S_M0V)}, {KSLOT}")                # ... and V(1) into slot 1
+        # offsets for iteration 0's DMA: K(2), V(1), clamped
+        for (dst0, dst1, ahead) in ((S_KOFF0, S_KOFF1, 2), (S_VOFF0, S_VOFF1, 1)):
+            e.salu(f"s_min_u32 {sr(S_TMP)}, {ahead}, {sr(S_TM1)}")
+            e.salu(f"s_mul_i32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_TSTEP)}")
+            e.salu(f"s_add_u32 {sr(dst0)}, {sr(S_TMP)}, {sr(S_RB0)}")
+            e.salu(f"s_add_u32 {sr(dst1)}, {sr(dst0)}, {sr(S_TMP2)}")
+        e.raw("; ---- O = 0, running maximum = -inf, row sums = 0")
+        for i in range(128):
+            e.valu(f"v_accvgpr_write_b32 {ar(i)}, 0", (), A(i))
+        for b in range(2):
+            e.valu(f"v_mov_b32 {vr(MC[b])}, {vr(NEGINF)}")
+            e.valu(f"v_mov_b32 {vr(LA[b])}, 0")
+            e.valu(f"v_mov_b32 {vr(LB[b])}, 0")
+        # ---- K(0) has landed for everyone: its fragments; then the ring bases move to where iteration 0 expects them
+        e.wait(vm=8)      # in-order counter: the 16 Q loads and the 4 K(0) pieces are older than the 4 + 4 pieces of K(1) and V(0)
+        e.barrier()
+        for sub in range(2):
+            for kk in range(8):
+                self.lds_k(sub, kk)
+        e.salu(f"s_mov_b32 {sr(S_IT)}, 0")
+
+    def dispatch(self):
+        """Head of every iteration: which variant does this wave run at tile S_IT?  it > dt + 1: idle; == dt + 1: drain; == dt: masked;
+        == 0: first; else steady. The loop ends after iteration T (the last wave's drain)."""
+        e = self
+        e.label("L_loop_%=")
+        e.salu(f"s_add_u32 {sr(S_TMP)}, {sr(S_DT)}, 1")
+        e.salu(f"s_cmp_gt_u32 {sr(S_IT)}, {sr(S_TMP)}")
+        e.salu("s_cbranch_scc1 L_idle_%=")
+        e.salu(f"s_cmp_eq_u32 {sr(S_IT)}, {sr(S_TMP)}")
+        e.salu("s_cbranch_scc1 L_drain_%=")
+        e.salu(f"s_cmp_eq_u32 {sr(S_IT)}, {sr(S_DT)}")
+        e.salu("s_cbranch_scc1 L_diag_%=")
+        e.salu(f"s_cmp_eq_u32 {sr(S_IT)}, 0")
+        e.salu("s_cbranch_scc1 L_first_%=")
+        if self.mutant:
+            e.salu(f"s_cmp_eq_u32 {sr(S_IT)}, {sr(S_MUT)}")
+            e.salu("s_cbranch_scc1 L_steadydrop_%=")
+        e.salu("s_branch L_steady_%=")
+        e.label("L_diag_%=")
+        e.salu(f"s_cmp_eq_u32 {sr(S_IT)}, 0")
+        e.salu("s_cbranch_scc1 L_firstmasked_%=")
+        e.salu("s_branch L_masked_%=")
+
+    def next_iter(self):
+        e = self
+        e.salu(f"s_add_u32 {sr(S_IT)}, {sr(S_IT)}, 1")
+        e.salu(f"s_cmp_le_u32 {sr(S_IT)}, {sr(S_T)}")
+        e.salu("s_cbranch_scc1 L_loop_%=")
+        e.salu("s_branch L_epilogue_%=")
+
+    def epilogue(self):
+        e = self
+        lane, r, h = T[0], T[1], T[2]
+        e.label("L_epilogue_%=")
+        e.wait(vm=0, lgkm=0)
+        e.salu("s_nop 15")
+        e.valu(f"v_mbcnt_lo_u32_b32 {vr(lane)}, -1, 0")
+        e.valu(f"v_mbcnt_hi_u32_b32 {vr(lane)}, -1, {vr(lane)}")
+        e.valu(f"v_and_b32 {vr(r)}, 31, {vr(lane)}")
+        e.valu(f"v_lshrrev_b32 {vr(h)}, 5, {vr(lane)}")
+        inv = (T[3], T[4])
+        for b in range(2):
+            l, t = T[5], T[6]
+            e.valu(f"v_add_f32 {vr(l)}, {vr(LA[b])}, {vr(LB[b])}")
+            e.valu(f"v_mov_b32 {vr(t)}, {vr(l)}")
+            e.salu("s_nop 1")
+            e.valu(f"v_permlane32_swap_b32 {vr(l)}, {vr(t)}")
+            e.valu(f"v_add_f32 {vr(l)}, {vr(l)}, {vr(t)}")                   # the row sum of the query: both key halves
+            e.valu(f"v_rcp_f32 {vr(inv[b])}, {vr(l)}")
+            e.valu(f"v_log_f32 {vr(l)}, {vr(l)}")
+            e.salu("s_nop 0")
+            e.valu(f"v_add_f32 {vr(l)}, {vr(l)}, {vr(MC[b])}")
+            e.valu(f"v_mul_f32 {vr(l)}, 0x3f317218, {vr(l)}")                 # ln 2: LSE in natural-log units
+            # lanes 0..31 store the LSE of query 64 w + 32 b + r
+            e.valu(f"v_lshlrev_b32 {vr(t)}, 2, {vr(r)}")
+            e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 8")
+            e.salu(f"s_add_u32 {sr(S_TMP)}, {sr(S_TMP)}, {128 * b}")
+            e.valu(f"v_add_u32 {vr(t)}, {sr(S_TMP)}, {vr(t)}")
+            e.salu(f"s_cmp_eq_u64 {sr(S_LSE, 2)}, 0")
+            e.salu(f"s_cbranch_scc1 L_nolse{b}_%=")
+            e.salu("s_mov_b32 exec_hi, 0")
+            e.out.append(Ins(f"global_store_dword {vr(t)}, {vr(l)}, {sr(S_LSE, 2)}", "vmem", V(t) + V(l)))
+            e.salu("s_mov_b64 exec, -1")
+            e.label(f"L_nolse{b}_%=")
+        # O^T accumulators -> 16-bit rows of this wave's staging slab: lane (r, h) writes 4 consecutive d of query 32 b + r
+        st = T[7]
+        e.valu(f"v_mul_u32_u24 {vr(st)}, {STAGE_ROW}, {vr(r)}")
+        e.valu(f"v_lshl_add_u32 {vr(st)}, {vr(h)}, 3, {vr(st)}")
+        e.valu(f"v_add_u32 {vr(st)}, {sr(S_STAGE)}, {vr(st)}")
+        for b in range(2):
+            for db in range(4):
+                for gq in range(4):
+                    a0 = OA(b, db) + 4 * gq
+                    x = T[8:12]
+                    for j in range(4):
+                        e.valu(f"v_accvgpr_read_b32 {vr(x[j])}, {ar(a0 + j)}")
+                    for j in range(4):
+                        e.valu(f"v_mul_f32 {vr(x[j])}, {vr(x[j])}, {vr(inv[b])}")
+                    e.valu(f"{self.cvt} {vr(x[0])}, {vr(x[0])}, {vr(x[1])}")
+                    e.valu(f"{self.cvt} {vr(x[1])}, {vr(x[2])}, {vr(x[3])}")
+                    e.out.append(Ins(f"ds_write_b64 {vr(st)}, {vr(x[0], 2)} offset:{32 * b * STAGE_ROW + 64 * db + 16 * gq}", "lds"))
+        e.wait(lgkm=0)   # the same wave reads back what it wrote: LDS operations of one wave complete in order
+        # rows out: 4 rows per instruction (16 lanes x 16 B each)
+        rd, oo = T[12], T[13]
+        e.valu(f"v_lshrrev_b32 {vr(rd)}, 4, {vr(lane)}")
+        e.valu(f"v_and_b32 {vr(oo)}, 15, {vr(lane)}")
+        e.valu(f"v_lshlrev_b32 {vr(oo)}, 4, {vr(oo)}")
+        e.valu(f"v_mul_lo_u32 {vr(T[14])}, {vr(rd)}, {sr(S_OSR)}")
+        e.valu(f"v_mul_u32_u24 {vr(rd)}, {STAGE_ROW}, {vr(rd)}")
+        e.valu(f"v_add3_u32 {vr(rd)}, {vr(rd)}, {vr(oo)}, {sr(S_STAGE)}")
+        e.valu(f"v_add_u32 {vr(oo)}, {vr(oo)}, {vr(T[14])}")
+        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 6")
+        e.salu(f"s_mul_i32 {sr(S_X0)}, {sr(S_TMP)}, {sr(S_OSR)}")
+        e.salu(f"s_lshl_b32 {sr(S_X1)}, {sr(S_OSR)}, 2")
+        for j in range(16):
+            d = 100 + 4 * (j % 8)   # v[100..131]: the fragment registers are free now
+            e.out.append(Ins(f"ds_read_b128 {vr(d, 4)}, {vr(rd)} offset:{4 * j * STAGE_ROW}", "lds"))
+            if j % 8 == 7:
+                e.wait(lgkm=0)
+                for i in range(8):
+                    e.out.append(Ins(f"buffer_store_dwordx4 {vr(100 + 4 * i, 4)}, {vr(oo)}, {sr(O_SRD, 4)}, {sr(S_X0)} offen", "vmem"))
+                    e.salu(f"s_add_u32 {sr(S_X0)}, {sr(S_X0)}, {sr(S_X1)}")
+        e.wait(vm=0)
+        e.barrier()   # the next block of this workgroup reuses the ring and the slabs
+
+    def build(self):
+        self.prologue()
+        self.dispatch()
+        for name, kw in (("steady", dict(has_prev=True, has_cur=True)), ("first", dict(has_prev=False, has_cur=True)),
+                         ("masked", dict(has_prev=True, has_cur=True, masked=True)), ("firstmasked", dict(has_prev=False, has_cur=True, masked=True)),
+                         ("drain", dict(has_prev=True, has_cur=False)), ("idle", dict(has_prev=False, has_cur=False))):
+            self.iteration(name, **kw)
+            self.next_iter()
+        if self.mutant:
+            self.iteration("steadydrop", has_prev=True, has_cur=True, drop=True)
+            self.next_iter()
+        self.epilogue()
+        return self
+
+
+# ------------------------------------------------------------------ static checks on the emitted stream
+def check(ins):
+    """Walks each variant's stream twice (an iteration behind itself) and enforces:
+       * an MFMA result is read or overwritten by a non-MFMA instruction only >= 2 MFMAs later (and by an MFMA only as its own
+         accumulate chain or >= 2 MFMAs later);
+       * a VALU result feeds an MFMA's A / B / C only with >= 4 instructions in between;
+       * an LDS read's destination is used only behind an s_waitcnt lgkmcnt(0) that follows the read."""
+    problems = []
+    # split into variants
+    cur, variants = None, {}
+    for i in ins:
+        if i.kind == "label" and re.match(r"L_(steady|first|masked|firstmasked|drain|idle|steadydrop)_%=:", i.text):
+            cur = i.text[2:-4]
+            variants[cur] = []
+        elif i.kind == "label" and i.text.startswith("L_epilogue"):
+            cur = None
+        elif cur is not None:
+            variants[cur].append(i)
+    for name, body in variants.items():
+        seq = [x for x in body if x.kind not in ("raw", "label", "nomfma")] * 2
+        last_mfma_write, last_valu_write, pending_lds = {}, {}, {}
+        n_mfma, n_ins = 0, 0
+        for x in seq:
+            n_ins += 1
+            if x.kind == "mfma":
+                n_mfma += 1
+            if x.kind == "salu" and x.text.startswith("s_nop"):
+                n_ins += int(x.text.split()[1])
+            if x.kind == "wait" and "lgkm" in x.tag:
+                pending_lds.clear()
+            for reg in x.reads:
+                if reg in pending_lds:
+                    problems.append(f"{name}: '{x.text}' uses {reg} of an LDS read not yet waited for")
+                if reg in last_mfma_write:
+                    m, tag, at = last_mfma_write[reg]
+                    chain = x.kind == "mfma" and reg in x.writes and n_mfma - m == 1
+                    if not chain and n_mfma - m < 2 and n_ins - at < 22:
+                        problems.append(f"{name}: '{x.text}' reads {reg} {n_mfma - m} MFMA(s) / {n_ins - at} wait states after '{tag}' wrote it")
+                if x.kind == "mfma" and reg in last_valu_write and n_ins - last_valu_write[reg] < 4:
+                    problems.append(f"{name}: '{x.text}' reads {reg} {n_ins - last_valu_write[reg]} instruction(s) after a VALU wrote it")
+            for reg in x.writes:
+                if x.kind != "mfma" and reg in last_mfma_write and n_mfma - last_mfma_write[reg][0] < 2 and n_ins - last_mfma_write[reg][2] < 22:
+                    problems.append(f"{name}: '{x.text}' overwrites {reg} right behind '{last_mfma_write[reg][1]}'")
+                if x.kind == "mfma":
+                    last_mfma_write[reg] = (n_mfma, x.tag, n_ins)
+                    last_valu_write.pop(reg, None)
+                elif x.kind == "lds":
+                    pending_lds[reg] = n_ins
+                    last_mfma_write.pop(reg, None)
+                else:
+                    last_valu_write[reg] = n_ins
+                    last_mfma_write.pop(reg, None)
+    return problems
+
+
+def gap_table(ins, name="steady"):
+    """Fillers per MFMA gap of one variant: the issue-cost estimate the placement is judged by (MI355X_MICROARCH.md: MFMA 8, v_exp 8,
+    other VALU 4, LDS read ~2, DMA piece ~60, SALU / wait 4)."""
+    cost = {"valu": 4, "trans": 8, "lds": 2, "dma": 60, "salu": 4, "wait": 4, "barrier": 4, "vmem": 8}
+    rows, cur, on = [], None, False
+    for i in ins:
+        if i.kind == "label":
+            if re.match(r"L_(steady|first|masked|firstmasked|drain|idle|steadydrop|epilogue|loop|diag)_%=:", i.text):
+                on = i.text == f"L_{name}_%=:"
+            continue
+        if not on or i.tag == "rare":
+            continue
+        if i.kind in ("mfma", "nomfma"):
+            cur = {"mfma": i.tag, "n": 0, "cycles": 8 if i.kind == "mfma" else 0}
+            rows.append(cur)
+        elif cur is not None and i.kind in cost:
+            cur["n"] += 1
+            cur["cycles"] += cost[i.kind]
+    return rows
+
+
+# ------------------------------------------------------------------ address-map self test (pure Python model of the LDS image)
+def selftest():
+    """The three views of one tile image must agree: what the DMA pieces write, what the K row reads deliver as the A operand of
+    v_mfma_32x32x16 (lane (r, h): A[row r][k = 8 h + j]), and what the transposed reads deliver as the V^T operand in the k order of
+    a score accumulator used as the B operand (element j of half h <-> key 16 ks + 8 (j >> 2) + 4 h + (j & 3))."""
+    sr_b = 256 + 64   # a row stride that is not the tile's own
+    lds = {}
+    for w in range(4):
+        for rgi, rg in enumerate((2 * w, 2 * w + 1)):
+            for hp in range(2):
+                base = 4096 * w + 2048 * rgi + 1024 * hp
+                for L in range(64):
+                    row7, sub32, slot, b4 = (L >> 2) & 7, L >> 5, L & 3, (L >> 4) & 1
+                    x = b4 if rg % 2 == 0 else (2 | b4)
+                    src = 8 * rg * sr_b + row7 * sr_b + 64 * sub32 + 16 * (slot ^ x) + 128 * hp   # soffset + voffset + inst offset
+                    row, colbyte = src // sr_b, src % sr_b
+                    for byte in range(0, 16, 2):
+                        lds[base + 16 * L + byte] = (row, (colbyte + byte) // 2)
+    assert len(lds) == 64 * 128
+    # K row reads
+    for sub in range(2):
+        for kk in range(8):
+            for lane in range(64):
+                r, h = lane & 31, lane >> 5
+                b0 = 2048 * (r >> 3) + 64 * (r & 7) + 16 * (h ^ ((r >> 2) & 3))
+                addr = (b0 ^ (32 if kk & 1 else 0)) + 8192 * sub + 512 * (kk >> 1)
+                for j in range(8):
+                    assert lds[addr + 2 * j] == (32 * sub + r, 16 * kk + 8 * h + j), ("K", sub, kk, lane, j, lds[addr + 2 * j])
+    # V transposed reads
+    for ks in range(4):
+        for db in range(4):
+            for sec in range(2):
+                sub, s = ks >> 1, ks & 1
+                imm = 2048 * (4 * sub + 2 * s + sec) + 512 * db
+                got = {}
+                for grp in range(4):
+                    blk = {}
+                    for i in range(16):
+                        lane = 16 * grp + i
+                        h, q, p, g1 = lane >> 5, i >> 2, i & 3, grp & 1
+                        t0 = 64 * (4 * h + q) + 16 * ((2 * g1 + (p >> 1)) ^ h) + 8 * (p & 1)
+                        addr = (t0 ^ (32 if sec else 0)) + imm
+                        for c in range(4):
+                            blk[(q, 4 * p + c)] = lds[addr + 2 * c]
+                    for i in range(16):
+                        got[16 * grp + i] = [blk[(qq, i)] for qq in range(4)]
+                for lane in range(64):
+                    r, h = lane & 31, lane >> 5
+                    for e in range(4):
+                        j = 4 * sec + e
+                        key = 16 * ks + 8 * (j >> 2) + 4 * h + (j & 3)
+                        assert got[lane][e] == (key, 32 * db + r), ("V", ks, db, sec, lane, e, got[lane][e], (key, 32 * db + r))
+    return True
+
+
+CLOBBERS = (["memory", "vcc", "scc"] + [f"s{i}" for i in range(36, 80)] + [f"v{i}" for i in range(N_VGPR)] + [f"a{i}" for i in range(256)])
+
+
+def render(ins):
+    lines = []
+    for i in ins:
+        if i.kind == "nomfma":
+            continue
+        if i.kind == "raw" and i.text.startswith("#"):
+            lines.append(i.text)
+        elif i.kind == "raw":
+            lines.append(f'    "{i.text}\\n"')
+        elif i.kind == "label":
+            lines.append(f'    "{i.text}\\n"')
+        else:
+            lines.append(f'    "\\t{i.text}\\n"')
+    return "\n".join(lines)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check-only", action="store_true")
+    ap.add_argument("--gaps", default="", help="print the gap table of a variant")
+    args = ap.parse_args()
+    assert selftest()
+    g = Gen(False).build()
+    probs = check(g.out)
+    if args.gaps:
+        tot = 0
+        for k, row in enumerate(gap_table(g.out, args.gaps)):
+            tot += max(32, row["cycles"]) if row["mfma"] else row["cycles"]
+            print(f"{k:3d} {row['mfma']:20s} fillers {row['n']:2d}  est. cycles {row['cycles']:4d}")
+        print("estimated cycles per iteration:", tot)
+    for p in probs[:40]:
+        print("HAZARD:", p, file=sys.stderr)
+    if probs:
+        return 1
+    if args.check_only:
+        return 0
+    texts = {}
+    for f16 in (False, True):
+        for mut in (False, True):
+            gg = Gen(f16, mut).build()
+            assert not check(gg.out), check(gg.out)[:5]
+            texts[(f16, mut)] = render(gg.out).replace(chr(10), " " + chr(92) + chr(10))
+    n_ins = sum(1 for i in g.out if i.kind not in ("raw", "label", "nomfma"))
+    text = f"""// GENERATED by tools/gen_attn_fwd.py - do not edit; edit the generator and run it again.
+// The 16-bit causal-attention forward of one 256-row query block as ONE instruction stream per element type ({n_ins} instructions):
+// 4 waves x 64 query rows, one wave per SIMD, all 512 registers asm-owned; see the generator's header for the structure.
+#pragma once
+#define KF_FWD_W4_LDS_BYTES {LDS_BYTES}
+#define KF_FWD_W4_CLOBBERS {", ".join('"' + c + '"' for c in CLOBBERS)}
+#ifdef KF_MUTANT  // + one more variant of the tile body: the probabilities of tile %[mut] are dropped (tests/test_gpu_attention_mutants.py)
+#define KF_FWD_W4_ASM_BF16 \\
+{texts[(False, True)]}
+#define KF_FWD_W4_ASM_F16 \\
+{texts[(True, True)]}
+#else
+#define KF_FWD_W4_ASM_BF16 \\
+{texts[(False, False)]}
+#define KF_FWD_W4_ASM_F16 \\
+{texts[(True, False)]}
+#endif
+"""
+    OUT.write_text(text)
+    print(f"wrote {OUT} ({n_ins} instructions per element type)")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
