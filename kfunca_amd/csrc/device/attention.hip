@@ -590,7 +590,10 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
 // causal mirror, as the other kernels) and hands the stream its scalars; every lane-dependent value is formed inside.
 // Head size 128, Sq a multiple of 256, Skv >= Sq, K and V with the same row stride; everything else keeps attn_fwd_v3_kernel.
 // ------------------------------------------------------------------------------------------
-#include "attn_fwd_w4.inc"
+#ifndef KF_FWD_W4_INC // (tools/scratch/fwd_w4_ablate.sh builds timing variants of the stream from another file)
+#define KF_FWD_W4_INC "attn_fwd_w4.inc"
+#endif
+#include KF_FWD_W4_INC
 template <bool BF>
 __global__ __launch_bounds__(256) void attn_fwd_w4_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];

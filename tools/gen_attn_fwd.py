@@ -82,8 +82,9 @@ def A(i, n=1): return [("a", j) for j in range(i, i + n)]
 
 
 class Gen:
-    def __init__(self, f16=False, mutant=False):
+    def __init__(self, f16=False, mutant=False, ablate=()):
         self.mutant = mutant
+        self.ablate = set(ablate)   # timing experiments only (tools/scratch/fwd_w4_ablate.sh): parts of the tile body left out - WRONG results
         self.mfma = "v_mfma_f32_32x32x16_f16" if f16 else "v_mfma_f32_32x32x16_bf16"
         self.cvt = "v_cvt_pk_f16_f32" if f16 else "v_cvt_pk_bf16_f32"
         self.out = []   # list of Ins (and labels / comments as kind "raw")
@@ -109,11 +110,13 @@ class Gen:
                             V(VF(ks, db), 4) + V(P(b, ks), 4) + A(o, 16), A(o, 16), tag=f"pv b{b} ks{ks} db{db}"))
 
     def lds_k(self, sub, kk):   # K fragment (sub, kk) of the tile at the K bases
+        if "lds" in self.ablate: return
         imm = 8192 * sub + 512 * (kk >> 1)
         self.out.append(Ins(f"ds_read_b128 {ar(KF(sub, kk), 4)}, {vr(KB[kk & 1])} offset:{imm}", "lds", V(KB[kk & 1]), A(KF(sub, kk), 4)))
 
     def lds_v(self, ks, db, second):  # half of V^T fragment (ks, db): keys 16 ks + 4 h + {0..3} (+ 8 for the second half)
         sub, s = ks >> 1, ks & 1
+        if "lds" in self.ablate: return
         imm = 2048 * (4 * sub + 2 * s + second) + 512 * db
         self.out.append(Ins(f"ds_read_b64_tr_b16 {vr(VF(ks, db) + 2 * second, 2)}, {vr(VB[second])} offset:{imm}", "lds",
                             V(VB[second]), V(VF(ks, db) + 2 * second, 2)))
@@ -122,13 +125,24 @@ class Gen:
         parts = ([f"vmcnt({vm})"] if vm is not None else []) + ([f"lgkmcnt({lgkm})"] if lgkm is not None else [])
         self.out.append(Ins("s_waitcnt " + " ".join(parts), "wait", tag=f"{'vm' if vm is not None else ''}{'lgkm' if lgkm is not None else ''}"))
 
-    def barrier(self): self.out.append(Ins("s_barrier", "barrier"))
+    def barrier(self):
+        if "barrier" in self.ablate and getattr(self, "in_loop", False): return
+        self.out.append(Ins("s_barrier", "barrier"))
 
-    def dma(self, srd, voff, soff, m0_from, m0_add, inst_off):
+    def dma_m0(self, m0_from, m0_add):
+        if "dma" in self.ablate and getattr(self, "in_loop", False): return
         self.salu(f"s_add_u32 m0, {sr(m0_from)}, {m0_add}" if m0_add else f"s_mov_b32 m0, {sr(m0_from)}")
-        self.salu("s_nop 0")
+
+    def dma_load(self, srd, voff, soff, inst_off):
+        if "dma" in self.ablate and getattr(self, "in_loop", False): return
+        if self.out[-1].text.startswith(("s_add_u32 m0", "s_mov_b32 m0")):
+            self.salu("s_nop 0")   # SALU write of M0 -> LDS-DMA: one wait state (in the tile loop a gap's other fillers stand between the two)
         o = f" offset:{inst_off}" if inst_off else ""
         self.out.append(Ins(f"buffer_load_dwordx4 {vr(voff)}, {sr(srd, 4)}, {sr(soff)} offen{o} lds", "dma", V(voff)))
+
+    def dma(self, srd, voff, soff, m0_from, m0_add, inst_off):
+        self.dma_m0(m0_from, m0_add)
+        self.dma_load(srd, voff, soff, inst_off)
 
     # -------------------------------------------------------------- the filler streams of one iteration
     def softmax_ops(self, b, cur, masked, drop):
@@ -226,23 +240,27 @@ class Gen:
         has_prev: it owes tile it - 1 its second half (block 1's softmax tail and P V). Neither: only the DMA and the barrier."""
         G = [[] for _ in range(64)]   # fillers per gap, (order key, emit function)
         def put(g, key, fn): G[g % 64].append((key, fn))
-        if has_cur:
+        self.in_loop = True
+        if "valu" in self.ablate:
+            has_cur_sm = has_prev_sm = False
+        else:
+            has_cur_sm, has_prev_sm = has_cur, has_prev
+        if has_cur_sm:
             for (g, k, fn) in self.softmax_ops(0, True, masked, drop):
                 put(g, (0, k), fn)
             for (g, k, fn) in self.softmax_ops(1, True, masked, drop):
                 if 32 + g < 64:
                     put(32 + g, (1, k), fn)
-        if has_prev:
+        if has_prev_sm:
             for (g, k, fn) in self.softmax_ops(1, False, False, False):   # the tail of the PREVIOUS tile's block 1 (never the diagonal tile's mask: that sits in the head)
                 if 32 + g >= 64:
                     put(32 + g - 64, (1, k), fn)
-        # V^T fragments: tile it - 1 for slot B (read in A), tile it for slot D (read in C); in consumption order, 3 per gap
-        def vreads(g0):
+        # V^T fragments of tile it: read ONCE, in slot C, in consumption order, 2 per gap; they serve slot D (block 0) and slot B of
+        # the NEXT iteration (block 1's P V of the same tile): the 64 registers are rewritten only by slot C of that iteration
+        if has_cur:
             seq = [(ks, db, sec) for ks in range(4) for db in range(4) for sec in (0, 1)]
             for i, (ks, db, sec) in enumerate(seq):
-                put(g0 + i // 3, (2, i), lambda ks=ks, db=db, sec=sec: self.lds_v(ks, db, sec))
-        if has_prev: vreads(0)
-        if has_cur: vreads(32)
+                put(32 + i // 2, (2, i), lambda ks=ks, db=db, sec=sec: self.lds_v(ks, db, sec))
         # K fragments of tile it + 1 (slot D; its own tiles only)
         if has_cur and not masked:
             seq = [(sub, kk) for sub in range(2) for kk in range(8)]
@@ -254,20 +272,18 @@ class Gen:
                   (V_SRD, DMA[0], S_VOFF0, S_M0V, 0, 0), (V_SRD, DMA[0], S_VOFF0, S_M0V, 896, 128),
                   (V_SRD, DMA[1], S_VOFF1, S_M0V, 2048, 0), (V_SRD, DMA[1], S_VOFF1, S_M0V, 2048 + 896, 128)]
         for i, p in enumerate(pieces):
-            put(23 + i, (3, i), lambda p=p: self.dma(*p))
+            put(23 + i, (-1, i), lambda p=p: self.dma_m0(p[3], p[4]))      # M0 first in the gap, the load last
+            put(23 + i, (3, i), lambda p=p: self.dma_load(p[0], p[1], p[2], p[5]))
         # loop bookkeeping (slot B, behind the DMA): ring toggles, next source offsets
         def book():
             for r in (KB[0], KB[1], VB[0], VB[1]):
                 self.valu(f"v_xor_b32 {vr(r)}, {KSLOT}, {vr(r)}", V(r), V(r))
             self.salu(f"s_xor_b32 {sr(S_M0K)}, {sr(S_M0K)}, {KSLOT}")
             self.salu(f"s_xor_b32 {sr(S_M0V)}, {sr(S_M0V)}, {KSLOT}")
-            # K(it + 3) and V(it + 2) for the next iteration, clamped to the last tile (a clamped piece is fetched again and never read)
-            for (dst0, dst1, ahead) in ((S_KOFF0, S_KOFF1, 3), (S_VOFF0, S_VOFF1, 2)):
-                self.salu(f"s_add_u32 {sr(S_TMP)}, {sr(S_IT)}, {ahead}")
-                self.salu(f"s_min_u32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_TM1)}")
-                self.salu(f"s_mul_i32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_TSTEP)}")
-                self.salu(f"s_add_u32 {sr(dst0)}, {sr(S_TMP)}, {sr(S_RB0)}")
-                self.salu(f"s_lshl_b32 {sr(S_TMP2)}, {sr(S_KVSR)}, 3")
+            # K(it + 3) and V(it + 2) for the next iteration: one tile further, saturating at the last tile (a clamped piece is fetched again and never read)
+            for (dst0, dst1) in ((S_KOFF0, S_KOFF1), (S_VOFF0, S_VOFF1)):
+                self.salu(f"s_add_u32 {sr(dst0)}, {sr(dst0)}, {sr(S_TSTEP)}")
+                self.salu(f"s_min_u32 {sr(dst0)}, {sr(dst0)}, {sr(S_X2)}")
                 self.salu(f"s_add_u32 {sr(dst1)}, {sr(dst0)}, {sr(S_TMP2)}")
         put(31, (4, 0), book)
 
@@ -281,7 +297,7 @@ class Gen:
                 self.salu("s_nop 15")   # no MFMAs in this slot of the first tile: the S chain that has just been issued gets its time
                 self.salu("s_nop 7")
             if g == 16:
-                self.wait(vm=0, lgkm=0)    # this wave's DMA pieces of the previous iteration have landed; V^T fragments of slot A
+                self.wait(vm=0)            # this wave's DMA pieces of the previous iteration have landed
                 self.barrier()             # everyone's: K(it + 1), V(it) are in LDS, V(it - 1) and K(it) are no longer read
             if g == 48 and has_cur:
                 self.wait(lgkm=0)          # V^T fragments (read in slot C)
@@ -298,6 +314,7 @@ class Gen:
                 self.out.append(Ins("", "nomfma"))
             for _, fn in sorted(G[g], key=lambda t: t[0]):
                 fn()
+        self.in_loop = False
 
     # -------------------------------------------------------------- whole pass of one query block
     def prologue(self):
@@ -314,11 +331,14 @@ class Gen:
         for dst, src in ((S_C, "c"), (S_DEFER, "defer"), (S_T, "T"), (S_KVSR, "kvsr"), (S_QSR, "qsr"), (S_OSR, "osr"), (S_WID, "wid"), (S_LDS, "lds"), (S_MUT, "mut")):
             e.salu(f"s_mov_b32 {sr(dst)}, %[{src}]")
         e.salu(f"s_sub_u32 {sr(S_TM1)}, {sr(S_T)}, 1")
+        e.salu(f"s_lshl_b32 {sr(S_X2)}, {sr(S_KVSR)}, 6")
+        e.salu(f"s_mul_i32 {sr(S_X2)}, {sr(S_X2)}, {sr(S_TM1)}")
         e.salu(f"s_sub_u32 {sr(S_DT)}, {sr(S_T)}, 4")
         e.salu(f"s_add_u32 {sr(S_DT)}, {sr(S_DT)}, {sr(S_WID)}")            # this wave's diagonal tile
         e.salu(f"s_lshl_b32 {sr(S_TSTEP)}, {sr(S_KVSR)}, 6")                  # bytes per 64-key tile
         e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 4")
         e.salu(f"s_mul_i32 {sr(S_RB0)}, {sr(S_TMP)}, {sr(S_KVSR)}")          # rows 16 w .. of a tile: this wave's two row groups
+        e.salu(f"s_add_u32 {sr(S_X2)}, {sr(S_X2)}, {sr(S_RB0)}")             # ... of the LAST tile: where the source offsets saturate
         e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 12")
         e.salu(f"s_add_u32 {sr(S_M0K)}, {sr(S_LDS)}, {sr(S_TMP)}")           # DMA destination of this wave inside a K slot ...
         e.salu(f"s_add_u32 {sr(S_M0V)}, {sr(S_M0K)}, {VSLOT0}")              # ... and a V slot
@@ -428,24 +448,26 @@ class Gen:
         """Head of every iteration: which variant does this wave run at tile S_IT?  it > dt + 1: idle; == dt + 1: drain; == dt: masked;
         == 0: first; else steady. The loop ends after iteration T (the last wave's drain)."""
         e = self
-        e.label("L_loop_%=")
-        e.salu(f"s_add_u32 {sr(S_TMP)}, {sr(S_DT)}, 1")
-        e.salu(f"s_cmp_gt_u32 {sr(S_IT)}, {sr(S_TMP)}")
-        e.salu("s_cbranch_scc1 L_idle_%=")
-        e.salu(f"s_cmp_eq_u32 {sr(S_IT)}, {sr(S_TMP)}")
-        e.salu("s_cbranch_scc1 L_drain_%=")
+        e.salu("s_branch L_loop_%=")
+        e.label("L_tail_%=")      # it >= dt: the diagonal tile, the drain, then idle iterations
         e.salu(f"s_cmp_eq_u32 {sr(S_IT)}, {sr(S_DT)}")
         e.salu("s_cbranch_scc1 L_diag_%=")
+        e.salu(f"s_add_u32 {sr(S_TMP)}, {sr(S_DT)}, 1")
+        e.salu(f"s_cmp_eq_u32 {sr(S_IT)}, {sr(S_TMP)}")
+        e.salu("s_cbranch_scc1 L_drain_%=")
+        e.salu("s_branch L_idle_%=")
+        e.label("L_diag_%=")
+        e.salu(f"s_cmp_eq_u32 {sr(S_IT)}, 0")
+        e.salu("s_cbranch_scc1 L_firstmasked_%=")
+        e.salu("s_branch L_masked_%=")
+        e.label("L_loop_%=")      # the common case first: 0 < it < dt falls through into the steady body
+        e.salu(f"s_cmp_ge_u32 {sr(S_IT)}, {sr(S_DT)}")
+        e.salu("s_cbranch_scc1 L_tail_%=")
         e.salu(f"s_cmp_eq_u32 {sr(S_IT)}, 0")
         e.salu("s_cbranch_scc1 L_first_%=")
         if self.mutant:
             e.salu(f"s_cmp_eq_u32 {sr(S_IT)}, {sr(S_MUT)}")
             e.salu("s_cbranch_scc1 L_steadydrop_%=")
-        e.salu("s_branch L_steady_%=")
-        e.label("L_diag_%=")
-        e.salu(f"s_cmp_eq_u32 {sr(S_IT)}, 0")
-        e.salu("s_cbranch_scc1 L_firstmasked_%=")
-        e.salu("s_branch L_masked_%=")
 
     def next_iter(self):
         e = self
@@ -526,8 +548,8 @@ class Gen:
                 for i in range(8):
                     e.out.append(Ins(f"buffer_store_dwordx4 {vr(100 + 4 * i, 4)}, {vr(oo)}, {sr(O_SRD, 4)}, {sr(S_X0)} offen", "vmem"))
                     e.salu(f"s_add_u32 {sr(S_X0)}, {sr(S_X0)}, {sr(S_X1)}")
-        e.wait(vm=0)
-        e.barrier()   # the next block of this workgroup reuses the ring and the slabs
+        # no wait and no barrier here: nobody reads the ring after the last iteration's barrier, a wave's DMA pieces always land in its
+        # own quarter of a slot (in order behind its older ones), the slab is the wave's own, and the stores drain under the next block's prologue
 
     def build(self):
         self.prologue()
@@ -698,9 +720,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check-only", action="store_true")
     ap.add_argument("--gaps", default="", help="print the gap table of a variant")
+    ap.add_argument("--out", default=str(OUT))
+    ap.add_argument("--ablate", default="", help="comma list of dma, valu, lds, barrier: leave that part of the tile body out (timing experiments; wrong results)")
     args = ap.parse_args()
+    abl = tuple(x for x in args.ablate.split(",") if x)
     assert selftest()
-    g = Gen(False).build()
+    g = Gen(False, ablate=abl).build()
     probs = check(g.out)
     if args.gaps:
         tot = 0
@@ -710,15 +735,15 @@ def main():
         print("estimated cycles per iteration:", tot)
     for p in probs[:40]:
         print("HAZARD:", p, file=sys.stderr)
-    if probs:
+    if probs and not abl:   # (an ablated stream is a timing experiment: its results are wrong anyway)
         return 1
     if args.check_only:
         return 0
     texts = {}
     for f16 in (False, True):
         for mut in (False, True):
-            gg = Gen(f16, mut).build()
-            assert not check(gg.out), check(gg.out)[:5]
+            gg = Gen(f16, mut, ablate=abl).build()
+            assert abl or not check(gg.out), check(gg.out)[:5]
             texts[(f16, mut)] = render(gg.out).replace(chr(10), " " + chr(92) + chr(10))
     n_ins = sum(1 for i in g.out if i.kind not in ("raw", "label", "nomfma"))
     text = f"""// GENERATED by tools/gen_attn_fwd.py - do not edit; edit the generator and run it again.
@@ -739,8 +764,8 @@ def main():
 {texts[(True, False)]}
 #endif
 """
-    OUT.write_text(text)
-    print(f"wrote {OUT} ({n_ins} instructions per element type)")
+    Path(args.out).write_text(text)
+    print(f"wrote {args.out} ({n_ins} instructions per element type)")
     return 0
 
 
