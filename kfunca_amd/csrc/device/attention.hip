@@ -67,6 +67,9 @@ struct AttnArgs {
     int nbh;         // pairs in this launch (forward and the other forms: B H, bh0 = 0)
     char *ds;        // backward: dS = P o (dP - delta) in 16 bits, written by the dK/dV kernel, read by the dQ kernel (null: not kept)
     int64_t ds_nqb, ds_nkwb; // its tile grid: 256-query blocks x 32-key blocks (DS_* below)
+#ifdef KF_FWD_W4_STAMPS
+    unsigned long long *dbg; // diagnostic build (tools/attn_fwd_w4_timeline.py): where every wave writes its cycle sums
+#endif
 };
 
 // dS workspace (backward): the dK/dV kernel already holds dS = P o (dP - delta) as packed 16-bit MFMA operands; it stores them
@@ -622,18 +625,26 @@ __global__ __launch_bounds__(256) void attn_fwd_w4_kernel(const AttnArgs a) {
 #ifdef KF_MUTANT
         if (a.mutant == 1 && qblk == nxb - 1) mut = 1; // defect 1: the head's last block drops key tile 1
 #endif
+#ifdef KF_FWD_W4_STAMPS // diagnostic build (tools/attn_fwd_w4_timeline.py): eight cycle sums per wave and block into the debug buffer
+        unsigned long long *dbg = a.dbg;
+        const unsigned dbgoff = (blockIdx.x * 2 + pass) * 4 * 32;
+#define KF_W4_EXTRA , [dbg] "s"(dbg), [dbgoff] "s"(dbgoff)
+#else
+#define KF_W4_EXTRA
+#endif
         if constexpr (BF)
             asm volatile(KF_FWD_W4_ASM_BF16
                          :
                          : [qp] "s"(qp), [kp] "s"(kp), [vp] "s"(vp), [op] "s"(op), [lsep] "s"(lsep), [qsr] "s"(qsr), [kvsr] "s"(kvsr), [osr] "s"(osr),
-                           [T] "s"(T), [wid] "s"(wid), [c] "s"(c), [defer] "s"(defer), [lds] "s"(lds), [mut] "s"(mut)
+                           [T] "s"(T), [wid] "s"(wid), [c] "s"(c), [defer] "s"(defer), [lds] "s"(lds), [mut] "s"(mut) KF_W4_EXTRA
                          : KF_FWD_W4_CLOBBERS);
         else
             asm volatile(KF_FWD_W4_ASM_F16
                          :
                          : [qp] "s"(qp), [kp] "s"(kp), [vp] "s"(vp), [op] "s"(op), [lsep] "s"(lsep), [qsr] "s"(qsr), [kvsr] "s"(kvsr), [osr] "s"(osr),
-                           [T] "s"(T), [wid] "s"(wid), [c] "s"(c), [defer] "s"(defer), [lds] "s"(lds), [mut] "s"(mut)
+                           [T] "s"(T), [wid] "s"(wid), [c] "s"(c), [defer] "s"(defer), [lds] "s"(lds), [mut] "s"(mut) KF_W4_EXTRA
                          : KF_FWD_W4_CLOBBERS);
+#undef KF_W4_EXTRA
     }
 }
 
@@ -2429,6 +2440,10 @@ static int attn_fwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
     KF_REQUIRE(scale > 0.f && scale < INFINITY, KF_ERR_INVALID, "attention: the softmax scale must be positive and finite");
     a.scale = scale;
     a.scale_log2e = scale * kLog2e;
+#ifdef KF_FWD_W4_STAMPS
+    extern unsigned long long *kf_attn_tl_host_ptr();
+    a.dbg = kf_attn_tl_host_ptr();
+#endif
     a.xcd_map = ((B * H) % 8 == 0) && !knob(KNOB_ATTN_NO_XCD);
     a.defer = knob(KNOB_ATTN_NO_DEFER) ? -INFINITY : kDeferMax; // A/B switch: rescale O at every tile
 #ifdef KF_MUTANT
@@ -2717,8 +2732,11 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
 }
 
 #ifdef KF_ATTN_TIMELINE
+static unsigned long long *g_attn_tl_host = nullptr;
+unsigned long long *kf_attn_tl_host_ptr() { return g_attn_tl_host; }
 extern "C" int kfdbg_attn_timeline(void *buf) { // buf: grid x 2 passes x 8 waves x 8 counters of 8 bytes, zero-filled by the caller
     unsigned long long *p = (unsigned long long *)buf;
+    g_attn_tl_host = p;
     return hipMemcpyToSymbol(HIP_SYMBOL(kf::g_attn_tl), &p, sizeof(p)) == hipSuccess ? KF_OK : KF_ERR_HIP;
 }
 #endif

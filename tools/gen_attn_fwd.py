@@ -59,6 +59,14 @@ S_LDS, S_STAGE, S_X0, S_X1, S_X2 = 74, 75, 76, 77, 78
 S_MUT = 79  # mutation build: the tile whose probabilities are dropped (-1: none)
 N_VGPR = 200  # v0 .. v199 are the stream's; the rest of the arch file stays the compiler's (it has nowhere else to keep a scalar it cannot hold in SGPRs)
 
+# ---- placement tables (gap = position behind MFMA number `gap` of the 64 of a tile iteration; slot A 0..15, B 16..31, C 32..47, D 48..63)
+# Measured (tools/attn_fwd_w4_timeline.py, cycles per steady iteration, slots A / B / C / D): all 8 pieces in slot B and the V reads two per gap
+# over slot C: 606 / 824 / 742 / 703 = 2875; the 4 V pieces moved to slot D's tail and the V reads spread over gaps 22 .. 47 (into the DMA slot):
+# 612 / 891 / 683 / 754 = 2940 - LDS reads beside DMA pieces cost more than they relieve.
+DMA_G = [23, 24, 25, 26, 27, 28, 29, 30]   # all 8 pieces behind the barrier, one per gap (K first: it is needed a slot earlier)
+BOOK_K_G, BOOK_V_G, BOOK_VB_G = 31, 31, 31  # ring toggles + next source offsets, each behind the last use of the old slot
+VREAD_G = [32 + i // 3 for i in range(32)]  # slot C, three per gap: done five gaps before slot D's wait
+
 KSLOT = 16384
 VSLOT0 = 32768
 STAGE0 = 65536
@@ -82,8 +90,9 @@ def A(i, n=1): return [("a", j) for j in range(i, i + n)]
 
 
 class Gen:
-    def __init__(self, f16=False, mutant=False, ablate=()):
+    def __init__(self, f16=False, mutant=False, ablate=(), stamps=False):
         self.mutant = mutant
+        self.stamps = stamps        # diagnostic build (tools/attn_fwd_w4_timeline.py): s_memtime at the slot boundaries, eight sums per wave and block
         self.ablate = set(ablate)   # timing experiments only (tools/scratch/fwd_w4_ablate.sh): parts of the tile body left out - WRONG results
         self.mfma = "v_mfma_f32_32x32x16_f16" if f16 else "v_mfma_f32_32x32x16_bf16"
         self.cvt = "v_cvt_pk_f16_f32" if f16 else "v_cvt_pk_bf16_f32"
@@ -144,6 +153,17 @@ class Gen:
         self.dma_m0(m0_from, m0_add)
         self.dma_load(srd, voff, soff, inst_off)
 
+    def stamp(self, bucket):
+        """Diagnostic build only: the cycles since the previous stamp go to accumulator `bucket` (0 prologue, 1..4 the steady tile's slots
+        A..D, 5 the other variants' iterations, 6 epilogue; s91 counts steady iterations). The SMEM round trip of each stamp (~100 cycles)
+        lands in the bucket that FOLLOWS it: tools/attn_fwd_w4_timeline.py calibrates it with two stamps back to back (bucket 7)."""
+        if not self.stamps: return
+        self.salu("s_memtime s[80:81]")
+        self.salu("s_waitcnt lgkmcnt(0)")
+        self.salu("s_sub_u32 s83, s80, s82")
+        self.salu(f"s_add_u32 s{84 + bucket}, s{84 + bucket}, s83")
+        self.salu("s_mov_b32 s82, s80")
+
     # -------------------------------------------------------------- the filler streams of one iteration
     def softmax_ops(self, b, cur, masked, drop):
         """All VALU ops of block b's softmax of one tile as (gap, order, emit) tuples; gaps are relative to the block's S slot
@@ -170,18 +190,25 @@ class Gen:
                               V(S(b, 16 * sub + e)) + V(NEGINF) + [("vcc", 0)], V(S(b, 16 * sub + e)))
                 add(g, m)
         # ---- tile maximum per lane: two chains (sub 0 -> MXA, sub 1 -> MXB), v_max3 takes two new values per instruction
-        shift = 0
-        chains = ((0, MXA[b], 9, 1.2), (1, MXB[b], 17, 2.0))
-        if masked:
-            chains = ((0, MXA[0], 11, 2.0),) if b == 0 else ((0, MXA[1], 9, 1.2), (1, MXB[1], 19, 4.0))
-        for sub, mx, g0, per in chains:
-            base = S(b, 16 * sub)
-            seq = [(base, base + 1, base + 2)] + [(mx, base + 3 + 2 * j, min(base + 4 + 2 * j, base + 15)) for j in range(7)]
-            for j, (x, y, z) in enumerate(seq):
-                add(g0 + int(j / per), lambda x=x, y=y, z=z, mx=mx: self.valu(f"v_max3_f32 {vr(mx)}, {vr(x)}, {vr(y)}, {vr(z)}", V(x) + V(y) + V(z), V(mx)))
+        # sub 1's sixteen values (ready only at gap 17, the decision at 21) go as TWO interleaved chains of four: no max3 waits for the one in front of it
+        MXC = T[3]
+        def chain(vals, mx, gaps):
+            seq = [(vals[0], vals[1], vals[2])] + [(mx, vals[3 + 2 * j], vals[min(4 + 2 * j, len(vals) - 1)]) for j in range((len(vals) - 2) // 2)]
+            assert len(seq) == len(gaps), (len(seq), len(gaps))
+            for (x, y, z), g in zip(seq, gaps):
+                add(g, lambda x=x, y=y, z=z, mx=mx: self.valu(f"v_max3_f32 {vr(mx)}, {vr(x)}, {vr(y)}, {vr(z)}", V(x) + V(y) + V(z), V(mx)))
+        s0, s1 = [S(b, e) for e in range(16)], [S(b, 16 + e) for e in range(16)]
+        if masked and b == 0:        # sub 1 lies wholly above the diagonal (MXB = -inf above); sub 0 behind its mask ops
+            chain(s0, MXA[0], [11, 11, 12, 12, 13, 13, 14, 14])
+            add(15, lambda: self.valu(f"v_mov_b32 {vr(MXC)}, {vr(NEGINF)}", V(NEGINF), V(MXC)))
+        else:
+            chain(s0, MXA[b], [9, 9, 10, 11, 12, 13, 14, 14])
+            g1 = [19, 19, 20, 20] if masked else [17, 18, 19, 20]
+            chain(s1[:8], MXB[b], g1)
+            chain(s1[8:], MXC, g1)
         # ---- decision: does any query of the wave exceed the maximum in use by more than `defer` exponent units?
-        gd = 21 + shift
-        add(gd, lambda: self.valu(f"v_max_f32 {vr(MXA[b])}, {vr(MXA[b])}, {vr(MXB[b])}", V(MXA[b]) + V(MXB[b]), V(MXA[b])))
+        gd = 21
+        add(gd, lambda: self.valu(f"v_max3_f32 {vr(MXA[b])}, {vr(MXA[b])}, {vr(MXB[b])}, {vr(MXC)}", V(MXA[b]) + V(MXB[b]) + V(MXC), V(MXA[b])))
         add(gd, lambda: self.valu(f"v_fma_f32 {vr(DV)}, {vr(MXA[b])}, {s_c}, -{vr(MC[b])}", V(MXA[b]) + V(MC[b]), V(DV)))
         add(gd + 1, lambda: self.valu(f"v_cmp_lt_f32 vcc, {sr(S_DEFER)}, {vr(DV)}", V(DV), [("vcc", 0)]))
         add(gd + 1, lambda: self.rescale(b))
@@ -257,10 +284,14 @@ class Gen:
                     put(32 + g - 64, (1, k), fn)
         # V^T fragments of tile it: read ONCE, in slot C, in consumption order, 2 per gap; they serve slot D (block 0) and slot B of
         # the NEXT iteration (block 1's P V of the same tile): the 64 registers are rewritten only by slot C of that iteration
+        # A fragment (ks, db) may be rewritten once slot B's MFMA 16 + 4 ks + db has read it, and V(it) is in LDS since the barrier at gap
+        # 16: the 32 reads spread over gaps 22 .. 47 (VREAD_G) instead of crowding slot C.
         if has_cur:
             seq = [(ks, db, sec) for ks in range(4) for db in range(4) for sec in (0, 1)]
             for i, (ks, db, sec) in enumerate(seq):
-                put(32 + i // 2, (2, i), lambda ks=ks, db=db, sec=sec: self.lds_v(ks, db, sec))
+                g = VREAD_G[i]
+                assert g >= 16 + 4 * ks + db + 2
+                put(g, (2, i), lambda ks=ks, db=db, sec=sec: self.lds_v(ks, db, sec))
         # K fragments of tile it + 1 (slot D; its own tiles only)
         if has_cur and not masked:
             seq = [(sub, kk) for sub in range(2) for kk in range(8)]
@@ -272,20 +303,28 @@ class Gen:
                   (V_SRD, DMA[0], S_VOFF0, S_M0V, 0, 0), (V_SRD, DMA[0], S_VOFF0, S_M0V, 896, 128),
                   (V_SRD, DMA[1], S_VOFF1, S_M0V, 2048, 0), (V_SRD, DMA[1], S_VOFF1, S_M0V, 2048 + 896, 128)]
         for i, p in enumerate(pieces):
-            put(23 + i, (-1, i), lambda p=p: self.dma_m0(p[3], p[4]))      # M0 first in the gap, the load last
-            put(23 + i, (3, i), lambda p=p: self.dma_load(p[0], p[1], p[2], p[5]))
+            put(DMA_G[i], (-1, i), lambda p=p: self.dma_m0(p[3], p[4]))      # M0 first in the gap, the load last
+            put(DMA_G[i], (3, i), lambda p=p: self.dma_load(p[0], p[1], p[2], p[5]))
         # loop bookkeeping (slot B, behind the DMA): ring toggles, next source offsets
-        def book():
-            for r in (KB[0], KB[1], VB[0], VB[1]):
+        # each toggle sits between the last use of the old slot and the first use of the new one
+        def book_vb():   # V read bases -> the slot of V(it): behind the barrier, before the first V read
+            for r in VB:
+                self.valu(f"v_xor_b32 {vr(r)}, {KSLOT}, {vr(r)}", V(r), V(r))
+        def book_k():    # behind the K pieces, before slot D's K reads: K read bases -> K(it + 1)'s slot; DMA side -> K(it + 3)
+            for r in KB:
                 self.valu(f"v_xor_b32 {vr(r)}, {KSLOT}, {vr(r)}", V(r), V(r))
             self.salu(f"s_xor_b32 {sr(S_M0K)}, {sr(S_M0K)}, {KSLOT}")
+            self.salu(f"s_add_u32 {sr(S_KOFF0)}, {sr(S_KOFF0)}, {sr(S_TSTEP)}")   # one tile further, saturating at the last tile (a clamped piece is fetched again, never read)
+            self.salu(f"s_min_u32 {sr(S_KOFF0)}, {sr(S_KOFF0)}, {sr(S_X2)}")
+            self.salu(f"s_add_u32 {sr(S_KOFF1)}, {sr(S_KOFF0)}, {sr(S_TMP2)}")
+        def book_v():    # behind the V pieces: DMA side -> V(it + 2)
             self.salu(f"s_xor_b32 {sr(S_M0V)}, {sr(S_M0V)}, {KSLOT}")
-            # K(it + 3) and V(it + 2) for the next iteration: one tile further, saturating at the last tile (a clamped piece is fetched again and never read)
-            for (dst0, dst1) in ((S_KOFF0, S_KOFF1), (S_VOFF0, S_VOFF1)):
-                self.salu(f"s_add_u32 {sr(dst0)}, {sr(dst0)}, {sr(S_TSTEP)}")
-                self.salu(f"s_min_u32 {sr(dst0)}, {sr(dst0)}, {sr(S_X2)}")
-                self.salu(f"s_add_u32 {sr(dst1)}, {sr(dst0)}, {sr(S_TMP2)}")
-        put(31, (4, 0), book)
+            self.salu(f"s_add_u32 {sr(S_VOFF0)}, {sr(S_VOFF0)}, {sr(S_TSTEP)}")
+            self.salu(f"s_min_u32 {sr(S_VOFF0)}, {sr(S_VOFF0)}, {sr(S_X2)}")
+            self.salu(f"s_add_u32 {sr(S_VOFF1)}, {sr(S_VOFF0)}, {sr(S_TMP2)}")
+        put(BOOK_VB_G, (4, 0), book_vb)
+        put(BOOK_K_G, (4, 1), book_k)
+        put(BOOK_V_G, (4, 2), book_v)
 
         self.label(f"L_{name}_%=")
         for g in range(64):
@@ -293,6 +332,8 @@ class Gen:
             # ---- waits in front of the slot's first MFMA
             if g == 0 and has_cur:
                 self.wait(lgkm=0)          # K fragments (read in slot D of the previous iteration / the prologue)
+            if name == "steady" and g in (16, 32, 48):
+                self.stamp(g // 16)        # slot A / B / C ends here
             if g == 16 and has_cur and not has_prev:
                 self.salu("s_nop 15")   # no MFMAs in this slot of the first tile: the S chain that has just been issued gets its time
                 self.salu("s_nop 7")
@@ -315,10 +356,20 @@ class Gen:
             for _, fn in sorted(G[g], key=lambda t: t[0]):
                 fn()
         self.in_loop = False
+        self.stamp(4 if name == "steady" else 5)
+        if self.stamps and name == "steady":
+            self.salu("s_add_u32 s91, s91, 1")
 
     # -------------------------------------------------------------- whole pass of one query block
     def prologue(self):
         e = self
+        if self.stamps:
+            for i in range(84, 92):
+                e.salu(f"s_mov_b32 s{i}, 0")
+            e.salu("s_memtime s[80:81]")
+            e.salu("s_waitcnt lgkmcnt(0)")
+            e.salu("s_mov_b32 s82, s80")
+            self.stamp(7)   # calibration: two stamps back to back
         e.raw("; ---- inputs into fixed registers")
         e.salu(f"s_mov_b64 {sr(K_SRD, 2)}, %[kp]")
         e.salu(f"s_mov_b64 {sr(V_SRD, 2)}, %[vp]")
@@ -443,6 +494,7 @@ class Gen:
             for kk in range(8):
                 self.lds_k(sub, kk)
         e.salu(f"s_mov_b32 {sr(S_IT)}, 0")
+        self.stamp(0)
 
     def dispatch(self):
         """Head of every iteration: which variant does this wave run at tile S_IT?  it > dt + 1: idle; == dt + 1: drain; == dt: masked;
@@ -548,6 +600,17 @@ class Gen:
                 for i in range(8):
                     e.out.append(Ins(f"buffer_store_dwordx4 {vr(100 + 4 * i, 4)}, {vr(oo)}, {sr(O_SRD, 4)}, {sr(S_X0)} offen", "vmem"))
                     e.salu(f"s_add_u32 {sr(S_X0)}, {sr(S_X0)}, {sr(S_X1)}")
+        if self.stamps:
+            self.stamp(6)
+            e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 5")                  # 8 dwords per wave
+            e.salu(f"s_add_u32 {sr(S_TMP)}, {sr(S_TMP)}, %[dbgoff]")
+            e.valu(f"v_mov_b32 {vr(T[0])}, {sr(S_TMP)}")
+            for i in range(8):
+                e.valu(f"v_mov_b32 {vr(100 + i)}, s{84 + i}")
+            e.salu("s_mov_b64 exec, 1")
+            e.out.append(Ins(f"global_store_dwordx4 {vr(T[0])}, {vr(100, 4)}, %[dbg]", "vmem"))
+            e.out.append(Ins(f"global_store_dwordx4 {vr(T[0])}, {vr(104, 4)}, %[dbg] offset:16", "vmem"))
+            e.salu("s_mov_b64 exec, -1")
         # no wait and no barrier here: nobody reads the ring after the last iteration's barrier, a wave's DMA pieces always land in its
         # own quarter of a slot (in order behind its older ones), the slab is the wave's own, and the stores drain under the next block's prologue
 
@@ -721,11 +784,12 @@ def main():
     ap.add_argument("--check-only", action="store_true")
     ap.add_argument("--gaps", default="", help="print the gap table of a variant")
     ap.add_argument("--out", default=str(OUT))
+    ap.add_argument("--stamps", action="store_true", help="diagnostic build: s_memtime stamps at the slot boundaries (needs -DKF_FWD_W4_STAMPS)")
     ap.add_argument("--ablate", default="", help="comma list of dma, valu, lds, barrier: leave that part of the tile body out (timing experiments; wrong results)")
     args = ap.parse_args()
     abl = tuple(x for x in args.ablate.split(",") if x)
     assert selftest()
-    g = Gen(False, ablate=abl).build()
+    g = Gen(False, ablate=abl, stamps=args.stamps).build()
     probs = check(g.out)
     if args.gaps:
         tot = 0
@@ -742,7 +806,7 @@ def main():
     texts = {}
     for f16 in (False, True):
         for mut in (False, True):
-            gg = Gen(f16, mut, ablate=abl).build()
+            gg = Gen(f16, mut, ablate=abl, stamps=args.stamps).build()
             assert abl or not check(gg.out), check(gg.out)[:5]
             texts[(f16, mut)] = render(gg.out).replace(chr(10), " " + chr(92) + chr(10))
     n_ins = sum(1 for i in g.out if i.kind not in ("raw", "label", "nomfma"))
@@ -751,7 +815,7 @@ def main():
 // 4 waves x 64 query rows, one wave per SIMD, all 512 registers asm-owned; see the generator's header for the structure.
 #pragma once
 #define KF_FWD_W4_LDS_BYTES {LDS_BYTES}
-#define KF_FWD_W4_CLOBBERS {", ".join('"' + c + '"' for c in CLOBBERS)}
+#define KF_FWD_W4_CLOBBERS {", ".join('"' + c + '"' for c in CLOBBERS + ([f"s{i}" for i in range(80, 92)] if args.stamps else []))}
 #ifdef KF_MUTANT  // + one more variant of the tile body: the probabilities of tile %[mut] are dropped (tests/test_gpu_attention_mutants.py)
 #define KF_FWD_W4_ASM_BF16 \\
 {texts[(False, True)]}
