@@ -1,0 +1,32 @@
+"""not gpu: the generated attention forward (tools/gen_attn_fwd.py -> kfunca_amd/csrc/device/attn_fwd_w4.inc).
+
+The tile body is one hand-placed instruction stream; what hipcc would otherwise do for it the generator does itself, and this test
+holds it to that: (1) the address maps of the LDS image - what the DMA pieces write, what the K row reads and the transposed V reads
+deliver as MFMA operands - agree in a pure-Python model (`selftest`); (2) every variant of the emitted stream keeps the distances the
+hardware does not interlock (`check`: MFMA result -> VALU, VALU -> MFMA operand, LDS read -> use behind a wait); (3) the committed .inc is
+what the generator writes today (nobody edited one without the other)."""
+import subprocess
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tools"))
+
+
+def test_address_maps_and_hazard_distances():
+    import gen_attn_fwd as G
+    assert G.selftest()
+    for f16 in (False, True):
+        for mut in (False, True):
+            g = G.Gen(f16, mut).build()
+            assert G.check(g.out) == []
+            variants = {i.text[2:-4] for i in g.out if i.kind == "label" and i.text.endswith("_%=:")}
+            assert {"steady", "first", "masked", "firstmasked", "drain", "idle"} <= variants and ("steadydrop" in variants) == mut
+            assert sum(1 for i in g.out if i.kind == "mfma") == (64 + 48 + 56 + 40 + 16 + (64 if mut else 0))  # MFMAs per variant: steady, first, masked, firstmasked, drain
+
+
+def test_committed_inc_is_the_generators_output(tmp_path):
+    out = tmp_path / "w4.inc"
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "gen_attn_fwd.py"), "--out", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert out.read_text() == (ROOT / "kfunca_amd" / "csrc" / "device" / "attn_fwd_w4.inc").read_text(), "run tools/gen_attn_fwd.py"

@@ -512,6 +512,8 @@ class Gen:
         e.salu(f"s_cmp_eq_u32 {sr(S_IT)}, 0")
         e.salu("s_cbranch_scc1 L_firstmasked_%=")
         e.salu("s_branch L_masked_%=")
+        for _ in range(getattr(self, "pad", 0)):
+            e.salu("s_nop 0")     # (code-placement experiment: shifts the steady body by 4 bytes per pad)
         e.label("L_loop_%=")      # the common case first: 0 < it < dt falls through into the steady body
         e.salu(f"s_cmp_ge_u32 {sr(S_IT)}, {sr(S_DT)}")
         e.salu("s_cbranch_scc1 L_tail_%=")
@@ -784,11 +786,13 @@ def main():
     ap.add_argument("--check-only", action="store_true")
     ap.add_argument("--gaps", default="", help="print the gap table of a variant")
     ap.add_argument("--out", default=str(OUT))
+    ap.add_argument("--pad", type=int, default=0, help="s_nop 0 x N in front of the loop head (code-placement experiment)")
     ap.add_argument("--stamps", action="store_true", help="diagnostic build: s_memtime stamps at the slot boundaries (needs -DKF_FWD_W4_STAMPS)")
     ap.add_argument("--ablate", default="", help="comma list of dma, valu, lds, barrier: leave that part of the tile body out (timing experiments; wrong results)")
     args = ap.parse_args()
     abl = tuple(x for x in args.ablate.split(",") if x)
     assert selftest()
+    Gen.pad = args.pad
     g = Gen(False, ablate=abl, stamps=args.stamps).build()
     probs = check(g.out)
     if args.gaps:
