@@ -1704,6 +1704,61 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// dK / dV, round 4: 4 waves x 64 keys, one wave per SIMD, the whole 512-register file asm-owned (dK^T and dV^T of the wave's 64 keys in
+// all 256 accumulator registers, its K and V fragments in 128 vector registers), a block's pass as ONE generated instruction stream:
+// tools/gen_attn_dkv.py -> attn_dkv_w4.inc (structure, register map, placement documented there). The wrapper maps the workgroup to
+// its two 256-key blocks (a block and its causal mirror) and hands over scalars only. Head size 128, Skv a multiple of 256, K / V and
+// dK / dV with one row stride each; everything else keeps attn_bwd_dkv_v4_kernel. Same dS tiles, same row constants.
+// ------------------------------------------------------------------------------------------
+#ifndef KF_DKV_W4_INC
+#define KF_DKV_W4_INC "attn_dkv_w4.inc"
+#endif
+#include KF_DKV_W4_INC
+constexpr int K5B = 256; // keys per block
+template <bool BF, bool DS>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int xb0;
+    int64_t bh;
+    const int nkb = (int)(a.Skv / K5B), nwx = a.persist ? nkb / 2 : nkb;
+    a_block_map(nwx, a.nbh, a.xcd_map, xb0, bh);
+    bh += a.bh0;
+    const unsigned lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)smem;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const char *qp = a.q + a_head(a.lq, bh, a.H), *dop = a.d_o + a_head(a.ldo, bh, a.H);
+    const char *kh = a.k + a_head(a.lk, bh, a.H), *vh = a.v + a_head(a.lv, bh, a.H);
+    char *dkh = a.dk + a_head(a.ldk, bh, a.H), *dvh = a.dv + a_head(a.ldv, bh, a.H);
+    const float *cp = a.nlse + bh * a.Sq;
+    const unsigned cdelta = (unsigned)((const char *)a.ndelta - (const char *)a.nlse);
+    const int qsr = (int)a.lq.sr, dosr = (int)a.ldo.sr, kvsr = (int)a.lk.sr, osr = (int)a.ldk.sr;
+    const float scale = a.scale;
+    const int ns_all = (int)(a.Sq / BQS), dsqb = (int)(a.ds_nkwb * 8);
+#pragma nounroll
+    for (int pass = 0; pass < (a.persist ? 2 : 1); ++pass) {
+        const int xb = ((pass & 1) != (a.persist_rev != 0)) ? nkb - 1 - xb0 : xb0;
+        const int64_t k0 = (int64_t)xb * K5B;
+        const char *kp = kh + k0 * a.lk.sr, *vp = vh + k0 * a.lv.sr;
+        char *dkp = dkh + k0 * a.ldk.sr, *dvp = dvh + k0 * a.ldv.sr;
+        const int s0 = (int)(k0 / BQS);                    // the first slice with a query that sees one of the block's keys
+        const int ns = ns_all > s0 ? ns_all : s0;          // (a block beyond the last query: no slices, zero gradients)
+        const char *dsp = DS ? a.ds + (((bh - a.bh0) * a.ds_nqb * a.ds_nkwb + (k0 >> 5)) * 8) * DS_TILE : nullptr;
+        int mut = -1;
+#ifdef KF_MUTANT
+        if (a.mutant == 2 && xb == 0 && wid < 2) mut = 4; // defect 2: queries 128..159 contribute nothing to keys 0..127
+#endif
+#define KF_DKV_OPERANDS                                                                                                                       \
+    [qp] "s"(qp), [dop] "s"(dop), [kp] "s"(kp), [vp] "s"(vp), [dkp] "s"(dkp), [dvp] "s"(dvp), [cp] "s"(cp), [dsp] "s"(dsp), [cdelta] "s"(cdelta), \
+        [qsr] "s"(qsr), [dosr] "s"(dosr), [kvsr] "s"(kvsr), [osr] "s"(osr), [s0] "s"(s0), [ns] "s"(ns), [dsqb] "s"(dsqb), [wid] "s"(wid),       \
+        [scale] "s"(scale), [lds] "s"(lds), [mut] "s"(mut)
+        if constexpr (BF && DS) asm volatile(KF_DKV_W4_ASM_BF16_DS : : KF_DKV_OPERANDS : KF_DKV_W4_CLOBBERS);
+        else if constexpr (BF) asm volatile(KF_DKV_W4_ASM_BF16_NODS : : KF_DKV_OPERANDS : KF_DKV_W4_CLOBBERS);
+        else if constexpr (DS) asm volatile(KF_DKV_W4_ASM_F16_DS : : KF_DKV_OPERANDS : KF_DKV_W4_CLOBBERS);
+        else asm volatile(KF_DKV_W4_ASM_F16_NODS : : KF_DKV_OPERANDS : KF_DKV_W4_CLOBBERS);
+#undef KF_DKV_OPERANDS
+    }
+}
+
 // ==========================================================================================
 // forward, f32 (the reference's dtype: CausalAttentionForwardFN<float, 64 | 128>, causal_attention.h:66-258), on the
 // exact-f32 matrix instruction v_mfma_f32_32x32x2_f32 (a k-ordered fma chain, 157 TFLOP/s dense, 1/16 of the bf16 rate -
@@ -2643,7 +2698,22 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
                 a.persist_rev = 1; // the short block of the pair first: 2.17 ms against 2.32 the other way round (2.22 unpaired)
                 dim3 gk4((unsigned)((a.persist ? nkb4 / 2 : nkb4) * a.nbh));
                 KF_PROF(D == 64 ? "attn_bwd_dkv_mfma_d64" : "attn_bwd_dkv_mfma", st);
-                if (D == 64) {
+                // round 4: 64 keys per wave (attn_bwd_dkv_w4_kernel) wherever its shape conditions hold; KF_ATTN_DKV_V4 keeps the 32-key kernel (A/B)
+                const int64_t nkb5 = Skv / K5B;
+                if (D == AD && Skv % K5B == 0 && a.lk.sr == a.lv.sr && a.ldk.sr == a.ldv.sr && (uint64_t)Sq * (uint64_t)std::max(a.lq.sr, a.ldo.sr) < (1ull << 32) &&
+                    (uint64_t)K5B * (uint64_t)std::max(a.lk.sr, a.ldk.sr) < (1ull << 31) && (uint64_t)((const char *)a.ndelta - (const char *)a.nlse) < (1ull << 31) &&
+                    !knob(KNOB_ATTN_DKV_V4)) {
+                    a.persist = (nkb5 % 2 == 0 && nkb5 >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
+                    dim3 gk5((unsigned)((a.persist ? nkb5 / 2 : nkb5) * a.nbh));
+#define KF_DKV5(BF_, DS_)                                                                                    \
+    {                                                                                                        \
+        if ((rc = set_lds(attn_bwd_dkv_w4_kernel<BF_, DS_>, KF_DKV_W4_LDS_BYTES)) != KF_OK) return rc;        \
+        attn_bwd_dkv_w4_kernel<BF_, DS_><<<gk5, 256, KF_DKV_W4_LDS_BYTES, st>>>(a);                          \
+    }
+                    if (bf) { if (keep_ds) KF_DKV5(true, true) else KF_DKV5(true, false) }
+                    else { if (keep_ds) KF_DKV5(false, true) else KF_DKV5(false, false) }
+#undef KF_DKV5
+                } else if (D == 64) {
                     if (bf) { if (keep_ds) KF_DKV(true, true, 64) else KF_DKV(true, false, 64) }
                     else { if (keep_ds) KF_DKV(false, true, 64) else KF_DKV(false, false, 64) }
                 } else if (bf) { if (keep_ds) KF_DKV(true, true, 128) else KF_DKV(true, false, 128) }

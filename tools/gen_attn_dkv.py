@@ -1,0 +1,695 @@
+#!/usr/bin/env python3
+"""Generator of the 16-bit causal-attention dK / dV kernel for gfx950 as ONE hand-placed instruction stream
+(kfunca_amd/csrc/device/attn_dkv_w4.inc, included by attention.hip). The reference has no backward at all
+(src/core/binary_ops.cpp:16-33 is its only GradFunction); this is the kernel VERDICT round 3 #2 asks for:
+
+  * a workgroup = 4 waves = 256 keys of one (batch, head); a wave = 64 keys (two 32-key sub-blocks) and the whole register file:
+      a[0:127]   dV^T accumulators [ksb][db]     a[128:255] dK^T accumulators [ksb][db]          (never leave; no atomics: bitwise reproducible)
+      v[128:191] K fragments [ksb][kk] (pre-scaled by scale log2 e)      v[192:255] V fragments [ksb][kk]        (B operands, loaded once)
+      v[0:31]    S accumulators [ksb] -> p = exp2(S'') in place          v[32:63]   dP accumulators -> dS = p dP' in place -> packed in place
+      v[64:79]   P packed [ksb][s]                                        v[80:111]  ONE ring of 8 A-operand fragments
+      v[112:127] addresses and temporaries
+  * "key on the lane": S = Q K^T and dP = dO V^T come out with the key on the lane and the query in the register, which makes the
+    accumulators - packed - the B operands of dV^T += dO^T P and dK^T += Q^T dS with no lane movement (cdna_hip_programming.md, section 3).
+    A query slice (32 queries) is 64 MFMAs in four slots of 16:  S | dP | dV | dK, each slot ksb-major, so the 8 fragments of its A
+    operand (Q rows | dO rows | dO^T | Q^T of the slice) serve BOTH key sub-blocks: 512 B of LDS reads per MFMA, half of the 32-key
+    kernel's. The 8 fragments live in one ring: slot j of the ring is free after its second MFMA and takes fragment j of the NEXT set.
+  * row constants as initial accumulators: -lse log2(e) and -delta of the slice's queries are read straight into the S and dP
+    accumulator registers, the chains start from them (C = D), p = exp2(S'') needs no subtraction.
+  * Q / dO slices (+ their 64 row constants) arrive by LDS-DMA into a two-slot ring, one slice ahead, 4 + 1 pieces per wave; ONE barrier
+    per slice (in front of slot 4, whose MFMAs read no LDS); dS = P o (dP - delta), already packed as the dK product's operands, leaves
+    with 4 write-through stores per slice for the dQ kernel (the layout of DS_TILE in attention.hip).
+  * causal: a wave's first two computed slices are its diagonal ones (variants diag0 / diag1, the fully masked sub-block's MFMAs are
+    not issued); earlier slices it only keeps the DMA and the barrier going (idle).
+LDS waits are COUNTED and inserted by the generator (`finish_waits`): before an instruction that reads the destination of a pending LDS
+read, s_waitcnt lgkmcnt(N) with N = the reads issued after that one."""
+import argparse
+import re
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tools"))
+from gen_attn_fwd import A, Ins, V, ar, render, vr  # noqa: E402
+
+
+def sr(i, n=1):
+    """s-register text; a read-only input operand ("%[name]") passes through."""
+    if isinstance(i, str):
+        return i
+    return f"s{i}" if n == 1 else f"s[{i}:{i + n - 1}]"
+
+
+OUT = ROOT / "kfunca_amd" / "csrc" / "device" / "attn_dkv_w4.inc"
+
+# ------------------------------------------------------------------ register map
+def S(ksb, e=0): return 16 * ksb + e
+def DP(ksb, e=0): return 32 + 16 * ksb + e
+def DSP(ksb, s): return 32 + 16 * ksb + 4 * s      # packed dS of k-step s: the first 8 registers of the sub-block's dP tuple
+def P(ksb, s): return 64 + 8 * ksb + 4 * s
+def RING(j): return 80 + 4 * j
+RB, TB, LR = (112, 113), (114, 115), 116
+DMAQ, DMAD, DMAC, DSOFF, RM = 117, 118, 119, 120, 121
+T = [64, 65, 66, 67, 68, 69]   # prologue / epilogue temporaries: the P registers, idle then
+def KFR(ksb, kk): return 122 + 32 * ksb + 4 * kk
+def VFR(ksb, kk): return 186 + 32 * ksb + 4 * kk
+def DV(ksb, db): return 64 * ksb + 16 * db
+def DK(ksb, db): return 128 + 64 * ksb + 16 * db
+
+Q_SRD, DO_SRD, C_SRD, O_SRD = 36, 40, 44, 48
+S_QOFF, S_DOOFF, S_COFF, S_QSTEP, S_DOSTEP, S_QMAX, S_DOMAX, S_CMAX = 52, 53, 54, 55, 56, 57, 58, 59
+S_M0, S_IT, S_NS, S_D0, S_TMP, S_TMP2 = 60, 61, 62, 63, 64, 65
+S_DS0, S_DS1 = 66, 68   # pairs
+S_SL, S_STAGE = 70, 71
+S_DSQB, S_WID, S_LDS, S_SCALE, S_MUT, S_OSR = "%[dsqb]", "%[wid]", "%[lds]", "%[scale]", "%[mut]", "%[osr]"   # read-only inputs: used in place
+S_X0, S_X1 = 72, 73
+S_DSB = 74              # pair: dS base of this wave's first key sub-block at slice 0 of the workspace
+N_SGPR_HI = 76
+N_VGPR = 250            # v250 .. v255 stay the compiler's (it needs somewhere to keep scalars it cannot hold in SGPRs)
+
+BUF = 32768             # two slice buffers, toggled by XOR
+SLICE_DO = 8192         # dO tile behind the Q tile
+SLICE_C = 16384         # 32 x -lse log2 e | 32 x -delta
+STAGE0 = 2 * BUF
+STAGE_ROW = 272
+LDS_BYTES = STAGE0 + 4 * 64 * STAGE_ROW
+DS_TILE = 2048
+
+
+class Gen:
+    def __init__(self, f16=False, mutant=False, ds=True, ablate=()):
+        self.mfma = "v_mfma_f32_32x32x16_f16" if f16 else "v_mfma_f32_32x32x16_bf16"
+        self.cvt = "v_cvt_pk_f16_f32" if f16 else "v_cvt_pk_bf16_f32"
+        self.f16, self.mutant, self.ds, self.ablate = f16, mutant, ds, set(ablate)
+        self.out = []
+
+    # -------------------------------------------------------------- emit helpers
+    def raw(self, t): self.out.append(Ins(t, "raw"))
+    def label(self, n): self.out.append(Ins(f"{n}:", "label"))
+    def salu(self, t): self.out.append(Ins(t, "salu"))
+    def valu(self, t, reads=(), writes=(), trans=False): self.out.append(Ins(t, "trans" if trans else "valu", reads, writes))
+
+    def mm(self, d, dn, a, b, c_is_d=True, tag="", acc="v"):
+        """D = A B + D on registers: d first of 16 (VGPR or AGPR by `acc`), a / b first of 4 VGPRs."""
+        dst = vr(d, 16) if acc == "v" else ar(d, 16)
+        W = V(d, 16) if acc == "v" else A(d, 16)
+        self.out.append(Ins(f"{self.mfma} {dst}, {vr(a, 4)}, {vr(b, 4)}, {dst}", "mfma", V(a, 4) + V(b, 4) + W, W, tag=tag))
+
+    def lds_row(self, dst, kk, tile_off):      # A fragment of k-step kk of a 32-row tile: row = lane & 31, chunk 2 kk + (lane >> 5)
+        if "lds" in self.ablate: return
+        self.out.append(Ins(f"ds_read_b128 {vr(dst, 4)}, {vr(RB[kk & 1])} offset:{tile_off + 512 * (kk >> 1)}", "lds", V(RB[kk & 1]), V(dst, 4)))
+
+    def lds_tr(self, dst, s, db, sec, tile_off):  # half of the transposed fragment (k-step s = queries 16 s .., column block db)
+        if "lds" in self.ablate: return
+        self.out.append(Ins(f"ds_read_b64_tr_b16 {vr(dst + 2 * sec, 2)}, {vr(TB[sec])} offset:{tile_off + 2048 * (2 * s + sec) + 512 * db}", "lds",
+                            V(TB[sec]), V(dst + 2 * sec, 2)))
+
+    def lds_const(self, dst, g, off):           # 4 of the 16 row constants of this lane: rows 8 g + 4 h + {0..3}
+        if "lds" in self.ablate: return
+        self.out.append(Ins(f"ds_read_b128 {vr(dst + 4 * g, 4)}, {vr(LR)} offset:{SLICE_C + off + 32 * g}", "lds", V(LR), V(dst + 4 * g, 4)))
+
+    def barrier(self): self.out.append(Ins("s_barrier", "barrier"))
+
+    def dma_piece(self, srd, voff, soff, m0_add, inst_off, dword=False):
+        if "dma" in self.ablate and getattr(self, "in_loop", False): return
+        self.salu(f"s_add_u32 m0, {sr(S_M0)}, {m0_add}" if m0_add else f"s_mov_b32 m0, {sr(S_M0)}")
+        self.salu("s_nop 0")
+        o = f" offset:{inst_off}" if inst_off else ""
+        op = "buffer_load_dword" if dword else "buffer_load_dwordx4"
+        self.out.append(Ins(f"{op} {vr(voff)}, {sr(srd, 4)}, {sr(soff)} offen{o} lds", "dma", V(voff)))
+
+    def dma_slice(self):
+        """This wave's pieces of one slice: rows 8 w .. 8 w + 7 of the Q tile and of the dO tile (two 1-KiB pieces each), and the 64 row
+        constants (every wave fetches them: identical bytes, uniform counts)."""
+        self.dma_piece(Q_SRD, DMAQ, S_QOFF, 0, 0)
+        self.dma_piece(Q_SRD, DMAQ, S_QOFF, 896, 128)
+        self.dma_piece(DO_SRD, DMAD, S_DOOFF, SLICE_DO, 0)
+        self.dma_piece(DO_SRD, DMAD, S_DOOFF, SLICE_DO + 896, 128)
+        self.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 11")
+        self.salu(f"s_sub_u32 {sr(S_TMP)}, {sr(S_M0)}, {sr(S_TMP)}")        # (M0 base carries this wave's 2048-byte row group; the constants sit at the buffer's own offset)
+        self.salu(f"s_add_u32 m0, {sr(S_TMP)}, {SLICE_C}")
+        self.salu("s_nop 0")
+        self.out.append(Ins(f"buffer_load_dword {vr(DMAC)}, {sr(C_SRD, 4)}, {sr(S_COFF)} offen lds", "dma", V(DMAC)))
+
+    def advance_dma(self):
+        """Source offsets one slice further, saturating at the block's last slice (a clamped slice is fetched again and never used)."""
+        for off, step, mx in ((S_QOFF, S_QSTEP, S_QMAX), (S_DOOFF, S_DOSTEP, S_DOMAX)):
+            self.salu(f"s_add_u32 {sr(off)}, {sr(off)}, {sr(step)}")
+            self.salu(f"s_min_u32 {sr(off)}, {sr(off)}, {sr(mx)}")
+        self.salu(f"s_add_u32 {sr(S_COFF)}, {sr(S_COFF)}, 128")
+        self.salu(f"s_min_u32 {sr(S_COFF)}, {sr(S_COFF)}, {sr(S_CMAX)}")
+
+    # -------------------------------------------------------------- one slice of one variant
+    def slice(self, name, kind, prev_stores):
+        """kind: 'steady' | 'diag0' (sub-block 0 on the diagonal, sub-block 1 wholly above it: not computed) | 'diag1' (sub-block 0 visible,
+        sub-block 1 on the diagonal) | 'idle' | 'drop' (mutation build: the slice's probabilities are zero)."""
+        compute = kind != "idle"
+        ksbs = [0] if kind == "diag0" else [0, 1]
+        G = [[] for _ in range(64)]
+        def put(g, key, fn): G[g].append((key, fn))
+        self.in_loop = True
+        nvalu = "valu" in self.ablate
+
+        # ---- the ring: fragment j of the next set goes into slot j behind the slot's second use (gap 8 + j of the MFMA slot in front)
+        if compute:
+            for j in range(8):
+                put(8 + j, (2, j), lambda j=j: self.lds_row(RING(j), j, SLICE_DO))                         # dO rows, for slot 2
+                for sec in (0, 1):
+                    put(24 + j, (2, 2 * j + sec), lambda j=j, sec=sec: self.lds_tr(RING(j), j >> 2, j & 3, sec, SLICE_DO))  # dO^T, slot 3
+                    put(40 + j, (2, 2 * j + sec), lambda j=j, sec=sec: self.lds_tr(RING(j), j >> 2, j & 3, sec, 0))         # Q^T, slot 4
+            # -delta of this slice's queries into the dP accumulators (both sub-blocks): behind the previous slice's dK MFMAs, ahead of slot 2
+            for i, (ksb, g) in enumerate([(k, g) for k in ksbs for g in range(4)]):
+                put(1 + i, (1, i), lambda ksb=ksb, g=g: self.lds_const(DP(ksb), g, 128))
+        # ---- what the NEXT slice's head expects, read from the other buffer behind the barrier (every variant, idle ones too):
+        #      -lse log2 e into the S accumulators, its Q rows into the ring
+        for i, (ksb, g) in enumerate([(k, g) for k in (0, 1) for g in range(4)]):
+            put(50 + i, (1, i), lambda ksb=ksb, g=g: self.lds_const(S(ksb), g, 0))
+        for j in range(8):
+            put(56 + j, (2, j), lambda j=j: self.lds_row(RING(j), j, 0))
+
+        # ---- arithmetic
+        if compute and not nvalu:
+            for ksb in ksbs:
+                e0, m0 = (9, 26) if ksb == 0 else (24, 34)
+                diag = (kind == "diag0" and ksb == 0) or (kind == "diag1" and ksb == 1)
+                for n in range(16):
+                    x, d = S(ksb, n), DP(ksb, n)
+                    if kind == "drop":
+                        put(e0 + n, (0, 0), lambda x=x: self.valu(f"v_mov_b32 {vr(x)}, 0", (), V(x)))
+                    else:
+                        put(e0 + n, (0, 0), lambda x=x: self.valu(f"v_exp_f32 {vr(x)}, {vr(x)}", V(x), V(x), trans=True))
+                    if diag:  # key r > query (n & 3) + 8 (n >> 2) + 4 h  <=>  r - 4 h > kc
+                        kc = (n & 3) + 8 * (n >> 2)
+                        def m(x=x, kc=kc):
+                            self.valu(f"v_cmp_lt_i32 vcc, {kc}, {vr(RM)}", V(RM), [("vcc", 0)])
+                            self.valu(f"v_cndmask_b32_e64 {vr(x)}, {vr(x)}, 0, vcc", V(x) + [("vcc", 0)], V(x))
+                        put(e0 + n + 1, (0, 1), m)
+                    if n % 2 == 1:
+                        pd = P(ksb, n // 8) + (n % 8) // 2
+                        put(e0 + n + 2, (0, 2), lambda x=x, pd=pd: self.valu(f"{self.cvt} {vr(pd)}, {vr(x - 1)}, {vr(x)}", V(x - 1) + V(x), V(pd)))
+                    put(m0 + n, (0, 3), lambda x=x, d=d: self.valu(f"v_mul_f32 {vr(d)}, {vr(x)}, {vr(d)}", V(x) + V(d), V(d)))
+                    if n % 2 == 1:
+                        dd = DP(ksb, n // 2)
+                        put(m0 + n + 2, (0, 4), lambda d=d, dd=dd: self.valu(f"{self.cvt} {vr(dd)}, {vr(d - 1)}, {vr(d)}", V(d - 1) + V(d), V(dd)))
+        # ---- behind the barrier: ring toggle, DMA of slice it + 2 into the buffer this slice has finished with, then this slice's dS
+        def after_barrier():
+            for r in (RB[0], RB[1], TB[0], TB[1], LR):
+                self.valu(f"v_xor_b32 {vr(r)}, {BUF}, {vr(r)}", V(r), V(r))
+        put(48, (-3, 0), after_barrier)
+        put(49, (3, 0), self.dma_slice)
+        def book():
+            self.salu(f"s_xor_b32 {sr(S_M0)}, {sr(S_M0)}, {BUF}")
+            self.advance_dma()
+        put(50, (4, 0), book)
+        nst = 0
+        if self.ds and compute and "stores" not in self.ablate:
+            order = [(0, 0, 54), (0, 1, 56), (1, 0, 58), (1, 1, 60)]
+            for ksb, s, g in order:
+                if ksb not in ksbs:
+                    continue
+                nst += 1
+                base = S_DS0 if ksb == 0 else S_DS1
+                put(g, (5, 0), lambda ksb=ksb, s=s, base=base: self.out.append(
+                    Ins(f"global_store_dwordx4 {vr(DSOFF)}, {vr(DSP(ksb, s), 4)}, {sr(base, 2)} offset:{1024 * s} sc0 sc1", "vmem", V(DSOFF) + V(DSP(ksb, s), 4))))
+        def ds_next():   # the dS tile addresses of the next slice: sl + 1; a new 256-query block every 8 slices
+            self.salu(f"s_add_u32 {sr(S_SL)}, {sr(S_SL)}, 1")
+            self.salu(f"s_lshr_b32 {sr(S_TMP)}, {sr(S_SL)}, 3")
+            self.salu(f"s_mul_i32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_DSQB)}")
+            self.salu(f"s_and_b32 {sr(S_TMP2)}, {sr(S_SL)}, 7")
+            self.salu(f"s_add_u32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_TMP2)}")
+            self.salu(f"s_lshr_b32 {sr(S_TMP2)}, {sr(S_TMP)}, {32 - 11}")
+            self.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_TMP)}, 11")
+            self.salu(f"s_add_u32 {sr(S_DS0)}, {sr(S_DSB)}, {sr(S_TMP)}")
+            self.salu(f"s_addc_u32 {sr(S_DS0 + 1)}, {sr(S_DSB + 1)}, {sr(S_TMP2)}")
+            self.salu(f"s_add_u32 {sr(S_DS1)}, {sr(S_DS0)}, {8 * DS_TILE}")
+            self.salu(f"s_addc_u32 {sr(S_DS1 + 1)}, {sr(S_DS0 + 1)}, 0")
+        put(62, (6, 0), ds_next)
+
+        self.label(f"L_{name}_%=")
+        for g in range(64):
+            slot, j = g // 16, g % 16
+            if g == 48:
+                # this wave's pieces of the NEXT slice have landed (the stores issued behind them may still be on their way), every LDS
+                # read of the current buffer has returned; then everyone's
+                self.out.append(Ins(f"s_waitcnt vmcnt({prev_stores}) lgkmcnt(0)", "wait", tag="vmlgkm"))
+                self.barrier()
+            ksb, i = j >> 3, j & 7
+            if compute and ksb in ksbs:
+                if slot == 0: self.mm(S(ksb), 16, RING(i), KFR(ksb, i), tag=f"S ksb{ksb} kk{i}")
+                elif slot == 1: self.mm(DP(ksb), 16, RING(i), VFR(ksb, i), tag=f"dP ksb{ksb} kk{i}")
+                elif slot == 2: self.mm(DV(ksb, i & 3), 16, RING(i), P(ksb, i >> 2), tag=f"dV ksb{ksb} s{i >> 2} db{i & 3}", acc="a")
+                else: self.mm(DK(ksb, i & 3), 16, RING(i), DSP(ksb, i >> 2), tag=f"dK ksb{ksb} s{i >> 2} db{i & 3}", acc="a")
+            else:
+                self.out.append(Ins("", "nomfma"))
+                if compute and j == 8 and slot < 2:
+                    self.salu("s_nop 15")   # diag0: the chain that has just ended gets its time before its first reader
+                    self.salu("s_nop 7")
+            for _, fn in sorted(G[g], key=lambda t: t[0]):
+                fn()
+        self.in_loop = False
+        self.stores_of = getattr(self, "stores_of", {})
+        self.stores_of[kind] = nst
+
+    # -------------------------------------------------------------- block pass
+    def prologue(self):
+        e = self
+        ins = [("qp", Q_SRD), ("dop", DO_SRD), ("cp", C_SRD)]
+        for nm, srd in ins:
+            e.salu(f"s_mov_b64 {sr(srd, 2)}, %[{nm}]")
+            e.salu(f"s_mov_b32 {sr(srd + 2)}, 0xffffffff")
+            e.salu(f"s_mov_b32 {sr(srd + 3)}, 0x00020000")
+        e.salu(f"s_mov_b32 {sr(O_SRD + 2)}, 0xffffffff")
+        e.salu(f"s_mov_b32 {sr(O_SRD + 3)}, 0x00020000")
+        for dst, src in ((S_NS, "ns"), (S_SL, "s0")):
+            e.salu(f"s_mov_b32 {sr(dst)}, %[{src}]")
+        e.salu(f"s_mov_b64 {sr(S_DSB, 2)}, %[dsp]")
+        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 15")                      # this wave's first 32-key block of the dS tile grid: 2 w x 8 tiles of 2 KiB
+        e.salu(f"s_add_u32 {sr(S_DSB)}, {sr(S_DSB)}, {sr(S_TMP)}")
+        e.salu(f"s_addc_u32 {sr(S_DSB + 1)}, {sr(S_DSB + 1)}, 0")
+        e.salu(f"s_lshl_b32 {sr(S_D0)}, {sr(S_WID)}, 1")                       # this wave's diagonal slices: 2 w and 2 w + 1 of the block's
+        # DMA: slice s0's offsets, steps, saturation values
+        e.salu(f"s_lshl_b32 {sr(S_QSTEP)}, %[qsr], 5")
+        e.salu(f"s_lshl_b32 {sr(S_DOSTEP)}, %[dosr], 5")
+        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 3")
+        e.salu(f"s_mul_i32 {sr(S_X0)}, {sr(S_TMP)}, %[qsr]")                    # rows 8 w .. of a slice
+        e.salu(f"s_mul_i32 {sr(S_X1)}, {sr(S_TMP)}, %[dosr]")
+        e.salu(f"s_mul_i32 {sr(S_QOFF)}, {sr(S_SL)}, {sr(S_QSTEP)}")
+        e.salu(f"s_add_u32 {sr(S_QOFF)}, {sr(S_QOFF)}, {sr(S_X0)}")
+        e.salu(f"s_mul_i32 {sr(S_DOOFF)}, {sr(S_SL)}, {sr(S_DOSTEP)}")
+        e.salu(f"s_add_u32 {sr(S_DOOFF)}, {sr(S_DOOFF)}, {sr(S_X1)}")
+        e.salu(f"s_lshl_b32 {sr(S_COFF)}, {sr(S_SL)}, 7")
+        e.salu(f"s_sub_u32 {sr(S_TMP)}, {sr(S_NS)}, 1")                         # last slice (absolute index)
+        e.salu(f"s_mul_i32 {sr(S_QMAX)}, {sr(S_TMP)}, {sr(S_QSTEP)}")
+        e.salu(f"s_add_u32 {sr(S_QMAX)}, {sr(S_QMAX)}, {sr(S_X0)}")
+        e.salu(f"s_mul_i32 {sr(S_DOMAX)}, {sr(S_TMP)}, {sr(S_DOSTEP)}")
+        e.salu(f"s_add_u32 {sr(S_DOMAX)}, {sr(S_DOMAX)}, {sr(S_X1)}")
+        e.salu(f"s_lshl_b32 {sr(S_CMAX)}, {sr(S_TMP)}, 7")
+        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 11")
+        e.salu(f"s_add_u32 {sr(S_M0)}, {sr(S_LDS)}, {sr(S_TMP)}")               # DMA destination of this wave's row group in buffer 0
+        e.salu(f"s_mul_i32 {sr(S_TMP)}, {sr(S_WID)}, {64 * STAGE_ROW}")
+        e.salu(f"s_add_u32 {sr(S_STAGE)}, {sr(S_LDS)}, {STAGE0}")
+        e.salu(f"s_add_u32 {sr(S_STAGE)}, {sr(S_STAGE)}, {sr(S_TMP)}")
+        e.salu(f"s_sub_u32 {sr(S_NS)}, {sr(S_NS)}, {sr(S_SL)}")                 # slices of this block from here on (>= 0 by the caller)
+        # ---- lane constants
+        lane, r, h, t0, t1, t2 = T[0], T[1], T[2], T[3], T[4], T[5]
+        e.valu(f"v_mbcnt_lo_u32_b32 {vr(lane)}, -1, 0")
+        e.valu(f"v_mbcnt_hi_u32_b32 {vr(lane)}, -1, {vr(lane)}")
+        e.valu(f"v_and_b32 {vr(r)}, 31, {vr(lane)}")
+        e.valu(f"v_lshrrev_b32 {vr(h)}, 5, {vr(lane)}")
+        e.valu(f"v_lshlrev_b32 {vr(t0)}, 2, {vr(h)}")
+        e.valu(f"v_sub_u32 {vr(RM)}, {vr(r)}, {vr(t0)}")                        # r - 4 h
+        # row-read bases of a 32-row tile: 2048 (r >> 3) + 64 (r & 7) + 16 (h ^ ((r >> 2) & 3))
+        e.valu(f"v_lshrrev_b32 {vr(t0)}, 3, {vr(r)}")
+        e.valu(f"v_lshlrev_b32 {vr(t0)}, 11, {vr(t0)}")
+        e.valu(f"v_and_b32 {vr(t1)}, 7, {vr(r)}")
+        e.valu(f"v_lshl_add_u32 {vr(t0)}, {vr(t1)}, 6, {vr(t0)}")
+        e.valu(f"v_bfe_u32 {vr(t2)}, {vr(r)}, 2, 2")
+        e.valu(f"v_xor_b32 {vr(t2)}, {vr(t2)}, {vr(h)}")
+        e.valu(f"v_lshl_add_u32 {vr(RB[0])}, {vr(t2)}, 4, {vr(t0)}")
+        e.valu(f"v_add_u32 {vr(RB[0])}, {sr(S_LDS)}, {vr(RB[0])}")
+        e.valu(f"v_xor_b32 {vr(RB[1])}, 32, {vr(RB[0])}")
+        # transposed-read bases: i = lane & 15, q = i >> 2, p = i & 3, g = lane >> 4: 64 (4 h + q) + 16 ((2 (g & 1) + (p >> 1)) ^ h) + 8 (p & 1)
+        e.valu(f"v_bfe_u32 {vr(t0)}, {vr(lane)}, 2, 2")
+        e.valu(f"v_lshl_add_u32 {vr(t0)}, {vr(h)}, 2, {vr(t0)}")
+        e.valu(f"v_lshlrev_b32 {vr(t0)}, 6, {vr(t0)}")
+        e.valu(f"v_bfe_u32 {vr(t1)}, {vr(lane)}, 4, 1")
+        e.valu(f"v_bfe_u32 {vr(t2)}, {vr(lane)}, 1, 1")
+        e.valu(f"v_lshl_add_u32 {vr(t1)}, {vr(t1)}, 1, {vr(t2)}")
+        e.valu(f"v_xor_b32 {vr(t1)}, {vr(t1)}, {vr(h)}")
+        e.valu(f"v_lshl_add_u32 {vr(t0)}, {vr(t1)}, 4, {vr(t0)}")
+        e.valu(f"v_and_b32 {vr(t2)}, 1, {vr(lane)}")
+        e.valu(f"v_lshl_add_u32 {vr(TB[0])}, {vr(t2)}, 3, {vr(t0)}")
+        e.valu(f"v_add_u32 {vr(TB[0])}, {sr(S_LDS)}, {vr(TB[0])}")
+        e.valu(f"v_xor_b32 {vr(TB[1])}, 32, {vr(TB[0])}")
+        e.valu(f"v_lshl_add_u32 {vr(LR)}, {vr(h)}, 4, {sr(S_LDS)}")            # row constants: 16 h (+ 32 g + the slice offsets as immediates)
+        # DMA source offsets: row 8 w + row7 (row7 = (lane >> 2) & 7), chunk 4 sub32 + (slot ^ x), x = ((w & 1) << 1) | ((lane >> 4) & 1)
+        e.valu(f"v_bfe_u32 {vr(t0)}, {vr(lane)}, 2, 3")
+        e.valu(f"v_and_b32 {vr(t1)}, 3, {vr(lane)}")
+        e.valu(f"v_bfe_u32 {vr(t2)}, {vr(lane)}, 4, 1")
+        e.salu(f"s_and_b32 {sr(S_TMP)}, {sr(S_WID)}, 1")
+        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_TMP)}, 1")
+        e.valu(f"v_or_b32 {vr(t2)}, {sr(S_TMP)}, {vr(t2)}")
+        e.valu(f"v_xor_b32 {vr(t1)}, {vr(t1)}, {vr(t2)}")
+        e.valu(f"v_lshlrev_b32 {vr(t1)}, 4, {vr(t1)}")
+        e.valu(f"v_lshl_add_u32 {vr(t1)}, {vr(h)}, 6, {vr(t1)}")                # + 64 sub32
+        e.valu(f"v_mul_lo_u32 {vr(DMAQ)}, {vr(t0)}, %[qsr]")
+        e.valu(f"v_add_u32 {vr(DMAQ)}, {vr(DMAQ)}, {vr(t1)}")
+        e.valu(f"v_mul_lo_u32 {vr(DMAD)}, {vr(t0)}, %[dosr]")
+        e.valu(f"v_add_u32 {vr(DMAD)}, {vr(DMAD)}, {vr(t1)}")
+        # the 64 row constants: lanes 0..31 the slice's -lse log2 e, lanes 32..63 its -delta (%[cdelta] bytes further)
+        e.valu(f"v_lshlrev_b32 {vr(DMAC)}, 2, {vr(r)}")
+        e.valu(f"v_mul_lo_u32 {vr(t0)}, {vr(h)}, %[cdelta]")
+        e.valu(f"v_add_u32 {vr(DMAC)}, {vr(DMAC)}, {vr(t0)}")
+        # dS store: lane (key r, half h) writes its 16 bytes at 32 r + 16 h of a 1-KiB operand
+        e.valu(f"v_lshlrev_b32 {vr(DSOFF)}, 5, {vr(r)}")
+        e.valu(f"v_lshl_add_u32 {vr(DSOFF)}, {vr(h)}, 4, {vr(DSOFF)}")
+        # ---- the first two slices on their way
+        e.dma_slice()
+        e.salu(f"s_xor_b32 {sr(S_M0)}, {sr(S_M0)}, {BUF}")
+        e.advance_dma()
+        e.dma_slice()
+        e.salu(f"s_xor_b32 {sr(S_M0)}, {sr(S_M0)}, {BUF}")
+        e.advance_dma()
+        # ---- this wave's K and V fragments: key kw + 32 ksb + r, k = 16 kk + 8 h ..; K pre-scaled by scale log2(e)
+        e.valu(f"v_mul_lo_u32 {vr(t0)}, {vr(r)}, %[kvsr]")
+        e.valu(f"v_lshl_add_u32 {vr(t0)}, {vr(h)}, 4, {vr(t0)}")
+        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 6")
+        e.salu(f"s_mul_i32 {sr(S_X0)}, {sr(S_TMP)}, %[kvsr]")
+        e.salu(f"s_lshl_b32 {sr(S_TMP)}, %[kvsr], 5")
+        e.salu(f"s_add_u32 {sr(S_X1)}, {sr(S_X0)}, {sr(S_TMP)}")
+        for nm, fr in (("kp", KFR), ("vp", VFR)):
+            e.salu(f"s_mov_b64 {sr(O_SRD, 2)}, %[{nm}]")
+            e.salu("s_nop 4")
+            for ksb in range(2):
+                for kk in range(8):
+                    e.out.append(Ins(f"buffer_load_dwordx4 {vr(fr(ksb, kk), 4)}, {vr(t0)}, {sr(O_SRD, 4)}, {sr(S_X0 + ksb)} offen offset:{32 * kk}", "vmem"))
+            e.out.append(Ins("s_waitcnt vmcnt(0)", "wait", tag="vm"))       # (the SRD base is rewritten for V: its loads must have taken the old one; once per block)
+        for i in range(256):
+            e.valu(f"v_accvgpr_write_b32 {ar(i)}, 0")
+        # K *= scale log2(e): unpack the pair, two multiplies, pack (64 registers, once per block)
+        e.valu(f"v_mov_b32 {vr(t2)}, 0x3fb8aa3b")
+        e.valu(f"v_mul_f32 {vr(t2)}, {sr(S_SCALE)}, {vr(t2)}")
+        for i in range(64):
+            x = KFR(0, 0) + i
+            if self.f16:
+                e.valu(f"v_cvt_f32_f16 {vr(t0)}, {vr(x)}")
+                e.valu(f"v_cvt_f32_f16_sdwa {vr(t1)}, {vr(x)} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1")
+            else:
+                e.valu(f"v_lshlrev_b32 {vr(t0)}, 16, {vr(x)}")
+                e.valu(f"v_and_b32 {vr(t1)}, 0xffff0000, {vr(x)}")
+            e.valu(f"v_mul_f32 {vr(t0)}, {vr(t0)}, {vr(t2)}")
+            e.valu(f"v_mul_f32 {vr(t1)}, {vr(t1)}, {vr(t2)}")
+            e.valu(f"{self.cvt} {vr(x)}, {vr(t0)}, {vr(t1)}")
+        # dS tile bases of slice s0
+        e.salu(f"s_sub_u32 {sr(S_SL)}, {sr(S_SL)}, 1")
+        self.in_loop = False
+        # (ds_next of the slice body, inline: advances S_SL to s0 and forms S_DS0 / S_DS1)
+        e.salu(f"s_add_u32 {sr(S_SL)}, {sr(S_SL)}, 1")
+        e.salu(f"s_lshr_b32 {sr(S_TMP)}, {sr(S_SL)}, 3")
+        e.salu(f"s_mul_i32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_DSQB)}")
+        e.salu(f"s_and_b32 {sr(S_TMP2)}, {sr(S_SL)}, 7")
+        e.salu(f"s_add_u32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_TMP2)}")
+        e.salu(f"s_lshr_b32 {sr(S_TMP2)}, {sr(S_TMP)}, {32 - 11}")
+        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_TMP)}, 11")
+        e.salu(f"s_add_u32 {sr(S_DS0)}, {sr(S_DSB)}, {sr(S_TMP)}")
+        e.salu(f"s_addc_u32 {sr(S_DS0 + 1)}, {sr(S_DSB + 1)}, {sr(S_TMP2)}")
+        e.salu(f"s_add_u32 {sr(S_DS1)}, {sr(S_DS0)}, {8 * DS_TILE}")
+        e.salu(f"s_addc_u32 {sr(S_DS1 + 1)}, {sr(S_DS0 + 1)}, 0")
+        # ---- slice s0 has landed for everyone (slice s0 + 1's 5 pieces may still be in flight); the first slice's head state
+        e.out.append(Ins("s_waitcnt vmcnt(5)", "wait", tag="vm"))
+        e.barrier()
+        # (in the ORDER every slice's tail issues them: the loop's counted waits assume it)
+        order = [("c", i) for i in range(6)] + [("c", 6), ("r", 0), ("c", 7), ("r", 1)] + [("r", j) for j in range(2, 8)]
+        for kind, i in order:
+            if kind == "c": e.lds_const(S(i >> 2), i & 3, 0)
+            else: e.lds_row(RING(i), i, 0)
+        e.salu(f"s_mov_b32 {sr(S_IT)}, 0")
+
+    def dispatch(self):
+        e = self
+        e.label("L_loop_%=")
+        e.salu(f"s_cmp_ge_u32 {sr(S_IT)}, {sr(S_NS)}")
+        e.salu("s_cbranch_scc1 L_epilogue_%=")
+        e.salu(f"s_sub_u32 {sr(S_TMP)}, {sr(S_IT)}, {sr(S_D0)}")               # slices since this wave's first diagonal one (wraps below it)
+        e.salu(f"s_cmp_lt_i32 {sr(S_TMP)}, 0")
+        e.salu("s_cbranch_scc1 L_idle_%=")
+        e.salu(f"s_cmp_eq_u32 {sr(S_TMP)}, 0")
+        e.salu("s_cbranch_scc1 L_diag0_%=")
+        e.salu(f"s_cmp_eq_u32 {sr(S_TMP)}, 1")
+        e.salu("s_cbranch_scc1 L_diag1_%=")
+        if self.mutant:
+            e.salu(f"s_cmp_eq_u32 {sr(S_IT)}, {sr(S_MUT)}")
+            e.salu("s_cbranch_scc1 L_drop_%=")
+
+    def next_iter(self):
+        self.salu(f"s_add_u32 {sr(S_IT)}, {sr(S_IT)}, 1")
+        self.salu("s_branch L_loop_%=")
+
+    def epilogue(self):
+        e = self
+        lane, r, h = T[0], T[1], T[2]
+        e.label("L_epilogue_%=")
+        e.out.append(Ins("s_waitcnt vmcnt(0) lgkmcnt(0)", "wait", tag="vmlgkm"))
+        e.salu("s_nop 15")
+        e.valu(f"v_mbcnt_lo_u32_b32 {vr(lane)}, -1, 0")
+        e.valu(f"v_mbcnt_hi_u32_b32 {vr(lane)}, -1, {vr(lane)}")
+        e.valu(f"v_and_b32 {vr(r)}, 31, {vr(lane)}")
+        e.valu(f"v_lshrrev_b32 {vr(h)}, 5, {vr(lane)}")
+        st, rd, oo = T[3], T[4], T[5]
+        e.valu(f"v_mul_u32_u24 {vr(st)}, {STAGE_ROW}, {vr(r)}")
+        e.valu(f"v_lshl_add_u32 {vr(st)}, {vr(h)}, 3, {vr(st)}")
+        e.valu(f"v_add_u32 {vr(st)}, {sr(S_STAGE)}, {vr(st)}")
+        e.valu(f"v_lshrrev_b32 {vr(rd)}, 4, {vr(lane)}")
+        e.valu(f"v_and_b32 {vr(oo)}, 15, {vr(lane)}")
+        e.valu(f"v_lshlrev_b32 {vr(oo)}, 4, {vr(oo)}")
+        e.valu(f"v_mul_lo_u32 {vr(RM)}, {vr(rd)}, {sr(S_OSR)}")
+        e.valu(f"v_mul_u32_u24 {vr(rd)}, {STAGE_ROW}, {vr(rd)}")
+        e.valu(f"v_add3_u32 {vr(rd)}, {vr(rd)}, {vr(oo)}, {sr(S_STAGE)}")
+        e.valu(f"v_add_u32 {vr(oo)}, {vr(oo)}, {vr(RM)}")
+        for which, accf, ptr in ((0, DV, "dvp"), (1, DK, "dkp")):
+            # accumulators -> 16-bit rows of this wave's slab: lane (key r, half h) writes 4 consecutive d of key 32 ksb + r
+            for ksb in range(2):
+                for db in range(4):
+                    for gq in range(4):
+                        a0 = accf(ksb, db) + 4 * gq
+                        x = [RING(0) + i for i in range(4)]
+                        for jj in range(4):
+                            e.valu(f"v_accvgpr_read_b32 {vr(x[jj])}, {ar(a0 + jj)}")
+                        if which == 1:
+                            for jj in range(4):
+                                e.valu(f"v_mul_f32 {vr(x[jj])}, {sr(S_SCALE)}, {vr(x[jj])}")   # dK = scale dS^T Q
+                        e.valu(f"{self.cvt} {vr(x[0])}, {vr(x[0])}, {vr(x[1])}")
+                        e.valu(f"{self.cvt} {vr(x[1])}, {vr(x[2])}, {vr(x[3])}")
+                        e.out.append(Ins(f"ds_write_b64 {vr(st)}, {vr(x[0], 2)} offset:{32 * ksb * STAGE_ROW + 64 * db + 16 * gq}", "ldsw"))
+            e.out.append(Ins("s_waitcnt lgkmcnt(0)", "wait", tag="lgkm"))
+            e.salu(f"s_mov_b64 {sr(O_SRD, 2)}, %[{ptr}]")
+            e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 6")
+            e.salu(f"s_mul_i32 {sr(S_X0)}, {sr(S_TMP)}, {sr(S_OSR)}")
+            e.salu(f"s_lshl_b32 {sr(S_X1)}, {sr(S_OSR)}, 2")
+            for j in range(16):
+                d = 32 + 4 * (j % 8)    # v[32..63]: the dP registers are free now
+                e.out.append(Ins(f"ds_read_b128 {vr(d, 4)}, {vr(rd)} offset:{4 * j * STAGE_ROW}", "ldsw"))
+                if j % 8 == 7:
+                    e.out.append(Ins("s_waitcnt lgkmcnt(0)", "wait", tag="lgkm"))
+                    for i in range(8):
+                        e.out.append(Ins(f"buffer_store_dwordx4 {vr(32 + 4 * i, 4)}, {vr(oo)}, {sr(O_SRD, 4)}, {sr(S_X0)} offen", "vmem"))
+                        e.salu(f"s_add_u32 {sr(S_X0)}, {sr(S_X0)}, {sr(S_X1)}")
+            e.out.append(Ins("s_waitcnt vmcnt(0)", "wait", tag="vm"))   # (the SRD base changes for the second tensor; and the slab is rewritten)
+        e.barrier()   # the next block's DMA reuses the slice buffers: every wave is past its last reads (they are, since the last slice's barrier) - kept for the vmcnt bookkeeping of the prologue
+
+    def build(self):
+        self.prologue()
+        self.dispatch()
+        # prev_stores: the stores a wave issued behind its last DMA pieces in the PREVIOUS slice, by what that slice was
+        self.slice("steady", "steady", 4 if self.ds else 0)
+        self.next_iter()
+        self.slice("diag1", "diag1", 2 if self.ds else 0)
+        self.next_iter()
+        self.slice("diag0", "diag0", 0)
+        self.next_iter()
+        self.slice("idle", "idle", 0)
+        self.next_iter()
+        if self.mutant:
+            self.slice("drop", "drop", 4 if self.ds else 0)
+            self.next_iter()
+        self.epilogue()
+        finish_waits(self.out)
+        return self
+
+
+# ------------------------------------------------------------------ counted LDS waits
+VARIANTS = r"L_(steady|diag1|diag0|idle|drop)_%=:"
+
+
+def finish_waits(ins):
+    """Inserts `s_waitcnt lgkmcnt(N)` in front of every instruction that reads (or rewrites) the destination of an LDS read still in
+    flight, N = the LDS reads issued after it. Each variant's body is walked with the reads its predecessor's tail left pending (every
+    variant ends with the same 16 reads: the next slice's -lse constants and Q rows), the prologue and the epilogue linearly."""
+    # the tail every variant leaves behind
+    tail = []
+    on = False
+    for x in ins:
+        if x.kind == "label" and re.match(VARIANTS, x.text):
+            on = x.text.startswith("L_steady")
+            tail = [] if on else tail
+        elif on and x.kind == "lds":
+            tail.append(x)
+        elif on and x.kind == "wait" and "lgkm" in x.tag:
+            tail = []
+    out, pending = [], []
+    for x in ins:
+        if x.kind == "label" and re.match(VARIANTS, x.text):
+            pending = [t.writes for t in tail]
+        if x.kind == "label" and x.text.startswith("L_epilogue"):
+            pending = [t.writes for t in tail]
+        if x.kind == "wait" and "lgkm" in x.tag:
+            pending = []
+        touched = set(x.reads) | set(x.writes)
+        need = -1
+        for i, w in enumerate(pending):
+            if touched & set(w):
+                need = i
+        if need >= 0:
+            n = len(pending) - 1 - need
+            out.append(Ins(f"s_waitcnt lgkmcnt({n})", "wait", tag="auto"))
+            pending = pending[need + 1:]
+        if x.kind == "lds":
+            if len(pending) >= 15:   # the counter saturates at 15: retire the oldest first (it is 15 reads old)
+                out.append(Ins("s_waitcnt lgkmcnt(14)", "wait", tag="auto"))
+                pending = pending[len(pending) - 14:]
+            pending.append(x.writes)
+        out.append(x)
+    ins[:] = out
+
+
+def check(ins):
+    """Distances the hardware does not interlock, per variant (walked twice): an MFMA's VGPR / AGPR result is read or overwritten by
+    anything but its own accumulate chain only >= 2 MFMAs or >= 22 wait states later; a VALU result feeds an MFMA operand only with >= 4
+    instructions in between."""
+    problems = []
+    cur, variants = None, {}
+    for i in ins:
+        if i.kind == "label" and re.match(VARIANTS, i.text):
+            cur = i.text[2:-4]
+            variants[cur] = []
+        elif i.kind == "label" and i.text.startswith("L_epilogue"):
+            cur = None
+        elif cur is not None:
+            variants[cur].append(i)
+    for name, body in variants.items():
+        seq = [x for x in body if x.kind not in ("raw", "label", "nomfma")] * 2
+        lm, lv = {}, {}
+        n_mfma = n_ins = 0
+        for x in seq:
+            n_ins += 1
+            if x.kind == "mfma":
+                n_mfma += 1
+            if x.kind == "salu" and x.text.startswith("s_nop"):
+                n_ins += int(x.text.split()[1])
+            for reg in x.reads:
+                if reg in lm:
+                    m, tag, at = lm[reg]
+                    chain = x.kind == "mfma" and reg in x.writes
+                    if not chain and n_mfma - m < 2 and n_ins - at < 22:
+                        problems.append(f"{name}: '{x.text}' reads {reg} {n_mfma - m} MFMA(s) / {n_ins - at} wait states after '{tag}'")
+                if x.kind == "mfma" and reg in lv and n_ins - lv[reg] < 4:
+                    problems.append(f"{name}: '{x.text}' reads {reg} {n_ins - lv[reg]} instruction(s) after a VALU wrote it")
+            for reg in x.writes:
+                if x.kind != "mfma" and reg in lm and n_mfma - lm[reg][0] < 2 and n_ins - lm[reg][2] < 22:
+                    problems.append(f"{name}: '{x.text}' overwrites {reg} right behind '{lm[reg][1]}'")
+                if x.kind == "mfma":
+                    lm[reg] = (n_mfma, x.tag, n_ins)
+                    lv.pop(reg, None)
+                else:
+                    lm.pop(reg, None)
+                    if x.kind != "lds":
+                        lv[reg] = n_ins
+    return problems
+
+
+def selftest():
+    """The 32-row tile image: what this wave's DMA pieces write, what the row reads deliver as the A operand of S / dP (lane (r, h):
+    A[row r][k = 16 kk + 8 h + j]) and what the transposed reads deliver as the A operand of dV / dK in the k order of a score
+    accumulator used as the B operand (element j of half h <-> query 16 s + 8 (j >> 2) + 4 h + (j & 3))."""
+    srb = 256 + 96
+    lds = {}
+    for w in range(4):
+        for hp in range(2):
+            base = 2048 * w + 1024 * hp
+            for L in range(64):
+                row7, sub32, slot, b4 = (L >> 2) & 7, L >> 5, L & 3, (L >> 4) & 1
+                x = ((w & 1) << 1) | b4
+                src = 8 * w * srb + row7 * srb + 64 * sub32 + 16 * (slot ^ x) + 128 * hp
+                row, colbyte = src // srb, src % srb
+                for byte in range(0, 16, 2):
+                    lds[base + 16 * L + byte] = (row, (colbyte + byte) // 2)
+    assert len(lds) == 32 * 128
+    for kk in range(8):
+        for lane in range(64):
+            r, h = lane & 31, lane >> 5
+            b0 = 2048 * (r >> 3) + 64 * (r & 7) + 16 * (h ^ ((r >> 2) & 3))
+            addr = (b0 ^ (32 if kk & 1 else 0)) + 512 * (kk >> 1)
+            for j in range(8):
+                assert lds[addr + 2 * j] == (r, 16 * kk + 8 * h + j), ("row", kk, lane, j)
+    for s in range(2):
+        for db in range(4):
+            for sec in range(2):
+                imm = 2048 * (2 * s + sec) + 512 * db
+                got = {}
+                for grp in range(4):
+                    blk = {}
+                    for i in range(16):
+                        lane = 16 * grp + i
+                        h, q, p, g1 = lane >> 5, i >> 2, i & 3, grp & 1
+                        t0 = 64 * (4 * h + q) + 16 * ((2 * g1 + (p >> 1)) ^ h) + 8 * (p & 1)
+                        addr = (t0 ^ (32 if sec else 0)) + imm
+                        for c in range(4):
+                            blk[(q, 4 * p + c)] = lds[addr + 2 * c]
+                    for i in range(16):
+                        got[16 * grp + i] = [blk[(qq, i)] for qq in range(4)]
+                for lane in range(64):
+                    r, h = lane & 31, lane >> 5
+                    for e in range(4):
+                        j = 4 * sec + e
+                        qrow = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)
+                        assert got[lane][e] == (qrow, 32 * db + r), ("tr", s, db, sec, lane, e, got[lane][e])
+    return True
+
+
+CLOBBERS = (["memory", "vcc", "scc"] + [f"s{i}" for i in range(36, N_SGPR_HI)] + [f"v{i}" for i in range(N_VGPR)] + [f"a{i}" for i in range(256)])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check-only", action="store_true")
+    ap.add_argument("--out", default=str(OUT))
+    ap.add_argument("--ablate", default="")
+    ap.add_argument("--dump", default="", help="print one variant's stream")
+    args = ap.parse_args()
+    abl = tuple(x for x in args.ablate.split(",") if x)
+    assert selftest()
+    g = Gen(False, ablate=abl).build()
+    probs = check(g.out)
+    for p in probs[:40]:
+        print("HAZARD:", p, file=sys.stderr)
+    if args.dump:
+        on = False
+        for i in g.out:
+            if i.kind == "label" and re.match(VARIANTS, i.text):
+                on = i.text == f"L_{args.dump}_%=:"
+            if on:
+                print(f"{i.kind:7s} {i.text}  {i.tag}")
+    if probs and not abl:
+        return 1
+    if args.check_only:
+        return 0
+    texts = {}
+    for f16 in (False, True):
+        for mut in (False, True):
+            for ds in (True, False):
+                gg = Gen(f16, mut, ds, ablate=abl).build()
+                assert abl or not check(gg.out), check(gg.out)[:5]
+                texts[(f16, mut, ds)] = render(gg.out).replace(chr(10), " " + chr(92) + chr(10))
+    n_ins = sum(1 for i in g.out if i.kind not in ("raw", "label", "nomfma"))
+    def four(mut):
+        return "\n".join(f"#define KF_DKV_W4_ASM_{'F16' if f16 else 'BF16'}_{'DS' if ds else 'NODS'} \\\n{texts[(f16, mut, ds)]}"
+                         for f16 in (False, True) for ds in (True, False))
+    text = f"""// GENERATED by tools/gen_attn_dkv.py - do not edit; edit the generator and run it again.
+// The 16-bit causal-attention dK / dV pass of one 256-key block as ONE instruction stream ({n_ins} instructions): 4 waves x 64 keys,
+// one wave per SIMD, all 512 registers asm-owned; see the generator's header for the structure.
+#pragma once
+#define KF_DKV_W4_LDS_BYTES {LDS_BYTES}
+#define KF_DKV_W4_CLOBBERS {", ".join('"' + c + '"' for c in CLOBBERS)}
+#ifdef KF_MUTANT
+{four(True)}
+#else
+{four(False)}
+#endif
+"""
+    Path(args.out).write_text(text)
+    print(f"wrote {args.out} ({n_ins} instructions)")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
