@@ -30,3 +30,23 @@ def test_committed_inc_is_the_generators_output(tmp_path):
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "gen_attn_fwd.py"), "--out", str(out)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert out.read_text() == (ROOT / "kfunca_amd" / "csrc" / "device" / "attn_fwd_w4.inc").read_text(), "run tools/gen_attn_fwd.py"
+
+
+def test_dkv_generator_address_maps_hazards_and_freshness(tmp_path):
+    """The same three guarantees for the generated dK / dV pass (tools/gen_attn_dkv.py -> attn_dkv_w4.inc): tile-image model, hazard
+    distances in every variant of the slice body (both dtypes, mutation build, with and without the dS stores), committed stream ==
+    generator output."""
+    import gen_attn_dkv as G
+    assert G.selftest()
+    for f16 in (False, True):
+        for mut in (False, True):
+            for ds in (True, False):
+                g = G.Gen(f16, mut, ds).build()
+                assert G.check(g.out) == []
+                assert sum(1 for i in g.out if i.kind == "mfma") == 64 + 64 + 32 + (64 if mut else 0)   # steady, diag1, diag0 (one sub-block), drop
+                stores = sum(1 for i in g.out if "global_store_dwordx4" in i.text)
+                assert stores == ((4 + 4 + 2 + (4 if mut else 0)) if ds else 0)
+    out = tmp_path / "dkv.inc"
+    r = subprocess.run([sys.executable, str(ROOT / "tools" / "gen_attn_dkv.py"), "--out", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert out.read_text() == (ROOT / "kfunca_amd" / "csrc" / "device" / "attn_dkv_w4.inc").read_text(), "run tools/gen_attn_dkv.py"

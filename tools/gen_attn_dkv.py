@@ -64,8 +64,16 @@ S_SL, S_STAGE = 70, 71
 S_DSQB, S_WID, S_LDS, S_SCALE, S_MUT, S_OSR = "%[dsqb]", "%[wid]", "%[lds]", "%[scale]", "%[mut]", "%[osr]"   # read-only inputs: used in place
 S_X0, S_X1 = 72, 73
 S_DSB = 74              # pair: dS base of this wave's first key sub-block at slice 0 of the workspace
-N_SGPR_HI = 76
+V_SRD = 76             # 4-aligned quad: the V fragments' descriptor (prologue only)
+N_SGPR_HI = 80
 N_VGPR = 250            # v250 .. v255 stay the compiler's (it needs somewhere to keep scalars it cannot hold in SGPRs)
+
+# S and dP slots: sub-block 1's FIRST k-step goes first (its C operand is sub-block 0's registers, which still hold the row constants),
+# then sub-block 0's chain, then the rest of sub-block 1's: the 16 constants of a slice are read once, not once per sub-block.
+CHAIN_ORDER = [(1, 0)] + [(0, i) for i in range(8)] + [(1, i) for i in range(1, 8)]
+# ring slot j's last use in those slots: slot 0 at gap 1, slot j >= 1 at gap 8 + j; in the dV / dK slots (ksb-major) slot j at gap 8 + j
+RING_FREE_S = [1] + [8 + j for j in range(1, 8)]
+NEXTQ_G = [56 + j for j in range(8)]
 
 BUF = 32768             # two slice buffers, toggled by XOR
 SLICE_DO = 8192         # dO tile behind the Q tile
@@ -77,6 +85,10 @@ DS_TILE = 2048
 
 
 class Gen:
+    # non-temporal: measured same-box against write-through (sc0 sc1), sc1 and plain stores (tools/scratch/ab_dkv.sh): this kernel's time is the same
+    # under all four (1.99 - 2.04 ms on that box), the dQ kernel that streams the dS back runs 3 - 4 % faster behind nt stores (0.95 - 0.97 vs 1.00 ms)
+    store_policy = "nt"
+
     def __init__(self, f16=False, mutant=False, ds=True, ablate=()):
         self.mfma = "v_mfma_f32_32x32x16_f16" if f16 else "v_mfma_f32_32x32x16_bf16"
         self.cvt = "v_cvt_pk_f16_f32" if f16 else "v_cvt_pk_bf16_f32"
@@ -89,11 +101,14 @@ class Gen:
     def salu(self, t): self.out.append(Ins(t, "salu"))
     def valu(self, t, reads=(), writes=(), trans=False): self.out.append(Ins(t, "trans" if trans else "valu", reads, writes))
 
-    def mm(self, d, dn, a, b, c_is_d=True, tag="", acc="v"):
-        """D = A B + D on registers: d first of 16 (VGPR or AGPR by `acc`), a / b first of 4 VGPRs."""
+    def mm(self, d, dn, a, b, c=None, tag="", acc="v"):
+        """D = A B + C on registers: d first of 16 (VGPR or AGPR by `acc`), a / b first of 4 VGPRs, C = D unless `c` names another tuple."""
         dst = vr(d, 16) if acc == "v" else ar(d, 16)
         W = V(d, 16) if acc == "v" else A(d, 16)
-        self.out.append(Ins(f"{self.mfma} {dst}, {vr(a, 4)}, {vr(b, 4)}, {dst}", "mfma", V(a, 4) + V(b, 4) + W, W, tag=tag))
+        if c is None:
+            self.out.append(Ins(f"{self.mfma} {dst}, {vr(a, 4)}, {vr(b, 4)}, {dst}", "mfma", V(a, 4) + V(b, 4) + W, W, tag=tag))
+        else:
+            self.out.append(Ins(f"{self.mfma} {dst}, {vr(a, 4)}, {vr(b, 4)}, {vr(c, 16)}", "mfma", V(a, 4) + V(b, 4) + V(c, 16), W, tag=tag))
 
     def lds_row(self, dst, kk, tile_off):      # A fragment of k-step kk of a 32-row tile: row = lane & 31, chunk 2 kk + (lane >> 5)
         if "lds" in self.ablate: return
@@ -153,24 +168,25 @@ class Gen:
         # ---- the ring: fragment j of the next set goes into slot j behind the slot's second use (gap 8 + j of the MFMA slot in front)
         if compute:
             for j in range(8):
-                put(8 + j, (2, j), lambda j=j: self.lds_row(RING(j), j, SLICE_DO))                         # dO rows, for slot 2
+                put(max(RING_FREE_S[j], 6 + j), (2, j), lambda j=j: self.lds_row(RING(j), j, SLICE_DO))    # dO rows, for slot 2
                 for sec in (0, 1):
-                    put(24 + j, (2, 2 * j + sec), lambda j=j, sec=sec: self.lds_tr(RING(j), j >> 2, j & 3, sec, SLICE_DO))  # dO^T, slot 3
+                    put(16 + max(RING_FREE_S[j], 6 + j), (2, 2 * j + sec), lambda j=j, sec=sec: self.lds_tr(RING(j), j >> 2, j & 3, sec, SLICE_DO))  # dO^T, slot 3
                     put(40 + j, (2, 2 * j + sec), lambda j=j, sec=sec: self.lds_tr(RING(j), j >> 2, j & 3, sec, 0))         # Q^T, slot 4
-            # -delta of this slice's queries into the dP accumulators (both sub-blocks): behind the previous slice's dK MFMAs, ahead of slot 2
-            for i, (ksb, g) in enumerate([(k, g) for k in ksbs for g in range(4)]):
-                put(1 + i, (1, i), lambda ksb=ksb, g=g: self.lds_const(DP(ksb), g, 128))
+            # -delta of this slice's queries into sub-block 0's dP accumulator (sub-block 1's chain takes it as its C operand before
+            # sub-block 0's chain overwrites it: SECOND_FIRST below): behind the previous slice's dK MFMAs, ahead of slot 2
+            for g in range(4):
+                put(2 + g, (1, g), lambda g=g: self.lds_const(DP(0), g, 128))
         # ---- what the NEXT slice's head expects, read from the other buffer behind the barrier (every variant, idle ones too):
         #      -lse log2 e into the S accumulators, its Q rows into the ring
-        for i, (ksb, g) in enumerate([(k, g) for k in (0, 1) for g in range(4)]):
-            put(50 + i, (1, i), lambda ksb=ksb, g=g: self.lds_const(S(ksb), g, 0))
+        for g in range(4):
+            put(52 + g, (1, g), lambda g=g: self.lds_const(S(0), g, 0))
         for j in range(8):
-            put(56 + j, (2, j), lambda j=j: self.lds_row(RING(j), j, 0))
+            put(NEXTQ_G[j], (2, j), lambda j=j: self.lds_row(RING(j), j, 0))
 
         # ---- arithmetic
         if compute and not nvalu:
             for ksb in ksbs:
-                e0, m0 = (9, 26) if ksb == 0 else (24, 34)
+                e0, m0 = (10, 27) if ksb == 0 else (25, 34)
                 diag = (kind == "diag0" and ksb == 0) or (kind == "diag1" and ksb == 1)
                 for n in range(16):
                     x, d = S(ksb, n), DP(ksb, n)
@@ -210,7 +226,7 @@ class Gen:
                 nst += 1
                 base = S_DS0 if ksb == 0 else S_DS1
                 put(g, (5, 0), lambda ksb=ksb, s=s, base=base: self.out.append(
-                    Ins(f"global_store_dwordx4 {vr(DSOFF)}, {vr(DSP(ksb, s), 4)}, {sr(base, 2)} offset:{1024 * s} sc0 sc1", "vmem", V(DSOFF) + V(DSP(ksb, s), 4))))
+                    Ins(f"global_store_dwordx4 {vr(DSOFF)}, {vr(DSP(ksb, s), 4)}, {sr(base, 2)} offset:{1024 * s} {self.store_policy}", "vmem", V(DSOFF) + V(DSP(ksb, s), 4))))
         def ds_next():   # the dS tile addresses of the next slice: sl + 1; a new 256-query block every 8 slices
             self.salu(f"s_add_u32 {sr(S_SL)}, {sr(S_SL)}, 1")
             self.salu(f"s_lshr_b32 {sr(S_TMP)}, {sr(S_SL)}, 3")
@@ -234,14 +250,19 @@ class Gen:
                 self.out.append(Ins(f"s_waitcnt vmcnt({prev_stores}) lgkmcnt(0)", "wait", tag="vmlgkm"))
                 self.barrier()
             ksb, i = j >> 3, j & 7
+            if slot < 2:
+                ksb, i = CHAIN_ORDER[j]
             if compute and ksb in ksbs:
-                if slot == 0: self.mm(S(ksb), 16, RING(i), KFR(ksb, i), tag=f"S ksb{ksb} kk{i}")
-                elif slot == 1: self.mm(DP(ksb), 16, RING(i), VFR(ksb, i), tag=f"dP ksb{ksb} kk{i}")
+                c_from = None
+                if slot < 2 and ksb == 1 and i == 0:
+                    c_from = S(0) if slot == 0 else DP(0)      # the row constants, still untouched in sub-block 0's registers
+                if slot == 0: self.mm(S(ksb), 16, RING(i), KFR(ksb, i), tag=f"S ksb{ksb} kk{i}", c=c_from)
+                elif slot == 1: self.mm(DP(ksb), 16, RING(i), VFR(ksb, i), tag=f"dP ksb{ksb} kk{i}", c=c_from)
                 elif slot == 2: self.mm(DV(ksb, i & 3), 16, RING(i), P(ksb, i >> 2), tag=f"dV ksb{ksb} s{i >> 2} db{i & 3}", acc="a")
                 else: self.mm(DK(ksb, i & 3), 16, RING(i), DSP(ksb, i >> 2), tag=f"dK ksb{ksb} s{i >> 2} db{i & 3}", acc="a")
             else:
                 self.out.append(Ins("", "nomfma"))
-                if compute and j == 8 and slot < 2:
+                if compute and j == 9 and slot < 2:
                     self.salu("s_nop 15")   # diag0: the chain that has just ended gets its time before its first reader
                     self.salu("s_nop 7")
             for _, fn in sorted(G[g], key=lambda t: t[0]):
@@ -296,6 +317,22 @@ class Gen:
         e.valu(f"v_mbcnt_hi_u32_b32 {vr(lane)}, -1, {vr(lane)}")
         e.valu(f"v_and_b32 {vr(r)}, 31, {vr(lane)}")
         e.valu(f"v_lshrrev_b32 {vr(h)}, 5, {vr(lane)}")
+        # ---- first of all this wave's K and V fragments (their latency runs under everything else of the prologue): key kw + 32 ksb + r,
+        #      k = 16 kk + 8 h ..; K through O_SRD, V through a descriptor of its own
+        e.valu(f"v_mul_lo_u32 {vr(t0)}, {vr(r)}, %[kvsr]")
+        e.valu(f"v_lshl_add_u32 {vr(t0)}, {vr(h)}, 4, {vr(t0)}")
+        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 6")
+        e.salu(f"s_mul_i32 {sr(S_X0)}, {sr(S_TMP)}, %[kvsr]")
+        e.salu(f"s_lshl_b32 {sr(S_TMP)}, %[kvsr], 5")
+        e.salu(f"s_add_u32 {sr(S_X1)}, {sr(S_X0)}, {sr(S_TMP)}")
+        e.salu(f"s_mov_b64 {sr(O_SRD, 2)}, %[kp]")
+        e.salu(f"s_mov_b64 {sr(V_SRD, 2)}, %[vp]")
+        e.salu(f"s_mov_b32 {sr(V_SRD + 2)}, 0xffffffff")
+        e.salu(f"s_mov_b32 {sr(V_SRD + 3)}, 0x00020000")
+        for srd, fr in ((O_SRD, KFR), (V_SRD, VFR)):
+            for ksb in range(2):
+                for kk in range(8):
+                    e.out.append(Ins(f"buffer_load_dwordx4 {vr(fr(ksb, kk), 4)}, {vr(t0)}, {sr(srd, 4)}, {sr(S_X0 + ksb)} offen offset:{32 * kk}", "vmem"))
         e.valu(f"v_lshlrev_b32 {vr(t0)}, 2, {vr(h)}")
         e.valu(f"v_sub_u32 {vr(RM)}, {vr(r)}, {vr(t0)}")                        # r - 4 h
         # row-read bases of a 32-row tile: 2048 (r >> 3) + 64 (r & 7) + 16 (h ^ ((r >> 2) & 3))
@@ -350,23 +387,11 @@ class Gen:
         e.dma_slice()
         e.salu(f"s_xor_b32 {sr(S_M0)}, {sr(S_M0)}, {BUF}")
         e.advance_dma()
-        # ---- this wave's K and V fragments: key kw + 32 ksb + r, k = 16 kk + 8 h ..; K pre-scaled by scale log2(e)
-        e.valu(f"v_mul_lo_u32 {vr(t0)}, {vr(r)}, %[kvsr]")
-        e.valu(f"v_lshl_add_u32 {vr(t0)}, {vr(h)}, 4, {vr(t0)}")
-        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 6")
-        e.salu(f"s_mul_i32 {sr(S_X0)}, {sr(S_TMP)}, %[kvsr]")
-        e.salu(f"s_lshl_b32 {sr(S_TMP)}, %[kvsr], 5")
-        e.salu(f"s_add_u32 {sr(S_X1)}, {sr(S_X0)}, {sr(S_TMP)}")
-        for nm, fr in (("kp", KFR), ("vp", VFR)):
-            e.salu(f"s_mov_b64 {sr(O_SRD, 2)}, %[{nm}]")
-            e.salu("s_nop 4")
-            for ksb in range(2):
-                for kk in range(8):
-                    e.out.append(Ins(f"buffer_load_dwordx4 {vr(fr(ksb, kk), 4)}, {vr(t0)}, {sr(O_SRD, 4)}, {sr(S_X0 + ksb)} offen offset:{32 * kk}", "vmem"))
-            e.out.append(Ins("s_waitcnt vmcnt(0)", "wait", tag="vm"))       # (the SRD base is rewritten for V: its loads must have taken the old one; once per block)
         for i in range(256):
             e.valu(f"v_accvgpr_write_b32 {ar(i)}, 0")
-        # K *= scale log2(e): unpack the pair, two multiplies, pack (64 registers, once per block)
+        # K *= scale log2(e): unpack the pair, two multiplies, pack (64 registers, once per block). In-order counter: the 32 K / V loads are
+        # older than the 10 DMA pieces behind them.
+        e.out.append(Ins("s_waitcnt vmcnt(10)", "wait", tag="vm"))
         e.valu(f"v_mov_b32 {vr(t2)}, 0x3fb8aa3b")
         e.valu(f"v_mul_f32 {vr(t2)}, {sr(S_SCALE)}, {vr(t2)}")
         for i in range(64):
@@ -399,10 +424,10 @@ class Gen:
         e.out.append(Ins("s_waitcnt vmcnt(5)", "wait", tag="vm"))
         e.barrier()
         # (in the ORDER every slice's tail issues them: the loop's counted waits assume it)
-        order = [("c", i) for i in range(6)] + [("c", 6), ("r", 0), ("c", 7), ("r", 1)] + [("r", j) for j in range(2, 8)]
-        for kind, i in order:
-            if kind == "c": e.lds_const(S(i >> 2), i & 3, 0)
-            else: e.lds_row(RING(i), i, 0)
+        for g in range(4):
+            e.lds_const(S(0), g, 0)
+        for j in range(8):
+            e.lds_row(RING(j), j, 0)
         e.salu(f"s_mov_b32 {sr(S_IT)}, 0")
 
     def dispatch(self):
@@ -645,8 +670,10 @@ def main():
     ap.add_argument("--out", default=str(OUT))
     ap.add_argument("--ablate", default="")
     ap.add_argument("--dump", default="", help="print one variant's stream")
+    ap.add_argument("--store-policy", default=Gen.store_policy, help="cache bits of the dS stores (experiment)")
     args = ap.parse_args()
     abl = tuple(x for x in args.ablate.split(",") if x)
+    Gen.store_policy = args.store_policy
     assert selftest()
     g = Gen(False, ablate=abl).build()
     probs = check(g.out)
