@@ -145,7 +145,8 @@ class Workload:
         self.W_host = bf16_random(wrng, (n, n))
         self.W = H.DevBuf.from_numpy(self.W_host)
         self.dC = H.DevBuf.from_numpy(bf16_random(rng, (n, n)))
-        self.Cc, self.dA, self.dW = H.DevBuf(2 * n * n), H.DevBuf(2 * n * n), H.DevBuf(2 * n * n)
+        self.grad_f32 = bool(os.environ.get("KF_BENCH_GRAD_F32"))  # dW leaves the GEMM as float and is all-reduced as float
+        self.Cc, self.dA, self.dW = H.DevBuf(2 * n * n), H.DevBuf(2 * n * n), H.DevBuf((4 if self.grad_f32 else 2) * n * n)
         nbytes = AB * AH * AS * AD * 2
         self.q, self.k, self.v, self.o, self.do = (H.DevBuf(nbytes) for _ in range(5))
         self.dq, self.dk, self.dv = (H.DevBuf(nbytes) for _ in range(3))
@@ -171,14 +172,14 @@ class Workload:
         H.gemm(H.BF16, 0, 0, n, n, n, 1.0, self.A.ptr, n, self.W.ptr, n, 0.0, self.Cc.ptr, n, 0, None, None, 0, s)
         # the backward pair dA = dC W^T, dW = A^T dC: one grid (the second product starts under the first one's last tiles)
         H.gemm_grouped(H.BF16, [(0, 1, n, n, n, 1.0, 0.0, self.dC.ptr, n, self.W.ptr, n, self.dA.ptr, n),
-                                (1, 0, n, n, n, 1.0, 0.0, self.A.ptr, n, self.dC.ptr, n, self.dW.ptr, n)], s)
+                                (1, 0, n, n, n, 1.0, 0.0, self.A.ptr, n, self.dC.ptr, n, self.dW.ptr, n, int(self.grad_f32))], s)
         if pg is not None:  # gradient all-reduce on its own stream, overlapped with the attention pass
             ev_grad.record(s)
             H.stream_wait_event(comm_stream, ev_grad)
             if comm_events is not None:
                 e0, e1 = H.Event(), H.Event()
                 e0.record(comm_stream)
-            pg.allreduce_sum_device(self.dW.ptr, n * n, H.BF16, comm_stream)
+            pg.allreduce_sum_device(self.dW.ptr, n * n, H.F32 if self.grad_f32 else H.BF16, comm_stream)
             if comm_events is not None:
                 e1.record(comm_stream)
                 comm_events.append((e0, e1))
@@ -215,7 +216,13 @@ def spot_check(H, wl, check_dw=True):
     # (bar: the reference's own GEMM test, test/test_gemm.py:9-17, is a forward-only f64 case; the backward is this repository's)
     da_ok = rows_ok(wl.dA, O.gemm(dC_host[rows], wl.W_host, trans_b=True, code=O.BF16), np.abs(f64(dC_host[rows])) @ np.abs(f64(wl.W_host)).T)
     a_cols = np.ascontiguousarray(wl.A_host[:, rows])
-    dw_ok = rows_ok(wl.dW, O.gemm(a_cols, dC_host, trans_a=True, code=O.BF16), np.abs(f64(a_cols)).T @ np.abs(f64(dC_host))) if check_dw else None
+    dw_ok = rows_ok(wl.dW, O.gemm(a_cols, dC_host, trans_a=True, code=O.BF16), np.abs(f64(a_cols)).T @ np.abs(f64(dC_host))) if (check_dw and not wl.grad_f32) else None
+    if check_dw and wl.grad_f32:  # the float dW: against the f64 product, f32 accumulation noise only
+        got = np.empty((len(rows), n), dtype=np.float32)
+        for i, r in enumerate(rows):
+            H.check(H.lib().kf_memcpy_d2h(got[i].ctypes.data, wl.dW.ptr + r * n * 4, n * 4, None))
+        want, mag = f64(a_cols).T @ f64(dC_host), np.abs(f64(a_cols)).T @ np.abs(f64(dC_host))
+        dw_ok = bool((np.abs(got - want) <= 2e-6 * mag + 1e-6).all())
     # attention: EVERY element of head (0, 0) - O, LSE, dQ, dK, dV at S = 4096 - against the double-precision oracle under the
     # scale-aware bounds of oracle/checks.py (per element, per row, per head; no absolute tolerance), and the same head of the last
     # batch element (the batch is one element replicated) bit-identical to it
@@ -253,6 +260,20 @@ def check_allreduce(H, wl, pg, stream):
     each of its N - 1 additions rounds once: |err| <= N 2^-8 sum_r |dW_r| elementwise (N = 1: the all-reduce is the identity
     and the two must be bit-identical)."""
     n = GEMM_N
+    if wl.grad_f32:
+        # the float gradient path: each rank's dW is its f32 accumulators, RCCL adds floats. Against the sum of the ranks' own float dW
+        # taken in f64 on the host: f32 addition noise only - 2^-22 sum_r |dW_r| per addition level, NOTHING that scales like the 16-bit
+        # format's 2^-8 (the bound of the 16-bit path below grows with the number of ranks; this one does not in any way that matters)
+        reduced = wl.dW.to_numpy((n, n), np.float32)
+        local = H.DevBuf(4 * n * n)
+        H.gemm_ex(H.BF16, 1, 0, n, n, n, 1.0, wl.A.ptr, n, wl.dC.ptr, n, 0.0, local.ptr, n, stream=stream, c_f32=True)
+        H.device_sync()
+        mine = local.to_numpy((n, n), np.float32).astype(np.float64)
+        total = pg.allreduce_sum_host(mine.copy().reshape(-1)).reshape(n, n)
+        mag = pg.allreduce_sum_host(np.abs(mine).reshape(-1).copy()).reshape(n, n)
+        if pg.world == 1:
+            return bool(np.array_equal(reduced, local.to_numpy((n, n), np.float32)))
+        return bool((np.abs(reduced - total) <= 2.0 ** -20 * mag + 1e-6).all())
     reduced = wl.dW.to_numpy((n, n), np.uint16)
     local = H.DevBuf(2 * n * n)
     H.gemm(H.BF16, 1, 0, n, n, n, 1.0, wl.A.ptr, n, wl.dC.ptr, n, 0.0, local.ptr, n, 0, None, None, 0, stream)
@@ -507,9 +528,9 @@ def main():
             out["sustained_steps"] = sustained[0]
         if comm_events:
             ms = [e0.elapsed_ms(e1) for e0, e1 in comm_events]
-            nbytes = GEMM_N * GEMM_N * 2
+            nbytes = GEMM_N * GEMM_N * (4 if wl.grad_f32 else 2)
             t = sum(ms) / len(ms) * 1e-3
-            out["allreduce"] = {"ms": t * 1e3, "ms_p50": float(np.percentile(ms, 50)), "ms_max": float(max(ms)), "message_bytes": nbytes, "dtype": "bf16",
+            out["allreduce"] = {"ms": t * 1e3, "ms_p50": float(np.percentile(ms, 50)), "ms_max": float(max(ms)), "message_bytes": nbytes, "dtype": "f32" if wl.grad_f32 else "bf16",
                                 "busbw_GBps": 2.0 * (world - 1) / world * nbytes / t / 1e9 if world > 1 else 0.0,
                                 "xgmi_peak_GBps": XGMI_PEAK, "overlapped_with": "attention forward + backward"}
         if elapsed_off is not None:  # where the step time of an N-GPU job goes: compute alone, compute + collective, the collective alone

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KF_ABI_VERSION 6 /* 6: + KF_ERR_OOM from kf_malloc; 2: + kf_reduce_moments*, KF_EW_*_SCALAR, kf_graph_*, kf_attn_*_scaled; 3: + kf_sort*; 4: + kf_knobs_reload, kf_norm_*, kf_index_get, kf_gemm_ex, KF_EPI_*; 5: + kf_gemm_grouped_single_grid, kf_allreduce_sum_multi, kf_profile_samples, kf_attn_bwd accepts any workspace >= the statistics (all additive) */
+#define KF_ABI_VERSION 6 /* 6: + KF_ERR_OOM from kf_malloc, kf_gemm_epilogue.c_f32 / kf_gemm_problem.c_f32 (float output behind 16-bit operands); 2: + kf_reduce_moments*, KF_EW_*_SCALAR, kf_graph_*, kf_attn_*_scaled; 3: + kf_sort*; 4: + kf_knobs_reload, kf_norm_*, kf_index_get, kf_gemm_ex, KF_EPI_*; 5: + kf_gemm_grouped_single_grid, kf_allreduce_sum_multi, kf_profile_samples, kf_attn_bwd accepts any workspace >= the statistics (all additive) */
 
 /* ---- status ------------------------------------------------------------------------------ */
 enum {
@@ -299,6 +299,9 @@ typedef struct kf_gemm_epilogue {
     int64_t ldadd;
     void *aux;        /* [M,N] or NULL */
     int64_t ldaux;
+    int32_t c_f32;    /* ABI 6, 16-bit dtypes only: C (and beta C) is FLOAT [M, ldc floats per row]; the f32 accumulators leave unrounded -
+                         a weight gradient summed over ranks or micro-batches (beta = 1) loses nothing to the 16-bit format. bias / mul / add /
+                         aux stay 16-bit. 0: C has the operands' dtype. */
 } kf_gemm_epilogue;
 int kf_gemm_ex(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const void *A, int64_t lda,
                const void *B, int64_t ldb, float beta, void *C, int64_t ldc, const kf_gemm_epilogue *epi, void *stream);
@@ -320,6 +323,7 @@ typedef struct kf_gemm_problem {
     int64_t ldb;
     void *C;
     int64_t ldc;
+    int32_t c_f32;    /* ABI 6: this product's C is float (see kf_gemm_epilogue.c_f32) */
 } kf_gemm_problem;
 int kf_gemm_grouped(int dtype, int count, const kf_gemm_problem *problems, void *stream);
 /* 1 when kf_gemm_grouped would run these problems as ONE grid (the backward pair of a 16-bit linear layer on 256-tile shapes with

@@ -280,8 +280,10 @@ PYBIND11_MODULE(_C, m) {
         return x;
     });
     py::class_<gpu::GradBucket, std::shared_ptr<gpu::GradBucket>>(m, "GradBucket", py::module_local())
-        .def(py::init([](const std::vector<Tensor> &params, double cap_mb) { return gpu::GradBucket::create(params, (int64_t)(cap_mb * 1048576.0)); }),
-             py::arg("params"), py::arg("cap_mb") = 256.0)
+        .def(py::init([](const std::vector<Tensor> &params, double cap_mb, bool accum_f32) {
+                 return gpu::GradBucket::create(params, (int64_t)(cap_mb * 1048576.0), accum_f32);
+             }),
+             py::arg("params"), py::arg("cap_mb") = 256.0, py::arg("accum_f32") = false)
         .def("attach", &gpu::GradBucket::attach)
         .def("detach", &gpu::GradBucket::detach)
         .def("wait", &gpu::GradBucket::wait)

@@ -108,7 +108,7 @@ std::vector<GradBucket::Chunk> GradBucket::plan(const std::vector<int64_t> &nume
     return chunks;
 }
 
-std::shared_ptr<GradBucket> GradBucket::create(const std::vector<Tensor> &params, int64_t cap_bytes) {
+std::shared_ptr<GradBucket> GradBucket::create(const std::vector<Tensor> &params, int64_t cap_bytes, bool accum_f32) {
     CHECK_FAIL(!params.empty(), "GradBucket: no parameters");
     std::shared_ptr<GradBucket> b(new GradBucket());
     b->params_ = params;
@@ -123,9 +123,10 @@ std::shared_ptr<GradBucket> GradBucket::create(const std::vector<Tensor> &params
     }
     int64_t total = 0;
     b->offsets_ = slot_offsets(numels, &total);
-    const int64_t es = params[0].element_size_in_bytes();
+    const ScalarType flat_dtype = accum_f32 ? ScalarType::Float : params[0].dtype();
+    const int64_t es = (int64_t)element_size(flat_dtype);
     b->chunks_ = plan(numels, std::max<int64_t>(1, cap_bytes / es));
-    b->flat_ = zeros({total}, params[0].dtype(), b->device_);
+    b->flat_ = zeros({total}, flat_dtype, b->device_);
     b->chunk_of_.resize(params.size());
     for (size_t c = 0; c < b->chunks_.size(); ++c)
         for (int i = b->chunks_[c].first; i <= b->chunks_[c].last; ++i) b->chunk_of_[i] = (int)c;

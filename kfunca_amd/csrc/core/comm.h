@@ -41,7 +41,11 @@ public:
     static std::vector<int64_t> slot_offsets(const std::vector<int64_t> &numels, int64_t *total);
     static std::vector<Chunk> plan(const std::vector<int64_t> &numels, int64_t cap_elements);
 
-    static std::shared_ptr<GradBucket> create(const std::vector<Tensor> &params, int64_t cap_bytes);
+    // accum_f32: the flat buffer (and every parameter's .grad view of it) is FLOAT whatever the parameters' dtype: the dW GEMMs of 16-bit
+    // layers write their f32 accumulators into the slots unrounded (kf_gemm_epilogue.c_f32), RCCL sums floats, and the error of the
+    // reduced gradient no longer grows with the number of ranks (a 16-bit bucket rounds once per addition: N 2^-8 sum |dW_r| at worst).
+    // Twice the bytes on the wire; cap_bytes still bounds a chunk's message.
+    static std::shared_ptr<GradBucket> create(const std::vector<Tensor> &params, int64_t cap_bytes, bool accum_f32 = false);
     ~GradBucket() override;
     void attach();   // the parameters' gradients now live in (and are written straight into) the flat buffer
     void detach();

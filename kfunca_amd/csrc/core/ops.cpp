@@ -388,7 +388,13 @@ bool gemm_dtype_ok(ScalarType t) {
 
 // C[M,N] = alpha op(A) op(B) + beta C on raw 2-D geometry
 void launch_gemm(ScalarType dt, bool ta, bool tb, int64_t M, int64_t N, int64_t K, float alpha, const void *A, int64_t lda,
-                 const void *B, int64_t ldb, float beta, void *C, int64_t ldc, int device) {
+                 const void *B, int64_t ldb, float beta, void *C, int64_t ldc, int device, bool c_f32 = false) {
+    if (c_f32) { // 16-bit operands, float C (a gradient slot of an f32 bucket): the epilogue flag of the C ABI, no split-K scratch
+        kf_gemm_epilogue e{};
+        e.c_f32 = 1;
+        DEV_CALL(kf_gemm_ex(code(dt), ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, C, ldc, &e, dev::stream(device)));
+        return;
+    }
     size_t need = 0;
     DEV_CALL(kf_gemm_workspace_bytes(code(dt), ta, tb, M, N, K, &need));
     DataPtr scratch;
@@ -414,16 +420,19 @@ void gemm_any(ScalarType dt, bool ta, bool tb, int64_t M, int64_t N, int64_t K, 
     if (dt == ScalarType::Half || dt == ScalarType::BFloat16) { am = 128; ak = 64; }
     else if (dt == ScalarType::Float || dt == ScalarType::Double) { am = 64; ak = 16; }
     const bool aligned = am && M % am == 0 && N % am == 0 && K % ak == 0;
+    // a float C behind 16-bit operands (the slot of an f32 gradient bucket): written by the kernel itself, unrounded
+    const bool c_f32 = C2.dtype() == ScalarType::Float && (dt == ScalarType::Half || dt == ScalarType::BFloat16);
+    CHECK_FAIL(c_f32 || C2.dtype() == dt, "gemm: the output's dtype must be the operands' (or float behind 16-bit operands)");
     if (!am || aligned || M * N * K < ((int64_t)1 << 22)) {
-        launch_gemm(dt, ta, tb, M, N, K, alpha, A2.data_ptr(), A2.shape(1), B2.data_ptr(), B2.shape(1), beta, C2.data_ptr(), N, device);
+        launch_gemm(dt, ta, tb, M, N, K, alpha, A2.data_ptr(), A2.shape(1), B2.data_ptr(), B2.shape(1), beta, C2.data_ptr(), N, device, c_f32);
         return;
     }
     auto up = [](int64_t v, int64_t a) { return (v + a - 1) / a * a; };
     const int64_t Mp = up(M, am), Np = up(N, am), Kp = up(K, ak);
     Tensor Ap = pad2d(A2, ta ? Kp : Mp, ta ? Mp : Kp), Bp = pad2d(B2, tb ? Np : Kp, tb ? Kp : Np);
     const bool same_c = Mp == M && Np == N;
-    Tensor Cp = same_c ? C2 : (beta != 0.f ? pad2d(C2, Mp, Np) : empty({Mp, Np}, dt, device));
-    launch_gemm(dt, ta, tb, Mp, Np, Kp, alpha, Ap.data_ptr(), Ap.shape(1), Bp.data_ptr(), Bp.shape(1), beta, Cp.data_ptr(), Np, device);
+    Tensor Cp = same_c ? C2 : (beta != 0.f ? pad2d(C2, Mp, Np) : empty({Mp, Np}, C2.dtype(), device));
+    launch_gemm(dt, ta, tb, Mp, Np, Kp, alpha, Ap.data_ptr(), Ap.shape(1), Bp.data_ptr(), Bp.shape(1), beta, Cp.data_ptr(), Np, device, c_f32);
     if (!same_c) {
         Tensor head = Cp.narrow(0, 0, M).narrow(1, 0, N);
         copy_(C2, head);
@@ -435,9 +444,14 @@ void gemm_any(ScalarType dt, bool ta, bool tb, int64_t M, int64_t N, int64_t K, 
 // a fresh tensor for the second, and the engine sums the two.
 Tensor grad_target(const Tensor &b) {
     TensorImpl *bi = b.impl();
-    if (!b.has_grad_fn() && !bi->grad_)
-        if (std::shared_ptr<GradSink> sink = bi->sink_.lock())
-            if (Tensor s = sink->take_slot(bi); s.defined()) return s;
+    if (!b.has_grad_fn())
+        if (std::shared_ptr<GradSink> sink = bi->sink_.lock()) {
+            if (!bi->grad_)
+                if (Tensor s = sink->take_slot(bi); s.defined()) return s;
+            // a later producer of the same pass (or a pass that accumulates): its own tensor, in the BUCKET's dtype - a float bucket's
+            // gradients stay float all the way into the sum
+            return empty(b.sizes(), sink->slot(bi).dtype(), b.device());
+        }
     return empty(b.sizes(), b.dtype(), b.device());
 }
 
@@ -463,6 +477,7 @@ public:
             p[0].A = g2.data_ptr(); p[0].lda = N; p[0].B = b.data_ptr(); p[0].ldb = N; p[0].C = da.data_ptr(); p[0].ldc = K;
             p[1].trans_a = 1; p[1].trans_b = 0; p[1].M = K; p[1].N = N; p[1].K = M; p[1].alpha = alpha_; p[1].beta = 0.f;
             p[1].A = a2.data_ptr(); p[1].lda = K; p[1].B = g2.data_ptr(); p[1].ldb = N; p[1].C = db.data_ptr(); p[1].ldc = N;
+            p[1].c_f32 = db.dtype() == ScalarType::Float ? 1 : 0; // the slot of an f32 gradient bucket: dW leaves the accumulators unrounded
             if (kf_gemm_grouped_single_grid(code(a.dtype()), 2, p)) {
                 DEV_CALL(kf_gemm_grouped(code(a.dtype()), 2, p, dev::stream(a.device())));
                 out[0] = da;

@@ -40,6 +40,9 @@ struct GemmArgs {
     // [s nt / split, (s + 1) nt / split) and stores its raw f32 tile to part[s][M][N]; gemm_splitk_fold_kernel finishes
     int split;
     float *part;
+    // 16-bit operands, FLOAT output (and float beta C): the accumulators are f32 already - a weight gradient that is going to be summed
+    // over ranks, or accumulated over micro-batches, leaves without the 16-bit rounding (kf_gemm_ex: epilogue.c_f32, kf_gemm_problem.c_f32)
+    int c_f32;
 };
 
 // XCD-aware remap: consecutive logical tile ids land on the same XCD (its own 4 MiB L2) so
@@ -189,6 +192,15 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const GemmArgs g, int
             const int64_t m = m0 + ty + 16 * i, n = n0 + tx + 16 * j;
             if (m < g.M && n < g.N) {
                 A_t v = (A_t)g.alpha * acc[i][j];
+                if constexpr (sizeof(T) == 2) {
+                    if (g.c_f32) { // float C behind 16-bit operands
+                        float *Cf = (float *)g.C + m * g.ldc + n;
+                        if (g.beta != 0.f) v += g.beta * *Cf;
+                        if (g.epilogue == KF_EPI_BIAS_ROW) v += g_load<T>((const T *)g.bias + n);
+                        *Cf = g_epi<T>(g, m, n, v);
+                        continue;
+                    }
+                }
                 if (g.beta != 0.f) v += (A_t)g.beta * g_load<T>(C + m * g.ldc + n);
                 if (g.epilogue == KF_EPI_BIAS_ROW) v += g_load<T>((const T *)g.bias + n);
                 g_store<T>(C + m * g.ldc + n, g_epi<T>(g, m, n, v));
@@ -636,13 +648,15 @@ __global__ __launch_bounds__(256) void gemm_h_kernel(const GemmArgs g) {
             for (int e = 0; e < 16; ++e) {
                 const int64_t m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
                 float v = g.alpha * acc[i][j][e];
+                float *Cf = (float *)g.C + m * g.ldc + n;
                 if (g.beta != 0.f) {
-                    const uint16_t old = C[m * g.ldc + n];
-                    v += g.beta * (BF ? bf16_to_f32(bf16_t{old}) : f16_to_f32(f16_t{old}));
+                    const uint16_t old = g.c_f32 ? 0 : C[m * g.ldc + n];
+                    v += g.beta * (g.c_f32 ? *Cf : (BF ? bf16_to_f32(bf16_t{old}) : f16_to_f32(f16_t{old})));
                 }
                 v += bias;
                 if (BF) v = g_epi<bf16_t>(g, m, n, v); else v = g_epi<f16_t>(g, m, n, v);
-                C[m * g.ldc + n] = (uint16_t)g_pack2<BF>(v, 0.f);
+                if (g.c_f32) *Cf = v;
+                else C[m * g.ldc + n] = (uint16_t)g_pack2<BF>(v, 0.f);
             }
         }
 }
@@ -660,16 +674,18 @@ __global__ __launch_bounds__(256) void gemm_splitk_fold_kernel(const GemmArgs g)
         v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
     }
     uint16_t *C = (uint16_t *)g.C + m * g.ldc + n;
+    float *Cf = (float *)g.C + m * g.ldc + n;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         float t = g.alpha * v[e];
-        if (g.beta != 0.f) t += g.beta * (BF ? bf16_to_f32(bf16_t{C[e]}) : f16_to_f32(f16_t{C[e]}));
+        if (g.beta != 0.f) t += g.beta * (g.c_f32 ? Cf[e] : (BF ? bf16_to_f32(bf16_t{C[e]}) : f16_to_f32(f16_t{C[e]})));
         if (g.epilogue == KF_EPI_BIAS_ROW) {
             const uint16_t bb = ((const uint16_t *)g.bias)[n + e];
             t += BF ? bf16_to_f32(bf16_t{bb}) : f16_to_f32(f16_t{bb});
         }
         if (BF) t = g_epi<bf16_t>(g, m, n + e, t); else t = g_epi<f16_t>(g, m, n + e, t);
-        C[e] = (uint16_t)g_pack2<BF>(t, 0.f);
+        if (g.c_f32) Cf[e] = t;
+        else C[e] = (uint16_t)g_pack2<BF>(t, 0.f);
     }
 }
 
@@ -1243,6 +1259,23 @@ __device__ __forceinline__ void gemm_w4_body(const GemmArgs &g, const uint32_t b
                 v[e] = __uint_as_float(swp[0]);
                 v[4 + e] = __uint_as_float(swp[1]);
             }
+            if (g.c_f32) { // float C (8 consecutive columns of a row: two 16-byte stores when the rows allow)
+                float *df = (float *)g.C + row * g.ldc + col;
+                const bool wide4 = g.ldc % 4 == 0 && (uintptr_t)g.C % 16 == 0;
+                if (g.beta != 0.f) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += g.beta * df[e];
+                }
+                if constexpr (TAIL) h_epi8<BF>(g, row, col, v);
+                if (wide4) {
+                    *(float4 *)df = float4{v[0], v[1], v[2], v[3]};
+                    *(float4 *)(df + 4) = float4{v[4], v[5], v[6], v[7]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) df[e] = v[e];
+                }
+                continue;
+            }
             if (g.beta != 0.f) {
                 uint32_t ow[4];
                 if (wide) {
@@ -1433,6 +1466,8 @@ extern "C" int kf_gemm_grouped(int dtype, int count, const kf_gemm_problem *p, v
         hipStream_t st = as_stream(stream);
         GemmArgs g0{p[0].A, p[0].B, p[0].C, nullptr, p[0].M, p[0].N, p[0].K, p[0].lda, p[0].ldb, p[0].ldc, p[0].alpha, p[0].beta, KF_EPI_NONE, 0};
         GemmArgs g1{p[1].A, p[1].B, p[1].C, nullptr, p[1].M, p[1].N, p[1].K, p[1].lda, p[1].ldb, p[1].ldc, p[1].alpha, p[1].beta, KF_EPI_NONE, 0};
+        g0.c_f32 = p[0].c_f32 ? 1 : 0;
+        g1.c_f32 = p[1].c_f32 ? 1 : 0;
         g0.group_m = g1.group_m = (int)knob_int(KNOB_GEMM_GROUP_M, 4);
         const unsigned n0 = (unsigned)((p[0].M / G_BM) * (p[0].N / G_BN)), n1 = (unsigned)((p[1].M / G_BM) * (p[1].N / G_BN));
         KF_PROF(dtype == KF_BF16 ? "gemm_bf16_mfma_pair" : "gemm_f16_mfma_pair", st);
@@ -1447,8 +1482,12 @@ extern "C" int kf_gemm_grouped(int dtype, int count, const kf_gemm_problem *p, v
         return KF_OK;
     }
     for (int i = 0; i < count; ++i) {
-        const int rc = kf_gemm(dtype, p[i].trans_a, p[i].trans_b, p[i].M, p[i].N, p[i].K, p[i].alpha, p[i].A, p[i].lda, p[i].B, p[i].ldb, p[i].beta,
-                               p[i].C, p[i].ldc, KF_EPI_NONE, nullptr, nullptr, 0, stream);
+        kf_gemm_epilogue e{};
+        e.c_f32 = p[i].c_f32;
+        const int rc = p[i].c_f32 ? kf_gemm_ex(dtype, p[i].trans_a, p[i].trans_b, p[i].M, p[i].N, p[i].K, p[i].alpha, p[i].A, p[i].lda, p[i].B, p[i].ldb,
+                                               p[i].beta, p[i].C, p[i].ldc, &e, stream)
+                                  : kf_gemm(dtype, p[i].trans_a, p[i].trans_b, p[i].M, p[i].N, p[i].K, p[i].alpha, p[i].A, p[i].lda, p[i].B, p[i].ldb,
+                                            p[i].beta, p[i].C, p[i].ldc, KF_EPI_NONE, nullptr, nullptr, 0, stream);
         if (rc != KF_OK) return rc;
     }
     return KF_OK;
@@ -1478,7 +1517,8 @@ static int gemm_impl(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, 
     KF_REQUIRE((M + 63) / 64 * ((N + 63) / 64) <= 0x7fffffffLL, KF_ERR_INDEX_RANGE, "kf_gemm: too many output tiles for one launch");
     hipStream_t st = as_stream(stream);
     GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, beta, epilogue, 0};
-    if (ex) { g.mul = ex->mul; g.add = ex->add; g.aux = ex->aux; g.ldmul = ex->ldmul; g.ldadd = ex->ldadd; g.ldaux = ex->ldaux; }
+    if (ex) { g.mul = ex->mul; g.add = ex->add; g.aux = ex->aux; g.ldmul = ex->ldmul; g.ldadd = ex->ldadd; g.ldaux = ex->ldaux; g.c_f32 = ex->c_f32 ? 1 : 0; }
+    KF_REQUIRE(!g.c_f32 || dtype == KF_BF16 || dtype == KF_F16, KF_ERR_INVALID, "kf_gemm_ex: c_f32 asks for a float output behind 16-bit operands (dtype %d)", dtype);
     g.group_m = (int)knob_int(KNOB_GEMM_GROUP_M, 4);
 
     const bool al16 = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0);
@@ -1513,7 +1553,7 @@ static int gemm_impl(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, 
         if (h256_ok(M, N, K)) { // every operand layout is consumed in place
             // products with mul / add / aux operands take the 4-wave kernel's tail instantiation (round 3; same loop, same accumulation
             // order, so aux is bit-identical to the plain product)
-            const bool w4 = h256_use_w4(M, N); // profile labels name the kernel that ran (tests assert them)
+            const bool w4 = h256_use_w4(M, N) || g.c_f32; // profile labels name the kernel that ran (tests assert them); the float output lives in the 4-wave kernel
             KF_PROF(dtype == KF_BF16 ? (w4 ? "gemm_bf16_mfma" : "gemm_bf16_mfma_w8") : (w4 ? "gemm_f16_mfma" : "gemm_f16_mfma_w8"), st);
             return dtype == KF_BF16 ? launch_h256<true>(g, trans_a != 0, !trans_b, w4, st) : launch_h256<false>(g, trans_a != 0, !trans_b, w4, st);
         }

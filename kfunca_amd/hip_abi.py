@@ -65,13 +65,14 @@ class IterDesc(C.Structure):
 class GemmEpilogue(C.Structure):
     """kf_gemm_epilogue: C = (alpha AB + beta C + bias) o mul + add, aux = the value in brackets."""
     _fields_ = [("bias", C.c_void_p), ("mul", C.c_void_p), ("ldmul", C.c_int64), ("add", C.c_void_p), ("ldadd", C.c_int64),
-                ("aux", C.c_void_p), ("ldaux", C.c_int64)]
+                ("aux", C.c_void_p), ("ldaux", C.c_int64), ("c_f32", C.c_int32)]
 
 
 class GemmProblem(C.Structure):
     """kf_gemm_problem: one product of a kf_gemm_grouped call."""
     _fields_ = [("trans_a", C.c_int32), ("trans_b", C.c_int32), ("M", C.c_int64), ("N", C.c_int64), ("K", C.c_int64), ("alpha", C.c_float),
-                ("beta", C.c_float), ("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64), ("C", C.c_void_p), ("ldc", C.c_int64)]
+                ("beta", C.c_float), ("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64), ("C", C.c_void_p), ("ldc", C.c_int64),
+                ("c_f32", C.c_int32)]
 
 
 class AttnLayout(C.Structure):
@@ -470,13 +471,13 @@ def gemm(dtype, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, beta, Cptr, ld
 
 
 def gemm_ex(dtype, trans_a, trans_b, M, N, K, alpha, A, lda, B, ldb, beta, Cptr, ldc, bias=None, mul=None, ldmul=0, add=None, ldadd=0,
-            aux=None, ldaux=0, stream=None):
-    e = GemmEpilogue(bias, mul, ldmul, add, ldadd, aux, ldaux)
+            aux=None, ldaux=0, stream=None, c_f32=False):
+    e = GemmEpilogue(bias, mul, ldmul, add, ldadd, aux, ldaux, int(c_f32))
     check(lib().kf_gemm_ex(dtype, int(trans_a), int(trans_b), M, N, K, alpha, A, lda, B, ldb, beta, Cptr, ldc, C.byref(e), stream))
 
 
 def gemm_grouped(dtype, problems, stream=None):
-    """problems: tuples (trans_a, trans_b, M, N, K, alpha, beta, A, lda, B, ldb, C, ldc)."""
+    """problems: tuples (trans_a, trans_b, M, N, K, alpha, beta, A, lda, B, ldb, C, ldc[, c_f32])."""
     arr = (GemmProblem * len(problems))(*[GemmProblem(*p) for p in problems])
     check(lib().kf_gemm_grouped(dtype, len(problems), arr, stream))
 

@@ -401,3 +401,61 @@ def test_headline_backward_pair_vs_oracle_at_4096(code, eps):
     # and against f64 mathematics (the oracle's f32 chain differs from the tile order by accumulation noise only)
     assert (np.abs(got_da - f64(g[rows], code) @ f64(w, code).T) <= 2 * eps * np.abs(want_da) + 2e-6 * mag_da + 1e-6).all()
     assert (np.abs(got_dw - f64(a_cols, code).T @ f64(g, code)) <= 2 * eps * np.abs(want_dw) + 2e-6 * mag_dw + 1e-6).all()
+
+
+@pytest.mark.parametrize("code,eps", [(H.BF16, 2.0 ** -8), (H.F16, 2.0 ** -11)])
+def test_float_output_behind_16bit_operands(code, eps):
+    """kf_gemm_epilogue.c_f32 / kf_gemm_problem.c_f32 (ABI 6): 16-bit operands, FLOAT C - the f32 accumulators leave unrounded (a weight
+    gradient that will be summed over ranks or micro-batches). Every 16-bit kernel family: the 4-wave 256-tile kernel, the 128-tile kernel,
+    the generic one, the backward pair as one grid; beta = 1 accumulates in float. Bar: against f64 mathematics within f32 accumulation
+    noise (2e-6 sum |a||b|), i.e. ~2^8 times tighter than a 16-bit C allows; rounding the float result gives the 16-bit kernel's bits."""
+    rng = np.random.default_rng(640 + code)
+    for (M, N, K, label) in ((2048, 4096, 512, "mfma"), (256, 384, 128, "mfma_128"), (100, 130, 70, "generic")):
+        a = O.from_float(rng.uniform(-1, 1, (M, K)).astype(np.float32), code)
+        b = O.from_float(rng.uniform(-1, 1, (K, N)).astype(np.float32), code)
+        c0 = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+        da, db = H.DevBuf.from_numpy(a), H.DevBuf.from_numpy(b)
+        want = f64(a, code) @ f64(b, code)
+        mag = np.abs(f64(a, code)) @ np.abs(f64(b, code))
+        for ta, tb in ((False, False), (True, False), (False, True)):
+            sa = np.ascontiguousarray(a.T) if ta else a
+            sb = np.ascontiguousarray(b.T) if tb else b
+            dsa, dsb = H.DevBuf.from_numpy(sa), H.DevBuf.from_numpy(sb)
+            dc = H.DevBuf.from_numpy(c0)
+            H.profile_reset()
+            H.profile_enable(True)
+            H.gemm_ex(code, ta, tb, M, N, K, 0.5, dsa.ptr, sa.shape[1], dsb.ptr, sb.shape[1], 1.0, dc.ptr, N, c_f32=True)
+            H.device_sync()
+            H.profile_enable(False)
+            assert any(label in k for k in H.profile_results()), (label, H.profile_results())
+            got = dc.to_numpy((M, N), np.float32).astype(np.float64)
+            assert (np.abs(got - (0.5 * want + c0)) <= 2e-6 * mag + 1e-6).all(), (M, N, K, ta, tb)
+        # the float result, rounded once, is the 16-bit kernel's output
+        dc = H.DevBuf(4 * M * N)
+        H.gemm_ex(code, False, False, M, N, K, 1.0, da.ptr, K, db.ptr, N, 0.0, dc.ptr, N, c_f32=True)
+        H.device_sync()
+        rounded = O.from_float(dc.to_numpy((M, N), np.float32), code)
+        assert np.array_equal(rounded, run_gemm(code, a, b))
+    # the backward pair as ONE grid with a float dW (256 tiles per product: the pair kernel's shape), sampled rows against f64
+    n = 4096
+    a, w, g = (O.from_float(rng.uniform(-1, 1, (n, n)).astype(np.float32), code) for _ in range(3))
+    da, dw, dg = H.DevBuf.from_numpy(a), H.DevBuf.from_numpy(w), H.DevBuf.from_numpy(g)
+    o_da, o_dw = H.DevBuf(2 * n * n), H.DevBuf(4 * n * n)
+    H.profile_reset()
+    H.profile_enable(True)
+    H.gemm_grouped(code, [(0, 1, n, n, n, 1.0, 0.0, dg.ptr, n, dw.ptr, n, o_da.ptr, n), (1, 0, n, n, n, 1.0, 0.0, da.ptr, n, dg.ptr, n, o_dw.ptr, n, 1)])
+    H.device_sync()
+    H.profile_enable(False)
+    assert any(k.endswith("_pair") for k in H.profile_results()), H.profile_results()
+    rows = [0, 1, 255, 256, 2047, 3000, 4095]
+    got_dw = o_dw.to_numpy((n, n), np.float32)[rows].astype(np.float64)
+    a_cols = f64(np.ascontiguousarray(a[:, rows]), code)
+    want_dw, mag_dw = a_cols.T @ f64(g, code), np.abs(a_cols).T @ np.abs(f64(g, code))
+    assert (np.abs(got_dw - want_dw) <= 2e-6 * mag_dw + 1e-6).all()
+    sep = H.DevBuf(2 * n * n)
+    H.gemm(code, 0, 1, n, n, n, 1.0, dg.ptr, n, dw.ptr, n, 0.0, sep.ptr, n)
+    H.device_sync()
+    assert np.array_equal(o_da.to_numpy((n, n), a.dtype), sep.to_numpy((n, n), a.dtype))   # dA of the pair: untouched by its neighbour's float output
+    with pytest.raises(H.KfError) as e:  # float operands have nothing to gain: refused, not ignored
+        H.gemm_ex(H.F32, False, False, 64, 64, 64, 1.0, da.ptr, 64, dw.ptr, 64, 0.0, o_dw.ptr, 64, c_f32=True)
+    assert e.value.code == H.KF_ERR_INVALID

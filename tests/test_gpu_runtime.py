@@ -180,9 +180,18 @@ def test_bench_collective_path_and_checks_on_one_gpu():
                           "--warmup", "1", "--sustain-seconds", "0.2", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
     assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-1500:])
     line = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][-1])
-    assert line["checks"] == {"allreduce_dw_vs_gloo_sum": True, "gemm_rows_vs_oracle": True, "attn_head00_vs_oracle_scale_aware": True,
-                              "attn_last_batch_bit_identical": True, "attn_dv_checksum": True}, line["checks"]
+    assert line["checks"] == {"allreduce_dw_vs_gloo_sum": True, "gemm_rows_vs_oracle": True, "gemm_dA_rows_vs_oracle": True, "gemm_dW_rows_vs_oracle": True,
+                              "attn_head00_vs_oracle_scale_aware": True, "attn_last_batch_bit_identical": True, "attn_dv_checksum": True}, line["checks"]
+    # round 4: where an N-GPU step's time goes - the same loop without the collective, the exposed communication, the overlap
+    assert line["ms_per_step_no_comm"] > 0 and "exposed_comm_ms" in line and "overlap_efficiency" in line and line["allreduce"]["ms_max"] >= line["allreduce"]["ms_p50"] > 0
     worst = line["check_notes"]["attn_head00_worst_fraction_of_bound"]
     assert set(worst) == {"o", "dq", "dk", "dv"} and all(0 < v < 1 for v in worst.values()), worst
     assert line["allreduce"]["message_bytes"] == 4096 * 4096 * 2 and line["allreduce"]["ms"] > 0
     assert line["n_gpus"] == 1 and line["ms_per_step_sustained"] > 0 and line["roofline"]["frac"] > 0
+    # the float gradient path (KF_BENCH_GRAD_F32): dW leaves the pair launch as float, RCCL sums floats, the same checks hold
+    env["KF_BENCH_GRAD_F32"] = "1"
+    res = subprocess.run([sys.executable, str(Path(__file__).resolve().parent.parent / "bench.py"), "--gpus", "1", "--check", "--steps", "2",
+                          "--warmup", "1", "--sustain-seconds", "0", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-1500:])
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][-1])
+    assert all(line["checks"].values()) and line["checks"]["gemm_dW_rows_vs_oracle"] and line["allreduce"]["dtype"] == "f32" and line["allreduce"]["message_bytes"] == 4096 * 4096 * 4
