@@ -1519,7 +1519,9 @@ static int gemm_impl(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, 
     GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, beta, epilogue, 0};
     if (ex) { g.mul = ex->mul; g.add = ex->add; g.aux = ex->aux; g.ldmul = ex->ldmul; g.ldadd = ex->ldadd; g.ldaux = ex->ldaux; g.c_f32 = ex->c_f32 ? 1 : 0; }
     KF_REQUIRE(!g.c_f32 || dtype == KF_BF16 || dtype == KF_F16, KF_ERR_INVALID, "kf_gemm_ex: c_f32 asks for a float output behind 16-bit operands (dtype %d)", dtype);
-    g.group_m = (int)knob_int(KNOB_GEMM_GROUP_M, 4);
+    // tile rows per group of the XCD-aware tile walk: 4, and 8 once the grid is >= 1024 tiles of 256^2 (8192^3 NN: 1187 -> 1234 TFLOP/s per
+    // launch, same box, tools/scratch/gemm_stride.py; 2..8 alike at 768 tiles, 1 and 16 behind everywhere)
+    g.group_m = (int)knob_int(KNOB_GEMM_GROUP_M, (M / 256) * (N / 256) >= 1024 ? 8 : 4);
 
     const bool al16 = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0);
     if (dtype == KF_F32 && M % 64 == 0 && N % 64 == 0 && K % F_BK == 0 && K > 0 && al16 && lda % 4 == 0 && ldb % 4 == 0) {

@@ -12,7 +12,7 @@ from bench import BENCH_SOURCES, stamp  # noqa: E402
 
 ROUND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
-NAMES = {"gemm_h256_kernel": "gemm_bf16_mfma", "gemm_w4_pair_kernel": "gemm_bf16_mfma_pair", "gemm_w4_kernel": "gemm_bf16_mfma", "attn_fwd_v3_kernel": "attn_fwd_mfma", "attn_delta_kernel": "attn_bwd_delta",
+NAMES = {"gemm_h256_kernel": "gemm_bf16_mfma", "gemm_w4_pair_kernel": "gemm_bf16_mfma_pair", "gemm_w4_kernel": "gemm_bf16_mfma", "attn_fwd_v3_kernel": "attn_fwd_mfma", "attn_fwd_w4_kernel": "attn_fwd_mfma", "attn_bwd_dkv_w4_kernel": "attn_bwd_dkv_mfma", "attn_delta_kernel": "attn_bwd_delta",
          "attn_bwd_dkv_v4_kernel": "attn_bwd_dkv_mfma", "attn_bwd_dq_v2_kernel": "attn_bwd_dq_mfma", "attn_bwd_dq_ds_kernel": "attn_bwd_dq_mfma"}
 
 
@@ -39,4 +39,4 @@ for k in NAMES.values():
         out[k] = {"FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "bytes_per_launch": (2 * fk + wk) * 1024, "launches_sampled": len(fetch[k])}
 out.update(stamp(BENCH_SOURCES))  # bench.py quotes this file only for the device sources it was measured on
 json.dump(out, open(f"profiles/{ROUND}_pmc_traffic.json", "w"), indent=1)
-print(json.dumps({k: v["bytes_per_launch"] for k, v in out.items() if isinstance(v, dict)}, indent=1))
+print(json.dumps({k: v["bytes_per_launch"] for k, v in out.items() if isinstance(v, dict) and "bytes_per_launch" in v}, indent=1))

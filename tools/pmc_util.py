@@ -12,7 +12,7 @@ from bench import BENCH_SOURCES, stamp  # noqa: E402
 
 ROUND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
-NAMES = {"gemm_h256_kernel": "gemm_bf16_mfma", "gemm_w4_pair_kernel": "gemm_bf16_mfma_pair", "gemm_w4_kernel": "gemm_bf16_mfma", "attn_fwd_v3_kernel": "attn_fwd_mfma", "attn_bwd_dkv_v4_kernel": "attn_bwd_dkv_mfma",
+NAMES = {"gemm_h256_kernel": "gemm_bf16_mfma", "gemm_w4_pair_kernel": "gemm_bf16_mfma_pair", "gemm_w4_kernel": "gemm_bf16_mfma", "attn_fwd_v3_kernel": "attn_fwd_mfma", "attn_fwd_w4_kernel": "attn_fwd_mfma", "attn_bwd_dkv_w4_kernel": "attn_bwd_dkv_mfma", "attn_bwd_dkv_v4_kernel": "attn_bwd_dkv_mfma",
          "attn_bwd_dq_v2_kernel": "attn_bwd_dq_mfma", "attn_bwd_dq_ds_kernel": "attn_bwd_dq_mfma"}
 N_XCD, N_SIMD = 8, 1024
 
