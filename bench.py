@@ -107,7 +107,7 @@ def device_src_sha() -> str:
 
 # which device sources each kind of committed profile depends on (tests/test_profiles_fresh.py): a profile is STALE - and must be
 # re-collected before it is quoted - when any of its files has changed since it was taken
-BENCH_SOURCES = ("attention.hip", "attn_fwd_w4.inc", "gemm.hip", "common.h", "runtime.hip")
+BENCH_SOURCES = ("attention.hip", "attn_fwd_w4.inc", "attn_dkv_w4.inc", "gemm.hip", "common.h", "runtime.hip")
 MEMBOUND_SOURCES = ("elementwise.hip", "reduce.hip", "norm.hip", "index.hip", "sort.hip", "common.h", "offset_calc.h", "runtime.hip")
 
 
