@@ -130,7 +130,10 @@ def stamp_is_current(obj: dict, names) -> bool:
     files = obj.get("device_src_files")
     if files:
         now = device_src_shas(names)
-        return all(files.get(n) == h for n, h in now.items())
+        if all(n in files for n in now):
+            return all(files[n] == h for n, h in now.items())
+        # a dependency the stamp does not list (the list grew after it was taken): only the tree-wide hash can vouch for it
+        return all(files[n] == h for n, h in now.items() if n in files) and obj.get("device_src_sha") == device_src_sha()
     return obj.get("device_src_sha") == device_src_sha()
 
 
