@@ -243,6 +243,7 @@ def spot_check(H, wl, check_dw=True):
     try:
         margins = K.attn_check(q, k, v, O.BF16, o=got["o"], lse=lse_got, d_o=go, dq=got["dq"], dk=got["dk"], dv=got["dv"], what="bench head (0,0)")
         attn_ok, attn_note = True, {n: round(max(m.get("element", 0), m.get("row", 0), m.get("head", 0)), 3) for n, m in margins.items() if n != "lse"}
+        attn_note["lse"] = round(margins["lse"]["fraction_of_bound"], 3)   # the forward rounds c q to bf16: lse against that rounding's worst case (oracle/checks.py)
     except AssertionError as e:
         attn_ok, attn_note = False, str(e)
     same = all(np.array_equal(got[n], head(b, AB - 1)) for n, b in (("o", wl.o), ("dq", wl.dq), ("dk", wl.dk), ("dv", wl.dv)))

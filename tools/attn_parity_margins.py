@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Measured margins of the 16-bit attention kernels under the scale-aware bounds of oracle/checks.py (GPU box):
 
-    python tools/attn_parity_margins.py [--out gpurun_out/r03_attn_parity_margins.json]
+    python tools/attn_parity_margins.py [--out gpurun_out/r04_attn_parity_margins.json]
 
 For every shape / dtype / head size below: the worst element, row and head figures (fractions of the bound: 1 = at the bound) and the worst
 row-relative L2 error of O, dQ, dK, dV against the double-precision oracle, plus the LSE error. The constants in oracle/checks.py are set
@@ -27,7 +27,7 @@ SHAPES = [(1, 2, 256, 256, 128), (2, 3, 128, 384, 128), (1, 2, 384, 128, 128), (
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "r03_attn_parity_margins.json"))
+    ap.add_argument("--out", default=str(ROOT / "gpurun_out" / "r04_attn_parity_margins.json"))
     args = ap.parse_args()
     H.set_device(0)
     rows, worst = [], {}
@@ -49,6 +49,10 @@ def main():
                 rec["lse_max_abs"] = float(np.abs(lse.astype(np.float64) - ref["lse"]).max())
                 rec["lse_max_rel"] = float((np.abs(lse.astype(np.float64) - ref["lse"]) / (1 + np.abs(ref["lse"]))).max())
                 worst[(cname, "lse_rel")] = max(worst.get((cname, "lse_rel"), 0.0), rec["lse_max_rel"])
+                if D == 128 and Sq % 256 == 0 and Skv >= Sq:   # the forward that rounds c q to the element type: its lse against that rounding's worst case
+                    tol = 2e-6 * (1 + np.abs(ref["lse"])) + K.lse_scaled_query_bound(q, k, code)
+                    rec["lse_fraction_of_scaled_query_bound"] = float((np.abs(lse.astype(np.float64) - ref["lse"]) / tol).max())
+                    worst[(cname, "lse_scaled_query")] = max(worst.get((cname, "lse_scaled_query"), 0.0), rec["lse_fraction_of_scaled_query_bound"])
                 rows.append(rec)
                 print(json.dumps(rec), flush=True)
     out = {"constants": {"C_OUT": K.C_OUT, "C_SUM": K.C_SUM, "C_ROW": K.C_ROW, "C_Q": K.C_Q, "C_HEAD": K.C_HEAD, "C_QH": K.C_QH, "eps": {"bf16": 2.0 ** -8, "f16": 2.0 ** -11}},

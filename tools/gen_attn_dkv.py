@@ -570,7 +570,7 @@ def finish_waits(ins):
 def check(ins):
     """Distances the hardware does not interlock, per variant (walked twice): an MFMA's VGPR / AGPR result is read or overwritten by
     anything but its own accumulate chain only >= 2 MFMAs or >= 22 wait states later; a VALU result feeds an MFMA operand only with >= 4
-    instructions in between."""
+    instructions in between; a transcendental's result is never read by the very next instruction."""
     problems = []
     cur, variants = None, {}
     for i in ins:
@@ -585,7 +585,11 @@ def check(ins):
         seq = [x for x in body if x.kind not in ("raw", "label", "nomfma")] * 2
         lm, lv = {}, {}
         n_mfma = n_ins = 0
+        prev = None
         for x in seq:
+            if prev is not None and prev.kind == "trans" and x.kind in ("valu", "trans") and set(prev.writes) & set(x.reads):
+                problems.append(f"{name}: '{x.text}' reads the result of the transcendental right in front of it (no forwarding interlock on gfx950)")
+            prev = x
             n_ins += 1
             if x.kind == "mfma":
                 n_mfma += 1

@@ -44,6 +44,7 @@ LA, LB = (168, 170), (169, 171)   # row sums, two partial chains per block
 MXA, MXB = (172, 174), (173, 175)  # per-lane tile maxima (two chains)
 NEGINF, RM, DV = 176, 177, 178
 T = list(range(180, 196))  # temporaries (slow path, prologue, epilogue)
+NMC = (200, 216)           # sixteen copies of -MC per block: the C operand of a score chain's first MFMA (S^T arrives as score - maximum in use)
 def OA(b, db): return 64 * b + 16 * db           # AGPRs
 def QF(b, kk): return 128 + 32 * b + 4 * kk
 def KF(sub, kk): return 192 + 32 * sub + 4 * kk
@@ -57,7 +58,7 @@ S_TMP, S_TMP2, S_QSR, S_OSR, S_WID, S_TM1 = 66, 67, 68, 69, 70, 71
 S_LSE = 72  # pair
 S_LDS, S_STAGE, S_X0, S_X1, S_X2 = 74, 75, 76, 77, 78
 S_MUT = 79  # mutation build: the tile whose probabilities are dropped (-1: none)
-N_VGPR = 200  # v0 .. v199 are the stream's; the rest of the arch file stays the compiler's (it has nowhere else to keep a scalar it cannot hold in SGPRs)
+N_VGPR = 232  # v0 .. v231 are the stream's; the rest of the arch file stays the compiler's (it has nowhere else to keep a scalar it cannot hold in SGPRs)
 
 # ---- placement tables (gap = position behind MFMA number `gap` of the 64 of a tile iteration; slot A 0..15, B 16..31, C 32..47, D 48..63)
 # Measured (tools/attn_fwd_w4_timeline.py, cycles per steady iteration, slots A / B / C / D): all 8 pieces in slot B and the V reads two per gap
@@ -94,6 +95,7 @@ class Gen:
         self.mutant = mutant
         self.stamps = stamps        # diagnostic build (tools/attn_fwd_w4_timeline.py): s_memtime at the slot boundaries, eight sums per wave and block
         self.ablate = set(ablate)   # timing experiments only (tools/scratch/fwd_w4_ablate.sh): parts of the tile body left out - WRONG results
+        self.f16 = f16
         self.mfma = "v_mfma_f32_32x32x16_f16" if f16 else "v_mfma_f32_32x32x16_bf16"
         self.cvt = "v_cvt_pk_f16_f32" if f16 else "v_cvt_pk_bf16_f32"
         self.out = []   # list of Ins (and labels / comments as kind "raw")
@@ -107,11 +109,18 @@ class Gen:
     def valu(self, text, reads=(), writes=(), trans=False):
         self.out.append(Ins(text, "trans" if trans else "valu", reads, writes))
 
-    def qk(self, b, sub, kk):
+    def qk(self, b, sub, kk, first=False):
+        """One MFMA of S^T = K (c Q)^T. The chain starts from -MC (sixteen equal registers per lane: a lane holds one query), so the
+        accumulator IS the exponent; only a pass's first tile, which has no maximum yet, starts from 0."""
         d = S(b, 16 * sub)
-        c = "0" if kk == 0 else vr(d, 16)
+        if kk:
+            c, cr = vr(d, 16), V(d, 16)
+        elif first:
+            c, cr = "0", []
+        else:
+            c, cr = vr(NMC[b], 16), V(NMC[b], 16)
         self.out.append(Ins(f"{self.mfma} {vr(d, 16)}, {ar(KF(sub, kk), 4)}, {ar(QF(b, kk), 4)}, {c}", "mfma",
-                            A(KF(sub, kk), 4) + A(QF(b, kk), 4) + (V(d, 16) if kk else []), V(d, 16), tag=f"qk b{b} sub{sub} kk{kk}"))
+                            A(KF(sub, kk), 4) + A(QF(b, kk), 4) + cr, V(d, 16), tag=f"qk b{b} sub{sub} kk{kk}"))
 
     def pv(self, b, ks, db):
         o = OA(b, db)
@@ -165,12 +174,12 @@ class Gen:
         self.salu("s_mov_b32 s82, s80")
 
     # -------------------------------------------------------------- the filler streams of one iteration
-    def softmax_ops(self, b, cur, masked, drop):
+    def softmax_ops(self, b, cur, masked, drop, first=False):
         """All VALU ops of block b's softmax of one tile as (gap, order, emit) tuples; gaps are relative to the block's S slot
         (0 = behind the slot's first MFMA) and run to 57; the caller shifts block 1 by 32 and folds modulo 64."""
         ops = []
         s_c = sr(S_C)
-        def add(g, fn): ops.append((g, len(ops), fn))
+        def add(g, fn, key=None): ops.append((g, len(ops) if key is None else key, fn))
         # ---- masking of the diagonal tile (this wave's own diagonal): key (e & 3) + 8 (e >> 2) + 4 h > query r
         # (this variant runs once per wave and block: its gaps may be as full as they need to be; the chain's timing stays the steady one)
         if masked:
@@ -209,25 +218,41 @@ class Gen:
         # ---- decision: does any query of the wave exceed the maximum in use by more than `defer` exponent units?
         gd = 21
         add(gd, lambda: self.valu(f"v_max3_f32 {vr(MXA[b])}, {vr(MXA[b])}, {vr(MXB[b])}, {vr(MXC)}", V(MXA[b]) + V(MXB[b]) + V(MXC), V(MXA[b])))
-        add(gd, lambda: self.valu(f"v_fma_f32 {vr(DV)}, {vr(MXA[b])}, {s_c}, -{vr(MC[b])}", V(MXA[b]) + V(MC[b]), V(DV)))
-        add(gd + 1, lambda: self.valu(f"v_cmp_lt_f32 vcc, {sr(S_DEFER)}, {vr(DV)}", V(DV), [("vcc", 0)]))
-        add(gd + 1, lambda: self.rescale(b))
-        # ---- the exponent chain, one value per gap: fma (scale, subtract the maximum) | exp2 | row sum | pack pairs
+        # (the scores arrive as exponents relative to the maximum in use: the tile maximum IS the excess)
+        if first:
+            add(gd + 1, lambda: self.adopt_first(b))
+        else:
+            add(gd + 1, lambda: self.valu(f"v_cmp_lt_f32 vcc, {sr(S_DEFER)}, {vr(MXA[b])}", V(MXA[b]), [("vcc", 0)]))
+            add(gd + 1, lambda: self.rescale(b))
+        # ---- the exponent chain, one value per gap: exp2 | row sum | pack pairs
         g0 = gd + 2
-        src2 = vr(MC[b])
         for n in range(32):
             x = S(b, n)
             if drop:  # mutation build: this tile's probabilities are dropped (p = exp2(-inf) = 0)
                 add(g0 + n, lambda x=x: self.valu(f"v_mov_b32 {vr(x)}, {vr(NEGINF)}", V(NEGINF), V(x)))
-            else:
-                add(g0 + n, lambda x=x: self.valu(f"v_fma_f32 {vr(x)}, {vr(x)}, {s_c}, -{src2}", V(x) + V(MC[b]), V(x)))
-            add(g0 + n + 1, lambda x=x: self.valu(f"v_exp_f32 {vr(x)}, {vr(x)}", V(x), V(x), trans=True))
+            # (order inside a gap: exp | pack | row sum - the consumer of an exp stands at least two instructions behind it)
+            add(g0 + n + 1, lambda x=x: self.valu(f"v_exp_f32 {vr(x)}, {vr(x)}", V(x), V(x), trans=True), key=1000)
             l = (LA if n % 2 == 0 else LB)[b]
-            add(g0 + n + 2, lambda x=x, l=l: self.valu(f"v_add_f32 {vr(l)}, {vr(l)}, {vr(x)}", V(l) + V(x), V(l)))
+            add(g0 + n + 2, lambda x=x, l=l: self.valu(f"v_add_f32 {vr(l)}, {vr(l)}, {vr(x)}", V(l) + V(x), V(l)), key=1002)
             if n % 2 == 1:
                 d = P(b, n // 8) + (n % 8) // 2
-                add(g0 + n + 3, lambda x=x, d=d: self.valu(f"{self.cvt} {vr(d)}, {vr(x - 1)}, {vr(x)}", V(x - 1) + V(x), V(d)))
+                add(g0 + n + 3, lambda x=x, d=d: self.valu(f"{self.cvt} {vr(d)}, {vr(x - 1)}, {vr(x)}", V(x - 1) + V(x), V(d)), key=1001)
         return ops
+
+    def adopt_first(self, b):
+        """A pass's first tile: no maximum is in use yet (its score chains started from 0), so the tile's own maximum is adopted
+        unconditionally - MC, the sixteen copies of -MC, and the tile's 32 exponents shifted by it. O and the row sums are still 0."""
+        t0, t1 = T[0], T[1]
+        self.valu(f"v_mov_b32 {vr(t0)}, {vr(MXA[b])}", V(MXA[b]), V(t0))
+        self.valu(f"v_mov_b32 {vr(t1)}, {vr(MXA[b])}", V(MXA[b]), V(t1))
+        self.salu("s_nop 1")
+        self.valu(f"v_permlane32_swap_b32 {vr(t0)}, {vr(t1)}", V(t0) + V(t1), V(t0) + V(t1))
+        self.valu(f"v_max_f32 {vr(MC[b])}, {vr(t0)}, {vr(t1)}", V(t0) + V(t1), V(MC[b]))       # the same for the two lanes of a query
+        self.valu(f"v_xor_b32 {vr(t1)}, 0x80000000, {vr(MC[b])}", V(MC[b]), V(t1))
+        for i in range(16):
+            self.valu(f"v_mov_b32 {vr(NMC[b] + i)}, {vr(t1)}", V(t1), V(NMC[b] + i))
+        for n in range(32):
+            self.valu(f"v_add_f32 {vr(S(b, n))}, {vr(S(b, n))}, {vr(t1)}", V(S(b, n)) + V(t1), V(S(b, n)))
 
     def rescale(self, b):
         """The rare path, inline behind the decision: adopt the new maximum (the same for the two lanes of a query), scale the row
@@ -242,11 +267,14 @@ class Gen:
         self.salu("s_nop 1")
         self.valu(f"v_permlane32_swap_b32 {vr(t0)}, {vr(t1)}", V(t0) + V(t1), V(t0) + V(t1))
         self.valu(f"v_max_f32 {vr(t0)}, {vr(t0)}, {vr(t1)}", V(t0) + V(t1), V(t0))
-        self.valu(f"v_mul_f32 {vr(t0)}, {sr(S_C)}, {vr(t0)}", V(t0), V(t0))
-        self.valu(f"v_max_f32 {vr(t0)}, {vr(t0)}, {vr(MC[b])}", V(t0) + V(MC[b]), V(t0))           # new maximum
-        self.valu(f"v_sub_f32 {vr(t1)}, {vr(MC[b])}, {vr(t0)}", V(t0) + V(MC[b]), V(t1))
-        self.valu(f"v_mov_b32 {vr(MC[b])}, {vr(t0)}", V(t0), V(MC[b]))
-        self.valu(f"v_exp_f32 {vr(t1)}, {vr(t1)}", V(t1), V(t1), trans=True)                           # alpha = 2^(old - new), 0 at the first tile
+        self.valu(f"v_max_f32 {vr(t0)}, 0, {vr(t0)}", V(t0), V(t0))                                    # how far the maximum in use moves up (0: this query stays)
+        self.valu(f"v_add_f32 {vr(MC[b])}, {vr(MC[b])}, {vr(t0)}", V(t0) + V(MC[b]), V(MC[b]))       # new maximum
+        self.valu(f"v_xor_b32 {vr(t2)}, 0x80000000, {vr(MC[b])}", V(MC[b]), V(t2))
+        for i in range(16):
+            self.valu(f"v_mov_b32 {vr(NMC[b] + i)}, {vr(t2)}", V(t2), V(NMC[b] + i))
+        for n in range(32):                                                                            # this tile's exponents were formed against the old one
+            self.valu(f"v_sub_f32 {vr(S(b, n))}, {vr(S(b, n))}, {vr(t0)}", V(S(b, n)) + V(t0), V(S(b, n)))
+        self.valu(f"v_exp_f32 {vr(t1)}, -{vr(t0)}", V(t0), V(t1), trans=True)                          # alpha = 2^(old - new)
         self.salu("s_nop 0")
         self.valu(f"v_mul_f32 {vr(LA[b])}, {vr(LA[b])}, {vr(t1)}", V(LA[b]) + V(t1), V(LA[b]))
         self.valu(f"v_mul_f32 {vr(LB[b])}, {vr(LB[b])}, {vr(t1)}", V(LB[b]) + V(t1), V(LB[b]))
@@ -268,14 +296,15 @@ class Gen:
         G = [[] for _ in range(64)]   # fillers per gap, (order key, emit function)
         def put(g, key, fn): G[g % 64].append((key, fn))
         self.in_loop = True
+        first = has_cur and not has_prev   # a pass's first tile: no maximum in use yet
         if "valu" in self.ablate:
             has_cur_sm = has_prev_sm = False
         else:
             has_cur_sm, has_prev_sm = has_cur, has_prev
         if has_cur_sm:
-            for (g, k, fn) in self.softmax_ops(0, True, masked, drop):
+            for (g, k, fn) in self.softmax_ops(0, True, masked, drop, first):
                 put(g, (0, k), fn)
-            for (g, k, fn) in self.softmax_ops(1, True, masked, drop):
+            for (g, k, fn) in self.softmax_ops(1, True, masked, drop, first):
                 if 32 + g < 64:
                     put(32 + g, (1, k), fn)
         if has_prev_sm:
@@ -344,11 +373,11 @@ class Gen:
                 self.wait(lgkm=0)          # V^T fragments (read in slot C)
             # ---- the MFMA of this gap
             if slot == 0 and has_cur and not (masked and j >= 8):
-                self.qk(0, j // 8, j % 8)
+                self.qk(0, j // 8, j % 8, first)
             elif slot == 1 and has_prev:
                 self.pv(1, j // 4, j % 4)
             elif slot == 2 and has_cur:
-                self.qk(1, j // 8, j % 8)
+                self.qk(1, j // 8, j % 8, first)
             elif slot == 3 and has_cur:
                 self.pv(0, j // 4, j % 4)
             else:
@@ -450,9 +479,10 @@ class Gen:
         e.salu(f"s_mul_i32 {sr(S_X0)}, {sr(S_TMP)}, {sr(S_QSR)}")
         e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_QSR)}, 5")
         e.salu(f"s_add_u32 {sr(S_X1)}, {sr(S_X0)}, {sr(S_TMP)}")
+        # (into the score registers: they are scaled by scale log2(e) below, once per pass, and only then become the B operands in a[128:191])
         for b in range(2):
             for kk in range(8):
-                e.out.append(Ins(f"buffer_load_dwordx4 {ar(QF(b, kk), 4)}, {vr(t3)}, {sr(Q_SRD, 4)}, {sr(S_X0 + b)} offen offset:{32 * kk}", "vmem", V(t3), A(QF(b, kk), 4)))
+                e.out.append(Ins(f"buffer_load_dwordx4 {vr(QF(b, kk) - 128, 4)}, {vr(t3)}, {sr(Q_SRD, 4)}, {sr(S_X0 + b)} offen offset:{32 * kk}", "vmem", V(t3), V(QF(b, kk) - 128, 4)))
         # ---- tile 0 of K into slot 0
         e.raw("; ---- K(0) -> slot 0; then K(1) -> slot 1 and V(0) -> slot 0")
         e.salu(f"s_mov_b32 {sr(S_KOFF0)}, {sr(S_RB0)}")
@@ -487,6 +517,24 @@ class Gen:
             e.valu(f"v_mov_b32 {vr(MC[b])}, {vr(NEGINF)}")
             e.valu(f"v_mov_b32 {vr(LA[b])}, 0")
             e.valu(f"v_mov_b32 {vr(LB[b])}, 0")
+        # ---- Q *= scale log2(e), rounded to the element type once: the score MFMAs then deliver exponents (no multiply per score in the tile loop)
+        e.wait(vm=12)     # in-order counter: the 16 Q loads are older than the 12 DMA pieces
+        if self.f16:
+            c2 = T[8]
+            e.valu(f"v_cvt_f16_f32 {vr(c2)}, {sr(S_C)}")
+            e.valu(f"v_pack_b32_f16 {vr(c2)}, {vr(c2)}, {vr(c2)}")
+            for i in range(64):
+                e.valu(f"v_pk_mul_f16 {vr(i)}, {vr(i)}, {vr(c2)}")
+                e.valu(f"v_accvgpr_write_b32 {ar(128 + i)}, {vr(i)}", V(i), A(128 + i))
+        else:
+            for i in range(64):
+                hi, lo = T[8 + 2 * (i & 3)], T[9 + 2 * (i & 3)]
+                e.valu(f"v_and_b32 {vr(hi)}, 0xffff0000, {vr(i)}")
+                e.valu(f"v_lshlrev_b32 {vr(lo)}, 16, {vr(i)}")
+                e.valu(f"v_mul_f32 {vr(hi)}, {sr(S_C)}, {vr(hi)}")
+                e.valu(f"v_mul_f32 {vr(lo)}, {sr(S_C)}, {vr(lo)}")
+                e.valu(f"{self.cvt} {vr(i)}, {vr(lo)}, {vr(hi)}")
+                e.valu(f"v_accvgpr_write_b32 {ar(128 + i)}, {vr(i)}", V(i), A(128 + i))
         # ---- K(0) has landed for everyone: its fragments; then the ring bases move to where iteration 0 expects them
         e.wait(vm=8)      # in-order counter: the 16 Q loads and the 4 K(0) pieces are older than the 4 + 4 pieces of K(1) and V(0)
         e.barrier()
@@ -553,6 +601,19 @@ class Gen:
             e.salu("s_nop 0")
             e.valu(f"v_add_f32 {vr(l)}, {vr(l)}, {vr(MC[b])}")
             e.valu(f"v_mul_f32 {vr(l)}, 0x3f317218, {vr(l)}")                 # ln 2: LSE in natural-log units
+            dbg = __import__("os").environ.get("KF_GEN_DBG", "")
+            if dbg:  # debugging aid: raw state instead of the LSE (l: row sum; mc; la / lb: the lane's partial sums; *_hi: the upper lane half's)
+                src = {"mc": MC[b], "la": LA[b], "lb": LB[b], "nmc": NMC[b], "s0": S(b, 0), "s16": S(b, 16), "s31": S(b, 31)}.get(dbg.replace("_hi", ""))
+                if dbg == "l":
+                    e.valu(f"v_rcp_f32 {vr(l)}, {vr(inv[b])}")
+                    e.salu("s_nop 0")
+                else:
+                    e.valu(f"v_mov_b32 {vr(l)}, {vr(src)}")
+                    if dbg.endswith("_hi"):
+                        e.valu(f"v_mov_b32 {vr(t)}, {vr(src)}")
+                        e.salu("s_nop 1")
+                        e.valu(f"v_permlane32_swap_b32 {vr(l)}, {vr(t)}")
+                        e.valu(f"v_mov_b32 {vr(l)}, {vr(t)}")
             # lanes 0..31 store the LSE of query 64 w + 32 b + r
             e.valu(f"v_lshlrev_b32 {vr(t)}, 2, {vr(r)}")
             e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 8")
@@ -628,7 +689,33 @@ class Gen:
             self.iteration("steadydrop", has_prev=True, has_cur=True, drop=True)
             self.next_iter()
         self.epilogue()
+        self.fix_trans_use()
         return self
+
+    def fix_trans_use(self):
+        """gfx950 does not interlock a transcendental result against an instruction that reads it ONE wait state later (the
+        quarter-rate unit is still delivering lanes: measured round 4 - exp | s_nop 0 | add left the OLD value in the lanes with
+        (lane & 4) == 0; exp | s_nop 1 | add is clean, and so is any real instruction in between). Behind an MFMA the stream
+        never does that; where gaps hold no MFMA (drain, a first tile's empty slot, prologue, epilogue, the rare rescale) a
+        transcendental and its consumer can become neighbours: `s_nop 1` goes between them, and an `s_nop 0` that is all that
+        separates them is widened."""
+        out, prev, sep = [], None, 0
+        for x in self.out:
+            if x.kind in ("raw", "label", "nomfma"):
+                out.append(x)
+                if x.kind == "label": prev = None
+                continue
+            if prev is not None and x.kind == "salu" and x.text.startswith("s_nop") and sep == 0:
+                if int(x.text.split()[1]) < 1:
+                    x = Ins("s_nop 1", "salu")
+                out.append(x)
+                sep = 2
+                continue
+            if prev is not None and sep == 0 and x.kind in ("valu", "trans") and set(prev.writes) & set(x.reads):
+                out.append(Ins("s_nop 1", "salu"))
+            out.append(x)
+            prev, sep = (x, 0) if x.kind == "trans" else (None, 0)
+        self.out = out
 
 
 # ------------------------------------------------------------------ static checks on the emitted stream
@@ -653,7 +740,14 @@ def check(ins):
         seq = [x for x in body if x.kind not in ("raw", "label", "nomfma")] * 2
         last_mfma_write, last_valu_write, pending_lds = {}, {}, {}
         n_mfma, n_ins = 0, 0
+        prev, tws = None, 0
         for x in seq:
+            if x.kind == "salu" and x.text.startswith("s_nop") and prev is not None:
+                tws += int(x.text.split()[1]) + 1
+            elif prev is not None and x.kind in ("valu", "trans") and set(prev.writes) & set(x.reads) and tws < 2:
+                problems.append(f"{name}: '{x.text}' reads the result of '{prev.text}' {tws} wait state(s) behind it (a transcendental needs 2)")
+            if not (x.kind == "salu" and x.text.startswith("s_nop")):
+                prev, tws = (x, 0) if x.kind == "trans" else (None, 0)
             n_ins += 1
             if x.kind == "mfma":
                 n_mfma += 1
