@@ -67,8 +67,8 @@ struct AttnArgs {
     int nbh;         // pairs in this launch (forward and the other forms: B H, bh0 = 0)
     char *ds;        // backward: dS = P o (dP - delta) in 16 bits, written by the dK/dV kernel, read by the dQ kernel (null: not kept)
     int64_t ds_nqb, ds_nkwb; // its tile grid: 256-query blocks x 32-key blocks (DS_* below)
-#ifdef KF_FWD_W4_STAMPS
-    unsigned long long *dbg; // diagnostic build (tools/attn_fwd_w4_timeline.py): where every wave writes its cycle sums
+#if defined(KF_FWD_W4_STAMPS) || defined(KF_DKV_W4_STAMPS)
+    unsigned long long *dbg; // diagnostic builds (tools/attn_fwd_w4_timeline.py, attn_dkv_w4_timeline.py): where every wave writes its cycle sums
 #endif
 };
 
@@ -1747,15 +1747,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) 
 #ifdef KF_MUTANT
         if (a.mutant == 2 && xb == 0 && wid < 2) mut = 4; // defect 2: queries 128..159 contribute nothing to keys 0..127
 #endif
+#ifdef KF_DKV_W4_STAMPS // diagnostic build (tools/attn_dkv_w4_timeline.py): eight cycle sums per wave and block pass into the debug buffer
+        unsigned long long *dbg = a.dbg;
+        const unsigned dbgoff = (blockIdx.x * 2 + pass) * 4 * 32;
+#define KF_DKV_EXTRA , [dbg] "s"(dbg), [dbgoff] "s"(dbgoff)
+#else
+#define KF_DKV_EXTRA
+#endif
 #define KF_DKV_OPERANDS                                                                                                                       \
     [qp] "s"(qp), [dop] "s"(dop), [kp] "s"(kp), [vp] "s"(vp), [dkp] "s"(dkp), [dvp] "s"(dvp), [cp] "s"(cp), [dsp] "s"(dsp), [cdelta] "s"(cdelta), \
         [qsr] "s"(qsr), [dosr] "s"(dosr), [kvsr] "s"(kvsr), [osr] "s"(osr), [s0] "s"(s0), [ns] "s"(ns), [dsqb] "s"(dsqb), [wid] "s"(wid),       \
-        [scale] "s"(scale), [lds] "s"(lds), [mut] "s"(mut)
+        [scale] "s"(scale), [lds] "s"(lds), [mut] "s"(mut) KF_DKV_EXTRA
         if constexpr (BF && DS) asm volatile(KF_DKV_W4_ASM_BF16_DS : : KF_DKV_OPERANDS : KF_DKV_W4_CLOBBERS);
         else if constexpr (BF) asm volatile(KF_DKV_W4_ASM_BF16_NODS : : KF_DKV_OPERANDS : KF_DKV_W4_CLOBBERS);
         else if constexpr (DS) asm volatile(KF_DKV_W4_ASM_F16_DS : : KF_DKV_OPERANDS : KF_DKV_W4_CLOBBERS);
         else asm volatile(KF_DKV_W4_ASM_F16_NODS : : KF_DKV_OPERANDS : KF_DKV_W4_CLOBBERS);
 #undef KF_DKV_OPERANDS
+#undef KF_DKV_EXTRA
     }
 }
 
@@ -2644,6 +2652,10 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
     a.nbh = (int)(B * H);
     KF_REQUIRE(scale > 0.f && scale < INFINITY, KF_ERR_INVALID, "attention: the softmax scale must be positive and finite");
     a.scale = scale;
+#ifdef KF_DKV_W4_STAMPS
+    extern unsigned long long *kf_attn_tl_host_ptr();
+    a.dbg = kf_attn_tl_host_ptr();
+#endif
 #ifdef KF_MUTANT
     a.mutant = g_mutant;
 #endif

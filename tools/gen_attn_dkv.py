@@ -89,7 +89,8 @@ class Gen:
     # under all four (1.99 - 2.04 ms on that box), the dQ kernel that streams the dS back runs 3 - 4 % faster behind nt stores (0.95 - 0.97 vs 1.00 ms)
     store_policy = "nt"
 
-    def __init__(self, f16=False, mutant=False, ds=True, ablate=()):
+    def __init__(self, f16=False, mutant=False, ds=True, ablate=(), stamps=False):
+        self.stamps = stamps   # diagnostic build (tools/attn_dkv_w4_timeline.py, -DKF_DKV_W4_STAMPS): s_memtime sums per wave and block pass
         self.mfma = "v_mfma_f32_32x32x16_f16" if f16 else "v_mfma_f32_32x32x16_bf16"
         self.cvt = "v_cvt_pk_f16_f32" if f16 else "v_cvt_pk_bf16_f32"
         self.f16, self.mutant, self.ds, self.ablate = f16, mutant, ds, set(ablate)
@@ -100,6 +101,25 @@ class Gen:
     def label(self, n): self.out.append(Ins(f"{n}:", "label"))
     def salu(self, t): self.out.append(Ins(t, "salu"))
     def valu(self, t, reads=(), writes=(), trans=False): self.out.append(Ins(t, "trans" if trans else "valu", reads, writes))
+
+    def stamp_take(self):
+        """Diagnostic build: request the clock; the value is used by stamp_add() BEHIND a wait the stream has anyway (the slice barrier's
+        lgkmcnt(0)), so the stamps do not drain the LDS reads in flight - the schedule measured is the product's."""
+        if self.stamps: self.salu("s_memtime s[80:81]")
+
+    def stamp_add(self, bucket):
+        if not self.stamps: return
+        self.salu("s_sub_u32 s83, s80, s82")
+        self.salu(f"s_add_u32 s{84 + bucket}, s{84 + bucket}, s83")
+        self.salu("s_mov_b32 s82, s80")
+
+    def stamp(self, bucket):
+        """A whole stamp where nothing is in flight (prologue, epilogue): buckets 0 block start -> head reads, 1 steady / 2 diag1 / 3 diag0 /
+        4 idle slices (barrier to barrier, booked one slice late), 5 last booked barrier -> epilogue, 6 epilogue, 7 the number of steady slices."""
+        if not self.stamps: return
+        self.stamp_take()
+        self.out.append(Ins("s_waitcnt lgkmcnt(0)", "wait", tag="lgkm"))
+        self.stamp_add(bucket)
 
     def mm(self, d, dn, a, b, c=None, tag="", acc="v"):
         """D = A B + C on registers: d first of 16 (VGPR or AGPR by `acc`), a / b first of 4 VGPRs, C = D unless `c` names another tuple."""
@@ -249,6 +269,14 @@ class Gen:
                 # read of the current buffer has returned; then everyone's
                 self.out.append(Ins(f"s_waitcnt vmcnt({prev_stores}) lgkmcnt(0)", "wait", tag="vmlgkm"))
                 self.barrier()
+                # diagnostic build: the clock requested behind the PREVIOUS barrier has long returned (the wait above covers it): the period
+                # that ended there is booked now - one slice late, so a kind's bucket holds its predecessor's period at every change of
+                # kind (4 per pass) - and the next request goes out; nothing waits for it and no LDS read is drained for it (a counted
+                # wait behind it can only be stricter by one).
+                self.stamp_add({"steady": 1, "drop": 1, "diag1": 2, "diag0": 3, "idle": 4}[kind])
+                self.stamp_take()
+                if self.stamps and kind == "steady":
+                    self.salu("s_add_u32 s91, s91, 1")
             ksb, i = j >> 3, j & 7
             if slot < 2:
                 ksb, i = CHAIN_ORDER[j]
@@ -274,6 +302,12 @@ class Gen:
     # -------------------------------------------------------------- block pass
     def prologue(self):
         e = self
+        if self.stamps:
+            for i in range(84, 92):
+                e.salu(f"s_mov_b32 s{i}, 0")
+            e.salu("s_memtime s[80:81]")
+            e.salu("s_waitcnt lgkmcnt(0)")
+            e.salu("s_mov_b32 s82, s80")
         ins = [("qp", Q_SRD), ("dop", DO_SRD), ("cp", C_SRD)]
         for nm, srd in ins:
             e.salu(f"s_mov_b64 {sr(srd, 2)}, %[{nm}]")
@@ -423,6 +457,7 @@ class Gen:
         # ---- slice s0 has landed for everyone (slice s0 + 1's 5 pieces may still be in flight); the first slice's head state
         e.out.append(Ins("s_waitcnt vmcnt(5)", "wait", tag="vm"))
         e.barrier()
+        self.stamp(0)
         # (in the ORDER every slice's tail issues them: the loop's counted waits assume it)
         for g in range(4):
             e.lds_const(S(0), g, 0)
@@ -455,6 +490,7 @@ class Gen:
         lane, r, h = T[0], T[1], T[2]
         e.label("L_epilogue_%=")
         e.out.append(Ins("s_waitcnt vmcnt(0) lgkmcnt(0)", "wait", tag="vmlgkm"))
+        self.stamp(5)
         e.salu("s_nop 15")
         e.valu(f"v_mbcnt_lo_u32_b32 {vr(lane)}, -1, 0")
         e.valu(f"v_mbcnt_hi_u32_b32 {vr(lane)}, -1, {vr(lane)}")
@@ -500,6 +536,18 @@ class Gen:
                         e.out.append(Ins(f"buffer_store_dwordx4 {vr(32 + 4 * i, 4)}, {vr(oo)}, {sr(O_SRD, 4)}, {sr(S_X0)} offen", "vmem"))
                         e.salu(f"s_add_u32 {sr(S_X0)}, {sr(S_X0)}, {sr(S_X1)}")
             e.out.append(Ins("s_waitcnt vmcnt(0)", "wait", tag="vm"))   # (the SRD base changes for the second tensor; and the slab is rewritten)
+        if self.stamps:
+            self.stamp(6)
+            e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 5")                  # 8 dwords per wave
+            e.salu(f"s_add_u32 {sr(S_TMP)}, {sr(S_TMP)}, %[dbgoff]")
+            e.valu(f"v_mov_b32 {vr(T[0])}, {sr(S_TMP)}")
+            for i in range(8):
+                e.valu(f"v_mov_b32 {vr(32 + i)}, s{84 + i}")
+            e.salu("s_mov_b64 exec, 1")
+            e.out.append(Ins(f"global_store_dwordx4 {vr(T[0])}, {vr(32, 4)}, %[dbg]", "vmem"))
+            e.out.append(Ins(f"global_store_dwordx4 {vr(T[0])}, {vr(36, 4)}, %[dbg] offset:16", "vmem"))
+            e.salu("s_mov_b64 exec, -1")
+            e.out.append(Ins("s_waitcnt vmcnt(0)", "wait", tag="vm"))
         e.barrier()   # the next block's DMA reuses the slice buffers: every wave is past its last reads (they are, since the last slice's barrier) - kept for the vmcnt bookkeeping of the prologue
 
     def build(self):
@@ -675,11 +723,12 @@ def main():
     ap.add_argument("--ablate", default="")
     ap.add_argument("--dump", default="", help="print one variant's stream")
     ap.add_argument("--store-policy", default=Gen.store_policy, help="cache bits of the dS stores (experiment)")
+    ap.add_argument("--stamps", action="store_true", help="diagnostic build: s_memtime sums per slice kind, prologue, epilogue (needs -DKF_DKV_W4_STAMPS)")
     args = ap.parse_args()
     abl = tuple(x for x in args.ablate.split(",") if x)
     Gen.store_policy = args.store_policy
     assert selftest()
-    g = Gen(False, ablate=abl).build()
+    g = Gen(False, ablate=abl, stamps=args.stamps).build()
     probs = check(g.out)
     for p in probs[:40]:
         print("HAZARD:", p, file=sys.stderr)
@@ -698,7 +747,7 @@ def main():
     for f16 in (False, True):
         for mut in (False, True):
             for ds in (True, False):
-                gg = Gen(f16, mut, ds, ablate=abl).build()
+                gg = Gen(f16, mut, ds, ablate=abl, stamps=args.stamps).build()
                 assert abl or not check(gg.out), check(gg.out)[:5]
                 texts[(f16, mut, ds)] = render(gg.out).replace(chr(10), " " + chr(92) + chr(10))
     n_ins = sum(1 for i in g.out if i.kind not in ("raw", "label", "nomfma"))
@@ -710,7 +759,7 @@ def main():
 // one wave per SIMD, all 512 registers asm-owned; see the generator's header for the structure.
 #pragma once
 #define KF_DKV_W4_LDS_BYTES {LDS_BYTES}
-#define KF_DKV_W4_CLOBBERS {", ".join('"' + c + '"' for c in CLOBBERS)}
+#define KF_DKV_W4_CLOBBERS {", ".join('"' + c + '"' for c in CLOBBERS + ([f"s{i}" for i in range(80, 92)] if args.stamps else []))}
 #ifdef KF_MUTANT
 {four(True)}
 #else
