@@ -339,8 +339,6 @@ class Gen:
         e.salu(f"s_mul_i32 {sr(S_DOMAX)}, {sr(S_TMP)}, {sr(S_DOSTEP)}")
         e.salu(f"s_add_u32 {sr(S_DOMAX)}, {sr(S_DOMAX)}, {sr(S_X1)}")
         e.salu(f"s_lshl_b32 {sr(S_CMAX)}, {sr(S_TMP)}, 7")
-        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 11")
-        e.salu(f"s_add_u32 {sr(S_M0)}, {sr(S_LDS)}, {sr(S_TMP)}")               # DMA destination of this wave's row group in buffer 0
         e.salu(f"s_mul_i32 {sr(S_TMP)}, {sr(S_WID)}, {64 * STAGE_ROW}")
         e.salu(f"s_add_u32 {sr(S_STAGE)}, {sr(S_LDS)}, {STAGE0}")
         e.salu(f"s_add_u32 {sr(S_STAGE)}, {sr(S_STAGE)}, {sr(S_TMP)}")
@@ -351,22 +349,42 @@ class Gen:
         e.valu(f"v_mbcnt_hi_u32_b32 {vr(lane)}, -1, {vr(lane)}")
         e.valu(f"v_and_b32 {vr(r)}, 31, {vr(lane)}")
         e.valu(f"v_lshrrev_b32 {vr(h)}, 5, {vr(lane)}")
-        # ---- first of all this wave's K and V fragments (their latency runs under everything else of the prologue): key kw + 32 ksb + r,
-        #      k = 16 kk + 8 h ..; K through O_SRD, V through a descriptor of its own
-        e.valu(f"v_mul_lo_u32 {vr(t0)}, {vr(r)}, %[kvsr]")
-        e.valu(f"v_lshl_add_u32 {vr(t0)}, {vr(h)}, 4, {vr(t0)}")
+        # ---- first of all this wave's K and V tiles (64 keys = two 32-row tiles each) by LDS-DMA: K into the wave's quarter of the slice
+        #      ring (free until the first slices are requested), V into its quarter of the staging slab (free until the epilogue). The
+        #      fragments are then row reads of those tiles. (Round 4, first form: 32 buffer_load_dwordx4 per wave straight into the fragment
+        #      registers - a lane's 16 bytes of a 256-byte row each, 64 separate requests per instruction: 8192 requests per workgroup kept
+        #      the CU's address unit busy for most of the 12 k cycles tools/attn_dkv_w4_timeline.py showed before the first slice; a DMA piece
+        #      is 1 KiB of consecutive lanes.)
+        kve, kvo = S(0, 0), S(0, 1)     # source offsets of a piece, even / odd row group (the score registers are idle until the head reads)
+        e.valu(f"v_bfe_u32 {vr(t0)}, {vr(lane)}, 2, 3")                        # row7
+        e.valu(f"v_mul_lo_u32 {vr(t0)}, {vr(t0)}, %[kvsr]")
+        e.valu(f"v_lshl_add_u32 {vr(t0)}, {vr(h)}, 6, {vr(t0)}")               # + 64 sub32
+        e.valu(f"v_and_b32 {vr(t1)}, 3, {vr(lane)}")
+        e.valu(f"v_bfe_u32 {vr(t2)}, {vr(lane)}, 4, 1")
+        e.valu(f"v_xor_b32 {vr(t1)}, {vr(t1)}, {vr(t2)}")                       # slot ^ b4
+        e.valu(f"v_lshl_add_u32 {vr(kve)}, {vr(t1)}, 4, {vr(t0)}")
+        e.valu(f"v_xor_b32 {vr(t1)}, 2, {vr(t1)}")
+        e.valu(f"v_lshl_add_u32 {vr(kvo)}, {vr(t1)}, 4, {vr(t0)}")
         e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 6")
-        e.salu(f"s_mul_i32 {sr(S_X0)}, {sr(S_TMP)}, %[kvsr]")
-        e.salu(f"s_lshl_b32 {sr(S_TMP)}, %[kvsr], 5")
-        e.salu(f"s_add_u32 {sr(S_X1)}, {sr(S_X0)}, {sr(S_TMP)}")
+        e.salu(f"s_mul_i32 {sr(S_X0)}, {sr(S_TMP)}, %[kvsr]")                   # this wave's first key row, bytes
+        e.salu(f"s_lshl_b32 {sr(S_X1)}, %[kvsr], 3")                            # 8 rows further
         e.salu(f"s_mov_b64 {sr(O_SRD, 2)}, %[kp]")
         e.salu(f"s_mov_b64 {sr(V_SRD, 2)}, %[vp]")
         e.salu(f"s_mov_b32 {sr(V_SRD + 2)}, 0xffffffff")
         e.salu(f"s_mov_b32 {sr(V_SRD + 3)}, 0x00020000")
-        for srd, fr in ((O_SRD, KFR), (V_SRD, VFR)):
-            for ksb in range(2):
-                for kk in range(8):
-                    e.out.append(Ins(f"buffer_load_dwordx4 {vr(fr(ksb, kk), 4)}, {vr(t0)}, {sr(srd, 4)}, {sr(S_X0 + ksb)} offen offset:{32 * kk}", "vmem"))
+        e.salu(f"s_lshl_b32 {sr(S_TMP2)}, {sr(S_WID)}, 14")                     # 16 KiB per wave
+        e.salu(f"s_add_u32 {sr(S_M0)}, {sr(S_LDS)}, {sr(S_TMP2)}")
+        for srd, base in ((O_SRD, 0), (V_SRD, STAGE0)):
+            e.salu(f"s_mov_b32 {sr(S_TMP)}, {sr(S_X0)}")
+            for g in range(8):                                                     # row groups 0..7 of the wave's 64 keys
+                for half in range(2):
+                    e.salu(f"s_add_u32 m0, {sr(S_M0)}, {base + 2048 * g + 1024 * half - 128 * half}")
+                    e.salu("s_nop 0")
+                    o = " offset:128" if half else ""
+                    e.out.append(Ins(f"buffer_load_dwordx4 {vr(kvo if g & 1 else kve)}, {sr(srd, 4)}, {sr(S_TMP)} offen{o} lds", "dma", V(kvo if g & 1 else kve)))
+                e.salu(f"s_add_u32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_X1)}")
+        for i in range(8):
+            e.valu(f"v_mov_b32 {vr(S(0, 8) + i)}, 0")                            # (operands of the accumulator-clearing MFMAs below)
         e.valu(f"v_lshlrev_b32 {vr(t0)}, 2, {vr(h)}")
         e.valu(f"v_sub_u32 {vr(RM)}, {vr(r)}, {vr(t0)}")                        # r - 4 h
         # row-read bases of a 32-row tile: 2048 (r >> 3) + 64 (r & 7) + 16 (h ^ ((r >> 2) & 3))
@@ -414,18 +432,40 @@ class Gen:
         # dS store: lane (key r, half h) writes its 16 bytes at 32 r + 16 h of a 1-KiB operand
         e.valu(f"v_lshlrev_b32 {vr(DSOFF)}, 5, {vr(r)}")
         e.valu(f"v_lshl_add_u32 {vr(DSOFF)}, {vr(h)}, 4, {vr(DSOFF)}")
-        # ---- the first two slices on their way
+        # dV = dK = 0: sixteen MFMAs of zero operands (0 * 0 + 0 into 16 accumulator registers each) instead of 256 v_accvgpr_write - 16 issue
+        # slots, the matrix pipe does the rest while this wave computes on
+        for i in range(16):
+            e.out.append(Ins(f"{self.mfma} {ar(16 * i, 16)}, {vr(S(0, 8), 4)}, {vr(S(0, 12), 4)}, 0", "mfma", V(S(0, 8), 4) + V(S(0, 12), 4), A(16 * i, 16), tag="zero"))
+        # ---- the fragments: K (k = 16 kk + 8 h .. of key 32 ksb + r) as soon as this wave's 16 K pieces have landed, then V. In-order counter:
+        #      the pieces are this wave's own, nobody else reads or writes its quarters: no barrier in front of the reads
+        rbk = (S(0, 2), S(0, 3))
+        e.salu(f"s_lshl_b32 {sr(S_TMP2)}, {sr(S_WID)}, 14")
+        for i in range(2):
+            e.valu(f"v_add_u32 {vr(rbk[i])}, {sr(S_TMP2)}, {vr(RB[i])}")
+        e.out.append(Ins("s_waitcnt vmcnt(16)", "wait", tag="vm"))
+        for ksb in range(2):
+            for kk in range(8):
+                e.out.append(Ins(f"ds_read_b128 {vr(KFR(ksb, kk), 4)}, {vr(rbk[kk & 1])} offset:{8192 * ksb + 512 * (kk >> 1)}", "lds", V(rbk[kk & 1]), V(KFR(ksb, kk), 4)))
+        e.salu(f"s_add_u32 {sr(S_TMP2)}, {sr(S_TMP2)}, {STAGE0}")
+        rbv = (S(0, 4), S(0, 5))
+        for i in range(2):
+            e.valu(f"v_add_u32 {vr(rbv[i])}, {sr(S_TMP2)}, {vr(RB[i])}")
+        e.out.append(Ins("s_waitcnt vmcnt(0)", "wait", tag="vm"))
+        for ksb in range(2):
+            for kk in range(8):
+                e.out.append(Ins(f"ds_read_b128 {vr(VFR(ksb, kk), 4)}, {vr(rbv[kk & 1])} offset:{8192 * ksb + 512 * (kk >> 1)}", "lds", V(rbv[kk & 1]), V(VFR(ksb, kk), 4)))
+        e.out.append(Ins("s_waitcnt lgkmcnt(0)", "wait", tag="lgkm"))
+        e.barrier()     # every wave has its K fragments out of the ring
+        # ---- the first two slices on their way (their flight runs under the scaling of K below)
+        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 11")
+        e.salu(f"s_add_u32 {sr(S_M0)}, {sr(S_LDS)}, {sr(S_TMP)}")               # DMA destination of this wave's row group in buffer 0
         e.dma_slice()
         e.salu(f"s_xor_b32 {sr(S_M0)}, {sr(S_M0)}, {BUF}")
         e.advance_dma()
         e.dma_slice()
         e.salu(f"s_xor_b32 {sr(S_M0)}, {sr(S_M0)}, {BUF}")
         e.advance_dma()
-        for i in range(256):
-            e.valu(f"v_accvgpr_write_b32 {ar(i)}, 0")
-        # K *= scale log2(e): unpack the pair, two multiplies, pack (64 registers, once per block). In-order counter: the 32 K / V loads are
-        # older than the 10 DMA pieces behind them.
-        e.out.append(Ins("s_waitcnt vmcnt(10)", "wait", tag="vm"))
+        # K *= scale log2(e): unpack the pair, two multiplies, pack (64 registers, once per block)
         e.valu(f"v_mov_b32 {vr(t2)}, 0x3fb8aa3b")
         e.valu(f"v_mul_f32 {vr(t2)}, {sr(S_SCALE)}, {vr(t2)}")
         for i in range(64):
@@ -535,7 +575,8 @@ class Gen:
                     for i in range(8):
                         e.out.append(Ins(f"buffer_store_dwordx4 {vr(32 + 4 * i, 4)}, {vr(oo)}, {sr(O_SRD, 4)}, {sr(S_X0)} offen", "vmem"))
                         e.salu(f"s_add_u32 {sr(S_X0)}, {sr(S_X0)}, {sr(S_X1)}")
-            e.out.append(Ins("s_waitcnt vmcnt(0)", "wait", tag="vm"))   # (the SRD base changes for the second tensor; and the slab is rewritten)
+            # (no wait for the stores: their registers and the descriptor were read at issue, the slab is rewritten behind the lgkmcnt(0)
+            #  above; they drain under the second tensor's conversion and the next pass's prologue, whose counted waits they only make stricter)
         if self.stamps:
             self.stamp(6)
             e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 5")                  # 8 dwords per wave
