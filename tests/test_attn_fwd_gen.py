@@ -43,7 +43,7 @@ def test_dkv_generator_address_maps_hazards_and_freshness(tmp_path):
             for ds in (True, False):
                 g = G.Gen(f16, mut, ds).build()
                 assert G.check(g.out) == []
-                assert sum(1 for i in g.out if i.kind == "mfma") == 64 + 64 + 32 + (64 if mut else 0)   # steady, diag1, diag0 (one sub-block), drop
+                assert sum(1 for i in g.out if i.kind == "mfma") == 16 + 64 + 64 + 32 + (64 if mut else 0)   # accumulator clearing, steady, diag1, diag0 (one sub-block), drop
                 stores = sum(1 for i in g.out if "global_store_dwordx4" in i.text)
                 assert stores == ((4 + 4 + 2 + (4 if mut else 0)) if ds else 0)
     out = tmp_path / "dkv.inc"
