@@ -472,17 +472,30 @@ class Gen:
         e.valu(f"v_lshl_add_u32 {vr(DMA[0])}, {vr(t1)}, 4, {vr(t0)}")
         e.valu(f"v_xor_b32 {vr(t1)}, 2, {vr(t1)}")
         e.valu(f"v_lshl_add_u32 {vr(DMA[1])}, {vr(t1)}, 4, {vr(t0)}")
-        # ---- Q fragments first (the first MFMA needs them and K(0)): query 64 w + 32 b + r, k = 16 kk + 8 h .. + 7  ->  a[128 ..]
-        e.valu(f"v_mul_lo_u32 {vr(t3)}, {vr(r)}, {sr(S_QSR)}")
-        e.valu(f"v_lshl_add_u32 {vr(t3)}, {vr(h)}, 4, {vr(t3)}")
+        # ---- Q first (the first MFMA needs it and K(0)): this wave's 64 query rows = two 32-row tiles by LDS-DMA into its quarter of the
+        #      staging slab (its own slab: idle from its epilogue's last read to its next one), 16 pieces of 1 KiB; the fragments (query 32 b + r, k = 16 kk + 8 h ..) are then row
+        #      reads of those tiles. (First form: 16 buffer_load_dwordx4 per wave straight into registers - a lane's 16 bytes of a 256-byte
+        #      row each, 64 separate requests per instruction and 4096 per workgroup through the CU's one address unit.)
+        qe, qo = T[8], T[9]
+        e.valu(f"v_bfe_u32 {vr(t0)}, {vr(lane)}, 2, 3")
+        e.valu(f"v_mul_lo_u32 {vr(t0)}, {vr(t0)}, {sr(S_QSR)}")
+        e.valu(f"v_lshl_add_u32 {vr(t0)}, {vr(h)}, 6, {vr(t0)}")
+        e.valu(f"v_and_b32 {vr(t1)}, 3, {vr(lane)}")
+        e.valu(f"v_bfe_u32 {vr(t2)}, {vr(lane)}, 4, 1")
+        e.valu(f"v_xor_b32 {vr(t1)}, {vr(t1)}, {vr(t2)}")
+        e.valu(f"v_lshl_add_u32 {vr(qe)}, {vr(t1)}, 4, {vr(t0)}")
+        e.valu(f"v_xor_b32 {vr(t1)}, 2, {vr(t1)}")
+        e.valu(f"v_lshl_add_u32 {vr(qo)}, {vr(t1)}, 4, {vr(t0)}")
         e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 6")
-        e.salu(f"s_mul_i32 {sr(S_X0)}, {sr(S_TMP)}, {sr(S_QSR)}")
-        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_QSR)}, 5")
-        e.salu(f"s_add_u32 {sr(S_X1)}, {sr(S_X0)}, {sr(S_TMP)}")
-        # (into the score registers: they are scaled by scale log2(e) below, once per pass, and only then become the B operands in a[128:191])
-        for b in range(2):
-            for kk in range(8):
-                e.out.append(Ins(f"buffer_load_dwordx4 {vr(QF(b, kk) - 128, 4)}, {vr(t3)}, {sr(Q_SRD, 4)}, {sr(S_X0 + b)} offen offset:{32 * kk}", "vmem", V(t3), V(QF(b, kk) - 128, 4)))
+        e.salu(f"s_mul_i32 {sr(S_X0)}, {sr(S_TMP)}, {sr(S_QSR)}")                # this wave's first query row, bytes
+        e.salu(f"s_lshl_b32 {sr(S_X1)}, {sr(S_QSR)}, 3")                         # 8 rows further
+        for g in range(8):                                                         # (into the wave's OWN slab, S_STAGE: a wave that is early must not write where a late one still reads its O rows)
+            for half in range(2):
+                e.salu(f"s_add_u32 m0, {sr(S_STAGE)}, {2048 * g + 1024 * half - 128 * half}")
+                e.salu("s_nop 0")
+                o = " offset:128" if half else ""
+                e.out.append(Ins(f"buffer_load_dwordx4 {vr(qo if g & 1 else qe)}, {sr(Q_SRD, 4)}, {sr(S_X0)} offen{o} lds", "dma", V(qo if g & 1 else qe)))
+            e.salu(f"s_add_u32 {sr(S_X0)}, {sr(S_X0)}, {sr(S_X1)}")
         # ---- tile 0 of K into slot 0
         e.raw("; ---- K(0) -> slot 0; then K(1) -> slot 1 and V(0) -> slot 0")
         e.salu(f"s_mov_b32 {sr(S_KOFF0)}, {sr(S_RB0)}")
@@ -518,7 +531,15 @@ class Gen:
             e.valu(f"v_mov_b32 {vr(LA[b])}, 0")
             e.valu(f"v_mov_b32 {vr(LB[b])}, 0")
         # ---- Q *= scale log2(e), rounded to the element type once: the score MFMAs then deliver exponents (no multiply per score in the tile loop)
-        e.wait(vm=12)     # in-order counter: the 16 Q loads are older than the 12 DMA pieces
+        e.wait(vm=12)     # in-order counter: this wave's 16 Q pieces are older than its 12 K / V pieces; the quarter is its own: no barrier
+        qb = (T[10], T[11])
+        e.salu(f"s_sub_u32 {sr(S_TMP)}, {sr(S_STAGE)}, {sr(S_LDS)}")           # (S_TMP2 holds 8 key rows' bytes from here to the end of the loop)
+        for i in range(2):
+            e.valu(f"v_add_u32 {vr(qb[i])}, {sr(S_TMP)}, {vr(KB[i])}")           # (the K bases sit at slot 0 here: S_LDS + the lane's row / chunk)
+        for b in range(2):
+            for kk in range(8):
+                e.out.append(Ins(f"ds_read_b128 {vr(QF(b, kk) - 128, 4)}, {vr(qb[kk & 1])} offset:{8192 * b + 512 * (kk >> 1)}", "lds", V(qb[kk & 1]), V(QF(b, kk) - 128, 4)))
+        e.wait(lgkm=0)
         if self.f16:
             c2 = T[8]
             e.valu(f"v_cvt_f16_f32 {vr(c2)}, {sr(S_C)}")
