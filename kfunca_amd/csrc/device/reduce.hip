@@ -308,7 +308,11 @@ __global__ __launch_bounds__(kRB) void reduce_outer_tall_kernel(const RedArgs a,
     using X = typename Ops::X;
     __shared__ A smem[16][17];
     const int lx = threadIdx.x & 15, ly = threadIdx.x >> 4;
-    const int64_t c = (int64_t)blockIdx.x * 16 + lx;
+    // 16 columns of a 4-byte type are HALF a 128-byte line: the block with the other half must sit on the same XCD (block ids are dealt
+    // round-robin over the 8 XCDs, each with its own L2), or every line is fetched twice (rocprofv3, C1 sum(0): 2.01x the algorithmic bytes).
+    // Ids b and b + 8 share an XCD: they take neighbouring column groups.
+    const unsigned nb = gridDim.x, cb = (nb % 8 == 0) ? (blockIdx.x & 7u) * (nb >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int64_t c = (int64_t)cb * 16 + lx;
     const bool live = c < a.C;
     for (uint32_t z = blockIdx.z; z < a.nouter; z += gridDim.z) {
         uint32_t off[3];
