@@ -118,3 +118,34 @@ def test_rejects_a_leaky_mask_a_stale_maximum_and_zeros(case):
     o, _ = O.attn_fwd(c["q"], c["k"], c["v"], code=code)
     with pytest.raises(AssertionError):
         K.check_one("o", K.to_f64(o, code).astype(np.float16), c["ref"], O.F16)
+
+
+def test_lse_bound_of_the_scaled_query_forward():
+    """The round-4 forward rounds c * q (c = scale * log2 e) to the element type once per query block, so its score MFMAs deliver exponents.
+    oracle.checks.lse_scaled_query_bound is the rigorous price of that one rounding: it must hold for a simulation of exactly that
+    arithmetic (uniform, normal and spiked operands, both 16-bit types), and attn_check must still reject an lse that is off by a dropped
+    key tile or by 2 % - the bound widens the tolerance by what the rounding can do, no further."""
+    rng = np.random.default_rng(11)
+    Sq = 512
+    c = np.log2(np.e) / np.sqrt(D)
+    for code in (O.BF16, O.F16):
+        for dist in ("uniform", "normal", "spiked"):
+            draw = {"uniform": lambda s: rng.uniform(-1, 1, s), "normal": lambda s: rng.standard_normal(s),
+                    "spiked": lambda s: rng.uniform(-1, 1, s) * (1 + 15 * (rng.random(s) < 0.02))}[dist]
+            q, k, v = (O.from_float(draw((1, 1, Sq, D)).astype(np.float32), code) for _ in range(3))
+            qf, kf = K.to_f64(q, code)[0, 0], K.to_f64(k, code)[0, 0]
+            s2 = rnd(qf * c, code) @ kf.T                                   # exponents as the kernel forms them (f32 accumulation is far below this)
+            s2 = np.where(np.arange(Sq)[None, :] <= np.arange(Sq)[:, None], s2, -np.inf)
+            m = s2.max(axis=1)
+            lse = ((m + np.log2(np.exp2(s2 - m[:, None]).sum(axis=1))) * np.log(2.0)).astype(np.float32)[None, None]
+            out = K.attn_check(q, k, v, code, lse=lse, what=f"{dist} lse", scaled_query=True)
+            assert 0 < out["lse"]["fraction_of_bound"] < 1.0, (dist, out)
+            with pytest.raises(AssertionError):                             # the kernels that keep q as it is are still held to 2e-6
+                K.attn_check(q, k, v, code, lse=lse, what="unscaled bar", scaled_query=False)
+            if dist == "uniform":
+                s3 = s2.copy()
+                s3[Sq - 256:, 64:128] = -np.inf                             # the last block drops key tile 1
+                bad = ((m + np.log2(np.exp2(s3 - m[:, None]).sum(axis=1))) * np.log(2.0)).astype(np.float32)[None, None]
+                for wrong in (bad, lse * np.float32(1.02)):
+                    with pytest.raises(AssertionError):
+                        K.attn_check(q, k, v, code, lse=wrong, what="wrong lse", scaled_query=True)

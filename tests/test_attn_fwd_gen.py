@@ -50,3 +50,26 @@ def test_dkv_generator_address_maps_hazards_and_freshness(tmp_path):
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "gen_attn_dkv.py"), "--out", str(out)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert out.read_text() == (ROOT / "kfunca_amd" / "csrc" / "device" / "attn_dkv_w4.inc").read_text(), "run tools/gen_attn_dkv.py"
+
+
+def test_checkers_reject_a_transcendental_read_one_wait_state_later():
+    """gfx950 does not interlock a transcendental's result against a reader one wait state behind it (measured round 4: `v_exp; s_nop 0;
+    v_add` left the old value in the lanes with (lane & 4) == 0). Both generators' checkers must flag an adjacent consumer and the
+    `s_nop 0` form, and accept two wait states or a real instruction in between; the forward's stream, built WITHOUT its repair pass,
+    must trip the rule (the drain iteration has gaps without MFMAs)."""
+    import gen_attn_dkv as D
+    import gen_attn_fwd as G
+    Ins, V = G.Ins, G.V
+    exp = lambda: Ins("v_exp_f32 v1, v1", "trans", V(1), V(1))       # noqa: E731
+    use = lambda: Ins("v_add_f32 v2, v2, v1", "valu", V(2) + V(1), V(2))  # noqa: E731
+    other = lambda: Ins("v_mov_b32 v3, v4", "valu", V(4), V(3))      # noqa: E731
+    nop = lambda n: Ins(f"s_nop {n}", "salu")                        # noqa: E731
+    for mod, label in ((G, "L_steady_%=:"), (D, "L_steady_%=:")):
+        body = lambda mid: [Ins(label, "label"), exp()] + mid + [use(), Ins("L_epilogue_%=:", "label")]  # noqa: E731
+        assert any("transcendental" in p for p in mod.check(body([])))
+        assert any("transcendental" in p for p in mod.check(body([nop(0)])))
+        assert not any("transcendental" in p for p in mod.check(body([nop(1)])))
+        assert not any("transcendental" in p for p in mod.check(body([other()])))
+    g = G.Gen()
+    g.fix_trans_use = lambda: None
+    assert any("transcendental" in p for p in G.check(g.build().out))

@@ -674,11 +674,15 @@ def check(ins):
         seq = [x for x in body if x.kind not in ("raw", "label", "nomfma")] * 2
         lm, lv = {}, {}
         n_mfma = n_ins = 0
-        prev = None
+        prev, tws = None, 0
         for x in seq:
-            if prev is not None and prev.kind == "trans" and x.kind in ("valu", "trans") and set(prev.writes) & set(x.reads):
-                problems.append(f"{name}: '{x.text}' reads the result of the transcendental right in front of it (no forwarding interlock on gfx950)")
-            prev = x
+            # a transcendental's result: >= 2 wait states (or any real instruction) before its reader - gfx950 does not interlock one (gen_attn_fwd.py)
+            if x.kind == "salu" and x.text.startswith("s_nop") and prev is not None:
+                tws += int(x.text.split()[1]) + 1
+            elif prev is not None and x.kind in ("valu", "trans") and set(prev.writes) & set(x.reads) and tws < 2:
+                problems.append(f"{name}: '{x.text}' reads the result of the transcendental '{prev.text}' {tws} wait state(s) behind it (needs 2)")
+            if not (x.kind == "salu" and x.text.startswith("s_nop")):
+                prev, tws = (x, 0) if x.kind == "trans" else (None, 0)
             n_ins += 1
             if x.kind == "mfma":
                 n_mfma += 1
