@@ -1741,7 +1741,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) 
         const char *kp = kh + k0 * a.lk.sr, *vp = vh + k0 * a.lv.sr;
         char *dkp = dkh + k0 * a.ldk.sr, *dvp = dvh + k0 * a.ldv.sr;
         const int s0 = (int)(k0 / BQS);                    // the first slice with a query that sees one of the block's keys
-        const int ns = ns_all > s0 ? ns_all : s0;          // (a block beyond the last query: no slices, zero gradients)
+        const int ns = ns_all;                             // (a block beyond the last query, s0 >= ns: no slices, zero gradients; the stream clamps its first requests to slice ns - 1)
         const char *dsp = DS ? a.ds + (((bh - a.bh0) * a.ds_nqb * a.ds_nkwb + (k0 >> 5)) * 8) * DS_TILE : nullptr;
         int mut = -1;
 #ifdef KF_MUTANT

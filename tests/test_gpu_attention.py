@@ -410,3 +410,21 @@ def test_backward_workspace_is_bounded_any_size_above_the_statistics_is_accepted
         capped = bwd(code, q, k, v, o, lse, go)
     for n, a0, a1 in zip(("dq", "dk", "dv"), ref, capped):
         assert np.array_equal(a0.view(np.uint16), a1.view(np.uint16)), n
+
+
+def test_key_blocks_beyond_the_last_query_touch_nothing_behind_the_tensors():
+    """Skv >> Sq: most 256-key blocks of the dK / dV pass have no query that sees them. Their gradients are zero, and the pass must not
+    fetch Q / dO / row-constant slices that lie behind the tensors' last row on their behalf (round 4: the first two slices a block
+    requests were not saturated for such blocks - 2 MiB behind a 64 KiB Q here; whether that faulted depended on what the allocator had
+    mapped next to it). Values against the oracle, zeros where no query reaches, for both dtypes, paired and unpaired schedules."""
+    for code in (H.BF16, H.F16):
+        for (B, Hh, Sq, Skv) in ((1, 1, 256, 8192), (1, 3, 512, 4096)):
+            rng = np.random.default_rng(Sq + Skv + code)
+            q, k, v, go = (O.from_float(rng.uniform(-1, 1, s).astype(np.float32), code)
+                           for s in ((B, Hh, Sq, 128), (B, Hh, Skv, 128), (B, Hh, Skv, 128), (B, Hh, Sq, 128)))
+            for nopair in (None, "1"):
+                with H.knobs(KF_ATTN_NO_PAIR=nopair):
+                    o, lse = fwd(code, q, k, v)
+                    dq, dk, dv = bwd(code, q, k, v, o, lse, go)
+                assert not dk[:, :, Sq:].any() and not dv[:, :, Sq:].any(), (code, Sq, Skv, nopair)
+            K.attn_check(q, k, v, code, o=o, lse=lse, d_o=go, dq=dq, dk=dk, dv=dv, what=f"keys beyond the queries {Sq}x{Skv}")

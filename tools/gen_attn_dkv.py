@@ -339,10 +339,16 @@ class Gen:
         e.salu(f"s_mul_i32 {sr(S_DOMAX)}, {sr(S_TMP)}, {sr(S_DOSTEP)}")
         e.salu(f"s_add_u32 {sr(S_DOMAX)}, {sr(S_DOMAX)}, {sr(S_X1)}")
         e.salu(f"s_lshl_b32 {sr(S_CMAX)}, {sr(S_TMP)}, 7")
+        # a key block beyond the last query (Skv > Sq) has no slice (%[ns] is the number of slices the QUERIES have): the two slices the
+        # prologue requests anyway must not lie behind the tensors' last row (they are fetched, never used) - the same saturation
+        # advance_dma applies from the second request on
+        for off, mx in ((S_QOFF, S_QMAX), (S_DOOFF, S_DOMAX), (S_COFF, S_CMAX)):
+            e.salu(f"s_min_u32 {sr(off)}, {sr(off)}, {sr(mx)}")
         e.salu(f"s_mul_i32 {sr(S_TMP)}, {sr(S_WID)}, {64 * STAGE_ROW}")
         e.salu(f"s_add_u32 {sr(S_STAGE)}, {sr(S_LDS)}, {STAGE0}")
         e.salu(f"s_add_u32 {sr(S_STAGE)}, {sr(S_STAGE)}, {sr(S_TMP)}")
-        e.salu(f"s_sub_u32 {sr(S_NS)}, {sr(S_NS)}, {sr(S_SL)}")                 # slices of this block from here on (>= 0 by the caller)
+        e.salu(f"s_sub_i32 {sr(S_NS)}, {sr(S_NS)}, {sr(S_SL)}")                 # slices of this block from here on; none for a key block beyond the last query (Skv > Sq)
+        e.salu(f"s_max_i32 {sr(S_NS)}, {sr(S_NS)}, 0")
         # ---- lane constants
         lane, r, h, t0, t1, t2 = T[0], T[1], T[2], T[3], T[4], T[5]
         e.valu(f"v_mbcnt_lo_u32_b32 {vr(lane)}, -1, 0")
