@@ -53,9 +53,10 @@ def test_dkv_generator_address_maps_hazards_and_freshness(tmp_path):
 
 
 def test_checkers_reject_a_transcendental_read_one_wait_state_later():
-    """gfx950 does not interlock a transcendental's result against a reader one wait state behind it (measured round 4: `v_exp; s_nop 0;
-    v_add` left the old value in the lanes with (lane & 4) == 0). Both generators' checkers must flag an adjacent consumer and the
-    `s_nop 0` form, and accept two wait states or a real instruction in between; the forward's stream, built WITHOUT its repair pass,
+    """gfx950 does not interlock a transcendental's result against the very next instruction (measured round 4, tools/scratch/trans_hazard.hip:
+    `v_exp; v_add` as neighbours leave the old value in the lanes with (lane & 4) == 0; one wait state is what the hardware needs). The
+    generators keep one in reserve: both checkers must flag an adjacent consumer and the `s_nop 0` form, and accept two wait states or a
+    real instruction in between; the forward's stream, built WITHOUT its repair pass,
     must trip the rule (the drain iteration has gaps without MFMAs)."""
     import gen_attn_dkv as D
     import gen_attn_fwd as G

@@ -714,12 +714,12 @@ class Gen:
         return self
 
     def fix_trans_use(self):
-        """gfx950 does not interlock a transcendental result against an instruction that reads it ONE wait state later (the
-        quarter-rate unit is still delivering lanes: measured round 4 - exp | s_nop 0 | add left the OLD value in the lanes with
-        (lane & 4) == 0; exp | s_nop 1 | add is clean, and so is any real instruction in between). Behind an MFMA the stream
-        never does that; where gaps hold no MFMA (drain, a first tile's empty slot, prologue, epilogue, the rare rescale) a
-        transcendental and its consumer can become neighbours: `s_nop 1` goes between them, and an `s_nop 0` that is all that
-        separates them is widened."""
+        """gfx950 does not interlock a transcendental result against the VERY NEXT instruction reading it: the lanes with
+        (lane & 4) == 0 get the old register value (tools/scratch/trans_hazard.hip, profiles/r04_trans_hazard.txt). One wait state
+        is what the hardware needs (LLVM's hasTransForwardingHazard; hipcc inserts it for compiled code, never inside inline asm).
+        Behind an MFMA the stream never has the two as neighbours; where gaps hold no MFMA (drain, a first tile's empty slot,
+        prologue, epilogue, the rare rescale) they can be: `s_nop 1` (one more than needed) goes between them, and an `s_nop 0`
+        that is all that separates them is widened."""
         out, prev, sep = [], None, 0
         for x in self.out:
             if x.kind in ("raw", "label", "nomfma"):
