@@ -19,6 +19,8 @@ The constants are >= 2x the largest figures measured on MI355X over the shapes o
 (profiles/r03_attn_parity_margins.json); tests/test_attention_bounds.py shows on CPU that the same bounds reject a dropped tile, a
 zeroed slice, a wrong mask row and an all-zero gradient, tests/test_gpu_attention_mutants.py does so on the kernels themselves.
 """
+import os
+
 import numpy as np
 
 from . import oracle as O
@@ -73,7 +75,7 @@ def check_one(name, got16, ref, code, what="", rows=None):
 
 def lse_scaled_query_bound(q, k, code):
     """Worst-case |delta lse| when the kernel rounds c * q (c = scale * log2 e) to the element type ONCE per query block and lets
-    the score MFMAs deliver exponents (the round-4 forward, D = 128): every product q_i k_i of a score moves by at most
+    the score MFMAs deliver exponents (the opt-in scaled-operand form of the round-4 forward, KF_ATTN_SCALED_OPERANDS): every product q_i k_i of a score moves by at most
     eps |q_i k_i|, a score by eps * scale * sum_i |q_i k_i|, and lse - a p-weighted mean of the scores - by no more than the
     worst visible score of its row. [B, H, Sq] (natural-log units, like lse)."""
     qa, ka = np.abs(to_f64(q, code)), np.abs(to_f64(k, code))
@@ -91,8 +93,8 @@ def lse_scaled_query_bound(q, k, code):
 def attn_check(q, k, v, code, o=None, lse=None, d_o=None, dq=None, dk=None, dv=None, what="", ref=None, lse_tol=None, scaled_query=None):
     """Check whatever outputs are given (16-bit arrays [B,H,S,D]; lse f32 [B,H,Sq]) of causal attention on the 16-bit inputs q, k, v
     (and d_o for the gradients). Returns {name: margins}. `ref` = a precomputed oracle.attn_ref64 result. `scaled_query`: the forward
-    that produced `lse` is the one that rounds c * q to the element type (None: decided from the shape exactly as kf_attn_fwd
-    dispatches - D = 128, Sq % 256 == 0, Skv >= Sq; pass False under KF_ATTN_FWD_V3)."""
+    that produced `lse` is the one that rounds c * q to the element type (None: KF_ATTN_SCALED_OPERANDS is set and the shape is one
+    kf_attn_fwd gives that stream - D = 128, Sq % 256 == 0, Skv >= Sq)."""
     if ref is None:
         ref = O.attn_ref64(q, k, v, d_o if (dq is not None or dk is not None or dv is not None) else None, code=code)
     out = {}
@@ -101,13 +103,13 @@ def attn_check(q, k, v, code, o=None, lse=None, d_o=None, dq=None, dk=None, dv=N
             out[name] = check_one(name, got, ref, code, what)
     if lse is not None:
         # LSE is f32 out. The kernels that keep q as it is: the f32 score chain's error + the exp2 / log arithmetic, 2e-6 (1 + |lse|)
-        # (measured 1.7e-7). The forward that scales q in 16 bits: + the rigorous bound of that one rounding per row (measured on
+        # (measured 1.7e-7; the default). The opt-in forward that scales q in 16 bits: + the rigorous bound of that one rounding per row (measured on
         # MI355X: <= 0.1 of it on U(-1, 1) operands, where the roundings of a score's 128 products average out, up to 0.5 on
         # spiked operands where one product carries the score; `fraction_of_bound` in the returned record).
         tol = (lse_tol if lse_tol is not None else 2e-6) * (1.0 + np.abs(ref["lse"]))
         d = np.abs(lse.astype(np.float64) - ref["lse"])
-        if scaled_query is None:
-            scaled_query = q.shape[-1] == 128 and q.shape[2] % 256 == 0 and k.shape[2] >= q.shape[2]
+        if scaled_query is None:   # the opt-in form of the generated forward (KF_ATTN_SCALED_OPERANDS), on the shapes kf_attn_fwd gives it
+            scaled_query = bool(os.environ.get("KF_ATTN_SCALED_OPERANDS")) and q.shape[-1] == 128 and q.shape[2] % 256 == 0 and k.shape[2] >= q.shape[2]
         if scaled_query and lse_tol is None:
             tol = tol + lse_scaled_query_bound(q, k, code)
         assert np.isfinite(lse).all() and (d <= tol).all(), f"{what} lse: max error {d.max():.3e}"

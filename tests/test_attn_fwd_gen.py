@@ -18,11 +18,14 @@ def test_address_maps_and_hazard_distances():
     assert G.selftest()
     for f16 in (False, True):
         for mut in (False, True):
-            g = G.Gen(f16, mut).build()
-            assert G.check(g.out) == []
-            variants = {i.text[2:-4] for i in g.out if i.kind == "label" and i.text.endswith("_%=:")}
-            assert {"steady", "first", "masked", "firstmasked", "drain", "idle"} <= variants and ("steadydrop" in variants) == mut
-            assert sum(1 for i in g.out if i.kind == "mfma") == (64 + 48 + 56 + 40 + 16 + (64 if mut else 0))  # MFMAs per variant: steady, first, masked, firstmasked, drain
+            for scaled in (False, True):   # exact f32 scores (default) | the query scaled and rounded once per pass (KF_ATTN_SCALED_OPERANDS)
+                g = G.Gen(f16, mut, scaled=scaled).build()
+                assert G.check(g.out) == []
+                variants = {i.text[2:-4] for i in g.out if i.kind == "label" and i.text.endswith("_%=:")}
+                assert {"steady", "first", "masked", "firstmasked", "drain", "idle"} <= variants and ("steadydrop" in variants) == mut
+                assert sum(1 for i in g.out if i.kind == "mfma") == (64 + 48 + 56 + 40 + 16 + (64 if mut else 0))  # MFMAs per variant: steady, first, masked, firstmasked, drain
+                steady = [i for i in G.gap_table(g.out, "steady")]
+                assert sum(r["n"] for r in steady) > 0
 
 
 def test_committed_inc_is_the_generators_output(tmp_path):
@@ -41,11 +44,12 @@ def test_dkv_generator_address_maps_hazards_and_freshness(tmp_path):
     for f16 in (False, True):
         for mut in (False, True):
             for ds in (True, False):
-                g = G.Gen(f16, mut, ds).build()
-                assert G.check(g.out) == []
-                assert sum(1 for i in g.out if i.kind == "mfma") == 16 + 64 + 64 + 32 + (64 if mut else 0)   # accumulator clearing, steady, diag1, diag0 (one sub-block), drop
-                stores = sum(1 for i in g.out if "global_store_dwordx4" in i.text)
-                assert stores == ((4 + 4 + 2 + (4 if mut else 0)) if ds else 0)
+                for scaled in (False, True):   # exact f32 scores (default) | K scaled and rounded once per block
+                    g = G.Gen(f16, mut, ds, scaled=scaled).build()
+                    assert G.check(g.out) == []
+                    assert sum(1 for i in g.out if i.kind == "mfma") == 16 + 64 + 64 + 32 + (64 if mut else 0)   # accumulator clearing, steady, diag1, diag0 (one sub-block), drop
+                    stores = sum(1 for i in g.out if "global_store_dwordx4" in i.text)
+                    assert stores == ((4 + 4 + 2 + (4 if mut else 0)) if ds else 0)
     out = tmp_path / "dkv.inc"
     r = subprocess.run([sys.executable, str(ROOT / "tools" / "gen_attn_dkv.py"), "--out", str(out)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr

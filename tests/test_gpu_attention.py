@@ -428,3 +428,62 @@ def test_key_blocks_beyond_the_last_query_touch_nothing_behind_the_tensors():
                     dq, dk, dv = bwd(code, q, k, v, o, lse, go)
                 assert not dk[:, :, Sq:].any() and not dv[:, :, Sq:].any(), (code, Sq, Skv, nopair)
             K.attn_check(q, k, v, code, o=o, lse=lse, d_o=go, dq=dq, dk=dk, dv=dv, what=f"keys beyond the queries {Sq}x{Skv}")
+
+
+def test_rescale_path_on_every_tile():
+    """KF_ATTN_NO_DEFER makes the forward adopt every tile's maximum: the inline rare path of the generated stream (new maximum, the
+    copies of -max the score chains start from, this tile's exponents shifted, O and the row sums scaled) then runs on EVERY tile of
+    every block instead of almost never. Same bounds as the default schedule; the two agree to the rounding of P."""
+    for code in (H.BF16, H.F16):
+        for scale_in in (1.0, 3.0):
+            B, Hh, S = 1, 2, 1024
+            rng = np.random.default_rng(int(7 * scale_in) + code)
+            q, k, v = (O.from_float((scale_in * rng.standard_normal((B, Hh, S, 128))).astype(np.float32), code) for _ in range(3))
+            with H.knobs(KF_ATTN_NO_DEFER=None):
+                o0, l0 = fwd(code, q, k, v)
+            with H.knobs(KF_ATTN_NO_DEFER="1"):
+                o1, l1 = fwd(code, q, k, v)
+            K.attn_check(q, k, v, code, o=o1, lse=l1, what=f"rescale on every tile, inputs x{scale_in}")
+            K.attn_check(q, k, v, code, o=o0, lse=l0, what=f"deferred maximum, inputs x{scale_in}")
+            assert np.abs(l0 - l1).max() <= 1e-5 * (1 + np.abs(l0).max())   # the maximum in use cancels out of lse up to f32 rounding
+            d = np.abs(f(o0, code).astype(np.float64) - f(o1, code).astype(np.float64))
+            assert d.max() <= 4 * K.EPS[code] * np.abs(f(o0, code)).max()
+
+
+def test_exact_scores_hold_the_bounds_at_large_logits():
+    """Why the default streams keep q and k as they are: with inputs N(0, 3^2) the logits have a standard deviation of 9 and the softmax
+    is peaked. The default kernels (exact f32 scores) stay inside every bound; the opt-in scaled-operand streams (KF_ATTN_SCALED_OPERANDS:
+    c q and c k rounded to 16 bits once) move every score by eps * scale * sum |q k| and leave them - measured, recorded here so that the
+    trade stays visible (tools/scratch/large_logits.py, profiles/r04_attn_large_logits.txt)."""
+    code, B, Hh, S = H.BF16, 1, 2, 1024
+    rng = np.random.default_rng(30 + code)
+    q, k, v, go = (O.from_float((3.0 * rng.standard_normal((B, Hh, S, 128))).astype(np.float32), code) for _ in range(4))
+    ref = O.attn_ref64(q, k, v, go, code=code)
+    o, lse = fwd(code, q, k, v)
+    dq, dk, dv = bwd(code, q, k, v, o, lse, go)
+    m = K.attn_check(q, k, v, code, o=o, lse=lse, d_o=go, dq=dq, dk=dk, dv=dv, ref=ref, what="exact scores, logit std 9")
+    assert max(max(m[n][a] for a in ("element", "row", "head")) for n in K.NAMES) < 0.8, m
+    with H.knobs(KF_ATTN_SCALED_OPERANDS="1"):
+        o2, lse2 = fwd(code, q, k, v)
+    assert np.abs(lse2 - ref["lse"]).max() > 100 * np.abs(lse - ref["lse"]).max()    # the price of the faster form at this logit scale
+    with pytest.raises(AssertionError):
+        K.check_one("o", o2, ref, code, "scaled query, logit std 9")
+
+
+def test_scaled_operand_streams():
+    """KF_ATTN_SCALED_OPERANDS selects the faster forms of both generated kernels (c q / c k rounded to the element type once per
+    block): on the operands the parity suite uses they hold the same bounds (lse against that rounding's own bound), and the dK / dV form
+    is the arithmetic of the 32-key kernel - bit-identical gradients."""
+    for code in (H.BF16, H.F16):
+        for (B, Hh, Sq, Skv) in ((1, 2, 512, 512), (2, 8, 2048, 2048), (1, 2, 256, 768)):
+            rng = np.random.default_rng(Sq + Skv + code)
+            q, k, v, go = (O.from_float(rng.uniform(-1, 1, s).astype(np.float32), code)
+                           for s in ((B, Hh, Sq, 128), (B, Hh, Skv, 128), (B, Hh, Skv, 128), (B, Hh, Sq, 128)))
+            with H.knobs(KF_ATTN_SCALED_OPERANDS="1"):
+                o, lse = fwd(code, q, k, v)
+                g = bwd(code, q, k, v, o, lse, go)
+                K.attn_check(q, k, v, code, o=o, lse=lse, d_o=go, dq=g[0], dk=g[1], dv=g[2], what=f"scaled operands {Sq}x{Skv}", scaled_query=True)
+                with H.knobs(KF_ATTN_DKV_V4="1"):
+                    g4 = bwd(code, q, k, v, o, lse, go)
+            for a, b in zip(g, g4):
+                assert np.array_equal(a.view(np.uint16), b.view(np.uint16)), (code, Sq, Skv)

@@ -89,7 +89,12 @@ class Gen:
     # under all four (1.99 - 2.04 ms on that box), the dQ kernel that streams the dS back runs 3 - 4 % faster behind nt stores (0.95 - 0.97 vs 1.00 ms)
     store_policy = "nt"
 
-    def __init__(self, f16=False, mutant=False, ds=True, ablate=(), stamps=False):
+    def __init__(self, f16=False, mutant=False, ds=True, ablate=(), stamps=False, scaled=False):
+        # scaled: K is multiplied by scale log2(e) and ROUNDED to the element type once per block, the row constant is -lse log2(e), and the S
+        # accumulator is the exponent (no multiply per score: -32 VALU per slice, no scaling pass in the prologue... and a score error of
+        # eps scale sum|q k| that grows with the logits; KF_ATTN_SCALED_OPERANDS). Default: exact f32 scores - K as it is, the row
+        # constant is -lse / scale, one multiply by %[scale] (= scale log2(e) then) per score in front of its exp2.
+        self.scaled = scaled
         self.stamps = stamps   # diagnostic build (tools/attn_dkv_w4_timeline.py, -DKF_DKV_W4_STAMPS): s_memtime sums per wave and block pass
         self.mfma = "v_mfma_f32_32x32x16_f16" if f16 else "v_mfma_f32_32x32x16_bf16"
         self.cvt = "v_cvt_pk_f16_f32" if f16 else "v_cvt_pk_bf16_f32"
@@ -207,9 +212,13 @@ class Gen:
         if compute and not nvalu:
             for ksb in ksbs:
                 e0, m0 = (10, 27) if ksb == 0 else (25, 34)
+                if not self.scaled and ksb == 0:
+                    e0 = 11    # exact scores: sub-block 0's multiplies take gaps 10 .. 25, its exps follow one gap behind (two exps share gaps 25, 26)
                 diag = (kind == "diag0" and ksb == 0) or (kind == "diag1" and ksb == 1)
                 for n in range(16):
                     x, d = S(ksb, n), DP(ksb, n)
+                    if not self.scaled:   # exponent = (score - lse / scale) * scale log2(e): the accumulator holds the bracket
+                        put(e0 + n - 1, (0, -1), lambda x=x: self.valu(f"v_mul_f32 {vr(x)}, {sr(S_SCALE)}, {vr(x)}", V(x), V(x)))
                     if kind == "drop":
                         put(e0 + n, (0, 0), lambda x=x: self.valu(f"v_mov_b32 {vr(x)}, 0", (), V(x)))
                     else:
@@ -471,20 +480,21 @@ class Gen:
         e.dma_slice()
         e.salu(f"s_xor_b32 {sr(S_M0)}, {sr(S_M0)}, {BUF}")
         e.advance_dma()
-        # K *= scale log2(e): unpack the pair, two multiplies, pack (64 registers, once per block)
-        e.valu(f"v_mov_b32 {vr(t2)}, 0x3fb8aa3b")
-        e.valu(f"v_mul_f32 {vr(t2)}, {sr(S_SCALE)}, {vr(t2)}")
-        for i in range(64):
-            x = KFR(0, 0) + i
-            if self.f16:
-                e.valu(f"v_cvt_f32_f16 {vr(t0)}, {vr(x)}")
-                e.valu(f"v_cvt_f32_f16_sdwa {vr(t1)}, {vr(x)} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1")
-            else:
-                e.valu(f"v_lshlrev_b32 {vr(t0)}, 16, {vr(x)}")
-                e.valu(f"v_and_b32 {vr(t1)}, 0xffff0000, {vr(x)}")
-            e.valu(f"v_mul_f32 {vr(t0)}, {vr(t0)}, {vr(t2)}")
-            e.valu(f"v_mul_f32 {vr(t1)}, {vr(t1)}, {vr(t2)}")
-            e.valu(f"{self.cvt} {vr(x)}, {vr(t0)}, {vr(t1)}")
+        if self.scaled:
+            # K *= scale log2(e): unpack the pair, two multiplies, pack (64 registers, once per block)
+            e.valu(f"v_mov_b32 {vr(t2)}, 0x3fb8aa3b")
+            e.valu(f"v_mul_f32 {vr(t2)}, {sr(S_SCALE)}, {vr(t2)}")
+            for i in range(64):
+                x = KFR(0, 0) + i
+                if self.f16:
+                    e.valu(f"v_cvt_f32_f16 {vr(t0)}, {vr(x)}")
+                    e.valu(f"v_cvt_f32_f16_sdwa {vr(t1)}, {vr(x)} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1")
+                else:
+                    e.valu(f"v_lshlrev_b32 {vr(t0)}, 16, {vr(x)}")
+                    e.valu(f"v_and_b32 {vr(t1)}, 0xffff0000, {vr(x)}")
+                e.valu(f"v_mul_f32 {vr(t0)}, {vr(t0)}, {vr(t2)}")
+                e.valu(f"v_mul_f32 {vr(t1)}, {vr(t1)}, {vr(t2)}")
+                e.valu(f"{self.cvt} {vr(x)}, {vr(t0)}, {vr(t1)}")
         # dS tile bases of slice s0
         e.salu(f"s_sub_u32 {sr(S_SL)}, {sr(S_SL)}, 1")
         self.in_loop = False
@@ -553,6 +563,9 @@ class Gen:
         e.valu(f"v_mul_u32_u24 {vr(rd)}, {STAGE_ROW}, {vr(rd)}")
         e.valu(f"v_add3_u32 {vr(rd)}, {vr(rd)}, {vr(oo)}, {sr(S_STAGE)}")
         e.valu(f"v_add_u32 {vr(oo)}, {vr(oo)}, {vr(RM)}")
+        if not self.scaled:    # %[scale] is scale log2(e) in this form: the softmax scale itself = that times ln 2, once, in an address register that is idle here
+            e.valu(f"v_mov_b32 {vr(LR)}, 0x3f317218")
+            e.valu(f"v_mul_f32 {vr(LR)}, {sr(S_SCALE)}, {vr(LR)}")
         for which, accf, ptr in ((0, DV, "dvp"), (1, DK, "dkp")):
             # accumulators -> 16-bit rows of this wave's slab: lane (key r, half h) writes 4 consecutive d of key 32 ksb + r
             for ksb in range(2):
@@ -564,7 +577,7 @@ class Gen:
                             e.valu(f"v_accvgpr_read_b32 {vr(x[jj])}, {ar(a0 + jj)}")
                         if which == 1:
                             for jj in range(4):
-                                e.valu(f"v_mul_f32 {vr(x[jj])}, {sr(S_SCALE)}, {vr(x[jj])}")   # dK = scale dS^T Q
+                                e.valu(f"v_mul_f32 {vr(x[jj])}, {vr(LR) if not self.scaled else sr(S_SCALE)}, {vr(x[jj])}")   # dK = scale dS^T Q
                         e.valu(f"{self.cvt} {vr(x[0])}, {vr(x[0])}, {vr(x[1])}")
                         e.valu(f"{self.cvt} {vr(x[1])}, {vr(x[2])}, {vr(x[3])}")
                         e.out.append(Ins(f"ds_write_b64 {vr(st)}, {vr(x[0], 2)} offset:{32 * ksb * STAGE_ROW + 64 * db + 16 * gq}", "ldsw"))
@@ -774,13 +787,14 @@ def main():
     ap.add_argument("--ablate", default="")
     ap.add_argument("--dump", default="", help="print one variant's stream")
     ap.add_argument("--store-policy", default=Gen.store_policy, help="cache bits of the dS stores (experiment)")
+    ap.add_argument("--scaled", action="store_true", help="--dump / --check-only look at the scaled-K stream (the file always holds both forms)")
     ap.add_argument("--stamps", action="store_true", help="diagnostic build: s_memtime sums per slice kind, prologue, epilogue (needs -DKF_DKV_W4_STAMPS)")
     args = ap.parse_args()
     abl = tuple(x for x in args.ablate.split(",") if x)
     Gen.store_policy = args.store_policy
     assert selftest()
-    g = Gen(False, ablate=abl, stamps=args.stamps).build()
-    probs = check(g.out)
+    g = Gen(False, ablate=abl, stamps=args.stamps, scaled=args.scaled).build()
+    probs = check(g.out) + ([] if args.scaled else check(Gen(False, ablate=abl, stamps=args.stamps, scaled=True).build().out))
     for p in probs[:40]:
         print("HAZARD:", p, file=sys.stderr)
     if args.dump:
@@ -798,16 +812,19 @@ def main():
     for f16 in (False, True):
         for mut in (False, True):
             for ds in (True, False):
-                gg = Gen(f16, mut, ds, ablate=abl, stamps=args.stamps).build()
-                assert abl or not check(gg.out), check(gg.out)[:5]
-                texts[(f16, mut, ds)] = render(gg.out).replace(chr(10), " " + chr(92) + chr(10))
+                for sq in (False, True):
+                    gg = Gen(f16, mut, ds, ablate=abl, stamps=args.stamps, scaled=sq).build()
+                    assert abl or not check(gg.out), check(gg.out)[:5]
+                    texts[(f16, mut, ds, sq)] = render(gg.out).replace(chr(10), " " + chr(92) + chr(10))
     n_ins = sum(1 for i in g.out if i.kind not in ("raw", "label", "nomfma"))
     def four(mut):
-        return "\n".join(f"#define KF_DKV_W4_ASM_{'F16' if f16 else 'BF16'}_{'DS' if ds else 'NODS'} \\\n{texts[(f16, mut, ds)]}"
-                         for f16 in (False, True) for ds in (True, False))
+        return "\n".join(f"#define KF_DKV_W4_ASM_{'F16' if f16 else 'BF16'}_{'DS' if ds else 'NODS'}{'_SQ' if sq else ''} \\\n{texts[(f16, mut, ds, sq)]}"
+                         for f16 in (False, True) for ds in (True, False) for sq in (False, True))
     text = f"""// GENERATED by tools/gen_attn_dkv.py - do not edit; edit the generator and run it again.
 // The 16-bit causal-attention dK / dV pass of one 256-key block as ONE instruction stream ({n_ins} instructions): 4 waves x 64 keys,
 // one wave per SIMD, all 512 registers asm-owned; see the generator's header for the structure.
+// Two forms: exact f32 scores (default: %[scale] = scale log2 e, row constant -lse / scale), and _SQ = K scaled and rounded once per block
+// (KF_ATTN_SCALED_OPERANDS: %[scale] = the softmax scale, row constant -lse log2 e).
 #pragma once
 #define KF_DKV_W4_LDS_BYTES {LDS_BYTES}
 #define KF_DKV_W4_CLOBBERS {", ".join('"' + c + '"' for c in CLOBBERS + ([f"s{i}" for i in range(80, 92)] if args.stamps else []))}

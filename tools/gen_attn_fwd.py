@@ -91,8 +91,12 @@ def A(i, n=1): return [("a", j) for j in range(i, i + n)]
 
 
 class Gen:
-    def __init__(self, f16=False, mutant=False, ablate=(), stamps=False):
+    def __init__(self, f16=False, mutant=False, ablate=(), stamps=False, scaled=False):
         self.mutant = mutant
+        # scaled: the query is multiplied by scale log2(e) and ROUNDED to the element type once per pass, the score chains start from -max and
+        # deliver exponents (no multiply per score: -64 VALU per tile, ~4 % of the kernel) - at the price of a score error of eps scale sum|q k|,
+        # which grows with the logits (KF_ATTN_SCALED_OPERANDS). Default: exact f32 scores, one fma per score.
+        self.scaled = scaled
         self.stamps = stamps        # diagnostic build (tools/attn_fwd_w4_timeline.py): s_memtime at the slot boundaries, eight sums per wave and block
         self.ablate = set(ablate)   # timing experiments only (tools/scratch/fwd_w4_ablate.sh): parts of the tile body left out - WRONG results
         self.f16 = f16
@@ -115,7 +119,7 @@ class Gen:
         d = S(b, 16 * sub)
         if kk:
             c, cr = vr(d, 16), V(d, 16)
-        elif first:
+        elif first or not self.scaled:
             c, cr = "0", []
         else:
             c, cr = vr(NMC[b], 16), V(NMC[b], 16)
@@ -218,19 +222,26 @@ class Gen:
         # ---- decision: does any query of the wave exceed the maximum in use by more than `defer` exponent units?
         gd = 21
         add(gd, lambda: self.valu(f"v_max3_f32 {vr(MXA[b])}, {vr(MXA[b])}, {vr(MXB[b])}, {vr(MXC)}", V(MXA[b]) + V(MXB[b]) + V(MXC), V(MXA[b])))
-        # (the scores arrive as exponents relative to the maximum in use: the tile maximum IS the excess)
-        if first:
+        if not self.scaled:
+            # exact scores: the excess of the tile's maximum over the one in use, in exponent units
+            add(gd, lambda: self.valu(f"v_fma_f32 {vr(DV)}, {vr(MXA[b])}, {s_c}, -{vr(MC[b])}", V(MXA[b]) + V(MC[b]), V(DV)))
+            add(gd + 1, lambda: self.valu(f"v_cmp_lt_f32 vcc, {sr(S_DEFER)}, {vr(DV)}", V(DV), [("vcc", 0)]))
+            add(gd + 1, lambda: self.rescale(b))
+        elif first:
+            # (scaled query: the scores arrive as exponents relative to the maximum in use, the tile maximum IS the excess)
             add(gd + 1, lambda: self.adopt_first(b))
         else:
             add(gd + 1, lambda: self.valu(f"v_cmp_lt_f32 vcc, {sr(S_DEFER)}, {vr(MXA[b])}", V(MXA[b]), [("vcc", 0)]))
             add(gd + 1, lambda: self.rescale(b))
-        # ---- the exponent chain, one value per gap: exp2 | row sum | pack pairs
+        # ---- the exponent chain, one value per gap: [fma: scale, subtract the maximum |] exp2 | row sum | pack pairs
+        # (order inside a gap: exp | pack | row sum | fma - the consumer of an exp stands at least two instructions behind it)
         g0 = gd + 2
         for n in range(32):
             x = S(b, n)
             if drop:  # mutation build: this tile's probabilities are dropped (p = exp2(-inf) = 0)
-                add(g0 + n, lambda x=x: self.valu(f"v_mov_b32 {vr(x)}, {vr(NEGINF)}", V(NEGINF), V(x)))
-            # (order inside a gap: exp | pack | row sum - the consumer of an exp stands at least two instructions behind it)
+                add(g0 + n, lambda x=x: self.valu(f"v_mov_b32 {vr(x)}, {vr(NEGINF)}", V(NEGINF), V(x)), key=1003)
+            elif not self.scaled:
+                add(g0 + n, lambda x=x: self.valu(f"v_fma_f32 {vr(x)}, {vr(x)}, {s_c}, -{vr(MC[b])}", V(x) + V(MC[b]), V(x)), key=1003)
             add(g0 + n + 1, lambda x=x: self.valu(f"v_exp_f32 {vr(x)}, {vr(x)}", V(x), V(x), trans=True), key=1000)
             l = (LA if n % 2 == 0 else LB)[b]
             add(g0 + n + 2, lambda x=x, l=l: self.valu(f"v_add_f32 {vr(l)}, {vr(l)}, {vr(x)}", V(l) + V(x), V(l)), key=1002)
@@ -267,14 +278,21 @@ class Gen:
         self.salu("s_nop 1")
         self.valu(f"v_permlane32_swap_b32 {vr(t0)}, {vr(t1)}", V(t0) + V(t1), V(t0) + V(t1))
         self.valu(f"v_max_f32 {vr(t0)}, {vr(t0)}, {vr(t1)}", V(t0) + V(t1), V(t0))
-        self.valu(f"v_max_f32 {vr(t0)}, 0, {vr(t0)}", V(t0), V(t0))                                    # how far the maximum in use moves up (0: this query stays)
-        self.valu(f"v_add_f32 {vr(MC[b])}, {vr(MC[b])}, {vr(t0)}", V(t0) + V(MC[b]), V(MC[b]))       # new maximum
-        self.valu(f"v_xor_b32 {vr(t2)}, 0x80000000, {vr(MC[b])}", V(MC[b]), V(t2))
-        for i in range(16):
-            self.valu(f"v_mov_b32 {vr(NMC[b] + i)}, {vr(t2)}", V(t2), V(NMC[b] + i))
-        for n in range(32):                                                                            # this tile's exponents were formed against the old one
-            self.valu(f"v_sub_f32 {vr(S(b, n))}, {vr(S(b, n))}, {vr(t0)}", V(S(b, n)) + V(t0), V(S(b, n)))
-        self.valu(f"v_exp_f32 {vr(t1)}, -{vr(t0)}", V(t0), V(t1), trans=True)                          # alpha = 2^(old - new)
+        if self.scaled:
+            self.valu(f"v_max_f32 {vr(t0)}, 0, {vr(t0)}", V(t0), V(t0))                                    # how far the maximum in use moves up (0: this query stays)
+            self.valu(f"v_add_f32 {vr(MC[b])}, {vr(MC[b])}, {vr(t0)}", V(t0) + V(MC[b]), V(MC[b]))       # new maximum
+            self.valu(f"v_xor_b32 {vr(t2)}, 0x80000000, {vr(MC[b])}", V(MC[b]), V(t2))
+            for i in range(16):
+                self.valu(f"v_mov_b32 {vr(NMC[b] + i)}, {vr(t2)}", V(t2), V(NMC[b] + i))
+            for n in range(32):                                                                            # this tile's exponents were formed against the old one
+                self.valu(f"v_sub_f32 {vr(S(b, n))}, {vr(S(b, n))}, {vr(t0)}", V(S(b, n)) + V(t0), V(S(b, n)))
+            self.valu(f"v_exp_f32 {vr(t1)}, -{vr(t0)}", V(t0), V(t1), trans=True)                          # alpha = 2^(old - new)
+        else:
+            self.valu(f"v_mul_f32 {vr(t0)}, {sr(S_C)}, {vr(t0)}", V(t0), V(t0))
+            self.valu(f"v_max_f32 {vr(t0)}, {vr(t0)}, {vr(MC[b])}", V(t0) + V(MC[b]), V(t0))           # new maximum
+            self.valu(f"v_sub_f32 {vr(t1)}, {vr(MC[b])}, {vr(t0)}", V(t0) + V(MC[b]), V(t1))
+            self.valu(f"v_mov_b32 {vr(MC[b])}, {vr(t0)}", V(t0), V(MC[b]))
+            self.valu(f"v_exp_f32 {vr(t1)}, {vr(t1)}", V(t1), V(t1), trans=True)                           # alpha = 2^(old - new), 0 at the first tile
         self.salu("s_nop 0")
         self.valu(f"v_mul_f32 {vr(LA[b])}, {vr(LA[b])}, {vr(t1)}", V(LA[b]) + V(t1), V(LA[b]))
         self.valu(f"v_mul_f32 {vr(LB[b])}, {vr(LB[b])}, {vr(t1)}", V(LB[b]) + V(t1), V(LB[b]))
@@ -530,7 +548,8 @@ class Gen:
             e.valu(f"v_mov_b32 {vr(MC[b])}, {vr(NEGINF)}")
             e.valu(f"v_mov_b32 {vr(LA[b])}, 0")
             e.valu(f"v_mov_b32 {vr(LB[b])}, 0")
-        # ---- Q *= scale log2(e), rounded to the element type once: the score MFMAs then deliver exponents (no multiply per score in the tile loop)
+        # ---- the Q fragments out of the slab: straight into a[128:191] (exact scores), or through the score registers where they are multiplied by
+        #      scale log2(e) and rounded to the element type once (scaled query: the score MFMAs then deliver exponents)
         e.wait(vm=12)     # in-order counter: this wave's 16 Q pieces are older than its 12 K / V pieces; the quarter is its own: no barrier
         qb = (T[10], T[11])
         e.salu(f"s_sub_u32 {sr(S_TMP)}, {sr(S_STAGE)}, {sr(S_LDS)}")           # (S_TMP2 holds 8 key rows' bytes from here to the end of the loop)
@@ -538,9 +557,14 @@ class Gen:
             e.valu(f"v_add_u32 {vr(qb[i])}, {sr(S_TMP)}, {vr(KB[i])}")           # (the K bases sit at slot 0 here: S_LDS + the lane's row / chunk)
         for b in range(2):
             for kk in range(8):
-                e.out.append(Ins(f"ds_read_b128 {vr(QF(b, kk) - 128, 4)}, {vr(qb[kk & 1])} offset:{8192 * b + 512 * (kk >> 1)}", "lds", V(qb[kk & 1]), V(QF(b, kk) - 128, 4)))
+                if self.scaled:
+                    e.out.append(Ins(f"ds_read_b128 {vr(QF(b, kk) - 128, 4)}, {vr(qb[kk & 1])} offset:{8192 * b + 512 * (kk >> 1)}", "lds", V(qb[kk & 1]), V(QF(b, kk) - 128, 4)))
+                else:
+                    e.out.append(Ins(f"ds_read_b128 {ar(QF(b, kk), 4)}, {vr(qb[kk & 1])} offset:{8192 * b + 512 * (kk >> 1)}", "lds", V(qb[kk & 1]), A(QF(b, kk), 4)))
         e.wait(lgkm=0)
-        if self.f16:
+        if not self.scaled:
+            pass
+        elif self.f16:
             c2 = T[8]
             e.valu(f"v_cvt_f16_f32 {vr(c2)}, {sr(S_C)}")
             e.valu(f"v_pack_b32_f16 {vr(c2)}, {vr(c2)}, {vr(c2)}")
@@ -904,12 +928,13 @@ def main():
     ap.add_argument("--pad", type=int, default=0, help="s_nop 0 x N in front of the loop head (code-placement experiment)")
     ap.add_argument("--stamps", action="store_true", help="diagnostic build: s_memtime stamps at the slot boundaries (needs -DKF_FWD_W4_STAMPS)")
     ap.add_argument("--ablate", default="", help="comma list of dma, valu, lds, barrier: leave that part of the tile body out (timing experiments; wrong results)")
+    ap.add_argument("--scaled", action="store_true", help="--gaps / --check-only look at the scaled-query stream (the file always holds both)")
     args = ap.parse_args()
     abl = tuple(x for x in args.ablate.split(",") if x)
     assert selftest()
     Gen.pad = args.pad
-    g = Gen(False, ablate=abl, stamps=args.stamps).build()
-    probs = check(g.out)
+    g = Gen(False, ablate=abl, stamps=args.stamps, scaled=args.scaled).build()
+    probs = check(g.out) + ([] if args.scaled else check(Gen(False, ablate=abl, stamps=args.stamps, scaled=True).build().out))
     if args.gaps:
         tot = 0
         for k, row in enumerate(gap_table(g.out, args.gaps)):
@@ -925,26 +950,24 @@ def main():
     texts = {}
     for f16 in (False, True):
         for mut in (False, True):
-            gg = Gen(f16, mut, ablate=abl, stamps=args.stamps).build()
-            assert abl or not check(gg.out), check(gg.out)[:5]
-            texts[(f16, mut)] = render(gg.out).replace(chr(10), " " + chr(92) + chr(10))
+            for sq in (False, True):
+                gg = Gen(f16, mut, ablate=abl, stamps=args.stamps, scaled=sq).build()
+                assert abl or not check(gg.out), check(gg.out)[:5]
+                texts[(f16, mut, sq)] = render(gg.out).replace(chr(10), " " + chr(92) + chr(10))
     n_ins = sum(1 for i in g.out if i.kind not in ("raw", "label", "nomfma"))
+    def four(mut):
+        return "\n".join(f"#define KF_FWD_W4_ASM_{'F16' if f16 else 'BF16'}{'_SQ' if sq else ''} \\\n{texts[(f16, mut, sq)]}" for f16 in (False, True) for sq in (False, True))
     text = f"""// GENERATED by tools/gen_attn_fwd.py - do not edit; edit the generator and run it again.
 // The 16-bit causal-attention forward of one 256-row query block as ONE instruction stream per element type ({n_ins} instructions):
 // 4 waves x 64 query rows, one wave per SIMD, all 512 registers asm-owned; see the generator's header for the structure.
+// Two forms: exact f32 scores (default), and _SQ = the query scaled and rounded once per pass (KF_ATTN_SCALED_OPERANDS: faster, less exact).
 #pragma once
 #define KF_FWD_W4_LDS_BYTES {LDS_BYTES}
 #define KF_FWD_W4_CLOBBERS {", ".join('"' + c + '"' for c in CLOBBERS + ([f"s{i}" for i in range(80, 92)] if args.stamps else []))}
 #ifdef KF_MUTANT  // + one more variant of the tile body: the probabilities of tile %[mut] are dropped (tests/test_gpu_attention_mutants.py)
-#define KF_FWD_W4_ASM_BF16 \\
-{texts[(False, True)]}
-#define KF_FWD_W4_ASM_F16 \\
-{texts[(True, True)]}
+{four(True)}
 #else
-#define KF_FWD_W4_ASM_BF16 \\
-{texts[(False, False)]}
-#define KF_FWD_W4_ASM_F16 \\
-{texts[(True, False)]}
+{four(False)}
 #endif
 """
     Path(args.out).write_text(text)
