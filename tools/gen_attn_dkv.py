@@ -285,7 +285,7 @@ class Gen:
                 self.stamp_add({"steady": 1, "drop": 1, "diag1": 2, "diag0": 3, "idle": 4}[kind])
                 self.stamp_take()
                 if self.stamps and kind == "steady":
-                    self.salu("s_add_u32 s91, s91, 1")
+                    self.salu("s_add_u32 s90, s90, 1")        # bucket 6 is written at the very end: until then s90 counts the steady slices
             ksb, i = j >> 3, j & 7
             if slot < 2:
                 ksb, i = CHAIN_ORDER[j]
@@ -312,7 +312,7 @@ class Gen:
     def prologue(self):
         e = self
         if self.stamps:
-            for i in range(84, 92):
+            for i in range(84, 91):
                 e.salu(f"s_mov_b32 s{i}, 0")
             e.salu("s_memtime s[80:81]")
             e.salu("s_waitcnt lgkmcnt(0)")
@@ -597,11 +597,12 @@ class Gen:
             # (no wait for the stores: their registers and the descriptor were read at issue, the slab is rewritten behind the lgkmcnt(0)
             #  above; they drain under the second tensor's conversion and the next pass's prologue, whose counted waits they only make stricter)
         if self.stamps:
+            e.valu(f"v_mov_b32 {vr(32 + 7)}, s90")                            # [7] = the number of steady slices
+            e.salu("s_mov_b32 s90, 0")
             self.stamp(6)
-            e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 5")                  # 8 dwords per wave
-            e.salu(f"s_add_u32 {sr(S_TMP)}, {sr(S_TMP)}, %[dbgoff]")
+            e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 5")                  # 8 dwords per wave (%[dbg] already points at this pass)
             e.valu(f"v_mov_b32 {vr(T[0])}, {sr(S_TMP)}")
-            for i in range(8):
+            for i in range(7):
                 e.valu(f"v_mov_b32 {vr(32 + i)}, s{84 + i}")
             e.salu("s_mov_b64 exec, 1")
             e.out.append(Ins(f"global_store_dwordx4 {vr(T[0])}, {vr(32, 4)}, %[dbg]", "vmem"))
@@ -827,7 +828,7 @@ def main():
 // (KF_ATTN_SCALED_OPERANDS: %[scale] = the softmax scale, row constant -lse log2 e).
 #pragma once
 #define KF_DKV_W4_LDS_BYTES {LDS_BYTES}
-#define KF_DKV_W4_CLOBBERS {", ".join('"' + c + '"' for c in CLOBBERS + ([f"s{i}" for i in range(80, 92)] if args.stamps else []))}
+#define KF_DKV_W4_CLOBBERS {", ".join('"' + c + '"' for c in CLOBBERS + ([f"s{i}" for i in range(80, 91)] if args.stamps else []))}
 #ifdef KF_MUTANT
 {four(True)}
 #else
