@@ -1291,17 +1291,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     stage_pair(p0, 0);
     stage_pair(p0 + 1, 1);
     stage_pair(p0 + 2, 2);
-    { // (after the first three slice pairs are on their way: their latency runs under this arithmetic)
-        // K pre-scaled by c = scale log2(e), once per block: S'' = Q (c K)^T - lse log2(e) leaves the MFMA chain as the exponent
-        // itself (p = exp2(S''), no multiply per score: 32 VALU instructions fewer per slice pair). The 16-bit rounding of c K moves
-        // an exponent by ~1e-3 (p by < 1e-3 relative, a quarter of P's own 16-bit rounding); dK = scale dS^T Q does not see it.
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                if constexpr (BF) kf[kk][j] = (__bf16)((float)kf[kk][j] * c);
-                else kf[kk][j] = (_Float16)((float)kf[kk][j] * c);
-            }
+    { // (exact f32 scores since round 4: K stays as it is, the row constant is -lse / scale and every score is multiplied by c = scale log2(e) in
+      // front of its exp2. Rounds 2-3 scaled K by c in 16 bits here instead - 32 VALU instructions fewer per slice pair, and a score error of
+      // eps scale sum |q k| that left the parity bounds once the logits grew: profiles/r04_attn_large_logits.txt)
         // only MFMAs read them from here on: accumulator registers
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) asm volatile("" : "+a"(kf[kk]), "+a"(vf[kk]));
@@ -1393,7 +1385,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         k4_wait4_cv<4>(g2, cp);
 #define K4_EXP2(E)                                                                      \
     _Pragma("unroll") for (int e_ = (E); e_ < (E) + 2; ++e_) {                          \
-        float pv = KF_ABL_EXP(sv[e_]);                                                  \
+        float pv = KF_ABL_EXP(sv[e_] * c);                                              \
         if (MASK && nd > a_row(e_, 0)) pv = 0.f;                                        \
         if (KF_MUT(2, xb == 0 && qs == 4 * BQS)) pv = 0.f;                              \
         sv[e_] = pv;                                                                    \
@@ -1535,7 +1527,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         frag_t pf[2], df[2];
 #define K6_EXP(E)                                                        \
     {                                                                    \
-        float pv = __builtin_amdgcn_exp2f(sv[E]);                        \
+        float pv = __builtin_amdgcn_exp2f(sv[E] * c);                    \
         if (MASK && nd > a_row(E, 0)) pv = 0.f;                          \
         if (KF_MUT(2, xb == 0 && qs == 4 * BQS)) pv = 0.f;               \
         sv[E] = pv;                                                      \
@@ -1732,6 +1724,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) 
     const unsigned cdelta = (unsigned)((const char *)a.ndelta - (const char *)a.nlse);
     const int qsr = (int)a.lq.sr, dosr = (int)a.ldo.sr, kvsr = (int)a.lk.sr, osr = (int)a.ldk.sr;
     const float scale = SQ ? a.scale : a.scale_log2e; // (what the stream multiplies by: K once per block | every score in front of its exp2)
+    const float scl = a.scale;                         // (dK = scale dS^T Q)
     const int ns_all = (int)(a.Sq / BQS), dsqb = (int)(a.ds_nkwb * 8);
 #pragma nounroll
     for (int pass = 0; pass < (a.persist ? 2 : 1); ++pass) {
@@ -1755,7 +1748,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) 
 #define KF_DKV_OPERANDS                                                                                                                       \
     [qp] "s"(qp), [dop] "s"(dop), [kp] "s"(kp), [vp] "s"(vp), [dkp] "s"(dkp), [dvp] "s"(dvp), [cp] "s"(cp), [dsp] "s"(dsp), [cdelta] "s"(cdelta), \
         [qsr] "s"(qsr), [dosr] "s"(dosr), [kvsr] "s"(kvsr), [osr] "s"(osr), [s0] "s"(s0), [ns] "s"(ns), [dsqb] "s"(dsqb), [wid] "s"(wid),       \
-        [scale] "s"(scale), [lds] "s"(lds), [mut] "s"(mut) KF_DKV_EXTRA
+        [scale] "s"(scale), [scl] "s"(scl), [lds] "s"(lds), [mut] "s"(mut) KF_DKV_EXTRA
 #define KF_DKV_ASM(TEXT) asm volatile(TEXT : : KF_DKV_OPERANDS : KF_DKV_W4_CLOBBERS)
         if constexpr (SQ) {
             if constexpr (BF && DS) KF_DKV_ASM(KF_DKV_W4_ASM_BF16_DS_SQ);
@@ -2679,9 +2672,9 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
         const bool dkv_w4 = D == AD && Skv % K5B == 0 && a.lk.sr == a.lv.sr && a.ldk.sr == a.ldv.sr && (uint64_t)Sq * (uint64_t)std::max(a.lq.sr, a.ldo.sr) < (1ull << 32) &&
                             (uint64_t)K5B * (uint64_t)std::max(a.lk.sr, a.ldk.sr) < (1ull << 31) && (uint64_t)((const char *)a.ndelta - (const char *)a.nlse) < (1ull << 31) &&
                             !knob(KNOB_ATTN_DKV_V4);
-        // its default form keeps K as it is (exact f32 scores: exponent = (s - lse / scale) * scale log2 e); the scaled-K form and the 32-key
-        // kernel scale K by scale log2 e once per block and want -lse log2 e
-        const bool dkv_sq = !dkv_w4 || knob(KNOB_ATTN_SCALED_OPERANDS);
+        // exact f32 scores everywhere by default (exponent = (s - lse / scale) * scale log2 e: the row constant is -lse / scale); only the opt-in
+        // scaled-K form of the generated stream scales K by scale log2 e once per block and wants -lse log2 e
+        const bool dkv_sq = dkv_w4 && knob(KNOB_ATTN_SCALED_OPERANDS);
         const float rscale = dkv_sq ? kLog2e : 1.0f / scale;
         {
             KF_PROF("attn_bwd_delta", st);

@@ -472,8 +472,8 @@ def test_exact_scores_hold_the_bounds_at_large_logits():
 
 def test_scaled_operand_streams():
     """KF_ATTN_SCALED_OPERANDS selects the faster forms of both generated kernels (c q / c k rounded to the element type once per
-    block): on the operands the parity suite uses they hold the same bounds (lse against that rounding's own bound), and the dK / dV form
-    is the arithmetic of the 32-key kernel - bit-identical gradients."""
+    block): on the operands the parity suite uses they hold the same bounds (lse against that rounding's own bound). The DEFAULT dK / dV
+    stream is the arithmetic of the 32-key kernel (both exact-score now): bit-identical gradients."""
     for code in (H.BF16, H.F16):
         for (B, Hh, Sq, Skv) in ((1, 2, 512, 512), (2, 8, 2048, 2048), (1, 2, 256, 768)):
             rng = np.random.default_rng(Sq + Skv + code)
@@ -483,7 +483,9 @@ def test_scaled_operand_streams():
                 o, lse = fwd(code, q, k, v)
                 g = bwd(code, q, k, v, o, lse, go)
                 K.attn_check(q, k, v, code, o=o, lse=lse, d_o=go, dq=g[0], dk=g[1], dv=g[2], what=f"scaled operands {Sq}x{Skv}", scaled_query=True)
-                with H.knobs(KF_ATTN_DKV_V4="1"):
-                    g4 = bwd(code, q, k, v, o, lse, go)
+            o, lse = fwd(code, q, k, v)
+            g = bwd(code, q, k, v, o, lse, go)
+            with H.knobs(KF_ATTN_DKV_V4="1"):
+                g4 = bwd(code, q, k, v, o, lse, go)
             for a, b in zip(g, g4):
                 assert np.array_equal(a.view(np.uint16), b.view(np.uint16)), (code, Sq, Skv)

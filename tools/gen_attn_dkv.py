@@ -563,9 +563,6 @@ class Gen:
         e.valu(f"v_mul_u32_u24 {vr(rd)}, {STAGE_ROW}, {vr(rd)}")
         e.valu(f"v_add3_u32 {vr(rd)}, {vr(rd)}, {vr(oo)}, {sr(S_STAGE)}")
         e.valu(f"v_add_u32 {vr(oo)}, {vr(oo)}, {vr(RM)}")
-        if not self.scaled:    # %[scale] is scale log2(e) in this form: the softmax scale itself = that times ln 2, once, in an address register that is idle here
-            e.valu(f"v_mov_b32 {vr(LR)}, 0x3f317218")
-            e.valu(f"v_mul_f32 {vr(LR)}, {sr(S_SCALE)}, {vr(LR)}")
         for which, accf, ptr in ((0, DV, "dvp"), (1, DK, "dkp")):
             # accumulators -> 16-bit rows of this wave's slab: lane (key r, half h) writes 4 consecutive d of key 32 ksb + r
             for ksb in range(2):
@@ -577,7 +574,7 @@ class Gen:
                             e.valu(f"v_accvgpr_read_b32 {vr(x[jj])}, {ar(a0 + jj)}")
                         if which == 1:
                             for jj in range(4):
-                                e.valu(f"v_mul_f32 {vr(x[jj])}, {vr(LR) if not self.scaled else sr(S_SCALE)}, {vr(x[jj])}")   # dK = scale dS^T Q
+                                e.valu(f"v_mul_f32 {vr(x[jj])}, %[scl], {vr(x[jj])}")   # dK = scale dS^T Q (%[scale] is scale log2 e in the exact form)
                         e.valu(f"{self.cvt} {vr(x[0])}, {vr(x[0])}, {vr(x[1])}")
                         e.valu(f"{self.cvt} {vr(x[1])}, {vr(x[2])}, {vr(x[3])}")
                         e.out.append(Ins(f"ds_write_b64 {vr(st)}, {vr(x[0], 2)} offset:{32 * ksb * STAGE_ROW + 64 * db + 16 * gq}", "ldsw"))
