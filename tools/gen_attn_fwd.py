@@ -64,7 +64,8 @@ N_VGPR = 232  # v0 .. v231 are the stream's; the rest of the arch file stays the
 # Measured (tools/attn_fwd_w4_timeline.py, cycles per steady iteration, slots A / B / C / D): all 8 pieces in slot B and the V reads two per gap
 # over slot C: 606 / 824 / 742 / 703 = 2875; the 4 V pieces moved to slot D's tail and the V reads spread over gaps 22 .. 47 (into the DMA slot):
 # 612 / 891 / 683 / 754 = 2940 - LDS reads beside DMA pieces cost more than they relieve. (Exact-score stream, k-step 0's eight reads in gaps 18 .. 21 and
-# the rest two per gap in slot C: 611 / 878 / 674 / 665 = 2827 against 608 / 814 / 695 / 662 = 2779: slot B is the full one.)
+# the rest two per gap in slot C: 611 / 878 / 674 / 665 = 2827 against 608 / 814 / 695 / 662 = 2779: slot B is the full one. The pieces on every second gap
+# 17 .. 31 with the bookkeeping between them: 613 / 832 / 712 / 703 = 2861.)
 DMA_G = [23, 24, 25, 26, 27, 28, 29, 30]   # all 8 pieces behind the barrier, one per gap (K first: it is needed a slot earlier)
 BOOK_K_G, BOOK_V_G, BOOK_VB_G = 31, 31, 31  # ring toggles + next source offsets, each behind the last use of the old slot
 VREAD_G = [32 + i // 3 for i in range(32)]  # slot C, three per gap: done five gaps before slot D's wait
