@@ -523,6 +523,9 @@ def main():
                          "frac": achieved / PEAK_MFMA_BF16, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_flops_per_launch": KERNEL_FLOPS[dom]},
             "device_src_sha": device_src_sha(),
+            "data_note": "uniform(-1, 1) operands; each attention operand is ONE random [H, S, D] batch element replicated over the batch at distinct "
+                         "addresses (tests/test_gpu_baseline_sizes.py runs the same size with distinct data per head)",
+            "attention_scores": "scaled operands (KF_ATTN_SCALED_OPERANDS)" if os.environ.get("KF_ATTN_SCALED_OPERANDS") else "exact f32",
             "checks": checks,
             "check_notes": CHECK_NOTES,
         }
