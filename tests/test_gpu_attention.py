@@ -489,3 +489,18 @@ def test_scaled_operand_streams():
                 g4 = bwd(code, q, k, v, o, lse, go)
             for a, b in zip(g, g4):
                 assert np.array_equal(a.view(np.uint16), b.view(np.uint16)), (code, Sq, Skv)
+
+
+def test_forward_without_an_lse_buffer():
+    """kf_attn_fwd's lse pointer may be NULL (a caller that wants no backward): every forward kernel - the generated stream, the 8-wave
+    kernel, D = 64 - must skip the store and write the same O."""
+    for code in (H.BF16, H.F16):
+        for (B, Hh, S, D) in ((1, 2, 512, 128), (1, 2, 384, 128), (1, 2, 256, 64)):
+            rng = np.random.default_rng(S + D + code)
+            q, k, v = (O.from_float(rng.uniform(-1, 1, (B, Hh, S, D)).astype(np.float32), code) for _ in range(3))
+            o_ref, _ = fwd(code, q, k, v)
+            dq_, dk_, dv_ = (H.DevBuf.from_numpy(x) for x in (q, k, v))
+            o = H.DevBuf(q.nbytes)
+            H.attn_fwd(code, B, Hh, S, S, D, dq_.ptr, dk_.ptr, dv_.ptr, o.ptr, None)
+            H.device_sync()
+            assert np.array_equal(o.to_numpy(q.shape, q.dtype), o_ref), (code, S, D)
