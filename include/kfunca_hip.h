@@ -78,6 +78,10 @@ typedef struct kf_iter_desc {
 /* ---- runtime: replaces memory_engine.h:5-10 and Launcher (launcher_cuda.h:105-354) -------- */
 const char *kf_last_error(void);
 int kf_abi_version(void);
+/* content hash (16 hex digits) of the device sources this library was linked from: kfunca_amd/_build.py stamps it in at link time
+ * (no reference counterpart: launcher_cuda.h has no build identity). bench.py prints it as device_lib_sha and refuses to quote
+ * profile-derived figures when it differs from the source tree it runs in. */
+const char *kf_build_source_sha(void);
 int kf_device_count(int *count);
 int kf_set_device(int device);              /* dset_device, memory_engine.h:5           */
 int kf_get_device(int *device);

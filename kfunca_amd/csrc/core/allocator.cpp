@@ -105,18 +105,27 @@ size_t DeviceAllocator::release_cached_locked(int device) {
     auto dv = free_.find(device);
     if (dv == free_.end()) return 0;
     for (Pool &pool : dv->second) {
-        for (Block *b : pool) { // idle, owned by no graph (graph-held blocks live in graph_free_)
-            if (kf_free(b->ptr) != KF_OK) continue;
+        for (auto it = pool.begin(); it != pool.end();) { // idle, owned by no graph (graph-held blocks live in graph_free_)
+            Block *b = *it;
+            if (kf_free(b->ptr) != KF_OK) { // not freed: it stays a cached block (still reusable, still known by its pointer)
+                ++it;
+                continue;
+            }
             freed += b->size;
             by_ptr_.erase(b->ptr);
+            it = pool.erase(it);
             delete b;
         }
-        pool.clear();
     }
     return freed;
 }
 
 size_t DeviceAllocator::release_cached(int device) {
+    {
+        // a device synchronise + hipFree inside a stream capture would invalidate the capture (allocate() never gets here while capturing)
+        std::lock_guard<std::mutex> lk(mu_);
+        if (capturing_ != 0) return 0;
+    }
     dev::set_device(device);
     dev::synchronize(device); // nothing queued may still touch a block that was freed to the cache a moment ago
     std::lock_guard<std::mutex> lk(mu_);

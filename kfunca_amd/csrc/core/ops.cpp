@@ -465,13 +465,15 @@ public:
         Tensor gc = g.contiguous();
         std::vector<Tensor> out(2);
         Tensor g2 = gc.view({M, N}), a2 = a.view({M, K});
+        Tensor da, db; // kept when the fused pair is not taken: the slot is handed out once per pass (GradSink::take_slot), asking twice would lose it
         if (a.requires_grad() && b.requires_grad() && M % 256 == 0 && N % 256 == 0 && K % 256 == 0 &&
             (a.dtype() == ScalarType::Half || a.dtype() == ScalarType::BFloat16)) {
             // both gradients of a 16-bit layer on 256-tile shapes: ONE grid where the device library can fuse the pair
             // (kf_gemm_grouped_single_grid). Where it cannot - too many tiles, or a skinny product such as dA of x[256, 4096] W[4096, 16384] -
             // the two ordinary calls below run, which carry the split-K scratch kf_gemm_grouped's fall-back would not have.
             // a bucketed weight whose gradient starts empty takes dW straight into its bucket slot (update_grad then has nothing to copy)
-            Tensor da = empty(a.sizes(), a.dtype(), a.device()), db = grad_target(b);
+            da = empty(a.sizes(), a.dtype(), a.device());
+            db = grad_target(b);
             kf_gemm_problem p[2] = {};
             p[0].trans_a = 0; p[0].trans_b = 1; p[0].M = M; p[0].N = K; p[0].K = N; p[0].alpha = alpha_; p[0].beta = 0.f;
             p[0].A = g2.data_ptr(); p[0].lda = N; p[0].B = b.data_ptr(); p[0].ldb = N; p[0].C = da.data_ptr(); p[0].ldc = K;
@@ -486,12 +488,12 @@ public:
             }
         }
         if (a.requires_grad()) {
-            out[0] = empty(a.sizes(), a.dtype(), a.device());
+            out[0] = da.defined() ? da : empty(a.sizes(), a.dtype(), a.device());
             Tensor c2 = out[0].view({M, K});
             gemm_any(a.dtype(), false, true, M, K, N, alpha_, g2, b, 0.f, c2, a.device());
         }
         if (b.requires_grad()) {
-            out[1] = grad_target(b);
+            out[1] = db.defined() ? db : grad_target(b);
             gemm_any(a.dtype(), true, false, K, N, M, alpha_, a2, g2, 0.f, out[1], b.device());
         }
         return out;
@@ -564,7 +566,7 @@ public:
         if (ibias_ >= 0 && inputs[ibias_].requires_grad()) out[ibias_] = sum(dt, 0).view({N});
         Tensor a2 = a.view({M, K});
         if (a.requires_grad()) {
-            out[0] = empty(a.sizes(), a.dtype(), a.device());
+            out[0] = da.defined() ? da : empty(a.sizes(), a.dtype(), a.device());
             Tensor c2 = out[0].view({M, K});
             gemm_any(a.dtype(), false, true, M, K, N, alpha_, dt, b, 0.f, c2, a.device());
         }

@@ -126,6 +126,7 @@ constexpr float kLn2 = 0.6931471805599453f;
 // MFMA path, D = 128 | 64 (template parameter; the LDS images are those of D = 128 for both)
 // ==========================================================================================
 constexpr int AD = 128;              // head size the LDS images are laid out for
+constexpr float kPShiftF16 = 16384.f; // f16 backward: P is carried as P 2^14 into the dV product (see K4_CVTP; tools/gen_attn_dkv.py P_SHIFT)
 constexpr int AROW = AD * 2;         // bytes per row of a 16-bit tile
 constexpr int ABQ = 128, ABK = 64;   // forward / dQ: queries per block, keys per tile
 constexpr int OPAD = AROW + 8;       // epilogue staging row stride (bytes)
@@ -1347,6 +1348,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
 #define K4_CVT2(DST, J, A, B)                                              \
     if constexpr (BF) { DST[J] = (__bf16)(A); DST[(J) + 1] = (__bf16)(B); } \
     else { DST[J] = (_Float16)(A); DST[(J) + 1] = (_Float16)(B); }
+// the P pack: f16 carries P as P 2^14 (kPShiftF16: <= 16384, cannot overflow; the format's subnormal range then starts at 3.7e-9 instead of
+// 6.1e-5 - at large logits whole key columns of P lay below that and dV lost them); dV is scaled back when it is stored
+#define K4_CVTP(DST, J, A, B)                                              \
+    if constexpr (BF) { DST[J] = (__bf16)(A); DST[(J) + 1] = (__bf16)(B); } \
+    else { DST[J] = (_Float16)((A) * kPShiftF16); DST[(J) + 1] = (_Float16)((B) * kPShiftF16); }
 
     // SOFF: this slice's offset inside its pair buffer (bases e, o, t0, t1, l); the next slice's first groups are read off
     // (en, on, ln) + NOFF; LAST: the slice that ends a pair (barrier + DMA of the pair after next before its q6)
@@ -1415,7 +1421,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
 #define K4_Q3(KK)                                                                                       \
     k4_mfma_acc_t<BF>(dpv, g3[KK], vf[4 + (KK)], sv);                                                   \
     K4_EXP2(8 + 2 * (KK))                                                                               \
-    K4_CVT2(pf[0], 2 * (KK), sv[2 * (KK)], sv[2 * (KK) + 1])                                            \
+    K4_CVTP(pf[0], 2 * (KK), sv[2 * (KK)], sv[2 * (KK) + 1])                                            \
     k4_trp<DO + 4096 + 512 * (KK)>(t0, t1, t5.lo[KK], t5.hi[KK]);
         K4_Q3(0) K4_Q3(1) K4_Q3(2) K4_Q3(3)
 #undef K4_Q3
@@ -1431,7 +1437,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     dv[DD] = a_mfma<BF>(k4_frag<BF>(t4, DD), pf[0], dv[DD]);                                                            \
     asm volatile("" : "+a"(dv[DD]), "+v"(dpv), "+v"(sv));                                                               \
     dpv[2 * (DD)] = KF_ABL_MUL(sv[2 * (DD)], dpv[2 * (DD)]); dpv[2 * (DD) + 1] = KF_ABL_MUL_ODD(sv[2 * (DD) + 1], dpv[2 * (DD) + 1]); \
-    K4_CVT2(pf[1], 2 * (DD), sv[8 + 2 * (DD)], sv[9 + 2 * (DD)])                                                        \
+    K4_CVTP(pf[1], 2 * (DD), sv[8 + 2 * (DD)], sv[9 + 2 * (DD)])                                                        \
     asm volatile("" : "+a"(dv[((DD) + 1) & 3]), "+v"(dpv), "+v"(pf[1]));                                                \
     k4_trp<SOFF + 512 * (DD)>(t0, t1, t6.lo[DD], t6.hi[DD]);
         K4_Q4(0) K4_Q4(1) K4_Q4(2) K4_Q4(3)
@@ -1560,13 +1566,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         K6_EXP(0) K6_EXP(1) K6_EXP(2)
         k4_trp<SOFF>(t0, t1, t6.lo[0], t6.hi[0]);
         k4_mfma_acc_t<BF>(dpv, g1[1], vf[1], sv);
-        K6_EXP(3) K6_EXP(4) K6_EXP(5) K4_CVT2(pf[0], 0, sv[0], sv[1]) K4_CVT2(pf[0], 2, sv[2], sv[3])
+        K6_EXP(3) K6_EXP(4) K6_EXP(5) K4_CVTP(pf[0], 0, sv[0], sv[1]) K4_CVTP(pf[0], 2, sv[2], sv[3])
         k4_trp<SOFF + 512>(t0, t1, t6.lo[1], t6.hi[1]);
         k4_mfma_acc_t<BF>(dpv, g1[2], vf[2], sv);
-        K6_EXP(6) K6_EXP(7) K6_EXP(8) K4_CVT2(pf[0], 4, sv[4], sv[5])
+        K6_EXP(6) K6_EXP(7) K6_EXP(8) K4_CVTP(pf[0], 4, sv[4], sv[5])
         k4_trp<SOFF + 4096>(t0, t1, t7.lo[0], t7.hi[0]);
         k4_mfma_acc_t<BF>(dpv, g1[3], vf[3], sv);
-        K6_EXP(9) K6_EXP(10) K6_EXP(11) K4_CVT2(pf[0], 6, sv[6], sv[7])
+        K6_EXP(9) K6_EXP(10) K6_EXP(11) K4_CVTP(pf[0], 6, sv[6], sv[7])
         k4_trp<SOFF + 4096 + 512>(t0, t1, t7.lo[1], t7.hi[1]);
         k4_keep(c_s);
         // p4: dV k-step 0 (2 MFMAs); the last exponentials; dS = p dP' for elements 0..7; P of k-step 1 packed
@@ -1589,12 +1595,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         asm volatile("s_nop 2" : "+v"(dpv)); // (the dP chain's result is read a few instructions on)
         dv[0] = a_mfma<BF>(k4_frag<BF>(t4, 0), pf[0], dv[0]);
         asm volatile("" : "+a"(dv[0]), "+v"(dpv), "+v"(sv));
-        K6_EXP(12) K6_EXP(13) K6_MUL2(0) K6_MUL2(2) K4_CVT2(pf[1], 0, sv[8], sv[9]) K4_CVT2(pf[1], 2, sv[10], sv[11])
+        K6_EXP(12) K6_EXP(13) K6_MUL2(0) K6_MUL2(2) K4_CVTP(pf[1], 0, sv[8], sv[9]) K4_CVTP(pf[1], 2, sv[10], sv[11])
         asm volatile("" : "+a"(dv[1]), "+v"(dpv), "+v"(sv));
         k4_rowc1<NOFF>(ln, cs[0]); k4_rowc1<NOFF + 32>(ln, cs[1]);
         dv[1] = a_mfma<BF>(k4_frag<BF>(t4, 1), pf[0], dv[1]);
         asm volatile("" : "+a"(dv[1]), "+v"(dpv), "+v"(sv));
-        K6_EXP(14) K6_EXP(15) K6_MUL2(4) K6_MUL2(6) K4_CVT2(pf[1], 4, sv[12], sv[13]) K4_CVT2(pf[1], 6, sv[14], sv[15])
+        K6_EXP(14) K6_EXP(15) K6_MUL2(4) K6_MUL2(6) K4_CVTP(pf[1], 4, sv[12], sv[13]) K4_CVTP(pf[1], 6, sv[14], sv[15])
         asm volatile("" : "+a"(dv[0]), "+v"(dpv), "+v"(pf[1]));
         k4_rowc1<NOFF + 64>(ln, cs[2]); k4_rowc1<NOFF + 96>(ln, cs[3]);
         k4_keep(c_p);
@@ -1680,13 +1686,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
 #endif
 #undef K4_MFMA4
 #undef K4_CVT2
+#undef K4_CVTP
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // drain the ring and the last prefetch before LDS is reused
     __syncthreads();
     // (Round 3, tried and dropped: requesting the NEXT pass's K / V fragments and first three slice pairs here, in front of this
     // epilogue - slabs moved to the ring's fourth slot - so that their latency runs under it: 2.32-2.35 ms against 2.29-2.31 on the
     // same box (tools/scratch/ab_attn.sh): thirty LDS-DMA issues in front of the stores delay the epilogue by more than the next
     // pass's prologue gains.)
-    a_store_rows<BF, DB>(smem + wid * 32 * OPAD, a.dv + a_head(a.ldv, bh, a.H) + kw * a.ldv.sr, dv, 1.f, a.ldv.sr);
+    a_store_rows<BF, DB>(smem + wid * 32 * OPAD, a.dv + a_head(a.ldv, bh, a.H) + kw * a.ldv.sr, dv, BF ? 1.f : 1.f / kPShiftF16, a.ldv.sr);
     a_store_rows<BF, DB>(smem + wid * 32 * OPAD, a.dk + a_head(a.ldk, bh, a.H) + kw * a.ldk.sr, dk, a.scale, a.ldk.sr);
     if (a.persist) __syncthreads(); // the staging slabs overlap the ring the next block fills
 #ifdef KF_ATTN_TIMELINE

@@ -37,7 +37,7 @@ CODE2NP = {BOOL: np.bool_, U8: np.uint8, I8: np.int8, I16: np.int16, I32: np.int
            F16: np.float16, BF16: np.uint16, F32: np.float32, F64: np.float64}
 
 EXPORTS = [
-    "kf_last_error", "kf_abi_version", "kf_device_count", "kf_set_device", "kf_get_device", "kf_malloc", "kf_free",
+    "kf_last_error", "kf_abi_version", "kf_build_source_sha", "kf_device_count", "kf_set_device", "kf_get_device", "kf_malloc", "kf_free",
     "kf_memcpy_h2d", "kf_memcpy_d2h", "kf_memcpy_d2d", "kf_memset_zero", "kf_stream_create", "kf_stream_destroy",
     "kf_stream_sync", "kf_stream_wait_event", "kf_device_sync", "kf_event_create", "kf_event_destroy", "kf_event_record", "kf_event_sync",
     "kf_event_elapsed_ms", "kf_graph_begin_capture", "kf_graph_end_capture", "kf_graph_launch", "kf_graph_destroy", "kf_profile_enable", "kf_profile_reset", "kf_profile_count", "kf_profile_get", "kf_profile_samples", "kf_knobs_reload",
@@ -90,6 +90,11 @@ class DeviceProps(C.Structure):
 _lib = None
 
 
+def build_source_sha() -> str:
+    """The device-source hash linked into the loaded library (kf_build_source_sha): compare with kfunca_amd._build.device_src_sha()."""
+    return lib().kf_build_source_sha().decode()
+
+
 def lib():
     """Load libkfunca_hip.so; raises if it has not been built (python -m kfunca_amd._build)."""
     global _lib
@@ -99,6 +104,7 @@ def lib():
                               "(there is no CPU fallback)")
         _lib = C.CDLL(str(LIB_PATH))
         _lib.kf_last_error.restype = C.c_char_p
+        _lib.kf_build_source_sha.restype = C.c_char_p
         vp, i64, sz = C.c_void_p, C.c_int64, C.c_size_t
         _lib.kf_malloc.argtypes = [C.POINTER(vp), sz]
         _lib.kf_free.argtypes = [vp]

@@ -149,3 +149,46 @@ def test_lse_bound_of_the_scaled_query_forward():
                 for wrong in (bad, lse * np.float32(1.02)):
                     with pytest.raises(AssertionError):
                         K.attn_check(q, k, v, code, lse=wrong, what="wrong lse", scaled_query=True)
+
+
+@pytest.mark.parametrize("code", [O.BF16, O.F16])
+def test_format_floor_on_the_reference_tests_input_range(code):
+    """Round 5: inputs U(-10, 10), the range the reference's attention test draws from (test/test_nn.py:22-24): logit std 33, the softmax
+    one-hot, most of P below what a 16-bit format (or f32 itself) holds. The relative bounds alone reject ANY 16-bit kernel there - key
+    columns whose dV / dK are sums of terms below the format - and with oracle.checks.format_floor they accept a simulation of the
+    kernels' arithmetic (P 2^14 and dS rounded to the element type before the second product) while every structural defect is still
+    rejected: the floor is 1e-5 of the outputs and less."""
+    Sx = 512
+    rng = np.random.default_rng(77 + code)
+    q, k, v, go = (O.from_float(rng.uniform(-10, 10, (1, 1, Sx, D)).astype(np.float32), code) for _ in range(4))
+    ref = O.attn_ref64(q, k, v, go, code=code)
+    qf, kf, vf, gf = (K.to_f64(x, code)[0, 0] for x in (q, k, v, go))
+    sc = 1.0 / np.sqrt(D)
+    s = np.where(np.arange(Sx)[None, :] <= np.arange(Sx)[:, None], qf @ kf.T * sc, -np.inf)
+    p = np.exp(s - ref["lse"][0, 0][:, None])
+    dp = gf @ vf.T
+    ds = p * (dp - (p * dp).sum(axis=1, keepdims=True))
+    flush32 = lambda x: np.where(np.abs(x) < 2.0 ** -126, 0.0, x)  # noqa: E731  (f32 arithmetic in front of the 16-bit rounding)
+    sh = 2.0 ** K.P_SHIFT_F16 if code == O.F16 else 1.0
+    sim = {"dv": rnd(rnd(flush32(p) * sh, code).T @ gf / sh, code), "dk": rnd(rnd(flush32(ds), code).T @ qf * sc, code),
+           "dq": rnd(rnd(flush32(ds), code) @ kf * sc, code)}
+    fl = K.format_floor(q, k, v, go, code)
+    for n in ("dq", "dk", "dv"):
+        m = K.check_one(n, to16(sim[n][None, None], code), ref, code, what=f"simulated kernel U(-10,10) {n}", floor=fl[n])
+        assert max(m[a] for a in ("element", "row", "head")) < 0.8, (n, m)
+        assert (fl[n] <= 1e-5 * np.abs(ref[n]).max()).all(), n            # the floor is nothing against the outputs themselves
+    if code == O.F16:   # why the floor exists: the same outputs against the relative bounds alone (bf16: ABS_ULP = the flush limit does it)
+        with pytest.raises(AssertionError, match="scale-aware bound"):
+            K.check_one("dv", to16(rnd(rnd(p, code).T @ gf, code)[None, None], code), ref, code, what="no floor, P at its natural scale")
+    # still rejected under the floor: the last 32-query slice missing from a 128-key block's sums, a zeroed key block, all zeros
+    for n0 in (0, 256):
+        blk = slice(n0, n0 + 128)
+        dv_bad, dk_bad = ref["dv"][0, 0].copy(), ref["dk"][0, 0].copy()
+        dv_bad[blk] -= p[Sx - 32:, blk].T @ gf[Sx - 32:]
+        dk_bad[blk] -= ds[Sx - 32:, blk].T @ qf[Sx - 32:] * sc
+        for n, bad in (("dv", dv_bad), ("dk", dk_bad)):
+            with pytest.raises(AssertionError, match="scale-aware bound"):
+                K.check_one(n, to16(bad[None, None], code), ref, code, what="defect", floor=fl[n])
+    for n in ("dq", "dk", "dv"):
+        with pytest.raises(AssertionError, match="scale-aware bound"):
+            K.check_one(n, to16(np.zeros_like(ref[n]), code), ref, code, what="zeros", floor=fl[n])

@@ -65,6 +65,8 @@ S_DSQB, S_WID, S_LDS, S_SCALE, S_MUT, S_OSR = "%[dsqb]", "%[wid]", "%[lds]", "%[
 S_X0, S_X1 = 72, 73
 S_DSB = 74              # pair: dS base of this wave's first key sub-block at slice 0 of the workspace
 V_SRD = 76             # 4-aligned quad: the V fragments' descriptor (prologue only)
+S_PSH = 76             # f16 streams, from the end of the prologue on: 2^P_SHIFT as a float (the multiplier of the P pack, below)
+P_SHIFT = 14           # f16: P is carried as P 2^14 (<= 16384: cannot overflow; subnormal only below 3.7e-9 instead of 6.1e-5), dV scaled back in the epilogue
 N_SGPR_HI = 80
 N_VGPR = 250            # v250 .. v255 stay the compiler's (it needs somewhere to keep scalars it cannot hold in SGPRs)
 
@@ -229,6 +231,22 @@ class Gen:
                             self.valu(f"v_cmp_lt_i32 vcc, {kc}, {vr(RM)}", V(RM), [("vcc", 0)])
                             self.valu(f"v_cndmask_b32_e64 {vr(x)}, {vr(x)}, 0, vcc", V(x) + [("vcc", 0)], V(x))
                         put(e0 + n + 1, (0, 1), m)
+                    if self.f16:
+                        # f16 (round 5): both packs are mixed-precision FMAs that multiply in f32 and round ONCE to f16 - the same number of VALU
+                        # instructions as multiply + multiply + convert. P leaves as P 2^14 (the f16 format holds nothing below 6e-8 and nothing
+                        # exactly below 6.1e-5: at large logits whole key columns of P sat there and dV lost them - VERDICT round 4 #1; dV is
+                        # scaled back in the epilogue); dS = p dP' is rounded once instead of twice and stays at its natural scale (no shift is safe:
+                        # |dS| has no bound the kernel knows).
+                        if n % 2 == 1:
+                            pd = P(ksb, n // 8) + (n % 8) // 2
+                            def pk(x=x, pd=pd):
+                                self.valu(f"v_fma_mixlo_f16 {vr(pd)}, {vr(x - 1)}, {sr(S_PSH)}, 0", V(x - 1), V(pd))
+                                self.valu(f"v_fma_mixhi_f16 {vr(pd)}, {vr(x)}, {sr(S_PSH)}, 0", V(x) + V(pd), V(pd))
+                            put(e0 + n + 2, (0, 2), pk)
+                            dd = DP(ksb, n // 2)
+                            put(m0 + n - 1, (0, 3), lambda x=x, d=d, dd=dd: self.valu(f"v_fma_mixlo_f16 {vr(dd)}, {vr(x - 1)}, {vr(d - 1)}, 0", V(x - 1) + V(d - 1), V(dd)))
+                            put(m0 + n, (0, 3), lambda x=x, d=d, dd=dd: self.valu(f"v_fma_mixhi_f16 {vr(dd)}, {vr(x)}, {vr(d)}, 0", V(x) + V(d) + V(dd), V(dd)))
+                        continue
                     if n % 2 == 1:
                         pd = P(ksb, n // 8) + (n % 8) // 2
                         put(e0 + n + 2, (0, 2), lambda x=x, pd=pd: self.valu(f"{self.cvt} {vr(pd)}, {vr(x - 1)}, {vr(x)}", V(x - 1) + V(x), V(pd)))
@@ -471,6 +489,8 @@ class Gen:
                 e.out.append(Ins(f"ds_read_b128 {vr(VFR(ksb, kk), 4)}, {vr(rbv[kk & 1])} offset:{8192 * ksb + 512 * (kk >> 1)}", "lds", V(rbv[kk & 1]), V(VFR(ksb, kk), 4)))
         e.out.append(Ins("s_waitcnt lgkmcnt(0)", "wait", tag="lgkm"))
         e.barrier()     # every wave has its K fragments out of the ring
+        if self.f16:
+            e.salu(f"s_mov_b32 {sr(S_PSH)}, 0x{(127 + P_SHIFT) << 23:08x}")          # 2^14 (the V descriptor's registers are free from here on)
         # ---- the first two slices on their way (their flight runs under the scaling of K below)
         e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 11")
         e.salu(f"s_add_u32 {sr(S_M0)}, {sr(S_LDS)}, {sr(S_TMP)}")               # DMA destination of this wave's row group in buffer 0
@@ -575,6 +595,9 @@ class Gen:
                         if which == 1:
                             for jj in range(4):
                                 e.valu(f"v_mul_f32 {vr(x[jj])}, %[scl], {vr(x[jj])}")   # dK = scale dS^T Q (%[scale] is scale log2 e in the exact form)
+                        elif self.f16:
+                            for jj in range(4):
+                                e.valu(f"v_ldexp_f32 {vr(x[jj])}, {vr(x[jj])}, {-P_SHIFT}")  # dV was accumulated from P 2^14
                         e.valu(f"{self.cvt} {vr(x[0])}, {vr(x[0])}, {vr(x[1])}")
                         e.valu(f"{self.cvt} {vr(x[1])}, {vr(x[2])}, {vr(x[3])}")
                         e.out.append(Ins(f"ds_write_b64 {vr(st)}, {vr(x[0], 2)} offset:{32 * ksb * STAGE_ROW + 64 * db + 16 * gq}", "ldsw"))
@@ -775,7 +798,7 @@ def selftest():
     return True
 
 
-CLOBBERS = (["memory", "vcc", "scc"] + [f"s{i}" for i in range(36, N_SGPR_HI)] + [f"v{i}" for i in range(N_VGPR)] + [f"a{i}" for i in range(256)])
+CLOBBERS = (["memory", "vcc", "scc", "m0"] + [f"s{i}" for i in range(36, N_SGPR_HI)] + [f"v{i}" for i in range(N_VGPR)] + [f"a{i}" for i in range(256)])
 
 
 def main():

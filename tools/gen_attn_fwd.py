@@ -903,7 +903,9 @@ def selftest():
     return True
 
 
-CLOBBERS = (["memory", "vcc", "scc"] + [f"s{i}" for i in range(36, 80)] + [f"v{i}" for i in range(N_VGPR)] + [f"a{i}" for i in range(256)])
+# m0 is written by every DMA piece; exec is all ones on entry (a full 256-thread block, no divergence in the wrapper) and is restored to -1
+# wherever the stream narrows it (lse store): the block assumes and leaves exec == -1
+CLOBBERS = (["memory", "vcc", "scc", "m0"] + [f"s{i}" for i in range(36, 80)] + [f"v{i}" for i in range(N_VGPR)] + [f"a{i}" for i in range(256)])
 
 
 def render(ins):
