@@ -1755,7 +1755,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) 
         if (a.mutant == 2 && xb == 0 && wid < 2) mut = 4; // defect 2: queries 128..159 contribute nothing to keys 0..127
 #endif
 #ifdef KF_DKV_W4_STAMPS // diagnostic build (tools/attn_dkv_w4_timeline.py): eight cycle sums per wave and block pass into the debug buffer
-        const char *dbg = (const char *)a.dbg + (size_t)(blockIdx.x * 2 + pass) * 4 * 32;
+        const char *dbg = (const char *)a.dbg + (size_t)(blockIdx.x * 2 + pass) * 4 * 64;
 #define KF_DKV_EXTRA , [dbg] "s"(dbg)
 #else
 #define KF_DKV_EXTRA

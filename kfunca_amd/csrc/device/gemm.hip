@@ -633,32 +633,62 @@ __global__ __launch_bounds__(256) void gemm_h_kernel(const GemmArgs g) {
             }
         return;
     }
-    uint16_t *C = (uint16_t *)g.C;
+    // Round 5 (the C4 tail cost 30 % at 2048^3): the accumulators go through LDS - the ring is free now - and every
+    // lane then owns EIGHT consecutive columns of a row: one 16-byte access per operand (C read for beta, the tail's mul / add / aux, C
+    // written) instead of sixteen 2-byte ones per accumulator tuple, 16 lanes per 256-byte row. The arithmetic per element is unchanged
+    // (alpha acc, + beta C, + bias, tail).
+    constexpr int EROW = H_BN + 4; // floats per staged row (16-byte aligned rows, the two lane halves on different banks)
+    static_assert(H_BM * EROW * 4 <= H_STAGES * 2 * H_TILE_BYTES, "the staged tile must fit into the ring");
+    float *stg = (float *)smem;
+    __syncthreads(); // every wave's re-fetched tail tiles have landed (its own vmcnt(0) above) and nobody reads the ring any more
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int64_t n = n0 + wc * 64 + j * 32 + xl;
-            float bias = 0.f;
-            if (g.epilogue == KF_EPI_BIAS_ROW) {
-                const uint16_t bb = ((const uint16_t *)g.bias)[n];
-                bias = BF ? bf16_to_f32(bf16_t{bb}) : f16_to_f32(f16_t{bb});
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                stg[(wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl) * EROW + wc * 64 + j * 32 + xl] = acc[i][j][e];
+    __syncthreads();
+    const bool wide4 = g.ldc % 4 == 0 && (uintptr_t)g.C % 16 == 0;
+#pragma unroll
+    for (int r = 0; r < H_BM * H_BN / 8 / 256; ++r) {
+        const int gi = (int)threadIdx.x + 256 * r, row = gi >> 4, c8 = (gi & 15) * 8;
+        const int64_t m = m0 + row, n = n0 + c8;
+        const float4 lo = *(const float4 *)(stg + row * EROW + c8), hi = *(const float4 *)(stg + row * EROW + c8 + 4);
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = g.alpha * v[e];
+        float *Cf = (float *)g.C + m * g.ldc + n;
+        if (g.beta != 0.f) {
+            float old[8];
+            if (g.c_f32) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) old[e] = Cf[e];
+            } else {
+                h_ld8<BF>(g.C, g.ldc, m, n, old);
             }
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t m = m0 + wr * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hl;
-                float v = g.alpha * acc[i][j][e];
-                float *Cf = (float *)g.C + m * g.ldc + n;
-                if (g.beta != 0.f) {
-                    const uint16_t old = g.c_f32 ? 0 : C[m * g.ldc + n];
-                    v += g.beta * (g.c_f32 ? *Cf : (BF ? bf16_to_f32(bf16_t{old}) : f16_to_f32(f16_t{old})));
-                }
-                v += bias;
-                if (BF) v = g_epi<bf16_t>(g, m, n, v); else v = g_epi<f16_t>(g, m, n, v);
-                if (g.c_f32) *Cf = v;
-                else C[m * g.ldc + n] = (uint16_t)g_pack2<BF>(v, 0.f);
-            }
+            for (int e = 0; e < 8; ++e) v[e] += g.beta * old[e];
         }
+        if (g.epilogue == KF_EPI_BIAS_ROW) {
+            float bias[8];
+            h_ld8<BF>(g.bias, 0, 0, n, bias);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += bias[e];
+        }
+        h_epi8<BF>(g, m, n, v);
+        if (g.c_f32) {
+            if (wide4) {
+                *(float4 *)Cf = float4{v[0], v[1], v[2], v[3]};
+                *(float4 *)(Cf + 4) = float4{v[4], v[5], v[6], v[7]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) Cf[e] = v[e];
+            }
+        } else {
+            h_st8<BF>(g.C, g.ldc, m, n, v);
+        }
+    }
 }
 
 // split-K fold: C = alpha sum_s part[s] + beta C + bias, then the element-wise tail; slices added in slice order (fixed: the result

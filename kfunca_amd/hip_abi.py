@@ -92,7 +92,8 @@ _lib = None
 
 def build_source_sha() -> str:
     """The device-source hash linked into the loaded library (kf_build_source_sha): compare with kfunca_amd._build.device_src_sha()."""
-    return lib().kf_build_source_sha().decode()
+    l = lib()
+    return l.kf_build_source_sha().decode() if hasattr(l, "kf_build_source_sha") else "unstamped"
 
 
 def lib():
@@ -104,7 +105,8 @@ def lib():
                               "(there is no CPU fallback)")
         _lib = C.CDLL(str(LIB_PATH))
         _lib.kf_last_error.restype = C.c_char_p
-        _lib.kf_build_source_sha.restype = C.c_char_p
+        if hasattr(_lib, "kf_build_source_sha"):   # (a diagnostic variant library under KF_HIP_LIB is linked without the stamp)
+            _lib.kf_build_source_sha.restype = C.c_char_p
         vp, i64, sz = C.c_void_p, C.c_int64, C.c_size_t
         _lib.kf_malloc.argtypes = [C.POINTER(vp), sz]
         _lib.kf_free.argtypes = [vp]

@@ -62,7 +62,7 @@ def main():
     ws = H.DevBuf(need)
     nkb = S // 256
     nwg = B * Hh * (nkb // 2)
-    tl = H.DevBuf.from_numpy(np.zeros((nwg, 2, 4, 8), dtype=np.uint32))
+    tl = H.DevBuf.from_numpy(np.zeros((nwg, 2, 4, 16), dtype=np.uint32))
     fn = H.lib().kfdbg_attn_timeline
     fn.argtypes = [ctypes.c_void_p]
     H.attn_fwd(H.BF16, B, Hh, S, S, D, bufs["q"].ptr, bufs["k"].ptr, bufs["v"].ptr, bufs["o"].ptr, lse.ptr)
@@ -79,7 +79,7 @@ def main():
     H.profile_enable(False)
     H.check(fn(None))
     ms = {k: v[0] / v[1] for k, v in H.profile_results().items()}["attn_bwd_dkv_mfma"]
-    t = tl.to_numpy((nwg, 2, 4, 8), np.uint32).astype(np.float64)   # [workgroup, pass, wave, sums]
+    t = tl.to_numpy((nwg, 2, 4, 16), np.uint32).astype(np.float64)   # [workgroup, pass, wave, sums]
     # slices per wave and pass by kind, from the shape: key block x of nkb runs slices 8 x .. S / 32 - 1; wave w: idle 2 w, diag0 1, diag1 1, steady the rest
     tot = S // 32
     n_pass = nwg * 2
@@ -89,6 +89,8 @@ def main():
     n_steady = t[..., 7].sum()
     print(f"  steady slice (barrier to barrier)      {t[..., 1].sum() / n_steady:7.0f} cycles   (64 MFMAs = 2048 of matrix pipe: {100 * 2048 * n_steady / t[..., 1].sum():.0f} % busy), "
           f"{steady_per_cu:.1f} per wave and pass")
+    sA, sB, sC = (t[..., 8 + i].sum() / n_steady for i in range(3))
+    print(f"    of which slot S {sA:.0f} | slot dP {sB:.0f} | slot dV {sC:.0f} | barrier wait + barrier + slot dK {t[..., 1].sum() / n_steady - sA - sB - sC:.0f}   (16 MFMAs = 512 of matrix pipe each)")
     for i, (nm, per_wave) in enumerate((("diag1 slice (sub-block 1 on the diagonal)", 1), ("diag0 slice (sub-block 0 on the diagonal, 32 MFMAs)", 1), ("idle slice (keys above the slice: no MFMAs)", 3))):
         n = n_pass * 4 * (per_wave if i < 2 else 0) if i < 2 else n_pass * (0 + 2 + 4 + 6)
         print(f"  {nm:52s} {t[..., 2 + i].sum() / max(n, 1):7.0f} cycles each, {n / (n_pass * 4):.1f} per wave and pass")

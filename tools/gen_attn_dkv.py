@@ -90,6 +90,7 @@ class Gen:
     # non-temporal: measured same-box against write-through (sc0 sc1), sc1 and plain stores (tools/scratch/ab_dkv.sh): this kernel's time is the same
     # under all four (1.99 - 2.04 ms on that box), the dQ kernel that streams the dS back runs 3 - 4 % faster behind nt stores (0.95 - 0.97 vs 1.00 ms)
     store_policy = "nt"
+    skip_tail_dma = True    # (A/B: --no-skip-tail-dma)
 
     def __init__(self, f16=False, mutant=False, ds=True, ablate=(), stamps=False, scaled=False):
         # scaled: K is multiplied by scale log2(e) and ROUNDED to the element type once per block, the row constant is -lse log2(e), and the S
@@ -259,7 +260,15 @@ class Gen:
             for r in (RB[0], RB[1], TB[0], TB[1], LR):
                 self.valu(f"v_xor_b32 {vr(r)}, {BUF}, {vr(r)}", V(r), V(r))
         put(48, (-3, 0), after_barrier)
-        put(49, (3, 0), self.dma_slice)
+        def dma_guarded():
+            # slice it + 2 of this pass - if there is one: round 4 re-fetched the clamped last slice twice per pass (never used), and the
+            # epilogue waited ~2.5 k cycles for those ten pieces (tools/attn_dkv_w4_timeline.py: "last barrier -> epilogue")
+            self.salu(f"s_add_u32 {sr(S_TMP)}, {sr(S_IT)}, 2")
+            self.salu(f"s_cmp_lt_u32 {sr(S_TMP)}, {sr(S_NS)}")
+            self.salu(f"s_cbranch_scc0 L_nodma_{name}_%=")
+            self.dma_slice()
+            self.label(f"L_nodma_{name}_%=")
+        put(49, (3, 0), dma_guarded if self.skip_tail_dma else self.dma_slice)
         def book():
             self.salu(f"s_xor_b32 {sr(S_M0)}, {sr(S_M0)}, {BUF}")
             self.advance_dma()
@@ -291,7 +300,11 @@ class Gen:
         self.label(f"L_{name}_%=")
         for g in range(64):
             slot, j = g // 16, g % 16
+            if self.stamps and kind == "steady" and g in (0, 16, 32):
+                self.salu(f"s_memtime s[{92 + 2 * (g // 16)}:{93 + 2 * (g // 16)}]")     # slot boundaries of a steady slice (consumed behind the barrier's wait)
             if g == 48:
+                if self.stamps and kind == "steady":
+                    self.salu("s_memtime s[98:99]")                                          # in front of the barrier's wait
                 # this wave's pieces of the NEXT slice have landed (the stores issued behind them may still be on their way), every LDS
                 # read of the current buffer has returned; then everyone's
                 self.out.append(Ins(f"s_waitcnt vmcnt({prev_stores}) lgkmcnt(0)", "wait", tag="vmlgkm"))
@@ -304,6 +317,10 @@ class Gen:
                 self.stamp_take()
                 if self.stamps and kind == "steady":
                     self.salu("s_add_u32 s90, s90, 1")        # bucket 6 is written at the very end: until then s90 counts the steady slices
+                    # slots S | dP | dV of this slice (gap 0 -> 16 -> 32 -> the barrier's wait); what is left of the slice is wait + barrier + slot dK
+                    for acc, hi, lo in ((91, 94, 92), (100, 96, 94), (101, 98, 96)):
+                        self.salu(f"s_sub_u32 s83, s{hi}, s{lo}")
+                        self.salu(f"s_add_u32 s{acc}, s{acc}, s83")
             ksb, i = j >> 3, j & 7
             if slot < 2:
                 ksb, i = CHAIN_ORDER[j]
@@ -330,7 +347,7 @@ class Gen:
     def prologue(self):
         e = self
         if self.stamps:
-            for i in range(84, 91):
+            for i in list(range(84, 92)) + [100, 101]:
                 e.salu(f"s_mov_b32 s{i}, 0")
             e.salu("s_memtime s[80:81]")
             e.salu("s_waitcnt lgkmcnt(0)")
@@ -565,7 +582,16 @@ class Gen:
         e = self
         lane, r, h = T[0], T[1], T[2]
         e.label("L_epilogue_%=")
-        e.out.append(Ins("s_waitcnt vmcnt(0) lgkmcnt(0)", "wait", tag="vmlgkm"))
+        # nothing this wave has in flight writes LDS any more (no DMA beyond the pass's last slice), and its dS stores read their registers
+        # at issue: only the LDS reads of the last slice's tail have to be back before their registers are reused
+        e.out.append(Ins("s_waitcnt lgkmcnt(0)" if self.skip_tail_dma else "s_waitcnt vmcnt(0) lgkmcnt(0)", "wait", tag="vmlgkm"))
+        if self.skip_tail_dma:
+            # (a pass WITHOUT slices - a key block beyond the last query - comes here straight from the prologue, whose second request is
+            #  still in flight: it must have landed before the barrier below lets the next pass's K tiles into the ring)
+            e.salu(f"s_cmp_lg_u32 {sr(S_NS)}, 0")
+            e.salu("s_cbranch_scc1 L_epi_go_%=")
+            e.out.append(Ins("s_waitcnt vmcnt(0)", "wait", tag="vm"))
+            e.label("L_epi_go_%=")
         self.stamp(5)
         e.salu("s_nop 15")
         e.valu(f"v_mbcnt_lo_u32_b32 {vr(lane)}, -1, 0")
@@ -620,13 +646,17 @@ class Gen:
             e.valu(f"v_mov_b32 {vr(32 + 7)}, s90")                            # [7] = the number of steady slices
             e.salu("s_mov_b32 s90, 0")
             self.stamp(6)
-            e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 5")                  # 8 dwords per wave (%[dbg] already points at this pass)
+            e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 6")                  # 16 dwords per wave (%[dbg] already points at this pass)
             e.valu(f"v_mov_b32 {vr(T[0])}, {sr(S_TMP)}")
             for i in range(7):
                 e.valu(f"v_mov_b32 {vr(32 + i)}, s{84 + i}")
+            for i, r in enumerate((91, 100, 101)):
+                e.valu(f"v_mov_b32 {vr(40 + i)}, s{r}")                        # [8..10] = steady slices: slot S, slot dP, slot dV
+            e.valu(f"v_mov_b32 {vr(43)}, 0")
             e.salu("s_mov_b64 exec, 1")
             e.out.append(Ins(f"global_store_dwordx4 {vr(T[0])}, {vr(32, 4)}, %[dbg]", "vmem"))
             e.out.append(Ins(f"global_store_dwordx4 {vr(T[0])}, {vr(36, 4)}, %[dbg] offset:16", "vmem"))
+            e.out.append(Ins(f"global_store_dwordx4 {vr(T[0])}, {vr(40, 4)}, %[dbg] offset:32", "vmem"))
             e.salu("s_mov_b64 exec, -1")
             e.out.append(Ins("s_waitcnt vmcnt(0)", "wait", tag="vm"))
         e.barrier()   # the next block's DMA reuses the slice buffers: every wave is past its last reads (they are, since the last slice's barrier) - kept for the vmcnt bookkeeping of the prologue
@@ -809,10 +839,12 @@ def main():
     ap.add_argument("--dump", default="", help="print one variant's stream")
     ap.add_argument("--store-policy", default=Gen.store_policy, help="cache bits of the dS stores (experiment)")
     ap.add_argument("--scaled", action="store_true", help="--dump / --check-only look at the scaled-K stream (the file always holds both forms)")
+    ap.add_argument("--no-skip-tail-dma", action="store_true", help="A/B: request the two clamped slices behind a pass's last one, as round 4 did")
     ap.add_argument("--stamps", action="store_true", help="diagnostic build: s_memtime sums per slice kind, prologue, epilogue (needs -DKF_DKV_W4_STAMPS)")
     args = ap.parse_args()
     abl = tuple(x for x in args.ablate.split(",") if x)
     Gen.store_policy = args.store_policy
+    Gen.skip_tail_dma = not args.no_skip_tail_dma
     assert selftest()
     g = Gen(False, ablate=abl, stamps=args.stamps, scaled=args.scaled).build()
     probs = check(g.out) + ([] if args.scaled else check(Gen(False, ablate=abl, stamps=args.stamps, scaled=True).build().out))
@@ -848,7 +880,7 @@ def main():
 // (KF_ATTN_SCALED_OPERANDS: %[scale] = the softmax scale, row constant -lse log2 e).
 #pragma once
 #define KF_DKV_W4_LDS_BYTES {LDS_BYTES}
-#define KF_DKV_W4_CLOBBERS {", ".join('"' + c + '"' for c in CLOBBERS + ([f"s{i}" for i in range(80, 91)] if args.stamps else []))}
+#define KF_DKV_W4_CLOBBERS {", ".join('"' + c + '"' for c in CLOBBERS + ([f"s{i}" for i in range(80, 102)] if args.stamps else []))}
 #ifdef KF_MUTANT
 {four(True)}
 #else
