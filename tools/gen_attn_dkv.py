@@ -66,6 +66,7 @@ S_X0, S_X1 = 72, 73
 S_DSB = 74              # pair: dS base of this wave's first key sub-block at slice 0 of the workspace
 V_SRD = 76             # 4-aligned quad: the V fragments' descriptor (prologue only)
 S_PSH = 76             # f16 streams, from the end of the prologue on: 2^P_SHIFT as a float (the multiplier of the P pack, below)
+S_M0C, S_MKT, S_MKC = 77, 78, 79   # from the end of the prologue on: DMA destination of the row constants; the ring's XOR masks (tiles | constants)
 P_SHIFT = 14           # f16: P is carried as P 2^14 (<= 16384: cannot overflow; subnormal only below 3.7e-9 instead of 6.1e-5), dV scaled back in the epilogue
 N_SGPR_HI = 80
 N_VGPR = 250            # v250 .. v255 stay the compiler's (it needs somewhere to keep scalars it cannot hold in SGPRs)
@@ -77,10 +78,20 @@ CHAIN_ORDER = [(1, 0)] + [(0, i) for i in range(8)] + [(1, i) for i in range(1, 
 RING_FREE_S = [1] + [8 + j for j in range(1, 8)]
 NEXTQ_G = [56 + j for j in range(8)]
 
-BUF = 32768             # two slice buffers, toggled by XOR
+# Round 5: a FOUR-slot slice ring in the 64 KiB the two-slot ring had (round 4: two slots of 32 KiB, half of each unused). A slot = the Q tile
+# (8 KiB) + the dO tile (8 KiB); the 64 row constants of a slice live in their own 4 x 256 B area behind the ring. The DMA of slice it + 2 then
+# overwrites the slot slice it - 2 was read from - a whole slice behind every wave's last read of it - so the slice barrier no longer has to
+# prove "all my LDS reads of this slot have returned" (s_waitcnt lgkmcnt(0) in front of it: the transposed Q reads issued in the eight gaps
+# before stalled there every slice: tools/attn_dkv_w4_timeline.py, "barrier wait + barrier + slot dK" 993 cycles for 512 of matrix pipe); it only
+# publishes the next slice's arrival. Slot b -> b + 1 (mod 4) is an XOR with 0x4000 (b even) or 0xC000 (b odd): one SGPR mask that flips bit
+# 15 every slice; the constants' area steps by 256 the same way (0x100 / 0x300). (All of it relies on the dynamic LDS starting at a
+# multiple of 64 KiB - offset 0 - as the two-slot XOR did.)
+BUF = 16384             # one ring slot: Q tile | dO tile
+NBUF = 4
 SLICE_DO = 8192         # dO tile behind the Q tile
-SLICE_C = 16384         # 32 x -lse log2 e | 32 x -delta
-STAGE0 = 2 * BUF
+CBASE = NBUF * BUF      # 4 x (32 x -lse / scale | 32 x -delta)
+CSLOT = 256
+STAGE0 = CBASE + NBUF * CSLOT
 STAGE_ROW = 272
 LDS_BYTES = STAGE0 + 4 * 64 * STAGE_ROW
 DS_TILE = 2048
@@ -90,7 +101,7 @@ class Gen:
     # non-temporal: measured same-box against write-through (sc0 sc1), sc1 and plain stores (tools/scratch/ab_dkv.sh): this kernel's time is the same
     # under all four (1.99 - 2.04 ms on that box), the dQ kernel that streams the dS back runs 3 - 4 % faster behind nt stores (0.95 - 0.97 vs 1.00 ms)
     store_policy = "nt"
-    skip_tail_dma = True    # (A/B: --no-skip-tail-dma)
+    skip_tail_dma = False   # (A/B: --skip-tail-dma; measured same-box: no gain, 1.98 - 2.07 ms with it against 1.97 - 2.00 without)
 
     def __init__(self, f16=False, mutant=False, ds=True, ablate=(), stamps=False, scaled=False):
         # scaled: K is multiplied by scale log2(e) and ROUNDED to the element type once per block, the row constant is -lse log2(e), and the S
@@ -149,7 +160,7 @@ class Gen:
 
     def lds_const(self, dst, g, off):           # 4 of the 16 row constants of this lane: rows 8 g + 4 h + {0..3}
         if "lds" in self.ablate: return
-        self.out.append(Ins(f"ds_read_b128 {vr(dst + 4 * g, 4)}, {vr(LR)} offset:{SLICE_C + off + 32 * g}", "lds", V(LR), V(dst + 4 * g, 4)))
+        self.out.append(Ins(f"ds_read_b128 {vr(dst + 4 * g, 4)}, {vr(LR)} offset:{off + 32 * g}", "lds", V(LR), V(dst + 4 * g, 4)))
 
     def barrier(self): self.out.append(Ins("s_barrier", "barrier"))
 
@@ -168,11 +179,17 @@ class Gen:
         self.dma_piece(Q_SRD, DMAQ, S_QOFF, 896, 128)
         self.dma_piece(DO_SRD, DMAD, S_DOOFF, SLICE_DO, 0)
         self.dma_piece(DO_SRD, DMAD, S_DOOFF, SLICE_DO + 896, 128)
-        self.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 11")
-        self.salu(f"s_sub_u32 {sr(S_TMP)}, {sr(S_M0)}, {sr(S_TMP)}")        # (M0 base carries this wave's 2048-byte row group; the constants sit at the buffer's own offset)
-        self.salu(f"s_add_u32 m0, {sr(S_TMP)}, {SLICE_C}")
+        self.salu(f"s_mov_b32 m0, {sr(S_M0C)}")
         self.salu("s_nop 0")
         self.out.append(Ins(f"buffer_load_dword {vr(DMAC)}, {sr(C_SRD, 4)}, {sr(S_COFF)} offen lds", "dma", V(DMAC)))
+
+    def ring_step(self):
+        """DMA destinations one ring slot on (slot b -> b + 1 mod 4: XOR 0x4000 from an even slot, 0xC000 from an odd one; the read bases
+        made the same step behind the barrier, with the same masks), then the masks for the next slice."""
+        self.salu(f"s_xor_b32 {sr(S_M0)}, {sr(S_M0)}, {sr(S_MKT)}")
+        self.salu(f"s_xor_b32 {sr(S_M0C)}, {sr(S_M0C)}, {sr(S_MKC)}")
+        self.salu(f"s_xor_b32 {sr(S_MKT)}, {sr(S_MKT)}, {2 * BUF}")
+        self.salu(f"s_xor_b32 {sr(S_MKC)}, {sr(S_MKC)}, {2 * CSLOT}")
 
     def advance_dma(self):
         """Source offsets one slice further, saturating at the block's last slice (a clamped slice is fetched again and never used)."""
@@ -257,8 +274,9 @@ class Gen:
                         put(m0 + n + 2, (0, 4), lambda d=d, dd=dd: self.valu(f"{self.cvt} {vr(dd)}, {vr(d - 1)}, {vr(d)}", V(d - 1) + V(d), V(dd)))
         # ---- behind the barrier: ring toggle, DMA of slice it + 2 into the buffer this slice has finished with, then this slice's dS
         def after_barrier():
-            for r in (RB[0], RB[1], TB[0], TB[1], LR):
-                self.valu(f"v_xor_b32 {vr(r)}, {BUF}, {vr(r)}", V(r), V(r))
+            for r in (RB[0], RB[1], TB[0], TB[1]):
+                self.valu(f"v_xor_b32 {vr(r)}, {sr(S_MKT)}, {vr(r)}", V(r), V(r))
+            self.valu(f"v_xor_b32 {vr(LR)}, {sr(S_MKC)}, {vr(LR)}", V(LR), V(LR))
         put(48, (-3, 0), after_barrier)
         def dma_guarded():
             # slice it + 2 of this pass - if there is one: round 4 re-fetched the clamped last slice twice per pass (never used), and the
@@ -270,7 +288,7 @@ class Gen:
             self.label(f"L_nodma_{name}_%=")
         put(49, (3, 0), dma_guarded if self.skip_tail_dma else self.dma_slice)
         def book():
-            self.salu(f"s_xor_b32 {sr(S_M0)}, {sr(S_M0)}, {BUF}")
+            self.ring_step()
             self.advance_dma()
         put(50, (4, 0), book)
         nst = 0
@@ -307,7 +325,12 @@ class Gen:
                     self.salu("s_memtime s[98:99]")                                          # in front of the barrier's wait
                 # this wave's pieces of the NEXT slice have landed (the stores issued behind them may still be on their way), every LDS
                 # read of the current buffer has returned; then everyone's
-                self.out.append(Ins(f"s_waitcnt vmcnt({prev_stores}) lgkmcnt(0)", "wait", tag="vmlgkm"))
+                # (no lgkmcnt here: the slot this slice reads is not rewritten before slice it + 2's request, two barriers on; the stamps build
+                #  keeps the full wait - it consumes its clock requests behind it)
+                if self.stamps:
+                    self.out.append(Ins(f"s_waitcnt vmcnt({prev_stores}) lgkmcnt(0)", "wait", tag="vmlgkm"))
+                else:
+                    self.out.append(Ins(f"s_waitcnt vmcnt({prev_stores})", "wait", tag="vm"))
                 self.barrier()
                 # diagnostic build: the clock requested behind the PREVIOUS barrier has long returned (the wait above covers it): the period
                 # that ended there is booked now - one slice late, so a kind's bucket holds its predecessor's period at every change of
@@ -460,7 +483,8 @@ class Gen:
         e.valu(f"v_lshl_add_u32 {vr(TB[0])}, {vr(t2)}, 3, {vr(t0)}")
         e.valu(f"v_add_u32 {vr(TB[0])}, {sr(S_LDS)}, {vr(TB[0])}")
         e.valu(f"v_xor_b32 {vr(TB[1])}, 32, {vr(TB[0])}")
-        e.valu(f"v_lshl_add_u32 {vr(LR)}, {vr(h)}, 4, {sr(S_LDS)}")            # row constants: 16 h (+ 32 g + the slice offsets as immediates)
+        e.valu(f"v_lshl_add_u32 {vr(LR)}, {vr(h)}, 4, {sr(S_LDS)}")            # row constants: 16 h (+ 32 g + 128 for -delta as immediates), slot 0 of their area
+        e.valu(f"v_add_u32 {vr(LR)}, {CBASE}, {vr(LR)}")
         # DMA source offsets: row 8 w + row7 (row7 = (lane >> 2) & 7), chunk 4 sub32 + (slot ^ x), x = ((w & 1) << 1) | ((lane >> 4) & 1)
         e.valu(f"v_bfe_u32 {vr(t0)}, {vr(lane)}, 2, 3")
         e.valu(f"v_and_b32 {vr(t1)}, 3, {vr(lane)}")
@@ -510,12 +534,15 @@ class Gen:
             e.salu(f"s_mov_b32 {sr(S_PSH)}, 0x{(127 + P_SHIFT) << 23:08x}")          # 2^14 (the V descriptor's registers are free from here on)
         # ---- the first two slices on their way (their flight runs under the scaling of K below)
         e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 11")
-        e.salu(f"s_add_u32 {sr(S_M0)}, {sr(S_LDS)}, {sr(S_TMP)}")               # DMA destination of this wave's row group in buffer 0
+        e.salu(f"s_add_u32 {sr(S_M0)}, {sr(S_LDS)}, {sr(S_TMP)}")               # DMA destination of this wave's row group in ring slot 0
+        e.salu(f"s_add_u32 {sr(S_M0C)}, {sr(S_LDS)}, {CBASE}")                  # ... and of the row constants (every wave fetches all 64: identical bytes)
+        e.salu(f"s_mov_b32 {sr(S_MKT)}, {BUF}")                                 # slot 0 -> 1
+        e.salu(f"s_mov_b32 {sr(S_MKC)}, {CSLOT}")
         e.dma_slice()
-        e.salu(f"s_xor_b32 {sr(S_M0)}, {sr(S_M0)}, {BUF}")
+        e.ring_step()
         e.advance_dma()
         e.dma_slice()
-        e.salu(f"s_xor_b32 {sr(S_M0)}, {sr(S_M0)}, {BUF}")
+        e.ring_step()                                                           # the DMA side now points at slot 2, the masks are slot 0 -> 1 again: the loop's first step
         e.advance_dma()
         if self.scaled:
             # K *= scale log2(e): unpack the pair, two multiplies, pack (64 registers, once per block)
@@ -839,12 +866,12 @@ def main():
     ap.add_argument("--dump", default="", help="print one variant's stream")
     ap.add_argument("--store-policy", default=Gen.store_policy, help="cache bits of the dS stores (experiment)")
     ap.add_argument("--scaled", action="store_true", help="--dump / --check-only look at the scaled-K stream (the file always holds both forms)")
-    ap.add_argument("--no-skip-tail-dma", action="store_true", help="A/B: request the two clamped slices behind a pass's last one, as round 4 did")
+    ap.add_argument("--skip-tail-dma", action="store_true", help="A/B: no DMA request beyond a pass's last slice (measured: no gain)")
     ap.add_argument("--stamps", action="store_true", help="diagnostic build: s_memtime sums per slice kind, prologue, epilogue (needs -DKF_DKV_W4_STAMPS)")
     args = ap.parse_args()
     abl = tuple(x for x in args.ablate.split(",") if x)
     Gen.store_policy = args.store_policy
-    Gen.skip_tail_dma = not args.no_skip_tail_dma
+    Gen.skip_tail_dma = args.skip_tail_dma
     assert selftest()
     g = Gen(False, ablate=abl, stamps=args.stamps, scaled=args.scaled).build()
     probs = check(g.out) + ([] if args.scaled else check(Gen(False, ablate=abl, stamps=args.stamps, scaled=True).build().out))
