@@ -335,13 +335,13 @@ def cpu_baseline():
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` without a torchrun environment: start the N ranks as CHILD processes (this process has
     not touched, and never touches, a GPU), pass rank 0's output through and return the worst exit status."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    # rendezvous over a FILE store in a fresh temporary directory (kfunca_amd/parallel.py, KF_RDZV_FILE): round 4 picked a TCP port by
+    # bind-then-close, which any other job on the box could take in between
+    import tempfile
+    rdzv = Path(tempfile.mkdtemp(prefix="kf_rdzv_")) / "store"
     procs = []
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), KF_RDZV_FILE=str(rdzv))
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
     out0, codes = supervise(procs, RANK_TIMEOUT_S)

@@ -1722,8 +1722,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
 #include KF_DKV_W4_INC
 constexpr int K5B = 256; // keys per block
 // SQ: the scaled-K form (KF_ATTN_SCALED_OPERANDS; the row constants must then be -lse log2 e); default: exact f32 scores, row constants -lse / scale
-template <bool BF, bool DS, bool SQ>
+// D64: the head-size-64 stream (round 5; exact scores only: SQ must be false)
+template <bool BF, bool DS, bool SQ, bool D64 = false>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) {
+    static_assert(!(SQ && D64), "the scaled-K form exists for head size 128 only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int xb0;
     int64_t bh;
@@ -1765,7 +1767,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) 
         [qsr] "s"(qsr), [dosr] "s"(dosr), [kvsr] "s"(kvsr), [osr] "s"(osr), [s0] "s"(s0), [ns] "s"(ns), [dsqb] "s"(dsqb), [wid] "s"(wid),       \
         [scale] "s"(scale), [scl] "s"(scl), [lds] "s"(lds), [mut] "s"(mut) KF_DKV_EXTRA
 #define KF_DKV_ASM(TEXT) asm volatile(TEXT : : KF_DKV_OPERANDS : KF_DKV_W4_CLOBBERS)
-        if constexpr (SQ) {
+        if constexpr (D64) {
+            if constexpr (BF && DS) KF_DKV_ASM(KF_DKV_W4_D64_ASM_BF16_DS);
+            else if constexpr (BF) KF_DKV_ASM(KF_DKV_W4_D64_ASM_BF16_NODS);
+            else if constexpr (DS) KF_DKV_ASM(KF_DKV_W4_D64_ASM_F16_DS);
+            else KF_DKV_ASM(KF_DKV_W4_D64_ASM_F16_NODS);
+        } else if constexpr (SQ) {
             if constexpr (BF && DS) KF_DKV_ASM(KF_DKV_W4_ASM_BF16_DS_SQ);
             else if constexpr (BF) KF_DKV_ASM(KF_DKV_W4_ASM_BF16_NODS_SQ);
             else if constexpr (DS) KF_DKV_ASM(KF_DKV_W4_ASM_F16_DS_SQ);
@@ -2683,12 +2690,12 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
     if (mfma_ok(dtype, Sq, Skv, D)) {
         const bool bf = dtype == KF_BF16;
         // round 4: 64 keys per wave (attn_bwd_dkv_w4_kernel) wherever its shape conditions hold; KF_ATTN_DKV_V4 keeps the 32-key kernel (A/B)
-        const bool dkv_w4 = D == AD && Skv % K5B == 0 && a.lk.sr == a.lv.sr && a.ldk.sr == a.ldv.sr && (uint64_t)Sq * (uint64_t)std::max(a.lq.sr, a.ldo.sr) < (1ull << 32) &&
+        const bool dkv_w4 = (D == AD || D == 64) && Skv % K5B == 0 && a.lk.sr == a.lv.sr && a.ldk.sr == a.ldv.sr && (uint64_t)Sq * (uint64_t)std::max(a.lq.sr, a.ldo.sr) < (1ull << 32) &&
                             (uint64_t)K5B * (uint64_t)std::max(a.lk.sr, a.ldk.sr) < (1ull << 31) && (uint64_t)((const char *)a.ndelta - (const char *)a.nlse) < (1ull << 31) &&
                             !knob(KNOB_ATTN_DKV_V4);
         // exact f32 scores everywhere by default (exponent = (s - lse / scale) * scale log2 e: the row constant is -lse / scale); only the opt-in
         // scaled-K form of the generated stream scales K by scale log2 e once per block and wants -lse log2 e
-        const bool dkv_sq = dkv_w4 && knob(KNOB_ATTN_SCALED_OPERANDS);
+        const bool dkv_sq = dkv_w4 && D == AD && knob(KNOB_ATTN_SCALED_OPERANDS);
         const float rscale = dkv_sq ? kLog2e : 1.0f / scale;
         {
             KF_PROF("attn_bwd_delta", st);
@@ -2746,10 +2753,16 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
         if ((rc = set_lds(attn_bwd_dkv_w4_kernel<BF_, DS_, SQ_>, KF_DKV_W4_LDS_BYTES)) != KF_OK) return rc;        \
         attn_bwd_dkv_w4_kernel<BF_, DS_, SQ_><<<gk5, 256, KF_DKV_W4_LDS_BYTES, st>>>(a);                          \
     }
-#define KF_DKV5S(BF_, DS_) { if (dkv_sq) KF_DKV5(BF_, DS_, true) else KF_DKV5(BF_, DS_, false) }
+#define KF_DKV5D(BF_, DS_)                                                                                              \
+    {                                                                                                                   \
+        if ((rc = set_lds(attn_bwd_dkv_w4_kernel<BF_, DS_, false, true>, KF_DKV_W4_LDS_BYTES)) != KF_OK) return rc;     \
+        attn_bwd_dkv_w4_kernel<BF_, DS_, false, true><<<gk5, 256, KF_DKV_W4_LDS_BYTES, st>>>(a);                        \
+    }
+#define KF_DKV5S(BF_, DS_) { if (D == 64) KF_DKV5D(BF_, DS_) else if (dkv_sq) KF_DKV5(BF_, DS_, true) else KF_DKV5(BF_, DS_, false) }
                     if (bf) { if (keep_ds) KF_DKV5S(true, true) else KF_DKV5S(true, false) }
                     else { if (keep_ds) KF_DKV5S(false, true) else KF_DKV5S(false, false) }
 #undef KF_DKV5S
+#undef KF_DKV5D
 #undef KF_DKV5
                 } else if (D == 64) {
                     if (bf) { if (keep_ds) KF_DKV(true, true, 64) else KF_DKV(true, false, 64) }

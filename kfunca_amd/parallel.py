@@ -75,10 +75,16 @@ class ProcessGroup:
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", str(self.rank)))
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
         if not dist.is_initialized():
-            dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            rdzv = os.environ.get("KF_RDZV_FILE")
+            if rdzv:
+                # ranks this repository's own launchers started (bench.py / tools/block_bench.py --gpus N without torchrun): a FILE store in a
+                # fresh temporary directory of the parent - no TCP port to guess, nothing another job on the box can race for
+                dist.init_process_group("gloo", init_method=f"file://{rdzv}", rank=self.rank, world_size=self.world)
+            else:   # under torch.distributed.run: its MASTER_ADDR / MASTER_PORT
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29517")
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
         self.backend = backend
         self.comm = None
         if backend == "auto":

@@ -47,12 +47,13 @@ WSHAPES = ((DM, 3 * DM), (DM, DM), (DM, F), (DM, F), (F, DM))  # qkv, out-proj, 
 def launch_ranks(n: int) -> int:
     """Start the n ranks as CHILD processes (this process has not touched, and never touches, a GPU), pass rank 0's line through and
     return the worst exit status."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    # rendezvous over a FILE store in a fresh temporary directory (kfunca_amd/parallel.py, KF_RDZV_FILE): round 4 picked a TCP port by
+    # bind-then-close, which any other job on the box could take in between
+    import tempfile
+    rdzv = Path(tempfile.mkdtemp(prefix="kf_rdzv_")) / "store"
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), KF_RDZV_FILE=str(rdzv))
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
     from bench import RANK_TIMEOUT_S, supervise  # bounded: a rank that fails or hangs ends the others (bench.py)

@@ -51,10 +51,7 @@ def RING(j): return 80 + 4 * j
 RB, TB, LR = (112, 113), (114, 115), 116
 DMAQ, DMAD, DMAC, DSOFF, RM = 117, 118, 119, 120, 121
 T = [64, 65, 66, 67, 68, 69]   # prologue / epilogue temporaries: the P registers, idle then
-def KFR(ksb, kk): return 122 + 32 * ksb + 4 * kk
-def VFR(ksb, kk): return 186 + 32 * ksb + 4 * kk
-def DV(ksb, db): return 64 * ksb + 16 * db
-def DK(ksb, db): return 128 + 64 * ksb + 16 * db
+# (K / V fragments and the dV / dK accumulators depend on the head size: Gen.KFR / VFR / DV / DK)
 
 Q_SRD, DO_SRD, C_SRD, O_SRD = 36, 40, 44, 48
 S_QOFF, S_DOOFF, S_COFF, S_QSTEP, S_DOSTEP, S_QMAX, S_DOMAX, S_CMAX = 52, 53, 54, 55, 56, 57, 58, 59
@@ -103,7 +100,18 @@ class Gen:
     store_policy = "nt"
     skip_tail_dma = False   # (A/B: --skip-tail-dma; measured same-box: no gain, 1.98 - 2.07 ms with it against 1.97 - 2.00 without)
 
-    def __init__(self, f16=False, mutant=False, ds=True, ablate=(), stamps=False, scaled=False):
+    def __init__(self, f16=False, mutant=False, ds=True, ablate=(), stamps=False, scaled=False, D=128):
+        # D = 64 (round 5, VERDICT round 4 #4: the reference's second fast head size, causal_attention_kernel.cu:40-52): the same stream with half
+        # the k-steps and half the column blocks - 32 MFMAs per slice in four slots of 8 (slice64), the same per-score VALU work, so the
+        # slice is VALU-issue bound where D = 128 is matrix bound. The LDS images keep their 256-byte rows with only the first 128 used: every
+        # address formula, swizzle and read instruction is the D = 128 one, a tile's 8-row group is ONE 1-KiB DMA piece instead of two.
+        assert D in (64, 128) and not (scaled and D == 64)
+        self.D, self.NKK, self.NDB = D, D // 16, D // 32
+        kf0 = 122
+        self.KFR = lambda ksb, kk: kf0 + 4 * self.NKK * ksb + 4 * kk
+        self.VFR = lambda ksb, kk: kf0 + 8 * self.NKK + 4 * self.NKK * ksb + 4 * kk
+        self.DV = lambda ksb, db: 16 * self.NDB * ksb + 16 * db
+        self.DK = lambda ksb, db: 32 * self.NDB + 16 * self.NDB * ksb + 16 * db
         # scaled: K is multiplied by scale log2(e) and ROUNDED to the element type once per block, the row constant is -lse log2(e), and the S
         # accumulator is the exponent (no multiply per score: -32 VALU per slice, no scaling pass in the prologue... and a score error of
         # eps scale sum|q k| that grows with the logits; KF_ATTN_SCALED_OPERANDS). Default: exact f32 scores - K as it is, the row
@@ -176,9 +184,9 @@ class Gen:
         """This wave's pieces of one slice: rows 8 w .. 8 w + 7 of the Q tile and of the dO tile (two 1-KiB pieces each), and the 64 row
         constants (every wave fetches them: identical bytes, uniform counts)."""
         self.dma_piece(Q_SRD, DMAQ, S_QOFF, 0, 0)
-        self.dma_piece(Q_SRD, DMAQ, S_QOFF, 896, 128)
+        if self.D == 128: self.dma_piece(Q_SRD, DMAQ, S_QOFF, 896, 128)
         self.dma_piece(DO_SRD, DMAD, S_DOOFF, SLICE_DO, 0)
-        self.dma_piece(DO_SRD, DMAD, S_DOOFF, SLICE_DO + 896, 128)
+        if self.D == 128: self.dma_piece(DO_SRD, DMAD, S_DOOFF, SLICE_DO + 896, 128)
         self.salu(f"s_mov_b32 m0, {sr(S_M0C)}")
         self.salu("s_nop 0")
         self.out.append(Ins(f"buffer_load_dword {vr(DMAC)}, {sr(C_SRD, 4)}, {sr(S_COFF)} offen lds", "dma", V(DMAC)))
@@ -351,10 +359,10 @@ class Gen:
                 c_from = None
                 if slot < 2 and ksb == 1 and i == 0:
                     c_from = S(0) if slot == 0 else DP(0)      # the row constants, still untouched in sub-block 0's registers
-                if slot == 0: self.mm(S(ksb), 16, RING(i), KFR(ksb, i), tag=f"S ksb{ksb} kk{i}", c=c_from)
-                elif slot == 1: self.mm(DP(ksb), 16, RING(i), VFR(ksb, i), tag=f"dP ksb{ksb} kk{i}", c=c_from)
-                elif slot == 2: self.mm(DV(ksb, i & 3), 16, RING(i), P(ksb, i >> 2), tag=f"dV ksb{ksb} s{i >> 2} db{i & 3}", acc="a")
-                else: self.mm(DK(ksb, i & 3), 16, RING(i), DSP(ksb, i >> 2), tag=f"dK ksb{ksb} s{i >> 2} db{i & 3}", acc="a")
+                if slot == 0: self.mm(S(ksb), 16, RING(i), self.KFR(ksb, i), tag=f"S ksb{ksb} kk{i}", c=c_from)
+                elif slot == 1: self.mm(DP(ksb), 16, RING(i), self.VFR(ksb, i), tag=f"dP ksb{ksb} kk{i}", c=c_from)
+                elif slot == 2: self.mm(self.DV(ksb, i & 3), 16, RING(i), P(ksb, i >> 2), tag=f"dV ksb{ksb} s{i >> 2} db{i & 3}", acc="a")
+                else: self.mm(self.DK(ksb, i & 3), 16, RING(i), DSP(ksb, i >> 2), tag=f"dK ksb{ksb} s{i >> 2} db{i & 3}", acc="a")
             else:
                 self.out.append(Ins("", "nomfma"))
                 if compute and j == 9 and slot < 2:
@@ -365,6 +373,138 @@ class Gen:
         self.in_loop = False
         self.stores_of = getattr(self, "stores_of", {})
         self.stores_of[kind] = nst
+
+    # -------------------------------------------------------------- one slice, head size 64: 32 MFMAs in four slots of 8
+    def slice64(self, name, kind, prev_stores):
+        """Same products, same registers, same LDS images as slice(); what changes is the count (4 k-steps, 2 column blocks) and with it
+        the placement: gap g of 32, slots S 0..7 | dP 8..15 | dV 16..23 | dK 24..31 (barrier in front of 24). The ring's eight slots hold TWO
+        fragment sets of four: Q rows -> 0..3 (slot S), dO rows -> 4..7 (slot dP), dO^T -> 0..3 (slot dV), Q^T -> 4..7 (slot dK); a set is
+        read while the slot BEFORE its consumer runs. The exponent chains run two scores per gap."""
+        compute = kind != "idle"
+        ksbs = [0] if kind == "diag0" else [0, 1]
+        NG = 32
+        G = [[] for _ in range(NG)]
+        def put(g, key, fn):
+            assert 0 <= g < NG, g
+            G[g].append((key, fn))
+        self.in_loop = True
+        nvalu = "valu" in self.ablate
+        ORDER = [(1, 0)] + [(0, i) for i in range(4)] + [(1, i) for i in range(1, 4)]
+        if compute:
+            for kk in range(4):       # dO rows (slot dP) into ring 4..7: free since the previous slice's dK MFMA 28 + kk
+                put(kk, (2, kk), lambda kk=kk: self.lds_row(RING(4 + kk), kk, SLICE_DO))
+            for i in range(4):        # dO^T fragment (s, db) = (i >> 1, i & 1) (slot dV) into ring 0..3: slot i's last use in slot S is gap [1, 5, 6, 7][i]
+                for sec in (0, 1):
+                    put(5 + i, (2, 2 * i + sec), lambda i=i, sec=sec: self.lds_tr(RING(i), i >> 1, i & 1, sec, SLICE_DO))
+            for i in range(4):        # Q^T (slot dK) into ring 4..7: last use in slot dP is gap [9, 13, 14, 15][i]
+                for sec in (0, 1):
+                    put(12 + i, (2, 2 * i + sec), lambda i=i, sec=sec: self.lds_tr(RING(4 + i), i >> 1, i & 1, sec, 0))
+            for g in range(4):        # -delta of this slice into sub-block 0's dP accumulator (behind the previous slice's dK MFMAs and dS stores)
+                put(1 + g // 2, (1, g), lambda g=g: self.lds_const(DP(0), g, 128))
+        # the NEXT slice's head, from the next ring slot, behind the barrier (every variant): -lse / scale into the S accumulators, Q rows into ring 0..3
+        for g in range(4):
+            put(26 + g // 2, (1, g), lambda g=g: self.lds_const(S(0), g, 0))
+        for kk in range(4):           # (ring slot kk's last use in slot dV is gap 20 + kk)
+            put(24 + kk, (2, kk), lambda kk=kk: self.lds_row(RING(kk), kk, 0))
+
+        if compute and not nvalu:
+            for ksb in ksbs:
+                e0, m0 = (6, 15) if ksb == 0 else (11, 19)   # score n: multiply at e0 + n // 2, exp2 one gap on; dS multiply at m0 + n // 2
+                diag = (kind == "diag0" and ksb == 0) or (kind == "diag1" and ksb == 1)
+                for n in range(16):
+                    x, d = S(ksb, n), DP(ksb, n)
+                    ge, gm = e0 + n // 2, m0 + n // 2
+                    put(ge, (0, -1), lambda x=x: self.valu(f"v_mul_f32 {vr(x)}, {sr(S_SCALE)}, {vr(x)}", V(x), V(x)))
+                    if kind == "drop":
+                        put(ge + 1, (0, 0), lambda x=x: self.valu(f"v_mov_b32 {vr(x)}, 0", (), V(x)))
+                    else:
+                        put(ge + 1, (0, 0), lambda x=x: self.valu(f"v_exp_f32 {vr(x)}, {vr(x)}", V(x), V(x), trans=True))
+                    if diag:
+                        kc = (n & 3) + 8 * (n >> 2)
+                        def m(x=x, kc=kc):
+                            self.valu(f"v_cmp_lt_i32 vcc, {kc}, {vr(RM)}", V(RM), [("vcc", 0)])
+                            self.valu(f"v_cndmask_b32_e64 {vr(x)}, {vr(x)}, 0, vcc", V(x) + [("vcc", 0)], V(x))
+                        put(ge + 2, (0, 1), m)
+                    if n % 2 == 1:
+                        pd, dd = P(ksb, n // 8) + (n % 8) // 2, DP(ksb, n // 2)
+                        if self.f16:   # (see slice(): P leaves as P 2^14, dS is rounded once)
+                            def pk(x=x, pd=pd):
+                                self.valu(f"v_fma_mixlo_f16 {vr(pd)}, {vr(x - 1)}, {sr(S_PSH)}, 0", V(x - 1), V(pd))
+                                self.valu(f"v_fma_mixhi_f16 {vr(pd)}, {vr(x)}, {sr(S_PSH)}, 0", V(x) + V(pd), V(pd))
+                            put(ge + 3, (0, 2), pk)
+                            def dsk(x=x, d=d, dd=dd):
+                                self.valu(f"v_fma_mixlo_f16 {vr(dd)}, {vr(x - 1)}, {vr(d - 1)}, 0", V(x - 1) + V(d - 1), V(dd))
+                                self.valu(f"v_fma_mixhi_f16 {vr(dd)}, {vr(x)}, {vr(d)}, 0", V(x) + V(d) + V(dd), V(dd))
+                            put(gm, (0, 3), dsk)
+                        else:
+                            put(ge + 3, (0, 2), lambda x=x, pd=pd: self.valu(f"{self.cvt} {vr(pd)}, {vr(x - 1)}, {vr(x)}", V(x - 1) + V(x), V(pd)))
+                    if not self.f16:
+                        put(gm, (0, 3), lambda x=x, d=d: self.valu(f"v_mul_f32 {vr(d)}, {vr(x)}, {vr(d)}", V(x) + V(d), V(d)))
+                        if n % 2 == 1:
+                            dd = DP(ksb, n // 2)
+                            put(gm + 1, (0, 4), lambda d=d, dd=dd: self.valu(f"{self.cvt} {vr(dd)}, {vr(d - 1)}, {vr(d)}", V(d - 1) + V(d), V(dd)))
+        def after_barrier():
+            for r in (RB[0], RB[1], TB[0], TB[1]):
+                self.valu(f"v_xor_b32 {vr(r)}, {sr(S_MKT)}, {vr(r)}", V(r), V(r))
+            self.valu(f"v_xor_b32 {vr(LR)}, {sr(S_MKC)}, {vr(LR)}", V(LR), V(LR))
+        put(24, (-3, 0), after_barrier)
+        put(25, (3, 0), self.dma_slice)
+        def book():
+            self.ring_step()
+            self.advance_dma()
+        put(26, (4, 0), book)
+        nst = 0
+        if self.ds and compute and "stores" not in self.ablate:
+            for ksb, s_, g in [(0, 0, 26), (0, 1, 27), (1, 0, 29), (1, 1, 30)]:
+                if ksb not in ksbs:
+                    continue
+                nst += 1
+                base = S_DS0 if ksb == 0 else S_DS1
+                put(g, (5, 0), lambda ksb=ksb, s_=s_, base=base: self.out.append(
+                    Ins(f"global_store_dwordx4 {vr(DSOFF)}, {vr(DSP(ksb, s_), 4)}, {sr(base, 2)} offset:{1024 * s_} {self.store_policy}", "vmem", V(DSOFF) + V(DSP(ksb, s_), 4))))
+        put(31, (6, 0), self.ds_next)
+
+        self.label(f"L_{name}_%=")
+        for g in range(NG):
+            slot, j = g // 8, g % 8
+            if g == 24:
+                self.out.append(Ins(f"s_waitcnt vmcnt({prev_stores})", "wait", tag="vm"))
+                self.barrier()
+            ksb, i = j >> 2, j & 3
+            if slot < 2:
+                ksb, i = ORDER[j]
+            if compute and ksb in ksbs:
+                c_from = None
+                if slot < 2 and ksb == 1 and i == 0:
+                    c_from = S(0) if slot == 0 else DP(0)
+                if slot == 0: self.mm(S(ksb), 16, RING(i), self.KFR(ksb, i), tag=f"S ksb{ksb} kk{i}", c=c_from)
+                elif slot == 1: self.mm(DP(ksb), 16, RING(4 + i), self.VFR(ksb, i), tag=f"dP ksb{ksb} kk{i}", c=c_from)
+                elif slot == 2: self.mm(self.DV(ksb, i & 1), 16, RING(i), P(ksb, i >> 1), tag=f"dV ksb{ksb} s{i >> 1} db{i & 1}", acc="a")
+                else: self.mm(self.DK(ksb, i & 1), 16, RING(4 + i), DSP(ksb, i >> 1), tag=f"dK ksb{ksb} s{i >> 1} db{i & 1}", acc="a")
+            else:
+                self.out.append(Ins("", "nomfma"))
+                if compute and j == 5 and slot < 2:
+                    self.salu("s_nop 15")   # diag0: the chain that has just ended gets its time before its first reader
+                    self.salu("s_nop 7")
+            for _, fn in sorted(G[g], key=lambda t: t[0]):
+                fn()
+        self.in_loop = False
+        self.stores_of = getattr(self, "stores_of", {})
+        self.stores_of[kind] = nst
+
+    def ds_next(self):
+        """The dS tile addresses of the next slice: sl + 1; a new 256-query block every 8 slices."""
+        self.salu(f"s_add_u32 {sr(S_SL)}, {sr(S_SL)}, 1")
+        self.salu(f"s_lshr_b32 {sr(S_TMP)}, {sr(S_SL)}, 3")
+        self.salu(f"s_mul_i32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_DSQB)}")
+        self.salu(f"s_and_b32 {sr(S_TMP2)}, {sr(S_SL)}, 7")
+        self.salu(f"s_add_u32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_TMP2)}")
+        self.salu(f"s_lshr_b32 {sr(S_TMP2)}, {sr(S_TMP)}, {32 - 11}")
+        self.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_TMP)}, 11")
+        self.salu(f"s_add_u32 {sr(S_DS0)}, {sr(S_DSB)}, {sr(S_TMP)}")
+        self.salu(f"s_addc_u32 {sr(S_DS0 + 1)}, {sr(S_DSB + 1)}, {sr(S_TMP2)}")
+        self.salu(f"s_add_u32 {sr(S_DS1)}, {sr(S_DS0)}, {8 * DS_TILE}")
+        self.salu(f"s_addc_u32 {sr(S_DS1 + 1)}, {sr(S_DS0 + 1)}, 0")
 
     # -------------------------------------------------------------- block pass
     def prologue(self):
@@ -450,7 +590,7 @@ class Gen:
         for srd, base in ((O_SRD, 0), (V_SRD, STAGE0)):
             e.salu(f"s_mov_b32 {sr(S_TMP)}, {sr(S_X0)}")
             for g in range(8):                                                     # row groups 0..7 of the wave's 64 keys
-                for half in range(2):
+                for half in range(2 if self.D == 128 else 1):           # (D = 64: a row group's 8 x 128 B are ONE piece, the first half of the image)
                     e.salu(f"s_add_u32 m0, {sr(S_M0)}, {base + 2048 * g + 1024 * half - 128 * half}")
                     e.salu("s_nop 0")
                     o = " offset:128" if half else ""
@@ -508,7 +648,7 @@ class Gen:
         e.valu(f"v_lshl_add_u32 {vr(DSOFF)}, {vr(h)}, 4, {vr(DSOFF)}")
         # dV = dK = 0: sixteen MFMAs of zero operands (0 * 0 + 0 into 16 accumulator registers each) instead of 256 v_accvgpr_write - 16 issue
         # slots, the matrix pipe does the rest while this wave computes on
-        for i in range(16):
+        for i in range(4 * self.NDB):
             e.out.append(Ins(f"{self.mfma} {ar(16 * i, 16)}, {vr(S(0, 8), 4)}, {vr(S(0, 12), 4)}, 0", "mfma", V(S(0, 8), 4) + V(S(0, 12), 4), A(16 * i, 16), tag="zero"))
         # ---- the fragments: K (k = 16 kk + 8 h .. of key 32 ksb + r) as soon as this wave's 16 K pieces have landed, then V. In-order counter:
         #      the pieces are this wave's own, nobody else reads or writes its quarters: no barrier in front of the reads
@@ -516,18 +656,18 @@ class Gen:
         e.salu(f"s_lshl_b32 {sr(S_TMP2)}, {sr(S_WID)}, 14")
         for i in range(2):
             e.valu(f"v_add_u32 {vr(rbk[i])}, {sr(S_TMP2)}, {vr(RB[i])}")
-        e.out.append(Ins("s_waitcnt vmcnt(16)", "wait", tag="vm"))
+        e.out.append(Ins(f"s_waitcnt vmcnt({2 * self.NKK})", "wait", tag="vm"))       # the V pieces may still be in flight
         for ksb in range(2):
-            for kk in range(8):
-                e.out.append(Ins(f"ds_read_b128 {vr(KFR(ksb, kk), 4)}, {vr(rbk[kk & 1])} offset:{8192 * ksb + 512 * (kk >> 1)}", "lds", V(rbk[kk & 1]), V(KFR(ksb, kk), 4)))
+            for kk in range(self.NKK):
+                e.out.append(Ins(f"ds_read_b128 {vr(self.KFR(ksb, kk), 4)}, {vr(rbk[kk & 1])} offset:{8192 * ksb + 512 * (kk >> 1)}", "lds", V(rbk[kk & 1]), V(self.KFR(ksb, kk), 4)))
         e.salu(f"s_add_u32 {sr(S_TMP2)}, {sr(S_TMP2)}, {STAGE0}")
         rbv = (S(0, 4), S(0, 5))
         for i in range(2):
             e.valu(f"v_add_u32 {vr(rbv[i])}, {sr(S_TMP2)}, {vr(RB[i])}")
         e.out.append(Ins("s_waitcnt vmcnt(0)", "wait", tag="vm"))
         for ksb in range(2):
-            for kk in range(8):
-                e.out.append(Ins(f"ds_read_b128 {vr(VFR(ksb, kk), 4)}, {vr(rbv[kk & 1])} offset:{8192 * ksb + 512 * (kk >> 1)}", "lds", V(rbv[kk & 1]), V(VFR(ksb, kk), 4)))
+            for kk in range(self.NKK):
+                e.out.append(Ins(f"ds_read_b128 {vr(self.VFR(ksb, kk), 4)}, {vr(rbv[kk & 1])} offset:{8192 * ksb + 512 * (kk >> 1)}", "lds", V(rbv[kk & 1]), V(self.VFR(ksb, kk), 4)))
         e.out.append(Ins("s_waitcnt lgkmcnt(0)", "wait", tag="lgkm"))
         e.barrier()     # every wave has its K fragments out of the ring
         if self.f16:
@@ -549,7 +689,7 @@ class Gen:
             e.valu(f"v_mov_b32 {vr(t2)}, 0x3fb8aa3b")
             e.valu(f"v_mul_f32 {vr(t2)}, {sr(S_SCALE)}, {vr(t2)}")
             for i in range(64):
-                x = KFR(0, 0) + i
+                x = self.KFR(0, 0) + i
                 if self.f16:
                     e.valu(f"v_cvt_f32_f16 {vr(t0)}, {vr(x)}")
                     e.valu(f"v_cvt_f32_f16_sdwa {vr(t1)}, {vr(x)} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1")
@@ -575,14 +715,19 @@ class Gen:
         e.salu(f"s_add_u32 {sr(S_DS1)}, {sr(S_DS0)}, {8 * DS_TILE}")
         e.salu(f"s_addc_u32 {sr(S_DS1 + 1)}, {sr(S_DS0 + 1)}, 0")
         # ---- slice s0 has landed for everyone (slice s0 + 1's 5 pieces may still be in flight); the first slice's head state
-        e.out.append(Ins("s_waitcnt vmcnt(5)", "wait", tag="vm"))
+        e.out.append(Ins(f"s_waitcnt vmcnt({5 if self.D == 128 else 3})", "wait", tag="vm"))    # (a slice is 5 pieces per wave at D = 128, 3 at D = 64)
         e.barrier()
         self.stamp(0)
         # (in the ORDER every slice's tail issues them: the loop's counted waits assume it)
-        for g in range(4):
-            e.lds_const(S(0), g, 0)
-        for j in range(8):
-            e.lds_row(RING(j), j, 0)
+        if self.D == 128:
+            for g in range(4):
+                e.lds_const(S(0), g, 0)
+            for j in range(8):
+                e.lds_row(RING(j), j, 0)
+        else:               # slice64's tail: Q rows at gaps 24 .. 27, the constants in front of them at 26, 27
+            e.lds_row(RING(0), 0, 0); e.lds_row(RING(1), 1, 0)
+            e.lds_const(S(0), 0, 0); e.lds_const(S(0), 1, 0); e.lds_row(RING(2), 2, 0)
+            e.lds_const(S(0), 2, 0); e.lds_const(S(0), 3, 0); e.lds_row(RING(3), 3, 0)
         e.salu(f"s_mov_b32 {sr(S_IT)}, 0")
 
     def dispatch(self):
@@ -629,17 +774,17 @@ class Gen:
         e.valu(f"v_mul_u32_u24 {vr(st)}, {STAGE_ROW}, {vr(r)}")
         e.valu(f"v_lshl_add_u32 {vr(st)}, {vr(h)}, 3, {vr(st)}")
         e.valu(f"v_add_u32 {vr(st)}, {sr(S_STAGE)}, {vr(st)}")
-        e.valu(f"v_lshrrev_b32 {vr(rd)}, 4, {vr(lane)}")
-        e.valu(f"v_and_b32 {vr(oo)}, 15, {vr(lane)}")
+        e.valu(f"v_lshrrev_b32 {vr(rd)}, {4 if self.D == 128 else 3}, {vr(lane)}")     # row of a store instruction: 16 lanes per 256-byte row | 8 lanes per 128-byte row
+        e.valu(f"v_and_b32 {vr(oo)}, {15 if self.D == 128 else 7}, {vr(lane)}")
         e.valu(f"v_lshlrev_b32 {vr(oo)}, 4, {vr(oo)}")
         e.valu(f"v_mul_lo_u32 {vr(RM)}, {vr(rd)}, {sr(S_OSR)}")
         e.valu(f"v_mul_u32_u24 {vr(rd)}, {STAGE_ROW}, {vr(rd)}")
         e.valu(f"v_add3_u32 {vr(rd)}, {vr(rd)}, {vr(oo)}, {sr(S_STAGE)}")
         e.valu(f"v_add_u32 {vr(oo)}, {vr(oo)}, {vr(RM)}")
-        for which, accf, ptr in ((0, DV, "dvp"), (1, DK, "dkp")):
+        for which, accf, ptr in ((0, self.DV, "dvp"), (1, self.DK, "dkp")):
             # accumulators -> 16-bit rows of this wave's slab: lane (key r, half h) writes 4 consecutive d of key 32 ksb + r
             for ksb in range(2):
-                for db in range(4):
+                for db in range(self.NDB):
                     for gq in range(4):
                         a0 = accf(ksb, db) + 4 * gq
                         x = [RING(0) + i for i in range(4)]
@@ -658,10 +803,11 @@ class Gen:
             e.salu(f"s_mov_b64 {sr(O_SRD, 2)}, %[{ptr}]")
             e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 6")
             e.salu(f"s_mul_i32 {sr(S_X0)}, {sr(S_TMP)}, {sr(S_OSR)}")
-            e.salu(f"s_lshl_b32 {sr(S_X1)}, {sr(S_OSR)}, 2")
-            for j in range(16):
+            rows_per = 4 if self.D == 128 else 8                                    # rows one store instruction covers
+            e.salu(f"s_lshl_b32 {sr(S_X1)}, {sr(S_OSR)}, {2 if self.D == 128 else 3}")
+            for j in range(64 // rows_per):
                 d = 32 + 4 * (j % 8)    # v[32..63]: the dP registers are free now
-                e.out.append(Ins(f"ds_read_b128 {vr(d, 4)}, {vr(rd)} offset:{4 * j * STAGE_ROW}", "ldsw"))
+                e.out.append(Ins(f"ds_read_b128 {vr(d, 4)}, {vr(rd)} offset:{rows_per * j * STAGE_ROW}", "ldsw"))
                 if j % 8 == 7:
                     e.out.append(Ins("s_waitcnt lgkmcnt(0)", "wait", tag="lgkm"))
                     for i in range(8):
@@ -691,17 +837,18 @@ class Gen:
     def build(self):
         self.prologue()
         self.dispatch()
+        sl = self.slice if self.D == 128 else self.slice64
         # prev_stores: the stores a wave issued behind its last DMA pieces in the PREVIOUS slice, by what that slice was
-        self.slice("steady", "steady", 4 if self.ds else 0)
+        sl("steady", "steady", 4 if self.ds else 0)
         self.next_iter()
-        self.slice("diag1", "diag1", 2 if self.ds else 0)
+        sl("diag1", "diag1", 2 if self.ds else 0)
         self.next_iter()
-        self.slice("diag0", "diag0", 0)
+        sl("diag0", "diag0", 0)
         self.next_iter()
-        self.slice("idle", "idle", 0)
+        sl("idle", "idle", 0)
         self.next_iter()
         if self.mutant:
-            self.slice("drop", "drop", 4 if self.ds else 0)
+            sl("drop", "drop", 4 if self.ds else 0)
             self.next_iter()
         self.epilogue()
         finish_waits(self.out)
@@ -896,15 +1043,24 @@ def main():
                     gg = Gen(f16, mut, ds, ablate=abl, stamps=args.stamps, scaled=sq).build()
                     assert abl or not check(gg.out), check(gg.out)[:5]
                     texts[(f16, mut, ds, sq)] = render(gg.out).replace(chr(10), " " + chr(92) + chr(10))
+    texts64 = {}
+    for f16 in (False, True):
+        for mut in (False, True):
+            for ds in (True, False):
+                gg = Gen(f16, mut, ds, ablate=abl, D=64).build()
+                assert abl or not check(gg.out), check(gg.out)[:5]
+                texts64[(f16, mut, ds)] = render(gg.out).replace(chr(10), " " + chr(92) + chr(10))
     n_ins = sum(1 for i in g.out if i.kind not in ("raw", "label", "nomfma"))
     def four(mut):
-        return "\n".join(f"#define KF_DKV_W4_ASM_{'F16' if f16 else 'BF16'}_{'DS' if ds else 'NODS'}{'_SQ' if sq else ''} \\\n{texts[(f16, mut, ds, sq)]}"
-                         for f16 in (False, True) for ds in (True, False) for sq in (False, True))
+        return "\n".join([f"#define KF_DKV_W4_ASM_{'F16' if f16 else 'BF16'}_{'DS' if ds else 'NODS'}{'_SQ' if sq else ''} \\\n{texts[(f16, mut, ds, sq)]}"
+                          for f16 in (False, True) for ds in (True, False) for sq in (False, True)] +
+                         [f"#define KF_DKV_W4_D64_ASM_{'F16' if f16 else 'BF16'}_{'DS' if ds else 'NODS'} \\\n{texts64[(f16, mut, ds)]}"
+                          for f16 in (False, True) for ds in (True, False)])
     text = f"""// GENERATED by tools/gen_attn_dkv.py - do not edit; edit the generator and run it again.
 // The 16-bit causal-attention dK / dV pass of one 256-key block as ONE instruction stream ({n_ins} instructions): 4 waves x 64 keys,
 // one wave per SIMD, all 512 registers asm-owned; see the generator's header for the structure.
 // Two forms: exact f32 scores (default: %[scale] = scale log2 e, row constant -lse / scale), and _SQ = K scaled and rounded once per block
-// (KF_ATTN_SCALED_OPERANDS: %[scale] = the softmax scale, row constant -lse log2 e).
+// (KF_ATTN_SCALED_OPERANDS: %[scale] = the softmax scale, row constant -lse log2 e). _D64_ = head size 64 (exact form only): 32 MFMAs per slice.
 #pragma once
 #define KF_DKV_W4_LDS_BYTES {LDS_BYTES}
 #define KF_DKV_W4_CLOBBERS {", ".join('"' + c + '"' for c in CLOBBERS + ([f"s{i}" for i in range(80, 102)] if args.stamps else []))}
