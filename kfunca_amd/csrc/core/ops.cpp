@@ -566,7 +566,7 @@ public:
         if (ibias_ >= 0 && inputs[ibias_].requires_grad()) out[ibias_] = sum(dt, 0).view({N});
         Tensor a2 = a.view({M, K});
         if (a.requires_grad()) {
-            out[0] = da.defined() ? da : empty(a.sizes(), a.dtype(), a.device());
+            out[0] = empty(a.sizes(), a.dtype(), a.device());
             Tensor c2 = out[0].view({M, K});
             gemm_any(a.dtype(), false, true, M, K, N, alpha_, dt, b, 0.f, c2, a.device());
         }

@@ -600,8 +600,10 @@ __global__ __launch_bounds__(FNT, 2) void attn_fwd_v3_kernel(const AttnArgs a) {
 #include KF_FWD_W4_INC
 // SQ: the scaled-query form of the stream (KF_ATTN_SCALED_OPERANDS): c q rounded to the element type once per pass, no multiply per score -
 // about 4 % faster, and a score error of eps scale sum |q k| that grows with the logits. Default: exact f32 scores.
-template <bool BF, bool SQ>
+// D64: the head-size-64 stream (round 5; exact scores only)
+template <bool BF, bool SQ, bool D64 = false>
 __global__ __launch_bounds__(256) void attn_fwd_w4_kernel(const AttnArgs a) {
+    static_assert(!(SQ && D64), "the scaled-query form exists for head size 128 only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int xb0;
     int64_t bh;
@@ -638,7 +640,9 @@ __global__ __launch_bounds__(256) void attn_fwd_w4_kernel(const AttnArgs a) {
 #define KF_W4_OPERANDS                                                                                                              \
     [qp] "s"(qp), [kp] "s"(kp), [vp] "s"(vp), [op] "s"(op), [lsep] "s"(lsep), [qsr] "s"(qsr), [kvsr] "s"(kvsr), [osr] "s"(osr), [T] "s"(T), \
         [wid] "s"(wid), [c] "s"(c), [defer] "s"(defer), [lds] "s"(lds), [mut] "s"(mut) KF_W4_EXTRA
-        if constexpr (BF && SQ) asm volatile(KF_FWD_W4_ASM_BF16_SQ : : KF_W4_OPERANDS : KF_FWD_W4_CLOBBERS);
+        if constexpr (D64 && BF) asm volatile(KF_FWD_W4_D64_ASM_BF16 : : KF_W4_OPERANDS : KF_FWD_W4_CLOBBERS);
+        else if constexpr (D64) asm volatile(KF_FWD_W4_D64_ASM_F16 : : KF_W4_OPERANDS : KF_FWD_W4_CLOBBERS);
+        else if constexpr (BF && SQ) asm volatile(KF_FWD_W4_ASM_BF16_SQ : : KF_W4_OPERANDS : KF_FWD_W4_CLOBBERS);
         else if constexpr (BF) asm volatile(KF_FWD_W4_ASM_BF16 : : KF_W4_OPERANDS : KF_FWD_W4_CLOBBERS);
         else if constexpr (SQ) asm volatile(KF_FWD_W4_ASM_F16_SQ : : KF_W4_OPERANDS : KF_FWD_W4_CLOBBERS);
         else asm volatile(KF_FWD_W4_ASM_F16 : : KF_W4_OPERANDS : KF_FWD_W4_CLOBBERS);
@@ -2543,15 +2547,23 @@ static int attn_fwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
         dim3 grid3((unsigned)((a.persist ? nxb3 / (2 * a.persist) : nxb3) * B * H));
         KF_PROF(D == 64 ? "attn_fwd_mfma_d64" : "attn_fwd_mfma", st);
         // round 4: the one-wave-per-SIMD stream (attn_fwd_w4_kernel) wherever its shape conditions hold; KF_ATTN_FWD_V3 keeps the 8-wave kernel (A/B)
-        if (D == AD && Sq % FQ == 0 && Skv >= Sq && a.lk.sr == a.lv.sr && (uint64_t)Skv * (uint64_t)a.lk.sr < (1ull << 32) &&
+        if ((D == AD || D == 64) && Sq % FQ == 0 && Skv >= Sq && a.lk.sr == a.lv.sr && (uint64_t)Skv * (uint64_t)a.lk.sr < (1ull << 32) &&
             (uint64_t)FQ * (uint64_t)std::max(a.lq.sr, a.lo.sr) < (1ull << 31) && !knob(KNOB_ATTN_FWD_V3)) {
 #define KF_FWD4(BF_, SQ_)                                                                                   \
     {                                                                                                       \
         if ((rc = set_lds(attn_fwd_w4_kernel<BF_, SQ_>, KF_FWD_W4_LDS_BYTES)) != KF_OK) return rc;           \
         attn_fwd_w4_kernel<BF_, SQ_><<<grid3, 256, KF_FWD_W4_LDS_BYTES, st>>>(a);                           \
     }
-            const bool sq = knob(KNOB_ATTN_SCALED_OPERANDS); // opt-in: c q rounded once per pass (faster; score error grows with the logits)
-            if (dtype == KF_BF16) { if (sq) KF_FWD4(true, true) else KF_FWD4(true, false) }
+            const bool sq = D == AD && knob(KNOB_ATTN_SCALED_OPERANDS); // opt-in: c q rounded once per pass (faster; score error grows with the logits)
+            if (D == 64) {
+                if (dtype == KF_BF16) {
+                    if ((rc = set_lds(attn_fwd_w4_kernel<true, false, true>, KF_FWD_W4_LDS_BYTES)) != KF_OK) return rc;
+                    attn_fwd_w4_kernel<true, false, true><<<grid3, 256, KF_FWD_W4_LDS_BYTES, st>>>(a);
+                } else {
+                    if ((rc = set_lds(attn_fwd_w4_kernel<false, false, true>, KF_FWD_W4_LDS_BYTES)) != KF_OK) return rc;
+                    attn_fwd_w4_kernel<false, false, true><<<grid3, 256, KF_FWD_W4_LDS_BYTES, st>>>(a);
+                }
+            } else if (dtype == KF_BF16) { if (sq) KF_FWD4(true, true) else KF_FWD4(true, false) }
             else { if (sq) KF_FWD4(false, true) else KF_FWD4(false, false) }
 #undef KF_FWD4
             KF_LAUNCH_CHECK();

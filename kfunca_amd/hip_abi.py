@@ -107,6 +107,15 @@ def lib():
         _lib.kf_last_error.restype = C.c_char_p
         if hasattr(_lib, "kf_build_source_sha"):   # (a diagnostic variant library under KF_HIP_LIB is linked without the stamp)
             _lib.kf_build_source_sha.restype = C.c_char_p
+            # a library that was NOT built from the sources beside it must not pass for them (a failed rebuild leaves the old .so behind):
+            # refuse it unless told otherwise (KF_ALLOW_STALE_LIB=1)
+            from . import _build
+            if (_build.CSRC / "device").exists() and not os.environ.get("KF_ALLOW_STALE_LIB"):
+                built, tree = _lib.kf_build_source_sha().decode(), _build.device_src_sha()
+                if built != tree:
+                    _lib = None
+                    raise ImportError(f"{LIB_PATH} was built from device sources {built}, the tree is {tree}: rebuild it (python -m kfunca_amd._build); "
+                                      "KF_ALLOW_STALE_LIB=1 loads it anyway")
         vp, i64, sz = C.c_void_p, C.c_int64, C.c_size_t
         _lib.kf_malloc.argtypes = [C.POINTER(vp), sz]
         _lib.kf_free.argtypes = [vp]

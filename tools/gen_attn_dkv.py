@@ -375,14 +375,25 @@ class Gen:
         self.stores_of[kind] = nst
 
     # -------------------------------------------------------------- one slice, head size 64: 32 MFMAs in four slots of 8
-    def slice64(self, name, kind, prev_stores):
-        """Same products, same registers, same LDS images as slice(); what changes is the count (4 k-steps, 2 column blocks) and with it
-        the placement: gap g of 32, slots S 0..7 | dP 8..15 | dV 16..23 | dK 24..31 (barrier in front of 24). The ring's eight slots hold TWO
-        fragment sets of four: Q rows -> 0..3 (slot S), dO rows -> 4..7 (slot dP), dO^T -> 0..3 (slot dV), Q^T -> 4..7 (slot dK); a set is
-        read while the slot BEFORE its consumer runs. The exponent chains run two scores per gap."""
+    def slice64(self, name, kind, vm_ok):
+        """Same products, same accumulators, same LDS images as slice(); what changes is the count (4 k-steps, 2 column blocks) and with it
+        the whole placement: gap g of 32, slots S 0..7 | dP 8..15 | dV 16..23 | dK 24..31. A gap is 32 cycles of matrix pipe at D = 128 and at
+        D = 64, but the per-score VALU work is the same: this slice is VALU-issue bound, its gaps are short, and an LDS read eight gaps ahead of
+        its consumer (the D = 128 distance) is only ~300 cycles ahead - it came back late at every slot head (first form of this stream: 2170
+        cycles per slice). Head size 64 leaves 64 vector registers free (K / V fragments are half as many), so here every fragment set has its OWN
+        registers and is read a whole slice (24 gaps) ahead:
+            RA Q rows   v[80:95]   consumer slot S  of slice it + 1, read at gaps  8..11 of slice it
+            RB dO rows  v[96:111]  consumer slot dP of slice it + 1, read at gaps 16..19
+            RC dO^T     v[186:201] consumer slot dV of slice it + 1, read at gaps 24..27
+            RD Q^T      v[202:217] consumer slot dK of slice it,     read at gaps  0.. 3 (compute variants only; in front of everything else)
+            -lse / scale of slice it + 1 -> S accumulators at gaps 24, 25; -delta -> dP accumulators at 28, 29
+        All of slice it + 1's reads sit behind the slice barrier, which moves to gap 8 (in front of slot dP), and the DMA requests run THREE
+        slices ahead (the four-slot ring allows it: slice it + 3 overwrites the slot of slice it - 1, whose last read was consumed before
+        this barrier): slice it + 1, published by this barrier, was requested two slices ago. vm_ok = what may still be in flight at the
+        barrier's wait (the requests of slice it + 2 and the dS stores of the two slices before: build() derives it per variant)."""
         compute = kind != "idle"
         ksbs = [0] if kind == "diag0" else [0, 1]
-        NG = 32
+        NG, BAR = 32, 8
         G = [[] for _ in range(NG)]
         def put(g, key, fn):
             assert 0 <= g < NG, g
@@ -390,22 +401,23 @@ class Gen:
         self.in_loop = True
         nvalu = "valu" in self.ablate
         ORDER = [(1, 0)] + [(0, i) for i in range(4)] + [(1, i) for i in range(1, 4)]
+        RA, RB_, RC, RD = (lambda i: 80 + 4 * i), (lambda i: 96 + 4 * i), (lambda i: 186 + 4 * i), (lambda i: 202 + 4 * i)
         if compute:
-            for kk in range(4):       # dO rows (slot dP) into ring 4..7: free since the previous slice's dK MFMA 28 + kk
-                put(kk, (2, kk), lambda kk=kk: self.lds_row(RING(4 + kk), kk, SLICE_DO))
-            for i in range(4):        # dO^T fragment (s, db) = (i >> 1, i & 1) (slot dV) into ring 0..3: slot i's last use in slot S is gap [1, 5, 6, 7][i]
+            for i in range(4):        # Q^T of THIS slice (slot dK); fragment (s, db) = (i >> 1, i & 1); RD(i)'s last use was gap 28 + i of the previous slice
                 for sec in (0, 1):
-                    put(5 + i, (2, 2 * i + sec), lambda i=i, sec=sec: self.lds_tr(RING(i), i >> 1, i & 1, sec, SLICE_DO))
-            for i in range(4):        # Q^T (slot dK) into ring 4..7: last use in slot dP is gap [9, 13, 14, 15][i]
-                for sec in (0, 1):
-                    put(12 + i, (2, 2 * i + sec), lambda i=i, sec=sec: self.lds_tr(RING(4 + i), i >> 1, i & 1, sec, 0))
-            for g in range(4):        # -delta of this slice into sub-block 0's dP accumulator (behind the previous slice's dK MFMAs and dS stores)
-                put(1 + g // 2, (1, g), lambda g=g: self.lds_const(DP(0), g, 128))
-        # the NEXT slice's head, from the next ring slot, behind the barrier (every variant): -lse / scale into the S accumulators, Q rows into ring 0..3
-        for g in range(4):
-            put(26 + g // 2, (1, g), lambda g=g: self.lds_const(S(0), g, 0))
-        for kk in range(4):           # (ring slot kk's last use in slot dV is gap 20 + kk)
-            put(24 + kk, (2, kk), lambda kk=kk: self.lds_row(RING(kk), kk, 0))
+                    put(i, (-5, 2 * i + sec), lambda i=i, sec=sec: self.lds_tr(RD(i), i >> 1, i & 1, sec, 0))
+        # everything the NEXT slice reads, behind the barrier, in EVERY variant and in one fixed order (finish_waits counts on it)
+        for kk in range(4):           # RA(kk)'s last use is gap [1, 5, 6, 7][kk]
+            put(BAR + kk, (2, kk), lambda kk=kk: self.lds_row(RA(kk), kk, 0))
+        for kk in range(4):           # RB(kk)'s last use is gap [9, 13, 14, 15][kk]
+            put(16 + kk, (2, kk), lambda kk=kk: self.lds_row(RB_(kk), kk, SLICE_DO))
+        for g in range(4):            # the S accumulators are free once sub-block 0's dS multiplies have read p (gap 22)
+            put(24 + g // 2, (1, g), lambda g=g: self.lds_const(S(0), g, 0))
+        for i in range(4):            # RC(i)'s last use is gap 20 + i
+            for sec in (0, 1):
+                put(24 + i, (2, 2 * i + sec), lambda i=i, sec=sec: self.lds_tr(RC(i), i >> 1, i & 1, sec, SLICE_DO))
+        for g in range(4):            # sub-block 0's dP tuple is free behind its dK MFMAs (24 .. 27) and dS stores (26, 27)
+            put(28 + g // 2, (1, g), lambda g=g: self.lds_const(DP(0), g, 128))
 
         if compute and not nvalu:
             for ksb in ksbs:
@@ -447,12 +459,18 @@ class Gen:
             for r in (RB[0], RB[1], TB[0], TB[1]):
                 self.valu(f"v_xor_b32 {vr(r)}, {sr(S_MKT)}, {vr(r)}", V(r), V(r))
             self.valu(f"v_xor_b32 {vr(LR)}, {sr(S_MKC)}, {vr(LR)}", V(LR), V(LR))
-        put(24, (-3, 0), after_barrier)
-        put(25, (3, 0), self.dma_slice)
+        put(BAR, (-3, 0), after_barrier)
+        put(BAR + 1, (3, 0), self.dma_slice)
         def book():
-            self.ring_step()
+            # the DMA side runs three slots ahead of the read side: the other parity, so the other step mask
+            self.salu(f"s_xor_b32 {sr(S_TMP)}, {sr(S_MKT)}, {2 * BUF}")
+            self.salu(f"s_xor_b32 {sr(S_M0)}, {sr(S_M0)}, {sr(S_TMP)}")
+            self.salu(f"s_xor_b32 {sr(S_TMP)}, {sr(S_MKC)}, {2 * CSLOT}")
+            self.salu(f"s_xor_b32 {sr(S_M0C)}, {sr(S_M0C)}, {sr(S_TMP)}")
+            self.salu(f"s_xor_b32 {sr(S_MKT)}, {sr(S_MKT)}, {2 * BUF}")
+            self.salu(f"s_xor_b32 {sr(S_MKC)}, {sr(S_MKC)}, {2 * CSLOT}")
             self.advance_dma()
-        put(26, (4, 0), book)
+        put(BAR + 2, (4, 0), book)
         nst = 0
         if self.ds and compute and "stores" not in self.ablate:
             for ksb, s_, g in [(0, 0, 26), (0, 1, 27), (1, 0, 29), (1, 1, 30)]:
@@ -467,8 +485,8 @@ class Gen:
         self.label(f"L_{name}_%=")
         for g in range(NG):
             slot, j = g // 8, g % 8
-            if g == 24:
-                self.out.append(Ins(f"s_waitcnt vmcnt({prev_stores})", "wait", tag="vm"))
+            if g == BAR:
+                self.out.append(Ins(f"s_waitcnt vmcnt({vm_ok})", "wait", tag="vm"))
                 self.barrier()
             ksb, i = j >> 2, j & 3
             if slot < 2:
@@ -477,10 +495,10 @@ class Gen:
                 c_from = None
                 if slot < 2 and ksb == 1 and i == 0:
                     c_from = S(0) if slot == 0 else DP(0)
-                if slot == 0: self.mm(S(ksb), 16, RING(i), self.KFR(ksb, i), tag=f"S ksb{ksb} kk{i}", c=c_from)
-                elif slot == 1: self.mm(DP(ksb), 16, RING(4 + i), self.VFR(ksb, i), tag=f"dP ksb{ksb} kk{i}", c=c_from)
-                elif slot == 2: self.mm(self.DV(ksb, i & 1), 16, RING(i), P(ksb, i >> 1), tag=f"dV ksb{ksb} s{i >> 1} db{i & 1}", acc="a")
-                else: self.mm(self.DK(ksb, i & 1), 16, RING(4 + i), DSP(ksb, i >> 1), tag=f"dK ksb{ksb} s{i >> 1} db{i & 1}", acc="a")
+                if slot == 0: self.mm(S(ksb), 16, RA(i), self.KFR(ksb, i), tag=f"S ksb{ksb} kk{i}", c=c_from)
+                elif slot == 1: self.mm(DP(ksb), 16, RB_(i), self.VFR(ksb, i), tag=f"dP ksb{ksb} kk{i}", c=c_from)
+                elif slot == 2: self.mm(self.DV(ksb, i & 1), 16, RC(i), P(ksb, i >> 1), tag=f"dV ksb{ksb} s{i >> 1} db{i & 1}", acc="a")
+                else: self.mm(self.DK(ksb, i & 1), 16, RD(i), DSP(ksb, i >> 1), tag=f"dK ksb{ksb} s{i >> 1} db{i & 1}", acc="a")
             else:
                 self.out.append(Ins("", "nomfma"))
                 if compute and j == 5 and slot < 2:
@@ -684,6 +702,11 @@ class Gen:
         e.dma_slice()
         e.ring_step()                                                           # the DMA side now points at slot 2, the masks are slot 0 -> 1 again: the loop's first step
         e.advance_dma()
+        if self.D == 64:                                                        # three slices ahead (slice64): slot 2 as well, the DMA side moves on to slot 3
+            e.dma_slice()
+            e.salu(f"s_xor_b32 {sr(S_M0)}, {sr(S_M0)}, {BUF}")
+            e.salu(f"s_xor_b32 {sr(S_M0C)}, {sr(S_M0C)}, {CSLOT}")
+            e.advance_dma()
         if self.scaled:
             # K *= scale log2(e): unpack the pair, two multiplies, pack (64 registers, once per block)
             e.valu(f"v_mov_b32 {vr(t2)}, 0x3fb8aa3b")
@@ -715,7 +738,7 @@ class Gen:
         e.salu(f"s_add_u32 {sr(S_DS1)}, {sr(S_DS0)}, {8 * DS_TILE}")
         e.salu(f"s_addc_u32 {sr(S_DS1 + 1)}, {sr(S_DS0 + 1)}, 0")
         # ---- slice s0 has landed for everyone (slice s0 + 1's 5 pieces may still be in flight); the first slice's head state
-        e.out.append(Ins(f"s_waitcnt vmcnt({5 if self.D == 128 else 3})", "wait", tag="vm"))    # (a slice is 5 pieces per wave at D = 128, 3 at D = 64)
+        e.out.append(Ins(f"s_waitcnt vmcnt({5 if self.D == 128 else 6})", "wait", tag="vm"))    # (D = 128: slice s0 + 1's 5 pieces may be in flight; D = 64: two slices of 3)
         e.barrier()
         self.stamp(0)
         # (in the ORDER every slice's tail issues them: the loop's counted waits assume it)
@@ -724,10 +747,14 @@ class Gen:
                 e.lds_const(S(0), g, 0)
             for j in range(8):
                 e.lds_row(RING(j), j, 0)
-        else:               # slice64's tail: Q rows at gaps 24 .. 27, the constants in front of them at 26, 27
-            e.lds_row(RING(0), 0, 0); e.lds_row(RING(1), 1, 0)
-            e.lds_const(S(0), 0, 0); e.lds_const(S(0), 1, 0); e.lds_row(RING(2), 2, 0)
-            e.lds_const(S(0), 2, 0); e.lds_const(S(0), 3, 0); e.lds_row(RING(3), 3, 0)
+        else:               # what slice64 reads for its successor, in its order: Q rows, dO rows, [-lse / scale, dO^T], -delta
+            for kk in range(4): e.lds_row(80 + 4 * kk, kk, 0)
+            for kk in range(4): e.lds_row(96 + 4 * kk, kk, SLICE_DO)
+            for i in range(4):
+                if i < 2:
+                    e.lds_const(S(0), 2 * i, 0); e.lds_const(S(0), 2 * i + 1, 0)
+                for sec in (0, 1): e.lds_tr(186 + 4 * i, i >> 1, i & 1, sec, SLICE_DO)
+            for g in range(4): e.lds_const(DP(0), g, 128)
         e.salu(f"s_mov_b32 {sr(S_IT)}, 0")
 
     def dispatch(self):
@@ -838,17 +865,25 @@ class Gen:
         self.prologue()
         self.dispatch()
         sl = self.slice if self.D == 128 else self.slice64
-        # prev_stores: the stores a wave issued behind its last DMA pieces in the PREVIOUS slice, by what that slice was
-        sl("steady", "steady", 4 if self.ds else 0)
+        # D = 128 - prev_stores: the stores a wave issued behind its last DMA pieces in the PREVIOUS slice, by what that slice was.
+        # D = 64 - what may be in flight at the barrier of slice it: the 3 pieces of slice it + 2 (requested one slice ago) and the dS stores of
+        # slices it - 2 and it - 1, which were issued behind the pieces of slice it + 1 that the wait is for; a wave runs idle* diag0 diag1
+        # steady*, so the two slices before a steady one stored 2 + 4 (its first) or 4 + 4: the smaller count is the safe one
+        st = (lambda a, b: 3 + ((a + b) if self.ds else 0))
+        vm = {"steady": 4, "diag1": 2, "diag0": 0, "idle": 0, "drop": 4} if self.D == 128 else \
+             {"steady": st(2, 4), "diag1": st(0, 2), "diag0": st(0, 0), "idle": st(0, 0), "drop": st(2, 4)}
+        if self.D == 128 and not self.ds:
+            vm = {k: 0 for k in vm}
+        sl("steady", "steady", vm["steady"])
         self.next_iter()
-        sl("diag1", "diag1", 2 if self.ds else 0)
+        sl("diag1", "diag1", vm["diag1"])
         self.next_iter()
-        sl("diag0", "diag0", 0)
+        sl("diag0", "diag0", vm["diag0"])
         self.next_iter()
-        sl("idle", "idle", 0)
+        sl("idle", "idle", vm["idle"])
         self.next_iter()
         if self.mutant:
-            sl("drop", "drop", 4 if self.ds else 0)
+            sl("drop", "drop", vm["drop"])
             self.next_iter()
         self.epilogue()
         finish_waits(self.out)
@@ -874,12 +909,14 @@ def finish_waits(ins):
             tail.append(x)
         elif on and x.kind == "wait" and "lgkm" in x.tag:
             tail = []
+    # (never more than 15 in flight: the walk below retires the oldest before a 16th is issued, in every variant and in the prologue - so only
+    #  the LAST 15 reads of the tail can still be pending where a variant starts; the counter's field is 4 bits wide)
     out, pending = [], []
     for x in ins:
         if x.kind == "label" and re.match(VARIANTS, x.text):
-            pending = [t.writes for t in tail]
+            pending = [t.writes for t in tail][-15:]
         if x.kind == "label" and x.text.startswith("L_epilogue"):
-            pending = [t.writes for t in tail]
+            pending = [t.writes for t in tail][-15:]
         if x.kind == "wait" and "lgkm" in x.tag:
             pending = []
         touched = set(x.reads) | set(x.writes)

@@ -25,6 +25,7 @@ Structure (cdna_hip_programming.md, "4-wave, one-wave-per-SIMD, persistent struc
 
 The file written is a C++ header with one string literal per element type (bf16 / f16) and the clobber list."""
 import argparse
+import os
 import re
 import sys
 from pathlib import Path
@@ -35,7 +36,7 @@ OUT = ROOT / "kfunca_amd" / "csrc" / "device" / "attn_fwd_w4.inc"
 # ------------------------------------------------------------------ register map
 def S(b, n): return 32 * b + n                  # score / probability n (0..31 = sub * 16 + register) of block b
 def P(b, ks): return 64 + 16 * b + 4 * ks        # packed 16-bit P fragment of k-step ks (4 VGPRs)
-def VF(ks, db): return 96 + 16 * ks + 4 * db     # V^T fragment (4 VGPRs)
+# (V^T / Q / K fragments and the O accumulators depend on the head size: Gen.VF / QF / KF / OA)
 KB = (160, 161)          # K row-read bases (even / odd k-step)
 VB = (162, 163)          # V transposed-read bases (first / second read of a fragment)
 DMA = (164, 165)         # LDS-DMA source offsets (even / odd row group)
@@ -45,9 +46,6 @@ MXA, MXB = (172, 174), (173, 175)  # per-lane tile maxima (two chains)
 NEGINF, RM, DV = 176, 177, 178
 T = list(range(180, 196))  # temporaries (slow path, prologue, epilogue)
 NMC = (200, 216)           # sixteen copies of -MC per block: the C operand of a score chain's first MFMA (S^T arrives as score - maximum in use)
-def OA(b, db): return 64 * b + 16 * db           # AGPRs
-def QF(b, kk): return 128 + 32 * b + 4 * kk
-def KF(sub, kk): return 192 + 32 * sub + 4 * kk
 
 # scalar registers (all clobbered; inputs are copied in)
 # (s32 .. s35 are the ABI's stack / frame registers: not ours to clobber)
@@ -93,7 +91,19 @@ def A(i, n=1): return [("a", j) for j in range(i, i + n)]
 
 
 class Gen:
-    def __init__(self, f16=False, mutant=False, ablate=(), stamps=False, scaled=False):
+    def __init__(self, f16=False, mutant=False, ablate=(), stamps=False, scaled=False, D=128):
+        # D = 64 (round 5; the reference's second fast head size, causal_attention_kernel.cu:40-52): half the k-steps and half
+        # the column blocks - a 64-key tile is 32 MFMAs in four slots of 8 - with the SAME softmax work per tile, so the tile is VALU-issue bound
+        # (three scores per gap in the exponent chain). LDS images keep their 256-byte rows with the first 128 bytes used: every address formula
+        # is the D = 128 one, a row group of a tile is ONE 1-KiB DMA piece instead of two. Exact scores only.
+        assert D in (64, 128) and not (scaled and D == 64)
+        self.D, self.NKK, self.NDB = D, D // 16, D // 32
+        self.SL = 2 * self.NKK               # MFMAs per slot (S of a block: 2 sub-tiles x NKK k-steps; P V: 4 k-steps x NDB column blocks)
+        self.NG = 4 * self.SL                # gaps per tile iteration
+        self.VF = lambda ks, db: 96 + 4 * self.NDB * ks + 4 * db        # V^T fragment (4 VGPRs)
+        self.OA = lambda b, db: 16 * self.NDB * b + 16 * db             # AGPRs
+        self.QF = lambda b, kk: 128 + 4 * self.NKK * b + 4 * kk
+        self.KF = lambda sub, kk: 192 + 4 * self.NKK * sub + 4 * kk
         self.mutant = mutant
         # scaled: the query is multiplied by scale log2(e) and ROUNDED to the element type once per pass, the score chains start from -max and
         # deliver exponents (no multiply per score: -64 VALU per tile, ~4 % of the kernel) - at the price of a score error of eps scale sum|q k|,
@@ -125,25 +135,25 @@ class Gen:
             c, cr = "0", []
         else:
             c, cr = vr(NMC[b], 16), V(NMC[b], 16)
-        self.out.append(Ins(f"{self.mfma} {vr(d, 16)}, {ar(KF(sub, kk), 4)}, {ar(QF(b, kk), 4)}, {c}", "mfma",
-                            A(KF(sub, kk), 4) + A(QF(b, kk), 4) + cr, V(d, 16), tag=f"qk b{b} sub{sub} kk{kk}"))
+        self.out.append(Ins(f"{self.mfma} {vr(d, 16)}, {ar(self.KF(sub, kk), 4)}, {ar(self.QF(b, kk), 4)}, {c}", "mfma",
+                            A(self.KF(sub, kk), 4) + A(self.QF(b, kk), 4) + cr, V(d, 16), tag=f"qk b{b} sub{sub} kk{kk}"))
 
     def pv(self, b, ks, db):
-        o = OA(b, db)
-        self.out.append(Ins(f"{self.mfma} {ar(o, 16)}, {vr(VF(ks, db), 4)}, {vr(P(b, ks), 4)}, {ar(o, 16)}", "mfma",
-                            V(VF(ks, db), 4) + V(P(b, ks), 4) + A(o, 16), A(o, 16), tag=f"pv b{b} ks{ks} db{db}"))
+        o = self.OA(b, db)
+        self.out.append(Ins(f"{self.mfma} {ar(o, 16)}, {vr(self.VF(ks, db), 4)}, {vr(P(b, ks), 4)}, {ar(o, 16)}", "mfma",
+                            V(self.VF(ks, db), 4) + V(P(b, ks), 4) + A(o, 16), A(o, 16), tag=f"pv b{b} ks{ks} db{db}"))
 
     def lds_k(self, sub, kk):   # K fragment (sub, kk) of the tile at the K bases
         if "lds" in self.ablate: return
         imm = 8192 * sub + 512 * (kk >> 1)
-        self.out.append(Ins(f"ds_read_b128 {ar(KF(sub, kk), 4)}, {vr(KB[kk & 1])} offset:{imm}", "lds", V(KB[kk & 1]), A(KF(sub, kk), 4)))
+        self.out.append(Ins(f"ds_read_b128 {ar(self.KF(sub, kk), 4)}, {vr(KB[kk & 1])} offset:{imm}", "lds", V(KB[kk & 1]), A(self.KF(sub, kk), 4)))
 
     def lds_v(self, ks, db, second):  # half of V^T fragment (ks, db): keys 16 ks + 4 h + {0..3} (+ 8 for the second half)
         sub, s = ks >> 1, ks & 1
         if "lds" in self.ablate: return
         imm = 2048 * (4 * sub + 2 * s + second) + 512 * db
-        self.out.append(Ins(f"ds_read_b64_tr_b16 {vr(VF(ks, db) + 2 * second, 2)}, {vr(VB[second])} offset:{imm}", "lds",
-                            V(VB[second]), V(VF(ks, db) + 2 * second, 2)))
+        self.out.append(Ins(f"ds_read_b64_tr_b16 {vr(self.VF(ks, db) + 2 * second, 2)}, {vr(VB[second])} offset:{imm}", "lds",
+                            V(VB[second]), V(self.VF(ks, db) + 2 * second, 2)))
 
     def wait(self, vm=None, lgkm=None):
         parts = ([f"vmcnt({vm})"] if vm is not None else []) + ([f"lgkmcnt({lgkm})"] if lgkm is not None else [])
@@ -190,15 +200,17 @@ class Gen:
         # (this variant runs once per wave and block: its gaps may be as full as they need to be; the chain's timing stays the steady one)
         if masked:
             sub = 0 if b == 0 else 1   # b0: sub 0 is the diagonal, sub 1 lies wholly above it; b1: sub 0 is visible, sub 1 is the diagonal
+            d64 = self.D == 64
             if b == 0:
                 for e in range(16):  # sub 1 of block 0: all of it (its 8 MFMAs are not issued)
-                    add(2 + e // 3, lambda e=e: self.valu(f"v_mov_b32 {vr(S(0, 16 + e))}, {vr(NEGINF)}", V(NEGINF), V(S(0, 16 + e))))
-                add(8, lambda: self.valu(f"v_mov_b32 {vr(MXB[0])}, {vr(NEGINF)}", V(NEGINF), V(MXB[0])))
-                add(8, lambda: self.salu("s_nop 15"))   # no MFMAs follow the diagonal sub-tile's chain in this slot: give its last one its time
-                add(8, lambda: self.salu("s_nop 7"))
+                    add((1 + e // 4) if d64 else (2 + e // 3), lambda e=e: self.valu(f"v_mov_b32 {vr(S(0, 16 + e))}, {vr(NEGINF)}", V(NEGINF), V(S(0, 16 + e))))
+                gn = self.NKK        # behind the diagonal sub-tile's last MFMA
+                add(gn, lambda: self.valu(f"v_mov_b32 {vr(MXB[0])}, {vr(NEGINF)}", V(NEGINF), V(MXB[0])))
+                add(gn, lambda: self.salu("s_nop 15"))   # no MFMAs follow the diagonal sub-tile's chain in this slot: give its last one its time
+                add(gn, lambda: self.salu("s_nop 7"))
             for e in range(16):
                 kc = (e & 3) + 8 * (e >> 2)
-                g = (9 if sub == 0 else 17) + e // 8
+                g = ((5 if sub == 0 else 9) if d64 else (9 if sub == 0 else 17)) + e // 8
                 def m(e=e, kc=kc, sub=sub):
                     self.valu(f"v_cmp_gt_i32 vcc, {kc}, {vr(RM)}", V(RM), [("vcc", 0)])
                     self.valu(f"v_cndmask_b32 {vr(S(b, 16 * sub + e))}, {vr(S(b, 16 * sub + e))}, {vr(NEGINF)}, vcc",
@@ -213,16 +225,27 @@ class Gen:
             for (x, y, z), g in zip(seq, gaps):
                 add(g, lambda x=x, y=y, z=z, mx=mx: self.valu(f"v_max3_f32 {vr(mx)}, {vr(x)}, {vr(y)}, {vr(z)}", V(x) + V(y) + V(z), V(mx)))
         s0, s1 = [S(b, e) for e in range(16)], [S(b, 16 + e) for e in range(16)]
-        if masked and b == 0:        # sub 1 lies wholly above the diagonal (MXB = -inf above); sub 0 behind its mask ops
+        if self.D == 64:             # sub 0's scores are readable from gap 5 (its chain ends at MFMA 3), sub 1's from gap 9
+            if masked and b == 0:
+                chain(s0, MXA[0], [7, 7, 8, 8, 9, 9, 10, 10])
+                add(11, lambda: self.valu(f"v_mov_b32 {vr(MXC)}, {vr(NEGINF)}", V(NEGINF), V(MXC)))
+            else:
+                chain(s0, MXA[b], [5, 5, 6, 6, 7, 7, 8, 8])
+                g1 = [11, 11, 12, 12] if masked else [9, 9, 10, 10]
+                chain(s1[:8], MXB[b], g1)
+                chain(s1[8:], MXC, g1)
+            gd = 13
+        elif masked and b == 0:      # sub 1 lies wholly above the diagonal (MXB = -inf above); sub 0 behind its mask ops
             chain(s0, MXA[0], [11, 11, 12, 12, 13, 13, 14, 14])
             add(15, lambda: self.valu(f"v_mov_b32 {vr(MXC)}, {vr(NEGINF)}", V(NEGINF), V(MXC)))
+            gd = 21
         else:
             chain(s0, MXA[b], [9, 9, 10, 11, 12, 13, 14, 14])
             g1 = [19, 19, 20, 20] if masked else [17, 18, 19, 20]
             chain(s1[:8], MXB[b], g1)
             chain(s1[8:], MXC, g1)
+            gd = 21
         # ---- decision: does any query of the wave exceed the maximum in use by more than `defer` exponent units?
-        gd = 21
         add(gd, lambda: self.valu(f"v_max3_f32 {vr(MXA[b])}, {vr(MXA[b])}, {vr(MXB[b])}, {vr(MXC)}", V(MXA[b]) + V(MXB[b]) + V(MXC), V(MXA[b])))
         if not self.scaled:
             # exact scores: the excess of the tile's maximum over the one in use, in exponent units
@@ -238,18 +261,20 @@ class Gen:
         # ---- the exponent chain, one value per gap: [fma: scale, subtract the maximum |] exp2 | row sum | pack pairs
         # (order inside a gap: exp | pack | row sum | fma - the consumer of an exp stands at least two instructions behind it)
         g0 = gd + 2
+        per = 3 if self.D == 64 else 1   # scores per gap: the block's P V slot starts 24 (D = 64) or 48 gaps behind its S slot
         for n in range(32):
             x = S(b, n)
+            gn = g0 + n // per
             if drop:  # mutation build: this tile's probabilities are dropped (p = exp2(-inf) = 0)
-                add(g0 + n, lambda x=x: self.valu(f"v_mov_b32 {vr(x)}, {vr(NEGINF)}", V(NEGINF), V(x)), key=1003)
+                add(gn, lambda x=x: self.valu(f"v_mov_b32 {vr(x)}, {vr(NEGINF)}", V(NEGINF), V(x)), key=1003)
             elif not self.scaled:
-                add(g0 + n, lambda x=x: self.valu(f"v_fma_f32 {vr(x)}, {vr(x)}, {s_c}, -{vr(MC[b])}", V(x) + V(MC[b]), V(x)), key=1003)
-            add(g0 + n + 1, lambda x=x: self.valu(f"v_exp_f32 {vr(x)}, {vr(x)}", V(x), V(x), trans=True), key=1000)
+                add(gn, lambda x=x: self.valu(f"v_fma_f32 {vr(x)}, {vr(x)}, {s_c}, -{vr(MC[b])}", V(x) + V(MC[b]), V(x)), key=1003)
+            add(gn + 1, lambda x=x: self.valu(f"v_exp_f32 {vr(x)}, {vr(x)}", V(x), V(x), trans=True), key=1000)
             l = (LA if n % 2 == 0 else LB)[b]
-            add(g0 + n + 2, lambda x=x, l=l: self.valu(f"v_add_f32 {vr(l)}, {vr(l)}, {vr(x)}", V(l) + V(x), V(l)), key=1002)
+            add(gn + 2, lambda x=x, l=l: self.valu(f"v_add_f32 {vr(l)}, {vr(l)}, {vr(x)}", V(l) + V(x), V(l)), key=1002)
             if n % 2 == 1:
                 d = P(b, n // 8) + (n % 8) // 2
-                add(g0 + n + 3, lambda x=x, d=d: self.valu(f"{self.cvt} {vr(d)}, {vr(x - 1)}, {vr(x)}", V(x - 1) + V(x), V(d)), key=1001)
+                add(gn + 3, lambda x=x, d=d: self.valu(f"{self.cvt} {vr(d)}, {vr(x - 1)}, {vr(x)}", V(x - 1) + V(x), V(d)), key=1001)
         return ops
 
     def adopt_first(self, b):
@@ -298,7 +323,7 @@ class Gen:
         self.salu("s_nop 0")
         self.valu(f"v_mul_f32 {vr(LA[b])}, {vr(LA[b])}, {vr(t1)}", V(LA[b]) + V(t1), V(LA[b]))
         self.valu(f"v_mul_f32 {vr(LB[b])}, {vr(LB[b])}, {vr(t1)}", V(LB[b]) + V(t1), V(LB[b]))
-        for base in range(OA(b, 0), OA(b, 0) + 64, 8):
+        for base in range(self.OA(b, 0), self.OA(b, 0) + 16 * self.NDB, 8):
             for j in range(8):
                 self.valu(f"v_accvgpr_read_b32 {vr(T[4 + j])}, {ar(base + j)}", A(base + j), V(T[4 + j]))
             for j in range(8):
@@ -313,8 +338,9 @@ class Gen:
     def iteration(self, name, has_prev, has_cur, masked=False, drop=False):
         """has_cur: this wave computes tile `it` (S of both blocks, block 0's softmax and P V, the head of block 1's softmax);
         has_prev: it owes tile it - 1 its second half (block 1's softmax tail and P V). Neither: only the DMA and the barrier."""
-        G = [[] for _ in range(64)]   # fillers per gap, (order key, emit function)
-        def put(g, key, fn): G[g % 64].append((key, fn))
+        SL, NG, NKK, NDB = self.SL, self.NG, self.NKK, self.NDB
+        G = [[] for _ in range(NG)]   # fillers per gap, (order key, emit function)
+        def put(g, key, fn): G[g % NG].append((key, fn))
         self.in_loop = True
         first = has_cur and not has_prev   # a pass's first tile: no maximum in use yet
         if "valu" in self.ablate:
@@ -325,35 +351,41 @@ class Gen:
             for (g, k, fn) in self.softmax_ops(0, True, masked, drop, first):
                 put(g, (0, k), fn)
             for (g, k, fn) in self.softmax_ops(1, True, masked, drop, first):
-                if 32 + g < 64:
-                    put(32 + g, (1, k), fn)
+                if 2 * SL + g < NG:
+                    put(2 * SL + g, (1, k), fn)
         if has_prev_sm:
             for (g, k, fn) in self.softmax_ops(1, False, False, False):   # the tail of the PREVIOUS tile's block 1 (never the diagonal tile's mask: that sits in the head)
-                if 32 + g >= 64:
-                    put(32 + g - 64, (1, k), fn)
+                if 2 * SL + g >= NG:
+                    put(2 * SL + g - NG, (1, k), fn)
         # V^T fragments of tile it: read ONCE, in slot C, in consumption order, 2 per gap; they serve slot D (block 0) and slot B of
         # the NEXT iteration (block 1's P V of the same tile): the 64 registers are rewritten only by slot C of that iteration
         # A fragment (ks, db) may be rewritten once slot B's MFMA 16 + 4 ks + db has read it, and V(it) is in LDS since the barrier at gap
         # 16: the 32 reads spread over gaps 22 .. 47 (VREAD_G) instead of crowding slot C.
         if has_cur:
-            seq = [(ks, db, sec) for ks in range(4) for db in range(4) for sec in (0, 1)]
+            seq = [(ks, db, sec) for ks in range(4) for db in range(NDB) for sec in (0, 1)]
             for i, (ks, db, sec) in enumerate(seq):
-                g = VREAD_G[i]
-                assert g >= 16 + 4 * ks + db + 2
+                # (D = 64: 16 reads, two per gap, each right behind slot B's last use of its registers (gaps 10 .. 17): the wait in front of slot D
+                #  drains the LDS queue, so a read issued just before it would stand there for its whole latency - first form, reads in 16 .. 23: 1.95 -> 1.71 ms only)
+                g = VREAD_G[i] if self.D == 128 else max(SL + 2 + i // 2, int(os.environ.get("KF_GEN_F64_V", SL + 2)) + i // 2)
+                assert g >= SL + NDB * ks + db + 2
                 put(g, (2, i), lambda ks=ks, db=db, sec=sec: self.lds_v(ks, db, sec))
         # K fragments of tile it + 1 (slot D; its own tiles only)
         if has_cur and not masked:
-            seq = [(sub, kk) for sub in range(2) for kk in range(8)]
+            seq = [(sub, kk) for sub in range(2) for kk in range(NKK)]
             for i, (sub, kk) in enumerate(seq):
-                put(48 + (i * 3) // 4, (2, i), lambda sub=sub, kk=kk: self.lds_k(sub, kk))
+                put((48 + (i * 3) // 4) if self.D == 128 else (3 * SL + i // int(os.environ.get("KF_GEN_F64_K", 2))), (2, i), lambda sub=sub, kk=kk: self.lds_k(sub, kk))   # (D = 64: done four gaps before the next tile's wait)
         # LDS-DMA of K(it + 2) and V(it + 1): this wave's 4 + 4 pieces, behind the barrier, one per gap from gap 23
         pieces = [(K_SRD, DMA[0], S_KOFF0, S_M0K, 0, 0), (K_SRD, DMA[0], S_KOFF0, S_M0K, 896, 128),
                   (K_SRD, DMA[1], S_KOFF1, S_M0K, 2048, 0), (K_SRD, DMA[1], S_KOFF1, S_M0K, 2048 + 896, 128),
                   (V_SRD, DMA[0], S_VOFF0, S_M0V, 0, 0), (V_SRD, DMA[0], S_VOFF0, S_M0V, 896, 128),
                   (V_SRD, DMA[1], S_VOFF1, S_M0V, 2048, 0), (V_SRD, DMA[1], S_VOFF1, S_M0V, 2048 + 896, 128)]
+        dma_g = DMA_G
+        if self.D == 64:     # a row group's 8 x 128 B are ONE piece (the first half of the image): 2 K + 2 V pieces per wave, behind the barrier at gap 8
+            pieces = [p for p in pieces if p[5] == 0]
+            dma_g = [11, 12, 13, 14]
         for i, p in enumerate(pieces):
-            put(DMA_G[i], (-1, i), lambda p=p: self.dma_m0(p[3], p[4]))      # M0 first in the gap, the load last
-            put(DMA_G[i], (3, i), lambda p=p: self.dma_load(p[0], p[1], p[2], p[5]))
+            put(dma_g[i], (-1, i), lambda p=p: self.dma_m0(p[3], p[4]))      # M0 first in the gap, the load last
+            put(dma_g[i], (3, i), lambda p=p: self.dma_load(p[0], p[1], p[2], p[5]))
         # loop bookkeeping (slot B, behind the DMA): ring toggles, next source offsets
         # each toggle sits between the last use of the old slot and the first use of the new one
         def book_vb():   # V read bases -> the slot of V(it): behind the barrier, before the first V read
@@ -371,35 +403,36 @@ class Gen:
             self.salu(f"s_add_u32 {sr(S_VOFF0)}, {sr(S_VOFF0)}, {sr(S_TSTEP)}")
             self.salu(f"s_min_u32 {sr(S_VOFF0)}, {sr(S_VOFF0)}, {sr(S_X2)}")
             self.salu(f"s_add_u32 {sr(S_VOFF1)}, {sr(S_VOFF0)}, {sr(S_TMP2)}")
-        put(BOOK_VB_G, (4, 0), book_vb)
-        put(BOOK_K_G, (4, 1), book_k)
-        put(BOOK_V_G, (4, 2), book_v)
+        gb = 31 if self.D == 128 else 15      # (BOOK_*_G: the last gap of slot B)
+        put(gb if self.D == 128 else SL + 1, (4, 0), book_vb)   # (D = 64: the V reads start at gap SL + 2)
+        put(gb, (4, 1), book_k)
+        put(gb, (4, 2), book_v)
 
         self.label(f"L_{name}_%=")
-        for g in range(64):
-            slot, j = g // 16, g % 16
+        for g in range(NG):
+            slot, j = g // SL, g % SL
             # ---- waits in front of the slot's first MFMA
             if g == 0 and has_cur:
                 self.wait(lgkm=0)          # K fragments (read in slot D of the previous iteration / the prologue)
-            if name == "steady" and g in (16, 32, 48):
+            if name == "steady" and self.D == 128 and g in (16, 32, 48):
                 self.stamp(g // 16)        # slot A / B / C ends here
-            if g == 16 and has_cur and not has_prev:
+            if g == SL and has_cur and not has_prev:
                 self.salu("s_nop 15")   # no MFMAs in this slot of the first tile: the S chain that has just been issued gets its time
                 self.salu("s_nop 7")
-            if g == 16:
+            if g == SL:
                 self.wait(vm=0)            # this wave's DMA pieces of the previous iteration have landed
                 self.barrier()             # everyone's: K(it + 1), V(it) are in LDS, V(it - 1) and K(it) are no longer read
-            if g == 48 and has_cur:
+            if g == 3 * SL and has_cur:
                 self.wait(lgkm=0)          # V^T fragments (read in slot C)
             # ---- the MFMA of this gap
-            if slot == 0 and has_cur and not (masked and j >= 8):
-                self.qk(0, j // 8, j % 8, first)
+            if slot == 0 and has_cur and not (masked and j >= NKK):
+                self.qk(0, j // NKK, j % NKK, first)
             elif slot == 1 and has_prev:
-                self.pv(1, j // 4, j % 4)
+                self.pv(1, j // NDB, j % NDB)
             elif slot == 2 and has_cur:
-                self.qk(1, j // 8, j % 8, first)
+                self.qk(1, j // NKK, j % NKK, first)
             elif slot == 3 and has_cur:
-                self.pv(0, j // 4, j % 4)
+                self.pv(0, j // NDB, j % NDB)
             else:
                 self.out.append(Ins("", "nomfma"))
             for _, fn in sorted(G[g], key=lambda t: t[0]):
@@ -510,7 +543,7 @@ class Gen:
         e.salu(f"s_mul_i32 {sr(S_X0)}, {sr(S_TMP)}, {sr(S_QSR)}")                # this wave's first query row, bytes
         e.salu(f"s_lshl_b32 {sr(S_X1)}, {sr(S_QSR)}, 3")                         # 8 rows further
         for g in range(8):                                                         # (into the wave's OWN slab, S_STAGE: a wave that is early must not write where a late one still reads its O rows)
-            for half in range(2):
+            for half in range(2 if self.D == 128 else 1):
                 e.salu(f"s_add_u32 m0, {sr(S_STAGE)}, {2048 * g + 1024 * half - 128 * half}")
                 e.salu("s_nop 0")
                 o = " offset:128" if half else ""
@@ -521,7 +554,7 @@ class Gen:
         e.salu(f"s_mov_b32 {sr(S_KOFF0)}, {sr(S_RB0)}")
         e.salu(f"s_lshl_b32 {sr(S_TMP2)}, {sr(S_KVSR)}, 3")
         e.salu(f"s_add_u32 {sr(S_KOFF1)}, {sr(S_KOFF0)}, {sr(S_TMP2)}")
-        for i in range(4):
+        for i in (range(4) if self.D == 128 else (0, 2)):
             self.dma(K_SRD, DMA[i >> 1], S_KOFF0 + (i >> 1), S_M0K, 2048 * (i >> 1) + 896 * (i & 1), 128 * (i & 1))
         # K(1) (clamped) and V(0)
         e.salu(f"s_min_u32 {sr(S_TMP)}, 1, {sr(S_TM1)}")
@@ -531,9 +564,9 @@ class Gen:
         e.salu(f"s_mov_b32 {sr(S_VOFF0)}, {sr(S_RB0)}")
         e.salu(f"s_add_u32 {sr(S_VOFF1)}, {sr(S_VOFF0)}, {sr(S_TMP2)}")
         e.salu(f"s_xor_b32 {sr(S_M0K)}, {sr(S_M0K)}, {KSLOT}")
-        for i in range(4):
+        for i in (range(4) if self.D == 128 else (0, 2)):
             self.dma(K_SRD, DMA[i >> 1], S_KOFF0 + (i >> 1), S_M0K, 2048 * (i >> 1) + 896 * (i & 1), 128 * (i & 1))
-        for i in range(4):
+        for i in (range(4) if self.D == 128 else (0, 2)):
             self.dma(V_SRD, DMA[i >> 1], S_VOFF0 + (i >> 1), S_M0V, 2048 * (i >> 1) + 896 * (i & 1), 128 * (i & 1))
         e.salu(f"s_xor_b32 {sr(S_M0K)}, {sr(S_M0K)}, {KSLOT}")                # iteration 0 stages K(2) into slot 0 ...
         e.salu(f"s_xor_b32 {sr(S_M0V)}, {sr(S_M0V)}, {KSLOT}")                # ... and V(1) into slot 1
@@ -544,7 +577,7 @@ class Gen:
             e.salu(f"s_add_u32 {sr(dst0)}, {sr(S_TMP)}, {sr(S_RB0)}")
             e.salu(f"s_add_u32 {sr(dst1)}, {sr(dst0)}, {sr(S_TMP2)}")
         e.raw("; ---- O = 0, running maximum = -inf, row sums = 0")
-        for i in range(128):
+        for i in range(32 * self.NDB):
             e.valu(f"v_accvgpr_write_b32 {ar(i)}, 0", (), A(i))
         for b in range(2):
             e.valu(f"v_mov_b32 {vr(MC[b])}, {vr(NEGINF)}")
@@ -552,17 +585,17 @@ class Gen:
             e.valu(f"v_mov_b32 {vr(LB[b])}, 0")
         # ---- the Q fragments out of the slab: straight into a[128:191] (exact scores), or through the score registers where they are multiplied by
         #      scale log2(e) and rounded to the element type once (scaled query: the score MFMAs then deliver exponents)
-        e.wait(vm=12)     # in-order counter: this wave's 16 Q pieces are older than its 12 K / V pieces; the quarter is its own: no barrier
+        e.wait(vm=12 if self.D == 128 else 6)     # in-order counter: this wave's 16 (8) Q pieces are older than its 12 (6) K / V pieces; the quarter is its own: no barrier
         qb = (T[10], T[11])
         e.salu(f"s_sub_u32 {sr(S_TMP)}, {sr(S_STAGE)}, {sr(S_LDS)}")           # (S_TMP2 holds 8 key rows' bytes from here to the end of the loop)
         for i in range(2):
             e.valu(f"v_add_u32 {vr(qb[i])}, {sr(S_TMP)}, {vr(KB[i])}")           # (the K bases sit at slot 0 here: S_LDS + the lane's row / chunk)
         for b in range(2):
-            for kk in range(8):
+            for kk in range(self.NKK):
                 if self.scaled:
-                    e.out.append(Ins(f"ds_read_b128 {vr(QF(b, kk) - 128, 4)}, {vr(qb[kk & 1])} offset:{8192 * b + 512 * (kk >> 1)}", "lds", V(qb[kk & 1]), V(QF(b, kk) - 128, 4)))
+                    e.out.append(Ins(f"ds_read_b128 {vr(self.QF(b, kk) - 128, 4)}, {vr(qb[kk & 1])} offset:{8192 * b + 512 * (kk >> 1)}", "lds", V(qb[kk & 1]), V(self.QF(b, kk) - 128, 4)))
                 else:
-                    e.out.append(Ins(f"ds_read_b128 {ar(QF(b, kk), 4)}, {vr(qb[kk & 1])} offset:{8192 * b + 512 * (kk >> 1)}", "lds", V(qb[kk & 1]), A(QF(b, kk), 4)))
+                    e.out.append(Ins(f"ds_read_b128 {ar(self.QF(b, kk), 4)}, {vr(qb[kk & 1])} offset:{8192 * b + 512 * (kk >> 1)}", "lds", V(qb[kk & 1]), A(self.QF(b, kk), 4)))
         e.wait(lgkm=0)
         if not self.scaled:
             pass
@@ -583,10 +616,10 @@ class Gen:
                 e.valu(f"{self.cvt} {vr(i)}, {vr(lo)}, {vr(hi)}")
                 e.valu(f"v_accvgpr_write_b32 {ar(128 + i)}, {vr(i)}", V(i), A(128 + i))
         # ---- K(0) has landed for everyone: its fragments; then the ring bases move to where iteration 0 expects them
-        e.wait(vm=8)      # in-order counter: the 16 Q loads and the 4 K(0) pieces are older than the 4 + 4 pieces of K(1) and V(0)
+        e.wait(vm=8 if self.D == 128 else 4)      # in-order counter: the Q loads and the K(0) pieces are older than the 4 + 4 (2 + 2) pieces of K(1) and V(0)
         e.barrier()
         for sub in range(2):
-            for kk in range(8):
+            for kk in range(self.NKK):
                 self.lds_k(sub, kk)
         e.salu(f"s_mov_b32 {sr(S_IT)}, 0")
         self.stamp(0)
@@ -678,9 +711,9 @@ class Gen:
         e.valu(f"v_lshl_add_u32 {vr(st)}, {vr(h)}, 3, {vr(st)}")
         e.valu(f"v_add_u32 {vr(st)}, {sr(S_STAGE)}, {vr(st)}")
         for b in range(2):
-            for db in range(4):
+            for db in range(self.NDB):
                 for gq in range(4):
-                    a0 = OA(b, db) + 4 * gq
+                    a0 = self.OA(b, db) + 4 * gq
                     x = T[8:12]
                     for j in range(4):
                         e.valu(f"v_accvgpr_read_b32 {vr(x[j])}, {ar(a0 + j)}")
@@ -692,8 +725,8 @@ class Gen:
         e.wait(lgkm=0)   # the same wave reads back what it wrote: LDS operations of one wave complete in order
         # rows out: 4 rows per instruction (16 lanes x 16 B each)
         rd, oo = T[12], T[13]
-        e.valu(f"v_lshrrev_b32 {vr(rd)}, 4, {vr(lane)}")
-        e.valu(f"v_and_b32 {vr(oo)}, 15, {vr(lane)}")
+        e.valu(f"v_lshrrev_b32 {vr(rd)}, {4 if self.D == 128 else 3}, {vr(lane)}")      # 16 lanes per 256-byte row | 8 lanes per 128-byte row
+        e.valu(f"v_and_b32 {vr(oo)}, {15 if self.D == 128 else 7}, {vr(lane)}")
         e.valu(f"v_lshlrev_b32 {vr(oo)}, 4, {vr(oo)}")
         e.valu(f"v_mul_lo_u32 {vr(T[14])}, {vr(rd)}, {sr(S_OSR)}")
         e.valu(f"v_mul_u32_u24 {vr(rd)}, {STAGE_ROW}, {vr(rd)}")
@@ -701,10 +734,11 @@ class Gen:
         e.valu(f"v_add_u32 {vr(oo)}, {vr(oo)}, {vr(T[14])}")
         e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 6")
         e.salu(f"s_mul_i32 {sr(S_X0)}, {sr(S_TMP)}, {sr(S_OSR)}")
-        e.salu(f"s_lshl_b32 {sr(S_X1)}, {sr(S_OSR)}, 2")
-        for j in range(16):
+        rows_per = 4 if self.D == 128 else 8                                        # rows one store instruction covers
+        e.salu(f"s_lshl_b32 {sr(S_X1)}, {sr(S_OSR)}, {2 if self.D == 128 else 3}")
+        for j in range(64 // rows_per):
             d = 100 + 4 * (j % 8)   # v[100..131]: the fragment registers are free now
-            e.out.append(Ins(f"ds_read_b128 {vr(d, 4)}, {vr(rd)} offset:{4 * j * STAGE_ROW}", "lds"))
+            e.out.append(Ins(f"ds_read_b128 {vr(d, 4)}, {vr(rd)} offset:{rows_per * j * STAGE_ROW}", "lds"))
             if j % 8 == 7:
                 e.wait(lgkm=0)
                 for i in range(8):
@@ -958,13 +992,21 @@ def main():
                 gg = Gen(f16, mut, ablate=abl, stamps=args.stamps, scaled=sq).build()
                 assert abl or not check(gg.out), check(gg.out)[:5]
                 texts[(f16, mut, sq)] = render(gg.out).replace(chr(10), " " + chr(92) + chr(10))
+    texts64 = {}
+    for f16 in (False, True):
+        for mut in (False, True):
+            gg = Gen(f16, mut, ablate=abl, D=64).build()
+            assert abl or not check(gg.out), check(gg.out)[:5]
+            texts64[(f16, mut)] = render(gg.out).replace(chr(10), " " + chr(92) + chr(10))
     n_ins = sum(1 for i in g.out if i.kind not in ("raw", "label", "nomfma"))
     def four(mut):
-        return "\n".join(f"#define KF_FWD_W4_ASM_{'F16' if f16 else 'BF16'}{'_SQ' if sq else ''} \\\n{texts[(f16, mut, sq)]}" for f16 in (False, True) for sq in (False, True))
+        return "\n".join([f"#define KF_FWD_W4_ASM_{'F16' if f16 else 'BF16'}{'_SQ' if sq else ''} \\\n{texts[(f16, mut, sq)]}" for f16 in (False, True) for sq in (False, True)] +
+                         [f"#define KF_FWD_W4_D64_ASM_{'F16' if f16 else 'BF16'} \\\n{texts64[(f16, mut)]}" for f16 in (False, True)])
     text = f"""// GENERATED by tools/gen_attn_fwd.py - do not edit; edit the generator and run it again.
 // The 16-bit causal-attention forward of one 256-row query block as ONE instruction stream per element type ({n_ins} instructions):
 // 4 waves x 64 query rows, one wave per SIMD, all 512 registers asm-owned; see the generator's header for the structure.
 // Two forms: exact f32 scores (default), and _SQ = the query scaled and rounded once per pass (KF_ATTN_SCALED_OPERANDS: faster, less exact).
+// _D64_ = head size 64 (exact form only): a 64-key tile is 32 MFMAs, the exponent chain runs three scores per gap.
 #pragma once
 #define KF_FWD_W4_LDS_BYTES {LDS_BYTES}
 #define KF_FWD_W4_CLOBBERS {", ".join('"' + c + '"' for c in CLOBBERS + ([f"s{i}" for i in range(80, 92)] if args.stamps else []))}
