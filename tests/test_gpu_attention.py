@@ -523,6 +523,36 @@ def test_scaled_operand_streams():
                     assert np.array_equal(a.view(np.uint16), b.view(np.uint16)), (code, n, Sq, Skv)
 
 
+@pytest.mark.parametrize("code", [H.BF16, H.F16])
+def test_head_size_64_generated_streams_against_the_hand_kernels(code):
+    """Round 5: head size 64 - the reference's second fast size (causal_attention_kernel.cu:40-52) - runs the generated
+    streams too (gen_attn_fwd.py / gen_attn_dkv.py with D = 64) wherever their shape conditions hold. Both the streams and the round-2/3 hand
+    kernels (KF_ATTN_FWD_V3 / KF_ATTN_DKV_V4) must hold the bounds against the oracle, and they must agree with each other: the forward to
+    the rounding of P (different tile shapes, different moments of adopting a new maximum), dK / dV / dQ of the bf16 stream to the bit (the
+    same arithmetic in the same order; f16: dV to the bit, dK / dQ to one rounding of dS - see test_scaled_operand_streams)."""
+    for (B, Hh, Sq, Skv) in ((1, 2, 512, 512), (2, 8, 2048, 2048), (1, 2, 256, 768)):
+        rng = np.random.default_rng(64 + Sq + Skv + code)
+        q, k, v, go = (O.from_float(rng.uniform(-1, 1, s).astype(np.float32), code)
+                       for s in ((B, Hh, Sq, 64), (B, Hh, Skv, 64), (B, Hh, Skv, 64), (B, Hh, Sq, 64)))
+        ref = O.attn_ref64(q, k, v, go, code=code)
+        o, lse = fwd(code, q, k, v)
+        g = bwd(code, q, k, v, o, lse, go)
+        K.attn_check(q, k, v, code, o=o, lse=lse, d_o=go, dq=g[0], dk=g[1], dv=g[2], ref=ref, what=f"D64 streams {Sq}x{Skv}")
+        with H.knobs(KF_ATTN_FWD_V3="1", KF_ATTN_DKV_V4="1"):
+            o3, lse3 = fwd(code, q, k, v)
+            g4 = bwd(code, q, k, v, o, lse, go)          # (the same O and lse: the backward kernels alone are compared)
+        K.attn_check(q, k, v, code, o=o3, lse=lse3, d_o=go, dq=g4[0], dk=g4[1], dv=g4[2], ref=ref, what=f"D64 hand kernels {Sq}x{Skv}")
+        assert np.abs(lse - lse3).max() <= 1e-5 * (1 + np.abs(lse).max())
+        d = np.abs(f(o, code).astype(np.float64) - f(o3, code).astype(np.float64))
+        assert d.max() <= 4 * K.EPS[code] * np.abs(f(o, code)).max()
+        for n, a, b in zip(("dq", "dk", "dv"), g, g4):
+            if code == H.F16 and n != "dv":
+                fa, fb = f(a, code).astype(np.float64), f(b, code).astype(np.float64)
+                assert (np.abs(fa - fb) <= 2.0 ** -9 * np.abs(fa).max(axis=-1, keepdims=True) + 2.0 ** -24).all(), (code, n, Sq, Skv)
+            else:
+                assert np.array_equal(a.view(np.uint16), b.view(np.uint16)), (code, n, Sq, Skv)
+
+
 def test_forward_without_an_lse_buffer():
     """kf_attn_fwd's lse pointer may be NULL (a caller that wants no backward): every forward kernel - the generated stream, the 8-wave
     kernel, D = 64 - must skip the store and write the same O."""

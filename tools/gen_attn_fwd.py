@@ -64,9 +64,11 @@ N_VGPR = 232  # v0 .. v231 are the stream's; the rest of the arch file stays the
 # 612 / 891 / 683 / 754 = 2940 - LDS reads beside DMA pieces cost more than they relieve. (Exact-score stream, k-step 0's eight reads in gaps 18 .. 21 and
 # the rest two per gap in slot C: 611 / 878 / 674 / 665 = 2827 against 608 / 814 / 695 / 662 = 2779: slot B is the full one. The pieces on every second gap
 # 17 .. 31 with the bookkeeping between them: 613 / 832 / 712 / 703 = 2861.)
-DMA_G = [23, 24, 25, 26, 27, 28, 29, 30]   # all 8 pieces behind the barrier, one per gap (K first: it is needed a slot earlier)
+DMA_G = [int(os.environ.get("KF_GEN_F128_DMA0", 23)) + i for i in range(8)]   # all 8 pieces behind the barrier, one per gap (K first: it is needed a slot earlier)
 BOOK_K_G, BOOK_V_G, BOOK_VB_G = 31, 31, 31  # ring toggles + next source offsets, each behind the last use of the old slot
-VREAD_G = [32 + i // 3 for i in range(32)]  # slot C, three per gap: done five gaps before slot D's wait
+# (round 5: four per gap instead of three, and the K reads of slot D two per gap: both sets are back eight gaps before the s_waitcnt lgkmcnt(0)
+#  that drains the queue for them instead of five / four - same-box 1.178 / 1.195 / 1.186 ms against 1.203 / 1.223 / 1.208, tools/scratch/ab_fwd128.sh)
+VREAD_G = [32 + i // int(os.environ.get("KF_GEN_F128_V", 4)) for i in range(32)]  # slot C, four per gap: done eight gaps before slot D's wait
 
 KSLOT = 16384
 VSLOT0 = 32768
@@ -373,7 +375,7 @@ class Gen:
         if has_cur and not masked:
             seq = [(sub, kk) for sub in range(2) for kk in range(NKK)]
             for i, (sub, kk) in enumerate(seq):
-                put((48 + (i * 3) // 4) if self.D == 128 else (3 * SL + i // int(os.environ.get("KF_GEN_F64_K", 2))), (2, i), lambda sub=sub, kk=kk: self.lds_k(sub, kk))   # (D = 64: done four gaps before the next tile's wait)
+                put((48 + i // int(os.environ.get("KF_GEN_F128_K", 2))) if self.D == 128 else (3 * SL + i // int(os.environ.get("KF_GEN_F64_K", 2))), (2, i), lambda sub=sub, kk=kk: self.lds_k(sub, kk))   # (D = 64: done four gaps before the next tile's wait)
         # LDS-DMA of K(it + 2) and V(it + 1): this wave's 4 + 4 pieces, behind the barrier, one per gap from gap 23
         pieces = [(K_SRD, DMA[0], S_KOFF0, S_M0K, 0, 0), (K_SRD, DMA[0], S_KOFF0, S_M0K, 896, 128),
                   (K_SRD, DMA[1], S_KOFF1, S_M0K, 2048, 0), (K_SRD, DMA[1], S_KOFF1, S_M0K, 2048 + 896, 128),

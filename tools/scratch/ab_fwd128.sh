@@ -1,0 +1,10 @@
+#!/bin/bash
+# same-box A/B of forward variants at the C3 shape: ab_fwd128.sh ROUNDS lib ... ("" = the product)
+cd "$(dirname "$0")/../.."
+R=$1; shift
+for r in $(seq $R); do
+  for lib in "$@"; do
+    printf "%-36s" "${lib:-product}"
+    KF_HIP_LIB=${lib:+$PWD/$lib} python tools/attn_bench.py --no-bwd --rounds 7 2>&1 | grep "attn_fwd" | tr '\n' ' '; echo
+  done
+done
