@@ -24,6 +24,7 @@
 LDS waits are COUNTED and inserted by the generator (`finish_waits`): before an instruction that reads the destination of a pending LDS
 read, s_waitcnt lgkmcnt(N) with N = the reads issued after that one."""
 import argparse
+import os
 import re
 import sys
 from pathlib import Path
@@ -150,6 +151,17 @@ class Gen:
 
     def mm(self, d, dn, a, b, c=None, tag="", acc="v"):
         """D = A B + C on registers: d first of 16 (VGPR or AGPR by `acc`), a / b first of 4 VGPRs, C = D unless `c` names another tuple."""
+        if os.environ.get("KF_GEN_DKV_PROBE_16X16"):
+            # TIMING PROBE ONLY (wrong results): the same FLOPs as two v_mfma_f32_16x16x32 on the same operand registers - what would the cheaper
+            # matrix shape buy under the power cap? (tools/scratch: never in the product)
+            m16 = self.mfma.replace("32x32x16", "16x16x32")
+            r = (lambda i, n: vr(i, n)) if acc == "v" else (lambda i, n: ar(i, n))
+            W = V(d, 16) if acc == "v" else A(d, 16)
+            cc = d if c is None else c
+            cr = (lambda i: r(i, 4)) if c is None else (lambda i: vr(i, 4))
+            self.out.append(Ins(f"{m16} {r(d, 4)}, {vr(a, 4)}, {vr(b, 4)}, {cr(cc)}", "mfma", V(a, 4) + V(b, 4) + (W if c is None else V(c, 16)), W, tag=tag))
+            self.out.append(Ins(f"{m16} {r(d + 8, 4)}, {vr(a, 4)}, {vr(b, 4)}, {cr(cc + 8)}", "raw"))
+            return
         dst = vr(d, 16) if acc == "v" else ar(d, 16)
         W = V(d, 16) if acc == "v" else A(d, 16)
         if c is None:
