@@ -9,9 +9,13 @@
 // a descending sort is the ascending sort of the complemented key, which keeps equal keys in input order exactly like
 // the reference's reversed digit bins.
 //
-//   * n <= 8192: one block sorts spb segments in LDS with a bitonic network over (key, position) composites -
+//   * n <= 512: one block sorts spb segments in LDS with a bitonic network over (key, position) composites -
 //     positions are unique, so the total order IS the stable order and no ranking pass is needed. Short segments share a
 //     block (2048 slots per block), so [68185 segments x 13 keys] does not launch 68185 nearly empty blocks.
+//   * 512 < n <= 8192 (round 5): ONE block sorts ONE segment by a least-significant-digit radix sort that never leaves LDS - 8-bit digits, one
+//     pass per key byte, the ballot ranking of the long-segment path below, positions carried as 16-bit values. The bitonic network needs
+//     log2(P) (log2(P) + 1) / 2 = 78 LDS passes over a 4096-key segment (40 k cycles of LDS pipe); four radix passes need ~10 k cycles of VALU.
+//     Padding slots hold the largest key and the largest positions: a stable sort leaves them behind every real key.
 //   * n > 8192: least-significant-digit radix sort, 8-bit digits (one pass per key byte), four launches per pass:
 //     tile histograms -> two-level exclusive scan (inside chunks of 64 tiles, then over the chunks) -> stable scatter. A tile is 4096 keys, 1024 consecutive keys per wave.
 //     Ranking inside a wave is by digit match: 8 ballots give each lane the set of lanes holding its digit, the lane's
@@ -136,6 +140,98 @@ __global__ __launch_bounds__(1024) void sort_small_kernel(const SmallArgs a) {
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// mid-size segments: block-local LSD radix sort in LDS (one segment per block)
+// ------------------------------------------------------------------------------------------
+template <typename U, int W, int KIND, int NW, int ITEMS>
+__global__ __launch_bounds__(NW * 64) void sort_block_radix_kernel(const SmallArgs a) {
+    constexpr int NT = NW * 64, TILE = NT * ITEMS, WK = 64 * ITEMS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    U *skey = (U *)smem;                                            // [TILE]
+    uint16_t *spos = (uint16_t *)(smem + (size_t)TILE * sizeof(U)); // [TILE]
+    uint32_t(*cnt)[256] = (uint32_t(*)[256])(smem + (size_t)TILE * (sizeof(U) + 2));
+    uint32_t *dstart = (uint32_t *)(cnt + NW), *wsum = dstart + 256;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int64_t segoff = (int64_t)blockIdx.x * a.n;
+    const U flip = a.desc ? KeyBits<U, W>::all : (U)0;
+    const uint64_t below = (1ull << lane) - 1;
+    U key[ITEMS];
+    uint32_t pos[ITEMS], rank[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) { // index order: wave w holds items w WK + r 64 + lane (the order the ranks below are taken in)
+        const int i = w * WK + r * 64 + lane;
+        key[r] = i < a.n ? to_ordered<U, W, KIND>(load_raw<U, W>(a.in, segoff + i), flip) : KeyBits<U, W>::all; // (padding: behind every real key)
+        pos[r] = (uint32_t)i;
+    }
+#pragma unroll 1
+    for (int pass = 0; pass < W; ++pass) {
+        const int shift = 8 * pass;
+        for (int x = tid; x < NW * 256; x += NT) (&cnt[0][0])[x] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) { // rank among the wave's keys of the same digit: a popcount of the matching lanes below (stable)
+            const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+            uint64_t m = ~0ull;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const bool bit = (d >> b) & 1u;
+                const uint64_t bb = __ballot(bit);
+                m &= bit ? bb : ~bb;
+            }
+            const uint32_t prev = cnt[w][d];
+            rank[r] = prev + (uint32_t)__popcll(m & below);
+            if ((m & below) == 0) cnt[w][d] = prev + (uint32_t)__popcll(m); // the lowest lane of the match set
+        }
+        __syncthreads();
+        if (tid < 256) { // digit tid: the waves' counts -> exclusive offsets over the waves; exclusive scan of the digit totals
+            uint32_t total = 0;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) {
+                const uint32_t c = cnt[i][tid];
+                cnt[i][tid] = total;
+                total += c;
+            }
+            uint32_t inc = total;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t up = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += up;
+            }
+            if (lane == 63) wsum[w] = inc;
+            dstart[tid] = inc - total; // (+ the waves in front: below)
+        }
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t off = 0;
+            for (int i = 0; i < w; ++i) off += wsum[i];
+            dstart[tid] += off;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < ITEMS; ++r) {
+            const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+            const uint32_t lp = dstart[d] + cnt[w][d] + rank[r];
+            skey[lp] = key[r];
+            spos[lp] = (uint16_t)pos[r];
+        }
+        __syncthreads();
+        if (pass + 1 < W) {
+#pragma unroll
+            for (int r = 0; r < ITEMS; ++r) {
+                const int i = w * WK + r * 64 + lane;
+                key[r] = skey[i];
+                pos[r] = spos[i];
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < a.n; i += NT) {
+        store_raw<U, W>(a.out, segoff + i, from_ordered<U, W, KIND>(skey[i], flip));
+        a.pos[segoff + i] = (int64_t)spos[i];
+    }
+}
+template <int NW, int ITEMS> static size_t block_radix_lds(size_t usz) { return (size_t)NW * 64 * ITEMS * (usz + 2) + (size_t)NW * 1024 + 1024 + 64; }
 
 // ------------------------------------------------------------------------------------------
 // long segments: LSD radix sort, 8-bit digits
@@ -334,7 +430,8 @@ __global__ __launch_bounds__(R_NT) void radix_scatter_kernel(const RadixArgs a) 
     }
 }
 
-constexpr int64_t kSmallMax = 8192;
+constexpr int64_t kSmallMax = 8192;  // one block per segment (or several segments per block) up to here
+constexpr int64_t kBitonicMax = 512; // ... by the bitonic network up to here, by radix passes in LDS above
 
 struct SortPlan {
     bool small;
@@ -360,6 +457,23 @@ static SortPlan make_plan(int dtype, int64_t nseg, int64_t n) {
 
 template <typename U, int W, int KIND>
 static int run_sort(const void *in, void *out, int64_t *pos, int64_t nseg, int64_t n, int desc, const SortPlan &p, char *ws, hipStream_t st) {
+    if (p.small && n > kBitonicMax) { // one segment per block, radix passes in LDS
+        SmallArgs a{in, out, pos, nseg, (int)n, 0, 1, desc};
+        KF_REQUIRE(nseg <= 0x7fffffff, KF_ERR_INDEX_RANGE, "kf_sort: too many segments");
+        KF_PROF("sort_radix_lds", st);
+#define KF_BLOCK_RADIX(NW_, IT_)                                                                                                         \
+    {                                                                                                                                    \
+        const size_t lds = block_radix_lds<NW_, IT_>(sizeof(U));                                                                         \
+        KF_HIP_TRY(hipFuncSetAttribute((const void *)sort_block_radix_kernel<U, W, KIND, NW_, IT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        sort_block_radix_kernel<U, W, KIND, NW_, IT_><<<(unsigned)nseg, NW_ * 64, lds, st>>>(a);                                          \
+    }
+        if (n <= 1024) KF_BLOCK_RADIX(4, 4)
+        else if (n <= 4096) KF_BLOCK_RADIX(4, 16)
+        else KF_BLOCK_RADIX(8, 16)
+#undef KF_BLOCK_RADIX
+        KF_LAUNCH_CHECK();
+        return KF_OK;
+    }
     if (p.small) {
         SmallArgs a{in, out, pos, nseg, (int)n, 0, 1, desc};
         while ((1 << a.logp) < n) ++a.logp;

@@ -75,7 +75,7 @@ def test_golden_topk_large_values():
 @pytest.mark.parametrize("code", [H.U8, H.I8, H.I16, H.I32, H.I64, H.F16, H.BF16, H.F32, H.F64])
 def test_every_dtype_every_path(code):
     rng = np.random.default_rng(700 + code)
-    for nseg, n in ((1, 1), (3, 2), (70, 3), (1000, 13), (5, 64), (7, 65), (3, 1000), (2, 2048), (3, 2049), (2, 4096), (2, 8192),
+    for nseg, n in ((1, 1), (3, 2), (70, 3), (1000, 13), (5, 64), (7, 65), (3, 512), (3, 513), (3, 1000), (2, 1024), (2, 1025), (2, 2048), (3, 2049), (2, 4096), (2, 4097), (2, 8192),
                     (3, 8193), (5, 22223), (2, 100000)):
         for desc in (False, True):
             check(draw(rng, (nseg, n), code), code, desc)
@@ -83,7 +83,7 @@ def test_every_dtype_every_path(code):
 
 def test_stability_with_heavy_duplicates():
     rng = np.random.default_rng(711)
-    for code, shape in ((H.I32, (3, 300000)), (H.F32, (2, 50000)), (H.I64, (2, 20000)), (H.I16, (64, 500))):
+    for code, shape in ((H.I32, (3, 300000)), (H.F32, (2, 50000)), (H.I64, (2, 20000)), (H.I16, (64, 500)), (H.I32, (4, 3000)), (H.I64, (3, 6000)), (H.I8, (5, 700))):   # (the last three: the block-local radix path)
         keys = rng.integers(-3, 4, size=shape).astype(NP_OF[code])
         for desc in (False, True):
             check(keys, code, desc)
@@ -97,7 +97,7 @@ def test_special_float_values():
         bits = base.view(ut).copy()
         bits[7] |= ut(1) << ut(8 * base.itemsize - 1)  # a NaN with the sign bit set, whatever np.nan's sign was
         base = bits.view(dt)
-        for reps in (1, 1000):  # LDS path and radix path
+        for reps in (1, 100, 500, 1000):  # bitonic, block-local radix (1100 and 5500 keys), global radix
             keys = np.tile(base, reps)[None, :]
             for desc in (False, True):
                 check(keys, code, desc)
