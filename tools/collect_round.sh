@@ -10,7 +10,7 @@ export KF_ROUND=$R
 bash tools/roundend.sh > gpurun_out/${R}_roundend.log 2>&1; tail -5 gpurun_out/${R}_roundend.log
 bash tools/pmc_traffic.sh > gpurun_out/${R}_pmc_traffic.log 2>&1; cp profiles/${R}_pmc_traffic.json gpurun_out/ 2>/dev/null
 bash tools/pmc_util.sh > gpurun_out/${R}_pmc_util.log 2>&1; cp profiles/${R}_pmc_util.json gpurun_out/ 2>/dev/null
-bash tools/membound_prof.sh > gpurun_out/${R}_membound.log 2>&1; cp profiles/${R}_membound_rocprof.json profiles/${R}_membound_kernel_stats.csv profiles/${R}_membound_kernel_stats.stamp.json gpurun_out/ 2>/dev/null
+bash tools/membound_prof.sh > gpurun_out/${R}_membound.log 2>&1   # (writes its results into gpurun_out/ itself)
 bash tools/gemm_pmc.sh > gpurun_out/${R}_gemm_pmc.log 2>&1; cp profiles/${R}_gemm_pmc.json gpurun_out/ 2>/dev/null
 python tools/gemm_sweep.py --json gpurun_out/${R}_gemm_sweep.json > gpurun_out/${R}_gemm_sweep.txt 2>&1
 python tools/attn_large_logits.py > gpurun_out/${R}_attn_large_logits.txt 2>&1
