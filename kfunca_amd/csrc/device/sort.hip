@@ -236,7 +236,10 @@ template <int NW, int ITEMS> static size_t block_radix_lds(size_t usz) { return 
 // ------------------------------------------------------------------------------------------
 // long segments: LSD radix sort, 8-bit digits
 // ------------------------------------------------------------------------------------------
-constexpr int R_NT = 256, R_ITEMS = 16, R_TILE = R_NT * R_ITEMS, R_WAVE_KEYS = 64 * R_ITEMS;
+#ifndef KF_SORT_R_ITEMS
+#define KF_SORT_R_ITEMS 16 // keys per thread. Measured (round 5, [1, 64 Mi] f32): 16 -> 2.22 ms, 32 (8192-key tiles: longer runs, half the blocks per CU) -> 2.85 ms
+#endif
+constexpr int R_NT = 256, R_ITEMS = KF_SORT_R_ITEMS, R_TILE = R_NT * R_ITEMS, R_WAVE_KEYS = 64 * R_ITEMS;
 
 struct RadixArgs {
     const void *src_keys; // typed keys (first pass) or ordered keys of U
@@ -344,8 +347,9 @@ template <typename U, int W, int KIND>
 __global__ __launch_bounds__(R_NT) void radix_scatter_kernel(const RadixArgs a) {
     __shared__ uint32_t cnt[R_NT / 64][256];
     __shared__ uint32_t dstart[256], gbase[256], wsum[R_NT / 64];
-    __shared__ U skey[R_TILE];
-    __shared__ uint32_t spos[R_TILE];
+    extern __shared__ __attribute__((aligned(16))) char rsmem[]; // the tile in its new order: keys, then positions (dynamic: 64 - 96 KiB)
+    U *skey = (U *)rsmem;
+    uint32_t *spos = (uint32_t *)(rsmem + (size_t)R_TILE * sizeof(U));
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int tile = blockIdx.x % a.ntiles;
     const int64_t seg = blockIdx.x / a.ntiles, segoff = seg * a.n;
@@ -521,7 +525,9 @@ static int run_sort(const void *in, void *out, int64_t *pos, int64_t nseg, int64
         radix_hist_kernel<U, W, KIND><<<(unsigned)grid, R_NT, 0, st>>>(a);
         radix_scan_tiles_kernel<<<(unsigned)(nseg * p.nchunks), 256, 0, st>>>(counts, cbase, p.ntiles, p.nchunks);
         radix_scan_kernel<<<(unsigned)nseg, 1024, 0, st>>>(cbase, dbase, p.nchunks);
-        radix_scatter_kernel<U, W, KIND><<<(unsigned)grid, R_NT, 0, st>>>(a);
+        const size_t lds = (size_t)R_TILE * (sizeof(U) + 4);
+        KF_HIP_TRY(hipFuncSetAttribute((const void *)radix_scatter_kernel<U, W, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        radix_scatter_kernel<U, W, KIND><<<(unsigned)grid, R_NT, lds, st>>>(a);
         KF_LAUNCH_CHECK();
     }
     return KF_OK;

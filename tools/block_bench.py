@@ -28,7 +28,6 @@ import os
 # the pool's host driver only supports dmabuf IPC: without this RCCL's cross-process buffer sharing fails (hipIpcGetMemHandle: invalid argument).
 # Must be in the environment before HIP initialises; children inherit it.
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-import socket
 import subprocess
 import sys
 import time
