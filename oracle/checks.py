@@ -22,7 +22,8 @@ logit std 33, the softmax one-hot), most entries of P lie far below either limit
 the double-precision oracle returns 1e-50 there, no 16-bit kernel can. The floor adds, per output element, one absolute rounding of every
 term's intermediate times the other factor: dV_j += u_P sum_i |dO_i|, dK_j += u_dS scale sum_i |Q_i|, dQ_i += u_dS scale sum_j |K_j|
 (sums over the causally visible partners; u = half the subnormal spacing for f16 - 2^-25, and 2^-25 2^-14 for P, which the backward kernels
-carry as P 2^14 - and the flush limit 2^-126 for bf16). Relative to the outputs themselves these floors are 1e-5 and less on every tested
+carry as P 2^14 - and the flush limit 2^-126 for bf16; plus, for both types, the entries of P that f32's exp2 itself returns as 0: 2^-126 times
+the |dP - delta| they are multiplied by). Relative to the outputs themselves these floors are 1e-5 and less on every tested
 input: a dropped tile, a wrong mask row or a zeroed slice is as visible as before (tests/test_attention_bounds.py).
 The constants are >= 2x the largest figures measured on MI355X over the shapes of tools/attn_parity_margins.py
 (profiles/r03_attn_parity_margins.json); tests/test_attention_bounds.py shows on CPU that the same bounds reject a dropped tile, a
@@ -81,8 +82,15 @@ def format_floor(q, k, v, d_o, code, scale=None):
         c = np.cumsum(x, axis=2)
         return c[:, :, np.minimum(np.arange(Sq), Skv - 1)]
 
-    return {"dv": C_FLOOR * u_p * suffix_over_queries(da), "dk": C_FLOOR * u_ds * scale * suffix_over_queries(qa),
-            "dq": C_FLOOR * u_ds * scale * prefix_over_keys(ka)}
+    # ... and f32 itself: exp2 returns 0 below 2^-126, so an entry of P that small takes its whole dS = P (dP - delta) with it, whatever
+    # |dP - delta| <= 2 ||dO_i|| ||V_j|| is (U(-10, 10) at D = 64: P 1e-39 times 4000 is a dK entry of 6e-37 - representable in bf16, and 0 in
+    # every kernel that forms P in f32). Both element types.
+    p32 = 2.0 ** -126
+    a_i = 2.0 * np.linalg.norm(to_f64(d_o, code), axis=-1, keepdims=True)       # [B, H, Sq, 1]
+    vn_j = np.linalg.norm(to_f64(v, code), axis=-1, keepdims=True)              # [B, H, Skv, 1]
+    return {"dv": C_FLOOR * u_p * suffix_over_queries(da),
+            "dk": C_FLOOR * scale * (u_ds * suffix_over_queries(qa) + p32 * vn_j * suffix_over_queries(a_i * qa)),
+            "dq": C_FLOOR * scale * (u_ds * prefix_over_keys(ka) + p32 * a_i * prefix_over_keys(vn_j * ka))}
 
 
 def margins(got, ref, mag, quad, eps, ulp=0.0, coh=None, floor=None):

@@ -459,9 +459,10 @@ def _draw_large(dist, rng, shape):
     return float(dist[1]) * rng.standard_normal(shape)
 
 
+@pytest.mark.parametrize("D", [128, 64])
 @pytest.mark.parametrize("dist", ["n2", "n3", "u10"])
 @pytest.mark.parametrize("code", [H.BF16, H.F16])
-def test_exact_scores_hold_the_bounds_at_large_logits(code, dist):
+def test_exact_scores_hold_the_bounds_at_large_logits(code, dist, D):
     """Why the default streams keep q and k as they are, and (round 5) both 16-bit types on the inputs that stress them:
     N(0, 2^2) / N(0, 3^2) (logit std 4 / 9, a peaked softmax) and U(-10, 10), the range the reference's own attention test draws from
     (test/test_nn.py:22-24; logit std 33: one-hot rows, most of P below what f16 - or f32 - can hold). The default kernels (exact f32
@@ -469,13 +470,13 @@ def test_exact_scores_hold_the_bounds_at_large_logits(code, dist):
     through the 8-wave forward + 32-key dK/dV kernels; profiles/r05_attn_large_logits.txt has the table (tools/attn_large_logits.py)."""
     B, Hh, S = 1, 2, 1024
     rng = np.random.default_rng({"n2": 20, "n3": 30, "u10": 100}[dist] + code)
-    q, k, v, go = (O.from_float(_draw_large(dist, rng, (B, Hh, S, 128)).astype(np.float32), code) for _ in range(4))
+    q, k, v, go = (O.from_float(_draw_large(dist, rng, (B, Hh, S, D)).astype(np.float32), code) for _ in range(4))
     ref = O.attn_ref64(q, k, v, go, code=code)
     for knobs in ({}, {"KF_ATTN_FWD_V3": "1", "KF_ATTN_DKV_V4": "1"}):
         with H.knobs(**knobs):
             o, lse = fwd(code, q, k, v)
             dq, dk, dv = bwd(code, q, k, v, o, lse, go)
-        m = K.attn_check(q, k, v, code, o=o, lse=lse, d_o=go, dq=dq, dk=dk, dv=dv, ref=ref, what=f"exact scores, inputs {dist} {knobs}")
+        m = K.attn_check(q, k, v, code, o=o, lse=lse, d_o=go, dq=dq, dk=dk, dv=dv, ref=ref, what=f"exact scores, D {D}, inputs {dist} {knobs}")
         assert max(max(m[n][a] for a in ("element", "row", "head")) for n in K.NAMES) <= 1.0, m   # (attn_check has asserted it per output)
 
 

@@ -14,6 +14,7 @@ bash tools/membound_prof.sh > gpurun_out/${R}_membound.log 2>&1   # (writes its 
 bash tools/gemm_pmc.sh > gpurun_out/${R}_gemm_pmc.log 2>&1; cp profiles/${R}_gemm_pmc.json gpurun_out/ 2>/dev/null
 python tools/gemm_sweep.py --json gpurun_out/${R}_gemm_sweep.json > gpurun_out/${R}_gemm_sweep.txt 2>&1
 python tools/attn_large_logits.py > gpurun_out/${R}_attn_large_logits.txt 2>&1
+python tools/attn_large_logits.py --D 64 --forms default,v3v4 > gpurun_out/${R}_attn_large_logits_d64.txt 2>&1
 python tools/attn_bench.py --B 8 --H 64 --D 64 --rounds 5 --variants default,KF_ATTN_FWD_V3=1+KF_ATTN_DKV_V4=1 > gpurun_out/${R}_attn_d64.txt 2>&1
 python tools/attn_parity_margins.py --out gpurun_out/${R}_attn_parity_margins.json > gpurun_out/${R}_attn_parity_margins.log 2>&1
 for F in reference fused fused-norm; do python tools/block_bench.py --form $F --steps 20 --json gpurun_out/${R}_block_c5_$F.json > /dev/null 2> gpurun_out/${R}_block_$F.err; done
