@@ -415,7 +415,8 @@ def test_backward_workspace_is_bounded_any_size_above_the_statistics_is_accepted
         assert np.array_equal(a0.view(np.uint16), a1.view(np.uint16)), n
 
 
-def test_key_blocks_beyond_the_last_query_touch_nothing_behind_the_tensors():
+@pytest.mark.parametrize("D", [128, 64])
+def test_key_blocks_beyond_the_last_query_touch_nothing_behind_the_tensors(D):
     """Skv >> Sq: most 256-key blocks of the dK / dV pass have no query that sees them. Their gradients are zero, and the pass must not
     fetch Q / dO / row-constant slices that lie behind the tensors' last row on their behalf (round 4: the first two slices a block
     requests were not saturated for such blocks - 2 MiB behind a 64 KiB Q here; whether that faulted depended on what the allocator had
@@ -424,16 +425,17 @@ def test_key_blocks_beyond_the_last_query_touch_nothing_behind_the_tensors():
         for (B, Hh, Sq, Skv) in ((1, 1, 256, 8192), (1, 3, 512, 4096)):
             rng = np.random.default_rng(Sq + Skv + code)
             q, k, v, go = (O.from_float(rng.uniform(-1, 1, s).astype(np.float32), code)
-                           for s in ((B, Hh, Sq, 128), (B, Hh, Skv, 128), (B, Hh, Skv, 128), (B, Hh, Sq, 128)))
+                           for s in ((B, Hh, Sq, D), (B, Hh, Skv, D), (B, Hh, Skv, D), (B, Hh, Sq, D)))
             for nopair in (None, "1"):
                 with H.knobs(KF_ATTN_NO_PAIR=nopair):
                     o, lse = fwd(code, q, k, v)
                     dq, dk, dv = bwd(code, q, k, v, o, lse, go)
-                assert not dk[:, :, Sq:].any() and not dv[:, :, Sq:].any(), (code, Sq, Skv, nopair)
+                assert not dk[:, :, Sq:].any() and not dv[:, :, Sq:].any(), (code, D, Sq, Skv, nopair)
             K.attn_check(q, k, v, code, o=o, lse=lse, d_o=go, dq=dq, dk=dk, dv=dv, what=f"keys beyond the queries {Sq}x{Skv}")
 
 
-def test_rescale_path_on_every_tile():
+@pytest.mark.parametrize("D", [128, 64])
+def test_rescale_path_on_every_tile(D):
     """KF_ATTN_NO_DEFER makes the forward adopt every tile's maximum: the inline rare path of the generated stream (new maximum, the
     copies of -max the score chains start from, this tile's exponents shifted, O and the row sums scaled) then runs on EVERY tile of
     every block instead of almost never. Same bounds as the default schedule; the two agree to the rounding of P."""
@@ -441,7 +443,7 @@ def test_rescale_path_on_every_tile():
         for scale_in in (1.0, 3.0):
             B, Hh, S = 1, 2, 1024
             rng = np.random.default_rng(int(7 * scale_in) + code)
-            q, k, v = (O.from_float((scale_in * rng.standard_normal((B, Hh, S, 128))).astype(np.float32), code) for _ in range(3))
+            q, k, v = (O.from_float((scale_in * rng.standard_normal((B, Hh, S, D))).astype(np.float32), code) for _ in range(3))
             with H.knobs(KF_ATTN_NO_DEFER=None):
                 o0, l0 = fwd(code, q, k, v)
             with H.knobs(KF_ATTN_NO_DEFER="1"):
