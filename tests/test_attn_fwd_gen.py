@@ -78,3 +78,31 @@ def test_checkers_reject_a_transcendental_read_one_wait_state_later():
     g = G.Gen()
     g.fix_trans_use = lambda: None
     assert any("transcendental" in p for p in G.check(g.build().out))
+
+
+def test_head_size_64_streams_hazards_counts_and_wait_fields():
+    """Round 5: both generators at D = 64 (the reference's second fast head size). Hazard distances in every variant, the MFMA counts of
+    the half-size tile / slice (32 per steady body), and - the regression of the round - no s_waitcnt field beyond what the hardware has:
+    lgkmcnt is 4 bits wide (the first D = 64 dK/dV stream asked for lgkmcnt(23): the assembler refused it, the old library stayed in
+    place, and nothing said so)."""
+    import re
+
+    import gen_attn_dkv as D
+    import gen_attn_fwd as G
+    for f16 in (False, True):
+        for mut in (False, True):
+            g = G.Gen(f16, mut, D=64).build()
+            assert G.check(g.out) == []
+            assert sum(1 for i in g.out if i.kind == "mfma") == (32 + 24 + 28 + 20 + 8 + (32 if mut else 0))   # steady, first, masked, firstmasked, drain (+ steadydrop)
+            for ds in (True, False):
+                d = D.Gen(f16, mut, ds, D=64).build()
+                assert D.check(d.out) == []
+                assert sum(1 for i in d.out if i.kind == "mfma") == 8 + 32 + 32 + 16 + (32 if mut else 0)        # accumulator clearing, steady, diag1, diag0, drop
+    for d in (D.Gen(False, D=64).build(), D.Gen(False, D=128).build(), D.Gen(True, scaled=True).build()):
+        for i in d.out:
+            for field, width in (("lgkmcnt", 15), ("vmcnt", 63)):
+                for m in re.finditer(field + r"\((\d+)\)", i.text):
+                    assert int(m.group(1)) <= width, i.text
+    inc = (ROOT / "kfunca_amd" / "csrc" / "device" / "attn_dkv_w4.inc").read_text() + (ROOT / "kfunca_amd" / "csrc" / "device" / "attn_fwd_w4.inc").read_text()
+    for name in ("KF_DKV_W4_D64_ASM_BF16_DS", "KF_DKV_W4_D64_ASM_F16_NODS", "KF_FWD_W4_D64_ASM_BF16", "KF_FWD_W4_D64_ASM_F16"):
+        assert f"#define {name} " in inc, name
