@@ -556,6 +556,26 @@ def test_head_size_64_generated_streams_against_the_hand_kernels(code):
                 assert np.array_equal(a.view(np.uint16), b.view(np.uint16)), (code, n, Sq, Skv)
 
 
+@pytest.mark.parametrize("D", [128, 64])
+def test_generated_dkv_stream_on_ragged_query_counts(D):
+    """The dK / dV stream needs Skv % 256 == 0 and nothing of Sq but a multiple of 32: passes of 1, 2, 3, 9 and 25 slices, key blocks with fewer
+    slices than the requests the prologue sends ahead (2 at D = 128, 3 at D = 64: clamped re-fetches), queries that end inside a key block.
+    (The forward falls back to the 8-wave kernel for Sq % 256 != 0: the pairing of the two is part of the case.)"""
+    for code in (H.BF16, H.F16):
+        for (B, Hh, Sq, Skv) in ((1, 2, 32, 256), (1, 1, 64, 256), (2, 2, 96, 512), (1, 2, 288, 512), (1, 2, 800, 1024)):
+            rng = np.random.default_rng(D + Sq + Skv + code)
+            q, k, v, go = (O.from_float(rng.uniform(-1, 1, s).astype(np.float32), code)
+                           for s in ((B, Hh, Sq, D), (B, Hh, Skv, D), (B, Hh, Skv, D), (B, Hh, Sq, D)))
+            o, lse = fwd(code, q, k, v)
+            dq, dk, dv = bwd(code, q, k, v, o, lse, go)
+            K.attn_check(q, k, v, code, o=o, lse=lse, d_o=go, dq=dq, dk=dk, dv=dv, what=f"ragged Sq, D {D} {Sq}x{Skv}")
+            with H.knobs(KF_ATTN_DKV_V4="1"):
+                g4 = bwd(code, q, k, v, o, lse, go)
+            assert np.array_equal(dv.view(np.uint16), g4[2].view(np.uint16)), (code, D, Sq, Skv)
+            if code == H.BF16:
+                assert np.array_equal(dk.view(np.uint16), g4[1].view(np.uint16)) and np.array_equal(dq.view(np.uint16), g4[0].view(np.uint16)), (D, Sq, Skv)
+
+
 def test_forward_without_an_lse_buffer():
     """kf_attn_fwd's lse pointer may be NULL (a caller that wants no backward): every forward kernel - the generated stream, the 8-wave
     kernel, D = 64 - must skip the store and write the same O."""
