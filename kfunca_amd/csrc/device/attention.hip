@@ -55,6 +55,7 @@ struct AttnArgs {
     float scale_log2e; // scale * log2(e), formed on the host (attn_fwd_w4_kernel hands it to its instruction stream as a scalar)
     int xcd_map; // 1: nbh % 8 == 0, heads are pinned to XCDs (a_block_map)
     float defer; // forward: adopt a new running maximum only beyond this many exponent units (kDeferMax; -inf: always)
+    unsigned nvwg;   // the generated kernels: virtual workgroups (= gridDim.x unless KF_ATTN_GRID_WGS asks for fewer real ones: grid-stride loop)
     int persist;     // k > 0: a workgroup handles k pairs {block x, its causal mirror}: equal work per workgroup (k = 1 is used)
     int persist_rev; // the short block of a pair first
     // global layouts of the 16-bit matrix-core path: byte strides of batch, head and row (the last dim is contiguous). Contiguous
@@ -92,8 +93,7 @@ __host__ __device__ inline size_t ds_bytes(int64_t nbh, int64_t Sq, int64_t Skv)
 // base of (batch, head) bh = b * H + h under a layout
 __device__ __forceinline__ int64_t a_head(const AttnArgs::Lay &l, int64_t bh, int64_t H) { return (bh / H) * l.sb + (bh % H) * l.sh; }
 
-__device__ __forceinline__ void a_block_map(int nx, int nbh, int xcd_map, int &x, int64_t &bh) {
-    const unsigned id = blockIdx.x;
+__device__ __forceinline__ void a_block_map(int nx, int nbh, int xcd_map, int &x, int64_t &bh, unsigned id = blockIdx.x) {
     if (xcd_map) { // nbh % 8 == 0
         const unsigned xcd = id & 7u, slot = id >> 3;
         x = (int)(slot % (unsigned)nx);
@@ -605,18 +605,22 @@ template <bool BF, bool SQ, bool D64 = false>
 __global__ __launch_bounds__(256) void attn_fwd_w4_kernel(const AttnArgs a) {
     static_assert(!(SQ && D64), "the scaled-query form exists for head size 128 only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int xb0;
-    int64_t bh;
     const int nxb = (int)(a.Sq / FQ);
     const int nwx = a.persist ? nxb / 2 : nxb;
-    a_block_map(nwx, a.nbh, a.xcd_map, xb0, bh);
     const unsigned lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)smem;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float c = a.scale_log2e, defer = a.defer; // (kernel arguments are scalar registers; a float product formed here would be a vector one)
+    const int qsr = (int)a.lq.sr, kvsr = (int)a.lk.sr, osr = (int)a.lo.sr;
+    // (a.nvwg virtual workgroups over gridDim.x real ones: KF_ATTN_GRID_WGS, an experiment - default one each. A stride of a multiple of 8 keeps
+    //  a virtual workgroup on the XCD its id maps to.)
+#pragma nounroll
+    for (unsigned vwg = blockIdx.x; vwg < a.nvwg; vwg += gridDim.x) {
+    int xb0;
+    int64_t bh;
+    a_block_map(nwx, a.nbh, a.xcd_map, xb0, bh, vwg);
     const char *kp = a.k + a_head(a.lk, bh, a.H), *vp = a.v + a_head(a.lv, bh, a.H);
     const char *qh = a.q + a_head(a.lq, bh, a.H);
     char *oh = a.out + a_head(a.lo, bh, a.H);
-    const float c = a.scale_log2e, defer = a.defer; // (kernel arguments are scalar registers; a float product formed here would be a vector one)
-    const int qsr = (int)a.lq.sr, kvsr = (int)a.lk.sr, osr = (int)a.lo.sr;
 #pragma nounroll
     for (int pass = 0; pass < (a.persist ? 2 : 1); ++pass) {
         const int xb = ((pass & 1) != (a.persist_rev != 0)) ? nxb - 1 - xb0 : xb0;
@@ -632,7 +636,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4_kernel(const AttnArgs a) {
 #endif
 #ifdef KF_FWD_W4_STAMPS // diagnostic build (tools/attn_fwd_w4_timeline.py): eight cycle sums per wave and block into the debug buffer
         unsigned long long *dbg = a.dbg;
-        const unsigned dbgoff = (blockIdx.x * 2 + pass) * 4 * 32;
+        const unsigned dbgoff = (vwg * 2 + pass) * 4 * 32;
 #define KF_W4_EXTRA , [dbg] "s"(dbg), [dbgoff] "s"(dbgoff)
 #else
 #define KF_W4_EXTRA
@@ -648,6 +652,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4_kernel(const AttnArgs a) {
         else asm volatile(KF_FWD_W4_ASM_F16 : : KF_W4_OPERANDS : KF_FWD_W4_CLOBBERS);
 #undef KF_W4_OPERANDS
 #undef KF_W4_EXTRA
+    }
     }
 }
 
@@ -1731,22 +1736,24 @@ template <bool BF, bool DS, bool SQ, bool D64 = false>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) {
     static_assert(!(SQ && D64), "the scaled-K form exists for head size 128 only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    int xb0;
-    int64_t bh;
     const int nkb = (int)(a.Skv / K5B), nwx = a.persist ? nkb / 2 : nkb;
-    a_block_map(nwx, a.nbh, a.xcd_map, xb0, bh);
-    bh += a.bh0;
     const unsigned lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)smem;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const char *qp = a.q + a_head(a.lq, bh, a.H), *dop = a.d_o + a_head(a.ldo, bh, a.H);
-    const char *kh = a.k + a_head(a.lk, bh, a.H), *vh = a.v + a_head(a.lv, bh, a.H);
-    char *dkh = a.dk + a_head(a.ldk, bh, a.H), *dvh = a.dv + a_head(a.ldv, bh, a.H);
-    const float *cp = a.nlse + bh * a.Sq;
     const unsigned cdelta = (unsigned)((const char *)a.ndelta - (const char *)a.nlse);
     const int qsr = (int)a.lq.sr, dosr = (int)a.ldo.sr, kvsr = (int)a.lk.sr, osr = (int)a.ldk.sr;
     const float scale = SQ ? a.scale : a.scale_log2e; // (what the stream multiplies by: K once per block | every score in front of its exp2)
     const float scl = a.scale;                         // (dK = scale dS^T Q)
     const int ns_all = (int)(a.Sq / BQS), dsqb = (int)(a.ds_nkwb * 8);
+#pragma nounroll
+    for (unsigned vwg = blockIdx.x; vwg < a.nvwg; vwg += gridDim.x) { // (virtual workgroups: see attn_fwd_w4_kernel)
+    int xb0;
+    int64_t bh;
+    a_block_map(nwx, a.nbh, a.xcd_map, xb0, bh, vwg);
+    bh += a.bh0;
+    const char *qp = a.q + a_head(a.lq, bh, a.H), *dop = a.d_o + a_head(a.ldo, bh, a.H);
+    const char *kh = a.k + a_head(a.lk, bh, a.H), *vh = a.v + a_head(a.lv, bh, a.H);
+    char *dkh = a.dk + a_head(a.ldk, bh, a.H), *dvh = a.dv + a_head(a.ldv, bh, a.H);
+    const float *cp = a.nlse + bh * a.Sq;
 #pragma nounroll
     for (int pass = 0; pass < (a.persist ? 2 : 1); ++pass) {
         const int xb = ((pass & 1) != (a.persist_rev != 0)) ? nkb - 1 - xb0 : xb0;
@@ -1761,7 +1768,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) 
         if (a.mutant == 2 && xb == 0 && wid < 2) mut = 4; // defect 2: queries 128..159 contribute nothing to keys 0..127
 #endif
 #ifdef KF_DKV_W4_STAMPS // diagnostic build (tools/attn_dkv_w4_timeline.py): eight cycle sums per wave and block pass into the debug buffer
-        const char *dbg = (const char *)a.dbg + (size_t)(blockIdx.x * 2 + pass) * 4 * 64;
+        const char *dbg = (const char *)a.dbg + (size_t)(vwg * 2 + pass) * 4 * 64;
 #define KF_DKV_EXTRA , [dbg] "s"(dbg)
 #else
 #define KF_DKV_EXTRA
@@ -1790,6 +1797,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) 
 #undef KF_DKV_ASM
 #undef KF_DKV_OPERANDS
 #undef KF_DKV_EXTRA
+    }
     }
 }
 
@@ -2545,6 +2553,9 @@ static int attn_fwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
         const int64_t nxb3 = (Sq + FQ - 1) / FQ;
         a.persist = (nxb3 % 2 == 0 && nxb3 >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
         dim3 grid3((unsigned)((a.persist ? nxb3 / (2 * a.persist) : nxb3) * B * H));
+        a.nvwg = grid3.x;
+        dim3 grid3w = grid3; // the generated kernels' real grid: all virtual workgroups, or KF_ATTN_GRID_WGS of them looping (a multiple of 8)
+        if (const long gw = knob_int(KNOB_ATTN_GRID_WGS, 0); gw >= 8 && (unsigned)gw < grid3.x) grid3w.x = (unsigned)(gw / 8 * 8);
         KF_PROF(D == 64 ? "attn_fwd_mfma_d64" : "attn_fwd_mfma", st);
         // round 4: the one-wave-per-SIMD stream (attn_fwd_w4_kernel) wherever its shape conditions hold; KF_ATTN_FWD_V3 keeps the 8-wave kernel (A/B)
         if ((D == AD || D == 64) && Sq % FQ == 0 && Skv >= Sq && a.lk.sr == a.lv.sr && (uint64_t)Skv * (uint64_t)a.lk.sr < (1ull << 32) &&
@@ -2552,16 +2563,16 @@ static int attn_fwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
 #define KF_FWD4(BF_, SQ_)                                                                                   \
     {                                                                                                       \
         if ((rc = set_lds(attn_fwd_w4_kernel<BF_, SQ_>, KF_FWD_W4_LDS_BYTES)) != KF_OK) return rc;           \
-        attn_fwd_w4_kernel<BF_, SQ_><<<grid3, 256, KF_FWD_W4_LDS_BYTES, st>>>(a);                           \
+        attn_fwd_w4_kernel<BF_, SQ_><<<grid3w, 256, KF_FWD_W4_LDS_BYTES, st>>>(a);                           \
     }
             const bool sq = D == AD && knob(KNOB_ATTN_SCALED_OPERANDS); // opt-in: c q rounded once per pass (faster; score error grows with the logits)
             if (D == 64) {
                 if (dtype == KF_BF16) {
                     if ((rc = set_lds(attn_fwd_w4_kernel<true, false, true>, KF_FWD_W4_LDS_BYTES)) != KF_OK) return rc;
-                    attn_fwd_w4_kernel<true, false, true><<<grid3, 256, KF_FWD_W4_LDS_BYTES, st>>>(a);
+                    attn_fwd_w4_kernel<true, false, true><<<grid3w, 256, KF_FWD_W4_LDS_BYTES, st>>>(a);
                 } else {
                     if ((rc = set_lds(attn_fwd_w4_kernel<false, false, true>, KF_FWD_W4_LDS_BYTES)) != KF_OK) return rc;
-                    attn_fwd_w4_kernel<false, false, true><<<grid3, 256, KF_FWD_W4_LDS_BYTES, st>>>(a);
+                    attn_fwd_w4_kernel<false, false, true><<<grid3w, 256, KF_FWD_W4_LDS_BYTES, st>>>(a);
                 }
             } else if (dtype == KF_BF16) { if (sq) KF_FWD4(true, true) else KF_FWD4(true, false) }
             else { if (sq) KF_FWD4(false, true) else KF_FWD4(false, false) }
@@ -2760,6 +2771,8 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
                 if (dkv_w4) {
                     a.persist = (nkb5 % 2 == 0 && nkb5 >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
                     dim3 gk5((unsigned)((a.persist ? nkb5 / 2 : nkb5) * a.nbh));
+                    a.nvwg = gk5.x;
+                    if (const long gw = knob_int(KNOB_ATTN_GRID_WGS, 0); gw >= 8 && (unsigned)gw < gk5.x) gk5.x = (unsigned)(gw / 8 * 8);
 #define KF_DKV5(BF_, DS_, SQ_)                                                                                    \
     {                                                                                                             \
         if ((rc = set_lds(attn_bwd_dkv_w4_kernel<BF_, DS_, SQ_>, KF_DKV_W4_LDS_BYTES)) != KF_OK) return rc;        \
