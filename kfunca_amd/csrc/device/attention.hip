@@ -1744,8 +1744,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) 
     const float scale = SQ ? a.scale : a.scale_log2e; // (what the stream multiplies by: K once per block | every score in front of its exp2)
     const float scl = a.scale;                         // (dK = scale dS^T Q)
     const int ns_all = (int)(a.Sq / BQS), dsqb = (int)(a.ds_nkwb * 8);
+#ifdef KF_DKV_W4_STAMPS // (the diagnostic build clobbers 22 more scalar registers: no room for the loop's state beside the stream's inputs)
+    {
+        const unsigned vwg = blockIdx.x;
+#else
 #pragma nounroll
     for (unsigned vwg = blockIdx.x; vwg < a.nvwg; vwg += gridDim.x) { // (virtual workgroups: see attn_fwd_w4_kernel)
+#endif
     int xb0;
     int64_t bh;
     a_block_map(nwx, a.nbh, a.xcd_map, xb0, bh, vwg);

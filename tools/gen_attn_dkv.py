@@ -108,6 +108,10 @@ class Gen:
         # address formula, swizzle and read instruction is the D = 128 one, a tile's 8-row group is ONE 1-KiB DMA piece instead of two.
         assert D in (64, 128) and not (scaled and D == 64)
         self.D, self.NKK, self.NDB = D, D // 16, D // 32
+        # early (D = 128): the scalar bookkeeping of a slice - ring step + source offsets of the next request (10 s_*), dS tile addresses (11 s_*) - runs in
+        # slot S of the slice that USES it (gaps 10, 12) instead of slot dK of the slice before (gaps 50, 62): slot dK is the full one (DMA pieces, dS stores,
+        # ring toggles, the next slice's head reads). The prologue then leaves both one step behind.
+        self.early = D == 128 and os.environ.get("KF_GEN_DKV_EARLY", "0") == "1"
         kf0 = 122
         self.KFR = lambda ksb, kk: kf0 + 4 * self.NKK * ksb + 4 * kk
         self.VFR = lambda ksb, kk: kf0 + 8 * self.NKK + 4 * self.NKK * ksb + 4 * kk
@@ -182,7 +186,9 @@ class Gen:
         if "lds" in self.ablate: return
         self.out.append(Ins(f"ds_read_b128 {vr(dst + 4 * g, 4)}, {vr(LR)} offset:{off + 32 * g}", "lds", V(LR), V(dst + 4 * g, 4)))
 
-    def barrier(self): self.out.append(Ins("s_barrier", "barrier"))
+    def barrier(self):
+        if "barrier" in self.ablate and getattr(self, "in_loop", False): return   # (timing experiment: wrong results)
+        self.out.append(Ins("s_barrier", "barrier"))
 
     def dma_piece(self, srd, voff, soff, m0_add, inst_off, dword=False):
         if "dma" in self.ablate and getattr(self, "in_loop", False): return
@@ -310,7 +316,7 @@ class Gen:
         def book():
             self.ring_step()
             self.advance_dma()
-        put(50, (4, 0), book)
+        put(10 if self.early else 50, (4, 0), book)
         nst = 0
         if self.ds and compute and "stores" not in self.ablate:
             order = [(0, 0, 54), (0, 1, 56), (1, 0, 58), (1, 1, 60)]
@@ -333,7 +339,7 @@ class Gen:
             self.salu(f"s_addc_u32 {sr(S_DS0 + 1)}, {sr(S_DSB + 1)}, {sr(S_TMP2)}")
             self.salu(f"s_add_u32 {sr(S_DS1)}, {sr(S_DS0)}, {8 * DS_TILE}")
             self.salu(f"s_addc_u32 {sr(S_DS1 + 1)}, {sr(S_DS0 + 1)}, 0")
-        put(62, (6, 0), ds_next)
+        put(12 if self.early else 62, (6, 0), ds_next)
 
         self.label(f"L_{name}_%=")
         for g in range(64):
@@ -712,8 +718,9 @@ class Gen:
         e.ring_step()
         e.advance_dma()
         e.dma_slice()
-        e.ring_step()                                                           # the DMA side now points at slot 2, the masks are slot 0 -> 1 again: the loop's first step
-        e.advance_dma()
+        if not self.early:                                                      # (early: the first slice's own gap 10 takes this step)
+            e.ring_step()                                                       # the DMA side now points at slot 2, the masks are slot 0 -> 1 again: the loop's first step
+            e.advance_dma()
         if self.D == 64:                                                        # three slices ahead (slice64): slot 2 as well, the DMA side moves on to slot 3
             e.dma_slice()
             e.salu(f"s_xor_b32 {sr(S_M0)}, {sr(S_M0)}, {BUF}")
@@ -737,18 +744,8 @@ class Gen:
         # dS tile bases of slice s0
         e.salu(f"s_sub_u32 {sr(S_SL)}, {sr(S_SL)}, 1")
         self.in_loop = False
-        # (ds_next of the slice body, inline: advances S_SL to s0 and forms S_DS0 / S_DS1)
-        e.salu(f"s_add_u32 {sr(S_SL)}, {sr(S_SL)}, 1")
-        e.salu(f"s_lshr_b32 {sr(S_TMP)}, {sr(S_SL)}, 3")
-        e.salu(f"s_mul_i32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_DSQB)}")
-        e.salu(f"s_and_b32 {sr(S_TMP2)}, {sr(S_SL)}, 7")
-        e.salu(f"s_add_u32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_TMP2)}")
-        e.salu(f"s_lshr_b32 {sr(S_TMP2)}, {sr(S_TMP)}, {32 - 11}")
-        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_TMP)}, 11")
-        e.salu(f"s_add_u32 {sr(S_DS0)}, {sr(S_DSB)}, {sr(S_TMP)}")
-        e.salu(f"s_addc_u32 {sr(S_DS0 + 1)}, {sr(S_DSB + 1)}, {sr(S_TMP2)}")
-        e.salu(f"s_add_u32 {sr(S_DS1)}, {sr(S_DS0)}, {8 * DS_TILE}")
-        e.salu(f"s_addc_u32 {sr(S_DS1 + 1)}, {sr(S_DS0 + 1)}, 0")
+        # (ds_next of the slice body, inline: advances S_SL to s0 and forms S_DS0 / S_DS1; early: the first slice's own gap 12 does)
+        if not self.early: self.ds_next()
         # ---- slice s0 has landed for everyone (slice s0 + 1's 5 pieces may still be in flight); the first slice's head state
         e.out.append(Ins(f"s_waitcnt vmcnt({5 if self.D == 128 else 6})", "wait", tag="vm"))    # (D = 128: slice s0 + 1's 5 pieces may be in flight; D = 64: two slices of 3)
         e.barrier()

@@ -396,10 +396,15 @@ class Gen:
         def book_k():    # behind the K pieces, before slot D's K reads: K read bases -> K(it + 1)'s slot; DMA side -> K(it + 3)
             for r in KB:
                 self.valu(f"v_xor_b32 {vr(r)}, {KSLOT}, {vr(r)}", V(r), V(r))
+            if salu_gap is None: book_k_salu()
+        def book_k_salu():
             self.salu(f"s_xor_b32 {sr(S_M0K)}, {sr(S_M0K)}, {KSLOT}")
             self.salu(f"s_add_u32 {sr(S_KOFF0)}, {sr(S_KOFF0)}, {sr(S_TSTEP)}")   # one tile further, saturating at the last tile (a clamped piece is fetched again, never read)
             self.salu(f"s_min_u32 {sr(S_KOFF0)}, {sr(S_KOFF0)}, {sr(S_X2)}")
             self.salu(f"s_add_u32 {sr(S_KOFF1)}, {sr(S_KOFF0)}, {sr(S_TMP2)}")
+        # round 5: the SCALAR half of the bookkeeping (DMA destinations and source offsets of the next tile: 9 s_* instructions) leaves the full slot B for slot
+        # C (gap 44: behind this tile's pieces, ahead of the next tile's) - same-box 1.170 / 1.147 / 1.166 ms against 1.175 / 1.203 / 1.177; gap 60: no difference
+        salu_gap = int(os.environ.get("KF_GEN_F128_BOOKS", 44)) if self.D == 128 else None
         def book_v():    # behind the V pieces: DMA side -> V(it + 2)
             self.salu(f"s_xor_b32 {sr(S_M0V)}, {sr(S_M0V)}, {KSLOT}")
             self.salu(f"s_add_u32 {sr(S_VOFF0)}, {sr(S_VOFF0)}, {sr(S_TSTEP)}")
@@ -408,7 +413,11 @@ class Gen:
         gb = 31 if self.D == 128 else 15      # (BOOK_*_G: the last gap of slot B)
         put(gb if self.D == 128 else SL + 1, (4, 0), book_vb)   # (D = 64: the V reads start at gap SL + 2)
         put(gb, (4, 1), book_k)
-        put(gb, (4, 2), book_v)
+        if salu_gap is None:
+            put(gb, (4, 2), book_v)
+        else:
+            put(salu_gap, (4, 1), book_k_salu)
+            put(salu_gap, (4, 2), book_v)
 
         self.label(f"L_{name}_%=")
         for g in range(NG):
