@@ -28,11 +28,16 @@ def main():
     ap.add_argument("--S", type=int, default=4096)
     ap.add_argument("--zeros", action="store_true")
     ap.add_argument("--build-only", action="store_true")
+    ap.add_argument("--name", default="", help="suffix of the diagnostic library (placement experiments: KF_GEN_* set, --name X --build-only, then --name X)")
     args = ap.parse_args()
+    global LIB, INC
+    if args.name:
+        LIB = LIB.with_name(LIB.stem + "_" + args.name + ".so")
+        INC = INC.with_name(INC.stem + "_" + args.name + ".inc")
     if not LIB.exists() or args.build_only:
         INC.parent.mkdir(exist_ok=True)
         subprocess.run([sys.executable, str(ROOT / "tools" / "gen_attn_dkv.py"), "--stamps", "--out", str(INC)], check=True)
-        subprocess.run([sys.executable, str(ROOT / "tools" / "scratch" / "build_variant.py"), "dkv_stamps", "attention.hip", "-DKF_ATTN_TIMELINE=3",
+        subprocess.run([sys.executable, str(ROOT / "tools" / "scratch" / "build_variant.py"), LIB.stem[4:], "attention.hip", "-DKF_ATTN_TIMELINE=3",
                         "-DKF_DKV_W4_STAMPS", f'-DKF_DKV_W4_INC="{INC}"'], check=True)
         if args.build_only:
             return

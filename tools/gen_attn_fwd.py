@@ -64,7 +64,7 @@ N_VGPR = 232  # v0 .. v231 are the stream's; the rest of the arch file stays the
 # 612 / 891 / 683 / 754 = 2940 - LDS reads beside DMA pieces cost more than they relieve. (Exact-score stream, k-step 0's eight reads in gaps 18 .. 21 and
 # the rest two per gap in slot C: 611 / 878 / 674 / 665 = 2827 against 608 / 814 / 695 / 662 = 2779: slot B is the full one. The pieces on every second gap
 # 17 .. 31 with the bookkeeping between them: 613 / 832 / 712 / 703 = 2861.)
-DMA_G = [int(os.environ.get("KF_GEN_F128_DMA0", 23)) + i for i in range(8)]   # all 8 pieces behind the barrier, one per gap (K first: it is needed a slot earlier)
+DMA_G = [int(os.environ.get("KF_GEN_F128_DMA0", 23)) + i for i in range(4)] + [int(os.environ.get("KF_GEN_F128_VDMA0", 27)) + i for i in range(4)]   # 4 K + 4 V pieces behind the barrier, one per gap (K first: it is needed a slot earlier)
 BOOK_K_G, BOOK_V_G, BOOK_VB_G = 31, 31, 31  # ring toggles + next source offsets, each behind the last use of the old slot
 # (round 5: four per gap instead of three, and the K reads of slot D two per gap: both sets are back eight gaps before the s_waitcnt lgkmcnt(0)
 #  that drains the queue for them instead of five / four - same-box 1.178 / 1.195 / 1.186 ms against 1.203 / 1.223 / 1.208, tools/scratch/ab_fwd128.sh)
@@ -397,6 +397,8 @@ class Gen:
             for r in KB:
                 self.valu(f"v_xor_b32 {vr(r)}, {KSLOT}, {vr(r)}", V(r), V(r))
             if salu_gap is None: book_k_salu()
+        kb_gap = int(os.environ.get("KF_GEN_F128_KBG", 31)) if self.D == 128 else None      # (experiments: the two read-base toggles elsewhere)
+        vb_gap = int(os.environ.get("KF_GEN_F128_VBG", 31)) if self.D == 128 else None
         def book_k_salu():
             self.salu(f"s_xor_b32 {sr(S_M0K)}, {sr(S_M0K)}, {KSLOT}")
             self.salu(f"s_add_u32 {sr(S_KOFF0)}, {sr(S_KOFF0)}, {sr(S_TSTEP)}")   # one tile further, saturating at the last tile (a clamped piece is fetched again, never read)
@@ -411,8 +413,8 @@ class Gen:
             self.salu(f"s_min_u32 {sr(S_VOFF0)}, {sr(S_VOFF0)}, {sr(S_X2)}")
             self.salu(f"s_add_u32 {sr(S_VOFF1)}, {sr(S_VOFF0)}, {sr(S_TMP2)}")
         gb = 31 if self.D == 128 else 15      # (BOOK_*_G: the last gap of slot B)
-        put(gb if self.D == 128 else SL + 1, (4, 0), book_vb)   # (D = 64: the V reads start at gap SL + 2)
-        put(gb, (4, 1), book_k)
+        put(vb_gap if self.D == 128 else SL + 1, (4, 0), book_vb)   # (D = 64: the V reads start at gap SL + 2)
+        put(kb_gap if self.D == 128 else gb, (4, 1), book_k)
         if salu_gap is None:
             put(gb, (4, 2), book_v)
         else:
