@@ -2,6 +2,7 @@
 // (src/register.cpp:59-225) — same function names, arities and semantics — over the rebuilt host core.
 // kfunca_amd/__init__.py re-exports it, so `import kfunca_amd as kfunca` runs the reference's tests.
 #include <pybind11/numpy.h>
+#include <cstdlib>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
@@ -336,7 +337,11 @@ PYBIND11_MODULE(_C, m) {
     m.def("_promote_types", &promote_types);
     m.def("_pool_index", &utils::memory::DeviceAllocator::pool_index);
     m.def("release_cached", [](int device) { return utils::memory::DeviceAllocator::GetInstance()->release_cached(device); }, py::arg("device") = 0);
-    m.def("_alloc_fail_above", [](size_t bytes) { utils::memory::DeviceAllocator::GetInstance()->debug_fail_above(bytes); });
+    // test hook (tests/test_gpu_host_api.py: a simulated shortage): refuses to arm unless the process says it is a test
+    m.def("_alloc_fail_above", [](size_t bytes) {
+        CHECK_FAIL(bytes == 0 || std::getenv("KF_TEST_HOOKS") != nullptr, "_alloc_fail_above is a test hook: set KF_TEST_HOOKS=1");
+        utils::memory::DeviceAllocator::GetInstance()->debug_fail_above(bytes);
+    });
     m.def("_alloc_oom_retries", []() { return utils::memory::DeviceAllocator::GetInstance()->oom_retries(); });
 
     py::class_<Tensor>(m, "tensor", py::module_local())

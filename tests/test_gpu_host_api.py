@@ -513,6 +513,11 @@ def test_out_of_memory_is_recoverable_and_the_attention_backward_falls_back():
     kfunca.synchronize(0)
     kfunca.release_cached(0)  # so that the scratch request reaches the driver (and the hook) instead of a cached block
     before = kfunca._alloc_oom_retries()
+    import os
+    with pytest.raises(RuntimeError, match="test hook"):
+        os.environ.pop("KF_TEST_HOOKS", None)
+        kfunca._alloc_fail_above(600 << 10)          # the hook does not arm in a process that has not declared itself a test
+    os.environ["KF_TEST_HOOKS"] = "1"
     kfunca._alloc_fail_above(600 << 10)  # dS of the two heads is 1 MiB, every tensor of this problem 256 KiB
     try:
         got = run()
