@@ -17,11 +17,14 @@
 //     log2(P) (log2(P) + 1) / 2 = 78 LDS passes over a 4096-key segment (40 k cycles of LDS pipe); four radix passes need ~10 k cycles of VALU.
 //     Padding slots hold the largest key and the largest positions: a stable sort leaves them behind every real key.
 //   * n > 8192: least-significant-digit radix sort, 8-bit digits (one pass per key byte), four launches per pass:
-//     tile histograms -> two-level exclusive scan (inside chunks of 64 tiles, then over the chunks) -> stable scatter. A tile is 4096 keys, 1024 consecutive keys per wave.
-//     Ranking inside a wave is by digit match: 8 ballots give each lane the set of lanes holding its digit, the lane's
-//     rank is a popcount below itself - no per-key atomics, stable by construction. The tile is first reordered in LDS,
-//     then written out, so every digit's run leaves as consecutive addresses. The first pass reads the caller's typed
-//     keys, the last writes typed keys and int64 positions; the passes in between ping-pong through the workspace.
+//     tile histograms -> two-level exclusive scan (inside chunks of 64 tiles, then over the chunks) -> stable scatter. A tile is 8192 keys of up to
+//     four bytes (512 threads) or 4096 eight-byte keys (256 threads), 1024 consecutive keys per wave.
+//     Ranking inside a wave is by digit match: 8 ballots give each lane the set of lanes holding its digit (one three-input
+//     bit operation per half and bit), the lane's rank is a popcount below itself - no per-key atomics, stable by construction.
+//     The tile is first reordered in LDS, then written out, so every digit's run leaves as consecutive addresses; every XCD
+//     works on one contiguous eighth of the tiles, so neighbouring tiles' runs meet in one L2. The first pass reads the caller's
+//     typed keys, the last writes typed keys and int64 positions; the passes in between ping-pong through the workspace.
+//     Round 5, [1, 64 Mi] f32: 2.19 -> 1.24 ms (scatter 466 -> 231 us per pass = 16 B per key at 4.6 TB/s, histogram 110 -> 65, scans 22 -> 15).
 #include "common.h"
 
 namespace kf {
@@ -141,6 +144,21 @@ __global__ __launch_bounds__(1024) void sort_small_kernel(const SmallArgs a) {
     }
 }
 
+// The set of lanes (among those of m) that hold the same 8-bit digit as this lane: eight ballots, each folded into the running set by one
+// three-input bit operation per half (m & ~(ballot ^ spread), spread = the lane's digit bit on all 32 positions): 4 VALU per bit.
+__device__ __forceinline__ uint64_t match_digit8(uint32_t d, uint64_t m) {
+    uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        uint32_t spread = (uint32_t)((int32_t)(d << (31 - b)) >> 31);
+        asm volatile("" : "+v"(spread)); // (kept opaque: the ballot is taken from the spread bit, not from a second extraction of the digit)
+        const uint64_t bb = __ballot(spread != 0);
+        lo = __builtin_amdgcn_bitop3_b32(lo, (uint32_t)bb, spread, 0x90);
+        hi = __builtin_amdgcn_bitop3_b32(hi, (uint32_t)(bb >> 32), spread, 0x90);
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // ------------------------------------------------------------------------------------------
 // mid-size segments: block-local LSD radix sort in LDS (one segment per block)
 // ------------------------------------------------------------------------------------------
@@ -172,13 +190,7 @@ __global__ __launch_bounds__(NW * 64) void sort_block_radix_kernel(const SmallAr
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) { // rank among the wave's keys of the same digit: a popcount of the matching lanes below (stable)
             const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
-            uint64_t m = ~0ull;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const bool bit = (d >> b) & 1u;
-                const uint64_t bb = __ballot(bit);
-                m &= bit ? bb : ~bb;
-            }
+            const uint64_t m = match_digit8(d, ~0ull);
             const uint32_t prev = cnt[w][d];
             rank[r] = prev + (uint32_t)__popcll(m & below);
             if ((m & below) == 0) cnt[w][d] = prev + (uint32_t)__popcll(m); // the lowest lane of the match set
@@ -203,15 +215,16 @@ __global__ __launch_bounds__(NW * 64) void sort_block_radix_kernel(const SmallAr
         }
         __syncthreads();
         if (tid < 256) {
-            uint32_t off = 0;
+            uint32_t off = dstart[tid];
             for (int i = 0; i < w; ++i) off += wsum[i];
-            dstart[tid] += off;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) cnt[i][tid] += off; // where wave i's keys of this digit start in the reordered segment
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < ITEMS; ++r) {
             const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
-            const uint32_t lp = dstart[d] + cnt[w][d] + rank[r];
+            const uint32_t lp = cnt[w][d] + rank[r];
             skey[lp] = key[r];
             spos[lp] = (uint16_t)pos[r];
         }
@@ -236,10 +249,26 @@ template <int NW, int ITEMS> static size_t block_radix_lds(size_t usz) { return 
 // ------------------------------------------------------------------------------------------
 // long segments: LSD radix sort, 8-bit digits
 // ------------------------------------------------------------------------------------------
-#ifndef KF_SORT_R_ITEMS
-#define KF_SORT_R_ITEMS 16 // keys per thread. Measured (round 5, [1, 64 Mi] f32): 16 -> 2.22 ms, 32 (8192-key tiles: longer runs, half the blocks per CU) -> 2.85 ms
+// Tile shape by key width: threads per block, keys per thread (a wave owns 64 ITEMS consecutive keys). Measured, round 5, [1, 64 Mi] f32, one pass
+// of the scatter kernel: 256 x 16 -> 254 us, 512 x 8 -> 239, 512 x 16 -> 231 (and half the tile counts to write, scan and read back).
+#ifndef KF_SORT_R_NT
+#define KF_SORT_R_NT 512
 #endif
-constexpr int R_NT = 256, R_ITEMS = KF_SORT_R_ITEMS, R_TILE = R_NT * R_ITEMS, R_WAVE_KEYS = 64 * R_ITEMS;
+#ifndef KF_SORT_R_ITEMS
+#define KF_SORT_R_ITEMS 16
+#endif
+#ifndef KF_SORT_R64_NT
+#define KF_SORT_R64_NT 256
+#endif
+#ifndef KF_SORT_R64_ITEMS
+#define KF_SORT_R64_ITEMS 16
+#endif
+template <typename U> struct RadixCfg;
+template <> struct RadixCfg<uint32_t> { static constexpr int NT = KF_SORT_R_NT, ITEMS = KF_SORT_R_ITEMS, TILE = NT * ITEMS; };
+template <> struct RadixCfg<uint64_t> { static constexpr int NT = KF_SORT_R64_NT, ITEMS = KF_SORT_R64_ITEMS, TILE = NT * ITEMS; };
+#define KF_RADIX_CFG(U_) \
+    constexpr int R_NT = RadixCfg<U_>::NT, R_ITEMS = RadixCfg<U_>::ITEMS, R_TILE = RadixCfg<U_>::TILE, R_WAVE_KEYS = 64 * R_ITEMS; \
+    (void)R_NT; (void)R_ITEMS; (void)R_TILE; (void)R_WAVE_KEYS
 
 struct RadixArgs {
     const void *src_keys; // typed keys (first pass) or ordered keys of U
@@ -253,32 +282,71 @@ struct RadixArgs {
     int ntiles, nchunks, shift, first, last, desc;
 };
 
+// Block -> tile. Blocks are dealt to the eight XCDs round-robin; every XCD takes one contiguous eighth of the tiles, so the runs that
+// neighbouring tiles write behind each other meet in ONE L2 (round 5, [1, 64 Mi] f32: scatter 417 -> 359 us per pass; groups of 4 consecutive
+// tiles per XCD do as well: 357).
+__device__ __forceinline__ int radix_tile_of(int b, int ntiles) {
+    const int q = ntiles >> 3, r = ntiles & 7, x = b & 7;
+    return x * q + (x < r ? x : r) + (b >> 3);
+}
+
 template <typename U, int W, int KIND>
 __device__ __forceinline__ U radix_load(const RadixArgs &a, int64_t at, U flip) {
     return a.first ? to_ordered<U, W, KIND>(load_raw<U, W>(a.src_keys, at), flip) : ((const U *)a.src_keys)[at];
 }
 
+// Tile histogram of one digit. The counters are kept in H_REP replicas picked by the lane (a replica's 256 counters start one bank further
+// than the last one's): a digit that most keys share - the exponent byte of floats, the upper bytes of small integers - is then an
+// 8-lane, not a 64-lane, serialisation of the LDS add. Whole tiles of 4- or 8-byte keys on a 16-byte boundary are read with 16-byte loads
+// (the order inside a tile does not matter here).
+constexpr int H_REP = 8, H_STRIDE = 257;
+
 template <typename U, int W, int KIND>
-__global__ __launch_bounds__(R_NT) void radix_hist_kernel(const RadixArgs a) {
-    __shared__ uint32_t h[R_NT / 64][256];
-    const int tid = threadIdx.x, w = tid >> 6;
-    const int tile = blockIdx.x % a.ntiles;
+__global__ __launch_bounds__(RadixCfg<U>::NT) void radix_hist_kernel(const RadixArgs a) {
+    KF_RADIX_CFG(U);
+    __shared__ uint32_t h[H_REP * H_STRIDE];
+    const int tid = threadIdx.x;
+    const int tile = radix_tile_of(blockIdx.x % a.ntiles, a.ntiles);
     const int64_t seg = blockIdx.x / a.ntiles, segoff = seg * a.n;
     const U flip = a.desc ? KeyBits<U, W>::all : (U)0;
-#pragma unroll
-    for (int i = 0; i < R_NT / 64; ++i) h[i][tid] = 0;
+    for (int i = tid; i < H_REP * H_STRIDE; i += R_NT) h[i] = 0;
     __syncthreads();
+    uint32_t *hr = h + (tid & (H_REP - 1)) * H_STRIDE;
     const int64_t base = (int64_t)tile * R_TILE;
+    constexpr int ES = (int)sizeof(U);          // bytes of a stored key where the 16-byte path applies (typed keys of the same width, or ordered keys)
+    constexpr int PER = 16 / ES, NV = R_ITEMS / PER;
+    const bool same_width = !a.first || W == ES;
+    if (same_width && base + R_TILE <= a.n && ((((uintptr_t)a.src_keys) + (size_t)(segoff + base) * ES) & 15) == 0) {
+        const uint4 *src = (const uint4 *)((const char *)a.src_keys + (size_t)(segoff + base) * ES);
+        uint4 v[NV];
+#pragma unroll
+        for (int r = 0; r < NV; ++r) v[r] = src[r * R_NT + tid];
+#pragma unroll
+        for (int r = 0; r < NV; ++r) {
+            const uint32_t e[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
+#pragma unroll
+            for (int c = 0; c < PER; ++c) {
+                U raw;
+                if constexpr (ES == 4) raw = (U)e[c];
+                else raw = (U)(((uint64_t)e[2 * c + 1] << 32) | e[2 * c]);
+                const U o = a.first ? to_ordered<U, W, KIND>(raw, flip) : raw;
+                atomicAdd(&hr[(uint32_t)(o >> a.shift) & 255u], 1u);
+            }
+        }
+    } else {
 #pragma unroll 4
-    for (int r = 0; r < R_ITEMS; ++r) {
-        const int64_t i = base + r * R_NT + tid;
-        if (i < a.n) atomicAdd(&h[w][(uint32_t)(radix_load<U, W, KIND>(a, segoff + i, flip) >> a.shift) & 255u], 1u);
+        for (int r = 0; r < R_ITEMS; ++r) {
+            const int64_t i = base + r * R_NT + tid;
+            if (i < a.n) atomicAdd(&hr[(uint32_t)(radix_load<U, W, KIND>(a, segoff + i, flip) >> a.shift) & 255u], 1u);
+        }
     }
     __syncthreads();
-    uint32_t c = 0;
+    if (tid < 256) {
+        uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < R_NT / 64; ++i) c += h[i][tid];
-    a.counts[((size_t)seg * a.ntiles + tile) * 256 + tid] = c;
+        for (int i = 0; i < H_REP; ++i) c += h[i * H_STRIDE + tid];
+        a.counts[((size_t)seg * a.ntiles + tile) * 256 + tid] = c;
+    }
 }
 
 // Exclusive prefix of the tile histograms, per digit, in two levels so that one very long segment is not one block's
@@ -290,15 +358,21 @@ constexpr int R_CHUNK = 64;
 __global__ __launch_bounds__(256) void radix_scan_tiles_kernel(uint32_t *counts, uint32_t *chunk_sum, int ntiles, int nchunks) {
     const int d = threadIdx.x, chunk = blockIdx.x % nchunks;
     const int64_t seg = blockIdx.x / nchunks;
-    const int t0 = chunk * R_CHUNK, t1 = min(t0 + R_CHUNK, ntiles);
+    const int t0 = chunk * R_CHUNK, nt = min(R_CHUNK, ntiles - t0);
     uint32_t *c = counts + ((size_t)seg * ntiles + t0) * 256 + d;
+    uint32_t v[R_CHUNK]; // all of the chunk's counts of this digit are in flight at once: the walk is 64 loads deep, not 64 round trips long
+#pragma unroll
+    for (int t = 0; t < R_CHUNK; ++t) v[t] = t < nt ? c[(size_t)t * 256] : 0u;
     uint32_t run = 0;
-#pragma unroll 8
-    for (int t = 0; t < t1 - t0; ++t) {
-        const uint32_t v = c[(size_t)t * 256];
-        c[(size_t)t * 256] = run;
-        run += v;
+#pragma unroll
+    for (int t = 0; t < R_CHUNK; ++t) {
+        const uint32_t x = v[t];
+        v[t] = run;
+        run += x;
     }
+#pragma unroll
+    for (int t = 0; t < R_CHUNK; ++t)
+        if (t < nt) c[(size_t)t * 256] = v[t];
     chunk_sum[((size_t)seg * nchunks + chunk) * 256 + d] = run;
 }
 
@@ -309,18 +383,35 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *counts, uint
     const int64_t seg = blockIdx.x;
     uint32_t *c = counts + (size_t)seg * ntiles * 256 + d;
     const int chunk = (ntiles + 3) / 4, t0 = min(g * chunk, ntiles), t1 = min(t0 + chunk, ntiles);
+    constexpr int FAST = 64; // up to 256 chunks (64 Mi keys): each group's quarter sits in registers between the sum and the prefix
+    uint32_t v[FAST];
     uint32_t sum = 0;
+    if (chunk <= FAST) {
+#pragma unroll
+        for (int t = 0; t < FAST; ++t) v[t] = t0 + t < t1 ? c[(size_t)(t0 + t) * 256] : 0u;
+#pragma unroll
+        for (int t = 0; t < FAST; ++t) sum += v[t];
+    } else {
 #pragma unroll 8
-    for (int t = t0; t < t1; ++t) sum += c[(size_t)t * 256];
+        for (int t = t0; t < t1; ++t) sum += c[(size_t)t * 256];
+    }
     part[g][d] = sum;
     __syncthreads();
     uint32_t run = 0;
     for (int i = 0; i < g; ++i) run += part[i][d];
+    if (chunk <= FAST) {
+#pragma unroll
+        for (int t = 0; t < FAST; ++t) {
+            if (t0 + t < t1) c[(size_t)(t0 + t) * 256] = run;
+            run += v[t];
+        }
+    } else {
 #pragma unroll 8
-    for (int t = t0; t < t1; ++t) {
-        const uint32_t v = c[(size_t)t * 256];
-        c[(size_t)t * 256] = run;
-        run += v;
+        for (int t = t0; t < t1; ++t) {
+            const uint32_t x = c[(size_t)t * 256];
+            c[(size_t)t * 256] = run;
+            run += x;
+        }
     }
     // exclusive scan of the digit totals by group 0 (waves 0-3)
     uint32_t total = 0, inc = 0;
@@ -343,95 +434,144 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t *counts, uint
     }
 }
 
-template <typename U, int W, int KIND>
-__global__ __launch_bounds__(R_NT) void radix_scatter_kernel(const RadixArgs a) {
-    __shared__ uint32_t cnt[R_NT / 64][256];
-    __shared__ uint32_t dstart[256], gbase[256], wsum[R_NT / 64];
-    extern __shared__ __attribute__((aligned(16))) char rsmem[]; // the tile in its new order: keys, then positions (dynamic: 64 - 96 KiB)
-    U *skey = (U *)rsmem;
-    uint32_t *spos = (uint32_t *)(rsmem + (size_t)R_TILE * sizeof(U));
+// One tile of the stable scatter. FULL: every slot of the tile holds a key (all tiles of a segment but possibly its last one) - no validity
+// ballots, compares or guarded LDS accesses on that path (round 5: 359 -> 277 us per pass together with the 4-VALU-per-bit match).
+// (Tried and dropped, same run: keys and positions through ONE staging buffer one after the other - half the LDS, twice the tiles per CU,
+//  two more barriers: 244 us against 239 / 231 for the one-round 512 x 8 / 512 x 16 shapes.)
+template <typename U, int W, int KIND, bool FULL>
+__device__ __forceinline__ void radix_scatter_tile(const RadixArgs &a, uint32_t (*cnt)[256], uint32_t *gbase, uint32_t *wsum, char *stage, int tile,
+                                                   int64_t seg) {
+    KF_RADIX_CFG(U);
+    constexpr int NW = R_NT / 64;
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int tile = blockIdx.x % a.ntiles;
-    const int64_t seg = blockIdx.x / a.ntiles, segoff = seg * a.n;
+    const int64_t segoff = seg * a.n, tile0 = segoff + (int64_t)tile * R_TILE; // (uniform)
+    const int nv = FULL ? R_TILE : (int)(a.n - (int64_t)tile * R_TILE);
     const U flip = a.desc ? KeyBits<U, W>::all : (U)0;
-#pragma unroll
-    for (int i = 0; i < R_NT / 64; ++i) cnt[i][tid] = 0;
-    __syncthreads();
+    const uint32_t l0 = (uint32_t)(w * R_WAVE_KEYS + lane); // the tile-local index of this lane's first key; row r is l0 + 64 r
+    const uint64_t below = (1ull << lane) - 1;
 
     U key[R_ITEMS];
     uint32_t pos[R_ITEMS], rank[R_ITEMS];
-    const int64_t wbase = (int64_t)tile * R_TILE + w * R_WAVE_KEYS + lane;
-    const uint64_t below = (1ull << lane) - 1;
+    // (the first / later-pass branch stays OUTSIDE the row loops: all of a lane's loads are in flight before the first one is waited for -
+    //  with the branch inside the loop the first pass was sixteen round trips long: 348 us against 250 for the later passes)
+    if (a.first) {
+        const char *src = (const char *)a.src_keys + (size_t)tile0 * W;
 #pragma unroll
-    for (int r = 0; r < R_ITEMS; ++r) {
-        const int64_t i = wbase + r * 64;
-        const bool valid = i < a.n;
-        key[r] = valid ? radix_load<U, W, KIND>(a, segoff + i, flip) : (U)0;
-        pos[r] = valid ? (a.first ? (uint32_t)i : a.src_pos[segoff + i]) : 0u;
+        for (int r = 0; r < R_ITEMS; ++r) {
+            const uint32_t l = l0 + r * 64;
+            key[r] = (FULL || (int)l < nv) ? load_raw<U, W>(src, l) : (U)0;
+            pos[r] = (uint32_t)tile * R_TILE + l;
+        }
+#pragma unroll
+        for (int r = 0; r < R_ITEMS; ++r) key[r] = to_ordered<U, W, KIND>(key[r], flip);
+    } else {
+        const U *ksrc = (const U *)a.src_keys + tile0;
+        const uint32_t *psrc = a.src_pos + tile0;
+#pragma unroll
+        for (int r = 0; r < R_ITEMS; ++r) {
+            const uint32_t l = l0 + r * 64;
+            const bool valid = FULL || (int)l < nv;
+            key[r] = valid ? ksrc[l] : (U)0;
+            pos[r] = valid ? psrc[l] : 0u;
+        }
     }
 #pragma unroll
     for (int r = 0; r < R_ITEMS; ++r) {
-        const bool valid = wbase + r * 64 < a.n;
+        const bool valid = FULL || (int)(l0 + r * 64) < nv;
         const uint32_t d = (uint32_t)(key[r] >> a.shift) & 255u;
-        uint64_t m = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t bb = __ballot(bit);
-            m &= bit ? bb : ~bb;
-        }
+        const uint64_t m = match_digit8(d, FULL ? ~0ull : __ballot(valid));
         const uint32_t prev = cnt[w][d];
         rank[r] = prev + (uint32_t)__popcll(m & below);
         if (valid && (m & below) == 0) cnt[w][d] = prev + (uint32_t)__popcll(m); // the lowest lane of the match set
     }
     __syncthreads();
-    {
-        uint32_t c[R_NT / 64], total = 0;
+    uint32_t total = 0, inc = 0;
+    if (tid < 256) { // digit tid: the waves' counts -> exclusive offsets over the waves; exclusive scan of the digit totals
 #pragma unroll
-        for (int i = 0; i < R_NT / 64; ++i) {
-            c[i] = cnt[i][tid];
+        for (int i = 0; i < NW; ++i) {
+            const uint32_t c = cnt[i][tid];
             cnt[i][tid] = total;
-            total += c[i];
+            total += c;
         }
-        uint32_t inc = total;
+        inc = total;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t up = __shfl_up(inc, o, 64);
             if (lane >= o) inc += up;
         }
         if (lane == 63) wsum[w] = inc;
-        __syncthreads();
+    }
+    __syncthreads();
+    if (tid < 256) {
         uint32_t off = 0;
         for (int i = 0; i < w; ++i) off += wsum[i];
         const uint32_t ex = off + inc - total;
-        dstart[tid] = ex;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) cnt[i][tid] += ex; // where wave i's keys of this digit start in the reordered tile
         gbase[tid] = a.counts[((size_t)seg * a.ntiles + tile) * 256 + tid] + a.chunk_base[((size_t)seg * a.nchunks + tile / R_CHUNK) * 256 + tid] +
                      a.digit_base[(size_t)seg * 256 + tid] - ex;
     }
     __syncthreads();
 #pragma unroll
+    for (int r = 0; r < R_ITEMS; ++r) { // (from here on rank[] is the key's slot in the reordered tile)
+        const uint32_t d = (uint32_t)(key[r] >> a.shift) & 255u;
+        rank[r] += cnt[w][d];
+    }
+    U *skey = (U *)stage;
+    uint32_t *spos = (uint32_t *)(stage + (size_t)R_TILE * sizeof(U));
+#pragma unroll
     for (int r = 0; r < R_ITEMS; ++r) {
-        if (wbase + r * 64 < a.n) {
-            const uint32_t d = (uint32_t)(key[r] >> a.shift) & 255u;
-            const uint32_t lp = dstart[d] + cnt[w][d] + rank[r];
-            skey[lp] = key[r];
-            spos[lp] = pos[r];
+        if (FULL || (int)(l0 + r * 64) < nv) {
+            skey[rank[r]] = key[r];
+            spos[rank[r]] = pos[r];
         }
     }
     __syncthreads();
-    const int64_t left = a.n - (int64_t)tile * R_TILE;
-    const int nv = left < R_TILE ? (int)left : R_TILE;
-    for (int i = tid; i < nv; i += R_NT) {
-        const U k = skey[i];
-        const int64_t at = segoff + (uint32_t)(gbase[(uint32_t)(k >> a.shift) & 255u] + (uint32_t)i);
-        if (a.last) {
-            store_raw<U, W>(a.dst_keys, at, from_ordered<U, W, KIND>(k, flip));
-            ((int64_t *)a.dst_pos)[at] = (int64_t)spos[i];
-        } else {
-            ((U *)a.dst_keys)[at] = k;
-            ((uint32_t *)a.dst_pos)[at] = spos[i];
+    // (reads first, then the digit bases, then the stores - each step over all of the lane's slots, and the last-pass branch outside them)
+#pragma unroll
+    for (int r = 0; r < R_ITEMS; ++r) {
+        const int i = tid + r * R_NT;
+        key[r] = (FULL || i < nv) ? skey[i] : (U)0;
+        pos[r] = (FULL || i < nv) ? spos[i] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < R_ITEMS; ++r) rank[r] = gbase[(uint32_t)(key[r] >> a.shift) & 255u] + (uint32_t)(tid + r * R_NT);
+    if (a.last) {
+#pragma unroll
+        for (int r = 0; r < R_ITEMS; ++r) {
+            if (FULL || tid + r * R_NT < nv) {
+                store_raw<U, W>(a.dst_keys, segoff + rank[r], from_ordered<U, W, KIND>(key[r], flip));
+                ((int64_t *)a.dst_pos)[segoff + rank[r]] = (int64_t)pos[r];
+            }
+        }
+    } else {
+        U *kdst = (U *)a.dst_keys + segoff;
+        uint32_t *pdst = (uint32_t *)a.dst_pos + segoff;
+#pragma unroll
+        for (int r = 0; r < R_ITEMS; ++r) {
+            if (FULL || tid + r * R_NT < nv) {
+                kdst[rank[r]] = key[r];
+                pdst[rank[r]] = pos[r];
+            }
         }
     }
+}
+
+template <typename U, int W, int KIND>
+__global__ __launch_bounds__(RadixCfg<U>::NT) void radix_scatter_kernel(const RadixArgs a) {
+    KF_RADIX_CFG(U);
+    constexpr int NW = R_NT / 64;
+    __shared__ uint32_t cnt[NW][256];
+    __shared__ uint32_t gbase[256], wsum[4];
+    extern __shared__ __attribute__((aligned(16))) char rsmem[]; // the tile in its new order (dynamic)
+    const int tid = threadIdx.x;
+    const int tile = radix_tile_of(blockIdx.x % a.ntiles, a.ntiles);
+    const int64_t seg = blockIdx.x / a.ntiles;
+#pragma unroll
+    for (int i = 0; i < NW * 256 / R_NT; ++i) (&cnt[0][0])[i * R_NT + tid] = 0;
+    __syncthreads();
+    if ((int64_t)(tile + 1) * R_TILE <= a.n) radix_scatter_tile<U, W, KIND, true>(a, cnt, gbase, wsum, rsmem, tile, seg);
+    else radix_scatter_tile<U, W, KIND, false>(a, cnt, gbase, wsum, rsmem, tile, seg);
 }
 
 constexpr int64_t kSmallMax = 8192;  // one block per segment (or several segments per block) up to here
@@ -448,7 +588,8 @@ static SortPlan make_plan(int dtype, int64_t nseg, int64_t n) {
     p.small = n <= kSmallMax;
     if (p.small || nseg == 0) return p;
     const size_t usz = dtype_size(dtype) == 8 ? 8 : 4;
-    p.ntiles = (int)((n + R_TILE - 1) / R_TILE);
+    const int64_t tile = usz == 8 ? RadixCfg<uint64_t>::TILE : RadixCfg<uint32_t>::TILE;
+    p.ntiles = (int)((n + tile - 1) / tile);
     p.key_bytes = up256((size_t)nseg * n * usz);
     p.pos_bytes = up256((size_t)nseg * n * 4);
     p.nchunks = (p.ntiles + R_CHUNK - 1) / R_CHUNK;
@@ -498,6 +639,7 @@ static int run_sort(const void *in, void *out, int64_t *pos, int64_t nseg, int64
         KF_LAUNCH_CHECK();
         return KF_OK;
     }
+    KF_RADIX_CFG(U);
     char *keys[2] = {ws, ws + p.key_bytes};
     char *poss[2] = {ws + 2 * p.key_bytes, ws + 2 * p.key_bytes + p.pos_bytes};
     uint32_t *counts = (uint32_t *)(ws + 2 * p.key_bytes + 2 * p.pos_bytes);
