@@ -176,12 +176,17 @@ __global__ __launch_bounds__(NW * 64) void sort_block_radix_kernel(const SmallAr
     const uint64_t below = (1ull << lane) - 1;
     U key[ITEMS];
     uint32_t pos[ITEMS], rank[ITEMS];
+    // (no branch around a load: a slot behind the segment's end reads the segment's last key and is then replaced - all of a lane's loads are in
+    //  flight before the first is waited for; with `i < n ? load : pad` the sixteen loads were sixteen round trips)
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) { // index order: wave w holds items w WK + r 64 + lane (the order the ranks below are taken in)
         const int i = w * WK + r * 64 + lane;
-        key[r] = i < a.n ? to_ordered<U, W, KIND>(load_raw<U, W>(a.in, segoff + i), flip) : KeyBits<U, W>::all; // (padding: behind every real key)
+        key[r] = load_raw<U, W>(a.in, segoff + (i < a.n ? i : a.n - 1));
         pos[r] = (uint32_t)i;
     }
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r)
+        key[r] = (int)pos[r] < a.n ? to_ordered<U, W, KIND>(key[r], flip) : KeyBits<U, W>::all; // (padding: behind every real key)
 #pragma unroll 1
     for (int pass = 0; pass < W; ++pass) {
         const int shift = 8 * pass;
@@ -239,9 +244,19 @@ __global__ __launch_bounds__(NW * 64) void sort_block_radix_kernel(const SmallAr
             __syncthreads();
         }
     }
-    for (int i = tid; i < a.n; i += NT) {
-        store_raw<U, W>(a.out, segoff + i, from_ordered<U, W, KIND>(skey[i], flip));
-        a.pos[segoff + i] = (int64_t)spos[i];
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) { // (LDS reads of all of a lane's slots first, then the stores)
+        const int i = tid + r * NT;
+        key[r] = skey[i];
+        pos[r] = spos[i];
+    }
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const int i = tid + r * NT;
+        if (i < a.n) {
+            store_raw<U, W>(a.out, segoff + i, from_ordered<U, W, KIND>(key[r], flip));
+            a.pos[segoff + i] = (int64_t)pos[r];
+        }
     }
 }
 template <int NW, int ITEMS> static size_t block_radix_lds(size_t usz) { return (size_t)NW * 64 * ITEMS * (usz + 2) + (size_t)NW * 1024 + 1024 + 64; }
