@@ -110,16 +110,20 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormArgs a) {
     const T *x = (const T *)a.x + (live ? row : 0) * a.ldx;
     float xv[PACKS][V];
     float s = 0.f;
+    {
+        // all of a lane's row loads are issued before the first value is touched (with the unpack and the sum inside the guarded branch
+        // every pack was its own round trip); a pack behind the row's end is zeros, which add nothing to either sum
+        uint4 raw[PACKS];
 #pragma unroll
-    for (int p = 0; p < PACKS; ++p) {
-        const int64_t c = ((int64_t)p * TPR + tr) * V;
-        if (live && c < a.cols) {
-            n_unpack<T, V>(*(const uint4 *)(x + c), xv[p]);
+        for (int p = 0; p < PACKS; ++p) {
+            const int64_t c = ((int64_t)p * TPR + tr) * V;
+            raw[p] = (live && c < a.cols) ? *(const uint4 *)(x + c) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int p = 0; p < PACKS; ++p) {
+            n_unpack<T, V>(raw[p], xv[p]);
 #pragma unroll
             for (int i = 0; i < V; ++i) s += a.rms ? xv[p][i] * xv[p][i] : xv[p][i];
-        } else {
-#pragma unroll
-            for (int i = 0; i < V; ++i) xv[p][i] = 0.f;
         }
     }
     const float inv_n = 1.0f / (float)a.cols;
@@ -147,13 +151,25 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormArgs a) {
     }
     if (!live) return;
     T *y = (T *)a.y + row * a.ldx;
+    // weight and bias packs four at a time: their (L2-served) loads in flight together, then the arithmetic, then the stores
+    constexpr int G = PACKS < 4 ? PACKS : 4;
 #pragma unroll
-    for (int p = 0; p < PACKS; ++p) {
-        const int64_t c = ((int64_t)p * TPR + tr) * V;
-        if (c < a.cols) {
+    for (int p0 = 0; p0 < PACKS; p0 += G) {
+        uint4 wr[G], br[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int64_t c = ((int64_t)(p0 + g) * TPR + tr) * V;
+            const bool in = c < a.cols;
+            wr[g] = (a.w && in) ? *(const uint4 *)((const T *)a.w + c) : make_uint4(0u, 0u, 0u, 0u);
+            br[g] = (a.b && in) ? *(const uint4 *)((const T *)a.b + c) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int p = p0 + g;
+            const int64_t c = ((int64_t)p * TPR + tr) * V;
             float wv[V], bv[V], o[V];
-            if (a.w) n_unpack<T, V>(*(const uint4 *)((const T *)a.w + c), wv);
-            if (a.b) n_unpack<T, V>(*(const uint4 *)((const T *)a.b + c), bv);
+            n_unpack<T, V>(wr[g], wv);
+            n_unpack<T, V>(br[g], bv);
 #pragma unroll
             for (int i = 0; i < V; ++i) {
                 float t = (xv[p][i] - mean) * rstd;
@@ -161,7 +177,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormArgs a) {
                 if (a.b) t += bv[i];
                 o[i] = t;
             }
-            *(uint4 *)(y + c) = n_pack<T, V>(o);
+            if (c < a.cols) *(uint4 *)(y + c) = n_pack<T, V>(o);
         }
     }
 }
