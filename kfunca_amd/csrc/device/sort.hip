@@ -613,7 +613,7 @@ __device__ __forceinline__ void radix_scatter_tile(const RadixArgs &a, uint32_t 
         const uint32_t ex = off + inc - total;
 #pragma unroll
         for (int i = 0; i < NW; ++i) cnt[i][tid] += ex; // where wave i's keys of this digit start in the reordered tile
-        gbase[tid] = a.counts[((size_t)seg * a.ntiles + tile) * 256 + tid] + a.chunk_base[((size_t)seg * a.nchunks + tile / R_CHUNK) * 256 + tid] +
+        gbase[tid] = a.counts[((size_t)seg * a.ntiles + tile) * 256 + tid] + (a.nchunks ? a.chunk_base[((size_t)seg * a.nchunks + tile / R_CHUNK) * 256 + tid] : 0u) +
                      a.digit_base[(size_t)seg * 256 + tid] - ex;
     }
     __syncthreads();
@@ -727,11 +727,12 @@ static int run_sort(const void *in, void *out, int64_t *pos, int64_t nseg, int64
     if (p.small && n <= 64) { // rows of 64 slots in registers
         SmallArgs a{in, out, pos, nseg, (int)n, 0, 1, desc};
         while ((1 << a.logp) < n) ++a.logp;
+        if (a.logp < 1) a.logp = 1; // (a one-key segment takes a two-slot cell)
         const int64_t rows = (nseg + (64 >> a.logp) - 1) / (64 >> a.logp), grid = (rows + 4 * kWaveRows - 1) / (4 * kWaveRows);
         KF_REQUIRE(grid <= 0x7fffffff, KF_ERR_INDEX_RANGE, "kf_sort: too many segments");
         KF_PROF("sort_bitonic_wave", st);
         switch (a.logp) {
-        case 0: case 1: sort_wave_kernel<U, W, KIND, 1><<<(unsigned)grid, 256, 0, st>>>(a); break;
+        case 1: sort_wave_kernel<U, W, KIND, 1><<<(unsigned)grid, 256, 0, st>>>(a); break;
         case 2: sort_wave_kernel<U, W, KIND, 2><<<(unsigned)grid, 256, 0, st>>>(a); break;
         case 3: sort_wave_kernel<U, W, KIND, 3><<<(unsigned)grid, 256, 0, st>>>(a); break;
         case 4: sort_wave_kernel<U, W, KIND, 4><<<(unsigned)grid, 256, 0, st>>>(a); break;
@@ -770,6 +771,7 @@ static int run_sort(const void *in, void *out, int64_t *pos, int64_t nseg, int64
     const int64_t grid = nseg * p.ntiles;
     KF_REQUIRE(grid <= 0x7fffffff && nseg <= 0x7fffffff, KF_ERR_INDEX_RANGE, "kf_sort: too many tiles");
     KF_PROF("sort_radix", st);
+    const bool one_level = p.ntiles <= 256;
     for (int pass = 0; pass < W; ++pass) {
         RadixArgs a{};
         a.first = pass == 0;
@@ -787,8 +789,13 @@ static int run_sort(const void *in, void *out, int64_t *pos, int64_t nseg, int64
         a.shift = 8 * pass;
         a.desc = desc;
         radix_hist_kernel<U, W, KIND><<<(unsigned)grid, R_NT, 0, st>>>(a);
-        radix_scan_tiles_kernel<<<(unsigned)(nseg * p.nchunks), 256, 0, st>>>(counts, cbase, p.ntiles, p.nchunks);
-        radix_scan_kernel<<<(unsigned)nseg, 1024, 0, st>>>(cbase, dbase, p.nchunks);
+        if (one_level) { // up to 256 tiles per segment: the second-level kernel walks the tile counts themselves (one launch less per pass)
+            a.nchunks = 0;
+            radix_scan_kernel<<<(unsigned)nseg, 1024, 0, st>>>(counts, dbase, p.ntiles);
+        } else {
+            radix_scan_tiles_kernel<<<(unsigned)(nseg * p.nchunks), 256, 0, st>>>(counts, cbase, p.ntiles, p.nchunks);
+            radix_scan_kernel<<<(unsigned)nseg, 1024, 0, st>>>(cbase, dbase, p.nchunks);
+        }
         const size_t lds = (size_t)R_TILE * (sizeof(U) + 4);
         KF_HIP_TRY(hipFuncSetAttribute((const void *)radix_scatter_kernel<U, W, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         radix_scatter_kernel<U, W, KIND><<<(unsigned)grid, R_NT, lds, st>>>(a);
