@@ -134,3 +134,11 @@ def test_empty_and_errors():
     assert H.lib().kf_sort_workspace_bytes(H.F32, 1, 20000) > 0
     with pytest.raises(H.KfError, match="workspace"):
         H.check(H.lib().kf_sort(H.F32, big.ptr, out.ptr, pos2.ptr, 1, 20000, 0, None, 0, None))
+
+
+def test_many_tiles_and_segments():
+    # a few hundred tiles per segment (two scan levels), several segments in one launch, ragged last tiles, every key width
+    rng = np.random.default_rng(714)
+    for code, shape in ((H.F32, (1, 3_000_000)), (H.I32, (5, 400_003)), (H.F64, (2, 700_001)), (H.U8, (3, 300_000)), (H.BF16, (2, 1_000_000)), (H.I64, (7, 70_000))):
+        for desc in (False, True):
+            check(draw(rng, shape, code), code, desc)
