@@ -273,7 +273,16 @@ __global__ __launch_bounds__(kBlock) void ew_transpose_vec_kernel(const TransArg
     __shared__ U tile[TD][TD + (sizeof(U) >= 4 ? 1 : 2)];
     const uint32_t blk = blockIdx.x;
     const uint32_t bt = blk / (a.tiles0 * a.tiles1), rem = blk - bt * (a.tiles0 * a.tiles1);
-    const uint32_t t1 = rem / a.tiles0, t0 = rem - t1 * a.tiles0;
+    uint32_t t1 = rem / a.tiles0, t0 = rem - t1 * a.tiles0;
+    // Blocks go to the eight XCDs round-robin. SD x SD consecutive blocks of ONE XCD take the tiles of a super-tile whose rows are 1 KiB on both sides
+    // (4 x 4 tiles of 4-byte elements, 8 x 8 of 2-byte ones): what an XCD's L2 sees of both matrices within a short time is whole 1-KiB row pieces instead
+    // of lone 256- / 128-byte ones at the matrices' row pitch. Round 5, 16384^2: f32 0.42-0.46 -> 0.38-0.40 ms, bf16 0.31 -> 0.21 (4 x 4: 0.24).
+    constexpr uint32_t SL = sizeof(U) == 4 ? 2 : 3, SD = 1u << SL, SN = SD * SD;
+    if ((a.tiles0 & (SD - 1)) == 0 && (a.tiles1 & (SD - 1)) == 0 && ((a.tiles0 * a.tiles1) & (8 * SN - 1)) == 0) {
+        const uint32_t x = rem & 7, s = rem >> 3, super = (s / SN) * 8 + x, in = s & (SN - 1), s0 = a.tiles0 >> SL;
+        t0 = (super % s0) * SD + (in & (SD - 1));
+        t1 = (super / s0) * SD + (in >> SL);
+    }
     uint32_t boff[2];
     a.bc.get(bt, boff);
     const uint32_t i0 = t0 * TD, j0 = t1 * TD;

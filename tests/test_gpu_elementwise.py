@@ -237,6 +237,11 @@ def test_tiled_transpose_and_vector_convert_paths():
     x = rand_of(rng, (4096, 4096), H.F32)  # multi-tile, exact
     got = gpu_copy(Dev(x.T, base=x), Dev.empty((4096, 4096), H.F32)).get()
     assert np.array_equal(got, x.T)
+    for code, shape, perm in ((H.BF16, (2048, 2048), (1, 0)), (H.F32, (2, 1024, 512), (0, 2, 1)), (H.BF16, (2, 2048, 1024), (0, 2, 1)), (H.I16, (1024, 4096), (1, 0))):
+        x = rand_of(rng, shape, code)  # tile counts that take the XCD super-tile order (4 x 4 tiles of 4-byte, 8 x 8 of 2-byte elements), with a batch dim too
+        v = x.transpose(perm)
+        got = gpu_copy(Dev(v, code, base=x), Dev.empty(v.shape, code)).get()
+        assert np.array_equal(bits(got), bits(np.ascontiguousarray(v))), (code, shape, perm)
     for cs in (H.F32, H.F16, H.BF16):
         for n in (8, 1 << 16, (1 << 16) + 8):
             x = rand_of(rng, (n,), cs)
