@@ -9,12 +9,12 @@
 // a descending sort is the ascending sort of the complemented key, which keeps equal keys in input order exactly like
 // the reference's reversed digit bins.
 //
-//   * n <= 64 (round 5): bitonic network over (key, position) composites held in registers - a wave's 64 lanes are 64 / P segments of P slots,
-//     partners come through DPP / ds_swizzle / ds_bpermute, no LDS memory and no barrier; four rows per wave in flight.
-//     [1 Mi, 64] f32: 0.62 -> 0.19 ms = 5.6 TB/s of key + position traffic (0.70 of HBM).
-//   * 64 < n <= 512: one block sorts spb segments in LDS with a bitonic network over (key, position) composites -
-//     positions are unique, so the total order IS the stable order and no ranking pass is needed. Short segments share a
-//     block (2048 slots per block), so [68185 segments x 13 keys] does not launch 68185 nearly empty blocks.
+//   * n <= 512 (round 5): bitonic network over (key, position) composites held in REGISTERS - positions are unique, so the total order IS the
+//     stable order and no ranking pass is needed. n <= 64: a wave's 64 lanes are 64 / P segments of P slots, four rows per wave in flight;
+//     64 < n <= 512: one segment per wave, P / 64 slots per lane (partner distances of 64 and more pair two registers of one lane).
+//     Partners come through DPP / ds_swizzle / ds_bpermute, the compare becomes the select mask by one scalar XOR with a constant of the stage;
+//     no LDS memory, no barrier. [1 Mi, 64] f32: 0.62 -> 0.19 ms = 5.6 TB/s of key + position traffic (0.70 of HBM); 64 Mi keys in segments of
+//     128 / 256 / 512: 0.83 / 1.01 / 1.23 ms with the LDS network this replaced.
 //   * 512 < n <= 8192 (round 5): ONE block sorts ONE segment by a least-significant-digit radix sort that never leaves LDS - 8-bit digits, one
 //     pass per key byte, the ballot ranking of the long-segment path below, positions carried as 16-bit values. The bitonic network needs
 //     log2(P) (log2(P) + 1) / 2 = 78 LDS passes over a 4096-key segment (40 k cycles of LDS pipe); four radix passes need ~10 k cycles of VALU.
@@ -67,36 +67,6 @@ template <typename U, int W, int KIND> __device__ __forceinline__ U from_ordered
     return o;
 }
 
-// ------------------------------------------------------------------------------------------
-// short segments: bitonic network in LDS
-// ------------------------------------------------------------------------------------------
-template <typename U> struct Slots;
-template <> struct Slots<uint32_t> { // key and position in one 64-bit word: one compare
-    uint64_t *c;
-    struct V { uint64_t v; };
-    __device__ void init(char *smem, int) { c = (uint64_t *)smem; }
-    __device__ V get(int i) const { return {c[i]}; }
-    __device__ void put(int i, V x) { c[i] = x.v; }
-    static __device__ V make(uint32_t k, uint32_t i) { return {((uint64_t)k << 32) | i}; }
-    static __device__ bool lt(V a, V b) { return a.v < b.v; }
-    static __device__ uint32_t key(V a) { return (uint32_t)(a.v >> 32); }
-    static __device__ uint32_t pos(V a) { return (uint32_t)a.v; }
-    static size_t bytes(int e) { return (size_t)e * 8; }
-};
-template <> struct Slots<uint64_t> {
-    uint64_t *k;
-    uint32_t *p;
-    struct V { uint64_t k; uint32_t p; };
-    __device__ void init(char *smem, int e) { k = (uint64_t *)smem; p = (uint32_t *)(smem + (size_t)e * 8); }
-    __device__ V get(int i) const { return {k[i], p[i]}; }
-    __device__ void put(int i, V x) { k[i] = x.k; p[i] = x.p; }
-    static __device__ V make(uint64_t k, uint32_t i) { return {k, i}; }
-    static __device__ bool lt(V a, V b) { return a.k < b.k || (a.k == b.k && a.p < b.p); }
-    static __device__ uint64_t key(V a) { return a.k; }
-    static __device__ uint32_t pos(V a) { return a.p; }
-    static size_t bytes(int e) { return (size_t)e * 12; }
-};
-
 struct SmallArgs {
     const void *in;
     void *out;
@@ -104,48 +74,6 @@ struct SmallArgs {
     int64_t nseg;
     int n, logp, spb, desc;
 };
-
-template <typename U, int W, int KIND>
-__global__ __launch_bounds__(1024) void sort_small_kernel(const SmallArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int P = 1 << a.logp, E = a.spb << a.logp, nthr = blockDim.x, tid = threadIdx.x;
-    Slots<U> s;
-    s.init(smem, E);
-    using V = typename Slots<U>::V;
-    const U flip = a.desc ? KeyBits<U, W>::all : (U)0;
-    const int64_t seg0 = (int64_t)blockIdx.x * a.spb;
-    for (int e = tid; e < E; e += nthr) {
-        const int il = e & (P - 1);
-        const int64_t seg = seg0 + (e >> a.logp);
-        V v = Slots<U>::make(~(U)0, 0x80000000u | (uint32_t)il); // padding: behind every real key, every real position
-        if (seg < a.nseg && il < a.n) v = Slots<U>::make(to_ordered<U, W, KIND>(load_raw<U, W>(a.in, seg * a.n + il), flip), (uint32_t)il);
-        s.put(e, v);
-    }
-    __syncthreads();
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (E >> 1); t += nthr) {
-                const int i = 2 * t - (t & (j - 1)), l = i + j;
-                const bool up = ((i & (P - 1)) & k) == 0;
-                const V x = s.get(i), y = s.get(l);
-                if (Slots<U>::lt(y, x) == up) {
-                    s.put(i, y);
-                    s.put(l, x);
-                }
-            }
-            __syncthreads();
-        }
-    }
-    for (int e = tid; e < E; e += nthr) {
-        const int il = e & (P - 1);
-        const int64_t seg = seg0 + (e >> a.logp);
-        if (seg < a.nseg && il < a.n) {
-            const V v = s.get(e);
-            store_raw<U, W>(a.out, seg * a.n + il, from_ordered<U, W, KIND>(Slots<U>::key(v), flip));
-            a.pos[seg * a.n + il] = (int64_t)Slots<U>::pos(v);
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // segments of up to 64 keys: bitonic network in registers, one 64-slot row per wave instruction stream
@@ -158,13 +86,13 @@ __device__ __forceinline__ constexpr uint64_t lanes_with_bit_clear(int b) {
     return b == 1 ? 0x5555555555555555ull : b == 2 ? 0x3333333333333333ull : b == 4 ? 0x0F0F0F0F0F0F0F0Full : b == 8 ? 0x00FF00FF00FF00FFull
          : b == 16 ? 0x0000FFFF0000FFFFull : b == 32 ? 0x00000000FFFFFFFFull : ~0ull;
 }
-__device__ __forceinline__ uint32_t lane_xor(uint32_t v, int j) { // (j is a constant after unrolling)
-    if (j == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
-    if (j == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
-    if (j == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true); // row_ror:8
-    if (j == 4) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);                   // and 0x1f, xor 4
-    if (j == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);                  // and 0x1f, xor 16
-    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63) ^ 32) << 2), (int)v);
+template <int J> __device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+    if constexpr (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);       // quad_perm [1,0,3,2]
+    else if constexpr (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+    else if constexpr (J == 8) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true); // row_ror:8
+    else if constexpr (J == 4) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);                   // and 0x1f, xor 4
+    else if constexpr (J == 16) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401F);                 // and 0x1f, xor 16
+    else return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63) ^ 32) << 2), (int)v);
 }
 __device__ __forceinline__ uint32_t pick(uint64_t take, uint32_t mine, uint32_t other) {
     uint32_t r;
@@ -175,27 +103,67 @@ __device__ __forceinline__ uint32_t pick(uint64_t take, uint32_t mine, uint32_t 
 template <typename U> struct WaveSlot;
 template <> struct WaveSlot<uint32_t> {
     uint32_t k, p;
-    __device__ __forceinline__ void step(int kk, int j) {
-        const uint32_t ok = lane_xor(k, j), op = lane_xor(p, j);
+    // UP: the lanes whose pair is to come out ascending (a constant of the stage)
+    template <int J, uint64_t UP> __device__ __forceinline__ void step() {
+        const uint32_t ok = lane_xor<J>(k), op = lane_xor<J>(p);
         const uint64_t lt = __ballot((((uint64_t)ok << 32) | op) < (((uint64_t)k << 32) | p));
-        const uint64_t take = ~(lt ^ ~(lanes_with_bit_clear(j) ^ lanes_with_bit_clear(kk)));
+        const uint64_t take = lt ^ (lanes_with_bit_clear(J) ^ UP); // = NOT (lt XOR (this lane keeps the smaller one))
         k = pick(take, k, ok);
         p = pick(take, p, op);
+    }
+    // the pair (lo, hi) of ONE lane: ascending (UP) or descending
+    template <bool UP> static __device__ __forceinline__ void order(WaveSlot &lo, WaveSlot &hi) {
+        const uint64_t lt = __ballot((((uint64_t)hi.k << 32) | hi.p) < (((uint64_t)lo.k << 32) | lo.p));
+        const uint64_t take = UP ? lt : ~lt;
+        const uint32_t k0 = pick(take, lo.k, hi.k), p0 = pick(take, lo.p, hi.p);
+        hi.k = pick(take, hi.k, lo.k);
+        hi.p = pick(take, hi.p, lo.p);
+        lo.k = k0;
+        lo.p = p0;
     }
 };
 template <> struct WaveSlot<uint64_t> {
     uint64_t k;
     uint32_t p;
-    __device__ __forceinline__ void step(int kk, int j) {
+    template <int J, uint64_t UP> __device__ __forceinline__ void step() {
         const uint32_t klo = (uint32_t)k, khi = (uint32_t)(k >> 32);
-        const uint32_t olo = lane_xor(klo, j), ohi = lane_xor(khi, j), op = lane_xor(p, j);
+        const uint32_t olo = lane_xor<J>(klo), ohi = lane_xor<J>(khi), op = lane_xor<J>(p);
         const uint64_t ok = ((uint64_t)ohi << 32) | olo;
         const uint64_t lt = __ballot(ok < k || (ok == k && op < p));
-        const uint64_t take = ~(lt ^ ~(lanes_with_bit_clear(j) ^ lanes_with_bit_clear(kk)));
+        const uint64_t take = lt ^ (lanes_with_bit_clear(J) ^ UP);
         k = ((uint64_t)pick(take, khi, ohi) << 32) | pick(take, klo, olo);
         p = pick(take, p, op);
     }
+    template <bool UP> static __device__ __forceinline__ void order(WaveSlot &lo, WaveSlot &hi) {
+        const uint64_t lt = __ballot(hi.k < lo.k || (hi.k == lo.k && hi.p < lo.p));
+        const uint64_t take = UP ? lt : ~lt;
+        const uint32_t a0 = pick(take, (uint32_t)lo.k, (uint32_t)hi.k), a1 = pick(take, (uint32_t)(lo.k >> 32), (uint32_t)(hi.k >> 32)), p0 = pick(take, lo.p, hi.p);
+        const uint32_t b0 = pick(take, (uint32_t)hi.k, (uint32_t)lo.k), b1 = pick(take, (uint32_t)(hi.k >> 32), (uint32_t)(lo.k >> 32));
+        hi.p = pick(take, hi.p, lo.p);
+        hi.k = ((uint64_t)b1 << 32) | b0;
+        lo.k = ((uint64_t)a1 << 32) | a0;
+        lo.p = p0;
+    }
 };
+
+// The network as templates (every stage's partner distance, direction mask and register pairing is a compile-time constant):
+// slot = e 64 + lane, E slots per lane, P = 64 E slots per segment (E = 1: 64 / P segments of P slots per row).
+template <typename U, int P, int E, int K, int J, int e> __device__ __forceinline__ void net_slot(WaveSlot<U> (&x)[E]) {
+    constexpr bool up_e = ((e * 64) & K) == 0 || K >= P * (E == 1 ? 64 / P : 1); // (the last merge is ascending in every segment: its direction bit lies outside the slot index)
+    if constexpr (J >= 64) {
+        if constexpr ((e & (J >> 6)) == 0) WaveSlot<U>::template order<up_e>(x[e], x[e | (J >> 6)]);
+    } else {
+        constexpr uint64_t UP = (K < 64 && K < P) ? lanes_with_bit_clear(K) : (up_e ? ~0ull : 0ull);
+        x[e].template step<J, UP>();
+    }
+    if constexpr (e + 1 < E) net_slot<U, P, E, K, J, e + 1>(x);
+}
+template <typename U, int P, int E, int WR, int K, int J> __device__ __forceinline__ void net_from(WaveSlot<U> (&x)[WR][E]) { // stage (K, J) and all behind it
+#pragma unroll
+    for (int r = 0; r < WR; ++r) net_slot<U, P, E, K, J, 0>(x[r]);
+    if constexpr (J > 1) net_from<U, P, E, WR, K, J / 2>(x);
+    else if constexpr (K < P) net_from<U, P, E, WR, 2 * K, K>(x);
+}
 
 constexpr int kWaveRows = 4;
 template <typename U, int W, int KIND, int LOGP>
@@ -204,7 +172,7 @@ __global__ __launch_bounds__(256) void sort_wave_kernel(const SmallArgs a) {
     const int lane = threadIdx.x & 63, il = lane & (P - 1);
     const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * WR;
     const U flip = a.desc ? KeyBits<U, W>::all : (U)0;
-    WaveSlot<U> x[WR];
+    WaveSlot<U> x[WR][1];
     int64_t at[WR];
     bool live[WR];
 #pragma unroll
@@ -212,26 +180,62 @@ __global__ __launch_bounds__(256) void sort_wave_kernel(const SmallArgs a) {
         const int64_t seg = (row0 + r) * SPW + (lane >> LOGP);
         live[r] = seg < a.nseg && il < a.n;
         at[r] = live[r] ? seg * a.n + il : 0;
-        x[r].k = load_raw<U, W>(a.in, at[r]);
+        x[r][0].k = load_raw<U, W>(a.in, at[r]);
     }
 #pragma unroll
     for (int r = 0; r < WR; ++r) {
-        x[r].k = live[r] ? to_ordered<U, W, KIND>(x[r].k, flip) : ~(U)0; // padding: behind every real key, every real position
-        x[r].p = live[r] ? (uint32_t)il : 0x80000000u | (uint32_t)il;
+        x[r][0].k = live[r] ? to_ordered<U, W, KIND>(x[r][0].k, flip) : ~(U)0; // padding: behind every real key, every real position
+        x[r][0].p = live[r] ? (uint32_t)il : 0x80000000u | (uint32_t)il;
     }
-#pragma unroll
-    for (int k = 2; k <= P; k <<= 1)
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1)
-#pragma unroll
-            for (int r = 0; r < WR; ++r) x[r].step(k == P ? 64 : k, j); // (the last merge is ascending in every segment of the row: its direction bit lies outside the slot index)
+    net_from<U, P, 1, WR, 2, 1>(x);
 #pragma unroll
     for (int r = 0; r < WR; ++r) {
         if (live[r]) { // (a sorted row keeps its real keys in slots 0 .. n - 1 of every segment)
-            store_raw<U, W>(a.out, at[r], from_ordered<U, W, KIND>(x[r].k, flip));
-            a.pos[at[r]] = (int64_t)x[r].p;
+            store_raw<U, W>(a.out, at[r], from_ordered<U, W, KIND>(x[r][0].k, flip));
+            a.pos[at[r]] = (int64_t)x[r][0].p;
         }
     }
+}
+
+// Segments of 65 .. 512 keys: the same network with E = P / 64 slots per lane, one segment per wave: partner distances of 64 and
+// more pair two registers of one lane (no exchange at all), the shorter ones go through the lanes as above; a direction bit at or
+// above 64 is a constant of the register index.
+template <typename U, int W, int KIND, int LOGP>
+__global__ __launch_bounds__(256) void sort_wave_big_kernel(const SmallArgs a) {
+    constexpr int P = 1 << LOGP, E = P / 64, WR = E == 2 ? 2 : 1;
+    const int lane = threadIdx.x & 63;
+    const int64_t seg0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * WR;
+    const U flip = a.desc ? KeyBits<U, W>::all : (U)0;
+    WaveSlot<U> x[WR][E];
+#pragma unroll
+    for (int r = 0; r < WR; ++r)
+#pragma unroll
+        for (int e = 0; e < E; ++e) { // (clamped address, no branch around the load)
+            const int il = e * 64 + lane;
+            const bool live = seg0 + r < a.nseg && il < a.n;
+            x[r][e].k = load_raw<U, W>(a.in, live ? (seg0 + r) * a.n + il : 0);
+        }
+#pragma unroll
+    for (int r = 0; r < WR; ++r)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int il = e * 64 + lane;
+            const bool live = seg0 + r < a.nseg && il < a.n;
+            x[r][e].k = live ? to_ordered<U, W, KIND>(x[r][e].k, flip) : ~(U)0; // padding: behind every real key, every real position
+            x[r][e].p = live ? (uint32_t)il : 0x80000000u | (uint32_t)il;
+        }
+    net_from<U, P, E, WR, 2, 1>(x);
+#pragma unroll
+    for (int r = 0; r < WR; ++r)
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int il = e * 64 + lane;
+            if (seg0 + r < a.nseg && il < a.n) {
+                const int64_t at = (seg0 + r) * a.n + il;
+                store_raw<U, W>(a.out, at, from_ordered<U, W, KIND>(x[r][e].k, flip));
+                a.pos[at] = (int64_t)x[r][e].p;
+            }
+        }
 }
 
 // The set of lanes (among those of m) that hold the same 8-bit digit as this lane: eight ballots, each folded into the running set by one
@@ -742,23 +746,18 @@ static int run_sort(const void *in, void *out, int64_t *pos, int64_t nseg, int64
         KF_LAUNCH_CHECK();
         return KF_OK;
     }
-    if (p.small) {
+    if (p.small && n <= kBitonicMax) { // one segment per wave, up to eight slots per lane
         SmallArgs a{in, out, pos, nseg, (int)n, 0, 1, desc};
         while ((1 << a.logp) < n) ++a.logp;
-        if (a.logp < 1) a.logp = 1;
-        const int P = 1 << a.logp;
-        a.spb = P >= 2048 ? 1 : 2048 / P;
-        if ((int64_t)a.spb > nseg) a.spb = (int)nseg;
-        const int E = a.spb * P;
-        int nthr = E / 2;
-        nthr = nthr < 64 ? 64 : (nthr > 1024 ? 1024 : (nthr + 63) / 64 * 64);
-        const size_t lds = Slots<U>::bytes(E);
-        KF_HIP_TRY(hipFuncSetAttribute((const void *)sort_small_kernel<U, W, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)Slots<U>::bytes((int)kSmallMax)));
-        const int64_t grid = (nseg + a.spb - 1) / a.spb;
+        const int wr = a.logp == 7 ? 2 : 1;
+        const int64_t grid = (nseg + 4 * wr - 1) / (4 * wr);
         KF_REQUIRE(grid <= 0x7fffffff, KF_ERR_INDEX_RANGE, "kf_sort: too many segments");
-        KF_PROF("sort_bitonic_lds", st);
-        sort_small_kernel<U, W, KIND><<<(unsigned)grid, nthr, lds, st>>>(a);
+        KF_PROF("sort_bitonic_wave", st);
+        switch (a.logp) {
+        case 7: sort_wave_big_kernel<U, W, KIND, 7><<<(unsigned)grid, 256, 0, st>>>(a); break;
+        case 8: sort_wave_big_kernel<U, W, KIND, 8><<<(unsigned)grid, 256, 0, st>>>(a); break;
+        default: sort_wave_big_kernel<U, W, KIND, 9><<<(unsigned)grid, 256, 0, st>>>(a); break;
+        }
         KF_LAUNCH_CHECK();
         return KF_OK;
     }
