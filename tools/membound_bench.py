@@ -157,7 +157,7 @@ def main():
     H.check(H.lib().kf_memcpy_h2d(a.ptr, keys.ctypes.data, keys.nbytes, None))
     H.device_sync()
     for (nseg, n, tag) in ((4, 1024000, "sort f32 [4, 1024000] (reference's large case)"), (1, 1 << 26, "sort f32 [1, 64Mi]"),
-                           (16384, 4096, "sort f32 [16384, 4096] (radix passes in LDS)"), (1 << 20, 64, "sort f32 [1Mi, 64] (register bitonic)")):
+                           (16384, 4096, "sort f32 [16384, 4096] (radix passes in LDS)"), (1 << 17, 512, "sort f32 [128Ki, 512] (register bitonic, 8 slots per lane)"), (1 << 20, 64, "sort f32 [1Mi, 64] (register bitonic)")):
         need = H.lib().kf_sort_workspace_bytes(H.F32, nseg, n)
         ws = H.DevBuf(max(need, 16))
         ms, k = timed(tag, lambda: H.check(H.lib().kf_sort(H.F32, a.ptr, b.ptr, c.ptr, nseg, n, 0, ws.ptr, need, None)), args.rounds)
