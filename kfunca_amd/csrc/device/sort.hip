@@ -718,7 +718,7 @@ static int run_sort(const void *in, void *out, int64_t *pos, int64_t nseg, int64
 #define KF_BLOCK_RADIX(NW_, IT_)                                                                                                         \
     {                                                                                                                                    \
         const size_t lds = block_radix_lds<NW_, IT_>(sizeof(U));                                                                         \
-        KF_HIP_TRY(hipFuncSetAttribute((const void *)sort_block_radix_kernel<U, W, KIND, NW_, IT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        KF_ENSURE_LDS((sort_block_radix_kernel<U, W, KIND, NW_, IT_>), lds);                                                                 \
         sort_block_radix_kernel<U, W, KIND, NW_, IT_><<<(unsigned)nseg, NW_ * 64, lds, st>>>(a);                                          \
     }
         if (n <= 1024) KF_BLOCK_RADIX(4, 4)
@@ -796,7 +796,7 @@ static int run_sort(const void *in, void *out, int64_t *pos, int64_t nseg, int64
             radix_scan_kernel<<<(unsigned)nseg, 1024, 0, st>>>(cbase, dbase, p.nchunks);
         }
         const size_t lds = (size_t)R_TILE * (sizeof(U) + 4);
-        KF_HIP_TRY(hipFuncSetAttribute((const void *)radix_scatter_kernel<U, W, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        KF_ENSURE_LDS((radix_scatter_kernel<U, W, KIND>), lds);
         radix_scatter_kernel<U, W, KIND><<<(unsigned)grid, R_NT, lds, st>>>(a);
         KF_LAUNCH_CHECK();
     }
