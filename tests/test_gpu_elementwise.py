@@ -97,6 +97,11 @@ def test_mixed_dtypes_and_output_cast():
             want = O.binary(oop, a, b, a_code=ca, b_code=cb)
             assert got.code == O.promote(ca, cb)
             assert np.array_equal(bits(got.get()), bits(want)), (ca, cb, name)
+    for ca, cb in pairs + [(H.F32, H.BF16), (H.F64, H.I8), (H.I32, H.I64)]:  # contiguous, whole groups of eight: the wide mixed-dtype kernel
+        a, b = rand_of(rng, (40, 8, 5), ca), rand_of(rng, (40, 8, 5), cb)
+        for name, (hop, oop) in (("add", OPS["add"]), ("mul", OPS["mul"]), ("sub", OPS["sub"])):
+            got = gpu_binary(hop, Dev(a, ca), Dev(b, cb))
+            assert np.array_equal(bits(got.get()), bits(O.binary(oop, a, b, a_code=ca, b_code=cb))), (ca, cb, name, "wide")
     # provided output of another dtype: result is cast on store (tensor_memory_access.h:26-37)
     a, b = rand_of(rng, (100,), H.F32), rand_of(rng, (100,), H.F32)
     out = gpu_binary(H.EW_ADD, Dev(a), Dev(b), out=Dev.empty((100,), H.I32))
@@ -153,8 +158,8 @@ def test_copy_views_bit_exact():
 
 def test_convert_matrix_and_fill():
     rng = np.random.default_rng(10)
-    for cs in ALL:
-        x0 = rand_of(rng, (33, 7), cs)
+    for cs, shape in [(c, (33, 7)) for c in ALL] + [(c, (37, 8, 3)) for c in ALL]:  # (the second shape: whole groups of eight, the wide kernel)
+        x0 = rand_of(rng, shape, cs)
         for cd in ALL:
             x = x0
             if cd == H.U8 and cs in (H.F16, H.F32, H.F64):

@@ -95,6 +95,13 @@ def main():
     d = H.make_desc([view(c, (big,), H.BF16)], [view(a, (big,), H.F32)])
     ms, k = timed("convert", lambda: H.elementwise(H.EW_COPY, d), args.rounds)
     record("convert f32 -> bf16 256Mi", ms, 6 * big, k)
+    half = big // 2  # mixed dtypes (the runtime-cast kernel; eight elements per lane on contiguous operands since round 5)
+    d = H.make_desc([view(c, (half,), H.F32)], [view(a, (half,), H.F32), view(b, (half,), H.BF16)])
+    ms, k = timed("add mixed", lambda: H.elementwise(H.EW_ADD, d, H.F32), args.rounds)
+    record("add f32 + bf16 -> f32 128Mi (mixed dtypes)", ms, 10 * half, k)
+    d = H.make_desc([view(c, (half,), H.F32)], [view(a, (half,), H.I32)])
+    ms, k = timed("convert i32", lambda: H.elementwise(H.EW_COPY, d), args.rounds)
+    record("convert i32 -> f32 128Mi", ms, 8 * half, k)
     d = H.make_desc([view(c, (big,), H.F32)], [])
     ms, k = timed("fill", lambda: H.elementwise(H.EW_FILL, d, 0, 3.0), args.rounds)
     record("fill f32 256Mi", ms, 4 * big, k)
