@@ -461,6 +461,9 @@ static int make_plan(const kf_iter_desc *d, Plan &p, bool moments = false) {
         int64_t per = (p.R + p.vec - 1) / p.vec;
         p.tx = per >= kRB ? kRB : pow2_floor(per < 1 ? 1 : per);
         if (p.tx < per && p.tx < kRB) p.tx *= 2;
+        // many short rows: four packs per lane instead of one (a quarter of the lanes per row, four times the rows per block): the per-row work -
+        // offset calculation, shuffle tree, the one-lane store - is shared by four times the bytes ([1 Mi rows x 256] f32: 3.6 -> see DESIGN §4)
+        if (p.tx >= 4 && p.tx < kRB && (p.nout * (p.tx / 4) + kRB - 1) / kRB >= target_blocks) p.tx /= 4;
         const int ty = kRB / p.tx;
         const int64_t gx = (p.nout + ty - 1) / ty;
         int64_t ns = 1;
