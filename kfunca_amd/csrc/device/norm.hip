@@ -78,7 +78,7 @@ __device__ __forceinline__ uint4 n_pack(const float (&f)[V]) {
 template <int TPR>
 __device__ __forceinline__ float n_row_sum(float v, float *red) {
 #pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+    for (int m = (TPR < 64 ? TPR : 64) / 2; m > 0; m >>= 1) v += __shfl_xor(v, m, 64); // (TPR < 64: several rows per wave, each in its own lane group)
     if constexpr (TPR > 64) {
         constexpr int NW = TPR / 64;
         const int wid = threadIdx.x >> 6;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const NormArgs a) {
 template <int TPR>
 __device__ __forceinline__ void n_row_sum2(float &s1, float &s2, float (*red)[2][16], int parity) {
 #pragma unroll
-    for (int m = 32; m > 0; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
+    for (int m = (TPR < 64 ? TPR : 64) / 2; m > 0; m >>= 1) { s1 += __shfl_xor(s1, m, 64); s2 += __shfl_xor(s2, m, 64); }
     if constexpr (TPR > 64) {
         constexpr int NW = TPR / 64;
         const int wid = threadIdx.x >> 6;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(TPR < 256 ? 256 : TPR) void norm_bwd_kernel(const N
             }
         }
     } else {
-        __shared__ float slab[RPB][64 * V + 1];
+        __shared__ float slab[RPB][TPR * V + 1];
 #pragma unroll
         for (int p = 0; p < PACKS; ++p) {
             const int64_t c = ((int64_t)p * TPR + tr) * V;
@@ -479,10 +479,14 @@ static NormPlan norm_plan(int dtype, int64_t cols, int64_t ldx, const void *cons
     for (int i = 0; i < nptr; ++i)
         if (ptrs[i] && (uintptr_t)ptrs[i] % 16 != 0) return {0, 0};
     const int64_t npk = cols / V;
+    // rows of up to 32 packs (512 B): 8, 16 or 32 lanes per row, 32 / 16 / 8 rows per block - a whole wave on a 128-byte row left 56 of its 64 lanes idle
+    // (round 5, bf16 [4 Mi, 64]: forward 0.9 TB/s, backward 0.9)
+    for (int t = 8; t <= 32; t *= 2)
+        if (npk <= t && (!bwd || knob_int(KNOB_NORM_BWD_TPR, 0) == 0)) return {t, 1};
     if (bwd) {
         const long forced = knob_int(KNOB_NORM_BWD_TPR, 0); // A/B switch: threads per row (64 | 256 | 512 | 1024)
-        for (int p = 1; p <= 4; p *= 2) // short rows: one wave per row (no barrier), up to 4 packs per lane
-            if (npk <= 64 * p && (forced == 0 || forced == 64)) return {64, p};
+        for (int p = 1; p <= (forced == 64 ? 4 : 2); p *= 2) // short rows: one wave per row (no barrier), up to 2 packs per lane (4 packs without a row ahead:
+            if (npk <= 64 * p && (forced == 0 || forced == 64)) return {64, p}; // bf16 [131072, 2048] 4.2 - 4.4 TB/s against 5.05 with the row across one 256-thread block)
         for (int p = 1; p <= 2; ++p) // longer ones: one pack per lane wherever 1024 threads reach (the fewest registers), two beyond
             for (int t = 256; t <= 1024; t *= 2)
                 if (npk <= (int64_t)t * p && (forced == 0 || forced == t || (p == 2 && t == 1024))) return {t, p};
@@ -507,7 +511,9 @@ static int norm_bwd_blocks(const NormPlan &pl, int64_t rows) { // upper bound (w
 // let three blocks share a CU (768 resident): its last third ran at a third of the bandwidth (3.83 -> 3.48 TB/s).
 template <typename T, int TPR, int PACKS, bool RMS>
 static int norm_bwd_launch(NormArgs &a, hipStream_t st, int &nblk) {
-    constexpr int PF = TPR > 64 ? ((!RMS && sizeof(T) == 2 && TPR == 1024) ? 1 : 2) : 0; // (the 16-bit layer form at 1024 threads has 128 registers: one row ahead fits, two spill)
+    // (1024 threads leave 128 registers: the 16-bit layer form fits one row ahead, two spill; with TWO packs per lane the 16-bit forms fit one (rms) or none (layer) -
+    //  round 5: both had been built with two and ran out of scratch, bf16 [21845, 12288] backward 2.2 - 2.6 TB/s)
+    constexpr int PF = TPR > 64 ? ((sizeof(T) == 2 && TPR == 1024) ? (PACKS == 2 ? (RMS ? 1 : 0) : (RMS ? 2 : 1)) : 2) : 0;
     static int resident = 0;
     if (resident == 0) {
         int per_cu = 0, dev = 0;
@@ -537,6 +543,9 @@ static int norm_check(const char *who, int kind, int dtype, int64_t rows, int64_
 
 #define KF_NORM_DISPATCH(KERNEL, T, PL, ...)                                                     \
     switch ((PL).tpr * 100 + (PL).packs) {                                                       \
+    case 801: KERNEL<T, 8, 1> __VA_ARGS__; break;                                                \
+    case 1601: KERNEL<T, 16, 1> __VA_ARGS__; break;                                              \
+    case 3201: KERNEL<T, 32, 1> __VA_ARGS__; break;                                              \
     case 6401: KERNEL<T, 64, 1> __VA_ARGS__; break;                                              \
     case 6402: KERNEL<T, 64, 2> __VA_ARGS__; break;                                              \
     case 6404: KERNEL<T, 64, 4> __VA_ARGS__; break;                                              \
@@ -547,6 +556,9 @@ static int norm_check(const char *who, int kind, int dtype, int64_t rows, int64_
     }
 #define KF_NORM_DISPATCH_BWD(KERNEL, T, PL, RMS_, ...)                                           \
     switch ((PL).tpr * 100 + (PL).packs) {                                                       \
+    case 801: KERNEL<T, 8, 1, RMS_> __VA_ARGS__; break;                                          \
+    case 1601: KERNEL<T, 16, 1, RMS_> __VA_ARGS__; break;                                        \
+    case 3201: KERNEL<T, 32, 1, RMS_> __VA_ARGS__; break;                                        \
     case 6401: KERNEL<T, 64, 1, RMS_> __VA_ARGS__; break;                                        \
     case 6402: KERNEL<T, 64, 2, RMS_> __VA_ARGS__; break;                                        \
     case 6404: KERNEL<T, 64, 4, RMS_> __VA_ARGS__; break;                                        \

@@ -56,7 +56,8 @@ def test_golden_f32_forward_backward():
 
 
 @pytest.mark.parametrize("code,eps", [(H.BF16, 2.0 ** -7), (H.F16, 2.0 ** -10), (H.F32, 1e-5)])
-@pytest.mark.parametrize("rows,cols", [(3, 8), (70, 512), (33, 2048), (17, 4096), (9, 8192), (5, 16384), (2, 32768), (11, 1000), (6, 12288)])
+@pytest.mark.parametrize("rows,cols", [(3, 8), (70, 512), (33, 2048), (17, 4096), (9, 8192), (5, 16384), (2, 32768), (11, 1000), (6, 12288),
+                                       (1030, 16), (50, 32), (1000, 64), (333, 128), (77, 256), (41, 1536)])  # (8 / 16 / 32 lanes per row: several rows per wave)
 def test_vs_oracle_every_plan(code, eps, rows, cols):
     """Every register-tile plan (one wave per row with 1 / 2 / 4 packs, one block per row with 2..16 packs), the generic kernels
     (row length not a multiple of the pack; rows beyond the backward's tile) and no-weight / no-bias forms, vs the oracle."""
