@@ -1363,6 +1363,56 @@ __global__ __launch_bounds__(W4_NT) void gemm_w4_pair_kernel(const GemmArgs g0, 
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ---- ragged shapes through the matrix kernels (round 5) ---------------------------------------------------------------------------
+// A 16-bit or f32 product whose extents are not whole tiles used to fall to the scalar kernel (4000^3 bf16: 5 ms = 26 TFLOP/s; M = 16 ..
+// 64 rows against 8192 x 8192: 0.7 ms). With caller scratch (kf_gemm_workspace_bytes) the operands are copied into zero-padded images of
+// whole tiles, the tile kernels run on those (zeros add nothing: the valid region carries exactly the tile kernel's sums), and the valid
+// part of C is copied back. Copies move 16 bytes per lane wherever the ragged side happens to be 16-byte aligned.
+template <int ES>
+__global__ __launch_bounds__(256) void gemm_pad_copy_kernel(const char *src, int64_t ld_src, int64_t rows, int64_t cols, char *dst, int64_t cols_p, int64_t total) {
+    constexpr int PER = 16 / ES;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; // one 16-byte piece of the padded image
+    if (i >= total) return;
+    const int64_t per_row = cols_p / PER, r = i / per_row, c0 = (i - r * per_row) * PER;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (r < rows && c0 < cols) {
+        const char *q = src + (r * ld_src + c0) * ES;
+        if (c0 + PER <= cols && ((uintptr_t)q & 15) == 0) {
+            v = *(const uint4 *)q;
+        } else {
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int e = 0; e < PER; ++e)
+                if (c0 + e < cols) {
+                    if constexpr (ES == 2) w[e >> 1] |= (uint32_t)(*(const uint16_t *)(q + 2 * e)) << (16 * (e & 1));
+                    else w[e] = *(const uint32_t *)(q + 4 * e);
+                }
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    *(uint4 *)(dst + i * 16) = v;
+}
+template <int ES>
+__global__ __launch_bounds__(256) void gemm_unpad_copy_kernel(const char *src, int64_t cols_p, char *dst, int64_t ld_dst, int64_t rows, int64_t cols) {
+    constexpr int PER = 16 / ES;
+    const int64_t per_row = (cols + PER - 1) / PER, i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * per_row) return;
+    const int64_t r = i / per_row, c0 = (i - r * per_row) * PER;
+    const uint4 v = *(const uint4 *)(src + (r * cols_p + c0) * ES);
+    char *q = dst + (r * ld_dst + c0) * ES;
+    if (c0 + PER <= cols && ((uintptr_t)q & 15) == 0) {
+        *(uint4 *)q = v;
+    } else {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < PER; ++e)
+            if (c0 + e < cols) {
+                if constexpr (ES == 2) *(uint16_t *)(q + 2 * e) = (uint16_t)(w[e >> 1] >> (16 * (e & 1)));
+                else *(uint32_t *)(q + 4 * e) = w[e];
+            }
+    }
+}
+
 static bool h_fast_ok(int64_t M, int64_t N, int64_t K) { return M % H_BM == 0 && N % H_BN == 0 && K % H_BK == 0 && M > 0 && N > 0 && K > 0; }
 
 } // namespace kf
@@ -1395,6 +1445,35 @@ static int splitk_slices(int dtype, int64_t M, int64_t N, int64_t K) {
     return s;
 }
 
+struct PadPlan {
+    bool use;
+    int64_t Mp, Np, Kp;
+    size_t a_bytes, b_bytes, c_bytes, bias_bytes, inner_bytes, total;
+};
+static inline size_t pad256(size_t x) { return (x + 255) & ~(size_t)255; }
+static PadPlan pad_plan(int dtype, int64_t M, int64_t N, int64_t K) {
+    PadPlan p{};
+    const bool half = dtype == KF_BF16 || dtype == KF_F16;
+    if (!(half || dtype == KF_F32) || M <= 0 || N <= 0 || K <= 0 || knob(KNOB_GEMM_NO_PAD)) return p;
+    if ((double)M * (double)N * (double)K < (double)(1 << 24)) return p; // (below ~256^3 the scalar kernel's one launch is as good as five)
+    const int64_t tm = half ? 128 : 64, tk = half ? 64 : 16;
+    p.Mp = (M + tm - 1) / tm * tm;
+    p.Np = (N + tm - 1) / tm * tm;
+    p.Kp = (K + tk - 1) / tk * tk;
+    if (p.Mp == M && p.Np == N && p.Kp == K) return p; // whole tiles: nothing to pad (operands that are merely misaligned keep the scalar kernel)
+    const size_t es = half ? 2 : 4;
+    p.a_bytes = pad256((size_t)p.Mp * p.Kp * es);
+    p.b_bytes = pad256((size_t)p.Kp * p.Np * es);
+    p.c_bytes = pad256((size_t)p.Mp * p.Np * es);
+    p.bias_bytes = pad256((size_t)p.Np * es);
+    const int sl = splitk_slices(dtype, p.Mp, p.Np, p.Kp);
+    p.inner_bytes = sl > 1 ? pad256((size_t)sl * p.Mp * p.Np * sizeof(float)) : 0;
+    p.total = p.a_bytes + p.b_bytes + p.c_bytes + p.bias_bytes + p.inner_bytes;
+    p.use = true;
+    return p;
+}
+
+
 extern "C" int kf_gemm_workspace_bytes(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, size_t *bytes) {
     KF_REQUIRE(bytes, KF_ERR_INVALID, "kf_gemm_workspace_bytes: null out pointer");
     *bytes = 0;
@@ -1403,6 +1482,7 @@ extern "C" int kf_gemm_workspace_bytes(int dtype, int trans_a, int trans_b, int6
     (void)trans_a; (void)trans_b;
     const int s = splitk_slices(dtype, M, N, K);
     if (s > 1) *bytes = (size_t)s * (size_t)M * (size_t)N * sizeof(float);
+    else if (const PadPlan pp = pad_plan(dtype, M, N, K); pp.use) *bytes = pp.total; // ragged extents: zero-padded images + what the padded product takes
     return KF_OK;
 }
 
@@ -1615,6 +1695,48 @@ static int gemm_impl(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, 
             const unsigned gf = (unsigned)((M * (N / 4) + 255) / 256);
             if (dtype == KF_BF16) gemm_splitk_fold_kernel<true><<<gf, 256, 0, st>>>(g);
             else gemm_splitk_fold_kernel<false><<<gf, 256, 0, st>>>(g);
+            KF_LAUNCH_CHECK();
+        }
+        return KF_OK;
+    }
+    if (const PadPlan pp = pad_plan(dtype, M, N, K); pp.use && workspace && workspace_bytes >= pp.total && (uintptr_t)workspace % 16 == 0 &&
+                                                     !(g.mul || g.add || g.aux || g.c_f32) && K > 0) {
+        const int es = dtype == KF_F32 ? 4 : 2;
+        char *pa = (char *)workspace, *pb = pa + pp.a_bytes, *pc = pb + pp.b_bytes, *pbias = pc + pp.c_bytes, *inner = pbias + pp.bias_bytes;
+        const int64_t ar = trans_a ? K : M, ac = trans_a ? M : K, arp = trans_a ? pp.Kp : pp.Mp, acp = trans_a ? pp.Mp : pp.Kp;
+        const int64_t br = trans_b ? N : K, bc = trans_b ? K : N, brp = trans_b ? pp.Np : pp.Kp, bcp = trans_b ? pp.Kp : pp.Np;
+        bool use_a = false, use_b = false, use_c = false;
+        {
+            KF_PROF("gemm_pad", st);
+            auto pad = [&](const void *src, int64_t ld, int64_t rows, int64_t cols, char *dst, int64_t rows_p, int64_t cols_p) {
+                const int64_t total = rows_p * (cols_p * es / 16);
+                const unsigned gr = (unsigned)((total + 255) / 256);
+                if (es == 2) gemm_pad_copy_kernel<2><<<gr, 256, 0, st>>>((const char *)src, ld, rows, cols, dst, cols_p, total);
+                else gemm_pad_copy_kernel<4><<<gr, 256, 0, st>>>((const char *)src, ld, rows, cols, dst, cols_p, total);
+            };
+            // an operand that already is whole tiles on 16-byte rows is read where it lies (M = 16 rows against a tile-aligned 8192 x 8192 B:
+            // copying B would cost twice the product)
+            const int64_t ldq = 16 / es;
+            use_a = ar == arp && ac == acp && (uintptr_t)A % 16 == 0 && lda % ldq == 0;
+            use_b = br == brp && bc == bcp && (uintptr_t)B % 16 == 0 && ldb % ldq == 0;
+            use_c = M == pp.Mp && N == pp.Np;
+            if (!use_a) pad(A, lda, ar, ac, pa, arp, acp);
+            if (!use_b) pad(B, ldb, br, bc, pb, brp, bcp);
+            if (!use_c && beta != 0.f) pad(C, ldc, M, N, pc, pp.Mp, pp.Np);
+            if (!use_c && epilogue == KF_EPI_BIAS_ROW) pad(bias, N, 1, N, pbias, 1, pp.Np);
+            KF_LAUNCH_CHECK();
+        }
+        const int rc = gemm_impl(dtype, trans_a, trans_b, pp.Mp, pp.Np, pp.Kp, alpha, use_a ? A : (const void *)pa, use_a ? lda : acp, use_b ? B : (const void *)pb,
+                                 use_b ? ldb : bcp, beta, use_c ? C : (void *)pc, use_c ? ldc : pp.Np, epilogue,
+                                 epilogue == KF_EPI_BIAS_ROW ? (use_c ? bias : (const void *)pbias) : nullptr, nullptr, stream, pp.inner_bytes ? inner : nullptr,
+                                 pp.inner_bytes);
+        if (rc != KF_OK) return rc;
+        if (!use_c) {
+            KF_PROF("gemm_pad", st);
+            const int64_t total = M * ((N + 16 / es - 1) / (16 / es));
+            const unsigned gr = (unsigned)((total + 255) / 256);
+            if (es == 2) gemm_unpad_copy_kernel<2><<<gr, 256, 0, st>>>(pc, pp.Np, (char *)C, ldc, M, N);
+            else gemm_unpad_copy_kernel<4><<<gr, 256, 0, st>>>(pc, pp.Np, (char *)C, ldc, M, N);
             KF_LAUNCH_CHECK();
         }
         return KF_OK;

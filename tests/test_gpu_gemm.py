@@ -462,3 +462,45 @@ def test_float_output_behind_16bit_operands(code, eps):
     with pytest.raises(H.KfError) as e:  # float operands have nothing to gain: refused, not ignored
         H.gemm_ex(H.F32, False, False, 64, 64, 64, 1.0, da.ptr, 64, dw.ptr, 64, 0.0, o_dw.ptr, 64, c_f32=True)
     assert e.value.code == H.KF_ERR_INVALID
+
+
+@pytest.mark.parametrize("code,M,N,K", [(H.BF16, 1000, 1000, 1000), (H.F16, 300, 520, 700), (H.BF16, 16, 2048, 2048), (H.BF16, 129, 257, 4100), (H.F32, 500, 300, 260),
+                                        (H.F32, 33, 2000, 1025)])
+def test_ragged_extents_run_on_the_matrix_kernels(code, M, N, K):
+    """Extents that are not whole tiles: with caller scratch the product runs on zero-padded images through the tile kernels (round 5) -
+    every layout, alpha / beta, bias row, a C with a wider leading dimension whose pad columns must stay untouched; same bounds as whole tiles."""
+    rng = np.random.default_rng(M + 3 * N + 7 * K + code)
+    eps = {H.BF16: 2.0 ** -8, H.F16: 2.0 ** -11, H.F32: 2.0 ** -20}[code]
+    a = O.from_float(rng.uniform(-1, 1, (M, K)).astype(np.float32), code)
+    b = O.from_float(rng.uniform(-1, 1, (K, N)).astype(np.float32), code)
+    c = O.from_float(rng.uniform(-1, 1, (M, N)).astype(np.float32), code)
+    bias = O.from_float(rng.uniform(-1, 1, (N,)).astype(np.float32), code)
+    want = f64(a, code) @ f64(b, code)
+    mag = np.abs(f64(a, code)) @ np.abs(f64(b, code))
+    assert H.gemm_workspace_bytes(code, False, False, M, N, K) > 0
+    for ta in (False, True):
+        for tb in (False, True):
+            sa, sb = (np.ascontiguousarray(a.T) if ta else a), (np.ascontiguousarray(b.T) if tb else b)
+            H.profile_reset()
+            H.profile_enable(True)
+            got = f64(run_gemm(code, sa, sb, ta, tb), code)
+            H.profile_enable(False)
+            names = set(H.profile_results())
+            assert "gemm_pad" in names and "gemm_generic" not in names and any("mfma" in n for n in names), names
+            assert (np.abs(got - want) <= 2 * eps * np.abs(want) + 2 * eps * mag + 1e-30).all(), (ta, tb)
+    want_e = 0.5 * want + 2.0 * f64(c, code) + f64(bias, code)[None, :]
+    got = f64(run_gemm(code, a, b, alpha=0.5, beta=2.0, c=c.copy(), bias=bias), code)
+    assert (np.abs(got - want_e) <= 2 * eps * np.abs(want_e) + 2 * eps * (mag + 4) + 1e-30).all()
+    ldc = N + 3
+    cp = np.full((M, ldc), 7.0, dtype=np.float32)
+    cpad = O.from_float(cp, code)
+    da, db, dc = H.DevBuf.from_numpy(a), H.DevBuf.from_numpy(b), H.DevBuf.from_numpy(cpad)
+    need = H.gemm_workspace_bytes(code, False, False, M, N, K)
+    ws = H.DevBuf(need)
+    H.gemm(code, False, False, M, N, K, 1.0, da.ptr, K, db.ptr, N, 0.0, dc.ptr, ldc, H.EPI_NONE, None, ws.ptr, need)
+    H.device_sync()
+    out = f64(dc.to_numpy((M, ldc), cpad.dtype), code)
+    assert (out[:, N:] == 7.0).all()
+    assert (np.abs(out[:, :N] - want) <= 2 * eps * np.abs(want) + 2 * eps * mag + 1e-30).all()
+    with H.knobs(KF_GEMM_NO_PAD="1"):
+        assert H.gemm_workspace_bytes(code, False, False, M, N, K) == 0
