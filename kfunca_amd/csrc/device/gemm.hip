@@ -1419,10 +1419,13 @@ static bool h_fast_ok(int64_t M, int64_t N, int64_t K) { return M % H_BM == 0 &&
 
 using namespace kf;
 
-// the 256-tile kernel when its grid covers most of the chip (256 CUs, one 8-wave block each); smaller problems get four
-// times as many 128-tile blocks instead (2048^3: 64 tiles of 256^2 would leave three quarters of the CUs idle)
+// the 256-tile kernel when its grid covers a good part of the chip (256 CUs, one block each); smaller problems get four
+// times as many 128-tile blocks instead (2048^3: 64 tiles of 256^2 would leave three quarters of the CUs idle).
+// Where the line is (round 5, random bf16 operands, back to back, KF_GEMM_H256_MIN): 64 tiles 394 vs 721 TFLOP/s for the 128-tile kernel,
+// 81 tiles 573 vs 595, 100 tiles 592-610 vs 532-592, 121 tiles 720-752 vs 627-656, 128 tiles 816-850 vs 704-724, 144 tiles (3072^3) 886-923
+// vs 599 - the line had stood at 160 tiles.
 static bool h256_ok(int64_t M, int64_t N, int64_t K) {
-    return M % G_BM == 0 && N % G_BN == 0 && K % G_BK == 0 && M > 0 && N > 0 && K > 0 && (M / G_BM) * (N / G_BN) >= 160 &&
+    return M % G_BM == 0 && N % G_BN == 0 && K % G_BK == 0 && M > 0 && N > 0 && K > 0 && (M / G_BM) * (N / G_BN) >= knob_int(KNOB_GEMM_H256_MIN, 100) &&
            !knob(KNOB_GEMM_128);
 }
 
