@@ -7,7 +7,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from kfunca_amd import hip_abi as H
 H.set_device(0)
 rng = np.random.default_rng(0)
-shapes = [(2560, 2560, 2560), (2816, 2816, 2816), (2048, 4096, 4096), (3072, 3072, 3072), (3072, 3072, 8192), (3328, 3328, 3328), (3584, 3584, 3584), (2048, 2048, 2048), (2304, 2304, 4096)]
+shapes = [(1024, 8192, 8192), (8192, 1024, 8192), (512, 8192, 8192), (768, 8192, 4096), (1280, 5120, 5120), (1536, 6144, 6144), (2560, 2560, 2560), (2816, 2816, 2816), (2048, 4096, 4096), (3072, 3072, 3072), (3072, 3072, 8192), (3328, 3328, 3328), (3584, 3584, 3584), (2048, 2048, 2048), (2304, 2304, 4096)]
 mx = max(max(m * k, k * n, m * n) for m, n, k in shapes)
 src = rng.uniform(-1, 1, mx).astype(np.float32)
 u = src.view(np.uint32)
