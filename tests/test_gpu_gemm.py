@@ -328,13 +328,14 @@ def test_split_k_skinny_products(code, eps):
         assert H.gemm_workspace_bytes(code, False, False, M, N, K) == 0
 
 
+@pytest.mark.parametrize("Kp", [2560, 1792])  # 16 x 10 = 160 tiles each, and 16 x 7 = 112: above the 100-tile line of the 256-tile kernels since round 5
 @pytest.mark.parametrize("code", [H.BF16, H.F16])
-def test_grouped_backward_pair_is_the_two_products(code):
+def test_grouped_backward_pair_is_the_two_products(code, Kp):
     """kf_gemm_grouped on the backward pair of a linear layer (dA = dC W^T, dW = A^T dC) at a shape of the 4-wave 256-tile kernel: ONE
     launch (label ..._pair), results BIT-identical to the two separate kf_gemm launches (same per-tile arithmetic, another grid), with
     alpha / beta; any other list of problems is the per-problem calls in order."""
     rng = np.random.default_rng(123 + code)
-    M, N, Kp = 4096, 4096, 2560  # dA: [M, K'] = dC[M, N] W[K', N]^T -> 16 x 10 tiles; dW: [K', N] = A^T dC -> 10 x 16 tiles (>= 160 each)
+    M, N = 4096, 4096  # dA: [M, K'] = dC[M, N] W[K', N]^T -> 16 x (K' / 256) tiles; dW: [K', N] = A^T dC -> the same count
     a = O.from_float(rng.uniform(-1, 1, (M, Kp)).astype(np.float32), code)     # A  [M, K']
     w = O.from_float(rng.uniform(-1, 1, (Kp, N)).astype(np.float32), code)     # W  [K', N]
     g = O.from_float(rng.uniform(-1, 1, (M, N)).astype(np.float32), code)      # dC [M, N]
