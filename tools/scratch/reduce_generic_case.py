@@ -14,7 +14,10 @@ def contig(shape):
     return list(reversed(st))
 def V(buf, shape, code): return H.View(buf.ptr, shape, contig(shape), code)
 R = 16384
-cases = [("sum(1) bf16 [16384,16384]", (R, R), 1, H.BF16, H.RED_SUM), ("sum(0) bf16 [16384,16384]", (R, R), 0, H.BF16, H.RED_SUM),
+cases = [("sum(1) f32 [32Mi, 8] (R = 8)", (1 << 25, 8), 1, H.F32, H.RED_SUM), ("sum(1) f32 [4Mi, 64]", (1 << 22, 64), 1, H.F32, H.RED_SUM), ("sum(1) bf16 [8Mi, 32]", (1 << 23, 32), 1, H.BF16, H.RED_SUM),
+         ("sum(0) f32 [16, 16Mi] (R = 16)", (16, 1 << 24), 0, H.F32, H.RED_SUM), ("sum(0) f32 [4, 4096, 4096] (R = 4)", (4, 4096, 4096), 0, H.F32, H.RED_SUM), ("sum(1) f32 [4096, 3, 4096] (middle, R = 3)", (4096, 3, 4096), 1, H.F32, H.RED_SUM),
+         ("mean(0) bf16 [2, 128Mi]", (2, 1 << 27), 0, H.BF16, H.RED_MEAN),
+         ("sum(1) bf16 [16384,16384]", (R, R), 1, H.BF16, H.RED_SUM), ("sum(0) bf16 [16384,16384]", (R, R), 0, H.BF16, H.RED_SUM),
          ("sum(1) f16 [16384,16384]", (R, R), 1, H.F16, H.RED_SUM),
          ("sum(1) i32 [16384,16384]", (R, R), 1, H.I32, H.RED_SUM), ("sum(0) i64 [8192,16384]", (8192, R), 0, H.I64, H.RED_SUM),
          ("sum(1) f64 [8192,16384]", (8192, R), 1, H.F64, H.RED_SUM), ("mean(1) f32 [16384,16384]", (R, R), 1, H.F32, H.RED_MEAN),
