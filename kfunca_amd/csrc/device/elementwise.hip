@@ -363,6 +363,21 @@ __global__ __launch_bounds__(kBlock) void ew_transpose_kernel(const TransArgs a)
     }
 }
 
+// Block -> tile of the tiled transposes. Blocks go to the eight XCDs round-robin. SD x SD consecutive blocks of ONE XCD take the tiles of a super-tile whose
+// rows are 1 KiB on both sides (4 x 4 tiles of 4-byte elements, 8 x 8 of 2-byte ones): what an XCD's L2 sees of both matrices within a short time is whole
+// 1-KiB row pieces instead of lone 256- / 128-byte ones at the matrices' row pitch. Round 5, 16384^2: f32 0.42-0.46 -> 0.38-0.40 ms, bf16 0.31 -> 0.21 (4 x 4: 0.24).
+template <int ES>
+__device__ __forceinline__ void trans_tile_of(uint32_t tiles0, uint32_t tiles1, uint32_t rem, uint32_t &t0, uint32_t &t1) {
+    t1 = rem / tiles0;
+    t0 = rem - t1 * tiles0;
+    constexpr uint32_t SL = ES == 4 ? 2 : 3, SD = 1u << SL, SN = SD * SD;
+    if ((tiles0 & (SD - 1)) == 0 && (tiles1 & (SD - 1)) == 0 && ((tiles0 * tiles1) & (8 * SN - 1)) == 0) {
+        const uint32_t x = rem & 7, q = rem >> 3, super = (q / SN) * 8 + x, in = q & (SN - 1), s0 = tiles0 >> SL;
+        t0 = (super % s0) * SD + (in & (SD - 1));
+        t1 = (super / s0) * SD + (in >> SL);
+    }
+}
+
 // The same tile with 16-byte global accesses on BOTH sides (4- and 2-byte elements, whole tiles, 16-byte aligned rows): a lane
 // loads one pack of V = 16 / sizeof(U) consecutive elements of an input row, scatters it into the tile with V LDS stores,
 // then gathers V elements of one tile COLUMN (V LDS loads) into the pack it stores to the output row. One tile per block.
@@ -373,16 +388,8 @@ __global__ __launch_bounds__(kBlock) void ew_transpose_vec_kernel(const TransArg
     __shared__ U tile[TD][TD + (sizeof(U) >= 4 ? 1 : 2)];
     const uint32_t blk = blockIdx.x;
     const uint32_t bt = blk / (a.tiles0 * a.tiles1), rem = blk - bt * (a.tiles0 * a.tiles1);
-    uint32_t t1 = rem / a.tiles0, t0 = rem - t1 * a.tiles0;
-    // Blocks go to the eight XCDs round-robin. SD x SD consecutive blocks of ONE XCD take the tiles of a super-tile whose rows are 1 KiB on both sides
-    // (4 x 4 tiles of 4-byte elements, 8 x 8 of 2-byte ones): what an XCD's L2 sees of both matrices within a short time is whole 1-KiB row pieces instead
-    // of lone 256- / 128-byte ones at the matrices' row pitch. Round 5, 16384^2: f32 0.42-0.46 -> 0.38-0.40 ms, bf16 0.31 -> 0.21 (4 x 4: 0.24).
-    constexpr uint32_t SL = sizeof(U) == 4 ? 2 : 3, SD = 1u << SL, SN = SD * SD;
-    if ((a.tiles0 & (SD - 1)) == 0 && (a.tiles1 & (SD - 1)) == 0 && ((a.tiles0 * a.tiles1) & (8 * SN - 1)) == 0) {
-        const uint32_t x = rem & 7, s = rem >> 3, super = (s / SN) * 8 + x, in = s & (SN - 1), s0 = a.tiles0 >> SL;
-        t0 = (super % s0) * SD + (in & (SD - 1));
-        t1 = (super / s0) * SD + (in >> SL);
-    }
+    uint32_t t0, t1;
+    trans_tile_of<sizeof(U)>(a.tiles0, a.tiles1, rem, t0, t1);
     uint32_t boff[2];
     a.bc.get(bt, boff);
     const uint32_t i0 = t0 * TD, j0 = t1 * TD;
@@ -402,6 +409,53 @@ __global__ __launch_bounds__(kBlock) void ew_transpose_vec_kernel(const TransArg
 #pragma unroll
         for (int e = 0; e < V; ++e) p.v[e] = tile[g * V + e][r];
         *(Pack<U, V> *)(a.out + boff[0] + (size_t)(j0 + r) * a.out_s1 + (size_t)(i0 + g * V) * sizeof(U)) = p;
+    }
+}
+
+// out = op(x, y) where ONE operand is read along a dim other than the output's contiguous one (x + y.permute(1, 0)): the transposed operand
+// goes through the LDS tile exactly like the copy above, the straight one is read in the store phase, 16 bytes per lane on every side.
+// (Round 5: the strided kernel read that operand 4 bytes per lane at the row pitch: f32 [4096, 8192] 1.7 TB/s.)
+struct TransBinArgs {
+    const char *tin, *sin; // the transposed operand, the straight one
+    char *out;
+    uint32_t n0, n1;
+    uint32_t tin_s0, out_s1, sin_s1; // byte strides: transposed operand along dim 0; output and straight operand along dim j
+    uint32_t tiles0, tiles1, nbatch;
+    int op, t_first;                 // t_first: the transposed operand is the FIRST input of the operator
+    OffsetCalc<3> bc;                // batch dims: [0] = out bytes, [1] = transposed operand, [2] = straight operand
+};
+template <typename T>
+__global__ __launch_bounds__(kBlock) void ew_transpose_binary_kernel(const TransBinArgs a) {
+    using A = typename Acc<T>::type;
+    constexpr int TD = 64, V = 16 / (int)sizeof(T), G = TD / V;
+    __shared__ T tile[TD][TD + (sizeof(T) >= 4 ? 1 : 2)];
+    const uint32_t blk = blockIdx.x;
+    const uint32_t bt = blk / (a.tiles0 * a.tiles1), rem = blk - bt * (a.tiles0 * a.tiles1);
+    uint32_t t0, t1;
+    trans_tile_of<sizeof(T)>(a.tiles0, a.tiles1, rem, t0, t1);
+    uint32_t boff[3];
+    a.bc.get(bt, boff);
+    const uint32_t i0 = t0 * TD, j0 = t1 * TD;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < TD * G / kBlock; ++k) {
+        const int id = t + k * kBlock, r = id / G, g = id % G;
+        const Pack<T, V> p = *(const Pack<T, V> *)(a.tin + boff[1] + (size_t)(i0 + r) * a.tin_s0 + (size_t)(j0 + g * V) * sizeof(T));
+#pragma unroll
+        for (int e = 0; e < V; ++e) tile[r][g * V + e] = p.v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TD * G / kBlock; ++k) {
+        const int id = t + k * kBlock, r = id / G, g = id % G;
+        const Pack<T, V> sp = *(const Pack<T, V> *)(a.sin + boff[2] + (size_t)(j0 + r) * a.sin_s1 + (size_t)(i0 + g * V) * sizeof(T));
+        Pack<T, V> o;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const A x = to_acc<T>(tile[g * V + e][r]), y = to_acc<T>(sp.v[e]);
+            o.v[e] = from_acc<T>(a.t_first ? apply_op<A>(a.op, x, y) : apply_op<A>(a.op, y, x));
+        }
+        *(Pack<T, V> *)(a.out + boff[0] + (size_t)(j0 + r) * a.out_s1 + (size_t)(i0 + g * V) * sizeof(T)) = o;
     }
 }
 
@@ -538,6 +592,59 @@ static int launch_same(const kf_iter_desc *d, int op, uint64_t fill_bits, hipStr
                     const int grid = (int)(total < 256 * 16 ? total : 256 * 16);
                     ew_transpose_kernel<T><<<grid, kBlock, 0, st>>>(t);
                 }
+                KF_LAUNCH_CHECK();
+                return KF_OK;
+            }
+        }
+    }
+    if constexpr (MODE == 0 && NIN == 2 && (sizeof(T) == 4 || sizeof(T) == 2)) { // one operand transposed against the output: the LDS-tiled binary kernel
+        const int64_t es = sizeof(T);
+        int tt = 0, j = -1;
+        for (int t = 1; t <= 2 && d->ndim >= 2 && d->stride_bytes[0][0] == es; ++t)
+            if (d->stride_bytes[t][0] != es && d->stride_bytes[3 - t][0] == es && d->shape[0] % 64 == 0)
+                for (int i = 1; i < d->ndim && j < 0; ++i)
+                    if (d->stride_bytes[t][i] == es && d->shape[i] % 64 == 0) { tt = t; j = i; }
+        if (j > 0 && d->data[tt] != d->data[0]) { // (an output that IS the transposed operand keeps the element-by-element kernel)
+            const int ss = 3 - tt;
+            TransBinArgs t;
+            memset(&t, 0, sizeof(t));
+            t.tin = (const char *)d->data[tt];
+            t.sin = (const char *)d->data[ss];
+            t.out = (char *)d->data[0];
+            t.n0 = (uint32_t)d->shape[0];
+            t.n1 = (uint32_t)d->shape[j];
+            t.tin_s0 = (uint32_t)d->stride_bytes[tt][0];
+            t.out_s1 = (uint32_t)d->stride_bytes[0][j];
+            t.sin_s1 = (uint32_t)d->stride_bytes[ss][j];
+            t.tiles0 = t.n0 / 64;
+            t.tiles1 = t.n1 / 64;
+            t.op = op;
+            t.t_first = tt == 1;
+            kf_iter_desc bd;
+            memset(&bd, 0, sizeof(bd));
+            bd.ntensors = 3;
+            bd.noutputs = 1;
+            int nb = 0;
+            int64_t nbatch = 1;
+            bool ok = d->stride_bytes[tt][0] % 16 == 0 && d->stride_bytes[tt][0] > 0 && d->stride_bytes[0][j] % 16 == 0 && d->stride_bytes[ss][j] % 16 == 0 &&
+                      d->stride_bytes[0][j] > 0 && d->stride_bytes[ss][j] > 0 && (uintptr_t)t.tin % 16 == 0 && (uintptr_t)t.sin % 16 == 0 && (uintptr_t)t.out % 16 == 0;
+            for (int i = 1; i < d->ndim; ++i) {
+                if (i == j) continue;
+                bd.shape[nb] = d->shape[i];
+                bd.stride_bytes[0][nb] = d->stride_bytes[0][i];
+                bd.stride_bytes[1][nb] = d->stride_bytes[tt][i];
+                bd.stride_bytes[2][nb] = d->stride_bytes[ss][i];
+                if (d->stride_bytes[0][i] % 16 || d->stride_bytes[tt][i] % 16 || d->stride_bytes[ss][i] % 16) ok = false;
+                nbatch *= d->shape[i];
+                ++nb;
+            }
+            if (nb == 0) { bd.shape[0] = 1; nb = 1; }
+            bd.ndim = nb;
+            int three[3] = {0, 1, 2};
+            const int64_t total = (int64_t)t.tiles0 * t.tiles1 * nbatch;
+            if (ok && total < 0x7fffffffLL && total >= 64 && OffsetCalc<3>::build(t.bc, &bd, three, 1)) {
+                t.nbatch = (uint32_t)nbatch;
+                ew_transpose_binary_kernel<T><<<(unsigned)total, kBlock, 0, st>>>(t);
                 KF_LAUNCH_CHECK();
                 return KF_OK;
             }

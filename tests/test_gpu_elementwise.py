@@ -109,6 +109,27 @@ def test_mixed_dtypes_and_output_cast():
     assert np.array_equal(out.get(), want)
 
 
+def test_binary_with_a_transposed_operand():
+    """x (op) y.T and y.T (op) x through the LDS-tiled binary kernel (whole 64-tiles, with and without batch dims, non-commutative
+    operators in both operand orders), bit-exact; ragged shapes and a transposed operand that is also the output keep the strided kernel."""
+    rng = np.random.default_rng(81)
+    for code in (H.F32, H.BF16, H.F16, H.I32):
+        for shape, perm in (((512, 1024), (1, 0)), ((3, 256, 128), (0, 2, 1)), ((2, 2, 128, 192), (0, 1, 3, 2)), ((192, 3, 128), (2, 1, 0)), ((70, 130), (1, 0))):
+            yb = rand_of(rng, shape, code)
+            yt = yb.transpose(perm)
+            x = rand_of(rng, yt.shape, code)
+            if code == H.I32:
+                x = np.where(x == 0, 3, x).astype(x.dtype)
+                yb = np.where(yb == 0, 5, yb).astype(yb.dtype)
+                yt = yb.transpose(perm)
+            for name in ("add", "sub", "div"):
+                hop, oop = OPS[name]
+                got = gpu_binary(hop, Dev(x, code), Dev(yt, code, base=yb)).get()
+                assert np.array_equal(bits(got), bits(O.binary(oop, x, np.ascontiguousarray(yt), a_code=code, b_code=code))), (code, shape, perm, name, "x op yT")
+                got = gpu_binary(hop, Dev(yt, code, base=yb), Dev(x, code)).get()
+                assert np.array_equal(bits(got), bits(O.binary(oop, np.ascontiguousarray(yt), x, a_code=code, b_code=code))), (code, shape, perm, name, "yT op x")
+
+
 def test_vectorised_broadcast_paths():
     rng = np.random.default_rng(8)
     for code in (H.F32, H.BF16, H.F64):
