@@ -69,20 +69,81 @@ template <typename T> __device__ __forceinline__ void ia_st(T *p, float v) { *p 
 template <> __device__ __forceinline__ void ia_st<bf16_t>(bf16_t *p, float v) { *p = f32_to_bf16(v); }
 template <> __device__ __forceinline__ void ia_st<f16_t>(f16_t *p, float v) { *p = f32_to_f16(v); }
 
-__global__ __launch_bounds__(256) void index_wrap_kernel(const int64_t *idx, int64_t n, int64_t nrows, int64_t *out) {
+template <typename K>
+__global__ __launch_bounds__(256) void index_wrap_kernel(const int64_t *idx, int64_t n, int64_t nrows, K *out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) { const int64_t r = idx[i]; out[i] = r < 0 ? r + nrows : r; }
+    if (i < n) { const int64_t r = idx[i]; out[i] = (K)(r < 0 ? r + nrows : r); }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void index_add_sorted_kernel(const int64_t *key, const int64_t *pos, int64_t n, const T *src, int64_t cols,
+// One wave per run of equal destination rows, rows moved as 16-byte packs (round 5; rows of whole packs on 16-byte boundaries): the run's
+// positions are fetched 64 at a time into the lanes and handed round with readlane, a lane keeps the f32 sums of up to PACKS packs of the
+// row (a wider row is walked in column blocks), the run's rows are added in input order - the element-per-lane kernel below adds in the
+// same order, so the two agree bit for bit. bf16 [32768 x 4096] into 128256 rows: 0.44 -> see DESIGN §4 (2-byte loads, the run re-read per
+// 256-column chunk).
+template <typename T, typename K, int PACKS>
+__global__ __launch_bounds__(256) void index_add_sorted_vec_kernel(const K *key, const int64_t *pos, int64_t n, const T *src, int64_t cols, T *dst) {
+    constexpr int V = 16 / (int)sizeof(T);
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (j >= n) return;
+    const K k = key[j];
+    if (j > 0 && key[j - 1] == k) return; // not a run start
+    const int64_t npk = cols / V;
+    for (int64_t b0 = 0; b0 < npk; b0 += 64 * PACKS) { // column block: PACKS packs per lane
+        float acc[PACKS][V];
+#pragma unroll
+        for (int q = 0; q < PACKS; ++q)
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[q][e] = 0.f;
+        for (int64_t base = j;; base += 64) { // the run, 64 rows at a time
+            const int64_t jj = base + lane;
+            const bool same = jj < n && key[jj] == k;
+            const uint64_t m = __ballot(same);
+            const int cnt = m == ~0ull ? 64 : __builtin_ctzll(~m); // leading rows of this chunk that belong to the run
+            const int64_t p = same ? pos[jj] : 0;
+            for (int r = 0; r < cnt; ++r) {
+                const int64_t pr = ((int64_t)__builtin_amdgcn_readlane((int)(p >> 32), r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)p, r);
+                const uint4 *row = (const uint4 *)(src + pr * cols);
+                uint4 raw[PACKS];
+#pragma unroll
+                for (int q = 0; q < PACKS; ++q) {
+                    const int64_t c = b0 + (int64_t)q * 64 + lane;
+                    raw[q] = row[c < npk ? c : npk - 1]; // (clamped, no branch around the load)
+                }
+#pragma unroll
+                for (int q = 0; q < PACKS; ++q) {
+                    T t[V];
+                    __builtin_memcpy(t, &raw[q], 16);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[q][e] += ia_ld(&t[e]);
+                }
+            }
+            if (cnt < 64) break;
+        }
+#pragma unroll
+        for (int q = 0; q < PACKS; ++q) {
+            const int64_t c = b0 + (int64_t)q * 64 + lane;
+            if (c < npk) {
+                T t[V];
+#pragma unroll
+                for (int e = 0; e < V; ++e) ia_st(&t[e], acc[q][e]);
+                uint4 o;
+                __builtin_memcpy(&o, t, 16);
+                ((uint4 *)(dst + (int64_t)k * cols))[c] = o;
+            }
+        }
+    }
+}
+
+template <typename T, typename K>
+__global__ __launch_bounds__(256) void index_add_sorted_kernel(const K *key, const int64_t *pos, int64_t n, const T *src, int64_t cols,
                                                                int64_t nrows, T *dst) {
     const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (j >= n) return;
-    const int64_t k = key[j];
+    const K k = key[j];
     if (j > 0 && key[j - 1] == k) return; // not a run start
-    const int64_t r = k; // already wrapped
+    const int64_t r = (int64_t)k; // already wrapped
     for (int64_t c0 = 0; c0 < cols; c0 += 64 * 4) { // 4 columns per lane per sweep, the run re-walked per column chunk
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int64_t jj = j; jj < n && key[jj] == k; ++jj) {
@@ -148,21 +209,40 @@ extern "C" int kf_index_add(int dtype, const int64_t *idx, int64_t n, const void
     KF_REQUIRE((n + 3) / 4 <= 0x7fffffffLL, KF_ERR_INDEX_RANGE, "kf_index_add: too many indices for one launch");
     hipStream_t st = as_stream(stream);
     char *ws = (char *)workspace;
-    int64_t *wrapped = (int64_t *)ws, *sorted = (int64_t *)(ws + ia_align((size_t)n * 8)), *pos = (int64_t *)(ws + 2 * ia_align((size_t)n * 8));
+    void *wrapped = ws, *sorted = ws + ia_align((size_t)n * 8);
+    int64_t *pos = (int64_t *)(ws + 2 * ia_align((size_t)n * 8));
     void *sort_ws = ws + 3 * ia_align((size_t)n * 8);
+    // rows are numbered below 2^31 wherever a 32-bit key can hold them: four radix passes instead of eight (bf16 embedding backward, 32768 tokens:
+    // the sort 0.133 -> see DESIGN §4)
+    const bool k32 = nrows <= 0x7fffffffLL;
     {
         KF_PROF("index_wrap", st);
-        index_wrap_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(idx, n, nrows, wrapped);
+        if (k32) index_wrap_kernel<int32_t><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(idx, n, nrows, (int32_t *)wrapped);
+        else index_wrap_kernel<int64_t><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(idx, n, nrows, (int64_t *)wrapped);
         KF_LAUNCH_CHECK();
     }
-    const size_t sws = kf_sort_workspace_bytes(KF_I64, 1, n);
-    int rc = kf_sort(KF_I64, wrapped, sorted, pos, 1, n, 0, sws ? sort_ws : nullptr, sws, stream); // stable: equal rows keep input order
+    const int kcode = k32 ? KF_I32 : KF_I64;
+    const size_t sws = kf_sort_workspace_bytes(kcode, 1, n);
+    int rc = kf_sort(kcode, wrapped, sorted, pos, 1, n, 0, sws ? sort_ws : nullptr, sws, stream); // stable: equal rows keep input order
     if (rc != KF_OK) return rc;
     const unsigned grid = (unsigned)((n + 3) / 4);
     KF_PROF("index_add_sorted", st);
-    if (dtype == KF_F32) index_add_sorted_kernel<float><<<grid, 256, 0, st>>>(sorted, pos, n, (const float *)src, cols, nrows, (float *)dst);
-    else if (dtype == KF_BF16) index_add_sorted_kernel<bf16_t><<<grid, 256, 0, st>>>(sorted, pos, n, (const bf16_t *)src, cols, nrows, (bf16_t *)dst);
-    else index_add_sorted_kernel<f16_t><<<grid, 256, 0, st>>>(sorted, pos, n, (const f16_t *)src, cols, nrows, (f16_t *)dst);
+    const int es = dtype == KF_F32 ? 4 : 2;
+    const bool vec = (cols * es) % 16 == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0;
+    const int64_t npk = cols * es / 16;
+#define KF_IA(T_, K_)                                                                                                                              \
+    {                                                                                                                                              \
+        if (!vec) index_add_sorted_kernel<T_, K_><<<grid, 256, 0, st>>>((const K_ *)sorted, pos, n, (const T_ *)src, cols, nrows, (T_ *)dst);        \
+        else if (npk <= 64) index_add_sorted_vec_kernel<T_, K_, 1><<<grid, 256, 0, st>>>((const K_ *)sorted, pos, n, (const T_ *)src, cols, (T_ *)dst); \
+        else if (npk <= 128) index_add_sorted_vec_kernel<T_, K_, 2><<<grid, 256, 0, st>>>((const K_ *)sorted, pos, n, (const T_ *)src, cols, (T_ *)dst); \
+        else if (npk <= 256) index_add_sorted_vec_kernel<T_, K_, 4><<<grid, 256, 0, st>>>((const K_ *)sorted, pos, n, (const T_ *)src, cols, (T_ *)dst); \
+        else index_add_sorted_vec_kernel<T_, K_, 8><<<grid, 256, 0, st>>>((const K_ *)sorted, pos, n, (const T_ *)src, cols, (T_ *)dst);             \
+    }
+#define KF_IA_K(T_) \
+    if (k32) KF_IA(T_, int32_t) else KF_IA(T_, int64_t)
+    if (dtype == KF_F32) { KF_IA_K(float) } else if (dtype == KF_BF16) { KF_IA_K(bf16_t) } else { KF_IA_K(f16_t) }
+#undef KF_IA_K
+#undef KF_IA
     KF_LAUNCH_CHECK();
     return KF_OK;
 }
