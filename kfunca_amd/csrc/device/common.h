@@ -114,4 +114,8 @@ int ensure_dynamic_lds(const void *kernel, int bytes);
         if (rc_ != KF_OK) return rc_;                                                     \
     } while (0)
 
+// kf_sort with a promise about the keys (sort.hip)
+int sort_with_key_bits(int dtype, const void *keys_in, void *keys_out, int64_t *pos_out, int64_t nseg, int64_t n, int descending, void *workspace,
+                       size_t workspace_bytes, void *stream, int key_bits);
+
 } // namespace kf

@@ -223,7 +223,9 @@ extern "C" int kf_index_add(int dtype, const int64_t *idx, int64_t n, const void
     }
     const int kcode = k32 ? KF_I32 : KF_I64;
     const size_t sws = kf_sort_workspace_bytes(kcode, 1, n);
-    int rc = kf_sort(kcode, wrapped, sorted, pos, 1, n, 0, sws ? sort_ws : nullptr, sws, stream); // stable: equal rows keep input order
+    int bits = 1;
+    while (bits < 63 && ((int64_t)1 << bits) < nrows) ++bits; // wrapped rows are below nrows: the key bytes above that are the same in every key
+    int rc = sort_with_key_bits(kcode, wrapped, sorted, pos, 1, n, 0, sws ? sort_ws : nullptr, sws, stream, bits); // stable: equal rows keep input order
     if (rc != KF_OK) return rc;
     const unsigned grid = (unsigned)((n + 3) / 4);
     KF_PROF("index_add_sorted", st);

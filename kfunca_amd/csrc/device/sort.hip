@@ -72,7 +72,7 @@ struct SmallArgs {
     void *out;
     int64_t *pos;
     int64_t nseg;
-    int n, logp, spb, desc;
+    int n, logp, npass, desc; // npass: radix passes to run (the key bytes that can differ between keys; all of them unless the caller knows better)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NW * 64) void sort_block_radix_kernel(const SmallAr
     for (int r = 0; r < ITEMS; ++r)
         key[r] = (int)pos[r] < a.n ? to_ordered<U, W, KIND>(key[r], flip) : KeyBits<U, W>::all; // (padding: behind every real key)
 #pragma unroll 1
-    for (int pass = 0; pass < W; ++pass) {
+    for (int pass = 0; pass < a.npass; ++pass) {
         const int shift = 8 * pass;
         for (int x = tid; x < NW * 256; x += NT) (&cnt[0][0])[x] = 0;
         __syncthreads();
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(NW * 64) void sort_block_radix_kernel(const SmallAr
             spos[lp] = (uint16_t)pos[r];
         }
         __syncthreads();
-        if (pass + 1 < W) {
+        if (pass + 1 < a.npass) {
 #pragma unroll
             for (int r = 0; r < ITEMS; ++r) {
                 const int i = w * WK + r * 64 + lane;
@@ -710,9 +710,10 @@ static SortPlan make_plan(int dtype, int64_t nseg, int64_t n) {
 }
 
 template <typename U, int W, int KIND>
-static int run_sort(const void *in, void *out, int64_t *pos, int64_t nseg, int64_t n, int desc, const SortPlan &p, char *ws, hipStream_t st) {
+static int run_sort(const void *in, void *out, int64_t *pos, int64_t nseg, int64_t n, int desc, const SortPlan &p, char *ws, hipStream_t st, int npass) {
+    if (npass <= 0 || npass > W) npass = W;
     if (p.small && n > kBitonicMax) { // one segment per block, radix passes in LDS
-        SmallArgs a{in, out, pos, nseg, (int)n, 0, 1, desc};
+        SmallArgs a{in, out, pos, nseg, (int)n, 0, npass, desc};
         KF_REQUIRE(nseg <= 0x7fffffff, KF_ERR_INDEX_RANGE, "kf_sort: too many segments");
         KF_PROF("sort_radix_lds", st);
 #define KF_BLOCK_RADIX(NW_, IT_)                                                                                                         \
@@ -729,7 +730,7 @@ static int run_sort(const void *in, void *out, int64_t *pos, int64_t nseg, int64
         return KF_OK;
     }
     if (p.small && n <= 64) { // rows of 64 slots in registers
-        SmallArgs a{in, out, pos, nseg, (int)n, 0, 1, desc};
+        SmallArgs a{in, out, pos, nseg, (int)n, 0, npass, desc};
         while ((1 << a.logp) < n) ++a.logp;
         if (a.logp < 1) a.logp = 1; // (a one-key segment takes a two-slot cell)
         const int64_t rows = (nseg + (64 >> a.logp) - 1) / (64 >> a.logp), grid = (rows + 4 * kWaveRows - 1) / (4 * kWaveRows);
@@ -747,7 +748,7 @@ static int run_sort(const void *in, void *out, int64_t *pos, int64_t nseg, int64
         return KF_OK;
     }
     if (p.small && n <= kBitonicMax) { // one segment per wave, up to eight slots per lane
-        SmallArgs a{in, out, pos, nseg, (int)n, 0, 1, desc};
+        SmallArgs a{in, out, pos, nseg, (int)n, 0, npass, desc};
         while ((1 << a.logp) < n) ++a.logp;
         const int wr = a.logp == 7 ? 2 : 1;
         const int64_t grid = (nseg + 4 * wr - 1) / (4 * wr);
@@ -771,10 +772,10 @@ static int run_sort(const void *in, void *out, int64_t *pos, int64_t nseg, int64
     KF_REQUIRE(grid <= 0x7fffffff && nseg <= 0x7fffffff, KF_ERR_INDEX_RANGE, "kf_sort: too many tiles");
     KF_PROF("sort_radix", st);
     const bool one_level = p.ntiles <= 256;
-    for (int pass = 0; pass < W; ++pass) {
+    for (int pass = 0; pass < npass; ++pass) {
         RadixArgs a{};
         a.first = pass == 0;
-        a.last = pass == W - 1;
+        a.last = pass == npass - 1;
         a.src_keys = a.first ? in : keys[(pass - 1) & 1];
         a.src_pos = a.first ? nullptr : (const uint32_t *)poss[(pass - 1) & 1];
         a.dst_keys = a.last ? out : (void *)keys[pass & 1];
@@ -814,6 +815,14 @@ extern "C" size_t kf_sort_workspace_bytes(int dtype, int64_t nseg, int64_t n) {
 
 extern "C" int kf_sort(int dtype, const void *keys_in, void *keys_out, int64_t *pos_out, int64_t nseg, int64_t n, int descending,
                        void *workspace, size_t workspace_bytes, void *stream) {
+    return kf::sort_with_key_bits(dtype, keys_in, keys_out, pos_out, nseg, n, descending, workspace, workspace_bytes, stream, 0);
+}
+
+// key_bits > 0: the caller knows that all keys agree above their low key_bits bits (row numbers below a table's row count): the radix
+// passes over the bytes above them are skipped - the same result, fewer launches (the network for segments of up to 512 keys ignores it).
+int kf::sort_with_key_bits(int dtype, const void *keys_in, void *keys_out, int64_t *pos_out, int64_t nseg, int64_t n, int descending, void *workspace,
+                           size_t workspace_bytes, void *stream, int key_bits) {
+    const int npass = key_bits > 0 ? (key_bits + 7) / 8 : 0;
     KF_REQUIRE(dtype != KF_BOOL && dtype_size(dtype) != 0, KF_ERR_UNSUPPORTED, "kf_sort: dtype %d not supported (bool cannot be sorted)", dtype);
     KF_REQUIRE(nseg >= 0 && n >= 0, KF_ERR_INVALID, "kf_sort: negative extent");
     KF_REQUIRE(n <= 0x7fffffff, KF_ERR_INDEX_RANGE, "kf_sort: a segment can not have more than INT_MAX elements");
@@ -827,14 +836,14 @@ extern "C" int kf_sort(int dtype, const void *keys_in, void *keys_out, int64_t *
     char *ws = (char *)workspace;
     const int desc = descending != 0;
     switch (dtype) {
-    case KF_U8: return run_sort<uint32_t, 1, K_UNSIGNED>(keys_in, keys_out, pos_out, nseg, n, desc, p, ws, st);
-    case KF_I8: return run_sort<uint32_t, 1, K_SIGNED>(keys_in, keys_out, pos_out, nseg, n, desc, p, ws, st);
-    case KF_I16: return run_sort<uint32_t, 2, K_SIGNED>(keys_in, keys_out, pos_out, nseg, n, desc, p, ws, st);
-    case KF_F16: case KF_BF16: return run_sort<uint32_t, 2, K_FLOAT>(keys_in, keys_out, pos_out, nseg, n, desc, p, ws, st);
-    case KF_I32: return run_sort<uint32_t, 4, K_SIGNED>(keys_in, keys_out, pos_out, nseg, n, desc, p, ws, st);
-    case KF_F32: return run_sort<uint32_t, 4, K_FLOAT>(keys_in, keys_out, pos_out, nseg, n, desc, p, ws, st);
-    case KF_I64: return run_sort<uint64_t, 8, K_SIGNED>(keys_in, keys_out, pos_out, nseg, n, desc, p, ws, st);
-    case KF_F64: return run_sort<uint64_t, 8, K_FLOAT>(keys_in, keys_out, pos_out, nseg, n, desc, p, ws, st);
+    case KF_U8: return run_sort<uint32_t, 1, K_UNSIGNED>(keys_in, keys_out, pos_out, nseg, n, desc, p, ws, st, npass);
+    case KF_I8: return run_sort<uint32_t, 1, K_SIGNED>(keys_in, keys_out, pos_out, nseg, n, desc, p, ws, st, npass);
+    case KF_I16: return run_sort<uint32_t, 2, K_SIGNED>(keys_in, keys_out, pos_out, nseg, n, desc, p, ws, st, npass);
+    case KF_F16: case KF_BF16: return run_sort<uint32_t, 2, K_FLOAT>(keys_in, keys_out, pos_out, nseg, n, desc, p, ws, st, npass);
+    case KF_I32: return run_sort<uint32_t, 4, K_SIGNED>(keys_in, keys_out, pos_out, nseg, n, desc, p, ws, st, npass);
+    case KF_F32: return run_sort<uint32_t, 4, K_FLOAT>(keys_in, keys_out, pos_out, nseg, n, desc, p, ws, st, npass);
+    case KF_I64: return run_sort<uint64_t, 8, K_SIGNED>(keys_in, keys_out, pos_out, nseg, n, desc, p, ws, st, npass);
+    case KF_F64: return run_sort<uint64_t, 8, K_FLOAT>(keys_in, keys_out, pos_out, nseg, n, desc, p, ws, st, npass);
     default: break;
     }
     KF_REQUIRE(false, KF_ERR_UNSUPPORTED, "kf_sort: dtype %d not supported", dtype);

@@ -163,3 +163,30 @@ def test_index_add_is_the_gathers_backward(code, cols):
         want[r] = acc
     assert np.array_equal(O.to_float(outs[0], code), O.to_float(O.from_float(want, code), code))
     assert (O.to_float(outs[0], code)[11] == 5.0).all()
+
+
+def test_index_add_long_index_list_takes_the_global_sort_with_skipped_passes():
+    """20000 indices (beyond one block's radix sort) into 70000 rows: row numbers need 17 bits, so the sort behind the add runs three of the
+    four radix passes of its 32-bit keys (round 5) - same sums, in input order, bit for bit."""
+    rng = np.random.default_rng(181)
+    nrows, n, cols = 70000, 20000, 64
+    idx = rng.integers(-nrows, nrows, size=(n,)).astype(np.int64)
+    idx[::7] = 69999
+    src = rng.uniform(-1, 1, (n, cols)).astype(np.float32)
+    bi, bs = H.DevBuf.from_numpy(idx), H.DevBuf.from_numpy(src)
+    dst = H.DevBuf.from_numpy(np.full((nrows, cols), 5.0, dtype=np.float32))
+    ws = H.index_add(H.F32, bi.ptr, n, bs.ptr, cols, nrows, dst.ptr)
+    H.device_sync()
+    del ws
+    got = dst.to_numpy((nrows, cols), np.float32)
+    want = np.full((nrows, cols), 5.0, dtype=np.float32)
+    wrapped = np.where(idx < 0, idx + nrows, idx)
+    order = np.argsort(wrapped, kind="stable")
+    starts = np.flatnonzero(np.r_[True, wrapped[order][1:] != wrapped[order][:-1]])
+    ends = np.r_[starts[1:], n]
+    for s0, e0 in zip(starts, ends):
+        acc = np.zeros(cols, dtype=np.float32)
+        for j in order[s0:e0]:
+            acc = acc + src[j]
+        want[wrapped[order[s0]]] = acc
+    assert np.array_equal(got, want)
