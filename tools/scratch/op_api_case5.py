@@ -21,6 +21,7 @@ x, y = T((8192, 8200)), T((8192, 8200))
 n = 8192 * 4096
 timeit("x[:, 0:4096] + y[:, 0:4096] f32 (aligned slices)", lambda: x[:, 0:4096] + y[:, 0:4096], 12 * n)
 timeit("x[:, 1:4097] + y[:, 3:4099] f32 (unaligned slices)", lambda: x[:, 1:4097] + y[:, 3:4099], 12 * n)
+timeit("x[:, 0:4096] + y[:, 0:4096] f32 (aligned slices) AGAIN", lambda: x[:, 0:4096] + y[:, 0:4096], 12 * n)
 timeit("x[:, 1:4097].contiguous()", lambda: x[:, 1:4097].contiguous(), 8 * n)
 timeit("x[:, 1:4097].sum(1)", lambda: x[:, 1:4097].sum(1), 4 * n)
 timeit("x[:, 1:4097].sum(0)", lambda: x[:, 1:4097].sum(0), 4 * n)
@@ -28,4 +29,5 @@ xb, yb = T((8192, 8200), True), T((8192, 8200), True)
 timeit("bf16 x[:, 1:4097] + y[:, 3:4099] (unaligned)", lambda: xb[:, 1:4097] + yb[:, 3:4099], 6 * n)
 timeit("bf16 x[:, 8:4104] + y[:, 16:4112] (aligned)", lambda: xb[:, 8:4104] + yb[:, 16:4112], 6 * n)
 timeit("bf16 x[:, 1:4097].contiguous()", lambda: xb[:, 1:4097].contiguous(), 4 * n)
+timeit("x[:, 0:4096].contiguous()", lambda: x[:, 0:4096].contiguous(), 8 * n)
 timeit("x[::2].contiguous() f32 (every other row)", lambda: x[::2].contiguous(), 8 * 4096 * 8200)
