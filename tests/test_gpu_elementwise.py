@@ -130,6 +130,27 @@ def test_binary_with_a_transposed_operand():
                 assert np.array_equal(bits(got), bits(O.binary(oop, np.ascontiguousarray(yt), x, a_code=code, b_code=code))), (code, shape, perm, name, "yT op x")
 
 
+def test_in_place_with_a_transposed_operand_and_unaligned_row_slices():
+    """x += y.T (the output IS the straight operand) through the tiled kernel; row slices that start at an odd element keep the 16-byte
+    kernels (round 5) - all bit-exact, bytes outside the slices untouched."""
+    rng = np.random.default_rng(82)
+    for code in (H.F32, H.BF16):
+        yb = rand_of(rng, (256, 192), code)
+        x = rand_of(rng, (192, 256), code)
+        dx = Dev(x, code)
+        got = gpu_binary(OPS["add"][0], dx, Dev(yb.T, code, base=yb), out=dx).get()
+        assert np.array_equal(bits(got), bits(O.binary(OPS["add"][1], x, np.ascontiguousarray(yb.T), a_code=code, b_code=code))), code
+        a, b = rand_of(rng, (64, 530), code), rand_of(rng, (64, 530), code)
+        out_base = rand_of(rng, (64, 530), code)
+        va, vb, vo = a[:, 1:513], b[:, 3:515], out_base[:, 5:517]
+        want = out_base.copy()
+        dout = Dev(vo, code, base=out_base)
+        got = gpu_binary(OPS["add"][0], Dev(va, code, base=a), Dev(vb, code, base=b), out=dout)
+        want[:, 5:517] = O.binary(OPS["add"][1], np.ascontiguousarray(va), np.ascontiguousarray(vb), a_code=code, b_code=code)
+        host = got.buf.to_numpy(out_base.shape, out_base.dtype)
+        assert np.array_equal(bits(host), bits(want)), code
+
+
 def test_vectorised_broadcast_paths():
     rng = np.random.default_rng(8)
     for code in (H.F32, H.BF16, H.F64):

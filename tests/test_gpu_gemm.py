@@ -505,3 +505,25 @@ def test_ragged_extents_run_on_the_matrix_kernels(code, M, N, K):
     assert (np.abs(out[:, :N] - want) <= 2 * eps * np.abs(want) + 2 * eps * mag + 1e-30).all()
     with H.knobs(KF_GEMM_NO_PAD="1"):
         assert H.gemm_workspace_bytes(code, False, False, M, N, K) == 0
+
+
+@pytest.mark.parametrize("code,M,N,K", [(H.BF16, 256, 384, 1000), (H.BF16, 250, 384, 1024), (H.F32, 192, 128, 1001), (H.F16, 384, 250, 512)])
+def test_ragged_in_one_extent_only(code, M, N, K):
+    """Only K ragged (C is written in place, with beta and a bias row), only M or only N ragged (the aligned operand is read where it lies)."""
+    rng = np.random.default_rng(M * 5 + N * 11 + K)
+    eps = {H.BF16: 2.0 ** -8, H.F16: 2.0 ** -11, H.F32: 2.0 ** -20}[code]
+    a = O.from_float(rng.uniform(-1, 1, (M, K)).astype(np.float32), code)
+    b = O.from_float(rng.uniform(-1, 1, (K, N)).astype(np.float32), code)
+    c = O.from_float(rng.uniform(-1, 1, (M, N)).astype(np.float32), code)
+    bias = O.from_float(rng.uniform(-1, 1, (N,)).astype(np.float32), code)
+    assert H.gemm_workspace_bytes(code, False, False, M, N, K) > 0
+    want = 0.5 * (f64(a, code) @ f64(b, code)) + 2.0 * f64(c, code) + f64(bias, code)[None, :]
+    mag = np.abs(f64(a, code)) @ np.abs(f64(b, code)) + 4
+    for tb in (False, True):
+        sb = np.ascontiguousarray(b.T) if tb else b
+        H.profile_reset()
+        H.profile_enable(True)
+        got = f64(run_gemm(code, a, sb, tb=tb, alpha=0.5, beta=2.0, c=c.copy(), bias=bias), code)
+        H.profile_enable(False)
+        assert "gemm_generic" not in H.profile_results(), H.profile_results()
+        assert (np.abs(got - want) <= 2 * eps * np.abs(want) + 2 * eps * mag + 1e-30).all(), tb

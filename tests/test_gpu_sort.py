@@ -75,7 +75,7 @@ def test_golden_topk_large_values():
 @pytest.mark.parametrize("code", [H.U8, H.I8, H.I16, H.I32, H.I64, H.F16, H.BF16, H.F32, H.F64])
 def test_every_dtype_every_path(code):
     rng = np.random.default_rng(700 + code)
-    for nseg, n in ((1, 1), (1000, 1), (257, 2), (3, 2), (70, 3), (1000, 13), (333, 17), (100, 33), (50, 100), (37, 128), (20, 200), (9, 300), (11, 511), (5, 64), (7, 65), (3, 512), (3, 513), (3, 1000), (2, 1024), (2, 1025), (2, 2048), (3, 2049), (2, 4096), (2, 4097), (2, 8192),
+    for nseg, n in ((1, 1), (1000, 1), (257, 2), (3, 2), (70, 3), (1000, 13), (333, 17), (100, 33), (50, 100), (37, 128), (20, 200), (9, 300), (11, 511), (3, 65), (100000, 3), (5, 514), (5, 64), (7, 65), (3, 512), (3, 513), (3, 1000), (2, 1024), (2, 1025), (2, 2048), (3, 2049), (2, 4096), (2, 4097), (2, 8192),
                     (3, 8193), (5, 22223), (2, 100000),
                     (2, 16384), (3, 73733), (1, 200003)):   # (whole 8192-key tiles: the 16-byte histogram loads; nine tiles and a ragged one: the XCD tile map)
         for desc in (False, True):
