@@ -220,6 +220,38 @@ __global__ __launch_bounds__(kRB) void reduce_inner_kernel(const RedArgs a, cons
     }
 }
 
+// ---- column sums over a FEW rows (R <= 8; round 5): one lane per pack of columns, the rows' packs in flight together, rows added in order -
+// no LDS, no barrier, no idle row groups (mean(0) of bf16 [2, 128 Mi] ran at 2.6 TB/s through the four-row-group kernel below)
+template <typename T, typename Ops, int VEC>
+__global__ __launch_bounds__(256) void reduce_outer_few_kernel(const RedArgs a, const typename Ops::Fin fin) {
+    using A = typename Ops::A;
+    using X = typename Ops::X;
+    const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * VEC;
+    if (c >= a.C) return;
+    for (uint32_t z = blockIdx.z; z < a.nouter; z += gridDim.z) {
+        uint32_t off[3];
+        a.oc.get(z, off);
+        const char *col = a.in + off[1] + c * sizeof(T);
+        RPack<T, VEC> p[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) p[r] = *(const RPack<T, VEC> *)(col + (int64_t)(r < a.R ? r : a.R - 1) * a.r_stride); // (clamped, no branch around the load)
+        A acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = Ops::zero();
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (r < a.R) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    const X x[1] = {r_load<T>((const char *)&p[r].v[e])};
+                    Ops::template add_pack<1>(acc[e], x);
+                }
+            }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) fin.store(a, off[0], off[2], (uint32_t)(c + e), acc[e]);
+    }
+}
+
 // ---- outer: reduced dim strided, dim 1 contiguous (column sums) ------------------------------
 template <typename T, typename Ops, int VEC>
 __global__ __launch_bounds__(kRB) void reduce_outer_kernel(const RedArgs a, const typename Ops::Fin fin) {
@@ -580,6 +612,16 @@ static int run_reduce(const char *what, const kf_iter_desc *d, const Plan &p, co
             reduce_outer_tall_kernel<T, Ops><<<gt, kRB, 0, st>>>(a, fin);
             KF_LAUNCH_CHECK();
             return KF_OK;
+        }
+        if constexpr (!Ops::kPackRows) { // (sums and means; the moments keep their pairwise update)
+            if (p.R <= 8 && p.nsplit == 1) {
+                const int64_t packs = (p.C + p.vec - 1) / p.vec;
+                dim3 gf((unsigned)((packs + 255) / 256), 1, (unsigned)(p.nouter < 1024 ? p.nouter : 1024));
+                if (p.vec > 1) reduce_outer_few_kernel<T, Ops, 16 / sizeof(T)><<<gf, 256, 0, st>>>(a, fin);
+                else reduce_outer_few_kernel<T, Ops, 1><<<gf, 256, 0, st>>>(a, fin);
+                KF_LAUNCH_CHECK();
+                return KF_OK;
+            }
         }
         dim3 grid((unsigned)gx, (unsigned)p.nsplit, (unsigned)(p.nouter < 1024 ? p.nouter : 1024));
         if (p.vec > 1)
