@@ -220,6 +220,27 @@ __global__ __launch_bounds__(kRB) void reduce_inner_kernel(const RedArgs a, cons
     }
 }
 
+// ---- row sums over a FEW columns (one or two packs per row; round 5): one lane per row, its packs in flight together, no shuffles; a wave
+// stores 64 consecutive results (sum(1) of f32 [32 Mi, 8]: two lanes per row and a shuffle step ran at 3.9 TB/s)
+template <typename T, typename Ops, int VEC>
+__global__ __launch_bounds__(256) void reduce_inner_few_kernel(const RedArgs a, const typename Ops::Fin fin) {
+    using A = typename Ops::A;
+    const uint32_t o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= a.nout) return;
+    uint32_t off[3];
+    a.oc.get(o, off);
+    const char *row = a.in + off[1];
+    const int64_t npk = a.R / VEC; // (<= 4, whole packs)
+    RPack<T, VEC> p[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p[q] = *(const RPack<T, VEC> *)(row + (int64_t)(q < npk ? q : npk - 1) * (VEC * sizeof(T))); // (clamped, no branch around the load)
+    A acc = Ops::zero();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (q < npk) fold_pack<Ops, T, VEC>(acc, p[q]);
+    fin.store(a, off[0], off[2], 0, acc);
+}
+
 // ---- column sums over a FEW rows (R <= 8; round 5): one lane per pack of columns, the rows' packs in flight together, rows added in order -
 // no LDS, no barrier, no idle row groups (mean(0) of bf16 [2, 128 Mi] ran at 2.6 TB/s through the four-row-group kernel below)
 template <typename T, typename Ops, int VEC>
@@ -592,6 +613,13 @@ static int run_reduce(const char *what, const kf_iter_desc *d, const Plan &p, co
 
     if (p.path == PATH_INNER) {
         KF_REQUIRE(build_out_calc(0), KF_ERR_INVALID, "kf_reduce: bad shape/stride");
+        if constexpr (!Ops::kPackRows) {
+            if (p.vec > 1 && p.R <= 2 * p.vec && p.nsplit == 1 && p.nout >= 65536) { // many rows of one or two packs: a lane per row (four packs: 5.5 against 6.1 TB/s for the shuffle form)
+                reduce_inner_few_kernel<T, Ops, 16 / sizeof(T)><<<(unsigned)((p.nout + 255) / 256), 256, 0, st>>>(a, fin);
+                KF_LAUNCH_CHECK();
+                return KF_OK;
+            }
+        }
         const int ty = kRB / p.tx;
         dim3 grid((unsigned)((p.nout + ty - 1) / ty), (unsigned)p.nsplit);
         if (p.vec > 1)
