@@ -146,8 +146,19 @@ def stamp_is_current(obj: dict, names) -> bool:
     return obj.get("device_src_sha") == device_src_sha()
 
 
+def grad_f32_default(world: int) -> bool:
+    """Which gradient format the dW all-reduce uses. bf16 sums round once per addition: the check's bound N 2^-8 sum|dW_r| is 3 % of sum|dW| at
+    N = 8 - so from 8 ranks on the float path (the dW GEMM keeps its f32 accumulators, RCCL adds floats; twice the message bytes) is the
+    DEFAULT; below it bf16 is. KF_BENCH_GRAD_F32=1 / KF_BENCH_GRAD_BF16=1 force either."""
+    if os.environ.get("KF_BENCH_GRAD_F32"):
+        return True
+    if os.environ.get("KF_BENCH_GRAD_BF16"):
+        return False
+    return world >= 8
+
+
 class Workload:
-    def __init__(self, H, rank):
+    def __init__(self, H, rank, world=1):
         self.H = H
         rng = np.random.default_rng(1003 + 7919 * rank)  # seed = 1000 + config number (C3), rank-offset data
         n = GEMM_N
@@ -157,7 +168,7 @@ class Workload:
         self.W_host = bf16_random(wrng, (n, n))
         self.W = H.DevBuf.from_numpy(self.W_host)
         self.dC = H.DevBuf.from_numpy(bf16_random(rng, (n, n)))
-        self.grad_f32 = bool(os.environ.get("KF_BENCH_GRAD_F32"))  # dW leaves the GEMM as float and is all-reduced as float
+        self.grad_f32 = grad_f32_default(world)  # dW leaves the GEMM as float and is all-reduced as float
         self.Cc, self.dA, self.dW = H.DevBuf(2 * n * n), H.DevBuf(2 * n * n), H.DevBuf((4 if self.grad_f32 else 2) * n * n)
         nbytes = AB * AH * AS * AD * 2
         self.q, self.k, self.v, self.o, self.do = (H.DevBuf(nbytes) for _ in range(5))
@@ -331,19 +342,42 @@ def cpu_baseline():
                       f"of each of the 3 GEMMs ({t_gemm:.1f} s), scaled linearly to one step"}
 
 
+def mfma_ceiling(stream, warm_s=0.7, timed_s=0.3):
+    """TFLOP/s of a bare back-to-back MFMA loop on random bf16 operands on THIS box, now: {"32x32x16": .., "16x16x32": ..} - what the
+    matrix pipes hold under the power cap when nothing else is asked of them. None when the diagnostic library is not there."""
+    lib = ROOT / "kfunca_amd" / "_build" / "libkfunca_diag.so"
+    if not lib.exists():
+        return None
+    f = C.CDLL(str(lib)).kf_diag_mfma_ceiling
+    f.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.POINTER(C.c_double)]
+    out = {}
+    for shape, name in ((0, "32x32x16"), (1, "16x16x32")):
+        t = C.c_double(0.0)
+        if f(shape, 0, warm_s, timed_s, stream, C.byref(t)) != 0:
+            return None
+        out[name] = t.value
+    return out
+
+
+# the MFMA instruction shape of each timed kernel (which ceiling it is priced against)
+KERNEL_MFMA_SHAPE = {"gemm_bf16_mfma": "16x16x32", "gemm_bf16_mfma_pair": "16x16x32", "attn_fwd_mfma": "32x32x16",
+                     "attn_bwd_dkv_mfma": "32x32x16", "attn_bwd_dq_mfma": "32x32x16"}
+
+
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` without a torchrun environment: start the N ranks as CHILD processes (this process has
     not touched, and never touches, a GPU), pass rank 0's output through and return the worst exit status."""
     # rendezvous over a FILE store in a fresh temporary directory (kfunca_amd/parallel.py, KF_RDZV_FILE): round 4 picked a TCP port by
     # bind-then-close, which any other job on the box could take in between
     import tempfile
-    rdzv = Path(tempfile.mkdtemp(prefix="kf_rdzv_")) / "store"
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), KF_RDZV_FILE=str(rdzv))
-        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
-    out0, codes = supervise(procs, RANK_TIMEOUT_S)
+    with tempfile.TemporaryDirectory(prefix="kf_rdzv_") as tmp:   # removed with its store file whatever happens to the ranks (ADVICE round 5)
+        rdzv, t_job = Path(tmp) / "store", time.time()
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), KF_RDZV_FILE=str(rdzv), KF_RDZV_T0=repr(t_job))
+            procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+        out0, codes = supervise(procs, RANK_TIMEOUT_S)
     lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
     for ln in lines[:-1]:
         print(ln, file=sys.stderr)  # library banners etc.: THE line is the last one
@@ -382,18 +416,28 @@ def supervise(procs, timeout_s):
 
 def dry_run_cpu(args, rank, world):
     """The N > 1 plumbing without a GPU (tests/test_parallel_gloo.py): rendezvous, gradient bucket, sum all-reduce over gloo,
-    max-over-ranks timing and the one-line report — the same ProcessGroup calls the GPU path makes, host buffers instead."""
+    max-over-ranks timing and the one-line report — the same ProcessGroup calls the GPU path makes, host buffers instead.
+    KF_BENCH_DRY_FAULT="<rank>:exit" / "<rank>:hang" makes that rank exit with status 3 / never reach the collective: what the parent's
+    supervise() and the ranks' deadline() watchdogs are for."""
     from kfunca_amd import parallel
-    pg = parallel.ProcessGroup(backend="gloo")
+    fault = os.environ.get("KF_BENCH_DRY_FAULT", "")
+    with deadline("rendezvous"):
+        pg = parallel.ProcessGroup(backend="gloo")
+    if fault and int(fault.split(":")[0]) == rank:
+        if fault.endswith("exit"):
+            os._exit(3)
+        time.sleep(10 ** 6)   # "hang": this rank holds everybody's collective until a watchdog ends the job
     bucket = parallel.GradBucket([(64, 64)], dtype=np.float32)
     flat = np.full(bucket.numel, float(rank + 1), dtype=np.float32)
     t0 = time.perf_counter()
-    pg.allreduce_sum_host(flat)
-    elapsed = pg.max_over_ranks(time.perf_counter() - t0)
+    with deadline("dry-run all-reduce"):
+        pg.allreduce_sum_host(flat)
+        elapsed = pg.max_over_ranks(time.perf_counter() - t0)
     ok = bool((flat == world * (world + 1) / 2).all())
     pg.barrier()
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "allreduce_check": ok, "elapsed_s": elapsed}), flush=True)
+        print(json.dumps({"dry_run": True, "n_gpus": world, "allreduce_check": ok, "elapsed_s": elapsed,
+                          "grad_dtype": "f32" if grad_f32_default(world) else "bf16"}), flush=True)
     pg.close()
     return 0 if ok else 1
 
@@ -406,6 +450,7 @@ def main():
     ap.add_argument("--sustain-seconds", type=float, default=2.0, help="length of the sustained loop after the timed steps (0: skip)")
     ap.add_argument("--check", action="store_true", help="after timing, verify outputs (oracle spot checks; all-reduced dW vs the gloo sum)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ceiling", action="store_true", help="skip the bare-MFMA ceiling probe (roofline.frac_of_capped_mfma)")
     ap.add_argument("--dry-run-cpu", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -434,7 +479,7 @@ def main():
             pg = parallel.ProcessGroup(backend="rccl")  # gloo rendezvous (plumbing) + RCCL communicator through the C ABI
         C.CDLL(None).fflush(None)  # RCCL leaves its version banner in the C stdout buffer: out with it now
 
-    wl = Workload(H, rank)
+    wl = Workload(H, rank, world)
     stream = H.Stream()
     comm_stream = H.Stream() if pg else None
     ev_grad, ev_comm = (H.Event(), H.Event()) if pg else (None, None)
@@ -475,10 +520,13 @@ def main():
     if pg is not None and not no_comm_env:
         ab = [timed(args.steps, None, no_comm=(i % 2 == 0)) / args.steps * 1e3 for i in range(4)]   # off, on, off, on
         elapsed_off = (ab[0] + ab[2]) / 2 * 1e-3 * args.steps
+    # THE measured loop runs with per-launch profiling OFF (the event records were 1.6 % of `value`); the per-kernel
+    # table comes from a SECOND loop of the same length with profiling on, reported as `ms_per_step_profiled`.
+    elapsed = timed(args.steps)
     H.profile_reset()
     H.profile_enable(True)
     comm_events = [] if (pg and not no_comm_env) else None
-    elapsed = timed(args.steps, comm_events)
+    elapsed_prof = timed(args.steps, comm_events)
     H.profile_enable(False)
     prof = H.profile_results()
     samples = H.profile_samples()  # every launch's own HIP-event duration: percentiles, run-to-run spread
@@ -488,6 +536,10 @@ def main():
     if args.sustain_seconds > 0:
         n_sus = max(args.steps, int(math.ceil(args.sustain_seconds / max(elapsed / args.steps, 1e-6))))
         sustained = (n_sus, timed(n_sus))
+    # this box's own matrix-pipe ceiling under its power cap, right behind the sustained loop (the chip is warm): a bare MFMA loop of the
+    # dominant kernels' instruction shape on random bf16 register operands (kfunca_amd/csrc/diag/mfma_ceiling.hip -> _build/libkfunca_diag.so;
+    # not part of libkfunca_hip.so). ~1 s per shape.
+    ceiling = mfma_ceiling(stream.handle) if rank == 0 and not args.no_ceiling else None
 
     checks = {}
     if pg is not None and (args.check or force_comm):
@@ -523,6 +575,7 @@ def main():
             "value": world * TOKENS_STEP / (elapsed / args.steps),
             "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "ms_per_step_profiled": elapsed_prof / args.steps * 1e3,   # the second loop, per-launch HIP events on: where `kernels` comes from
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "bf16 GEMM 4096x4096x4096 fwd+bwd + bf16 causal attention fwd+bwd B=8 H=32 S=4096 D=128 per GPU",
                        "global_batch": AB * world, "seq_len": AS, "parallelism": f"dp{world}"},
@@ -535,6 +588,7 @@ def main():
             "roofline": {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_MFMA_BF16, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_MFMA_BF16, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_flops_per_launch": KERNEL_FLOPS[dom]},
+            "grad_dtype": "f32" if wl.grad_f32 else "bf16",   # what the dW GEMM writes and RCCL sums (f32 from 8 ranks on: grad_f32_default)
             "device_src_sha": device_src_sha(),
             "device_lib_sha": lib_sha,      # what the library that ran was linked from (kf_build_source_sha): equal to device_src_sha, or the build is stale
             "data_note": "uniform(-1, 1) operands; each attention operand is ONE random [H, S, D] batch element replicated over the batch at distinct "
@@ -543,6 +597,14 @@ def main():
             "checks": checks,
             "check_notes": CHECK_NOTES,
         }
+        if ceiling:
+            shape = KERNEL_MFMA_SHAPE.get(dom, "32x32x16")
+            out["roofline"]["capped_mfma_tflops"] = ceiling      # bare MFMA loops on this box, this process, after the sustained loop
+            out["roofline"]["frac_of_capped_mfma"] = achieved / ceiling[shape] if ceiling.get(shape) else None
+            out["roofline"]["capped_mfma_shape"] = shape
+            for k, v in kern.items():
+                if "tflops" in v and ceiling.get(KERNEL_MFMA_SHAPE.get(k, "")):
+                    v["frac_of_capped_mfma"] = v["tflops"] / ceiling[KERNEL_MFMA_SHAPE[k]]
         if sustained:
             out["ms_per_step_sustained"] = sustained[1] / sustained[0] * 1e3
             out["value_sustained"] = world * TOKENS_STEP / (sustained[1] / sustained[0])

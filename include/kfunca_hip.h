@@ -243,7 +243,8 @@ int kf_index_get(const void *table, int64_t nrows, int64_t row_bytes, const int6
 /*
  * The gather's backward without atomics: dst[r, :] = sum over {n : wrap(idx[n]) == r} of src[n, :], added in input order in f32
  * (the indices are wrapped, stably sorted with kf_sort, and each run of equal rows is summed by one wave: bitwise
- * reproducible). Rows no index names are left untouched (zero dst first). dtype in {KF_F32, KF_BF16, KF_F16}; src [n, cols],
+ * reproducible). Rows no index names are left untouched (zero dst first). An index outside [-nrows, nrows) names no row and its
+ * src row is DROPPED (no out-of-bounds write, no error: the call never synchronises). dtype in {KF_F32, KF_BF16, KF_F16}; src [n, cols],
  * dst [nrows, cols] contiguous; caller scratch of kf_index_add_workspace_bytes(n) bytes, no initialisation needed.
  */
 size_t kf_index_add_workspace_bytes(int64_t n);
@@ -284,6 +285,8 @@ enum {
  * f32 64 x 64 x 16) also reports scratch: given it, kf_gemm copies the ragged operands into zero-padded images of whole tiles, runs the
  * tile kernels on those and copies the valid part of C back (bf16 4000^3: 5.0 -> 0.11 ms; 16 x 8192 x 8192: 0.70 -> 0.05 ms); without it
  * (or with KF_GEMM_NO_PAD, which also makes the query return 0) the scalar kernel runs as before. Bytes of C outside [M, N] stay untouched.
+ * The scratch is three padded images (+ split-K partials): ~2 (Mp Kp + Kp Np + Mp Np) bytes in 16 bits - gigabytes for vocabulary-sized
+ * products; a workspace that is too small or not 16-byte aligned is not an error: the scalar kernel runs and the library says so once on stderr.
  */
 int kf_gemm_workspace_bytes(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, size_t *bytes);
 int kf_gemm(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, float alpha, const void *A,

@@ -303,7 +303,9 @@ PYBIND11_MODULE(_C, m) {
             py::list out;
             for (const auto &c : gpu::GradBucket::plan(numels, cap_elements)) out.append(py::make_tuple(c.first, c.last, c.offset, c.numel));
             return out;
-        });
+        })
+        // the firing bookkeeping alone (no device; the code arrived() / wait() run): chunk indices in the order their collectives leave
+        .def_static("simulate_fired_order", &gpu::GradBucket::simulate_fired_order, py::arg("numels"), py::arg("cap_elements"), py::arg("arrivals"));
 
     m.def("rms_norm", [](const Tensor &x, py::object w, double eps) { return gpu::rms_norm(x, w.is_none() ? Tensor() : w.cast<Tensor>(), eps); },
           py::arg("x"), py::arg("weight") = py::none(), py::arg("eps") = 1e-5);

@@ -108,6 +108,55 @@ std::vector<GradBucket::Chunk> GradBucket::plan(const std::vector<int64_t> &nume
     return chunks;
 }
 
+GradBucket::Tracker::Tracker(const std::vector<Chunk> &chunks, int nparams) : chunks_(chunks) {
+    chunk_of_.assign(nparams, 0);
+    for (size_t c = 0; c < chunks_.size(); ++c)
+        for (int i = chunks_[c].first; i <= chunks_[c].last; ++i) chunk_of_[i] = (int)c;
+    have_.assign(nparams, 0);
+    fired_.assign(chunks_.size(), 0);
+    missing_.resize(chunks_.size());
+    reset();
+}
+
+void GradBucket::Tracker::reset() {
+    pass_open_ = false;
+    std::fill(have_.begin(), have_.end(), 0);
+    std::fill(fired_.begin(), fired_.end(), 0);
+    for (size_t c = 0; c < chunks_.size(); ++c) missing_[c] = chunks_[c].last - chunks_[c].first + 1;
+}
+
+int GradBucket::Tracker::arrive(int i) {
+    if (!pass_open_) { fired_order_.clear(); pass_open_ = true; }
+    if (have_[i]) return -1; // a second backward pass before wait(): accumulated in place, the chunk has already left (caller's protocol)
+    have_[i] = 1;
+    const int c = chunk_of_[i];
+    if (--missing_[c] != 0) return -1;
+    fired_[c] = 1;
+    fired_order_.push_back(c);
+    return c;
+}
+
+std::vector<int> GradBucket::Tracker::finish() {
+    std::vector<int> late;
+    if (!pass_open_) fired_order_.clear();
+    for (size_t c = 0; c < chunks_.size(); ++c)
+        if (!fired_[c]) { late.push_back((int)c); fired_order_.push_back((int)c); }
+    const std::vector<int> order = fired_order_;
+    reset();
+    fired_order_ = order; // the finished pass's order stays readable until the next pass opens
+    return late;
+}
+
+std::vector<int> GradBucket::simulate_fired_order(const std::vector<int64_t> &numels, int64_t cap_elements, const std::vector<int> &arrivals) {
+    Tracker t(plan(numels, cap_elements), (int)numels.size());
+    for (int i : arrivals) {
+        CHECK_FAIL(i >= 0 && i < (int)numels.size(), "simulate_fired_order: parameter index ", i, " out of range");
+        t.arrive(i);
+    }
+    t.finish();
+    return t.fired_order();
+}
+
 std::shared_ptr<GradBucket> GradBucket::create(const std::vector<Tensor> &params, int64_t cap_bytes, bool accum_f32) {
     CHECK_FAIL(!params.empty(), "GradBucket: no parameters");
     std::shared_ptr<GradBucket> b(new GradBucket());
@@ -127,15 +176,9 @@ std::shared_ptr<GradBucket> GradBucket::create(const std::vector<Tensor> &params
     const int64_t es = (int64_t)element_size(flat_dtype);
     b->chunks_ = plan(numels, std::max<int64_t>(1, cap_bytes / es));
     b->flat_ = zeros({total}, flat_dtype, b->device_);
-    b->chunk_of_.resize(params.size());
-    for (size_t c = 0; c < b->chunks_.size(); ++c)
-        for (int i = b->chunks_[c].first; i <= b->chunks_[c].last; ++i) b->chunk_of_[i] = (int)c;
+    b->tracker_ = Tracker(b->chunks_, (int)params.size());
     for (size_t i = 0; i < params.size(); ++i) b->slots_.push_back(b->flat_.narrow(0, b->offsets_[i], numels[i]).view(params[i].sizes()));
-    b->have_.assign(params.size(), 0);
     b->taken_.assign(params.size(), 0);
-    b->fired_.assign(b->chunks_.size(), 0);
-    b->missing_.resize(b->chunks_.size());
-    for (size_t c = 0; c < b->chunks_.size(); ++c) b->missing_[c] = b->chunks_[c].last - b->chunks_[c].first + 1;
     dev::set_device(b->device_);
     DEV_CALL(kf_stream_create(&b->comm_stream_));
     b->ev_ready_.resize(b->chunks_.size(), nullptr);
@@ -192,17 +235,11 @@ Tensor GradBucket::take_slot(TensorImpl *leaf) {
 int64_t GradBucket::reduced_bytes() const { return flat_.numel() * flat_.element_size_in_bytes(); }
 
 void GradBucket::arrived(TensorImpl *leaf) {
-    const int i = index_.at(leaf);
-    if (!pass_open_) { fired_order_.clear(); pass_open_ = true; }
-    if (have_[i]) return; // a second backward pass before wait(): accumulated in place, the chunk has already left (caller's protocol)
-    have_[i] = 1;
-    const int c = chunk_of_[i];
-    if (--missing_[c] == 0) fire(c);
+    const int c = tracker_.arrive(index_.at(leaf));
+    if (c >= 0) fire(c);
 }
 
 void GradBucket::fire(int c) {
-    fired_[c] = 1;
-    fired_order_.push_back(c);
     timed_[c] = 0;
     const CommState cs = comm_snapshot();
     if (!cs.comm || !collectives_) return; // a single process without a communicator: the sum over one rank is the gradient itself
@@ -219,16 +256,11 @@ void GradBucket::fire(int c) {
 
 void GradBucket::wait() {
     void *compute = dev::stream(device_);
-    for (size_t c = 0; c < chunks_.size(); ++c) {
-        // a chunk whose parameters got no gradient this pass (unused in the graph) is still reduced: every rank must issue the same collectives
-        if (!fired_[c]) fire((int)c);
+    // a chunk whose parameters got no gradient this pass (unused in the graph) is still reduced: every rank must issue the same collectives
+    for (int c : tracker_.finish()) fire(c);
+    for (size_t c = 0; c < chunks_.size(); ++c)
         if (timed_[c]) DEV_CALL(kf_stream_wait_event(compute, ev_done_[c]));
-    }
-    pass_open_ = false;
-    std::fill(have_.begin(), have_.end(), 0);
     std::fill(taken_.begin(), taken_.end(), 0);
-    std::fill(fired_.begin(), fired_.end(), 0);
-    for (size_t c = 0; c < chunks_.size(); ++c) missing_[c] = chunks_[c].last - chunks_[c].first + 1;
 }
 
 std::vector<double> GradBucket::chunk_ms() {

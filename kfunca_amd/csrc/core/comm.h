@@ -40,6 +40,28 @@ public:
     // pure layout arithmetic (also what the CPU tests check): slot offsets (64-element aligned) and the chunks cut from the end
     static std::vector<int64_t> slot_offsets(const std::vector<int64_t> &numels, int64_t *total);
     static std::vector<Chunk> plan(const std::vector<int64_t> &numels, int64_t cap_elements);
+    // Which collective leaves when - the bookkeeping of one backward pass, device-free so that the CPU tests run the SAME code the GPU
+    // path runs (every rank must issue the same collectives in the same order: RCCL matches them by sequence). arrive(i): parameter i's
+    // gradient is complete; returns the chunk that is now complete (to be fired) or -1. finish(): the chunks no gradient completed this
+    // pass, in index order (still reduced: every rank issues every collective); then the tracker is ready for the next pass.
+    class Tracker {
+    public:
+        Tracker() = default;
+        Tracker(const std::vector<Chunk> &chunks, int nparams);
+        int arrive(int param);
+        std::vector<int> finish();
+        const std::vector<int> &fired_order() const { return fired_order_; }
+        int chunk_of(int param) const { return chunk_of_[param]; }
+    private:
+        void reset();
+        std::vector<Chunk> chunks_;
+        std::vector<int> chunk_of_, missing_, fired_order_;
+        std::vector<char> have_, fired_;
+        bool pass_open_ = false;
+    };
+    // the order in which the chunks of plan(numels, cap_elements) fire when the parameters' gradients arrive in `arrivals` (indices; repeats
+    // and absentees allowed), finish() included: pure arithmetic, what tests/test_parallel_gloo.py compares across 8 ranks
+    static std::vector<int> simulate_fired_order(const std::vector<int64_t> &numels, int64_t cap_elements, const std::vector<int> &arrivals);
 
     // accum_f32: the flat buffer (and every parameter's .grad view of it) is FLOAT whatever the parameters' dtype: the dW GEMMs of 16-bit
     // layers write their f32 accumulators into the slots unrounded (kf_gemm_epilogue.c_f32), RCCL sums floats, and the error of the
@@ -52,7 +74,7 @@ public:
     void wait();     // the compute stream waits for every chunk's collective; the bucket is ready for the next backward
     Tensor flat() const { return flat_; }
     const std::vector<Chunk> &chunks() const { return chunks_; }
-    const std::vector<int> &fired_order() const { return fired_order_; }  // chunk indices in the order their collectives were issued (last pass)
+    const std::vector<int> &fired_order() const { return tracker_.fired_order(); }  // chunk indices in the order their collectives were issued (last pass)
     int64_t reduced_bytes() const;
     // attribution (tools/block_bench.py): with collectives off the bucket still collects the gradients but issues nothing (the "off" arm
     // of exposed-communication timing); chunk_ms() = what each chunk's collective of the LAST pass took on the communication stream,
@@ -71,15 +93,15 @@ private:
     std::unordered_map<TensorImpl *, int> index_;
     std::vector<int64_t> offsets_;
     std::vector<Chunk> chunks_;
-    std::vector<int> chunk_of_, missing_, fired_order_;
-    std::vector<char> have_, fired_, taken_;
+    Tracker tracker_;
+    std::vector<char> taken_;
     std::vector<void *> ev_ready_, ev_done_, ev_start_;
     std::vector<char> timed_;
     bool collectives_ = true;
     void *comm_stream_ = nullptr;
     Tensor flat_;
     int device_ = 0;
-    bool attached_ = false, pass_open_ = false;
+    bool attached_ = false;
 };
 
 } // namespace gpu

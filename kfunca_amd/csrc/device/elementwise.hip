@@ -509,7 +509,12 @@ static int pick_vec(const kf_iter_desc *d, int esize) {
             const int64_t s0 = d->stride_bytes[t][0];
             if (!(s0 == esize || (s0 == 0 && t >= d->noutputs))) ok = false;
             if ((uintptr_t)d->data[t] % esize) ok = false; // (element alignment only: see Pack)
-            (void)vb;
+            // KF_EW_ALIGNED_ONLY: the pre-round-5 dispatch - a pack is taken only at pack alignment (A/B switch and escape hatch: the
+            // relaxed form leans on gfx950's unaligned global access mode; tests/test_kernel_hazards.py pins that the relaxed
+            // instantiations still compile to 16-byte accesses)
+            if (knob(KNOB_EW_ALIGNED_ONLY) && ((uintptr_t)d->data[t] % vb)) ok = false;
+            for (int k = 1; ok && knob(KNOB_EW_ALIGNED_ONLY) && k < d->ndim; ++k)
+                if (d->stride_bytes[t][k] % vb) ok = false;
         }
         if (ok) return vec;
     }

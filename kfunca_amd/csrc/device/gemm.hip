@@ -12,8 +12,10 @@
 //   f64      v_mfma_f64_16x16x4_f64, 64x64x16 block tile (the reference's only GEMM test is f64: 123x457x234,
 //            test/test_gemm.py:9-17 - ragged, so at the C ABI it takes the fallback below; the operator pads it).
 //   ragged shapes: a plain LDS-tiled FMA kernel.
+#include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -1709,6 +1711,11 @@ static int gemm_impl(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, 
         const int64_t ar = trans_a ? K : M, ac = trans_a ? M : K, arp = trans_a ? pp.Kp : pp.Mp, acp = trans_a ? pp.Mp : pp.Kp;
         const int64_t br = trans_b ? N : K, bc = trans_b ? K : N, brp = trans_b ? pp.Np : pp.Kp, bcp = trans_b ? pp.Kp : pp.Np;
         bool use_a = false, use_b = false, use_c = false;
+        // every pad / unpad launch is one thread per 16-byte piece of an image: the largest image bounds them all
+        {
+            const int64_t big = std::max(std::max(pp.Mp * pp.Kp, pp.Kp * pp.Np), pp.Mp * pp.Np) * es / 16;
+            KF_REQUIRE((big + 255) / 256 <= 0x7fffffffLL, KF_ERR_INDEX_RANGE, "kf_gemm: a padded operand image of %lld pieces exceeds the grid limit", (long long)big);
+        }
         {
             KF_PROF("gemm_pad", st);
             auto pad = [&](const void *src, int64_t ld, int64_t rows, int64_t cols, char *dst, int64_t rows_p, int64_t cols_p) {
@@ -1743,6 +1750,15 @@ static int gemm_impl(int dtype, int trans_a, int trans_b, int64_t M, int64_t N, 
             KF_LAUNCH_CHECK();
         }
         return KF_OK;
+    }
+    if (const PadPlan pp = pad_plan(dtype, M, N, K); pp.use && workspace && !(g.mul || g.add || g.aux || g.c_f32)) {
+        // a caller that DID bring scratch lands on the scalar kernel (20-40x slower): say why, once
+        static bool told = false;
+        if (!told) {
+            told = true;
+            fprintf(stderr, "[kfunca_hip] kf_gemm %lld x %lld x %lld: ragged extents need %zu bytes of 16-byte-aligned scratch (kf_gemm_workspace_bytes), got %zu at %p - "
+                            "running the scalar kernel\n", (long long)M, (long long)N, (long long)K, pp.total, workspace_bytes, workspace);
+        }
     }
     const int64_t gtiles = ((N + 31) / 32) * ((M + 31) / 32);
     KF_REQUIRE(gtiles <= 0x7fffffffLL, KF_ERR_INDEX_RANGE, "kf_gemm: %lld output tiles exceed the grid limit", (long long)gtiles);

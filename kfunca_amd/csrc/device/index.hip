@@ -72,7 +72,14 @@ template <> __device__ __forceinline__ void ia_st<f16_t>(f16_t *p, float v) { *p
 template <typename K>
 __global__ __launch_bounds__(256) void index_wrap_kernel(const int64_t *idx, int64_t n, int64_t nrows, K *out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) { const int64_t r = idx[i]; out[i] = (K)(r < 0 ? r + nrows : r); }
+    if (i < n) {
+        int64_t r = idx[i];
+        r = r < 0 ? r + nrows : r;
+        // an index outside [-nrows, nrows) names no row: it gets the key nrows (one past the last row), sorts behind every real row and its
+        // run is skipped by the add kernels - truncated to K it would look like a valid row AND break the promise made to the radix sort
+        // that no key differs above bit log2(nrows)
+        out[i] = (K)((r < 0 || r >= nrows) ? nrows : r);
+    }
 }
 
 // One wave per run of equal destination rows, rows moved as 16-byte packs (round 5; rows of whole packs on 16-byte boundaries): the run's
@@ -81,13 +88,14 @@ __global__ __launch_bounds__(256) void index_wrap_kernel(const int64_t *idx, int
 // same order, so the two agree bit for bit. bf16 [32768 x 4096] into 128256 rows: 0.44 -> see DESIGN §4 (2-byte loads, the run re-read per
 // 256-column chunk).
 template <typename T, typename K, int PACKS>
-__global__ __launch_bounds__(256) void index_add_sorted_vec_kernel(const K *key, const int64_t *pos, int64_t n, const T *src, int64_t cols, T *dst) {
+__global__ __launch_bounds__(256) void index_add_sorted_vec_kernel(const K *key, const int64_t *pos, int64_t n, const T *src, int64_t cols, int64_t nrows, T *dst) {
     constexpr int V = 16 / (int)sizeof(T);
     const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (j >= n) return;
     const K k = key[j];
     if (j > 0 && key[j - 1] == k) return; // not a run start
+    if ((int64_t)k >= nrows) return;      // the run of out-of-range indices (index_wrap_kernel): no row
     const int64_t npk = cols / V;
     for (int64_t b0 = 0; b0 < npk; b0 += 64 * PACKS) { // column block: PACKS packs per lane
         float acc[PACKS][V];
@@ -144,6 +152,7 @@ __global__ __launch_bounds__(256) void index_add_sorted_kernel(const K *key, con
     const K k = key[j];
     if (j > 0 && key[j - 1] == k) return; // not a run start
     const int64_t r = (int64_t)k; // already wrapped
+    if (r >= nrows) return;       // the run of out-of-range indices: no row
     for (int64_t c0 = 0; c0 < cols; c0 += 64 * 4) { // 4 columns per lane per sweep, the run re-walked per column chunk
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int64_t jj = j; jj < n && key[jj] == k; ++jj) {
@@ -214,7 +223,7 @@ extern "C" int kf_index_add(int dtype, const int64_t *idx, int64_t n, const void
     void *sort_ws = ws + 3 * ia_align((size_t)n * 8);
     // rows are numbered below 2^31 wherever a 32-bit key can hold them: four radix passes instead of eight (bf16 embedding backward, 32768 tokens:
     // the sort 0.133 -> see DESIGN §4)
-    const bool k32 = nrows <= 0x7fffffffLL;
+    const bool k32 = nrows < 0x7fffffffLL;   // (the key nrows itself must fit: it marks out-of-range indices)
     {
         KF_PROF("index_wrap", st);
         if (k32) index_wrap_kernel<int32_t><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(idx, n, nrows, (int32_t *)wrapped);
@@ -224,7 +233,7 @@ extern "C" int kf_index_add(int dtype, const int64_t *idx, int64_t n, const void
     const int kcode = k32 ? KF_I32 : KF_I64;
     const size_t sws = kf_sort_workspace_bytes(kcode, 1, n);
     int bits = 1;
-    while (bits < 63 && ((int64_t)1 << bits) < nrows) ++bits; // wrapped rows are below nrows: the key bytes above that are the same in every key
+    while (bits < 63 && ((int64_t)1 << bits) <= nrows) ++bits; // keys are 0..nrows inclusive: the key bytes above that are the same in every key
     int rc = sort_with_key_bits(kcode, wrapped, sorted, pos, 1, n, 0, sws ? sort_ws : nullptr, sws, stream, bits); // stable: equal rows keep input order
     if (rc != KF_OK) return rc;
     const unsigned grid = (unsigned)((n + 3) / 4);
@@ -235,10 +244,10 @@ extern "C" int kf_index_add(int dtype, const int64_t *idx, int64_t n, const void
 #define KF_IA(T_, K_)                                                                                                                              \
     {                                                                                                                                              \
         if (!vec) index_add_sorted_kernel<T_, K_><<<grid, 256, 0, st>>>((const K_ *)sorted, pos, n, (const T_ *)src, cols, nrows, (T_ *)dst);        \
-        else if (npk <= 64) index_add_sorted_vec_kernel<T_, K_, 1><<<grid, 256, 0, st>>>((const K_ *)sorted, pos, n, (const T_ *)src, cols, (T_ *)dst); \
-        else if (npk <= 128) index_add_sorted_vec_kernel<T_, K_, 2><<<grid, 256, 0, st>>>((const K_ *)sorted, pos, n, (const T_ *)src, cols, (T_ *)dst); \
-        else if (npk <= 256) index_add_sorted_vec_kernel<T_, K_, 4><<<grid, 256, 0, st>>>((const K_ *)sorted, pos, n, (const T_ *)src, cols, (T_ *)dst); \
-        else index_add_sorted_vec_kernel<T_, K_, 8><<<grid, 256, 0, st>>>((const K_ *)sorted, pos, n, (const T_ *)src, cols, (T_ *)dst);             \
+        else if (npk <= 64) index_add_sorted_vec_kernel<T_, K_, 1><<<grid, 256, 0, st>>>((const K_ *)sorted, pos, n, (const T_ *)src, cols, nrows, (T_ *)dst); \
+        else if (npk <= 128) index_add_sorted_vec_kernel<T_, K_, 2><<<grid, 256, 0, st>>>((const K_ *)sorted, pos, n, (const T_ *)src, cols, nrows, (T_ *)dst); \
+        else if (npk <= 256) index_add_sorted_vec_kernel<T_, K_, 4><<<grid, 256, 0, st>>>((const K_ *)sorted, pos, n, (const T_ *)src, cols, nrows, (T_ *)dst); \
+        else index_add_sorted_vec_kernel<T_, K_, 8><<<grid, 256, 0, st>>>((const K_ *)sorted, pos, n, (const T_ *)src, cols, nrows, (T_ *)dst);             \
     }
 #define KF_IA_K(T_) \
     if (k32) KF_IA(T_, int32_t) else KF_IA(T_, int64_t)

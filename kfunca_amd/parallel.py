@@ -19,10 +19,24 @@ import os
 # the pool's host driver only supports dmabuf IPC: without this RCCL's cross-process buffer sharing fails (hipIpcGetMemHandle: invalid argument).
 # Must be in the environment before HIP initialises; children inherit it.
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import time
 from dataclasses import dataclass
 from typing import List, Sequence, Tuple
 
 import numpy as np
+
+
+def _job_start() -> float:
+    """When this job began: the launcher's own clock at the moment it made the rendezvous directory (KF_RDZV_T0), else this process's
+    creation time. A store file older than that belongs to somebody else."""
+    t0 = os.environ.get("KF_RDZV_T0")
+    if t0:
+        return float(t0)
+    try:
+        import psutil
+        return psutil.Process().create_time()
+    except Exception:  # noqa: BLE001
+        return time.time()
 
 
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
@@ -79,7 +93,12 @@ class ProcessGroup:
             rdzv = os.environ.get("KF_RDZV_FILE")
             if rdzv:
                 # ranks this repository's own launchers started (bench.py / tools/block_bench.py --gpus N without torchrun): a FILE store in a
-                # fresh temporary directory of the parent - no TCP port to guess, nothing another job on the box can race for
+                # fresh temporary directory of the parent - no TCP port to guess, nothing another job on the box can race for. The store must
+                # be NEW: one left behind by a crashed job at the same path would hand this rendezvous that job's keys. The
+                # launcher's directory is fresh, so the file can only exist once a rank of THIS job has created it: younger than the job.
+                if os.path.exists(rdzv) and os.path.getmtime(rdzv) < _job_start() - 2.0:
+                    raise RuntimeError(f"KF_RDZV_FILE={rdzv} exists and is older than this job: a stale store of another job "
+                                       "(remove it, or let the launcher make a fresh directory)")
                 dist.init_process_group("gloo", init_method=f"file://{rdzv}", rank=self.rank, world_size=self.world)
             else:   # under torch.distributed.run: its MASTER_ADDR / MASTER_PORT
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

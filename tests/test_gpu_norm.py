@@ -165,6 +165,34 @@ def test_index_add_is_the_gathers_backward(code, cols):
     assert (O.to_float(outs[0], code)[11] == 5.0).all()
 
 
+@pytest.mark.parametrize("nrows,n,cols", [(300, 4000, 200), (256, 4000, 100), (70000, 20000, 64)])  # nrows a power of two: the sentinel key needs one more bit
+def test_index_add_drops_out_of_range_indices(nrows, n, cols):
+    """an index outside [-nrows, nrows) used to be truncated to a valid-looking row (and broke the radix sort's promise).
+    Now it names no row: its gradient row is dropped, every in-range sum is what it is without those entries, nothing is written
+    outside dst (a guard band behind dst stays untouched)."""
+    rng = np.random.default_rng(190 + cols)
+    idx = rng.integers(-nrows, nrows, size=(n,)).astype(np.int64)
+    bad = rng.choice(n, size=n // 10, replace=False)
+    idx[bad] = rng.choice(np.array([nrows, nrows + 5, -nrows - 1, 2 ** 31 + 3, -2 ** 40, 2 ** 62], dtype=np.int64), size=bad.size)
+    src = rng.uniform(-1, 1, (n, cols)).astype(np.float32)
+    bi, bs = H.DevBuf.from_numpy(idx), H.DevBuf.from_numpy(src)
+    guard = 64
+    dst = H.DevBuf.from_numpy(np.full((nrows + guard, cols), 5.0, dtype=np.float32))
+    ws = H.index_add(H.F32, bi.ptr, n, bs.ptr, cols, nrows, dst.ptr)
+    H.device_sync()
+    del ws
+    got = dst.to_numpy((nrows + guard, cols), np.float32)
+    want = np.full((nrows + guard, cols), 5.0, dtype=np.float32)
+    ok = (idx >= -nrows) & (idx < nrows)
+    wrapped = np.where(idx < 0, idx + nrows, idx)
+    for r in np.unique(wrapped[ok]):
+        acc = np.zeros(cols, dtype=np.float32)
+        for j in np.nonzero(ok & (wrapped == r))[0]:
+            acc = acc + src[j]
+        want[r] = acc
+    assert np.array_equal(got, want)
+
+
 def test_index_add_long_index_list_takes_the_global_sort_with_skipped_passes():
     """20000 indices (beyond one block's radix sort) into 70000 rows: row numbers need 17 bits, so the sort behind the add runs three of the
     four radix passes of its 32-bit keys (round 5) - same sums, in input order, bit for bit."""

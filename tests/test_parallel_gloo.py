@@ -81,7 +81,7 @@ def test_bench_launches_its_own_ranks_cpu_dry_run():
     lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, res.stdout
     line = json.loads(lines[0])
-    assert line == {"dry_run": True, "n_gpus": 2, "allreduce_check": True, "elapsed_s": line["elapsed_s"]}
+    assert line == {"dry_run": True, "n_gpus": 2, "allreduce_check": True, "elapsed_s": line["elapsed_s"], "grad_dtype": "bf16"}
 
 
 def test_gradient_bucket_plan_is_pure_arithmetic_and_cuts_from_the_end():
@@ -169,3 +169,101 @@ def test_block_gradients_of_two_batch_shards_sum_to_the_full_batch():
     out = mgr.dict()
     mp.spawn(_block_worker, args=(2, port, out), nprocs=2, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+# ---- N = 8 readiness without an 8-GPU node: the launcher, the file store, supervise() and the C5 chunk plan with
+# EIGHT ranks on CPU. 8 interpreters importing torch at once need ~2.5 GiB and a minute on 8 cores.
+def _run_tool(script, *argv, env_extra=None, timeout=600):
+    import subprocess
+    import sys
+    from pathlib import Path
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "KF_RDZV_FILE", "KF_RDZV_T0")}
+    env.update(env_extra or {})
+    root = Path(__file__).resolve().parent.parent
+    return subprocess.run([sys.executable, str(root / script), *argv], capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def test_bench_world8_cpu_dry_run_selects_float_gradients():
+    """`python bench.py --gpus 8 --dry-run-cpu`: eight self-launched ranks over the file store; from 8 ranks on the gradient all-reduce is
+    float by default (bench.grad_f32_default), bf16 when KF_BENCH_GRAD_BF16=1 asks for it."""
+    import json
+    res = _run_tool("bench.py", "--gpus", "8", "--dry-run-cpu")
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["dry_run"] and line["n_gpus"] == 8 and line["allreduce_check"] is True and line["grad_dtype"] == "f32"
+    import bench
+    assert [bench.grad_f32_default(n) for n in (1, 2, 4, 8)] == [False, False, False, True]
+    os.environ["KF_BENCH_GRAD_BF16"] = "1"
+    try:
+        assert bench.grad_f32_default(8) is False
+    finally:
+        del os.environ["KF_BENCH_GRAD_BF16"]
+
+
+@pytest.mark.parametrize("mode", ["exit", "hang"])
+def test_world8_job_ends_when_rank5_fails(mode):
+    """One rank of eight exits with status 3 / never reaches the collective: supervise() (exit) or the ranks' own deadline() watchdogs and
+    the parent's limit (hang) end the WHOLE job with a non-zero status and no JSON line - nobody waits for somebody else's limit."""
+    import time
+    t0 = time.monotonic()
+    res = _run_tool("bench.py", "--gpus", "8", "--dry-run-cpu",
+                    env_extra={"KF_BENCH_DRY_FAULT": f"5:{mode}", "KF_BENCH_PHASE_TIMEOUT_S": "20", "KF_BENCH_RANK_TIMEOUT_S": "240"})
+    took = time.monotonic() - t0
+    assert res.returncode != 0
+    assert not [ln for ln in res.stdout.splitlines() if ln.strip().startswith("{")], res.stdout
+    assert "ending the remaining ranks" in res.stderr, res.stderr[-2000:]
+    if mode == "exit":
+        assert "rank 5 exited with status 3" in res.stderr, res.stderr[-2000:]
+    assert took < 240, took
+
+
+def test_block_bench_world8_plan_and_fired_order():
+    """Config C5's runner with eight ranks on CPU: every rank computes the bucket's chunk plan and - through the C++ core's own Tracker, the
+    code GradBucket::arrived / wait run - the order the chunks' collectives leave in; all eight agree (RCCL matches collectives by sequence),
+    the bucket is float at 8 ranks and the chunking in ELEMENTS is the one the bf16 bucket has."""
+    import json
+    res = _run_tool("tools/block_bench.py", "--gpus", "8", "--dry-run-cpu")
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.strip()][-1])
+    assert line["dry_run"] and line["n_gpus"] == 8 and line["allreduce_check"] is True and line["grad_dtype"] == "f32"
+    assert [c[:2] for c in line["bucket_chunks"]] == [[4, 4], [3, 3], [2, 2], [0, 1]] and line["fired_order"] == [0, 1, 2, 3]
+
+
+def test_tracker_fires_each_chunk_once_whatever_the_arrival_order():
+    """GradBucket::Tracker (device-free): a chunk fires when its LAST parameter arrives, a repeated arrival (a second backward before wait())
+    fires nothing, chunks nobody completed are appended by finish() in index order - so every rank issues every collective exactly once."""
+    import itertools
+    import kfunca_amd as kfunca
+    numels, cap = [100, 7, 4096, 64, 1], 4200       # chunks (3,4) (1,2) (0,0): tests above
+    sim = kfunca.GradBucket.simulate_fired_order
+    assert sim(numels, cap, [4, 3, 2, 1, 0]) == [0, 1, 2]
+    assert sim(numels, cap, [0, 1, 2, 3, 4]) == [2, 1, 0]
+    assert sim(numels, cap, [4, 4, 3, 3]) == [0, 1, 2]          # repeats fire nothing; the rest leaves at finish()
+    assert sim(numels, cap, []) == [0, 1, 2]
+    assert sim(numels, cap, [2, 4, 0]) == [2, 0, 1]             # chunk 2 completes first; 0 and 1 are incomplete: finish() in index order
+    for order in itertools.permutations(range(5)):
+        assert sorted(sim(numels, cap, list(order))) == [0, 1, 2]
+    with pytest.raises(RuntimeError):
+        sim(numels, cap, [5])
+
+
+def test_stale_rendezvous_file_is_refused(tmp_path):
+    """a store file left behind by a crashed job must not be joined. ProcessGroup refuses a KF_RDZV_FILE older than the job."""
+    import time
+    store = tmp_path / "store"
+    store.write_bytes(b"left behind")
+    old = time.time() - 3600
+    os.utime(store, (old, old))
+    saved = {k: os.environ.get(k) for k in ("KF_RDZV_FILE", "KF_RDZV_T0", "RANK", "WORLD_SIZE")}
+    os.environ.update(KF_RDZV_FILE=str(store), KF_RDZV_T0=repr(time.time()), RANK="0", WORLD_SIZE="1")
+    try:
+        with pytest.raises(RuntimeError, match="stale store"):
+            parallel.ProcessGroup(backend="gloo")
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

@@ -49,14 +49,15 @@ def launch_ranks(n: int) -> int:
     # rendezvous over a FILE store in a fresh temporary directory (kfunca_amd/parallel.py, KF_RDZV_FILE): round 4 picked a TCP port by
     # bind-then-close, which any other job on the box could take in between
     import tempfile
-    rdzv = Path(tempfile.mkdtemp(prefix="kf_rdzv_")) / "store"
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), KF_RDZV_FILE=str(rdzv))
-        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
     from bench import RANK_TIMEOUT_S, supervise  # bounded: a rank that fails or hangs ends the others (bench.py)
-    out0, codes = supervise(procs, RANK_TIMEOUT_S)
+    with tempfile.TemporaryDirectory(prefix="kf_rdzv_") as tmp:   # removed with its store file whatever happens to the ranks
+        rdzv, t_job = Path(tmp) / "store", time.time()
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), KF_RDZV_FILE=str(rdzv), KF_RDZV_T0=repr(t_job))
+            procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr, text=True))
+        out0, codes = supervise(procs, RANK_TIMEOUT_S)
     lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
     for ln in lines[:-1]:
         print(ln, file=sys.stderr)
@@ -65,27 +66,48 @@ def launch_ranks(n: int) -> int:
     return max(abs(c) for c in codes)
 
 
-def bucket_plan(cap_mb: float, with_gains: bool):
-    """[(first, last, offset, numel)] for the block's parameters in forward order (chunk 0 = the last ones): pure arithmetic, no GPU."""
-    import kfunca_amd as kfunca
+def param_numels(with_gains: bool):
     numels = [a * b for a, b in WSHAPES]
     if with_gains:
         numels = [DM, numels[0], numels[1], DM, numels[2], numels[3], numels[4]]
-    return [tuple(int(v) for v in c) for c in kfunca.GradBucket.plan(numels, int(cap_mb * 1048576) // 2)]
+    return numels
+
+
+def bucket_plan(cap_mb: float, with_gains: bool, elem_bytes: int = 2):
+    """[(first, last, offset, numel)] for the block's parameters in forward order (chunk 0 = the last ones): pure arithmetic, no GPU."""
+    import kfunca_amd as kfunca
+    return [tuple(int(v) for v in c) for c in kfunca.GradBucket.plan(param_numels(with_gains), int(cap_mb * 1048576) // elem_bytes)]
+
+
+def grad_f32(args, world: int) -> bool:
+    """The bucket's element type: --grad f32 | bf16 | auto (default). auto = float from 8 ranks on (a 16-bit bucket rounds once per
+    addition: N 2^-8 sum|dW_r| = 3 % of sum|dW| at N = 8), bf16 below (half the bytes on the wire). DESIGN.md section 6."""
+    return args.grad == "f32" or (args.grad == "auto" and world >= 8)
 
 
 def dry_run_cpu(args, rank, world):
+    import kfunca_amd as kfunca
     from kfunca_amd import parallel
     pg = parallel.ProcessGroup(backend="gloo")
-    plan = bucket_plan(args.bucket_mb, args.form == "fused-norm")
+    with_gains = args.form == "fused-norm"
+    es = 4 if grad_f32(args, world) else 2
+    plan = bucket_plan(args.bucket_mb, with_gains)   # --bucket-mb counts 16-bit elements: a float bucket keeps the chunking and doubles the bytes
     total = sum(c[3] for c in plan)
+    nparams = len(WSHAPES) + (2 if with_gains else 0)
+    # the order the chunks' collectives leave in when the gradients arrive as the backward produces them (reverse of the forward's use) -
+    # run through the C++ core's own bookkeeping (GradBucket::Tracker, the code arrived() / wait() run on the GPU path). Every rank must
+    # get the SAME order: RCCL matches collectives by sequence number
+    numels = param_numels(with_gains)
+    fired = [int(c) for c in kfunca.GradBucket.simulate_fired_order(numels, int(args.bucket_mb * 1048576) // 2, list(range(nparams - 1, -1, -1)))]
     flat = np.full(1024, float(rank + 1), dtype=np.float32)  # a stand-in message: the plan is what is under test here
     pg.allreduce_sum_host(flat)
-    ok = bool((flat == world * (world + 1) / 2).all()) and plan[0][1] == len(WSHAPES) - 1 + (2 if args.form == "fused-norm" else 0) and plan[-1][0] == 0
-    same = pg.max_over_ranks(float(total)) == float(total)
+    ok = bool((flat == world * (world + 1) / 2).all()) and plan[0][1] == nparams - 1 and plan[-1][0] == 0
+    key = float(hash((tuple(plan), tuple(fired))) % (1 << 40))
+    same = pg.max_over_ranks(float(total)) == float(total) and pg.max_over_ranks(key) == key and -pg.max_over_ranks(-key) == key
     pg.barrier()
     if rank == 0:
-        print(json.dumps({"dry_run": True, "n_gpus": world, "bucket_chunks": plan, "bucket_elements": total, "allreduce_check": ok and same}), flush=True)
+        print(json.dumps({"dry_run": True, "n_gpus": world, "bucket_chunks": plan, "bucket_elements": total, "fired_order": fired,
+                          "grad_dtype": "f32" if es == 4 else "bf16", "allreduce_check": ok and same}), flush=True)
     pg.close()
     return 0 if ok and same else 1
 
@@ -102,6 +124,8 @@ def main():
                          "(same math); fused-norm: that plus the two rms_norms of a real pre-norm block")
     ap.add_argument("--bucket-mb", type=float, default=136.0,
                     help="largest chunk of the gradient bucket reduced by one collective (default: [down] [up] [gate] [out-proj + qkv], 128 MiB each)")
+    ap.add_argument("--grad", choices=["auto", "bf16", "f32"], default="auto",
+                    help="element type of the gradient bucket and of the RCCL sum: auto = f32 from 8 ranks on, bf16 below")
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--force-comm", action="store_true", help="one rank: still create the RCCL communicator and run the collectives")
     ap.add_argument("--dry-run-cpu", action="store_true", help=argparse.SUPPRESS)
@@ -157,7 +181,8 @@ def main():
         params, pnames = [gains[0], w[0], w[1], gains[1], w[2], w[3], w[4]], ["dgain1", "dWqkv", "dWo", "dgain2", "dWgate", "dWup", "dWdown"]
     else:
         params, pnames = list(w), ["dWqkv", "dWo", "dWgate", "dWup", "dWdown"]
-    bucket = kfunca.GradBucket(params, args.bucket_mb)
+    f32_bucket = grad_f32(args, world)
+    bucket = kfunca.GradBucket(params, args.bucket_mb * (2 if f32_bucket else 1), f32_bucket)   # the same chunking in elements either way
     bucket.attach()
 
     def body():
@@ -238,13 +263,13 @@ def main():
     if args.check:
         step()                                   # the reduced gradients of one more step ...
         kfunca.synchronize(dev)
-        reduced = bits_to_f32(bucket.flat().numpy()).copy()
+        reduced = (bucket.flat().numpy() if f32_bucket else bits_to_f32(bucket.flat().numpy())).copy()
         H.profile_reset()
         H.profile_enable(True)
         y_bits, dx_bits, dw_bits = local_gradients(kfunca, bucket, params, x, body, g, dev)  # ... and the same step with nothing reduced
         H.profile_enable(False)
         labels = set(H.profile_results())
-        checks.update(check_allreduce(kfunca, pg, bucket, params, reduced, dw_bits, world if kfunca.comm_initialized() else 1))
+        checks.update(check_allreduce(kfunca, pg, bucket, params, reduced, dw_bits, world if kfunca.comm_initialized() else 1, f32_bucket))
         if rank == 0:
             checks.update(check_shard(H, args.form, w_host, gain_host, x_host, g_host, y_bits, dx_bits, dict(zip(pnames, dw_bits)), labels))
 
@@ -256,10 +281,10 @@ def main():
                "form": args.form, "mode": "hip graph replay" if graph is not None else "eager", "n_gpus": world, "steps": args.steps,
                "ms_per_step": ms, "tokens_per_s": world * T / (ms * 1e-3), "matrix_tflops_per_gpu": flops / (ms * 1e-3) / 1e12,
                "scaling": "weak", "bucket": {"chunks_first_last_offset_numel": [list(c) for c in bucket.chunks()], "fired_order_last_step": fired,
-                                               "bytes_reduced_per_step": nbytes, "collective": "RCCL" if kfunca.comm_initialized() else "none (one rank)"},
+                                               "bytes_reduced_per_step": nbytes, "grad_dtype": "f32" if f32_bucket else "bf16", "collective": "RCCL" if kfunca.comm_initialized() else "none (one rank)"},
                "allreduce_busbw_lower_bound_GBps": (2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9) if world > 1 else 0.0,
                "allreduce_chunk_ms": chunk_ms,
-               "allreduce_chunk_busbw_GBps": [(2.0 * (world - 1) / world * c[3] * 2 / (t * 1e-3) / 1e9) if (world > 1 and t > 0) else 0.0
+               "allreduce_chunk_busbw_GBps": [(2.0 * (world - 1) / world * c[3] * (4 if f32_bucket else 2) / (t * 1e-3) / 1e9) if (world > 1 and t > 0) else 0.0
                                               for c, t in zip(bucket.chunks(), chunk_ms)],
                "ms_per_step_no_comm": ms_off, "ms_per_step_comm_ab_on_off_on_off": ab,
                "exposed_comm_ms": (ms_on_ab - ms_off) if ms_off is not None else None, "exposed_comm_noise_floor_ms": ab_noise,
@@ -311,7 +336,7 @@ def local_gradients(kfunca, bucket, params, x, body, g, dev):
     return out
 
 
-def check_allreduce(kfunca, pg, bucket, params, reduced_flat, local, world):
+def check_allreduce(kfunca, pg, bucket, params, reduced_flat, local, world, f32_bucket=False):
     """SURVEY.md section 8e's parity sentence on the live bucket: the RCCL-reduced flat gradient == the sum over ranks of each rank's own
     gradients (taken in f32 over gloo on the host), within N 2^-8 sum_r |dW_r| (RCCL adds bf16 values: one rounding per addition);
     with one rank the collective is the identity and the two must be bit-identical."""
@@ -322,13 +347,15 @@ def check_allreduce(kfunca, pg, bucket, params, reduced_flat, local, world):
         n = mine_bits.size
         got = reduced_flat[off:off + n]
         mine = bits_to_f32(mine_bits).reshape(-1)
-        if world == 1:
+        if world == 1 and not f32_bucket:
             ok = ok and bool(np.array_equal(got.view(np.uint32), mine.view(np.uint32)))
             continue
-        total = pg.allreduce_sum_host(mine.copy())
-        mag = pg.allreduce_sum_host(np.abs(mine))
+        total = pg.allreduce_sum_host(mine.copy()) if pg is not None else mine.copy()
+        mag = pg.allreduce_sum_host(np.abs(mine)) if pg is not None else np.abs(mine)
         err = np.abs(got.astype(np.float64) - total)
-        bound = world * 2.0 ** -8 * mag + 1e-30
+        # a float bucket sums the GEMMs' unrounded f32 accumulators: against the sum of the ranks' bf16-ROUNDED local gradients that is one
+        # rounding of each rank's term (2^-9 |dW_r|; 2^-8 leaves room for the f32 additions) - nothing that grows with the number of ranks
+        bound = (1 if f32_bucket else world) * 2.0 ** -8 * mag + 1e-30
         worst = max(worst, float((err / bound).max()))
         ok = ok and bool((err <= bound).all())
     return {"allreduce_vs_gloo_sum": ok, "allreduce_worst_fraction_of_bound": worst}
