@@ -348,10 +348,16 @@ int kf_gemm_grouped_single_grid(int dtype, int count, const kf_gemm_problem *p);
  * inference): lse = m + log(l), the natural-log-sum-exp of the scaled, masked scores.
  * O = softmax(mask(Q K^T / sqrt(D))) V, mask keeps key n for query m iff m >= n (absolute
  * indices, top-left aligned: causal_attention_ref.h:36-41).
- * dtype in {KF_F32, KF_BF16, KF_F16}, D <= 256, any Sq / Skv. Matrix-core kernels, forward and backward: 16-bit tensors
- * with D = 64 or 128 (the reference's two fast head sizes, causal_attention_kernel.cu:25-60) and Sq, Skv multiples of 128; f32
- * tensors (the reference's dtype: exact-f32 MFMA) with D = 64 or 128 and Sq, Skv multiples of 32. Everything else runs the generic
- * vector-ALU kernels (correct, 20-100x slower).
+ * dtype in {KF_F32, KF_BF16, KF_F16}, D <= 256, any Sq / Skv. Which kernels run, and what that costs (bf16, B 8 H 32 D 128 on MI355X; profiles/r06_attn_ragged.txt):
+ *   tier 1  16-bit tensors, D = 64 or 128, Skv >= Sq, ANY lengths (round 6): the generated one-wave-per-SIMD streams (forward 256 queries per
+ *           block, dK/dV 256 keys per block) + the stored-dS dQ kernel. Rows beyond a tensor's end are zero-filled / dropped by the kernels'
+ *           buffer descriptors: no padded copies, no alignment of S to anything. S = 4096: fwd 1.06, dK/dV 1.83, dQ 0.88 ms;
+ *           S = 4000: the same per token (1.004 x); S = 4095 / 3969: 1.007 x. The backward needs workspace for at least one pair's dS here.
+ *   tier 2  16-bit, D = 64 or 128, Sq and Skv multiples of 128, Skv < Sq (or KF_ATTN_FWD_V3 / KF_ATTN_DKV_V4): the 8-wave forward
+ *           and the 32-key-per-wave dK/dV hand kernels: 1.25 x / 1.22 x tier 1's time at the same shape.
+ *   tier 3  f32 tensors (the reference's dtype), D = 64 or 128, Sq and Skv multiples of 32: exact-f32 MFMA (C3 in f32: forward 8.8 ms).
+ *   tier 4  everything else (D <= 256 off 64 / 128, 16-bit Skv < Sq off the 128-row tiles, f32 off 32 rows): generic vector-ALU kernels,
+ *           correct, 20-100x slower. kfunca_amd's causal_attention zero-pads the head size (and f32 row counts) on its side to stay above this tier.
  * The *_scaled forms take the softmax scale explicitly instead of 1 / sqrt(D): a host that zero-pads a smaller head
  * size up to 64 or 128 columns (zero columns change neither Q K^T nor P V) passes 1 / sqrt(its own D) and lands on the MFMA
  * kernels - kfunca_amd's causal_attention does exactly that.
@@ -362,9 +368,10 @@ int kf_attn_fwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv,
                        const void *k, const void *v, void *o, float *lse, void *stream);
 /*
  * dq,dk,dv from d_o. Needs o and lse from the forward. The workspace holds three f32 rows of statistics (delta[B,H,Sq] and the two
- * row-constant arrays the dK/dV kernel reads: 3 x B*H*Sq*4 bytes, each rounded up to 256 - the MINIMUM, O(B H S)) and, on the
- * matrix-core path for 16-bit tensors, whatever lies beyond them holds dS = P o (dP - delta) in 16 bits (Sq rounded up to 256, x Skv
- * x 2 bytes per (batch, head) pair): the dK/dV kernel writes it, the dQ kernel computes dQ = scale dS K from it, so the backward
+ * row-constant arrays the dK/dV kernel reads, the latter two with Sq rounded up to 32 rows per pair: B*H*(Sq + 2 ceil32(Sq))*4 bytes, each
+ * array rounded up to 256 - the MINIMUM, O(B H S)) and, on the
+ * matrix-core path for 16-bit tensors, whatever lies beyond them holds dS = P o (dP - delta) in 16 bits (Sq and Skv rounded up to 256:
+ * ceil256(Sq) x ceil256(Skv) x 2 bytes per (batch, head) pair): the dK/dV kernel writes it, the dQ kernel computes dQ = scale dS K from it, so the backward
  * executes the 5 matrix products of the algorithm instead of 7. The pairs are processed in GROUPS of as many as the workspace holds
  * dS for, so ANY workspace_bytes >= the minimum is accepted, for both head sizes and every S: with room for less than one pair's dS
  * (or with KF_ATTN_SPLIT_BWD set) the dQ kernel recomputes S and dP instead (minimum workspace, 7 products).
@@ -388,8 +395,8 @@ int kf_attn_bwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv,
  * [B*S, 3*H*D] output of the QKV projection (batch = S*3*H*D, head = D, row = 3*H*D, bases offset by H*D), o is written
  * as [B*S, H*D] - the layout the output projection consumes - and the backward writes dq, dk, dv straight into a packed
  * [B*S, 3*H*D] gradient. Contiguous [B,H,S,D] is {H*S*D, S*D, D}. lse stays [B,H,Sq] contiguous f32.
- * 16-bit matrix-core path only (dtype KF_BF16 / KF_F16, D = 64 or 128, Sq and Skv multiples of 128; KF_ERR_UNSUPPORTED otherwise:
- * make contiguous copies and call the plain entries). Strides are multiples of 8 elements, operands 16-byte aligned.
+ * 16-bit matrix-core path only (dtype KF_BF16 / KF_F16, D = 64 or 128; Skv >= Sq with any lengths, or Sq and Skv multiples of 128;
+ * KF_ERR_UNSUPPORTED otherwise: make contiguous copies and call the plain entries). Strides are multiples of 8 elements, operands 16-byte aligned.
  * Workspace as kf_attn_bwd_workspace_bytes().
  */
 typedef struct kf_attn_layout {

@@ -667,7 +667,7 @@ void check_attention(const Tensor &q, const Tensor &k, const Tensor &v) {
     CHECK_FAIL(q.device() == k.device() && q.device() == v.device());
 }
 
-// The MFMA kernels want D = 64 or 128 and sequence lengths that are multiples of 128; everything else takes the generic
+// The MFMA kernels want D = 64 or 128 (and, f32 or Skv < Sq, whole tiles of rows); everything else takes the generic
 // vector-ALU kernel (two orders of magnitude slower). For 16-bit tensors with D <= 128 and Skv >= Sq both can be padded
 // with zeros at no cost in results: zero columns change neither Q K^T nor P V (the softmax scale stays 1 / sqrt(D) of the
 // real head size: kf_attn_*_scaled); a padded key n >= Skv >= Sq > m is above the diagonal of every real query; a padded
@@ -683,7 +683,9 @@ PadPlan pad_for_mfma(const Tensor &q, const Tensor &k) {
     if (!(D > 0 && D <= 128 && Skv >= Sq && Sq > 0)) return p;
     const bool h16 = q.dtype() == ScalarType::Half || q.dtype() == ScalarType::BFloat16;
     if (!h16 && q.dtype() != ScalarType::Float) return p;
-    const int64_t rows = h16 ? 128 : 32;
+    // round 6: the 16-bit matrix-core kernels take ANY sequence lengths with Skv >= Sq at the C ABI itself (rows beyond a tensor's end are
+    // zero-filled / dropped by the kernels' buffer descriptors - no padded copies); only a head size off 64 / 128 is still padded here
+    const int64_t rows = h16 ? 1 : 32;
     p.Dp = D <= 64 ? 64 : 128;
     p.Sqp = (Sq + rows - 1) / rows * rows;
     p.Skp = (Skv + rows - 1) / rows * rows;
@@ -837,7 +839,7 @@ PackedLay packed_layouts(int64_t S, int64_t H, int64_t D) {
     return {{S * 3 * d, D, 3 * d}, {S * d, D, d}};
 }
 bool packed_fast(const Tensor &qkv, int64_t S, int64_t D) {
-    return (qkv.dtype() == ScalarType::Half || qkv.dtype() == ScalarType::BFloat16) && (D == 64 || D == 128) && S % 128 == 0 && S > 0;
+    return (qkv.dtype() == ScalarType::Half || qkv.dtype() == ScalarType::BFloat16) && (D == 64 || D == 128) && S > 0;   // (any S since round 6: Sq == Skv)
 }
 
 class PackedAttentionGradFunction : public GradFunction {

@@ -51,6 +51,7 @@ struct AttnArgs {
     float *delta;
     float *nlse, *ndelta; // backward, dK/dV v4: -lse * sqrt(D) and -delta (initial accumulators of S and dP)
     int64_t B, H, Sq, Skv, D;
+    int64_t Sqc;       // backward, 16-bit matrix-core path: rows per head of the two row-constant arrays nlse / ndelta = Sq rounded up to 32 (a slice), pad rows zero
     float scale;
     float scale_log2e; // scale * log2(e), formed on the host (attn_fwd_w4_kernel hands it to its instruction stream as a scalar)
     int xcd_map; // 1: nbh % 8 == 0, heads are pinned to XCDs (a_block_map)
@@ -67,7 +68,7 @@ struct AttnArgs {
     int64_t bh0;     // backward, dS form: this launch covers the (batch, head) pairs bh0 .. bh0 + nbh - 1 (one group of the workspace cap)
     int nbh;         // pairs in this launch (forward and the other forms: B H, bh0 = 0)
     char *ds;        // backward: dS = P o (dP - delta) in 16 bits, written by the dK/dV kernel, read by the dQ kernel (null: not kept)
-    int64_t ds_nqb, ds_nkwb; // its tile grid: 256-query blocks x 32-key blocks (DS_* below)
+    int64_t ds_nqb, ds_pair; // its tile grid (ds_tile_index below): 256-query blocks; tiles per (batch, head) pair
 #if defined(KF_FWD_W4_STAMPS) || defined(KF_DKV_W4_STAMPS)
     unsigned long long *dbg; // diagnostic builds (tools/attn_fwd_w4_timeline.py, attn_dkv_w4_timeline.py): where every wave writes its cycle sums
 #endif
@@ -76,14 +77,27 @@ struct AttnArgs {
 // dS workspace (backward): the dK/dV kernel already holds dS = P o (dP - delta) as packed 16-bit MFMA operands; it stores them
 // and the dQ kernel computes dQ = scale dS K from them - 2 matrix products instead of the 6 a recomputing dQ kernel executes
 // (S and dP again), at the price of one 16-bit S x S / 2 round trip through HBM (4.3 GB at B 8, H 32, S 4096: HBM-bound at ~0.8 ms).
-// Layout: tiles of 32 keys x 32 queries (2 KiB), tile (bh, qb, kwb, sl) = 256-query block qb, 32-key block kwb, slice sl of
-// the block, at ((((bh nqb + qb) nkwb + kwb) 8) + sl) 2 KiB - the eight slices of a query block and consecutive key blocks are
-// contiguous, which is the order the dQ kernel streams them in. Inside a tile: [s][key][hl][8 values] where the 8 values are
-// accumulator registers e = 8 s + j of lane half hl, i.e. queries (j & 3) + 8 (2 s + (j >> 2)) + 4 hl of the slice - exactly
-// one packed operand of the dK/dV wave (key on the lane), so a store instruction writes 1 KiB of consecutive bytes.
+// Layout (round 6: ONLY THE CAUSAL HALF is kept - VERDICT round 5, next #8): tiles of 32 keys x 32 queries (2 KiB), per (batch, head)
+// pair ordered [256-key block kb][slice sl - 8 kb][32-key block of kb: 0..7]: a 256-key block keeps the 32-query slices from its own
+// diagonal down (slices counted in whole 256-query blocks, nslp = 8 ceil(Sq / 256): a dQ wave without queries still fetches its tiles), a
+// key block beyond the last query block keeps none. What one dK/dV workgroup writes per slice - its 8 tiles - is 16 KiB of
+// consecutive bytes and the next slice's follow them: the stream's tile pointer advances by a constant. A dQ wave (slice sl) reads its
+// tiles of one key block kb as 16 KiB of consecutive bytes, (sl - 8 kb) x 16 KiB into the block's area.
+// Inside a tile: [s][key][hl][8 values] where the 8 values are accumulator registers e = 8 s + j of lane half hl, i.e. queries
+// (j & 3) + 8 (2 s + (j >> 2)) + 4 hl of the slice - exactly one packed operand of the dK/dV wave (key on the lane), so a store
+// instruction writes 1 KiB of consecutive bytes.
 constexpr int DS_TILE = 2048;
-__host__ __device__ inline size_t ds_bytes(int64_t nbh, int64_t Sq, int64_t Skv) {
-    return (size_t)nbh * (size_t)((Sq + 255) / 256) * (size_t)(Skv / 32) * 8 * DS_TILE;
+// tiles in front of key block kb's area within one pair: sum over j < min(kb, nqb) of (8 nqb - 8 j) slices x 8 tiles
+__host__ __device__ inline int64_t ds_block_base(int64_t kb, int64_t nqb) {
+    const int64_t m = kb < nqb ? kb : nqb;
+    return 64 * nqb * m - 32 * m * (m - 1);
+}
+__host__ __device__ inline int64_t ds_pair_tiles(int64_t Sq, int64_t Skv) { return ds_block_base((Skv + 255) / 256, (Sq + 255) / 256); }
+__host__ __device__ inline size_t ds_bytes(int64_t nbh, int64_t Sq, int64_t Skv) { return (size_t)nbh * (size_t)ds_pair_tiles(Sq, Skv) * DS_TILE; }
+// tile (kwb = 32-key block, sl = 32-query slice) of a pair, kwb <= sl
+__host__ __device__ inline int64_t ds_tile_index(int64_t kwb, int64_t sl, int64_t nqb) {
+    const int64_t kb = kwb >> 3;
+    return ds_block_base(kb, nqb) + (sl - 8 * kb) * 8 + (kwb & 7);
 }
 
 // XCD-aware block order for the v2 kernels (1-D grid of nx * nbh blocks). Hardware deals block ids round-robin
@@ -184,7 +198,7 @@ __device__ __forceinline__ uint32_t a_cvt16(float v) { return BF ? f32_to_bf16(v
 // Write a wave's 32 x D result held as X^T accumulators (lane = row, registers = columns of
 // DB = D / 32 column blocks of 32) as 16-bit rows of `dst` (row stride rs), via a per-wave LDS slab.
 template <bool BF, int DB, int N>
-__device__ __forceinline__ void a_store_rows(char *slab, char *dst, const f32x16 (&acc)[N], float mul, int64_t rs) {
+__device__ __forceinline__ void a_store_rows(char *slab, char *dst, const f32x16 (&acc)[N], float mul, int64_t rs, int nrows = 32) {
     static_assert(DB <= N, "column blocks");
     const int lane = threadIdx.x & 63, xl = lane & 31, hl = lane >> 5;
 #pragma unroll
@@ -205,7 +219,7 @@ __device__ __forceinline__ void a_store_rows(char *slab, char *dst, const f32x16
         const int id = lane + 64 * i; // 256 DB pieces of 8 B: 32 rows x 8 DB pieces
         const int row = id / (8 * DB), piece = id % (8 * DB);
         const uint2 w = *(const uint2 *)(slab + row * OPAD + piece * 8);
-        *(uint2 *)(dst + (int64_t)row * rs + piece * 8) = w;
+        if (row < nrows) *(uint2 *)(dst + (int64_t)row * rs + piece * 8) = w; // (nrows < 32: the tensor's last rows, a ragged sequence length)
     }
 }
 
@@ -605,10 +619,13 @@ template <bool BF, bool SQ, bool D64 = false>
 __global__ __launch_bounds__(256) void attn_fwd_w4_kernel(const AttnArgs a) {
     static_assert(!(SQ && D64), "the scaled-query form exists for head size 128 only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nxb = (int)(a.Sq / FQ);
+    const int nxb = (int)((a.Sq + FQ - 1) / FQ);
     const int nwx = a.persist ? nxb / 2 : nxb;
     const unsigned lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)smem;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int dbytes = D64 ? 128 : 256;
+    // what the stream's descriptors may touch: K / V rows below Skv (bytes from the head's base; rows beyond read as zeros)
+    const unsigned kvn = (unsigned)((a.Skv - 1) * a.lk.sr + dbytes);
     const float c = a.scale_log2e, defer = a.defer; // (kernel arguments are scalar registers; a float product formed here would be a vector one)
     const int qsr = (int)a.lq.sr, kvsr = (int)a.lk.sr, osr = (int)a.lo.sr;
     // (a.nvwg virtual workgroups over gridDim.x real ones: KF_ATTN_GRID_WGS, an experiment - default one each. A stride of a multiple of 8 keeps
@@ -629,7 +646,9 @@ __global__ __launch_bounds__(256) void attn_fwd_w4_kernel(const AttnArgs a) {
         const char *qp = qh + q0 * a.lq.sr;
         char *op = oh + q0 * a.lo.sr;
         float *lsep = a.lse ? a.lse + bh * a.Sq + q0 : nullptr;
-        const int T = (int)((q0 + FQ) / ABK); // key tiles of this block: up to its last query's diagonal
+        const int T = (int)((q0 + FQ) / ABK); // key tiles of this block: up to its last query's diagonal (tiles beyond Skv arrive as zeros)
+        const int64_t qrows = a.Sq - q0 < FQ ? a.Sq - q0 : FQ; // the block's rows that exist: Q rows beyond them read as zeros, O / lse rows beyond are not stored
+        const unsigned qn = (unsigned)((qrows - 1) * a.lq.sr + dbytes), on = (unsigned)((qrows - 1) * a.lo.sr + dbytes), lsen = (unsigned)(qrows * 4);
         int mut = -1;
 #ifdef KF_MUTANT
         if (a.mutant == 1 && qblk == nxb - 1) mut = 1; // defect 1: the head's last block drops key tile 1
@@ -643,7 +662,7 @@ __global__ __launch_bounds__(256) void attn_fwd_w4_kernel(const AttnArgs a) {
 #endif
 #define KF_W4_OPERANDS                                                                                                              \
     [qp] "s"(qp), [kp] "s"(kp), [vp] "s"(vp), [op] "s"(op), [lsep] "s"(lsep), [qsr] "s"(qsr), [kvsr] "s"(kvsr), [osr] "s"(osr), [T] "s"(T), \
-        [wid] "s"(wid), [c] "s"(c), [defer] "s"(defer), [lds] "s"(lds), [mut] "s"(mut) KF_W4_EXTRA
+        [wid] "s"(wid), [c] "s"(c), [defer] "s"(defer), [lds] "s"(lds), [mut] "s"(mut), [kvn] "s"(kvn), [qn] "s"(qn), [on] "s"(on), [lsen] "s"(lsen) KF_W4_EXTRA
         if constexpr (D64 && BF) asm volatile(KF_FWD_W4_D64_ASM_BF16 : : KF_W4_OPERANDS : KF_FWD_W4_CLOBBERS);
         else if constexpr (D64) asm volatile(KF_FWD_W4_D64_ASM_F16 : : KF_W4_OPERANDS : KF_FWD_W4_CLOBBERS);
         else if constexpr (BF && SQ) asm volatile(KF_FWD_W4_ASM_BF16_SQ : : KF_W4_OPERANDS : KF_FWD_W4_CLOBBERS);
@@ -661,17 +680,19 @@ __global__ __launch_bounds__(256) void attn_fwd_w4_kernel(const AttnArgs a) {
 // ------------------------------------------------------------------------------------------
 template <bool BF, int R>
 __global__ __launch_bounds__(256) void attn_delta_kernel(const char *o, const char *d_o, float *delta, int64_t nrows, const float *lse, float *nlse,
-                                                         float *ndelta, float rscale, AttnArgs::Lay lo, AttnArgs::Lay ldo, int64_t S, int64_t H, int nparts) {
+                                                         float *ndelta, float rscale, AttnArgs::Lay lo, AttnArgs::Lay ldo, int64_t S, int64_t H, int nparts, int64_t Sc) {
     // 16 lanes per row, R rows per 16-lane group (rows row0 + 16 i): 2 R 16-byte loads in flight per lane
-    const int64_t row0 = (int64_t)blockIdx.x * (16 * R) + (threadIdx.x >> 4); // flat (b, h, s): the statistics stay [B, H, S] contiguous
+    // rows are numbered over [B H, Sc], Sc = S rounded up to 32: delta stays [B, H, S] contiguous, the two row-constant arrays are [B H, Sc] with
+    // ZERO pad rows (a ragged last slice of the dK/dV kernels reads its 32 constants: a zero constant beside a zero Q / dO row is harmless)
+    const int64_t row0 = (int64_t)blockIdx.x * (16 * R) + (threadIdx.x >> 4);
     const int part = threadIdx.x & 15;
     uint4 a[R], b[R];
 #pragma unroll
     for (int i = 0; i < R; ++i) {
         a[i] = b[i] = uint4{0, 0, 0, 0};
         const int64_t row = row0 + 16 * i;
-        if (row < nrows && part < nparts) { // nparts = D / 8 (16 | 8): 16-byte pieces of a row
-            const int64_t bh = row / S, sq = row - bh * S;
+        const int64_t bh = row / Sc, sq = row - bh * Sc;
+        if (row < nrows && sq < S && part < nparts) { // nparts = D / 8 (16 | 8): 16-byte pieces of a row
             a[i] = *(const uint4 *)(o + a_head(lo, bh, H) + sq * lo.sr + part * 16);
             b[i] = *(const uint4 *)(d_o + a_head(ldo, bh, H) + sq * ldo.sr + part * 16);
         }
@@ -695,10 +716,16 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const char *o, const ch
         }
         for (int msk = 8; msk > 0; msk >>= 1) acc += __shfl_xor(acc, msk, 64);
         if (row < nrows && part == 0) {
-            delta[row] = acc;
-            if (nlse) { // row constants of the dK/dV kernels: S' = Q K^T - lse / scale and dP' = dO V^T - delta come out of the MFMA chains ready
-                nlse[row] = -lse[row] * rscale;
-                ndelta[row] = -acc;
+            const int64_t bh = row / Sc, sq = row - bh * Sc;
+            if (sq < S) {
+                delta[bh * S + sq] = acc;
+                if (nlse) { // row constants of the dK/dV kernels: S' = Q K^T - lse / scale and dP' = dO V^T - delta come out of the MFMA chains ready
+                    nlse[row] = -lse[bh * S + sq] * rscale;
+                    ndelta[row] = -acc;
+                }
+            } else if (nlse) {
+                nlse[row] = 0.f;
+                ndelta[row] = 0.f;
             }
         }
     }
@@ -931,29 +958,32 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_ds_kernel(const AttnArgs a
     const int64_t q_end = q0 + FQ < a.Sq ? q0 + FQ : a.Sq;
     const int64_t kv_end = a.Skv < q_end ? a.Skv : q_end;
     const int nt = (int)((kv_end + ABK - 1) / ABK);
-    const char *dsg = a.ds + (((bh - a.bh0) * a.ds_nqb + qblk) * a.ds_nkwb * 8 + wid) * DS_TILE; // + kwb * 8 tiles (the workspace holds this launch's heads)
-    const int kwb_last = (int)(a.ds_nkwb - 1);
+    const char *dsg = a.ds + (bh - a.bh0) * a.ds_pair * DS_TILE; // this pair's tiles (the workspace holds this launch's heads)
+    const int kwb_last = (int)((a.Skv + 255) / 256 * 8 - 1);
+    const int slw = qblk * 8 + wid; // this wave's slice whether it has queries or not (the tile grid is padded to whole query blocks)
     auto stage = [&](int tile, int slot) { // 2 K pieces (this wave's share of the tile) + 4 dS pieces (its own two tiles)
         const int tl = tile < nt ? tile : nt - 1;
-        const char *kg = Kg + (int64_t)tl * ABK * a.lk.sr;
+        const int kfirst = tl * ABK, klast = (int)a.Skv - 1 - kfirst; // (rows of this tile that exist: 0 .. klast)
+        const char *kg = Kg + (int64_t)kfirst * a.lk.sr;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int row0 = (wid * 2 + i) * 4, row = row0 + krow;
             const int chunk = kpos ^ (((row & 3) << 2) | ((row >> 2) & 3));
+            // a key row beyond Skv (ragged last tile) is fetched from the tensor's LAST row instead: its dS column is exactly zero (it lies above every
+            // query's diagonal), so any finite K row serves - and that one is always there
+            const int srow = row < klast ? row : klast;
             if (D == AD || chunk < D / 8) // head size 64: see f_stage
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kg + row * a.lk.sr + chunk * 16),
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(kg + (int64_t)srow * a.lk.sr + chunk * 16),
                                                  (__attribute__((address_space(3))) void *)(smem + slot * FTILE + row0 * AROW), 16, 0, 0);
         }
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
             int kwb = 2 * tl + hf;
-            kwb = kwb < kwb_last ? kwb : kwb_last; // Skv % 64 == 32: the odd last key block has no partner (never consumed)
-#ifndef KF_DQ_FETCH_ALL
-            // key blocks above this wave's slice are never consumed (and were never written): fetch the slice's own last tile again instead -
-            // it came through a few steps ago, the bytes come from cache, not from HBM (this kernel is bound by its 4.3 GB of dS)
-            kwb = kwb <= sl ? kwb : (sl < kwb_last ? sl : kwb_last);
-#endif
-            const char *tg = dsg + (int64_t)kwb * 8 * DS_TILE;
+            kwb = kwb < kwb_last ? kwb : kwb_last;
+            // key blocks above this wave's slice are never consumed and have no tile (only the causal half is kept): fetch the slice's own last
+            // tile again instead - it came through a few steps ago, the bytes come from cache, not from HBM (this kernel is bound by its dS stream)
+            kwb = kwb <= slw ? kwb : (slw < kwb_last ? slw : kwb_last);
+            const char *tg = dsg + ds_tile_index(kwb, slw, a.ds_nqb) * DS_TILE;
 #pragma unroll
             for (int pc = 0; pc < 2; ++pc)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tg + ds_src[pc]),
@@ -980,7 +1010,8 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_ds_kernel(const AttnArgs a
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (active) a_store_rows<BF, DB>(smem + wid * 32 * OPAD, a.dq + a_head(a.ldq, bh, a.H) + qw * a.ldq.sr, dq, a.scale, a.ldq.sr);
+    if (active) a_store_rows<BF, DB>(smem + wid * 32 * OPAD, a.dq + a_head(a.ldq, bh, a.H) + qw * a.ldq.sr, dq, a.scale, a.ldq.sr,
+                                     (int)(a.Sq - qw < 32 ? a.Sq - qw : 32));
     if (a.persist) __syncthreads();
   }
 }
@@ -1271,13 +1302,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         soffq[i] = row * a.lq.sr + ch;
         soffd[i] = row * a.ldo.sr + ch;
     }
-    const float *rcg = lane < BQS ? a.nlse + bh * a.Sq + lane : a.ndelta + bh * a.Sq + lane - BQS;
+    const float *rcg = lane < BQS ? a.nlse + bh * a.Sqc + lane : a.ndelta + bh * a.Sqc + lane - BQS;
     const int ns = (int)(a.Sq / BQS), np = ns / 2;
     // dS tiles of this wave's 32 keys: tile (qb, kwb, sl) of the workspace, lane (key xl, half hl) writes operand s at
     // s * 1024 + xl * 32 + hl * 16 (see DS_TILE)
     unsigned ds_lane = (unsigned)(xl * 32 + hl * 16);
-    const char *ds_base = DS ? a.ds + (((bh - a.bh0) * a.ds_nqb * a.ds_nkwb + (kw >> 5)) * 8) * DS_TILE : nullptr; // + (qb nkwb 8 + sl) tiles per slice
-    const int ds_qb_tiles = (int)(a.ds_nkwb * 8);
+    // this wave's 32-key block kwb = kw / 32 of the pair: tile (kwb, sl) = ds_tile_index; + 8 tiles per slice from slice 8 (kwb / 8) on
+    const char *ds_base = DS ? a.ds + ((bh - a.bh0) * a.ds_pair + ds_tile_index(kw >> 5, 8 * (kw >> 8), a.ds_nqb)) * DS_TILE : nullptr;
+    const int ds_sl0 = 8 * (int)(kw >> 8);
     // a pair is 10 DMA operations per wave (ids 0..9: slice id / 5; Q rows i, dO rows i for i = 0, 1, then the row
     // constants); they are issued ONE per quarter-phase (an LDS-DMA instruction holds the wave's issue for 60-180 cycles,
     // which a lone wave per SIMD can only hide under MFMAs already queued)
@@ -1365,7 +1397,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
 
     // SOFF: this slice's offset inside its pair buffer (bases e, o, t0, t1, l); the next slice's first groups are read off
     // (en, on, ln) + NOFF; LAST: the slice that ends a pair (barrier + DMA of the pair after next before its q6)
-    auto slice_body = [&, ds_lane, ds_base, ds_qb_tiles](auto mask_c, auto soff_c, auto noff_c, auto last_c, unsigned e, unsigned o, unsigned t0,
+    auto slice_body = [&, ds_lane, ds_base, ds_sl0](auto mask_c, auto soff_c, auto noff_c, auto last_c, unsigned e, unsigned o, unsigned t0,
                           unsigned t1, unsigned l, unsigned en, unsigned on, unsigned ln, int64_t qs, int pr, int it) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(mask_c)::value, LAST = decltype(last_c)::value;
         constexpr int SOFF = decltype(soff_c)::value, NOFF = decltype(noff_c)::value, DO = SOFF + BQS * AROW;
@@ -1487,7 +1519,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         uint64_t tb = 0;
         if constexpr (DS) {
             const int sl_ = (int)(qs >> 5);
-            const char *tile = ds_base + ((int64_t)((sl_ >> 3) * ds_qb_tiles + (sl_ & 7)) << 11); // 32-bit tile index, DS_TILE = 2^11
+            const char *tile = ds_base + ((int64_t)((sl_ - ds_sl0) * 8) << 11); // DS_TILE = 2^11
             tb = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile) |
                  ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)tile >> 32)) << 32);
         }
@@ -1540,7 +1572,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     //   | p5: its Q rows (-> p0) | p6: its dP constants (-> p2) | p7: its dO rows (-> p2; carried in g1)
     // counted waits (reads issued after the awaited group): p0 8, p2 8, p4 12, p5 12, p6 12, p7 12. The pair barrier sits in front of
     // p4: everything read after it belongs to the next pair's buffer when the slice is a pair's last.
-    auto slice_body64 = [&, ds_lane, ds_base, ds_qb_tiles](auto mask_c, auto soff_c, auto noff_c, auto last_c, unsigned e, unsigned o, unsigned t0,
+    auto slice_body64 = [&, ds_lane, ds_base, ds_sl0](auto mask_c, auto soff_c, auto noff_c, auto last_c, unsigned e, unsigned o, unsigned t0,
                             unsigned t1, unsigned l, unsigned en, unsigned on, unsigned ln, int64_t qs, int pr, int it) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(mask_c)::value, LAST = decltype(last_c)::value;
         constexpr int SOFF = decltype(soff_c)::value, NOFF = decltype(noff_c)::value, DO = SOFF + BQS * AROW, NDO = NOFF + BQS * AROW;
@@ -1596,7 +1628,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         uint64_t tb = 0;
         if constexpr (DS) {
             const int sl_ = (int)(qs >> 5);
-            const char *tile = ds_base + ((int64_t)((sl_ >> 3) * ds_qb_tiles + (sl_ & 7)) << 11);
+            const char *tile = ds_base + ((int64_t)((sl_ - ds_sl0) * 8) << 11);
             tb = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile) |
                  ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)tile >> 32)) << 32);
         }
@@ -1736,14 +1768,17 @@ template <bool BF, bool DS, bool SQ, bool D64 = false>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) {
     static_assert(!(SQ && D64), "the scaled-K form exists for head size 128 only");
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int nkb = (int)(a.Skv / K5B), nwx = a.persist ? nkb / 2 : nkb;
+    const int nkb = (int)((a.Skv + K5B - 1) / K5B), nwx = a.persist ? nkb / 2 : nkb;
     const unsigned lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char *)smem;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned cdelta = (unsigned)((const char *)a.ndelta - (const char *)a.nlse);
     const int qsr = (int)a.lq.sr, dosr = (int)a.ldo.sr, kvsr = (int)a.lk.sr, osr = (int)a.ldk.sr;
     const float scale = SQ ? a.scale : a.scale_log2e; // (what the stream multiplies by: K once per block | every score in front of its exp2)
     const float scl = a.scale;                         // (dK = scale dS^T Q)
-    const int ns_all = (int)(a.Sq / BQS), dsqb = (int)(a.ds_nkwb * 8);
+    const int ns_all = (int)((a.Sq + BQS - 1) / BQS);
+    const int dbytes = D64 ? 128 : 256;
+    // what the stream's descriptors may touch (bytes from their bases; gen_attn_dkv.py prologue): Q / dO rows below Sq, this block's K / V / dK / dV rows below Skv
+    const unsigned qn = (unsigned)((a.Sq - 1) * a.lq.sr + dbytes), don = (unsigned)((a.Sq - 1) * a.ldo.sr + dbytes);
 #ifdef KF_DKV_W4_STAMPS // (the diagnostic build clobbers 22 more scalar registers: no room for the loop's state beside the stream's inputs)
     {
         const unsigned vwg = blockIdx.x;
@@ -1758,16 +1793,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) 
     const char *qp = a.q + a_head(a.lq, bh, a.H), *dop = a.d_o + a_head(a.ldo, bh, a.H);
     const char *kh = a.k + a_head(a.lk, bh, a.H), *vh = a.v + a_head(a.lv, bh, a.H);
     char *dkh = a.dk + a_head(a.ldk, bh, a.H), *dvh = a.dv + a_head(a.ldv, bh, a.H);
-    const float *cp = a.nlse + bh * a.Sq;
+    const float *cp = a.nlse + bh * a.Sqc;
 #pragma nounroll
     for (int pass = 0; pass < (a.persist ? 2 : 1); ++pass) {
         const int xb = ((pass & 1) != (a.persist_rev != 0)) ? nkb - 1 - xb0 : xb0;
         const int64_t k0 = (int64_t)xb * K5B;
         const char *kp = kh + k0 * a.lk.sr, *vp = vh + k0 * a.lv.sr;
         char *dkp = dkh + k0 * a.ldk.sr, *dvp = dvh + k0 * a.ldv.sr;
+        const int64_t krows = a.Skv - k0 < K5B ? a.Skv - k0 : K5B; // the block's keys that exist
+        const unsigned kn = (unsigned)((krows - 1) * a.lk.sr + dbytes), on = (unsigned)((krows - 1) * a.ldk.sr + dbytes);
         const int s0 = (int)(k0 / BQS);                    // the first slice with a query that sees one of the block's keys
         const int ns = ns_all;                             // (a block beyond the last query, s0 >= ns: no slices, zero gradients; the stream clamps its first requests to slice ns - 1)
-        const char *dsp = DS ? a.ds + (((bh - a.bh0) * a.ds_nqb * a.ds_nkwb + (k0 >> 5)) * 8) * DS_TILE : nullptr;
+        // this block's area of the dS workspace: its slices from s0 on, 8 tiles (16 KiB) each (ds_tile_index)
+        const char *dsp = DS ? a.ds + ((bh - a.bh0) * a.ds_pair + ds_block_base(xb, a.ds_nqb)) * DS_TILE : nullptr;
         int mut = -1;
 #ifdef KF_MUTANT
         if (a.mutant == 2 && xb == 0 && wid < 2) mut = 4; // defect 2: queries 128..159 contribute nothing to keys 0..127
@@ -1780,8 +1818,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) 
 #endif
 #define KF_DKV_OPERANDS                                                                                                                       \
     [qp] "s"(qp), [dop] "s"(dop), [kp] "s"(kp), [vp] "s"(vp), [dkp] "s"(dkp), [dvp] "s"(dvp), [cp] "s"(cp), [dsp] "s"(dsp), [cdelta] "s"(cdelta), \
-        [qsr] "s"(qsr), [dosr] "s"(dosr), [kvsr] "s"(kvsr), [osr] "s"(osr), [s0] "s"(s0), [ns] "s"(ns), [dsqb] "s"(dsqb), [wid] "s"(wid),       \
-        [scale] "s"(scale), [scl] "s"(scl), [lds] "s"(lds), [mut] "s"(mut) KF_DKV_EXTRA
+        [qsr] "s"(qsr), [dosr] "s"(dosr), [kvsr] "s"(kvsr), [osr] "s"(osr), [s0] "s"(s0), [ns] "s"(ns), [wid] "s"(wid),       \
+        [scale] "s"(scale), [scl] "s"(scl), [lds] "s"(lds), [mut] "s"(mut), [qn] "s"(qn), [don] "s"(don), [kn] "s"(kn), [on] "s"(on) KF_DKV_EXTRA
 #define KF_DKV_ASM(TEXT) asm volatile(TEXT : : KF_DKV_OPERANDS : KF_DKV_W4_CLOBBERS)
         if constexpr (D64) {
             if constexpr (BF && DS) KF_DKV_ASM(KF_DKV_W4_D64_ASM_BF16_DS);
@@ -2452,6 +2490,12 @@ __global__ __launch_bounds__(256) void attn_bwd_generic_kernel(const AttnArgs a)
 static bool mfma_ok(int dtype, int64_t Sq, int64_t Skv, int64_t D) {
     return (dtype == KF_BF16 || dtype == KF_F16) && (D == AD || D == 64) && Sq % 128 == 0 && Skv % 128 == 0 && Sq > 0 && Skv > 0;
 }
+// Round 6: the generated streams (attn_fwd_w4 / attn_bwd_dkv_w4) and the stored-dS dQ kernel take ANY sequence lengths with Skv >= Sq - rows
+// beyond a tensor's end are zero-filled / dropped by the buffer descriptors' range check, and a zero key lies above every real query's
+// diagonal when Skv >= Sq (with fewer keys than queries a ragged key count would need a key-length mask: those shapes keep the tiers below).
+static bool w4_any_ok(int dtype, int64_t Sq, int64_t Skv, int64_t D) {
+    return (dtype == KF_BF16 || dtype == KF_F16) && (D == AD || D == 64) && Sq > 0 && Skv >= Sq;
+}
 
 static inline size_t a_align(size_t v) { return (v + 255) / 256 * 256; }
 
@@ -2461,7 +2505,10 @@ static inline size_t a_align(size_t v) { return (v + 255) / 256 * 256; }
 // cannot hold one pair's dS - or KF_ATTN_SPLIT_BWD - selects the recomputing dQ kernel, whose workspace is the statistics alone.
 // kf_attn_bwd_workspace_bytes recommends statistics + min(all of dS, KF_ATTN_DS_CAP_MB (default 16 GiB)): the workspace is bounded
 // whatever B, H and S are, and ANY size >= the statistics is accepted (both head sizes, every S).
-static size_t bwd_stats_bytes(int64_t nbh, int64_t Sq) { return 3 * a_align((size_t)nbh * Sq * sizeof(float)); }
+static inline int64_t stat_rows(int64_t Sq) { return (Sq + 31) / 32 * 32; } // rows per head of the row-constant arrays (AttnArgs::Sqc)
+static size_t bwd_stats_bytes(int64_t nbh, int64_t Sq) { // delta [B H, Sq] | -lse / scale [B H, Sqc] | -delta [B H, Sqc]
+    return a_align((size_t)nbh * Sq * sizeof(float)) + 2 * a_align((size_t)nbh * stat_rows(Sq) * sizeof(float));
+}
 static int64_t ds_group(int64_t nbh, int64_t Sq, int64_t Skv, size_t budget) { // pairs whose dS fit into `budget` bytes
     const size_t one = ds_bytes(1, Sq, Skv);
     int64_t g = (int64_t)(budget / one);
@@ -2517,8 +2564,8 @@ extern "C" int kf_attn_fwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, i
 extern "C" int kf_attn_fwd_strided(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D, float scale, const void *q,
                                    const kf_attn_layout *lq, const void *k, const kf_attn_layout *lk, const void *v, const kf_attn_layout *lv,
                                    void *o, const kf_attn_layout *lo, float *lse, void *stream) {
-    KF_REQUIRE(mfma_ok(dtype, Sq, Skv, D), KF_ERR_UNSUPPORTED,
-               "kf_attn_fwd_strided: strided layouts are served by the 16-bit matrix-core kernels only (D = 64 or 128, Sq, Skv multiples of 128)");
+    KF_REQUIRE(mfma_ok(dtype, Sq, Skv, D) || w4_any_ok(dtype, Sq, Skv, D), KF_ERR_UNSUPPORTED,
+               "kf_attn_fwd_strided: strided layouts are served by the 16-bit matrix-core kernels only (D = 64 or 128; Skv >= Sq, or Sq, Skv multiples of 128)");
     AttnArgs::Lay lays[4];
     KF_REQUIRE(lay_from(lq, 2, lays[0]) && lay_from(lk, 2, lays[1]) && lay_from(lv, 2, lays[2]) && lay_from(lo, 2, lays[3]), KF_ERR_INVALID,
                "kf_attn_fwd_strided: strides must be non-negative multiples of 8 elements");
@@ -2553,7 +2600,10 @@ static int attn_fwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
 #endif
     if (lays) { a.lq = lays[0]; a.lk = lays[1]; a.lv = lays[2]; a.lo = lays[3]; }
     else { a.lq = a.lo = lay_contig(H, Sq, D, 2); a.lk = a.lv = lay_contig(H, Skv, D, 2); }
-    if (mfma_ok(dtype, Sq, Skv, D)) {
+    // the generated stream's shape conditions (KF_ATTN_FWD_V3 keeps the 8-wave kernel where that one can run: A/B)
+    const bool fwd_w4 = w4_any_ok(dtype, Sq, Skv, D) && a.lk.sr == a.lv.sr && (uint64_t)(Skv + FQ) * (uint64_t)a.lk.sr < (1ull << 32) &&
+                        (uint64_t)FQ * (uint64_t)std::max(a.lq.sr, a.lo.sr) < (1ull << 31) && !knob(KNOB_ATTN_FWD_V3);
+    if (mfma_ok(dtype, Sq, Skv, D) || fwd_w4) {
         const size_t lds3 = SRING * FBUF;
         const int64_t nxb3 = (Sq + FQ - 1) / FQ;
         a.persist = (nxb3 % 2 == 0 && nxb3 >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
@@ -2563,8 +2613,7 @@ static int attn_fwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
         if (const long gw = knob_int(KNOB_ATTN_GRID_WGS, 0); gw >= 8 && (unsigned)gw < grid3.x) grid3w.x = (unsigned)(gw / 8 * 8);
         KF_PROF(D == 64 ? "attn_fwd_mfma_d64" : "attn_fwd_mfma", st);
         // round 4: the one-wave-per-SIMD stream (attn_fwd_w4_kernel) wherever its shape conditions hold; KF_ATTN_FWD_V3 keeps the 8-wave kernel (A/B)
-        if ((D == AD || D == 64) && Sq % FQ == 0 && Skv >= Sq && a.lk.sr == a.lv.sr && (uint64_t)Skv * (uint64_t)a.lk.sr < (1ull << 32) &&
-            (uint64_t)FQ * (uint64_t)std::max(a.lq.sr, a.lo.sr) < (1ull << 31) && !knob(KNOB_ATTN_FWD_V3)) {
+        if (fwd_w4) {
 #define KF_FWD4(BF_, SQ_)                                                                                   \
     {                                                                                                       \
         if ((rc = set_lds(attn_fwd_w4_kernel<BF_, SQ_>, KF_FWD_W4_LDS_BYTES)) != KF_OK) return rc;           \
@@ -2596,6 +2645,8 @@ static int attn_fwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
         KF_LAUNCH_CHECK();
         return KF_OK;
     }
+    // (from here on: kernels of contiguous [B, H, S, D] tensors only)
+    KF_REQUIRE(!lays, KF_ERR_UNSUPPORTED, "kf_attn_fwd_strided: this shape / stride combination has no matrix-core kernel (ragged lengths want K and V with one row stride)");
     if (dtype == KF_F32 && (D == 64 || D == 128) && Sq % 32 == 0 && Skv % 32 == 0 && !knob(KNOB_ATTN_F32_GENERIC)) {
         // the reference's own fast path (f32, head size 64 or 128): exact-f32 MFMA
         const size_t ldsx = std::max((size_t)2 * XK * (D + 4), (size_t)4 * 32 * (D + 4)) * sizeof(float);
@@ -2644,7 +2695,7 @@ extern "C" int kf_attn_bwd_workspace_bytes(int dtype, int64_t B, int64_t H, int6
     int rc = check_common("kf_attn_bwd_workspace_bytes", dtype, B, H, Sq, Skv, D);
     if (rc != KF_OK) return rc;
     *bytes = bwd_stats_bytes(B * H, Sq); // delta | -lse log2(e) | -delta
-    if (mfma_ok(dtype, Sq, Skv, D) && !knob(KNOB_ATTN_SPLIT_BWD) && B * H > 0)
+    if ((mfma_ok(dtype, Sq, Skv, D) || w4_any_ok(dtype, Sq, Skv, D)) && !knob(KNOB_ATTN_SPLIT_BWD) && B * H > 0)
         *bytes += ds_bytes(ds_group(B * H, Sq, Skv, ds_cap()), Sq, Skv); // + dS in 16 bits (DS_TILE) of one group of pairs
     return KF_OK;
 }
@@ -2671,8 +2722,8 @@ extern "C" int kf_attn_bwd_strided(int dtype, int64_t B, int64_t H, int64_t Sq, 
                                    const void *o, const kf_attn_layout *lo, const float *lse, const void *d_o, const kf_attn_layout *ldo, void *dq,
                                    const kf_attn_layout *ldq, void *dk, const kf_attn_layout *ldk, void *dv, const kf_attn_layout *ldv,
                                    void *workspace, size_t workspace_bytes, void *stream) {
-    KF_REQUIRE(mfma_ok(dtype, Sq, Skv, D), KF_ERR_UNSUPPORTED,
-               "kf_attn_bwd_strided: strided layouts are served by the 16-bit matrix-core kernels only (D = 64 or 128, Sq, Skv multiples of 128)");
+    KF_REQUIRE(mfma_ok(dtype, Sq, Skv, D) || w4_any_ok(dtype, Sq, Skv, D), KF_ERR_UNSUPPORTED,
+               "kf_attn_bwd_strided: strided layouts are served by the 16-bit matrix-core kernels only (D = 64 or 128; Skv >= Sq, or Sq, Skv multiples of 128)");
     AttnArgs::Lay lays[8];
     const kf_attn_layout *in[8] = {lq, lk, lv, lo, ldo, ldq, ldk, ldv};
     for (int i = 0; i < 8; ++i)
@@ -2697,8 +2748,9 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
     a.q = (const char *)q; a.k = (const char *)k; a.v = (const char *)v; a.o = (const char *)o; a.d_o = (const char *)d_o;
     a.dq = (char *)dq; a.dk = (char *)dk; a.dv = (char *)dv;
     a.lse_r = lse; a.delta = (float *)workspace;
+    a.Sqc = stat_rows(Sq);
     a.nlse = (float *)((char *)workspace + a_align((size_t)B * H * Sq * sizeof(float)));
-    a.ndelta = (float *)((char *)workspace + 2 * a_align((size_t)B * H * Sq * sizeof(float)));
+    a.ndelta = (float *)((char *)a.nlse + a_align((size_t)B * H * a.Sqc * sizeof(float)));
     a.xcd_map = ((B * H) % 8 == 0) && !knob(KNOB_ATTN_NO_XCD);
     a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.D = D;
     a.nbh = (int)(B * H);
@@ -2715,12 +2767,16 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
     if (lays) { a.lq = lays[0]; a.lk = lays[1]; a.lv = lays[2]; a.lo = lays[3]; a.ldo = lays[4]; a.ldq = lays[5]; a.ldk = lays[6]; a.ldv = lays[7]; }
     else { a.lq = a.lo = a.ldo = a.ldq = lay_contig(H, Sq, D, 2); a.lk = a.lv = a.ldk = a.ldv = lay_contig(H, Skv, D, 2); }
     const int64_t nrows = B * H * Sq;
-    if (mfma_ok(dtype, Sq, Skv, D)) {
+    const bool tiled = mfma_ok(dtype, Sq, Skv, D); // whole 128-row tiles: every 16-bit matrix-core kernel can run
+    // round 4: 64 keys per wave (attn_bwd_dkv_w4_kernel) wherever its shape conditions hold; KF_ATTN_DKV_V4 keeps the 32-key kernel (A/B).
+    // round 6: any Sq, Skv with Skv >= Sq (w4_any_ok: rows beyond a tensor's end are zero-filled / dropped by the descriptors)
+    const bool dkv_w4 = ((tiled && Skv % K5B == 0) || w4_any_ok(dtype, Sq, Skv, D)) && a.lk.sr == a.lv.sr && a.ldk.sr == a.ldv.sr &&
+                        (uint64_t)(Sq + 32) * (uint64_t)std::max(a.lq.sr, a.ldo.sr) < (1ull << 32) && (uint64_t)K5B * (uint64_t)std::max(a.lk.sr, a.ldk.sr) < (1ull << 31) &&
+                        (uint64_t)((const char *)a.ndelta - (const char *)a.nlse) < (1ull << 31) && !knob(KNOB_ATTN_DKV_V4);
+    // a ragged shape has no other matrix-core kernels: it needs the generated dK/dV stream AND room for dS (the recomputing dQ kernel wants whole tiles)
+    const bool ragged_ok = !tiled && dkv_w4 && !knob(KNOB_ATTN_SPLIT_BWD) && ds_group(B * H, Sq, Skv, workspace_bytes - need) > 0;
+    if (tiled || ragged_ok) {
         const bool bf = dtype == KF_BF16;
-        // round 4: 64 keys per wave (attn_bwd_dkv_w4_kernel) wherever its shape conditions hold; KF_ATTN_DKV_V4 keeps the 32-key kernel (A/B)
-        const bool dkv_w4 = (D == AD || D == 64) && Skv % K5B == 0 && a.lk.sr == a.lv.sr && a.ldk.sr == a.ldv.sr && (uint64_t)Sq * (uint64_t)std::max(a.lq.sr, a.ldo.sr) < (1ull << 32) &&
-                            (uint64_t)K5B * (uint64_t)std::max(a.lk.sr, a.ldk.sr) < (1ull << 31) && (uint64_t)((const char *)a.ndelta - (const char *)a.nlse) < (1ull << 31) &&
-                            !knob(KNOB_ATTN_DKV_V4);
         // exact f32 scores everywhere by default (exponent = (s - lse / scale) * scale log2 e: the row constant is -lse / scale); only the opt-in
         // scaled-K form of the generated stream scales K by scale log2 e once per block and wants -lse log2 e
         const bool dkv_sq = dkv_w4 && D == AD && knob(KNOB_ATTN_SCALED_OPERANDS);
@@ -2728,9 +2784,10 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
         {
             KF_PROF("attn_bwd_delta", st);
             // two rows per 16-lane group (four 16-byte loads in flight per lane): 0.110 -> 0.101 ms at C3; four rows: 0.100
-            const unsigned gd2 = (unsigned)((nrows + 31) / 32);
-            if (bf) attn_delta_kernel<true, 2><<<gd2, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, rscale, a.lo, a.ldo, Sq, H, (int)(D / 8));
-            else attn_delta_kernel<false, 2><<<gd2, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows, a.lse_r, a.nlse, a.ndelta, rscale, a.lo, a.ldo, Sq, H, (int)(D / 8));
+            const int64_t nrows_c = B * H * a.Sqc;   // (rows of the padded row-constant arrays: the pad rows are written as zeros)
+            const unsigned gd2 = (unsigned)((nrows_c + 31) / 32);
+            if (bf) attn_delta_kernel<true, 2><<<gd2, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows_c, a.lse_r, a.nlse, a.ndelta, rscale, a.lo, a.ldo, Sq, H, (int)(D / 8), a.Sqc);
+            else attn_delta_kernel<false, 2><<<gd2, 256, 0, st>>>(a.o, a.d_o, a.delta, nrows_c, a.lse_r, a.nlse, a.ndelta, rscale, a.lo, a.ldo, Sq, H, (int)(D / 8), a.Sqc);
             KF_LAUNCH_CHECK();
         }
         const int64_t nbh = B * H;
@@ -2738,7 +2795,7 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
         const bool keep_ds = group > 0;
         a.ds = keep_ds ? (char *)workspace + need : nullptr;
         a.ds_nqb = (Sq + 255) / 256;
-        a.ds_nkwb = Skv / 32;
+        a.ds_pair = ds_pair_tiles(Sq, Skv);
         const int64_t nkb4 = Skv / K4B, nxq = (Sq + FQ - 1) / FQ;
         const int pair_kv = (nkb4 % 2 == 0 && nkb4 >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
         const int pair_q = (nxq % 2 == 0 && nxq >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
@@ -2772,7 +2829,7 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
                 a.persist_rev = 1; // the short block of the pair first: 2.17 ms against 2.32 the other way round (2.22 unpaired)
                 dim3 gk4((unsigned)((a.persist ? nkb4 / 2 : nkb4) * a.nbh));
                 KF_PROF(D == 64 ? "attn_bwd_dkv_mfma_d64" : "attn_bwd_dkv_mfma", st);
-                const int64_t nkb5 = Skv / K5B;
+                const int64_t nkb5 = (Skv + K5B - 1) / K5B;
                 if (dkv_w4) {
                     a.persist = (nkb5 % 2 == 0 && nkb5 >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
                     dim3 gk5((unsigned)((a.persist ? nkb5 / 2 : nkb5) * a.nbh));
@@ -2821,6 +2878,8 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
 #undef KF_DQ2
         return KF_OK;
     }
+    // (from here on: kernels of contiguous [B, H, S, D] tensors only)
+    KF_REQUIRE(!lays, KF_ERR_UNSUPPORTED, "kf_attn_bwd_strided: this shape / stride / workspace combination has no matrix-core kernel (ragged lengths want room for dS)");
     const unsigned gd = (unsigned)((nrows + 3) / 4);
     if (dtype == KF_F32 && (D == 64 || D == 128) && Sq % 32 == 0 && Skv % 32 == 0 && !knob(KNOB_ATTN_F32_GENERIC)) {
         // exact-f32 MFMA backward (the f32 forward's counterpart; the reference has no backward)

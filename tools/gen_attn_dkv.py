@@ -59,7 +59,7 @@ S_QOFF, S_DOOFF, S_COFF, S_QSTEP, S_DOSTEP, S_QMAX, S_DOMAX, S_CMAX = 52, 53, 54
 S_M0, S_IT, S_NS, S_D0, S_TMP, S_TMP2 = 60, 61, 62, 63, 64, 65
 S_DS0, S_DS1 = 66, 68   # pairs
 S_SL, S_STAGE = 70, 71
-S_DSQB, S_WID, S_LDS, S_SCALE, S_MUT, S_OSR = "%[dsqb]", "%[wid]", "%[lds]", "%[scale]", "%[mut]", "%[osr]"   # read-only inputs: used in place
+S_WID, S_LDS, S_SCALE, S_MUT, S_OSR = "%[wid]", "%[lds]", "%[scale]", "%[mut]", "%[osr]"   # read-only inputs: used in place
 S_X0, S_X1 = 72, 73
 S_DSB = 74              # pair: dS base of this wave's first key sub-block at slice 0 of the workspace
 V_SRD = 76             # 4-aligned quad: the V fragments' descriptor (prologue only)
@@ -324,22 +324,9 @@ class Gen:
                 if ksb not in ksbs:
                     continue
                 nst += 1
-                base = S_DS0 if ksb == 0 else S_DS1
-                put(g, (5, 0), lambda ksb=ksb, s=s, base=base: self.out.append(
-                    Ins(f"global_store_dwordx4 {vr(DSOFF)}, {vr(DSP(ksb, s), 4)}, {sr(base, 2)} offset:{1024 * s} {self.store_policy}", "vmem", V(DSOFF) + V(DSP(ksb, s), 4))))
-        def ds_next():   # the dS tile addresses of the next slice: sl + 1; a new 256-query block every 8 slices
-            self.salu(f"s_add_u32 {sr(S_SL)}, {sr(S_SL)}, 1")
-            self.salu(f"s_lshr_b32 {sr(S_TMP)}, {sr(S_SL)}, 3")
-            self.salu(f"s_mul_i32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_DSQB)}")
-            self.salu(f"s_and_b32 {sr(S_TMP2)}, {sr(S_SL)}, 7")
-            self.salu(f"s_add_u32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_TMP2)}")
-            self.salu(f"s_lshr_b32 {sr(S_TMP2)}, {sr(S_TMP)}, {32 - 11}")
-            self.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_TMP)}, 11")
-            self.salu(f"s_add_u32 {sr(S_DS0)}, {sr(S_DSB)}, {sr(S_TMP)}")
-            self.salu(f"s_addc_u32 {sr(S_DS0 + 1)}, {sr(S_DSB + 1)}, {sr(S_TMP2)}")
-            self.salu(f"s_add_u32 {sr(S_DS1)}, {sr(S_DS0)}, {8 * DS_TILE}")
-            self.salu(f"s_addc_u32 {sr(S_DS1 + 1)}, {sr(S_DS0 + 1)}, 0")
-        put(12 if self.early else 62, (6, 0), ds_next)
+                put(g, (5, 0), lambda ksb=ksb, s=s: self.out.append(
+                    Ins(f"global_store_dwordx4 {vr(DSOFF)}, {vr(DSP(ksb, s), 4)}, {sr(S_DS0, 2)} offset:{DS_TILE * ksb + 1024 * s} {self.store_policy}", "vmem", V(DSOFF) + V(DSP(ksb, s), 4))))
+        put(12 if self.early else 62, (6, 0), self.ds_next)
 
         self.label(f"L_{name}_%=")
         for g in range(64):
@@ -495,9 +482,8 @@ class Gen:
                 if ksb not in ksbs:
                     continue
                 nst += 1
-                base = S_DS0 if ksb == 0 else S_DS1
-                put(g, (5, 0), lambda ksb=ksb, s_=s_, base=base: self.out.append(
-                    Ins(f"global_store_dwordx4 {vr(DSOFF)}, {vr(DSP(ksb, s_), 4)}, {sr(base, 2)} offset:{1024 * s_} {self.store_policy}", "vmem", V(DSOFF) + V(DSP(ksb, s_), 4))))
+                put(g, (5, 0), lambda ksb=ksb, s_=s_: self.out.append(
+                    Ins(f"global_store_dwordx4 {vr(DSOFF)}, {vr(DSP(ksb, s_), 4)}, {sr(S_DS0, 2)} offset:{DS_TILE * ksb + 1024 * s_} {self.store_policy}", "vmem", V(DSOFF) + V(DSP(ksb, s_), 4))))
         put(31, (6, 0), self.ds_next)
 
         self.label(f"L_{name}_%=")
@@ -529,18 +515,11 @@ class Gen:
         self.stores_of[kind] = nst
 
     def ds_next(self):
-        """The dS tile addresses of the next slice: sl + 1; a new 256-query block every 8 slices."""
-        self.salu(f"s_add_u32 {sr(S_SL)}, {sr(S_SL)}, 1")
-        self.salu(f"s_lshr_b32 {sr(S_TMP)}, {sr(S_SL)}, 3")
-        self.salu(f"s_mul_i32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_DSQB)}")
-        self.salu(f"s_and_b32 {sr(S_TMP2)}, {sr(S_SL)}, 7")
-        self.salu(f"s_add_u32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_TMP2)}")
-        self.salu(f"s_lshr_b32 {sr(S_TMP2)}, {sr(S_TMP)}, {32 - 11}")
-        self.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_TMP)}, 11")
-        self.salu(f"s_add_u32 {sr(S_DS0)}, {sr(S_DSB)}, {sr(S_TMP)}")
-        self.salu(f"s_addc_u32 {sr(S_DS0 + 1)}, {sr(S_DSB + 1)}, {sr(S_TMP2)}")
-        self.salu(f"s_add_u32 {sr(S_DS1)}, {sr(S_DS0)}, {8 * DS_TILE}")
-        self.salu(f"s_addc_u32 {sr(S_DS1 + 1)}, {sr(S_DS0 + 1)}, 0")
+        """The dS tiles of the next slice: the block's area of the workspace holds its slices one behind the other, 8 tiles (16 KiB) each -
+        this wave's two (key sub-blocks 2 w, 2 w + 1) are S_DS0 and S_DS0 + 2 KiB. (Round 6, the causal-half layout of attention.hip's
+        ds_tile_index: until then the address was eleven scalar instructions per slice.)"""
+        self.salu(f"s_add_u32 {sr(S_DS0)}, {sr(S_DS0)}, {8 * DS_TILE}")
+        self.salu(f"s_addc_u32 {sr(S_DS0 + 1)}, {sr(S_DS0 + 1)}, 0")
 
     # -------------------------------------------------------------- block pass
     def prologue(self):
@@ -551,19 +530,26 @@ class Gen:
             e.salu("s_memtime s[80:81]")
             e.salu("s_waitcnt lgkmcnt(0)")
             e.salu("s_mov_b32 s82, s80")
-        ins = [("qp", Q_SRD), ("dop", DO_SRD), ("cp", C_SRD)]
-        for nm, srd in ins:
+        # num_records (round 6: ragged sequence lengths): gfx950 range-checks voffset + soffset + the instruction offset against it
+        # (tools/scratch/buffer_bounds.hip): a Q / dO row beyond the last query and a K / V row beyond the last key arrive in LDS as ZEROS, a
+        # dK / dV row beyond the last key is not stored - no instruction in the loop. Zero rows contribute nothing: P of a zero query row is
+        # finite (its row constants are zero: the pre-pass pads them), times dO = 0 and Q = 0; a zero key lies above every real query's diagonal.
+        ins = [("qp", Q_SRD, "qn"), ("dop", DO_SRD, "don"), ("cp", C_SRD, None)]
+        for nm, srd, n in ins:
             e.salu(f"s_mov_b64 {sr(srd, 2)}, %[{nm}]")
-            e.salu(f"s_mov_b32 {sr(srd + 2)}, 0xffffffff")
+            e.salu(f"s_mov_b32 {sr(srd + 2)}, " + (f"%[{n}]" if n else "0xffffffff"))
             e.salu(f"s_mov_b32 {sr(srd + 3)}, 0x00020000")
-        e.salu(f"s_mov_b32 {sr(O_SRD + 2)}, 0xffffffff")
+        e.salu(f"s_mov_b32 {sr(O_SRD + 2)}, %[kn]")                              # (the K tiles' descriptor here; the epilogue's stores set their own)
         e.salu(f"s_mov_b32 {sr(O_SRD + 3)}, 0x00020000")
         for dst, src in ((S_NS, "ns"), (S_SL, "s0")):
             e.salu(f"s_mov_b32 {sr(dst)}, %[{src}]")
-        e.salu(f"s_mov_b64 {sr(S_DSB, 2)}, %[dsp]")
-        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 15")                      # this wave's first 32-key block of the dS tile grid: 2 w x 8 tiles of 2 KiB
-        e.salu(f"s_add_u32 {sr(S_DSB)}, {sr(S_DSB)}, {sr(S_TMP)}")
-        e.salu(f"s_addc_u32 {sr(S_DSB + 1)}, {sr(S_DSB + 1)}, 0")
+        e.salu(f"s_mov_b64 {sr(S_DS0, 2)}, %[dsp]")                             # the block's area of the dS workspace: slice s0's 8 tiles first
+        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 12")                      # this wave's two tiles of a slice: 2 w, 2 w + 1 (2 KiB each)
+        e.salu(f"s_add_u32 {sr(S_DS0)}, {sr(S_DS0)}, {sr(S_TMP)}")
+        e.salu(f"s_addc_u32 {sr(S_DS0 + 1)}, {sr(S_DS0 + 1)}, 0")
+        if self.early:                                                          # (the first slice's own gap 12 takes the step)
+            e.salu(f"s_sub_u32 {sr(S_DS0)}, {sr(S_DS0)}, {8 * DS_TILE}")
+            e.salu(f"s_subb_u32 {sr(S_DS0 + 1)}, {sr(S_DS0 + 1)}, 0")
         e.salu(f"s_lshl_b32 {sr(S_D0)}, {sr(S_WID)}, 1")                       # this wave's diagonal slices: 2 w and 2 w + 1 of the block's
         # DMA: slice s0's offsets, steps, saturation values
         e.salu(f"s_lshl_b32 {sr(S_QSTEP)}, %[qsr], 5")
@@ -619,7 +605,7 @@ class Gen:
         e.salu(f"s_lshl_b32 {sr(S_X1)}, %[kvsr], 3")                            # 8 rows further
         e.salu(f"s_mov_b64 {sr(O_SRD, 2)}, %[kp]")
         e.salu(f"s_mov_b64 {sr(V_SRD, 2)}, %[vp]")
-        e.salu(f"s_mov_b32 {sr(V_SRD + 2)}, 0xffffffff")
+        e.salu(f"s_mov_b32 {sr(V_SRD + 2)}, %[kn]")
         e.salu(f"s_mov_b32 {sr(V_SRD + 3)}, 0x00020000")
         e.salu(f"s_lshl_b32 {sr(S_TMP2)}, {sr(S_WID)}, 14")                     # 16 KiB per wave
         e.salu(f"s_add_u32 {sr(S_M0)}, {sr(S_LDS)}, {sr(S_TMP2)}")
@@ -741,11 +727,7 @@ class Gen:
                 e.valu(f"v_mul_f32 {vr(t0)}, {vr(t0)}, {vr(t2)}")
                 e.valu(f"v_mul_f32 {vr(t1)}, {vr(t1)}, {vr(t2)}")
                 e.valu(f"{self.cvt} {vr(x)}, {vr(t0)}, {vr(t1)}")
-        # dS tile bases of slice s0
-        e.salu(f"s_sub_u32 {sr(S_SL)}, {sr(S_SL)}, 1")
         self.in_loop = False
-        # (ds_next of the slice body, inline: advances S_SL to s0 and forms S_DS0 / S_DS1; early: the first slice's own gap 12 does)
-        if not self.early: self.ds_next()
         # ---- slice s0 has landed for everyone (slice s0 + 1's 5 pieces may still be in flight); the first slice's head state
         e.out.append(Ins(f"s_waitcnt vmcnt({5 if self.D == 128 else 6})", "wait", tag="vm"))    # (D = 128: slice s0 + 1's 5 pieces may be in flight; D = 64: two slices of 3)
         e.barrier()
@@ -837,6 +819,7 @@ class Gen:
                         e.out.append(Ins(f"ds_write_b64 {vr(st)}, {vr(x[0], 2)} offset:{32 * ksb * STAGE_ROW + 64 * db + 16 * gq}", "ldsw"))
             e.out.append(Ins("s_waitcnt lgkmcnt(0)", "wait", tag="lgkm"))
             e.salu(f"s_mov_b64 {sr(O_SRD, 2)}, %[{ptr}]")
+            e.salu(f"s_mov_b32 {sr(O_SRD + 2)}, %[on]")                        # rows beyond the last key are not stored
             e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 6")
             e.salu(f"s_mul_i32 {sr(S_X0)}, {sr(S_TMP)}, {sr(S_OSR)}")
             rows_per = 4 if self.D == 128 else 8                                    # rows one store instruction covers

@@ -470,8 +470,12 @@ class Gen:
         e.salu(f"s_mov_b64 {sr(V_SRD, 2)}, %[vp]")
         e.salu(f"s_mov_b64 {sr(Q_SRD, 2)}, %[qp]")
         e.salu(f"s_mov_b64 {sr(O_SRD, 2)}, %[op]")
-        for srd in (K_SRD, V_SRD, Q_SRD, O_SRD):
-            e.salu(f"s_mov_b32 {sr(srd + 2)}, 0xffffffff")
+        # num_records = the bytes of the tensor that lie behind the base (round 6: ragged sequence lengths). gfx950 range-checks voffset +
+        # soffset + the instruction offset against it (tools/scratch/buffer_bounds.hip, profiles/r06_buffer_bounds.txt): a K / V / Q row
+        # beyond the tensor's last one arrives in LDS as ZEROS (LDS-DMA included), an O row beyond it is not stored - a last query block of
+        # fewer than 256 rows and a last key tile of fewer than 64 keys cost no instruction (zero keys lie above every real query's diagonal)
+        for srd, n in ((K_SRD, "kvn"), (V_SRD, "kvn"), (Q_SRD, "qn"), (O_SRD, "on")):
+            e.salu(f"s_mov_b32 {sr(srd + 2)}, %[{n}]")
             e.salu(f"s_mov_b32 {sr(srd + 3)}, 0x00020000")
         e.salu(f"s_mov_b64 {sr(S_LSE, 2)}, %[lsep]")
         for dst, src in ((S_C, "c"), (S_DEFER, "defer"), (S_T, "T"), (S_KVSR, "kvsr"), (S_QSR, "qsr"), (S_OSR, "osr"), (S_WID, "wid"), (S_LDS, "lds"), (S_MUT, "mut")):
@@ -714,8 +718,11 @@ class Gen:
             e.valu(f"v_add_u32 {vr(t)}, {sr(S_TMP)}, {vr(t)}")
             e.salu(f"s_cmp_eq_u64 {sr(S_LSE, 2)}, 0")
             e.salu(f"s_cbranch_scc1 L_nolse{b}_%=")
+            if b == 0:   # through a descriptor of the block's valid rows (the K descriptor's registers: K is done with): rows beyond Sq are not stored
+                e.salu(f"s_mov_b64 {sr(K_SRD, 2)}, {sr(S_LSE, 2)}")
+                e.salu(f"s_mov_b32 {sr(K_SRD + 2)}, %[lsen]")
             e.salu("s_mov_b32 exec_hi, 0")
-            e.out.append(Ins(f"global_store_dword {vr(t)}, {vr(l)}, {sr(S_LSE, 2)}", "vmem", V(t) + V(l)))
+            e.out.append(Ins(f"buffer_store_dword {vr(l)}, {vr(t)}, {sr(K_SRD, 4)}, 0 offen", "vmem", V(t) + V(l)))
             e.salu("s_mov_b64 exec, -1")
             e.label(f"L_nolse{b}_%=")
         # O^T accumulators -> 16-bit rows of this wave's staging slab: lane (r, h) writes 4 consecutive d of query 32 b + r
