@@ -370,8 +370,9 @@ int kf_attn_fwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv,
  * dq,dk,dv from d_o. Needs o and lse from the forward. The workspace holds three f32 rows of statistics (delta[B,H,Sq] and the two
  * row-constant arrays the dK/dV kernel reads, the latter two with Sq rounded up to 32 rows per pair: B*H*(Sq + 2 ceil32(Sq))*4 bytes, each
  * array rounded up to 256 - the MINIMUM, O(B H S)) and, on the
- * matrix-core path for 16-bit tensors, whatever lies beyond them holds dS = P o (dP - delta) in 16 bits (Sq and Skv rounded up to 256:
- * ceil256(Sq) x ceil256(Skv) x 2 bytes per (batch, head) pair): the dK/dV kernel writes it, the dQ kernel computes dQ = scale dS K from it, so the backward
+ * matrix-core path for 16-bit tensors, whatever lies beyond them holds dS = P o (dP - delta) in 16 bits - only its causal half (round 6):
+ * with nq = ceil(Sq / 256) and nk = ceil(Skv / 256), one 128-KiB square per (query block, key block at or below its diagonal), i.e.
+ * nq (nq + 1) / 2 squares per (batch, head) pair when Sq = Skv: 17 MiB at S = 4096 where the rectangle took 32: the dK/dV kernel writes it, the dQ kernel computes dQ = scale dS K from it, so the backward
  * executes the 5 matrix products of the algorithm instead of 7. The pairs are processed in GROUPS of as many as the workspace holds
  * dS for, so ANY workspace_bytes >= the minimum is accepted, for both head sizes and every S: with room for less than one pair's dS
  * (or with KF_ATTN_SPLIT_BWD set) the dQ kernel recomputes S and dP instead (minimum workspace, 7 products).

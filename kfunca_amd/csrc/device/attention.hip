@@ -68,7 +68,7 @@ struct AttnArgs {
     int64_t bh0;     // backward, dS form: this launch covers the (batch, head) pairs bh0 .. bh0 + nbh - 1 (one group of the workspace cap)
     int nbh;         // pairs in this launch (forward and the other forms: B H, bh0 = 0)
     char *ds;        // backward: dS = P o (dP - delta) in 16 bits, written by the dK/dV kernel, read by the dQ kernel (null: not kept)
-    int64_t ds_nqb, ds_pair; // its tile grid (ds_tile_index below): 256-query blocks; tiles per (batch, head) pair
+    int64_t ds_nkb, ds_pair; // its tile grid (ds_tile_index below): 256-key blocks; tiles per (batch, head) pair
 #if defined(KF_FWD_W4_STAMPS) || defined(KF_DKV_W4_STAMPS)
     unsigned long long *dbg; // diagnostic builds (tools/attn_fwd_w4_timeline.py, attn_dkv_w4_timeline.py): where every wave writes its cycle sums
 #endif
@@ -78,27 +78,26 @@ struct AttnArgs {
 // and the dQ kernel computes dQ = scale dS K from them - 2 matrix products instead of the 6 a recomputing dQ kernel executes
 // (S and dP again), at the price of one 16-bit S x S / 2 round trip through HBM (4.3 GB at B 8, H 32, S 4096: HBM-bound at ~0.8 ms).
 // Layout (round 6: ONLY THE CAUSAL HALF is kept - VERDICT round 5, next #8): tiles of 32 keys x 32 queries (2 KiB), per (batch, head)
-// pair ordered [256-key block kb][slice sl - 8 kb][32-key block of kb: 0..7]: a 256-key block keeps the 32-query slices from its own
-// diagonal down (slices counted in whole 256-query blocks, nslp = 8 ceil(Sq / 256): a dQ wave without queries still fetches its tiles), a
-// key block beyond the last query block keeps none. What one dK/dV workgroup writes per slice - its 8 tiles - is 16 KiB of
-// consecutive bytes and the next slice's follow them: the stream's tile pointer advances by a constant. A dQ wave (slice sl) reads its
-// tiles of one key block kb as 16 KiB of consecutive bytes, (sl - 8 kb) x 16 KiB into the block's area.
+// pair ordered [256-query block qb][256-key block kb <= qb][32-key block of kb: 0..7][slice of qb: 0..7] - the rectangular layout of rounds
+// 2-5 ([qb][32-key block][slice]) with every row cut off behind its diagonal square: row qb holds min(qb + 1, nkb) squares of 64 tiles.
+// What a dQ workgroup (one query block) reads is still ONE contiguous stream, 32 KiB per 64-key step; a dK/dV wave's tile of the next
+// slice is 2 KiB on, the next query block's a row further (a row grows by one square per query block: the stream keeps the step in a
+// scalar register). Query blocks are whole (a dQ wave without queries still fetches its tiles).
+// (Measured same-box before settling on this: [kb][slice][32-key block] - a constant pointer step for dK/dV - and [kb][qb][..] both cost
+// the dQ kernel 4-9 %: its stream then jumps between sixteen areas of the pair instead of walking one row.)
 // Inside a tile: [s][key][hl][8 values] where the 8 values are accumulator registers e = 8 s + j of lane half hl, i.e. queries
 // (j & 3) + 8 (2 s + (j >> 2)) + 4 hl of the slice - exactly one packed operand of the dK/dV wave (key on the lane), so a store
 // instruction writes 1 KiB of consecutive bytes.
 constexpr int DS_TILE = 2048;
-// tiles in front of key block kb's area within one pair: sum over j < min(kb, nqb) of (8 nqb - 8 j) slices x 8 tiles
-__host__ __device__ inline int64_t ds_block_base(int64_t kb, int64_t nqb) {
-    const int64_t m = kb < nqb ? kb : nqb;
-    return 64 * nqb * m - 32 * m * (m - 1);
+// tiles in front of query block qb's row within one pair: sum over j < qb of min(j + 1, nkb) squares of 64 tiles
+__host__ __device__ inline int64_t ds_row_base(int64_t qb, int64_t nkb) {
+    const int64_t m = qb < nkb ? qb : nkb;
+    return 32 * m * (m + 1) + (qb - m) * nkb * 64;
 }
-__host__ __device__ inline int64_t ds_pair_tiles(int64_t Sq, int64_t Skv) { return ds_block_base((Skv + 255) / 256, (Sq + 255) / 256); }
+__host__ __device__ inline int64_t ds_pair_tiles(int64_t Sq, int64_t Skv) { return ds_row_base((Sq + 255) / 256, (Skv + 255) / 256); }
 __host__ __device__ inline size_t ds_bytes(int64_t nbh, int64_t Sq, int64_t Skv) { return (size_t)nbh * (size_t)ds_pair_tiles(Sq, Skv) * DS_TILE; }
-// tile (kwb = 32-key block, sl = 32-query slice) of a pair, kwb <= sl
-__host__ __device__ inline int64_t ds_tile_index(int64_t kwb, int64_t sl, int64_t nqb) {
-    const int64_t kb = kwb >> 3;
-    return ds_block_base(kb, nqb) + (sl - 8 * kb) * 8 + (kwb & 7);
-}
+// tile (kwb = 32-key block, sl = 32-query slice) of a pair, kwb / 8 <= sl / 8
+__host__ __device__ inline int64_t ds_tile_index(int64_t kwb, int64_t sl, int64_t nkb) { return ds_row_base(sl >> 3, nkb) + kwb * 8 + (sl & 7); }
 
 // XCD-aware block order for the v2 kernels (1-D grid of nx * nbh blocks). Hardware deals block ids round-robin
 // over the 8 XCDs, each with a private 4 MiB L2. All nx blocks of one (batch, head) re-read that head's K/V
@@ -958,9 +957,10 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_ds_kernel(const AttnArgs a
     const int64_t q_end = q0 + FQ < a.Sq ? q0 + FQ : a.Sq;
     const int64_t kv_end = a.Skv < q_end ? a.Skv : q_end;
     const int nt = (int)((kv_end + ABK - 1) / ABK);
-    const char *dsg = a.ds + (bh - a.bh0) * a.ds_pair * DS_TILE; // this pair's tiles (the workspace holds this launch's heads)
-    const int kwb_last = (int)((a.Skv + 255) / 256 * 8 - 1);
-    const int slw = qblk * 8 + wid; // this wave's slice whether it has queries or not (the tile grid is padded to whole query blocks)
+    // this query block's row of the pair's tiles, this wave's slice of it (whether it has queries or not: the grid holds whole query blocks): + kwb * 8 tiles
+    const char *dsg = a.ds + ((bh - a.bh0) * a.ds_pair + ds_row_base(qblk, a.ds_nkb) + wid) * DS_TILE;
+    const int kwb_last = (int)(a.ds_nkb * 8 - 1);
+    const int slw = qblk * 8 + wid;
     auto stage = [&](int tile, int slot) { // 2 K pieces (this wave's share of the tile) + 4 dS pieces (its own two tiles)
         const int tl = tile < nt ? tile : nt - 1;
         const int kfirst = tl * ABK, klast = (int)a.Skv - 1 - kfirst; // (rows of this tile that exist: 0 .. klast)
@@ -983,7 +983,7 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_ds_kernel(const AttnArgs a
             // key blocks above this wave's slice are never consumed and have no tile (only the causal half is kept): fetch the slice's own last
             // tile again instead - it came through a few steps ago, the bytes come from cache, not from HBM (this kernel is bound by its dS stream)
             kwb = kwb <= slw ? kwb : (slw < kwb_last ? slw : kwb_last);
-            const char *tg = dsg + ds_tile_index(kwb, slw, a.ds_nqb) * DS_TILE;
+            const char *tg = dsg + (int64_t)kwb * 8 * DS_TILE;
 #pragma unroll
             for (int pc = 0; pc < 2; ++pc)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(tg + ds_src[pc]),
@@ -1307,9 +1307,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     // dS tiles of this wave's 32 keys: tile (qb, kwb, sl) of the workspace, lane (key xl, half hl) writes operand s at
     // s * 1024 + xl * 32 + hl * 16 (see DS_TILE)
     unsigned ds_lane = (unsigned)(xl * 32 + hl * 16);
-    // this wave's 32-key block kwb = kw / 32 of the pair: tile (kwb, sl) = ds_tile_index; + 8 tiles per slice from slice 8 (kwb / 8) on
-    const char *ds_base = DS ? a.ds + ((bh - a.bh0) * a.ds_pair + ds_tile_index(kw >> 5, 8 * (kw >> 8), a.ds_nqb)) * DS_TILE : nullptr;
-    const int ds_sl0 = 8 * (int)(kw >> 8);
+    // this wave's 32-key block kwb = kw / 32 of the pair: tile (kwb, sl) = ds_tile_index = row of query block sl / 8 + kwb * 8 + (sl & 7)
+    const char *ds_base = DS ? a.ds + ((bh - a.bh0) * a.ds_pair + (kw >> 5) * 8) * DS_TILE : nullptr;
+    const int ds_nkb = (int)a.ds_nkb;
     // a pair is 10 DMA operations per wave (ids 0..9: slice id / 5; Q rows i, dO rows i for i = 0, 1, then the row
     // constants); they are issued ONE per quarter-phase (an LDS-DMA instruction holds the wave's issue for 60-180 cycles,
     // which a lone wave per SIMD can only hide under MFMAs already queued)
@@ -1397,7 +1397,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
 
     // SOFF: this slice's offset inside its pair buffer (bases e, o, t0, t1, l); the next slice's first groups are read off
     // (en, on, ln) + NOFF; LAST: the slice that ends a pair (barrier + DMA of the pair after next before its q6)
-    auto slice_body = [&, ds_lane, ds_base, ds_sl0](auto mask_c, auto soff_c, auto noff_c, auto last_c, unsigned e, unsigned o, unsigned t0,
+    auto slice_body = [&, ds_lane, ds_base, ds_nkb](auto mask_c, auto soff_c, auto noff_c, auto last_c, unsigned e, unsigned o, unsigned t0,
                           unsigned t1, unsigned l, unsigned en, unsigned on, unsigned ln, int64_t qs, int pr, int it) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(mask_c)::value, LAST = decltype(last_c)::value;
         constexpr int SOFF = decltype(soff_c)::value, NOFF = decltype(noff_c)::value, DO = SOFF + BQS * AROW;
@@ -1519,7 +1519,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         uint64_t tb = 0;
         if constexpr (DS) {
             const int sl_ = (int)(qs >> 5);
-            const char *tile = ds_base + ((int64_t)((sl_ - ds_sl0) * 8) << 11); // DS_TILE = 2^11
+            const char *tile = ds_base + ((ds_row_base(sl_ >> 3, ds_nkb) + (sl_ & 7)) << 11); // DS_TILE = 2^11
             tb = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile) |
                  ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)tile >> 32)) << 32);
         }
@@ -1572,7 +1572,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     //   | p5: its Q rows (-> p0) | p6: its dP constants (-> p2) | p7: its dO rows (-> p2; carried in g1)
     // counted waits (reads issued after the awaited group): p0 8, p2 8, p4 12, p5 12, p6 12, p7 12. The pair barrier sits in front of
     // p4: everything read after it belongs to the next pair's buffer when the slice is a pair's last.
-    auto slice_body64 = [&, ds_lane, ds_base, ds_sl0](auto mask_c, auto soff_c, auto noff_c, auto last_c, unsigned e, unsigned o, unsigned t0,
+    auto slice_body64 = [&, ds_lane, ds_base, ds_nkb](auto mask_c, auto soff_c, auto noff_c, auto last_c, unsigned e, unsigned o, unsigned t0,
                             unsigned t1, unsigned l, unsigned en, unsigned on, unsigned ln, int64_t qs, int pr, int it) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(mask_c)::value, LAST = decltype(last_c)::value;
         constexpr int SOFF = decltype(soff_c)::value, NOFF = decltype(noff_c)::value, DO = SOFF + BQS * AROW, NDO = NOFF + BQS * AROW;
@@ -1628,7 +1628,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         uint64_t tb = 0;
         if constexpr (DS) {
             const int sl_ = (int)(qs >> 5);
-            const char *tile = ds_base + ((int64_t)((sl_ - ds_sl0) * 8) << 11);
+            const char *tile = ds_base + ((ds_row_base(sl_ >> 3, ds_nkb) + (sl_ & 7)) << 11);
             tb = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile) |
                  ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)tile >> 32)) << 32);
         }
@@ -1804,8 +1804,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) 
         const unsigned kn = (unsigned)((krows - 1) * a.lk.sr + dbytes), on = (unsigned)((krows - 1) * a.ldk.sr + dbytes);
         const int s0 = (int)(k0 / BQS);                    // the first slice with a query that sees one of the block's keys
         const int ns = ns_all;                             // (a block beyond the last query, s0 >= ns: no slices, zero gradients; the stream clamps its first requests to slice ns - 1)
-        // this block's area of the dS workspace: its slices from s0 on, 8 tiles (16 KiB) each (ds_tile_index)
-        const char *dsp = DS ? a.ds + ((bh - a.bh0) * a.ds_pair + ds_block_base(xb, a.ds_nqb)) * DS_TILE : nullptr;
+        // this block's first square of the dS workspace (ds_tile_index): row of query block xb, square xb; the stream walks down from there - dsrs =
+        // the bytes from a query block's last slice to the next block's first (its row's length less seven tiles), growing by a square per row up to dsrm
+        const char *dsp = DS ? a.ds + ((bh - a.bh0) * a.ds_pair + ds_row_base(xb, a.ds_nkb) + (int64_t)xb * 64) * DS_TILE : nullptr;
+        const int64_t rowlen = (xb + 1 < a.ds_nkb ? xb + 1 : a.ds_nkb);
+        const unsigned dsrs = (unsigned)((rowlen * 64 - 7) * DS_TILE), dsrm = (unsigned)((a.ds_nkb * 64 - 7) * DS_TILE);
         int mut = -1;
 #ifdef KF_MUTANT
         if (a.mutant == 2 && xb == 0 && wid < 2) mut = 4; // defect 2: queries 128..159 contribute nothing to keys 0..127
@@ -1818,7 +1821,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) 
 #endif
 #define KF_DKV_OPERANDS                                                                                                                       \
     [qp] "s"(qp), [dop] "s"(dop), [kp] "s"(kp), [vp] "s"(vp), [dkp] "s"(dkp), [dvp] "s"(dvp), [cp] "s"(cp), [dsp] "s"(dsp), [cdelta] "s"(cdelta), \
-        [qsr] "s"(qsr), [dosr] "s"(dosr), [kvsr] "s"(kvsr), [osr] "s"(osr), [s0] "s"(s0), [ns] "s"(ns), [wid] "s"(wid),       \
+        [qsr] "s"(qsr), [dosr] "s"(dosr), [kvsr] "s"(kvsr), [osr] "s"(osr), [s0] "s"(s0), [ns] "s"(ns), [dsrs] "s"(dsrs), [dsrm] "s"(dsrm), [wid] "s"(wid),       \
         [scale] "s"(scale), [scl] "s"(scl), [lds] "s"(lds), [mut] "s"(mut), [qn] "s"(qn), [don] "s"(don), [kn] "s"(kn), [on] "s"(on) KF_DKV_EXTRA
 #define KF_DKV_ASM(TEXT) asm volatile(TEXT : : KF_DKV_OPERANDS : KF_DKV_W4_CLOBBERS)
         if constexpr (D64) {
@@ -2794,8 +2797,8 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
         const int64_t group = knob(KNOB_ATTN_SPLIT_BWD) ? 0 : ds_group(nbh, Sq, Skv, workspace_bytes - need);
         const bool keep_ds = group > 0;
         a.ds = keep_ds ? (char *)workspace + need : nullptr;
-        a.ds_nqb = (Sq + 255) / 256;
         a.ds_pair = ds_pair_tiles(Sq, Skv);
+        a.ds_nkb = (Skv + 255) / 256;
         const int64_t nkb4 = Skv / K4B, nxq = (Sq + FQ - 1) / FQ;
         const int pair_kv = (nkb4 % 2 == 0 && nkb4 >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;
         const int pair_q = (nxq % 2 == 0 && nxq >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;

@@ -61,7 +61,7 @@ S_DS0, S_DS1 = 66, 68   # pairs
 S_SL, S_STAGE = 70, 71
 S_WID, S_LDS, S_SCALE, S_MUT, S_OSR = "%[wid]", "%[lds]", "%[scale]", "%[mut]", "%[osr]"   # read-only inputs: used in place
 S_X0, S_X1 = 72, 73
-S_DSB = 74              # pair: dS base of this wave's first key sub-block at slice 0 of the workspace
+S_DSSTEP = 74           # bytes from the last slice of the current query block to the first of the next one in the dS workspace (ds_next)
 V_SRD = 76             # 4-aligned quad: the V fragments' descriptor (prologue only)
 S_PSH = 76             # f16 streams, from the end of the prologue on: 2^P_SHIFT as a float (the multiplier of the P pack, below)
 S_M0C, S_MKT, S_MKC = 77, 78, 79   # from the end of the prologue on: DMA destination of the row constants; the ring's XOR masks (tiles | constants)
@@ -324,9 +324,10 @@ class Gen:
                 if ksb not in ksbs:
                     continue
                 nst += 1
-                put(g, (5, 0), lambda ksb=ksb, s=s: self.out.append(
-                    Ins(f"global_store_dwordx4 {vr(DSOFF)}, {vr(DSP(ksb, s), 4)}, {sr(S_DS0, 2)} offset:{DS_TILE * ksb + 1024 * s} {self.store_policy}", "vmem", V(DSOFF) + V(DSP(ksb, s), 4))))
-        put(12 if self.early else 62, (6, 0), self.ds_next)
+                base = S_DS0 if ksb == 0 else S_DS1
+                put(g, (5, 0), lambda ksb=ksb, s=s, base=base: self.out.append(
+                    Ins(f"global_store_dwordx4 {vr(DSOFF)}, {vr(DSP(ksb, s), 4)}, {sr(base, 2)} offset:{1024 * s} {self.store_policy}", "vmem", V(DSOFF) + V(DSP(ksb, s), 4))))
+        put(62, (6, 0), self.ds_next)
 
         self.label(f"L_{name}_%=")
         for g in range(64):
@@ -482,8 +483,9 @@ class Gen:
                 if ksb not in ksbs:
                     continue
                 nst += 1
-                put(g, (5, 0), lambda ksb=ksb, s_=s_: self.out.append(
-                    Ins(f"global_store_dwordx4 {vr(DSOFF)}, {vr(DSP(ksb, s_), 4)}, {sr(S_DS0, 2)} offset:{DS_TILE * ksb + 1024 * s_} {self.store_policy}", "vmem", V(DSOFF) + V(DSP(ksb, s_), 4))))
+                base = S_DS0 if ksb == 0 else S_DS1
+                put(g, (5, 0), lambda ksb=ksb, s_=s_, base=base: self.out.append(
+                    Ins(f"global_store_dwordx4 {vr(DSOFF)}, {vr(DSP(ksb, s_), 4)}, {sr(base, 2)} offset:{1024 * s_} {self.store_policy}", "vmem", V(DSOFF) + V(DSP(ksb, s_), 4))))
         put(31, (6, 0), self.ds_next)
 
         self.label(f"L_{name}_%=")
@@ -515,11 +517,20 @@ class Gen:
         self.stores_of[kind] = nst
 
     def ds_next(self):
-        """The dS tiles of the next slice: the block's area of the workspace holds its slices one behind the other, 8 tiles (16 KiB) each -
-        this wave's two (key sub-blocks 2 w, 2 w + 1) are S_DS0 and S_DS0 + 2 KiB. (Round 6, the causal-half layout of attention.hip's
-        ds_tile_index: until then the address was eleven scalar instructions per slice.)"""
-        self.salu(f"s_add_u32 {sr(S_DS0)}, {sr(S_DS0)}, {8 * DS_TILE}")
+        """The dS tiles of the next slice (attention.hip, ds_tile_index: [256-query block][256-key block][32-key block][slice of the query
+        block], 2 KiB each): one tile on inside a query block; into the next query block, its row's length less seven tiles on - a row grows by
+        one square of 64 tiles per query block until it holds all the key blocks. This wave's two tiles (32-key blocks 2 w, 2 w + 1) lie 8 apart."""
+        self.salu(f"s_add_u32 {sr(S_SL)}, {sr(S_SL)}, 1")
+        self.salu(f"s_and_b32 {sr(S_TMP2)}, {sr(S_SL)}, 7")
+        self.salu(f"s_cmp_eq_u32 {sr(S_TMP2)}, 0")
+        self.salu(f"s_cselect_b32 {sr(S_TMP)}, {sr(S_DSSTEP)}, {DS_TILE}")
+        self.salu(f"s_cselect_b32 {sr(S_TMP2)}, {64 * DS_TILE}, 0")
+        self.salu(f"s_add_u32 {sr(S_DS0)}, {sr(S_DS0)}, {sr(S_TMP)}")
         self.salu(f"s_addc_u32 {sr(S_DS0 + 1)}, {sr(S_DS0 + 1)}, 0")
+        self.salu(f"s_add_u32 {sr(S_DSSTEP)}, {sr(S_DSSTEP)}, {sr(S_TMP2)}")
+        self.salu(f"s_min_u32 {sr(S_DSSTEP)}, {sr(S_DSSTEP)}, %[dsrm]")
+        self.salu(f"s_add_u32 {sr(S_DS1)}, {sr(S_DS0)}, {8 * DS_TILE}")
+        self.salu(f"s_addc_u32 {sr(S_DS1 + 1)}, {sr(S_DS0 + 1)}, 0")
 
     # -------------------------------------------------------------- block pass
     def prologue(self):
@@ -543,13 +554,13 @@ class Gen:
         e.salu(f"s_mov_b32 {sr(O_SRD + 3)}, 0x00020000")
         for dst, src in ((S_NS, "ns"), (S_SL, "s0")):
             e.salu(f"s_mov_b32 {sr(dst)}, %[{src}]")
-        e.salu(f"s_mov_b64 {sr(S_DS0, 2)}, %[dsp]")                             # the block's area of the dS workspace: slice s0's 8 tiles first
-        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 12")                      # this wave's two tiles of a slice: 2 w, 2 w + 1 (2 KiB each)
+        e.salu(f"s_mov_b32 {sr(S_DSSTEP)}, %[dsrs]")
+        e.salu(f"s_mov_b64 {sr(S_DS0, 2)}, %[dsp]")                             # the block's diagonal square of the dS workspace: slice s0 = 8 kb
+        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 15")                      # this wave's 32-key blocks 2 w, 2 w + 1 of the block: 8 tiles (one per slice of a query block) each
         e.salu(f"s_add_u32 {sr(S_DS0)}, {sr(S_DS0)}, {sr(S_TMP)}")
         e.salu(f"s_addc_u32 {sr(S_DS0 + 1)}, {sr(S_DS0 + 1)}, 0")
-        if self.early:                                                          # (the first slice's own gap 12 takes the step)
-            e.salu(f"s_sub_u32 {sr(S_DS0)}, {sr(S_DS0)}, {8 * DS_TILE}")
-            e.salu(f"s_subb_u32 {sr(S_DS0 + 1)}, {sr(S_DS0 + 1)}, 0")
+        e.salu(f"s_add_u32 {sr(S_DS1)}, {sr(S_DS0)}, {8 * DS_TILE}")
+        e.salu(f"s_addc_u32 {sr(S_DS1 + 1)}, {sr(S_DS0 + 1)}, 0")
         e.salu(f"s_lshl_b32 {sr(S_D0)}, {sr(S_WID)}, 1")                       # this wave's diagonal slices: 2 w and 2 w + 1 of the block's
         # DMA: slice s0's offsets, steps, saturation values
         e.salu(f"s_lshl_b32 {sr(S_QSTEP)}, %[qsr], 5")
