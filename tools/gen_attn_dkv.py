@@ -785,7 +785,12 @@ class Gen:
         e.label("L_epilogue_%=")
         # nothing this wave has in flight writes LDS any more (no DMA beyond the pass's last slice), and its dS stores read their registers
         # at issue: only the LDS reads of the last slice's tail have to be back before their registers are reused
-        e.out.append(Ins("s_waitcnt lgkmcnt(0)" if self.skip_tail_dma else "s_waitcnt vmcnt(0) lgkmcnt(0)", "wait", tag="vmlgkm"))
+        # (round 6: without skip_tail_dma the requests of the slices fetched past the pass's end and the last slice's dS stores - which retire ~1 us
+        #  after issue - are still in flight here: nothing the epilogue touches depends on them (registers, the wave's slab). What must hold is that
+        #  they have LANDED before the barrier at the epilogue's end lets the next pass's K tiles into the ring: a counted wait in front of that
+        #  barrier - everything but the epilogue's own stores - instead of vmcnt(0) here. KF_GEN_EPI_VMWAIT=1 restores the old form: same-box A/B.)
+        self.epi_late_wait = not self.skip_tail_dma and not os.environ.get("KF_GEN_EPI_VMWAIT") and not self.stamps
+        e.out.append(Ins("s_waitcnt lgkmcnt(0)" if (self.skip_tail_dma or self.epi_late_wait) else "s_waitcnt vmcnt(0) lgkmcnt(0)", "wait", tag="vmlgkm"))
         if self.skip_tail_dma:
             # (a pass WITHOUT slices - a key block beyond the last query - comes here straight from the prologue, whose second request is
             #  still in flight: it must have landed before the barrier below lets the next pass's K tiles into the ring)
@@ -862,7 +867,10 @@ class Gen:
             e.out.append(Ins(f"global_store_dwordx4 {vr(T[0])}, {vr(40, 4)}, %[dbg] offset:32", "vmem"))
             e.salu("s_mov_b64 exec, -1")
             e.out.append(Ins("s_waitcnt vmcnt(0)", "wait", tag="vm"))
-        e.barrier()   # the next block's DMA reuses the slice buffers: every wave is past its last reads (they are, since the last slice's barrier) - kept for the vmcnt bookkeeping of the prologue
+        if self.epi_late_wait:
+            n_st = 2 * (64 // (4 if self.D == 128 else 8))     # this epilogue's own dV + dK row stores: the only memory operations that may still be in flight
+            e.out.append(Ins(f"s_waitcnt vmcnt({n_st})", "wait", tag="vm"))
+        e.barrier()   # the next block's DMA reuses the slice buffers: every wave is past its last reads (they are, since the last slice's barrier) and every wave's requests of this pass have landed
 
     def build(self):
         self.prologue()

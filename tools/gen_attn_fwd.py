@@ -679,7 +679,13 @@ class Gen:
         e = self
         lane, r, h = T[0], T[1], T[2]
         e.label("L_epilogue_%=")
-        e.wait(vm=0, lgkm=0)
+        # (round 6: no vmcnt here. What is still in flight - the pieces of the tiles fetched past the block's end - lands in this wave's OWN quarters of
+        #  the ring, which nothing reads any more, in order ahead of whatever the next pass requests into them; the epilogue works in registers and in
+        #  the wave's slab. KF_GEN_EPI_VMWAIT=1 restores the wait: same-box A/B.)
+        if os.environ.get("KF_GEN_EPI_VMWAIT"):
+            e.wait(vm=0, lgkm=0)
+        else:
+            e.wait(lgkm=0)
         e.salu("s_nop 15")
         e.valu(f"v_mbcnt_lo_u32_b32 {vr(lane)}, -1, 0")
         e.valu(f"v_mbcnt_hi_u32_b32 {vr(lane)}, -1, {vr(lane)}")
