@@ -456,6 +456,43 @@ Tensor grad_target(const Tensor &b) {
 }
 
 // dA = alpha * dC B^T, dB = alpha * A^T dC with A flattened to [M,K] (no reference counterpart)
+// Both gradients of a linear layer y = alpha a b from its output gradient g2 [M, N]: da = alpha g2 b^T (NT), db = alpha a2^T g2 (TN). A 16-bit
+// layer on 256-tile shapes gets them from ONE grid where the device library can fuse the pair (kf_gemm_grouped_single_grid: the second
+// product's first tiles start under the first one's last tiles); where it cannot - a skinny product such as dA of x[256, 4096] W[4096, 16384] -
+// two ordinary calls run, which carry the split-K scratch kf_gemm_grouped's fall-back would not have. A bucketed weight whose gradient starts
+// empty takes dW straight into its bucket slot (grad_target: update_grad then has nothing to copy); the slot is handed out ONCE per pass
+// (GradSink::take_slot), so it is asked for once here whichever way the products run.
+void linear_backward(const Tensor &a, const Tensor &b, const Tensor &g2, float alpha, int64_t M, int64_t N, int64_t K, Tensor &out_da, Tensor &out_db) {
+    Tensor a2 = a.view({M, K});
+    Tensor da, db;
+    if (a.requires_grad() && b.requires_grad() && M % 256 == 0 && N % 256 == 0 && K % 256 == 0 &&
+        (a.dtype() == ScalarType::Half || a.dtype() == ScalarType::BFloat16)) {
+        da = empty(a.sizes(), a.dtype(), a.device());
+        db = grad_target(b);
+        kf_gemm_problem p[2] = {};
+        p[0].trans_a = 0; p[0].trans_b = 1; p[0].M = M; p[0].N = K; p[0].K = N; p[0].alpha = alpha; p[0].beta = 0.f;
+        p[0].A = g2.data_ptr(); p[0].lda = N; p[0].B = b.data_ptr(); p[0].ldb = N; p[0].C = da.data_ptr(); p[0].ldc = K;
+        p[1].trans_a = 1; p[1].trans_b = 0; p[1].M = K; p[1].N = N; p[1].K = M; p[1].alpha = alpha; p[1].beta = 0.f;
+        p[1].A = a2.data_ptr(); p[1].lda = K; p[1].B = g2.data_ptr(); p[1].ldb = N; p[1].C = db.data_ptr(); p[1].ldc = N;
+        p[1].c_f32 = db.dtype() == ScalarType::Float ? 1 : 0; // the slot of an f32 gradient bucket: dW leaves the accumulators unrounded
+        if (kf_gemm_grouped_single_grid(code(a.dtype()), 2, p)) {
+            DEV_CALL(kf_gemm_grouped(code(a.dtype()), 2, p, dev::stream(a.device())));
+            out_da = da;
+            out_db = db;
+            return;
+        }
+    }
+    if (a.requires_grad()) {
+        out_da = da.defined() ? da : empty(a.sizes(), a.dtype(), a.device());
+        Tensor c2 = out_da.view({M, K});
+        gemm_any(a.dtype(), false, true, M, K, N, alpha, g2, b, 0.f, c2, a.device());
+    }
+    if (b.requires_grad()) {
+        out_db = db.defined() ? db : grad_target(b);
+        gemm_any(a.dtype(), true, false, K, N, M, alpha, a2, g2, 0.f, out_db, b.device());
+    }
+}
+
 class GemmGradFunction : public GradFunction {
 public:
     GemmGradFunction(const Tensor &a, const Tensor &b, float alpha) : alpha_(alpha) { inputs = {a, b}; }
@@ -464,38 +501,7 @@ public:
         const int64_t K = b.shape(0), N = b.shape(1), M = a.numel() / K;
         Tensor gc = g.contiguous();
         std::vector<Tensor> out(2);
-        Tensor g2 = gc.view({M, N}), a2 = a.view({M, K});
-        Tensor da, db; // kept when the fused pair is not taken: the slot is handed out once per pass (GradSink::take_slot), asking twice would lose it
-        if (a.requires_grad() && b.requires_grad() && M % 256 == 0 && N % 256 == 0 && K % 256 == 0 &&
-            (a.dtype() == ScalarType::Half || a.dtype() == ScalarType::BFloat16)) {
-            // both gradients of a 16-bit layer on 256-tile shapes: ONE grid where the device library can fuse the pair
-            // (kf_gemm_grouped_single_grid). Where it cannot - too many tiles, or a skinny product such as dA of x[256, 4096] W[4096, 16384] -
-            // the two ordinary calls below run, which carry the split-K scratch kf_gemm_grouped's fall-back would not have.
-            // a bucketed weight whose gradient starts empty takes dW straight into its bucket slot (update_grad then has nothing to copy)
-            da = empty(a.sizes(), a.dtype(), a.device());
-            db = grad_target(b);
-            kf_gemm_problem p[2] = {};
-            p[0].trans_a = 0; p[0].trans_b = 1; p[0].M = M; p[0].N = K; p[0].K = N; p[0].alpha = alpha_; p[0].beta = 0.f;
-            p[0].A = g2.data_ptr(); p[0].lda = N; p[0].B = b.data_ptr(); p[0].ldb = N; p[0].C = da.data_ptr(); p[0].ldc = K;
-            p[1].trans_a = 1; p[1].trans_b = 0; p[1].M = K; p[1].N = N; p[1].K = M; p[1].alpha = alpha_; p[1].beta = 0.f;
-            p[1].A = a2.data_ptr(); p[1].lda = K; p[1].B = g2.data_ptr(); p[1].ldb = N; p[1].C = db.data_ptr(); p[1].ldc = N;
-            p[1].c_f32 = db.dtype() == ScalarType::Float ? 1 : 0; // the slot of an f32 gradient bucket: dW leaves the accumulators unrounded
-            if (kf_gemm_grouped_single_grid(code(a.dtype()), 2, p)) {
-                DEV_CALL(kf_gemm_grouped(code(a.dtype()), 2, p, dev::stream(a.device())));
-                out[0] = da;
-                out[1] = db;
-                return out;
-            }
-        }
-        if (a.requires_grad()) {
-            out[0] = da.defined() ? da : empty(a.sizes(), a.dtype(), a.device());
-            Tensor c2 = out[0].view({M, K});
-            gemm_any(a.dtype(), false, true, M, K, N, alpha_, g2, b, 0.f, c2, a.device());
-        }
-        if (b.requires_grad()) {
-            out[1] = db.defined() ? db : grad_target(b);
-            gemm_any(a.dtype(), true, false, K, N, M, alpha_, a2, g2, 0.f, out[1], b.device());
-        }
+        linear_backward(a, b, gc.view({M, N}), alpha_, M, N, K, out[0], out[1]);
         return out;
     }
 
@@ -564,16 +570,9 @@ public:
             if (a.requires_grad() || b.requires_grad() || (ibias_ >= 0 && inputs[ibias_].requires_grad())) dt = mul(g2, m2);
         }
         if (ibias_ >= 0 && inputs[ibias_].requires_grad()) out[ibias_] = sum(dt, 0).view({N});
-        Tensor a2 = a.view({M, K});
-        if (a.requires_grad()) {
-            out[0] = empty(a.sizes(), a.dtype(), a.device());
-            Tensor c2 = out[0].view({M, K});
-            gemm_any(a.dtype(), false, true, M, K, N, alpha_, dt, b, 0.f, c2, a.device());
-        }
-        if (b.requires_grad()) {
-            out[1] = grad_target(b); // (a bucketed weight: dW straight into its bucket slot, as in GemmGradFunction)
-            gemm_any(a.dtype(), true, false, K, N, M, alpha_, a2, dt, 0.f, out[1], b.device());
-        }
+        // da = alpha d_t b^T and db = alpha a^T d_t: plain products (the tail's derivative is the element-wise d_t above) - as ONE grid where the
+        // pair fits (round 6: config C5's fused block ran them as two launches each: 11 single GEMM launches + 2 pairs per step; now 5 + 5)
+        linear_backward(a, b, dt, alpha_, M, N, K, out[0], out[1]);
         return out;
     }
 
