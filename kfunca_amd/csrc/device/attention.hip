@@ -84,7 +84,8 @@ struct AttnArgs {
 // slice is 2 KiB on, the next query block's a row further (a row grows by one square per query block: the stream keeps the step in a
 // scalar register). Query blocks are whole (a dQ wave without queries still fetches its tiles).
 // (Measured same-box before settling on this: [kb][slice][32-key block] - a constant pointer step for dK/dV - and [kb][qb][..] both cost
-// the dQ kernel 4-9 %: its stream then jumps between sixteen areas of the pair instead of walking one row.)
+// the dQ kernel 4-9 %: its stream then jumps between sixteen areas of the pair instead of walking one row. This form against the rectangle
+// under the same code, four interleaved runs each: dQ 0.929 vs 0.939 ms, dK/dV 1.979 vs 1.983 - no difference: gpurun_out -> profiles/r06_ab_ds_layout.txt.)
 // Inside a tile: [s][key][hl][8 values] where the 8 values are accumulator registers e = 8 s + j of lane half hl, i.e. queries
 // (j & 3) + 8 (2 s + (j >> 2)) + 4 hl of the slice - exactly one packed operand of the dK/dV wave (key on the lane), so a store
 // instruction writes 1 KiB of consecutive bytes.

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float seed) {
             for (int n = 0; n < NV; ++n) {
                 if constexpr (KIND == 0) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(v[n & 7]));
                 else if constexpr (KIND == 1) asm volatile("v_exp_f32 %0, %0" : "+v"(v[n & 7]));
+                else if constexpr (KIND == 3) { if (n == 0) asm volatile("v_exp_f32 %0, %0" : "+v"(v[n & 7])); else asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(v[n & 7])); }
                 else asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(w[n & 7]));
             }
         }
@@ -55,7 +56,7 @@ void run(float *o, int wps) {
     const double mfma_cycles = (double)wps * iters * 2 * 32;
     const double cyc = ms * 1e-3 * 2.4e9;
     printf("%s %-6s NV=%2d waves/SIMD=%d: %7.3f ms, %5.1f cycles per slot, MFMA util %.2f\n", SHAPE ? "16x16x32" : "32x32x16",
-           KIND == 0 ? "fma" : KIND == 1 ? "exp" : "pk_fma", NV, wps, ms, cyc / ((double)wps * iters * 2), mfma_cycles / cyc);
+           KIND == 0 ? "fma" : KIND == 1 ? "exp" : KIND == 3 ? "1exp+fma" : "pk_fma", NV, wps, ms, cyc / ((double)wps * iters * 2), mfma_cycles / cyc);
 }
 #define ALLW(NV, KIND, SHAPE) run<NV, KIND, SHAPE>(o, 1); run<NV, KIND, SHAPE>(o, 2); run<NV, KIND, SHAPE>(o, 4);
 int main() {
@@ -64,5 +65,9 @@ int main() {
     ALLW(1, 1, 0) ALLW(2, 1, 0) ALLW(4, 1, 0)
     ALLW(4, 2, 0) ALLW(8, 2, 0)
     ALLW(0, 0, 1) ALLW(4, 0, 1) ALLW(8, 0, 1) ALLW(2, 1, 1)
+    // the attention streams' mixes (round 6): per MFMA one v_exp_f32 + (NV - 1) other VALU - D = 128 forward 4.7 VALU / MFMA,
+    // D = 64 forward 9.3, D = 64 dK/dV 4.4: what would a SECOND wave per SIMD buy? (zero operands: no power cap; nominal 2.4 GHz)
+    printf("---- one v_exp_f32 + (NV - 1) v_fma_f32 per MFMA\n");
+    ALLW(4, 3, 0) ALLW(5, 3, 0) ALLW(9, 3, 0) ALLW(10, 3, 0)
     return 0;
 }
