@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KF_ABI_VERSION 6 /* 6: + KF_ERR_OOM from kf_malloc, kf_gemm_epilogue.c_f32 / kf_gemm_problem.c_f32 (float output behind 16-bit operands); 2: + kf_reduce_moments*, KF_EW_*_SCALAR, kf_graph_*, kf_attn_*_scaled; 3: + kf_sort*; 4: + kf_knobs_reload, kf_norm_*, kf_index_get, kf_gemm_ex, KF_EPI_*; 5: + kf_gemm_grouped_single_grid, kf_allreduce_sum_multi, kf_profile_samples, kf_attn_bwd accepts any workspace >= the statistics (all additive) */
+#define KF_ABI_VERSION 7 /* 7 (no signature changed): kf_attn_* run the matrix-core kernels on ANY sequence lengths with Skv >= Sq (no multiple-of-128 rule), the backward workspace keeps the causal half of dS only (kf_attn_bwd_workspace_bytes returns about half of version 6's figure; its row-constant arrays pad Sq to 32) - a caller must size the workspace with THIS library's query, kf_index_add drops indices outside [-nrows, nrows); 6: + KF_ERR_OOM from kf_malloc, kf_gemm_epilogue.c_f32 / kf_gemm_problem.c_f32 (float output behind 16-bit operands); 2: + kf_reduce_moments*, KF_EW_*_SCALAR, kf_graph_*, kf_attn_*_scaled; 3: + kf_sort*; 4: + kf_knobs_reload, kf_norm_*, kf_index_get, kf_gemm_ex, KF_EPI_*; 5: + kf_gemm_grouped_single_grid, kf_allreduce_sum_multi, kf_profile_samples, kf_attn_bwd accepts any workspace >= the statistics (all additive) */
 
 /* ---- status ------------------------------------------------------------------------------ */
 enum {

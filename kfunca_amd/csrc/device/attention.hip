@@ -1817,13 +1817,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) 
 #ifdef KF_DKV_W4_STAMPS // diagnostic build (tools/attn_dkv_w4_timeline.py): eight cycle sums per wave and block pass into the debug buffer
         const char *dbg = (const char *)a.dbg + (size_t)(vwg * 2 + pass) * 4 * 64;
 #define KF_DKV_EXTRA , [dbg] "s"(dbg)
+        // (the diagnostic stream clobbers 22 more scalar registers: the four descriptor bounds become the literal "no bound" - whole tiles only)
+        (void)qn; (void)don; (void)kn; (void)on;
+#define KF_DKV_BOUNDS [qn] "n"(-1), [don] "n"(-1), [kn] "n"(-1), [on] "n"(-1)
 #else
 #define KF_DKV_EXTRA
+#define KF_DKV_BOUNDS [qn] "s"(qn), [don] "s"(don), [kn] "s"(kn), [on] "s"(on)
 #endif
 #define KF_DKV_OPERANDS                                                                                                                       \
     [qp] "s"(qp), [dop] "s"(dop), [kp] "s"(kp), [vp] "s"(vp), [dkp] "s"(dkp), [dvp] "s"(dvp), [cp] "s"(cp), [dsp] "s"(dsp), [cdelta] "s"(cdelta), \
         [qsr] "s"(qsr), [dosr] "s"(dosr), [kvsr] "s"(kvsr), [osr] "s"(osr), [s0] "s"(s0), [ns] "s"(ns), [dsrs] "s"(dsrs), [dsrm] "s"(dsrm), [wid] "s"(wid),       \
-        [scale] "s"(scale), [scl] "s"(scl), [lds] "s"(lds), [mut] "s"(mut), [qn] "s"(qn), [don] "s"(don), [kn] "s"(kn), [on] "s"(on) KF_DKV_EXTRA
+        [scale] "s"(scale), [scl] "s"(scl), [lds] "s"(lds), [mut] "s"(mut), KF_DKV_BOUNDS KF_DKV_EXTRA
 #define KF_DKV_ASM(TEXT) asm volatile(TEXT : : KF_DKV_OPERANDS : KF_DKV_W4_CLOBBERS)
         if constexpr (D64) {
             if constexpr (BF && DS) KF_DKV_ASM(KF_DKV_W4_D64_ASM_BF16_DS);
@@ -1844,6 +1848,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) 
 #undef KF_DKV_ASM
 #undef KF_DKV_OPERANDS
 #undef KF_DKV_EXTRA
+#undef KF_DKV_BOUNDS
     }
     }
 }

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/kfunca_hip.h but not exported"
     assert sorted(H.EXPORTS) == names, "hip_abi.EXPORTS out of sync with the header"
-    assert lib.kf_abi_version() == 6
+    assert lib.kf_abi_version() == 7
 
 
 def test_struct_layout_matches_c():

@@ -5,7 +5,7 @@
 set -uo pipefail
 cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run under gpurun)}"
 export TMPDIR=/tmp
-R="${KF_ROUND:-r05}"
+R="${KF_ROUND:-r06}"
 export KF_ROUND=$R
 bash tools/roundend.sh > gpurun_out/${R}_roundend.log 2>&1; tail -5 gpurun_out/${R}_roundend.log
 bash tools/pmc_traffic.sh > gpurun_out/${R}_pmc_traffic.log 2>&1; cp profiles/${R}_pmc_traffic.json gpurun_out/ 2>/dev/null
@@ -21,6 +21,9 @@ for F in reference fused fused-norm; do python tools/block_bench.py --form $F --
 python tools/block_bench.py --form fused --force-comm --check --steps 20 --json gpurun_out/${R}_block_c5_check_1gpu.json > /dev/null 2> gpurun_out/${R}_block_check.err
 python tools/attn_dkv_w4_timeline.py > gpurun_out/${R}_attn_dkv_timeline.txt 2>&1
 python tools/attn_fwd_w4_timeline.py > gpurun_out/${R}_attn_fwd_timeline.txt 2>&1
+python tools/attn_ragged_bench.py --json gpurun_out/${R}_attn_ragged.json > gpurun_out/${R}_attn_ragged.txt 2>&1
+python tools/attn_ragged_bench.py --D 64 --H 64 --S 4096,4000,1000 >> gpurun_out/${R}_attn_ragged.txt 2>&1
+python tools/vendor_yardstick.py --json gpurun_out/${R}_vendor_yardstick.json > /dev/null 2> gpurun_out/${R}_vendor_yardstick.err
 cp gpurun_out/${R}_pmc_traffic.json profiles/ 2>/dev/null
 python bench.py > gpurun_out/bench_${R}_final.json 2> gpurun_out/bench_${R}_final.err
 tail -c 900 gpurun_out/bench_${R}_final.json

@@ -12,7 +12,7 @@ from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 from bench import stamp  # noqa: E402
 
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r05"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r06"
 N_XCD, N_SIMD = 8, 1024
 PEAK = {"bf16": 2500.0, "f32": 157.3}
 FLOP_PER_MFMA = {"bf16": 32 * 32 * 16 * 2 * 1.0, "f32": 32 * 32 * 2 * 2 * 1.0}

@@ -4,7 +4,7 @@
 set -uo pipefail
 cd "${GRAFT_REPO_ROOT:?GRAFT_REPO_ROOT is not set (run under gpurun)}"
 export TMPDIR=/tmp
-R="${KF_ROUND:-r05}"
+R="${KF_ROUND:-r06}"
 rm -rf gpurun_out/gp
 mkdir -p gpurun_out/gp
 i=0

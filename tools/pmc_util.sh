@@ -8,6 +8,6 @@ i=0
 for C in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_MFMA SQ_INSTS_VALU GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   rm -rf gpurun_out/pu$i
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/pu$i -o r -- python3 bench.py --steps 3 --warmup 1 --sustain-seconds 0 --no-cpu-baseline > gpurun_out/pu$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/pu$i -o r -- python3 bench.py --steps 3 --warmup 1 --sustain-seconds 0 --no-cpu-baseline --no-ceiling > gpurun_out/pu$i.log 2>&1
 done
 python3 tools/pmc_util.py "$R"
