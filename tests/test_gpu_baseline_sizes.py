@@ -221,3 +221,31 @@ def test_c3_full_config_sampled_heads_vs_oracle(Hh, D):
     bound = 2.0 ** -8 * (np.abs(f(dv, code).astype(np.float64)).sum(axis=2) + np.abs(f(go, code).astype(np.float64)).sum(axis=2) / np.sqrt(S))
     assert (np.abs(got - want) <= bound).all(), "sum dV == sum dO, all heads"
     assert np.isfinite(f(dq, code)).all() and np.isfinite(f(dk, code)).all()
+
+
+def test_c3_at_a_ragged_length_full_batch():
+    """Config C3's batch and heads at S = 4000 (round 6: ragged lengths on the generated streams, no padded copies): B = 8, H = 32, D = 128 -
+    XCD map on, 16 query / key blocks per head of which the last is 160 rows, 125 slices. Two sampled (b, h) pairs against the oracle, the
+    checksum sum_n dV = sum_m dO over all 256 heads, and the causal-prefix property: the first 1000 rows of O / LSE are those of the S = 1000
+    problem on the same tensors' prefixes, bit for bit (a row's result depends on nothing behind it)."""
+    code, B, Hh, S, D = H.BF16, 8, 32, 4000, 128
+    rng = np.random.default_rng(4000)
+    q, k, v, go = (_rand16(rng, (B, Hh, S, D), code) for _ in range(4))
+    H.profile_reset()
+    H.profile_enable(True)
+    o, lse = fwd(code, q, k, v)
+    dq, dk, dv = bwd(code, q, k, v, o, lse, go)
+    H.profile_enable(False)
+    ran = set(H.profile_results())
+    assert {"attn_fwd_mfma", "attn_bwd_dkv_mfma", "attn_bwd_dq_mfma"} <= ran and not any("generic" in x for x in ran), ran
+    for b, h in ((0, 0), (7, 31)):
+        sl = (slice(b, b + 1), slice(h, h + 1))
+        K.attn_check(q[sl], k[sl], v[sl], code, o=o[sl], lse=lse[sl], d_o=go[sl], dq=dq[sl], dk=dk[sl], dv=dv[sl], what=f"S=4000 ({b},{h})")
+    want = f(go, code).astype(np.float64).sum(axis=2)
+    got = f(dv, code).astype(np.float64).sum(axis=2)
+    bound = 2.0 ** -8 * (np.abs(f(dv, code).astype(np.float64)).sum(axis=2) + np.abs(f(go, code).astype(np.float64)).sum(axis=2) / np.sqrt(S))
+    assert (np.abs(got - want) <= bound).all(), "sum dV == sum dO, all heads"
+    cut = 1000
+    sub = (slice(0, 2), slice(0, 4))
+    o1, lse1 = fwd(code, *(np.ascontiguousarray(x[sub][:, :, :cut]) for x in (q, k, v)))
+    assert np.array_equal(o1, o[sub][:, :, :cut]) and np.array_equal(lse1.view(np.uint32), lse[sub][:, :, :cut].view(np.uint32))

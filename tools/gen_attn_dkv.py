@@ -905,45 +905,65 @@ class Gen:
 VARIANTS = r"L_(steady|diag1|diag0|idle|drop)_%=:"
 
 
+# 0: one counted wait per first use (rounds 4-5: 35 s_waitcnt per steady slice); N > 0: a wait also covers every later read that is N MFMA gaps old
+# (5: 11 per slice; same-box 1.952 vs 1.975 ms over five interleaved pairs, profiles/r06_ab_ds_layout.txt)
+WAIT_BATCH_AGE = int(os.environ.get("KF_GEN_DKV_WAIT_AGE", "5"))
+
+
 def finish_waits(ins):
     """Inserts `s_waitcnt lgkmcnt(N)` in front of every instruction that reads (or rewrites) the destination of an LDS read still in
     flight, N = the LDS reads issued after it. Each variant's body is walked with the reads its predecessor's tail left pending (every
-    variant ends with the same 16 reads: the next slice's -lse constants and Q rows), the prologue and the epilogue linearly."""
-    # the tail every variant leaves behind
-    tail = []
+    variant ends with the same 16 reads: the next slice's -lse constants and Q rows), the prologue and the epilogue linearly.
+    WAIT_BATCH_AGE (round 6): an s_waitcnt is an instruction of the wave's stream like any other (4 issue cycles in a gap that is
+    already full); with N > 0 a wait that has to be there anyway is widened over the younger reads that are at least N gaps old - they have
+    landed - so their own first uses need none. A wider wait is only ever stricter: correctness does not depend on N."""
+    # the tail every variant leaves behind (with how many MFMA gaps lie between each read and the variant's end)
+    tail, gaps_after = [], []
     on = False
     for x in ins:
         if x.kind == "label" and re.match(VARIANTS, x.text):
             on = x.text.startswith("L_steady")
-            tail = [] if on else tail
+            if on: tail, gaps_after = [], []
         elif on and x.kind == "lds":
             tail.append(x)
+            gaps_after.append(0)
         elif on and x.kind == "wait" and "lgkm" in x.tag:
-            tail = []
+            tail, gaps_after = [], []
+        elif on and x.kind in ("mfma", "nomfma"):
+            gaps_after = [g + 1 for g in gaps_after]
+        elif on and x.kind == "label" and x.text.startswith("L_loop"):
+            on = False
     # (never more than 15 in flight: the walk below retires the oldest before a 16th is issued, in every variant and in the prologue - so only
     #  the LAST 15 reads of the tail can still be pending where a variant starts; the counter's field is 4 bits wide)
-    out, pending = [], []
+    out, pending, born = [], [], []     # pending: destination registers of the reads in flight; born: the gap counter when each was issued
+    gap = 0
     for x in ins:
-        if x.kind == "label" and re.match(VARIANTS, x.text):
+        if x.kind == "label" and (re.match(VARIANTS, x.text) or x.text.startswith("L_epilogue")):
             pending = [t.writes for t in tail][-15:]
-        if x.kind == "label" and x.text.startswith("L_epilogue"):
-            pending = [t.writes for t in tail][-15:]
+            gap = 0
+            born = [-g for g in gaps_after][-15:]
+        if x.kind in ("mfma", "nomfma"):
+            gap += 1
         if x.kind == "wait" and "lgkm" in x.tag:
-            pending = []
+            pending, born = [], []
         touched = set(x.reads) | set(x.writes)
         need = -1
         for i, w in enumerate(pending):
             if touched & set(w):
                 need = i
         if need >= 0:
+            if WAIT_BATCH_AGE > 0:
+                while need + 1 < len(pending) and gap - born[need + 1] >= WAIT_BATCH_AGE:
+                    need += 1
             n = len(pending) - 1 - need
             out.append(Ins(f"s_waitcnt lgkmcnt({n})", "wait", tag="auto"))
-            pending = pending[need + 1:]
+            pending, born = pending[need + 1:], born[need + 1:]
         if x.kind == "lds":
             if len(pending) >= 15:   # the counter saturates at 15: retire the oldest first (it is 15 reads old)
                 out.append(Ins("s_waitcnt lgkmcnt(14)", "wait", tag="auto"))
-                pending = pending[len(pending) - 14:]
+                pending, born = pending[len(pending) - 14:], born[len(born) - 14:]
             pending.append(x.writes)
+            born.append(gap)
         out.append(x)
     ins[:] = out
 
