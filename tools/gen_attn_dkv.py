@@ -190,24 +190,39 @@ class Gen:
         if "barrier" in self.ablate and getattr(self, "in_loop", False): return   # (timing experiment: wrong results)
         self.out.append(Ins("s_barrier", "barrier"))
 
-    def dma_piece(self, srd, voff, soff, m0_add, inst_off, dword=False):
-        if "dma" in self.ablate and getattr(self, "in_loop", False): return
+    def dma_piece(self, srd, voff, soff, m0_add, inst_off, dword=False, sep=None):
+        """One LDS-DMA request. A scalar write of M0 needs one wait state before the request that reads it: `sep` (an emitter of ONE
+        instruction that had to be issued anyway - round 6: the read-base toggles behind the slice barrier) takes the place of the s_nop."""
+        if "dma" in self.ablate and getattr(self, "in_loop", False):
+            if sep: sep()
+            return
         self.salu(f"s_add_u32 m0, {sr(S_M0)}, {m0_add}" if m0_add else f"s_mov_b32 m0, {sr(S_M0)}")
-        self.salu("s_nop 0")
+        if sep: sep()
+        else: self.salu("s_nop 0")
         o = f" offset:{inst_off}" if inst_off else ""
         op = "buffer_load_dword" if dword else "buffer_load_dwordx4"
         self.out.append(Ins(f"{op} {vr(voff)}, {sr(srd, 4)}, {sr(soff)} offen{o} lds", "dma", V(voff)))
 
-    def dma_slice(self):
+    def dma_slice(self, seps=()):
         """This wave's pieces of one slice: rows 8 w .. 8 w + 7 of the Q tile and of the dO tile (two 1-KiB pieces each), and the 64 row
-        constants (every wave fetches them: identical bytes, uniform counts)."""
-        self.dma_piece(Q_SRD, DMAQ, S_QOFF, 0, 0)
-        if self.D == 128: self.dma_piece(Q_SRD, DMAQ, S_QOFF, 896, 128)
-        self.dma_piece(DO_SRD, DMAD, S_DOOFF, SLICE_DO, 0)
-        if self.D == 128: self.dma_piece(DO_SRD, DMAD, S_DOOFF, SLICE_DO + 896, 128)
-        self.salu(f"s_mov_b32 m0, {sr(S_M0C)}")
-        self.salu("s_nop 0")
-        self.out.append(Ins(f"buffer_load_dword {vr(DMAC)}, {sr(C_SRD, 4)}, {sr(S_COFF)} offen lds", "dma", V(DMAC)))
+        constants (every wave fetches them: identical bytes, uniform counts). seps: up to five one-instruction emitters that stand between an
+        M0 write and its request instead of an s_nop (any left over are emitted behind the last request)."""
+        seps = list(seps)
+        nxt = lambda: seps.pop(0) if seps else None  # noqa: E731
+        self.dma_piece(Q_SRD, DMAQ, S_QOFF, 0, 0, sep=nxt())
+        if self.D == 128: self.dma_piece(Q_SRD, DMAQ, S_QOFF, 896, 128, sep=nxt())
+        self.dma_piece(DO_SRD, DMAD, S_DOOFF, SLICE_DO, 0, sep=nxt())
+        if self.D == 128: self.dma_piece(DO_SRD, DMAD, S_DOOFF, SLICE_DO + 896, 128, sep=nxt())
+        sep = nxt()
+        if not ("dma" in self.ablate and getattr(self, "in_loop", False)):
+            self.salu(f"s_mov_b32 m0, {sr(S_M0C)}")
+            if sep: sep()
+            else: self.salu("s_nop 0")
+            self.out.append(Ins(f"buffer_load_dword {vr(DMAC)}, {sr(C_SRD, 4)}, {sr(S_COFF)} offen lds", "dma", V(DMAC)))
+        elif sep:
+            sep()
+        for f in seps:
+            f()
 
     def ring_step(self):
         """DMA destinations one ring slot on (slot b -> b + 1 mod 4: XOR 0x4000 from an even slot, 0xC000 from an odd one; the read bases
@@ -299,11 +314,14 @@ class Gen:
                         dd = DP(ksb, n // 2)
                         put(m0 + n + 2, (0, 4), lambda d=d, dd=dd: self.valu(f"{self.cvt} {vr(dd)}, {vr(d - 1)}, {vr(d)}", V(d - 1) + V(d), V(dd)))
         # ---- behind the barrier: ring toggle, DMA of slice it + 2 into the buffer this slice has finished with, then this slice's dS
+        # the five read-base toggles of the ring step (behind the barrier, ahead of the next slice's head reads at gap 52) - round 6: each between an M0
+        # write and the request that reads it, where an s_nop stood (KF_GEN_DKV_NOP_SEP=1: the old form, toggles at gap 48 and five s_nop)
+        toggles = [lambda r=r: self.valu(f"v_xor_b32 {vr(r)}, {sr(S_MKT)}, {vr(r)}", V(r), V(r)) for r in (RB[0], RB[1], TB[0], TB[1])]
+        toggles.append(lambda: self.valu(f"v_xor_b32 {vr(LR)}, {sr(S_MKC)}, {vr(LR)}", V(LR), V(LR)))
+        nop_sep = bool(os.environ.get("KF_GEN_DKV_NOP_SEP")) or self.skip_tail_dma
         def after_barrier():
-            for r in (RB[0], RB[1], TB[0], TB[1]):
-                self.valu(f"v_xor_b32 {vr(r)}, {sr(S_MKT)}, {vr(r)}", V(r), V(r))
-            self.valu(f"v_xor_b32 {vr(LR)}, {sr(S_MKC)}, {vr(LR)}", V(LR), V(LR))
-        put(48, (-3, 0), after_barrier)
+            for f in toggles: f()
+        if nop_sep: put(48, (-3, 0), after_barrier)
         def dma_guarded():
             # slice it + 2 of this pass - if there is one: round 4 re-fetched the clamped last slice twice per pass (never used), and the
             # epilogue waited ~2.5 k cycles for those ten pieces (tools/attn_dkv_w4_timeline.py: "last barrier -> epilogue")
@@ -312,7 +330,7 @@ class Gen:
             self.salu(f"s_cbranch_scc0 L_nodma_{name}_%=")
             self.dma_slice()
             self.label(f"L_nodma_{name}_%=")
-        put(49, (3, 0), dma_guarded if self.skip_tail_dma else self.dma_slice)
+        put(49, (3, 0), dma_guarded if self.skip_tail_dma else (self.dma_slice if nop_sep else (lambda: self.dma_slice(toggles))))
         def book():
             self.ring_step()
             self.advance_dma()
@@ -775,8 +793,15 @@ class Gen:
             e.salu(f"s_cmp_eq_u32 {sr(S_IT)}, {sr(S_MUT)}")
             e.salu("s_cbranch_scc1 L_drop_%=")
 
-    def next_iter(self):
+    def next_iter(self, steady=False):
         self.salu(f"s_add_u32 {sr(S_IT)}, {sr(S_IT)}, 1")
+        if steady and not self.mutant and not os.environ.get("KF_GEN_NO_STEADY_LOOP"):
+            # round 6: a wave runs idle* diag0 diag1 steady*: behind a steady slice comes a steady slice or the epilogue - three scalar instructions
+            # instead of the eleven of the general dispatch (an instruction of a lone wave's stream costs its issue slot whatever it does)
+            self.salu(f"s_cmp_lt_u32 {sr(S_IT)}, {sr(S_NS)}")
+            self.salu("s_cbranch_scc1 L_steady_%=")
+            self.salu("s_branch L_epilogue_%=")
+            return
         self.salu("s_branch L_loop_%=")
 
     def epilogue(self):
@@ -886,7 +911,7 @@ class Gen:
         if self.D == 128 and not self.ds:
             vm = {k: 0 for k in vm}
         sl("steady", "steady", vm["steady"])
-        self.next_iter()
+        self.next_iter(steady=True)
         sl("diag1", "diag1", vm["diag1"])
         self.next_iter()
         sl("diag0", "diag0", vm["diag0"])

@@ -668,9 +668,16 @@ class Gen:
             e.salu(f"s_cmp_eq_u32 {sr(S_IT)}, {sr(S_MUT)}")
             e.salu("s_cbranch_scc1 L_steadydrop_%=")
 
-    def next_iter(self):
+    def next_iter(self, steady=False):
         e = self
         e.salu(f"s_add_u32 {sr(S_IT)}, {sr(S_IT)}, 1")
+        if steady and not self.mutant and not os.environ.get("KF_GEN_NO_STEADY_LOOP"):
+            # round 6: behind a steady tile comes a steady tile until the wave's diagonal one (it == dt <= T - 1: the general dispatch's tail) - three
+            # scalar instructions instead of seven per tile
+            e.salu(f"s_cmp_lt_u32 {sr(S_IT)}, {sr(S_DT)}")
+            e.salu("s_cbranch_scc1 L_steady_%=")
+            e.salu("s_branch L_tail_%=")
+            return
         e.salu(f"s_cmp_le_u32 {sr(S_IT)}, {sr(S_T)}")
         e.salu("s_cbranch_scc1 L_loop_%=")
         e.salu("s_branch L_epilogue_%=")
@@ -791,7 +798,7 @@ class Gen:
                          ("masked", dict(has_prev=True, has_cur=True, masked=True)), ("firstmasked", dict(has_prev=False, has_cur=True, masked=True)),
                          ("drain", dict(has_prev=True, has_cur=False)), ("idle", dict(has_prev=False, has_cur=False))):
             self.iteration(name, **kw)
-            self.next_iter()
+            self.next_iter(steady=(name == "steady"))
         if self.mutant:
             self.iteration("steadydrop", has_prev=True, has_cur=True, drop=True)
             self.next_iter()
