@@ -1812,7 +1812,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) 
         const unsigned dsrs = (unsigned)((rowlen * 64 - 7) * DS_TILE), dsrm = (unsigned)((a.ds_nkb * 64 - 7) * DS_TILE);
         int mut = -1;
 #ifdef KF_MUTANT
-        if (a.mutant == 2 && xb == 0 && wid < 2) mut = 4; // defect 2: queries 128..159 contribute nothing to keys 0..127
+        if (a.mutant == 2 && xb == 0 && wid < 2) mut = 4; // defect 2: queries 128..159 contribute nothing to keys 0..127 (a steady slice of waves 0 and 1)
 #endif
 #ifdef KF_DKV_W4_STAMPS // diagnostic build (tools/attn_dkv_w4_timeline.py): eight cycle sums per wave and block pass into the debug buffer
         const char *dbg = (const char *)a.dbg + (size_t)(vwg * 2 + pass) * 4 * 64;

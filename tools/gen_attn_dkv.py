@@ -62,6 +62,7 @@ S_SL, S_STAGE = 70, 71
 S_WID, S_LDS, S_SCALE, S_MUT, S_OSR = "%[wid]", "%[lds]", "%[scale]", "%[mut]", "%[osr]"   # read-only inputs: used in place
 S_X0, S_X1 = 72, 73
 S_DSSTEP = 74           # bytes from the last slice of the current query block to the first of the next one in the dS workspace (ds_next)
+S_SPAN = 75             # 32-key sub-blocks between this wave's two (its second diagonal slice comes S_SPAN slices behind the first): 7 - 2 w balanced, 1 adjacent
 V_SRD = 76             # 4-aligned quad: the V fragments' descriptor (prologue only)
 S_PSH = 76             # f16 streams, from the end of the prologue on: 2^P_SHIFT as a float (the multiplier of the P pack, below)
 S_M0C, S_MKT, S_MKC = 77, 78, 79   # from the end of the prologue on: DMA destination of the row constants; the ring's XOR masks (tiles | constants)
@@ -112,6 +113,14 @@ class Gen:
         # slot S of the slice that USES it (gaps 10, 12) instead of slot dK of the slice before (gaps 50, 62): slot dK is the full one (DMA pieces, dS stores,
         # ring toggles, the next slice's head reads). The prologue then leaves both one step behind.
         self.early = D == 128 and os.environ.get("KF_GEN_DKV_EARLY", "0") == "1"
+        # balanced (round 6, VERDICT round 5 next #1 lever i): wave w owns the block's 32-key sub-blocks w and 7 - w instead of 2 w and 2 w + 1. A wave
+        # then has ONE sub-block at work from slice w on and both from slice 7 - w on: the pass's first four slices cost a one-sub-block slice (1.9 k
+        # cycles) instead of a full one for the sake of wave 0 alone while waves 1..3 idled. One more variant of the slice body ("half": sub-block 0
+        # only, unmasked). Results are bit-identical (a key's sums run over the same slices in the same order; the whole attention suite + the mutants
+        # pass on it). MEASURED same-box, five interleaved pairs (profiles/r06_ab_ds_layout.txt): 1.942 ms against 1.932 for the adjacent form - the
+        # 2.1 k cycles per pass the timeline promised (1.1 %) do not show: OFF (KF_GEN_DKV_BALANCED=1 builds it; the mutation build's defect 2 in
+        # attention.hip then wants wave 3 at slice 5).
+        self.balanced = D == 128 and bool(os.environ.get("KF_GEN_DKV_BALANCED"))
         kf0 = 122
         self.KFR = lambda ksb, kk: kf0 + 4 * self.NKK * ksb + 4 * kk
         self.VFR = lambda ksb, kk: kf0 + 8 * self.NKK + 4 * self.NKK * ksb + 4 * kk
@@ -245,7 +254,7 @@ class Gen:
         """kind: 'steady' | 'diag0' (sub-block 0 on the diagonal, sub-block 1 wholly above it: not computed) | 'diag1' (sub-block 0 visible,
         sub-block 1 on the diagonal) | 'idle' | 'drop' (mutation build: the slice's probabilities are zero)."""
         compute = kind != "idle"
-        ksbs = [0] if kind == "diag0" else [0, 1]
+        ksbs = [0] if kind in ("diag0", "half") else [0, 1]
         G = [[] for _ in range(64)]
         def put(g, key, fn): G[g].append((key, fn))
         self.in_loop = True
@@ -368,7 +377,7 @@ class Gen:
                 # that ended there is booked now - one slice late, so a kind's bucket holds its predecessor's period at every change of
                 # kind (4 per pass) - and the next request goes out; nothing waits for it and no LDS read is drained for it (a counted
                 # wait behind it can only be stricter by one).
-                self.stamp_add({"steady": 1, "drop": 1, "diag1": 2, "diag0": 3, "idle": 4}[kind])
+                self.stamp_add({"steady": 1, "drop": 1, "diag1": 2, "diag0": 3, "half": 3, "idle": 4}[kind])
                 self.stamp_take()
                 if self.stamps and kind == "steady":
                     self.salu("s_add_u32 s90, s90, 1")        # bucket 6 is written at the very end: until then s90 counts the steady slices
@@ -537,7 +546,7 @@ class Gen:
     def ds_next(self):
         """The dS tiles of the next slice (attention.hip, ds_tile_index: [256-query block][256-key block][32-key block][slice of the query
         block], 2 KiB each): one tile on inside a query block; into the next query block, its row's length less seven tiles on - a row grows by
-        one square of 64 tiles per query block until it holds all the key blocks. This wave's two tiles (32-key blocks 2 w, 2 w + 1) lie 8 apart."""
+        one square of 64 tiles per query block until it holds all the key blocks. This wave's two tiles (its two 32-key blocks) lie 8 S_SPAN apart."""
         self.salu(f"s_add_u32 {sr(S_SL)}, {sr(S_SL)}, 1")
         self.salu(f"s_and_b32 {sr(S_TMP2)}, {sr(S_SL)}, 7")
         self.salu(f"s_cmp_eq_u32 {sr(S_TMP2)}, 0")
@@ -547,7 +556,8 @@ class Gen:
         self.salu(f"s_addc_u32 {sr(S_DS0 + 1)}, {sr(S_DS0 + 1)}, 0")
         self.salu(f"s_add_u32 {sr(S_DSSTEP)}, {sr(S_DSSTEP)}, {sr(S_TMP2)}")
         self.salu(f"s_min_u32 {sr(S_DSSTEP)}, {sr(S_DSSTEP)}, %[dsrm]")
-        self.salu(f"s_add_u32 {sr(S_DS1)}, {sr(S_DS0)}, {8 * DS_TILE}")
+        self.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_SPAN)}, 14")
+        self.salu(f"s_add_u32 {sr(S_DS1)}, {sr(S_DS0)}, {sr(S_TMP)}")
         self.salu(f"s_addc_u32 {sr(S_DS1 + 1)}, {sr(S_DS0 + 1)}, 0")
 
     # -------------------------------------------------------------- block pass
@@ -574,12 +584,20 @@ class Gen:
             e.salu(f"s_mov_b32 {sr(dst)}, %[{src}]")
         e.salu(f"s_mov_b32 {sr(S_DSSTEP)}, %[dsrs]")
         e.salu(f"s_mov_b64 {sr(S_DS0, 2)}, %[dsp]")                             # the block's diagonal square of the dS workspace: slice s0 = 8 kb
-        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 15")                      # this wave's 32-key blocks 2 w, 2 w + 1 of the block: 8 tiles (one per slice of a query block) each
+        # this wave's two 32-key sub-blocks of the block: A = S_D0 (its first diagonal slice too) and A + S_SPAN
+        if self.balanced:
+            e.salu(f"s_mov_b32 {sr(S_D0)}, {sr(S_WID)}")                       # w and 7 - w
+            e.salu(f"s_lshl_b32 {sr(S_SPAN)}, {sr(S_WID)}, 1")
+            e.salu(f"s_sub_u32 {sr(S_SPAN)}, 7, {sr(S_SPAN)}")
+        else:
+            e.salu(f"s_lshl_b32 {sr(S_D0)}, {sr(S_WID)}, 1")                   # 2 w and 2 w + 1
+            e.salu(f"s_mov_b32 {sr(S_SPAN)}, 1")
+        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_D0)}, 14")                       # a 32-key block's tiles of a query block: 8 x 2 KiB, one per slice
         e.salu(f"s_add_u32 {sr(S_DS0)}, {sr(S_DS0)}, {sr(S_TMP)}")
         e.salu(f"s_addc_u32 {sr(S_DS0 + 1)}, {sr(S_DS0 + 1)}, 0")
-        e.salu(f"s_add_u32 {sr(S_DS1)}, {sr(S_DS0)}, {8 * DS_TILE}")
+        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_SPAN)}, 14")
+        e.salu(f"s_add_u32 {sr(S_DS1)}, {sr(S_DS0)}, {sr(S_TMP)}")
         e.salu(f"s_addc_u32 {sr(S_DS1 + 1)}, {sr(S_DS0 + 1)}, 0")
-        e.salu(f"s_lshl_b32 {sr(S_D0)}, {sr(S_WID)}, 1")                       # this wave's diagonal slices: 2 w and 2 w + 1 of the block's
         # DMA: slice s0's offsets, steps, saturation values
         e.salu(f"s_lshl_b32 {sr(S_QSTEP)}, %[qsr], 5")
         e.salu(f"s_lshl_b32 {sr(S_DOSTEP)}, %[dosr], 5")
@@ -629,9 +647,12 @@ class Gen:
         e.valu(f"v_lshl_add_u32 {vr(kve)}, {vr(t1)}, 4, {vr(t0)}")
         e.valu(f"v_xor_b32 {vr(t1)}, 2, {vr(t1)}")
         e.valu(f"v_lshl_add_u32 {vr(kvo)}, {vr(t1)}, 4, {vr(t0)}")
-        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 6")
-        e.salu(f"s_mul_i32 {sr(S_X0)}, {sr(S_TMP)}, %[kvsr]")                   # this wave's first key row, bytes
+        e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_D0)}, 5")
+        e.salu(f"s_mul_i32 {sr(S_X0)}, {sr(S_TMP)}, %[kvsr]")                   # this wave's first key row (sub-block A), bytes
         e.salu(f"s_lshl_b32 {sr(S_X1)}, %[kvsr], 3")                            # 8 rows further
+        e.salu(f"s_sub_u32 {sr(S_IT)}, {sr(S_SPAN)}, 1")                        # (S_IT is a temporary here) sub-block B lies S_SPAN sub-blocks behind A:
+        e.salu(f"s_lshl_b32 {sr(S_IT)}, {sr(S_IT)}, 5")                         # ... 32 (S_SPAN - 1) rows behind A's last row group
+        e.salu(f"s_mul_i32 {sr(S_IT)}, {sr(S_IT)}, %[kvsr]")
         e.salu(f"s_mov_b64 {sr(O_SRD, 2)}, %[kp]")
         e.salu(f"s_mov_b64 {sr(V_SRD, 2)}, %[vp]")
         e.salu(f"s_mov_b32 {sr(V_SRD + 2)}, %[kn]")
@@ -647,6 +668,8 @@ class Gen:
                     o = " offset:128" if half else ""
                     e.out.append(Ins(f"buffer_load_dwordx4 {vr(kvo if g & 1 else kve)}, {sr(srd, 4)}, {sr(S_TMP)} offen{o} lds", "dma", V(kvo if g & 1 else kve)))
                 e.salu(f"s_add_u32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_X1)}")
+                if g == 3:
+                    e.salu(f"s_add_u32 {sr(S_TMP)}, {sr(S_TMP)}, {sr(S_IT)}")   # on to sub-block B's rows
         for i in range(8):
             e.valu(f"v_mov_b32 {vr(S(0, 8) + i)}, 0")                            # (operands of the accumulator-clearing MFMAs below)
         e.valu(f"v_lshlrev_b32 {vr(t0)}, 2, {vr(h)}")
@@ -787,8 +810,11 @@ class Gen:
         e.salu("s_cbranch_scc1 L_idle_%=")
         e.salu(f"s_cmp_eq_u32 {sr(S_TMP)}, 0")
         e.salu("s_cbranch_scc1 L_diag0_%=")
-        e.salu(f"s_cmp_eq_u32 {sr(S_TMP)}, 1")
+        e.salu(f"s_cmp_eq_u32 {sr(S_TMP)}, {sr(S_SPAN)}")                      # its second sub-block's diagonal slice
         e.salu("s_cbranch_scc1 L_diag1_%=")
+        if self.balanced:
+            e.salu(f"s_cmp_lt_u32 {sr(S_TMP)}, {sr(S_SPAN)}")                  # between the two: only sub-block A is at work
+            e.salu("s_cbranch_scc1 L_half_%=")
         if self.mutant:
             e.salu(f"s_cmp_eq_u32 {sr(S_IT)}, {sr(S_MUT)}")
             e.salu("s_cbranch_scc1 L_drop_%=")
@@ -861,10 +887,13 @@ class Gen:
             e.out.append(Ins("s_waitcnt lgkmcnt(0)", "wait", tag="lgkm"))
             e.salu(f"s_mov_b64 {sr(O_SRD, 2)}, %[{ptr}]")
             e.salu(f"s_mov_b32 {sr(O_SRD + 2)}, %[on]")                        # rows beyond the last key are not stored
-            e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_WID)}, 6")
-            e.salu(f"s_mul_i32 {sr(S_X0)}, {sr(S_TMP)}, {sr(S_OSR)}")
+            e.salu(f"s_lshl_b32 {sr(S_TMP)}, {sr(S_D0)}, 5")
+            e.salu(f"s_mul_i32 {sr(S_X0)}, {sr(S_TMP)}, {sr(S_OSR)}")              # sub-block A's first row
             rows_per = 4 if self.D == 128 else 8                                    # rows one store instruction covers
             e.salu(f"s_lshl_b32 {sr(S_X1)}, {sr(S_OSR)}, {2 if self.D == 128 else 3}")
+            e.salu(f"s_sub_u32 {sr(S_TMP2)}, {sr(S_SPAN)}, 1")                      # sub-block B's rows: 32 (S_SPAN - 1) behind A's last
+            e.salu(f"s_lshl_b32 {sr(S_TMP2)}, {sr(S_TMP2)}, 5")
+            e.salu(f"s_mul_i32 {sr(S_TMP2)}, {sr(S_TMP2)}, {sr(S_OSR)}")
             for j in range(64 // rows_per):
                 d = 32 + 4 * (j % 8)    # v[32..63]: the dP registers are free now
                 e.out.append(Ins(f"ds_read_b128 {vr(d, 4)}, {vr(rd)} offset:{rows_per * j * STAGE_ROW}", "ldsw"))
@@ -873,6 +902,8 @@ class Gen:
                     for i in range(8):
                         e.out.append(Ins(f"buffer_store_dwordx4 {vr(32 + 4 * i, 4)}, {vr(oo)}, {sr(O_SRD, 4)}, {sr(S_X0)} offen", "vmem"))
                         e.salu(f"s_add_u32 {sr(S_X0)}, {sr(S_X0)}, {sr(S_X1)}")
+                    if rows_per * (j + 1) == 32:
+                        e.salu(f"s_add_u32 {sr(S_X0)}, {sr(S_X0)}, {sr(S_TMP2)}")
             # (no wait for the stores: their registers and the descriptor were read at issue, the slab is rewritten behind the lgkmcnt(0)
             #  above; they drain under the second tensor's conversion and the next pass's prologue, whose counted waits they only make stricter)
         if self.stamps:
@@ -906,7 +937,7 @@ class Gen:
         # slices it - 2 and it - 1, which were issued behind the pieces of slice it + 1 that the wait is for; a wave runs idle* diag0 diag1
         # steady*, so the two slices before a steady one stored 2 + 4 (its first) or 4 + 4: the smaller count is the safe one
         st = (lambda a, b: 3 + ((a + b) if self.ds else 0))
-        vm = {"steady": 4, "diag1": 2, "diag0": 0, "idle": 0, "drop": 4} if self.D == 128 else \
+        vm = {"steady": 4, "diag1": 2, "diag0": 0, "idle": 0, "drop": 4, "half": 2} if self.D == 128 else \
              {"steady": st(2, 4), "diag1": st(0, 2), "diag0": st(0, 0), "idle": st(0, 0), "drop": st(2, 4)}
         if self.D == 128 and not self.ds:
             vm = {k: 0 for k in vm}
@@ -918,6 +949,9 @@ class Gen:
         self.next_iter()
         sl("idle", "idle", vm["idle"])
         self.next_iter()
+        if self.balanced:
+            sl("half", "half", vm["half"])
+            self.next_iter()
         if self.mutant:
             sl("drop", "drop", vm["drop"])
             self.next_iter()
@@ -927,7 +961,7 @@ class Gen:
 
 
 # ------------------------------------------------------------------ counted LDS waits
-VARIANTS = r"L_(steady|diag1|diag0|idle|drop)_%=:"
+VARIANTS = r"L_(steady|diag1|diag0|idle|half|drop)_%=:"
 
 
 # 0: one counted wait per first use (rounds 4-5: 35 s_waitcnt per steady slice); N > 0: a wait also covers every later read that is N MFMA gaps old
