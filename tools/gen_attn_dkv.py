@@ -212,6 +212,15 @@ class Gen:
         op = "buffer_load_dword" if dword else "buffer_load_dwordx4"
         self.out.append(Ins(f"{op} {vr(voff)}, {sr(srd, 4)}, {sr(soff)} offen{o} lds", "dma", V(voff)))
 
+    def dma_only(self, srd, voff, soff, inst_off, dword=False):
+        """The request alone (its M0 write stands at the head of the same gap): an s_nop only if nothing else of the gap came between."""
+        if "dma" in self.ablate and getattr(self, "in_loop", False): return
+        if self.out[-1].text.startswith(("s_add_u32 m0", "s_mov_b32 m0")):
+            self.salu("s_nop 0")
+        o = f" offset:{inst_off}" if inst_off else ""
+        op = "buffer_load_dword" if dword else "buffer_load_dwordx4"
+        self.out.append(Ins(f"{op} {vr(voff)}, {sr(srd, 4)}, {sr(soff)} offen{o} lds", "dma", V(voff)))
+
     def dma_slice(self, seps=()):
         """This wave's pieces of one slice: rows 8 w .. 8 w + 7 of the Q tile and of the dO tile (two 1-KiB pieces each), and the 64 row
         constants (every wave fetches them: identical bytes, uniform counts). seps: up to five one-instruction emitters that stand between an
@@ -322,6 +331,11 @@ class Gen:
                     if n % 2 == 1:
                         dd = DP(ksb, n // 2)
                         put(m0 + n + 2, (0, 4), lambda d=d, dd=dd: self.valu(f"{self.cvt} {vr(dd)}, {vr(d - 1)}, {vr(d)}", V(d - 1) + V(d), V(dd)))
+        # (round 6) the five requests of slice it + 2 in gaps 0..4 - slot S, whose gaps hold next to nothing - instead of all five in gap 49 behind the barrier:
+        # same-box 1.844 / 1.849 ms against 1.873 / 1.868 (two runs of 4-5 interleaved pairs; gaps 2..6 the same, 6..10 and 12..16 half of it, all five in gap 0
+        # +1.7 %; profiles/r06_ab_ds_layout.txt). KF_GEN_DKV_DMA_GAPS="49": the old form; "g0,..,g4": one request per listed gap.
+        env_gaps = os.environ.get("KF_GEN_DKV_DMA_GAPS", "0,1,2,3,4" if self.D == 128 else "49")
+        dma_gaps = [] if env_gaps.strip() == "49" else [int(x) for x in env_gaps.split(",") if x]
         # ---- behind the barrier: ring toggle, DMA of slice it + 2 into the buffer this slice has finished with, then this slice's dS
         # the five read-base toggles of the ring step (behind the barrier, ahead of the next slice's head reads at gap 52) - round 6: each between an M0
         # write and the request that reads it, where an s_nop stood (KF_GEN_DKV_NOP_SEP=1: the old form, toggles at gap 48 and five s_nop)
@@ -339,11 +353,25 @@ class Gen:
             self.salu(f"s_cbranch_scc0 L_nodma_{name}_%=")
             self.dma_slice()
             self.label(f"L_nodma_{name}_%=")
-        put(49, (3, 0), dma_guarded if self.skip_tail_dma else (self.dma_slice if nop_sep else (lambda: self.dma_slice(toggles))))
+        # Where the five requests of slice it + 2 stand. They write the ring slot of slice it - 2, which every wave finished reading before the barrier of
+        # slice it - 1: ANY gap of this slice is safe. Default: all behind the barrier in gap 49 (with the toggles as separators). KF_GEN_DKV_DMA_GAPS="g0,..,g4":
+        # one piece per listed gap (round 6 experiment: a piece costs ~60 cycles of issue, a gap hides at most 24 of them - five pieces in gap 49 leave the
+        # matrix pipe idle for ~320 cycles, spread over five slack gaps for ~220 by the issue model).
+        if dma_gaps and not self.skip_tail_dma:
+            assert len(dma_gaps) == 5 and all(0 <= g < 62 for g in dma_gaps) and dma_gaps == sorted(dma_gaps), dma_gaps
+            if not nop_sep: put(48, (-3, 0), after_barrier)
+            pieces = [(Q_SRD, DMAQ, S_QOFF, 0, 0), (Q_SRD, DMAQ, S_QOFF, 896, 128), (DO_SRD, DMAD, S_DOOFF, SLICE_DO, 0), (DO_SRD, DMAD, S_DOOFF, SLICE_DO + 896, 128)]
+            for pc, g in zip(pieces, dma_gaps[:4]):
+                put(g, (-9, 0), lambda pc=pc: self.salu(f"s_add_u32 m0, {sr(S_M0)}, {pc[3]}" if pc[3] else f"s_mov_b32 m0, {sr(S_M0)}"))
+                put(g, (9, 0), lambda pc=pc: self.dma_only(pc[0], pc[1], pc[2], pc[4]))
+            put(dma_gaps[4], (-9, 0), lambda: self.salu(f"s_mov_b32 m0, {sr(S_M0C)}"))
+            put(dma_gaps[4], (9, 0), lambda: self.dma_only(C_SRD, DMAC, S_COFF, 0, dword=True))
+        else:
+            put(49, (3, 0), dma_guarded if self.skip_tail_dma else (self.dma_slice if nop_sep else (lambda: self.dma_slice(toggles))))
         def book():
             self.ring_step()
             self.advance_dma()
-        put(10 if self.early else 50, (4, 0), book)
+        put(10 if self.early else max([50] + [g + 1 for g in dma_gaps]), (4, 0), book)   # (the ring step and the next source offsets: behind the slice's last request)
         nst = 0
         if self.ds and compute and "stores" not in self.ablate:
             order = [(0, 0, 54), (0, 1, 56), (1, 0, 58), (1, 1, 60)]
@@ -368,10 +396,12 @@ class Gen:
                 # read of the current buffer has returned; then everyone's
                 # (no lgkmcnt here: the slot this slice reads is not rewritten before slice it + 2's request, two barriers on; the stamps build
                 #  keeps the full wait - it consumes its clock requests behind it)
+                # (what may still be in flight: the previous slice's stores - and, when this slice's own requests stand in front of the barrier, those five)
+                n_vm = prev_stores + (5 if dma_gaps and not self.skip_tail_dma and max(dma_gaps) < 48 and "dma" not in self.ablate else 0)
                 if self.stamps:
-                    self.out.append(Ins(f"s_waitcnt vmcnt({prev_stores}) lgkmcnt(0)", "wait", tag="vmlgkm"))
+                    self.out.append(Ins(f"s_waitcnt vmcnt({n_vm}) lgkmcnt(0)", "wait", tag="vmlgkm"))
                 else:
-                    self.out.append(Ins(f"s_waitcnt vmcnt({prev_stores})", "wait", tag="vm"))
+                    self.out.append(Ins(f"s_waitcnt vmcnt({n_vm})", "wait", tag="vm"))
                 self.barrier()
                 # diagnostic build: the clock requested behind the PREVIOUS barrier has long returned (the wait above covers it): the period
                 # that ended there is booked now - one slice late, so a kind's bucket holds its predecessor's period at every change of
