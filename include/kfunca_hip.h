@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define KF_ABI_VERSION 7 /* 7 (no signature changed): kf_attn_* run the matrix-core kernels on ANY sequence lengths with Skv >= Sq (no multiple-of-128 rule), the backward workspace keeps the causal half of dS only (kf_attn_bwd_workspace_bytes returns about half of version 6's figure; its row-constant arrays pad Sq to 32) - a caller must size the workspace with THIS library's query, kf_index_add drops indices outside [-nrows, nrows); 6: + KF_ERR_OOM from kf_malloc, kf_gemm_epilogue.c_f32 / kf_gemm_problem.c_f32 (float output behind 16-bit operands); 2: + kf_reduce_moments*, KF_EW_*_SCALAR, kf_graph_*, kf_attn_*_scaled; 3: + kf_sort*; 4: + kf_knobs_reload, kf_norm_*, kf_index_get, kf_gemm_ex, KF_EPI_*; 5: + kf_gemm_grouped_single_grid, kf_allreduce_sum_multi, kf_profile_samples, kf_attn_bwd accepts any workspace >= the statistics (all additive) */
+#define KF_ABI_VERSION 7 /* 7 (no signature changed): kf_attn_* run the matrix-core kernels on ANY sequence lengths with Skv >= Sq (no multiple-of-128 rule), the backward workspace's row-constant arrays pad Sq to 32 and its dS part has a second, half-size layout (the causal half: taken when the workspace does not hold full rows for every pair, or under KF_ATTN_DS_TRI) - a caller must size the workspace with THIS library's query, kf_index_add drops indices outside [-nrows, nrows); 6: + KF_ERR_OOM from kf_malloc, kf_gemm_epilogue.c_f32 / kf_gemm_problem.c_f32 (float output behind 16-bit operands); 2: + kf_reduce_moments*, KF_EW_*_SCALAR, kf_graph_*, kf_attn_*_scaled; 3: + kf_sort*; 4: + kf_knobs_reload, kf_norm_*, kf_index_get, kf_gemm_ex, KF_EPI_*; 5: + kf_gemm_grouped_single_grid, kf_allreduce_sum_multi, kf_profile_samples, kf_attn_bwd accepts any workspace >= the statistics (all additive) */
 
 /* ---- status ------------------------------------------------------------------------------ */
 enum {
@@ -370,14 +370,17 @@ int kf_attn_fwd_scaled(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv,
  * dq,dk,dv from d_o. Needs o and lse from the forward. The workspace holds three f32 rows of statistics (delta[B,H,Sq] and the two
  * row-constant arrays the dK/dV kernel reads, the latter two with Sq rounded up to 32 rows per pair: B*H*(Sq + 2 ceil32(Sq))*4 bytes, each
  * array rounded up to 256 - the MINIMUM, O(B H S)) and, on the
- * matrix-core path for 16-bit tensors, whatever lies beyond them holds dS = P o (dP - delta) in 16 bits - only its causal half (round 6):
- * with nq = ceil(Sq / 256) and nk = ceil(Skv / 256), one 128-KiB square per (query block, key block at or below its diagonal), i.e.
- * nq (nq + 1) / 2 squares per (batch, head) pair when Sq = Skv: 17 MiB at S = 4096 where the rectangle took 32: the dK/dV kernel writes it, the dQ kernel computes dQ = scale dS K from it, so the backward
- * executes the 5 matrix products of the algorithm instead of 7. The pairs are processed in GROUPS of as many as the workspace holds
+ * matrix-core path for 16-bit tensors, whatever lies beyond them holds dS = P o (dP - delta) in 16 bits, one 128-KiB square per (256-query
+ * block, 256-key block): the dK/dV kernel writes it, the dQ kernel computes dQ = scale dS K from it, so the backward executes the 5
+ * matrix products of the algorithm instead of 7. Two layouts, picked by what the workspace holds (round 6): FULL ROWS - nq x nk squares per
+ * (batch, head) pair, nq = ceil(Sq / 256), nk = ceil(Skv / 256): 32 MiB at S = 4096 - when there is room for every pair (the dQ kernel
+ * streams 3-12 % faster from rows on 2 MiB boundaries), else THE CAUSAL HALF - only the squares at or below a row's diagonal, nq (nq + 1) / 2
+ * when Sq = Skv: 17 MiB at S = 4096 - for as many pairs at a time as fit. The pairs are processed in GROUPS of as many as the workspace holds
  * dS for, so ANY workspace_bytes >= the minimum is accepted, for both head sizes and every S: with room for less than one pair's dS
  * (or with KF_ATTN_SPLIT_BWD set) the dQ kernel recomputes S and dP instead (minimum workspace, 7 products).
- * kf_attn_bwd_workspace_bytes() RECOMMENDS minimum + min(dS of all pairs, KF_ATTN_DS_CAP_MB MiB (default 16384)): bounded whatever
- * the problem size. No initialisation needed. Results do not depend on the group size (bit-identical).
+ * kf_attn_bwd_workspace_bytes() RECOMMENDS minimum + full rows for all pairs while that is within KF_ATTN_DS_CAP_MB MiB (default 16384), else
+ * minimum + the causal half of as many pairs as the cap holds; with KF_ATTN_DS_TRI=1 always the causal half (config C3: 4.25 GiB instead of 8):
+ * bounded whatever the problem size. No initialisation needed. Results depend neither on the group size nor on the layout (bit-identical).
  * No atomics in either form: dq, dk, dv are bitwise reproducible run to run.
  */
 int kf_attn_bwd_workspace_bytes(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Skv, int64_t D,

@@ -69,6 +69,7 @@ struct AttnArgs {
     int nbh;         // pairs in this launch (forward and the other forms: B H, bh0 = 0)
     char *ds;        // backward: dS = P o (dP - delta) in 16 bits, written by the dK/dV kernel, read by the dQ kernel (null: not kept)
     int64_t ds_nkb, ds_pair; // its tile grid (ds_tile_index below): 256-key blocks; tiles per (batch, head) pair
+    int ds_tri;              // 1: rows cut off behind their diagonal square (the causal half: half the bytes); 0: full rows (the rectangle of rounds 2-5)
 #if defined(KF_FWD_W4_STAMPS) || defined(KF_DKV_W4_STAMPS)
     unsigned long long *dbg; // diagnostic builds (tools/attn_fwd_w4_timeline.py, attn_dkv_w4_timeline.py): where every wave writes its cycle sums
 #endif
@@ -77,28 +78,30 @@ struct AttnArgs {
 // dS workspace (backward): the dK/dV kernel already holds dS = P o (dP - delta) as packed 16-bit MFMA operands; it stores them
 // and the dQ kernel computes dQ = scale dS K from them - 2 matrix products instead of the 6 a recomputing dQ kernel executes
 // (S and dP again), at the price of one 16-bit S x S / 2 round trip through HBM (4.3 GB at B 8, H 32, S 4096: HBM-bound at ~0.8 ms).
-// Layout (round 6: ONLY THE CAUSAL HALF is kept - VERDICT round 5, next #8): tiles of 32 keys x 32 queries (2 KiB), per (batch, head)
-// pair ordered [256-query block qb][256-key block kb <= qb][32-key block of kb: 0..7][slice of qb: 0..7] - the rectangular layout of rounds
-// 2-5 ([qb][32-key block][slice]) with every row cut off behind its diagonal square: row qb holds min(qb + 1, nkb) squares of 64 tiles.
+// Layout: tiles of 32 keys x 32 queries (2 KiB), per (batch, head) pair ordered [256-query block qb][256-key block kb][32-key block of kb: 0..7][slice of qb:
+// 0..7]. Two forms (ds_tri_mode below picks): FULL ROWS of nkb squares of 64 tiles (rounds 2-5: the rectangle, its upper half never touched), or - round 6,
+// VERDICT round 5 next #8 - THE CAUSAL HALF: every row cut off behind its diagonal square, row qb holds min(qb + 1, nkb) squares.
 // What a dQ workgroup (one query block) reads is still ONE contiguous stream, 32 KiB per 64-key step; a dK/dV wave's tile of the next
 // slice is 2 KiB on, the next query block's a row further (a row grows by one square per query block: the stream keeps the step in a
 // scalar register). Query blocks are whole (a dQ wave without queries still fetches its tiles).
 // (Measured same-box before settling on this: [kb][slice][32-key block] - a constant pointer step for dK/dV - and [kb][qb][..] both cost
-// the dQ kernel 4-9 %: its stream then jumps between sixteen areas of the pair instead of walking one row. This form against the rectangle
-// under the same code, four interleaved runs each: dQ 0.929 vs 0.939 ms, dK/dV 1.979 vs 1.983 - no difference: gpurun_out -> profiles/r06_ab_ds_layout.txt.)
+// the dQ kernel 4-9 %: its stream then jumps between sixteen areas of the pair instead of walking one row. The causal half against full rows under the
+// same code: no difference in tools/attn_bench.py's loop (0.929 vs 0.939 ms), 3-12 % slower dQ inside bench.py's step (rows no longer start on 2 MiB
+// boundaries; the pair stride is 17 MiB): profiles/r06_ab_ds_layout.txt - hence the two forms.)
 // Inside a tile: [s][key][hl][8 values] where the 8 values are accumulator registers e = 8 s + j of lane half hl, i.e. queries
 // (j & 3) + 8 (2 s + (j >> 2)) + 4 hl of the slice - exactly one packed operand of the dK/dV wave (key on the lane), so a store
 // instruction writes 1 KiB of consecutive bytes.
 constexpr int DS_TILE = 2048;
-// tiles in front of query block qb's row within one pair: sum over j < qb of min(j + 1, nkb) squares of 64 tiles
-__host__ __device__ inline int64_t ds_row_base(int64_t qb, int64_t nkb) {
+// tiles in front of query block qb's row within one pair. tri: sum over j < qb of min(j + 1, nkb) squares of 64 tiles; else qb rows of nkb squares
+__host__ __device__ inline int64_t ds_row_base(int64_t qb, int64_t nkb, int tri) {
+    if (!tri) return qb * nkb * 64;
     const int64_t m = qb < nkb ? qb : nkb;
     return 32 * m * (m + 1) + (qb - m) * nkb * 64;
 }
-__host__ __device__ inline int64_t ds_pair_tiles(int64_t Sq, int64_t Skv) { return ds_row_base((Sq + 255) / 256, (Skv + 255) / 256); }
-__host__ __device__ inline size_t ds_bytes(int64_t nbh, int64_t Sq, int64_t Skv) { return (size_t)nbh * (size_t)ds_pair_tiles(Sq, Skv) * DS_TILE; }
+__host__ __device__ inline int64_t ds_pair_tiles(int64_t Sq, int64_t Skv, int tri) { return ds_row_base((Sq + 255) / 256, (Skv + 255) / 256, tri); }
+__host__ __device__ inline size_t ds_bytes(int64_t nbh, int64_t Sq, int64_t Skv, int tri) { return (size_t)nbh * (size_t)ds_pair_tiles(Sq, Skv, tri) * DS_TILE; }
 // tile (kwb = 32-key block, sl = 32-query slice) of a pair, kwb / 8 <= sl / 8
-__host__ __device__ inline int64_t ds_tile_index(int64_t kwb, int64_t sl, int64_t nkb) { return ds_row_base(sl >> 3, nkb) + kwb * 8 + (sl & 7); }
+__host__ __device__ inline int64_t ds_tile_index(int64_t kwb, int64_t sl, int64_t nkb, int tri) { return ds_row_base(sl >> 3, nkb, tri) + kwb * 8 + (sl & 7); }
 
 // XCD-aware block order for the v2 kernels (1-D grid of nx * nbh blocks). Hardware deals block ids round-robin
 // over the 8 XCDs, each with a private 4 MiB L2. All nx blocks of one (batch, head) re-read that head's K/V
@@ -959,7 +962,7 @@ __global__ __launch_bounds__(FNT, 2) void attn_bwd_dq_ds_kernel(const AttnArgs a
     const int64_t kv_end = a.Skv < q_end ? a.Skv : q_end;
     const int nt = (int)((kv_end + ABK - 1) / ABK);
     // this query block's row of the pair's tiles, this wave's slice of it (whether it has queries or not: the grid holds whole query blocks): + kwb * 8 tiles
-    const char *dsg = a.ds + ((bh - a.bh0) * a.ds_pair + ds_row_base(qblk, a.ds_nkb) + wid) * DS_TILE;
+    const char *dsg = a.ds + ((bh - a.bh0) * a.ds_pair + ds_row_base(qblk, a.ds_nkb, a.ds_tri) + wid) * DS_TILE;
     const int kwb_last = (int)(a.ds_nkb * 8 - 1);
     const int slw = qblk * 8 + wid;
     auto stage = [&](int tile, int slot) { // 2 K pieces (this wave's share of the tile) + 4 dS pieces (its own two tiles)
@@ -1310,7 +1313,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     unsigned ds_lane = (unsigned)(xl * 32 + hl * 16);
     // this wave's 32-key block kwb = kw / 32 of the pair: tile (kwb, sl) = ds_tile_index = row of query block sl / 8 + kwb * 8 + (sl & 7)
     const char *ds_base = DS ? a.ds + ((bh - a.bh0) * a.ds_pair + (kw >> 5) * 8) * DS_TILE : nullptr;
-    const int ds_nkb = (int)a.ds_nkb;
+    const int ds_nkb = (int)a.ds_nkb, ds_tri = a.ds_tri;
     // a pair is 10 DMA operations per wave (ids 0..9: slice id / 5; Q rows i, dO rows i for i = 0, 1, then the row
     // constants); they are issued ONE per quarter-phase (an LDS-DMA instruction holds the wave's issue for 60-180 cycles,
     // which a lone wave per SIMD can only hide under MFMAs already queued)
@@ -1398,7 +1401,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
 
     // SOFF: this slice's offset inside its pair buffer (bases e, o, t0, t1, l); the next slice's first groups are read off
     // (en, on, ln) + NOFF; LAST: the slice that ends a pair (barrier + DMA of the pair after next before its q6)
-    auto slice_body = [&, ds_lane, ds_base, ds_nkb](auto mask_c, auto soff_c, auto noff_c, auto last_c, unsigned e, unsigned o, unsigned t0,
+    auto slice_body = [&, ds_lane, ds_base, ds_nkb, ds_tri](auto mask_c, auto soff_c, auto noff_c, auto last_c, unsigned e, unsigned o, unsigned t0,
                           unsigned t1, unsigned l, unsigned en, unsigned on, unsigned ln, int64_t qs, int pr, int it) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(mask_c)::value, LAST = decltype(last_c)::value;
         constexpr int SOFF = decltype(soff_c)::value, NOFF = decltype(noff_c)::value, DO = SOFF + BQS * AROW;
@@ -1520,7 +1523,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         uint64_t tb = 0;
         if constexpr (DS) {
             const int sl_ = (int)(qs >> 5);
-            const char *tile = ds_base + ((ds_row_base(sl_ >> 3, ds_nkb) + (sl_ & 7)) << 11); // DS_TILE = 2^11
+            const char *tile = ds_base + ((ds_row_base(sl_ >> 3, ds_nkb, ds_tri) + (sl_ & 7)) << 11); // DS_TILE = 2^11
             tb = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile) |
                  ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)tile >> 32)) << 32);
         }
@@ -1573,7 +1576,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
     //   | p5: its Q rows (-> p0) | p6: its dP constants (-> p2) | p7: its dO rows (-> p2; carried in g1)
     // counted waits (reads issued after the awaited group): p0 8, p2 8, p4 12, p5 12, p6 12, p7 12. The pair barrier sits in front of
     // p4: everything read after it belongs to the next pair's buffer when the slice is a pair's last.
-    auto slice_body64 = [&, ds_lane, ds_base, ds_nkb](auto mask_c, auto soff_c, auto noff_c, auto last_c, unsigned e, unsigned o, unsigned t0,
+    auto slice_body64 = [&, ds_lane, ds_base, ds_nkb, ds_tri](auto mask_c, auto soff_c, auto noff_c, auto last_c, unsigned e, unsigned o, unsigned t0,
                             unsigned t1, unsigned l, unsigned en, unsigned on, unsigned ln, int64_t qs, int pr, int it) __attribute__((always_inline)) {
         constexpr bool MASK = decltype(mask_c)::value, LAST = decltype(last_c)::value;
         constexpr int SOFF = decltype(soff_c)::value, NOFF = decltype(noff_c)::value, DO = SOFF + BQS * AROW, NDO = NOFF + BQS * AROW;
@@ -1629,7 +1632,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_v4_kernel(const AttnArgs a) 
         uint64_t tb = 0;
         if constexpr (DS) {
             const int sl_ = (int)(qs >> 5);
-            const char *tile = ds_base + ((ds_row_base(sl_ >> 3, ds_nkb) + (sl_ & 7)) << 11);
+            const char *tile = ds_base + ((ds_row_base(sl_ >> 3, ds_nkb, ds_tri) + (sl_ & 7)) << 11);
             tb = (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)tile) |
                  ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)tile >> 32)) << 32);
         }
@@ -1807,8 +1810,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_w4_kernel(const AttnArgs a) 
         const int ns = ns_all;                             // (a block beyond the last query, s0 >= ns: no slices, zero gradients; the stream clamps its first requests to slice ns - 1)
         // this block's first square of the dS workspace (ds_tile_index): row of query block xb, square xb; the stream walks down from there - dsrs =
         // the bytes from a query block's last slice to the next block's first (its row's length less seven tiles), growing by a square per row up to dsrm
-        const char *dsp = DS ? a.ds + ((bh - a.bh0) * a.ds_pair + ds_row_base(xb, a.ds_nkb) + (int64_t)xb * 64) * DS_TILE : nullptr;
-        const int64_t rowlen = (xb + 1 < a.ds_nkb ? xb + 1 : a.ds_nkb);
+        const char *dsp = DS ? a.ds + ((bh - a.bh0) * a.ds_pair + ds_row_base(xb, a.ds_nkb, a.ds_tri) + (int64_t)xb * 64) * DS_TILE : nullptr;
+        const int64_t rowlen = (a.ds_tri && xb + 1 < a.ds_nkb) ? xb + 1 : a.ds_nkb;   // (full rows: the step never grows - it starts at its maximum)
         const unsigned dsrs = (unsigned)((rowlen * 64 - 7) * DS_TILE), dsrm = (unsigned)((a.ds_nkb * 64 - 7) * DS_TILE);
         int mut = -1;
 #ifdef KF_MUTANT
@@ -2518,8 +2521,14 @@ static inline int64_t stat_rows(int64_t Sq) { return (Sq + 31) / 32 * 32; } // r
 static size_t bwd_stats_bytes(int64_t nbh, int64_t Sq) { // delta [B H, Sq] | -lse / scale [B H, Sqc] | -delta [B H, Sqc]
     return a_align((size_t)nbh * Sq * sizeof(float)) + 2 * a_align((size_t)nbh * stat_rows(Sq) * sizeof(float));
 }
-static int64_t ds_group(int64_t nbh, int64_t Sq, int64_t Skv, size_t budget) { // pairs whose dS fit into `budget` bytes
-    const size_t one = ds_bytes(1, Sq, Skv);
+// Which layout the dS tiles take. FULL ROWS (the rectangle of rounds 2-5) when the workspace holds them for every pair of the launch:
+// the dQ kernel streams 3-12 % faster from rows that start on 2 MiB boundaries (bench.py context, four interleaved runs on two boxes: 0.88 against 0.94-0.99 ms;
+// profiles/r06_ab_ds_layout.txt). Else THE CAUSAL HALF (round 6): 0.53 of the bytes at Sq = Skv = 4096 - twice the pairs per group under any cap, and C3 in one
+// group of 4.25 GiB where the rectangle needs 8. KF_ATTN_DS_TRI=1 takes the half whatever the workspace holds (kf_attn_bwd_workspace_bytes then asks for it).
+// Results do not depend on the layout (bit-identical).
+static int ds_tri_mode(int64_t nbh, int64_t Sq, int64_t Skv, size_t budget) { return (knob(KNOB_ATTN_DS_TRI) || budget < ds_bytes(nbh, Sq, Skv, 0)) ? 1 : 0; }
+static int64_t ds_group(int64_t nbh, int64_t Sq, int64_t Skv, size_t budget, int tri) { // pairs whose dS fit into `budget` bytes
+    const size_t one = ds_bytes(1, Sq, Skv, tri);
     int64_t g = (int64_t)(budget / one);
     if (g >= nbh) return nbh;
     if (g >= 8) g -= g % 8;
@@ -2705,7 +2714,10 @@ extern "C" int kf_attn_bwd_workspace_bytes(int dtype, int64_t B, int64_t H, int6
     if (rc != KF_OK) return rc;
     *bytes = bwd_stats_bytes(B * H, Sq); // delta | -lse log2(e) | -delta
     if ((mfma_ok(dtype, Sq, Skv, D) || w4_any_ok(dtype, Sq, Skv, D)) && !knob(KNOB_ATTN_SPLIT_BWD) && B * H > 0)
-        *bytes += ds_bytes(ds_group(B * H, Sq, Skv, ds_cap()), Sq, Skv); // + dS in 16 bits (DS_TILE) of one group of pairs
+    { // + dS in 16 bits (DS_TILE): full rows for every pair when the cap allows (the faster dQ stream), else the causal half of as many pairs as the cap holds
+        const int tri = ds_tri_mode(B * H, Sq, Skv, ds_cap());
+        *bytes += ds_bytes(ds_group(B * H, Sq, Skv, ds_cap(), tri), Sq, Skv, tri);
+    }
     return KF_OK;
 }
 
@@ -2783,7 +2795,8 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
                         (uint64_t)(Sq + 32) * (uint64_t)std::max(a.lq.sr, a.ldo.sr) < (1ull << 32) && (uint64_t)K5B * (uint64_t)std::max(a.lk.sr, a.ldk.sr) < (1ull << 31) &&
                         (uint64_t)((const char *)a.ndelta - (const char *)a.nlse) < (1ull << 31) && !knob(KNOB_ATTN_DKV_V4);
     // a ragged shape has no other matrix-core kernels: it needs the generated dK/dV stream AND room for dS (the recomputing dQ kernel wants whole tiles)
-    const bool ragged_ok = !tiled && dkv_w4 && !knob(KNOB_ATTN_SPLIT_BWD) && ds_group(B * H, Sq, Skv, workspace_bytes - need) > 0;
+    const int ds_tri = ds_tri_mode(B * H, Sq, Skv, workspace_bytes - need);
+    const bool ragged_ok = !tiled && dkv_w4 && !knob(KNOB_ATTN_SPLIT_BWD) && ds_group(B * H, Sq, Skv, workspace_bytes - need, ds_tri) > 0;
     if (tiled || ragged_ok) {
         const bool bf = dtype == KF_BF16;
         // exact f32 scores everywhere by default (exponent = (s - lse / scale) * scale log2 e: the row constant is -lse / scale); only the opt-in
@@ -2800,10 +2813,11 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
             KF_LAUNCH_CHECK();
         }
         const int64_t nbh = B * H;
-        const int64_t group = knob(KNOB_ATTN_SPLIT_BWD) ? 0 : ds_group(nbh, Sq, Skv, workspace_bytes - need);
+        const int64_t group = knob(KNOB_ATTN_SPLIT_BWD) ? 0 : ds_group(nbh, Sq, Skv, workspace_bytes - need, ds_tri);
         const bool keep_ds = group > 0;
         a.ds = keep_ds ? (char *)workspace + need : nullptr;
-        a.ds_pair = ds_pair_tiles(Sq, Skv);
+        a.ds_tri = ds_tri;
+        a.ds_pair = ds_pair_tiles(Sq, Skv, ds_tri);
         a.ds_nkb = (Skv + 255) / 256;
         const int64_t nkb4 = Skv / K4B, nxq = (Sq + FQ - 1) / FQ;
         const int pair_kv = (nkb4 % 2 == 0 && nkb4 >= 4 && !knob(KNOB_ATTN_NO_PAIR)) ? 1 : 0;

@@ -101,7 +101,7 @@ static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream
 // kf_knobs_reload() re-reads them (tests and tools that flip a switch between two calls).
 enum Knob {
     KNOB_ATTN_NO_XCD, KNOB_ATTN_NO_DEFER, KNOB_ATTN_NO_PAIR, KNOB_ATTN_F32_GENERIC, KNOB_ATTN_SPLIT_BWD, KNOB_GEMM_128, KNOB_GEMM_W4,
-    KNOB_GEMM_W8, KNOB_GEMM_GROUP_M, KNOB_GEMM_F64_GENERIC, KNOB_REDUCE_NO_TALL, KNOB_GEMM_NO_SPLITK, KNOB_GEMM_NO_GROUP, KNOB_ATTN_DS_CAP_MB, KNOB_NORM_BWD_TPR, KNOB_ATTN_FWD_V3, KNOB_ATTN_DKV_V4, KNOB_ATTN_SCALED_OPERANDS, KNOB_ATTN_GRID_WGS, KNOB_GEMM_NO_PAD, KNOB_GEMM_H256_MIN, KNOB_EW_ALIGNED_ONLY, KNOB_COUNT
+    KNOB_GEMM_W8, KNOB_GEMM_GROUP_M, KNOB_GEMM_F64_GENERIC, KNOB_REDUCE_NO_TALL, KNOB_GEMM_NO_SPLITK, KNOB_GEMM_NO_GROUP, KNOB_ATTN_DS_CAP_MB, KNOB_NORM_BWD_TPR, KNOB_ATTN_FWD_V3, KNOB_ATTN_DKV_V4, KNOB_ATTN_SCALED_OPERANDS, KNOB_ATTN_GRID_WGS, KNOB_GEMM_NO_PAD, KNOB_GEMM_H256_MIN, KNOB_EW_ALIGNED_ONLY, KNOB_ATTN_DS_TRI, KNOB_COUNT
 };
 bool knob(Knob k);              // the variable is set
 long knob_int(Knob k, long dflt); // its integer value, dflt when unset

@@ -68,7 +68,7 @@ static void prof_collect() { // folds finished records into per-name sums
 namespace kf {
 static const char *const g_knob_names[KNOB_COUNT] = {
     "KF_ATTN_NO_XCD", "KF_ATTN_NO_DEFER", "KF_ATTN_NO_PAIR", "KF_ATTN_F32_GENERIC", "KF_ATTN_SPLIT_BWD", "KF_GEMM_128", "KF_GEMM_W4",
-    "KF_GEMM_W8", "KF_GEMM_GROUP_M", "KF_GEMM_F64_GENERIC", "KF_REDUCE_NO_TALL", "KF_GEMM_NO_SPLITK", "KF_GEMM_NO_GROUP", "KF_ATTN_DS_CAP_MB", "KF_NORM_BWD_TPR", "KF_ATTN_FWD_V3", "KF_ATTN_DKV_V4", "KF_ATTN_SCALED_OPERANDS", "KF_ATTN_GRID_WGS", "KF_GEMM_NO_PAD", "KF_GEMM_H256_MIN", "KF_EW_ALIGNED_ONLY"};
+    "KF_GEMM_W8", "KF_GEMM_GROUP_M", "KF_GEMM_F64_GENERIC", "KF_REDUCE_NO_TALL", "KF_GEMM_NO_SPLITK", "KF_GEMM_NO_GROUP", "KF_ATTN_DS_CAP_MB", "KF_NORM_BWD_TPR", "KF_ATTN_FWD_V3", "KF_ATTN_DKV_V4", "KF_ATTN_SCALED_OPERANDS", "KF_ATTN_GRID_WGS", "KF_GEMM_NO_PAD", "KF_GEMM_H256_MIN", "KF_EW_ALIGNED_ONLY", "KF_ATTN_DS_TRI"};
 static std::mutex g_knob_mu;
 static bool g_knob_loaded = false;
 static bool g_knob_set[KNOB_COUNT];

@@ -370,10 +370,9 @@ def test_backward_forms_stored_ds_and_recomputing_split(code):
             with H.knobs(KF_ATTN_SPLIT_BWD=env):
                 small = 3 * ((B * Hh * Sq * 4 + 255) // 256 * 256)   # (Sq is a multiple of 32 here: the row-constant arrays need no pad rows)
                 need = H.attn_bwd_workspace_bytes(code, B, Hh, Sq, Skv, 128)
-                # dS, round 6: only the causal half - 256-key block kb keeps the 32-query slices from 8 kb on, slices counted in whole 256-query blocks
+                # dS as full rows (the default while the cap holds them for every pair): ceil(Sq / 256) x ceil(Skv / 256) squares of 64 tiles of 2 KiB
                 nqb, nkb = (Sq + 255) // 256, (Skv + 255) // 256
-                tiles = sum(max(0, 8 * nqb - 8 * kb) * 8 for kb in range(nkb))
-                assert need == (small if env else small + B * Hh * tiles * 2048), (form, need)
+                assert need == (small if env else small + B * Hh * nqb * nkb * 64 * 2048), (form, need)
                 H.profile_reset()
                 H.profile_enable(True)
                 res[form] = bwd(code, q, k, v, o, lse, go)
@@ -455,22 +454,32 @@ def test_backward_workspace_is_bounded_any_size_above_the_statistics_is_accepted
     o, lse = fwd(code, q, k, v)
     stats = 3 * ((B * Hh * S * 4 + 255) // 256 * 256)
     nb = (S + 255) // 256
-    one = 32 * nb * (nb + 1) * 2048  # dS of one pair, round 6: the causal half only - sum over 256-key blocks kb of (8 nb - 8 kb) slices x 8 tiles of 2 KiB
-    assert one <= 0.76 * (nb * 256 * S * 2)   # (two blocks: 3 / 4 of the rectangle; sixteen - config C3 - 17 / 32: checked below)
+    # dS of one pair in its two layouts (include/kfunca_hip.h): FULL ROWS (nb x nb squares of 128 KiB: what the query recommends while the cap holds it
+    # for every pair - the dQ kernel streams faster from 2 MiB-aligned rows) and, round 6, THE CAUSAL HALF (nb (nb + 1) / 2 squares), which the library
+    # takes whenever the workspace it is given does not hold full rows for all pairs, or under KF_ATTN_DS_TRI=1
+    one, half = nb * nb * 64 * 2048, 32 * nb * (nb + 1) * 2048
     full = H.attn_bwd_workspace_bytes(code, B, Hh, S, S, D)
     assert full == stats + B * Hh * one
-    # config C3 (B 8, H 32, S 4096): 8 GiB of dS until round 5, at most 0.55 of that now
-    c3 = H.attn_bwd_workspace_bytes(code, 8, 32, 4096, 4096, D) - 3 * 8 * 32 * 4096 * 4
-    assert c3 <= 0.55 * (8 * 32 * 4096 * 4096 * 2), c3
+    with H.knobs(KF_ATTN_DS_TRI="1"):
+        assert H.attn_bwd_workspace_bytes(code, B, Hh, S, S, D) == stats + B * Hh * half
+        # config C3 (B 8, H 32, S 4096): 8 GiB of dS as full rows, at most 0.55 of that as the causal half
+        c3 = H.attn_bwd_workspace_bytes(code, 8, 32, 4096, 4096, D) - 3 * 8 * 32 * 4096 * 4
+        assert c3 <= 0.55 * (8 * 32 * 4096 * 4096 * 2), c3
     ref = _bwd_ws(code, q, k, v, o, lse, go, full)
+    with H.knobs(KF_ATTN_DS_TRI="1"):   # the causal half for every pair at once: the same bits
+        tri = _bwd_ws(code, q, k, v, o, lse, go, stats + B * Hh * half)
+    for n, a0, a1 in zip(("dq", "dk", "dv"), ref, tri):
+        assert np.array_equal(a0.view(np.uint16), a1.view(np.uint16)), ("causal half", n)
     sfx = "_d64" if D == 64 else ""
     for pairs in (3, 8, 16, 23):
         H.profile_reset()
         H.profile_enable(True)
-        got = _bwd_ws(code, q, k, v, o, lse, go, stats + pairs * one + 100)
+        got = _bwd_ws(code, q, k, v, o, lse, go, stats + pairs * one + 100)   # less than full rows for all 24 pairs: groups of the causal half
         H.profile_enable(False)
         res = H.profile_results()
-        groups = -(-B * Hh // (pairs if pairs < 8 else pairs - pairs % 8))
+        g = (pairs * one + 100) // half
+        g = min(B * Hh, g if g < 8 else g - g % 8)
+        groups = -(-B * Hh // g)
         assert res["attn_bwd_dkv_mfma" + sfx][1] == groups and res["attn_bwd_dq_mfma" + sfx][1] == groups, (pairs, res)
         for n, a0, a1 in zip(("dq", "dk", "dv"), ref, got):
             assert np.array_equal(a0.view(np.uint16), a1.view(np.uint16)), (pairs, n)
@@ -484,8 +493,8 @@ def test_backward_workspace_is_bounded_any_size_above_the_statistics_is_accepted
     with pytest.raises(H.KfError) as e:
         _bwd_ws(code, q, k, v, o, lse, go, stats - 256)
     assert e.value.code == H.KF_ERR_WORKSPACE
-    with H.knobs(KF_ATTN_DS_CAP_MB="4"):  # 4 MiB = 8 pairs of 512 KiB
-        assert H.attn_bwd_workspace_bytes(code, B, Hh, S, S, D) == stats + 8 * one
+    with H.knobs(KF_ATTN_DS_CAP_MB="4"):  # 4 MiB: not full rows for all 24 pairs -> groups of the causal half, 10 pairs of 384 KiB fit: 8 (a multiple of 8)
+        assert H.attn_bwd_workspace_bytes(code, B, Hh, S, S, D) == stats + 8 * half
         capped = bwd(code, q, k, v, o, lse, go)
     for n, a0, a1 in zip(("dq", "dk", "dv"), ref, capped):
         assert np.array_equal(a0.view(np.uint16), a1.view(np.uint16)), n
