@@ -267,3 +267,27 @@ def test_stale_rendezvous_file_is_refused(tmp_path):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_bench_under_the_drivers_own_launch_line_cpu_dry_run():
+    """The driver starts N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py --gpus N ...`: the ranks find RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, must NOT start children of their
+    own, rendezvous over torchrun's TCP store and rank 0 alone prints the one JSON line."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from pathlib import Path
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "KF_RDZV_FILE", "KF_RDZV_T0")}
+    root = Path(__file__).resolve().parent.parent
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run-cpu"],
+                         capture_output=True, text=True, env=env, timeout=300, cwd=str(root))
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["dry_run"] and line["n_gpus"] == 2 and line["allreduce_check"] is True
