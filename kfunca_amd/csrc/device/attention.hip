@@ -2840,12 +2840,7 @@ static int attn_bwd_impl(int dtype, int64_t B, int64_t H, int64_t Sq, int64_t Sk
         // (Tried in round 3 and removed: the dS workspace as two half-group slots with group g's dQ - HBM-bound, it streams dS - on a second
         // stream beside group g + 1's matrix-bound dK/dV. At C3 the backward took 3.39-3.78 ms against 3.32-3.36 in sequence
         // (profiles/r03_attn_bwd_overlap_experiment.txt): both kernels fill every CU, so the dispatcher interleaves them instead of
-        // running them side by side, and each group boundary adds a tail. Round 6 repeated it with DISJOINT compute-unit masks
-        // (hipExtStreamCreateWithCUMask: dK/dV of group g on 256 - n CUs beside dQ of group g - 1 on the other n, the first dK/dV group and the
-        // last dQ group on the whole chip, group sizes chosen so that every launch is whole rounds of its partition): the step took 4.24-5.49 ms
-        // against 4.22 in sequence on the same box for n = 64 .. 128 (profiles/r06_bwd_cu_split_experiment.txt). The dQ stream is latency-bound
-        // per CU (144 KiB of LDS is what it keeps in flight: ~25 GB/s per CU, so it needs > 100 CUs to finish beside the dK/dV stream), and
-        // the chip is power-bound over the step: what the backward leaves unused comes back as clock in the FORWARD (1.04 -> 0.96 ms), not here.)
+        // running them side by side, and each group boundary adds a tail.)
         const int64_t grp = keep_ds ? group : nbh;
         // one group of (batch, head) pairs at a time: dK/dV (stores the group's dS), then dQ from it. Without dS: one group, all pairs.
         for (int64_t bh0 = 0; bh0 < nbh; bh0 += grp) {
