@@ -49,14 +49,15 @@ def to_f64(x, code):
 
 def gemm_ok(got16, a16, b16, code, trans_a=False, trans_b=False):
     """THE acceptance bound of a 16-bit GEMM output (tests/test_gpu_gemm.py and bench.py's spot check share it): against the
-    double-precision product of the 16-bit operands, |got - c| <= eps |c| + 1e-6 sum_k |a||b| - one rounding of the result to the
+    double-precision product of the 16-bit operands, |got - c| <= eps |c| + 1e-6 sum_k |a||b| + half a subnormal ulp - one rounding of the result to the
     element type (eps = half an ulp) plus f32 accumulation noise relative to the sum of the terms' magnitudes. Returns (ok, worst
     fraction of the bound)."""
     a, b = to_f64(a16, code), to_f64(b16, code)
     a = a.T if trans_a else a
     b = b.T if trans_b else b
     want, mag = a @ b, np.abs(a) @ np.abs(b)
-    frac = np.abs(to_f64(got16, code) - want) / (EPS[code] * np.abs(want) + 1e-6 * mag + 1e-30)
+    # (+ half an absolute ulp of the format's subnormal grid: at K = 1 a product of two small f16 operands has nothing else to hide behind)
+    frac = np.abs(to_f64(got16, code) - want) / (EPS[code] * np.abs(want) + 1e-6 * mag + 0.5 * ABS_ULP[code])
     return bool((frac <= 1.0).all()), float(frac.max())
 
 
