@@ -527,3 +527,19 @@ def test_ragged_in_one_extent_only(code, M, N, K):
         H.profile_enable(False)
         assert "gemm_generic" not in H.profile_results(), H.profile_results()
         assert (np.abs(got - want) <= 2 * eps * np.abs(want) + 2 * eps * mag + 1e-30).all(), tb
+
+
+@pytest.mark.parametrize("code", [H.F16, H.BF16, H.F32])
+def test_one_term_products_are_the_once_rounded_product(code):
+    """K = 1: every output is ONE product, rounded once to the element type - bit for bit, subnormal f16 results included (found by the randomised
+    stress, whose bound had no absolute floor: the kernels were right). Every operand layout, ragged M and N, extents of 1."""
+    rng = np.random.default_rng(77 + code)
+    for (M, N) in ((587, 275), (64, 64), (1, 300), (257, 1), (1, 1)):
+        a = O.from_float(rng.uniform(-1, 1, (M, 1)).astype(np.float32), code)
+        b = O.from_float(rng.uniform(-1, 1, (1, N)).astype(np.float32), code)
+        a[:: 7] = O.from_float(np.full((len(a[::7]), 1), 3e-4, np.float32), code)    # products of two small operands: f16 subnormals
+        want = O.from_float((f64(a, code) @ f64(b, code)).astype(np.float32), code)  # (the f32 product of two 16-bit values is exact; of two floats: one rounding)
+        for ta in (False, True):
+            for tb in (False, True):
+                got = run_gemm(code, np.ascontiguousarray(a.T) if ta else a, np.ascontiguousarray(b.T) if tb else b, ta=ta, tb=tb)
+                assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (code, M, N, ta, tb)
