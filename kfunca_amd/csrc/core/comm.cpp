@@ -20,7 +20,7 @@ std::mutex g_comm_mu;
 int code(ScalarType t) { return static_cast<int>(t); } // ScalarType order == KF_* codes (scalar_type.h)
 
 void check_dense(const Tensor &t, const char *who) {
-    CHECK_FAIL(t.defined() && t.is_contiguous(), who, ": the tensor must be dense (contiguous)");
+    CHECK_FAIL(t.defined() && t.is_dense(), who, ": the tensor must be dense (contiguous)");
 }
 } // namespace
 

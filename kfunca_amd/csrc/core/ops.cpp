@@ -337,7 +337,7 @@ std::tuple<Tensor, Tensor> sort(const Tensor &self, int64_t dim, bool descending
     CHECK_FAIL(self.dtype() != ScalarType::Bool, "Sort currently does not support bool dtypes.");
 
     // keys with the sorted dim contiguous: self itself, or a dense copy with that dim last (sort_ops_kernel.cu:572-581)
-    const bool direct = self.is_contiguous() && self.stride((int)dim) == 1;
+    const bool direct = self.is_dense() && self.stride((int)dim) == 1;
     Tensor keys = self;
     if (!direct) {
         keys = empty_strided(self.sizes(), dense_strides_dim_last(self, dim), self.dtype(), self.device());
@@ -499,7 +499,7 @@ public:
     std::vector<Tensor> backward(Tensor g) override {
         const Tensor &a = inputs[0], &b = inputs[1];
         const int64_t K = b.shape(0), N = b.shape(1), M = a.numel() / K;
-        Tensor gc = g.contiguous();
+        Tensor gc = g.dense();
         std::vector<Tensor> out(2);
         linear_backward(a, b, gc.view({M, N}), alpha_, M, N, K, out[0], out[1]);
         return out;
@@ -512,7 +512,8 @@ private:
 } // namespace
 
 void gemm_out(Tensor &out, const Tensor &a, const Tensor &b, float alpha, float beta) {
-    CHECK_FAIL(out.is_contiguous() && a.is_contiguous() && b.is_contiguous());
+    // (the reference asks its FLAG here, gemm_kernel.cu:9 - it refuses every view, dense or not, e.g. x.view(T, d); this host asks the strides: a superset)
+    CHECK_FAIL(out.is_dense() && a.is_dense() && b.is_dense());
     CHECK_FAIL(a.dim() >= 1);
     const int64_t k = a.shape(-1);
     CHECK_FAIL(k > 0);
@@ -560,7 +561,7 @@ public:
     std::vector<Tensor> backward(Tensor g) override {
         const Tensor &a = inputs[0], &b = inputs[1];
         const int64_t K = b.shape(0), N = b.shape(1), M = a.numel() / K;
-        Tensor g2 = g.contiguous().view({M, N});
+        Tensor g2 = g.dense().view({M, N});
         std::vector<Tensor> out(inputs.size());
         if (iadd_ >= 0 && inputs[iadd_].requires_grad()) out[iadd_] = g2.view(inputs[iadd_].sizes());
         Tensor dt = g2;
@@ -584,7 +585,7 @@ private:
 } // namespace
 
 Tensor gemm_fused(const Tensor &a, const Tensor &b, float alpha, const Tensor &bias, const Tensor &mul_t, const Tensor &add_t) {
-    CHECK_FAIL(a.defined() && b.defined() && a.is_contiguous() && b.is_contiguous() && a.dim() >= 1 && b.dim() == 2);
+    CHECK_FAIL(a.defined() && b.defined() && a.is_dense() && b.is_dense() && a.dim() >= 1 && b.dim() == 2);
     const int64_t k = a.shape(-1), n = b.shape(1);
     CHECK_FAIL(k > 0 && b.shape(0) == k && n > 0 && a.dtype() == b.dtype() && a.device() == b.device());
     CHECK_FAIL(gemm_dtype_ok(a.dtype()), "Unsupported ScalarType ", a.dtype());
@@ -592,9 +593,9 @@ Tensor gemm_fused(const Tensor &a, const Tensor &b, float alpha, const Tensor &b
     auto out_size = a.sizes();
     out_size.back() = n;
     for (const Tensor *t : {&mul_t, &add_t})
-        if (t->defined()) CHECK_FAIL(t->is_contiguous() && t->dtype() == a.dtype() && t->device() == a.device() && t->numel() == m * n && t->shape(-1) == n,
+        if (t->defined()) CHECK_FAIL(t->is_dense() && t->dtype() == a.dtype() && t->device() == a.device() && t->numel() == m * n && t->shape(-1) == n,
                                      "gemm_fused: mul / add must be contiguous tensors of the output's shape and dtype");
-    if (bias.defined()) CHECK_FAIL(bias.is_contiguous() && bias.dim() == 1 && bias.shape(0) == n && bias.dtype() == a.dtype() && bias.device() == a.device(),
+    if (bias.defined()) CHECK_FAIL(bias.is_dense() && bias.dim() == 1 && bias.shape(0) == n && bias.dtype() == a.dtype() && bias.device() == a.device(),
                                    "gemm_fused: bias must be a contiguous [N] tensor of the operands' dtype");
     Tensor out = empty(out_size, a.dtype(), a.device());
     const bool keep_raw = mul_t.defined() && mul_t.requires_grad();
@@ -642,7 +643,7 @@ Tensor gemm_fused(const Tensor &a, const Tensor &b, float alpha, const Tensor &b
 }
 
 Tensor gemm_ex(const Tensor &a, bool trans_a, const Tensor &b, bool trans_b, float alpha) {
-    CHECK_FAIL(a.dim() == 2 && b.dim() == 2 && a.is_contiguous() && b.is_contiguous());
+    CHECK_FAIL(a.dim() == 2 && b.dim() == 2 && a.is_dense() && b.is_dense());
     CHECK_FAIL(a.dtype() == b.dtype() && gemm_dtype_ok(a.dtype()));
     const int64_t M = trans_a ? a.shape(1) : a.shape(0), K = trans_a ? a.shape(0) : a.shape(1);
     const int64_t Kb = trans_b ? b.shape(1) : b.shape(0), N = trans_b ? b.shape(0) : b.shape(1);
@@ -662,7 +663,7 @@ void check_attention(const Tensor &q, const Tensor &k, const Tensor &v) {
     CHECK_FAIL(q.dtype() == k.dtype() && q.dtype() == v.dtype());
     CHECK_FAIL(q.dtype() == ScalarType::Float || q.dtype() == ScalarType::Half || q.dtype() == ScalarType::BFloat16,
                "Unsupported ScalarType ", q.dtype());
-    CHECK_FAIL(q.is_contiguous() && k.is_contiguous() && v.is_contiguous());
+    CHECK_FAIL(q.is_dense() && k.is_dense() && v.is_dense());
     CHECK_FAIL(q.device() == k.device() && q.device() == v.device());
 }
 
@@ -705,7 +706,7 @@ Tensor pad_to(const Tensor &t, int64_t rows, int64_t cols) { // [B,H,S,D] -> [B,
 Tensor unpad(const Tensor &t, int64_t rows, int64_t cols) {
     Tensor v = t.narrow(2, 0, rows);
     if (t.dim() == 4) v = v.narrow(3, 0, cols);
-    return v.contiguous();
+    return v.dense();
 }
 
 class AttentionGradFunction : public GradFunction {
@@ -770,7 +771,7 @@ std::tuple<Tensor, Tensor, Tensor> causal_attention_bwd(const Tensor &q, const T
     if (const PadPlan pp = pad_for_mfma(q, k); pp.pad) {
         const int64_t Sqp = pp.Sqp, Skp = pp.Skp, Dp = pp.Dp;
         Tensor qp = pad_to(q, Sqp, Dp), kp = pad_to(k, Skp, Dp), vp = pad_to(v, Skp, Dp), op = pad_to(out, Sqp, Dp);
-        Tensor lp = pad_to(lse, Sqp, 0), gp = pad_to(grad_out.contiguous(), Sqp, Dp);
+        Tensor lp = pad_to(lse, Sqp, 0), gp = pad_to(grad_out.dense(), Sqp, Dp);
         Tensor dqp = empty_like(qp), dkp = empty_like(kp), dvp = empty_like(vp);
         size_t need = 0;
         DataPtr scratch = attn_bwd_scratch(code(q.dtype()), B, H, Sqp, Skp, Dp, q.device(), need);
@@ -779,7 +780,7 @@ std::tuple<Tensor, Tensor, Tensor> causal_attention_bwd(const Tensor &q, const T
                                     dvp.data_ptr(), scratch.get(), need, dev::stream(q.device())));
         return {unpad(dqp, Sq, D), unpad(dkp, Skv, D), unpad(dvp, Skv, D)};
     }
-    Tensor go = grad_out.contiguous();
+    Tensor go = grad_out.dense();
     Tensor dq = empty_like(q), dk = empty_like(k), dv = empty_like(v);
     size_t need = 0;
     DataPtr scratch = attn_bwd_scratch(code(q.dtype()), B, H, Sq, Skv, D, q.device(), need);
@@ -851,7 +852,7 @@ public:
         const Tensor &qkv = inputs[0];
         const int64_t d = qkv.shape(1) / 3, D = d / H_;
         const int es = (int)qkv.element_size_in_bytes();
-        Tensor gc = g.contiguous();
+        Tensor gc = g.dense();
         Tensor dqkv = empty(qkv.sizes(), qkv.dtype(), qkv.device());
         const PackedLay L = packed_layouts(S_, H_, D);
         size_t need = 0;
@@ -871,16 +872,16 @@ private:
 } // namespace
 
 Tensor causal_attention_qkv(const Tensor &qkv, int64_t B, int64_t S, int64_t H) {
-    CHECK_FAIL(qkv.defined() && qkv.dim() == 2 && qkv.is_contiguous(), "causal_attention_qkv expects a contiguous [B*S, 3*H*D] tensor");
+    CHECK_FAIL(qkv.defined() && qkv.dim() == 2 && qkv.is_dense(), "causal_attention_qkv expects a contiguous [B*S, 3*H*D] tensor");
     CHECK_FAIL(B > 0 && S > 0 && H > 0 && qkv.shape(0) == B * S && qkv.shape(1) % (3 * H) == 0, "causal_attention_qkv: shape does not match B, S, H");
     const int64_t d = qkv.shape(1) / 3, D = d / H;
     if (!packed_fast(qkv, S, D)) {
         // off the strided kernels' shapes: the same result from the reference's own operators (which carry their own autograd)
         auto parts = tensor_split(qkv, {d, d, d}, 1);
         std::vector<Tensor> heads;
-        for (auto &t : parts) heads.push_back(t.contiguous().view({B, S, H, D}).permute({0, 2, 1, 3}).contiguous());
+        for (auto &t : parts) heads.push_back(t.dense().view({B, S, H, D}).permute({0, 2, 1, 3}).dense());
         Tensor a = causal_attention(heads[0], heads[1], heads[2]);
-        return a.permute({0, 2, 1, 3}).contiguous().view({B * S, d});
+        return a.permute({0, 2, 1, 3}).dense().view({B * S, d});
     }
     const int es = (int)qkv.element_size_in_bytes();
     Tensor out = empty({B * S, d}, qkv.dtype(), qkv.device());
@@ -912,7 +913,7 @@ public:
     std::vector<Tensor> backward(Tensor g) override {
         const Tensor &x = inputs[0];
         const int64_t cols = x.shape(-1), rows = x.numel() / cols;
-        Tensor gc = g.contiguous();
+        Tensor gc = g.dense();
         Tensor dx = empty(x.sizes(), x.dtype(), x.device());
         Tensor dw, db;
         const bool want_w = has_w_ && inputs[1].requires_grad(), want_b = has_b_ && inputs[has_w_ ? 2 : 1].requires_grad();
@@ -940,13 +941,13 @@ private:
 };
 
 Tensor norm_impl(int kind, const Tensor &x, const Tensor &w, const Tensor &b, double eps) {
-    CHECK_FAIL(x.defined() && x.dim() >= 1 && x.is_contiguous(), "norm expects a contiguous tensor");
+    CHECK_FAIL(x.defined() && x.dim() >= 1 && x.is_dense(), "norm expects a contiguous tensor");
     CHECK_FAIL(norm_dtype_ok(x.dtype()), "norm supports float, half and bfloat16");
     const int64_t cols = x.shape(-1);
     CHECK_FAIL(cols > 0);
     const int64_t rows = x.numel() / cols;
     for (const Tensor *p : {&w, &b})
-        if (p->defined()) CHECK_FAIL(p->dim() == 1 && p->shape(0) == cols && p->dtype() == x.dtype() && p->is_contiguous() && p->device() == x.device(),
+        if (p->defined()) CHECK_FAIL(p->dim() == 1 && p->shape(0) == cols && p->dtype() == x.dtype() && p->is_dense() && p->device() == x.device(),
                                      "norm weight / bias must be contiguous 1-D tensors of the normalised length and of x's dtype");
     Tensor y = empty(x.sizes(), x.dtype(), x.device());
     const bool grad = x.requires_grad() || (w.defined() && w.requires_grad()) || (b.defined() && b.requires_grad());
@@ -977,7 +978,7 @@ public:
     std::vector<Tensor> backward(Tensor g) override {
         const Tensor &table = inputs[0];
         const int64_t nrows = table.shape(0), cols = table.shape(1), n = indices_.numel();
-        Tensor gc = g.contiguous();
+        Tensor gc = g.dense();
         Tensor dt = zeros(table.sizes(), table.dtype(), table.device());
         const size_t need = kf_index_add_workspace_bytes(n);
         DataPtr scratch;
@@ -993,10 +994,10 @@ private:
 } // namespace
 
 Tensor embedding(const Tensor &table, const Tensor &indices) {
-    CHECK_FAIL(table.defined() && table.dim() == 2 && table.is_contiguous(), "embedding expects a contiguous 2-D table");
+    CHECK_FAIL(table.defined() && table.dim() == 2 && table.is_dense(), "embedding expects a contiguous 2-D table");
     CHECK_FAIL(indices.defined() && indices.dtype() == ScalarType::Long, "Indices must be of type Long.");
     CHECK_FAIL(indices.device() == table.device());
-    Tensor ix = indices.contiguous();
+    Tensor ix = indices.dense();
     auto shape = ix.sizes();
     shape.push_back(table.shape(1));
     Tensor out = empty(shape, table.dtype(), table.device());

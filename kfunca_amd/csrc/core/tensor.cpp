@@ -59,15 +59,15 @@ TensorImpl::TensorImpl(const std::vector<int64_t> &shape, const std::vector<int6
 
 TensorImpl::TensorImpl(const TensorImpl &o)
     : intrusive_ptr_target(), dim_(o.dim_), shape_(o.shape_), stride_(o.stride_), dtype_(o.dtype_), numel_(o.numel_),
-      storage_(o.storage_), storage_offset_(o.storage_offset_), is_contiguous_(o.is_contiguous_), requires_grad_(o.requires_grad_) {}
+      storage_(o.storage_), storage_offset_(o.storage_offset_), is_contiguous_(o.is_contiguous_), is_dense_(o.is_dense_), requires_grad_(o.requires_grad_) {}
 
-void TensorImpl::refresh_() { // numel + exact contiguity (size-1 dims never break it)
+void TensorImpl::refresh_() { // numel + exact density (size-1 dims never break it); the is_contiguous_ FLAG is not derived from the strides (tensor.h)
     numel_ = 1;
     for (int i = 0; i < dim_; ++i) numel_ *= shape_[i];
     int64_t expect = 1;
-    is_contiguous_ = true;
+    is_dense_ = true;
     for (int i = dim_ - 1; i >= 0; --i) {
-        if (shape_[i] != 1 && stride_[i] != expect) is_contiguous_ = false;
+        if (shape_[i] != 1 && stride_[i] != expect) is_dense_ = false;
         expect *= shape_[i];
     }
     for (int i = dim_; i < MAX_TENSOR_DIMS; ++i) shape_[i] = stride_[i] = 0;
@@ -105,6 +105,7 @@ void TensorImpl::as_strided_(const std::vector<int64_t> &sizes, const std::vecto
     }
     storage_offset_ = storage_offset;
     refresh_();
+    is_contiguous_ = false; // whatever the strides are (reference tensor_impl.cpp:95): found by tests/test_gpu_host_diff_fuzz.py - contiguous() of a dense view CLONES there
 }
 
 // ---- factories --------------------------------------------------------------------------------
@@ -168,6 +169,7 @@ any_t Tensor::item(const std::vector<int64_t> &indices) const {
 
 Tensor &Tensor::fill_(const any_t &value) { return gpu::fill_(*this, value); }
 Tensor Tensor::contiguous() const { return is_contiguous() ? *this : gpu::clone(*this); }
+Tensor Tensor::dense() const { return is_dense() ? *this : gpu::clone(*this); }
 
 // ---- views: pure metadata, bit-exact by construction (reference tensor.cpp:167-290) ------------
 namespace {
@@ -274,8 +276,7 @@ Tensor Tensor::narrow(int64_t dim, int64_t start, int64_t length) const {
     return slice(dim, start, start + length, 1);
 }
 
-Tensor Tensor::view(std::vector<int64_t> sizes) const {
-    CHECK_FAIL(is_contiguous());
+static std::vector<int64_t> view_sizes(const Tensor &t, std::vector<int64_t> sizes) { // one -1 is inferred (tensor.cpp:269-289 of the reference)
     int64_t known = 1;
     int infer = -1;
     for (size_t i = 0; i < sizes.size(); ++i) {
@@ -288,11 +289,18 @@ Tensor Tensor::view(std::vector<int64_t> sizes) const {
     }
     if (infer >= 0) {
         CHECK_FAIL(known != 0);
-        sizes[infer] = numel() / known;
+        sizes[infer] = t.numel() / known;
         known *= sizes[infer];
     }
-    CHECK_FAIL(known == numel());
-    return as_strided(sizes, {}, storage_offset());
+    CHECK_FAIL(known == t.numel());
+    return sizes;
+}
+
+Tensor Tensor::view(std::vector<int64_t> sizes) const {
+    // (the reference asks its FLAG, tensor.cpp:270: it refuses every tensor as_strided_ made, the result of view() itself included; this host asks the strides - a superset:
+    //  whatever view() accepts there it accepts here, with the same result)
+    CHECK_FAIL(is_dense());
+    return as_strided(view_sizes(*this, std::move(sizes)), {}, storage_offset());
 }
 
 bool Tensor::can_use_32bit_indexing() const {
@@ -350,7 +358,7 @@ void Tensor::update_grad(Tensor grad) {
         // for a weight gradient that is one read + one write of the parameter's size saved per step. Anything shared (the SAME
         // tensor handed to two inputs, as add's backward does; a view; the caller's own grad_output; a tensor a GradFunction
         // keeps) is still copied.
-        const bool exclusive = grad.impl_ref_count() == 1 && grad.storage_ref_count() == 1 && grad.is_contiguous() && grad.storage_offset() == 0 &&
+        const bool exclusive = grad.impl_ref_count() == 1 && grad.storage_ref_count() == 1 && grad.is_dense() && grad.storage_offset() == 0 &&
                                (size_t)grad.numel() * (size_t)grad.element_size_in_bytes() <= grad.storage_bytes() && !grad.has_grad_fn();
         if (exclusive) {
             impl->grad_ = std::make_unique<Tensor>(std::move(grad));

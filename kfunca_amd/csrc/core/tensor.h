@@ -110,7 +110,14 @@ public:
     bool defined() const { return storage_.get() != nullptr; }
     int device() const { return storage_->device(); }
     int64_t element_size_in_bytes() const { return (int64_t)element_size(dtype_); }
+    // The reference's flag, with the reference's meaning (tensor_impl.h:108, tensor_impl.cpp:95): TRUE for a freshly allocated tensor, FALSE for whatever
+    // as_strided_ made - every view, slice, select, permute, split part and the result of view() itself, dense or not. It decides what contiguous() returns:
+    // a CLONE exactly when it is false, so that the result never aliases a view (x.view(6).contiguous() += 1 leaves x alone there, and here). Where the reference
+    // merely REFUSES a tensor because of the flag (view(), numpy(), gemm) this host asks is_dense() instead: a superset with the same results.
     bool is_contiguous() const { return is_contiguous_; }
+    // What the strides say: the elements lie in row-major order without gaps (size-1 dims never break it). The kernels' own precondition: the operators this
+    // repository adds and every internal fast path ask THIS, not the flag.
+    bool is_dense() const { return is_dense_; }
     bool requires_grad() const { return requires_grad_; }
     void set_requires_grad(bool f) { requires_grad_ = f; }
 
@@ -129,6 +136,7 @@ private:
     intrusive_ptr<TensorStorage> storage_;
     int64_t storage_offset_ = 0;
     bool is_contiguous_ = true;
+    bool is_dense_ = true;
     bool requires_grad_ = false;
 };
 
@@ -174,7 +182,8 @@ public:
     bool has_grad_fn() const { return grad_fn_.get() != nullptr; }
     int device() const { return impl_->device(); }
     int64_t element_size_in_bytes() const { return impl_->element_size_in_bytes(); }
-    bool is_contiguous() const { return impl_->is_contiguous(); }
+    bool is_contiguous() const { return impl_->is_contiguous(); }   // the reference's flag (see TensorImpl)
+    bool is_dense() const { return impl_->is_dense(); }             // row-major without gaps, by the strides
     bool requires_grad() const { return impl_->requires_grad(); }
     void set_requires_grad(bool flag) { impl_->set_requires_grad(flag); }
     Tensor *grad() { return impl_->grad_.get(); }
@@ -188,7 +197,8 @@ public:
     any_t item(const std::vector<int64_t> &indices) const;
     Tensor &fill_(const any_t &value);
     int64_t offset(const std::vector<int64_t> &indices) const;
-    Tensor contiguous() const;
+    Tensor contiguous() const;                              // *this when the flag is set, else a clone (tensor.cpp:161-165 of the reference)
+    Tensor dense() const;                                   // *this when the strides are dense, else a clone: what the kernels need (no copy of a dense view)
     Tensor as_strided(std::vector<int64_t> sizes, std::vector<int64_t> strides, int64_t storage_offset = 0) const;
     Tensor permute(const std::vector<int64_t> dims) const;
     Tensor slice(int64_t dim, std::optional<int64_t> start, std::optional<int64_t> end, int64_t step = 1) const;

@@ -24,7 +24,8 @@ bool non_overlapping_and_dense(const IterOperand &t) {
     std::vector<std::pair<int64_t, int64_t>> v; // (stride, size)
     for (int i = t.ndim - 1; i >= 0; --i) {
         if (t.shape[i] == 0) return true; // no elements: nothing can overlap
-        if (t.shape[i] == 1) continue;    // the stride of an extent-1 dim addresses nothing
+        // (an extent-1 dim takes part with whatever stride it carries, as in the reference: x[::2][0:1] += 1 is refused there although the stride of that dim addresses
+        //  nothing - found by tests/test_gpu_host_diff_fuzz.py; this host used to skip such dims)
         v.emplace_back(t.stride[i], t.shape[i]);
     }
     std::stable_sort(v.begin(), v.end(), [](const auto &a, const auto &b) { return a.first < b.first; });

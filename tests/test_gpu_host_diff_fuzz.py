@@ -1,0 +1,318 @@
+"""-m gpu: randomised DIFFERENTIAL test of the two hosts - the reference's own host half (oracle/_ref/kfunca*.so: src/core/*.cpp + register.cpp,
+unmodified, over this repository's device library; tests/test_gpu_reference_host.py explains the build) against this repository's host core.
+
+A seeded generator writes small programs over the module API the reference defines (register.cpp:76-218): tensors from numpy, permute / slicing with steps /
+select / view / contiguous, broadcasting binary operators with type promotion (Tensor op Tensor, Tensor op scalar, in place on views), sum / mean / mean_var /
+norm_stat along a dimension, half / bfloat16 / float conversions, cat / split, fill_. The generator decides from a numpy shadow of every tensor's SHAPE only, so the
+two modules execute the same program; after every step both must have raised or both succeeded (the reference's CHECK_FAIL behaviour is part of the API), and at the
+end every live tensor must hold the SAME BITS, shape and dtype in both. Equal bits mean our Tensor / TensorIterator restatement (view strides, broadcast
+geometry, dimension coalescing and reordering, promotion, output allocation, reduction plans) drives the kernels exactly as the reference's does - on programs nobody
+wrote by hand. Rows a1-a3, a6, a13 of SURVEY.md section 8."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import kfunca_amd
+
+pytestmark = pytest.mark.gpu
+REFDIR = Path(__file__).resolve().parent.parent / "oracle" / "_ref"
+FLOATS, INTS = ("f4", "f8"), ("i4", "q")   # ("q": the reference's from_numpy knows int64 as long long only, register.cpp:28-37)
+
+
+@pytest.fixture(scope="module")
+def ref():
+    if not list(REFDIR.glob("kfunca*.so")):
+        pytest.skip("oracle/_ref/kfunca*.so not built (python oracle/build_ref_host.py, build container only)")
+    sys.path.insert(0, str(REFDIR))
+    import kfunca
+    assert Path(kfunca.__file__).parent == REFDIR
+    return kfunca
+
+
+def make_program(seed, steps=28):
+    """A list of instructions (plain tuples) + the numpy inputs they name. The shadow tracks shape, numpy-kind ('f' / 'i') and whether the tensor is 16-bit."""
+    rng = np.random.default_rng(seed)
+    prog, shadow = [], []   # shadow[i] = dict(shape=..., kind='f'|'i', h=bool, contig=bool)
+
+    def rand_shape():
+        nd = int(rng.integers(1, 5))
+        shape = [int(rng.choice([1, 2, 3, 4, 5, 7, 8, 16, 33, 70])) for _ in range(nd)]
+        while int(np.prod(shape)) > 150_000:      # (small tensors: the programs test geometry, not bandwidth)
+            shape[int(np.argmax(shape))] //= 2
+        return tuple(shape)
+
+    def new(shape=None, dt=None):
+        shape = rand_shape() if shape is None else shape
+        dt = str(rng.choice(FLOATS + INTS)) if dt is None else dt
+        if dt in FLOATS:
+            arr = rng.uniform(-4, 4, size=shape).astype(dt)
+        else:
+            arr = rng.integers(1, 9, size=shape).astype(dt) * rng.choice([-1, 1], size=shape).astype(dt)   # never zero: integer division stays defined
+        prog.append(("new", arr))
+        shadow.append(dict(shape=tuple(shape), kind=np.dtype(dt).kind, h=False, contig=True, off=False))
+        return len(shadow) - 1
+
+    def push(shape, kind, h, contig, off=False):
+        # off: the tensor may start behind its storage's first element. The reference's permute() drops the storage offset (tensor.cpp:189: as_strided without it -
+        # x[2:5].permute(0) is x[0:3] there; index_ops.cpp:22 does the same to index_put_): this host keeps it, so the generator never permutes such a tensor.
+        shadow.append(dict(shape=tuple(int(s) for s in shape), kind=kind, h=h, contig=contig, off=off))
+
+    new()
+    new()
+    for _ in range(steps):
+        op = rng.choice(["permute", "getitem", "contiguous", "view", "binary", "scalar", "inplace", "inplace_scalar", "reduce", "moments", "convert", "cat", "split",
+                         "fill", "new"], p=[.08, .12, .05, .06, .16, .06, .10, .04, .10, .04, .06, .04, .03, .02, .04])
+        i = int(rng.integers(0, len(shadow)))
+        s = shadow[i]
+        nd = len(s["shape"])
+        if op == "new":
+            new()
+        elif op == "permute":
+            if s["off"]:
+                continue
+            perm = [int(p) for p in rng.permutation(nd)]
+            prog.append(("permute", i, perm))
+            push([s["shape"][p] for p in perm], s["kind"], s["h"], False, False)
+        elif op == "getitem":
+            key, shp, moved = [], [], s["off"]
+            for d in range(nd):
+                n = s["shape"][d]
+                if rng.random() < 0.25 and nd - sum(1 for k in key if isinstance(k, int)) > 1:
+                    key.append(int(rng.integers(0, n)))
+                    moved = moved or key[-1] > 0
+                else:
+                    a = int(rng.integers(0, n))
+                    b = int(rng.integers(a + 1, n + 1))
+                    st = int(rng.choice([1, 1, 2, 3]))
+                    key.append((a, b, st))
+                    moved = moved or a > 0
+                    shp.append(len(range(a, b, st)))
+            if not shp:
+                continue
+            prog.append(("getitem", i, key))
+            push(shp, s["kind"], s["h"], False, moved)
+        elif op == "contiguous":
+            prog.append(("contiguous", i))
+            push(s["shape"], s["kind"], s["h"], True)
+        elif op == "view":
+            if not s["contig"]:
+                continue
+            n = int(np.prod(s["shape"]))
+            divs = [d for d in (1, 2, 3, 4, 5, 7, 8, 16) if n % d == 0]
+            a = int(rng.choice(divs))
+            rest = n // a
+            divs2 = [d for d in (1, 2, 3, 4, 5, 7, 8) if rest % d == 0]
+            b = int(rng.choice(divs2))
+            shp = [a, b, rest // b] if rng.random() < 0.5 else [a, -1, b]
+            prog.append(("view", i, shp))
+            push([a, b, rest // b] if shp[1] != -1 else [a, rest // b, b], s["kind"], s["h"], False)   # (the reference's flag: false for whatever as_strided_ made, view() included)
+        elif op in ("binary", "inplace"):
+            # the other operand: a fresh tensor whose shape broadcasts against tensor i (dims dropped from the front, dims set to 1), any dtype
+            shp = list(s["shape"])
+            for d in range(nd):
+                if rng.random() < 0.3:
+                    shp[d] = 1
+            drop = int(rng.integers(0, nd)) if rng.random() < 0.3 else 0
+            shp = shp[drop:]
+            if op == "binary" and rng.random() < 0.3 and nd < 4:     # ... or the fresh one is the larger
+                shp = [int(rng.choice([2, 3, 5]))] + list(s["shape"])
+            dt = str(rng.choice(FLOATS + INTS))
+            if s["h"]:
+                dt = "f4"     # (16-bit tensors meet float partners; the fresh operand may be converted below)
+            j = new(tuple(shp), dt)
+            if s["h"] and rng.random() < 0.7:
+                prog.append(("convert", j, "half" if s["h"] == "half" else "bfloat16"))
+                push(shp, "f", s["h"], True)
+                j = len(shadow) - 1
+            sym = str(rng.choice(["+", "-", "*", "/"]))
+            if op == "binary":
+                a, b = (i, j) if rng.random() < 0.5 else (j, i)
+                prog.append(("binary", sym, a, b))
+                out_shape = np.broadcast_shapes(shadow[a]["shape"], shadow[b]["shape"])
+                kind = "f" if "f" in (shadow[a]["kind"], shadow[b]["kind"]) else "i"
+                push(out_shape, kind, s["h"] if shadow[j]["h"] else False, True)
+            else:
+                if np.broadcast_shapes(s["shape"], tuple(shp)) != s["shape"]:
+                    continue
+                prog.append(("inplace", sym, i, j))
+        elif op in ("scalar", "inplace_scalar"):
+            val = float(rng.choice([2, 3, 0.5, -1.5, 7]))
+            if s["kind"] == "i":
+                val = float(int(val) or 2)
+            sym = str(rng.choice(["+", "-", "*", "/"]))
+            prog.append((op, sym, i, val))
+            if op == "scalar":
+                push(s["shape"], s["kind"], s["h"], True)
+        elif op == "reduce":
+            d = int(rng.integers(0, nd))
+            prog.append(("reduce", str(rng.choice(["sum", "mean"])), i, d))
+            shp = list(s["shape"])
+            shp[d] = 1
+            push(shp, s["kind"], s["h"], True)
+        elif op == "moments":
+            if s["kind"] != "f" or s["h"]:
+                continue
+            d = int(rng.integers(0, nd))
+            which = str(rng.choice(["mean_var", "mean_std", "norm_stat"]))
+            if which == "norm_stat" and (nd != 2 or d != 0):
+                which = "mean_var"      # (the reference's norm_stat takes dim 0 of a 2-D tensor only, norm_ops_kernel.cu:8; this host takes any - a superset, not compared)
+            prog.append(("moments", which, i, d))
+            shp = list(s["shape"])
+            shp[d] = 1
+            push(shp, "f", False, True)
+            push(shp, "f", False, True)
+        elif op == "convert":
+            to = str(rng.choice(["half", "bfloat16", "float"]))
+            prog.append(("convert", i, to))
+            push(s["shape"], "f", False if to == "float" else to, False, s["off"])    # (a conversion to the tensor's own type may hand back the tensor itself: never view() it)
+        elif op == "cat":
+            d = int(rng.integers(0, nd))
+            parts = [i]
+            for _ in range(int(rng.integers(1, 3))):
+                shp = list(s["shape"])
+                shp[d] = int(rng.choice([1, 2, 5]))
+                dt = {"f": "f4", "i": "q"}[s["kind"]]
+                j = new(tuple(shp), dt)
+                if s["h"]:
+                    prog.append(("convert", j, s["h"]))
+                    push(shp, "f", s["h"], True)
+                    j = len(shadow) - 1
+                parts.append(j)
+            prog.append(("cat", parts, d))
+            shp = list(s["shape"])
+            shp[d] = sum(shadow[p]["shape"][d] for p in parts)
+            push(shp, s["kind"], s["h"], True)
+        elif op == "split":
+            d = int(rng.integers(0, nd))
+            n = s["shape"][d]
+            if n < 2:
+                continue
+            a = int(rng.integers(1, n))
+            prog.append(("split", i, [a, n - a], d))
+            for k, part in enumerate((a, n - a)):
+                shp = list(s["shape"])
+                shp[d] = part
+                push(shp, s["kind"], s["h"], False, s["off"] or k > 0)
+        elif op == "fill":
+            prog.append(("fill", i, float(rng.choice([0, 1, -2, 3]))))
+    return prog
+
+
+def run(kf, prog):
+    """Execute; returns (per-step status list, final arrays). A step that raises leaves placeholders (None) for the tensors it would have made."""
+    ts, status = [], []
+    ops = {"+": lambda a, b: a + b, "-": lambda a, b: a - b, "*": lambda a, b: a * b, "/": lambda a, b: a / b}
+
+    def iop(sym, a, b):
+        if sym == "+":
+            a += b
+        elif sym == "-":
+            a -= b
+        elif sym == "*":
+            a *= b
+        else:
+            a /= b
+
+    for ins in prog:
+        made = {"new": 1, "permute": 1, "getitem": 1, "contiguous": 1, "view": 1, "binary": 1, "scalar": 1, "reduce": 1, "moments": 2, "convert": 1, "cat": 1,
+                "split": 2, "inplace": 0, "inplace_scalar": 0, "fill": 0}[ins[0]]
+        try:
+            k = ins[0]
+            if k == "new":
+                out = [kf.from_numpy(ins[1], 0)]
+            elif k == "permute":
+                out = [ts[ins[1]].permute(*ins[2])]
+            elif k == "getitem":
+                key = tuple(slice(*x) if isinstance(x, tuple) else x for x in ins[2])
+                out = [ts[ins[1]][key]]
+            elif k == "contiguous":
+                out = [ts[ins[1]].contiguous()]
+            elif k == "view":
+                out = [ts[ins[1]].view(*ins[2])]
+            elif k == "binary":
+                out = [ops[ins[1]](ts[ins[2]], ts[ins[3]])]
+            elif k == "scalar":
+                out = [ops[ins[1]](ts[ins[2]], ins[3])]
+            elif k == "inplace":
+                iop(ins[1], ts[ins[2]], ts[ins[3]])
+                out = []
+            elif k == "inplace_scalar":
+                iop(ins[1], ts[ins[2]], ins[3])
+                out = []
+            elif k == "reduce":
+                out = [getattr(ts[ins[2]], ins[1])(ins[3])]
+            elif k == "moments":
+                t = ts[ins[2]]
+                r = t.norm_stat(ins[3]) if ins[1] == "norm_stat" else t.mean_var(ins[3], ins[1] == "mean_std")
+                out = [r[0], r[1]]
+            elif k == "convert":
+                out = [getattr(ts[ins[1]], ins[2])()]
+            elif k == "cat":
+                out = [kf.cat([ts[p] for p in ins[1]], ins[2])]
+            elif k == "split":
+                out = list(ts[ins[1]].split(ins[2], ins[3]))
+                assert len(out) == 2
+            elif k == "fill":
+                ts[ins[1]].fill_(ins[2])
+                out = []
+            ts.extend(out)
+            status.append("ok")
+        except Exception as e:  # noqa: BLE001 - whatever the module raises: the OTHER module must raise at the same step
+            ts.extend([None] * made)
+            status.append(type(e).__name__ + ": " + " ".join(str(e).split())[:240])
+    finals = []
+    for t in ts:
+        if t is None:
+            finals.append(None)
+            continue
+        try:
+            c = t.contiguous()
+            dt = str(c.dtype())
+            if "Half" in dt or "BFloat16" in dt or "half" in dt.lower() or "bf" in dt.lower():
+                c = c.float()          # (16-bit values are exactly representable: the float image carries the same bits)
+            finals.append((dt, tuple(c.sizes()), c.numpy()))
+        except Exception as e:  # noqa: BLE001
+            finals.append(("raised", type(e).__name__))
+    return status, finals
+
+
+def origin(prog, n):
+    """The instruction that made tensor n (for the failure message)."""
+    made = {"new": 1, "permute": 1, "getitem": 1, "contiguous": 1, "view": 1, "binary": 1, "scalar": 1, "reduce": 1, "moments": 2, "convert": 1, "cat": 1, "split": 2}
+    k = 0
+    for ins in prog:
+        m = made.get(str(ins[0]), 0)
+        if k <= n < k + m:
+            return (str(ins[0]),) + tuple(x.shape if isinstance(x, np.ndarray) else x for x in ins[1:])
+        k += m
+    return None
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KF_DIFF_FUZZ_SEEDS", "200"))))
+def test_random_program_gives_the_same_bits_on_both_hosts(ref, seed):
+    prog = make_program(1000 + seed, steps=28 + seed % 17)
+    st_r, fin_r = run(ref, prog)
+    st_m, fin_m = run(kfunca_amd, prog)
+    for n, (a, b, ins) in enumerate(zip(st_r, st_m, prog)):
+        assert (a == "ok") == (b == "ok"), f"step {n} {ins[0]} {ins[1:] if ins[0] != 'new' else ins[1].shape}: reference host {a}, this host {b}"
+    assert len(fin_r) == len(fin_m)
+    live = 0
+    for n, (a, b) in enumerate(zip(fin_r, fin_m)):
+        assert (a is None) == (b is None), n
+        if a is None:
+            continue
+        if a[0] == "raised" or b[0] == "raised":
+            assert a[0] == b[0], (n, a[:2], b[:2])
+            continue
+        assert a[1] == b[1], (n, a[1], b[1])
+        assert a[2].dtype == b[2].dtype and a[2].shape == b[2].shape, (n, a[2].dtype, b[2].dtype, a[2].shape, b[2].shape)
+        if not np.array_equal(a[2].view(np.uint8), b[2].view(np.uint8)):
+            bad = np.argwhere(a[2] != b[2])
+            i = tuple(bad[0]) if len(bad) else ()
+            raise AssertionError(f"tensor {n}: the two hosts disagree (dtype {a[0]}, shape {a[1]}): {len(bad)} of {a[2].size} elements, first at {i}: "
+                                 f"reference host {a[2][i] if len(bad) else '?'}, this host {b[2][i] if len(bad) else '?'}; made by {origin(prog, n)}")
+        live += 1
+    assert live >= 1, st_r   # (a program whose early step both hosts refuse cascades: what is left must still agree)
