@@ -184,15 +184,28 @@ std::tuple<Tensor, Tensor> sort_stable_kernel(const Tensor &self, int64_t dim, b
     CHECK_FAIL(self.dtype() != ScalarType::Bool, "Sort currently does not support bool dtypes.");
     const int64_t n = self.shape(d);
     CHECK_FAIL(n <= std::numeric_limits<int>::max(), "The dimension being sorted can not have more than INT_MAX elements.");
-    // bring the sorted dim last, dense
-    std::vector<int64_t> perm, inverse(self.dim());
-    for (int i = 0; i < self.dim(); ++i)
-        if (i != d) perm.push_back(i);
-    perm.push_back(d);
-    for (int i = 0; i < self.dim(); ++i) inverse[perm[i]] = i;
-    Tensor keys = self.permute(perm).contiguous();
-    Tensor values = empty(keys.sizes(), self.dtype(), self.device());
-    Tensor positions = empty(keys.sizes(), ScalarType::Long, self.device());
+    // A dense image of self with the sorted dim fastest and the other dims in their memory order, made by copy_ into a strided allocation - what the
+    // reference's device half does (sort_ops_kernel.cu:569-577, 605-612). NOT permute().contiguous(): the reference's permute() drops a view's storage
+    // offset (tensor.cpp:189), and through it this seam sorted x[0:3] when asked for x[2:5] (found by tests/test_gpu_host_diff_fuzz.py, round 6).
+    const bool direct = self.is_contiguous() && self.stride(d) == 1;
+    std::vector<int64_t> st(self.dim());
+    Tensor keys = self;
+    if (!direct) {
+        std::vector<int> order;
+        for (int i = 0; i < self.dim(); ++i)
+            if (i != d) order.push_back(i);
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return self.stride(x) > self.stride(y); });
+        order.push_back(d);
+        int64_t run = 1;
+        for (int i = self.dim() - 1; i >= 0; --i) {
+            st[order[i]] = run;
+            run *= self.shape(order[i]);
+        }
+        keys = empty_strided(self.sizes(), st, self.dtype(), self.device());
+        keys.copy_(self);
+    }
+    Tensor values = direct ? empty_like(keys) : empty_strided(self.sizes(), st, self.dtype(), self.device());
+    Tensor positions = direct ? empty(self.sizes(), ScalarType::Long, self.device()) : empty_strided(self.sizes(), st, ScalarType::Long, self.device());
     if (self.numel() > 0) {
         const int64_t nseg = self.numel() / n;
         const size_t need = kf_sort_workspace_bytes(static_cast<int>(self.dtype()), nseg, n);
@@ -200,8 +213,11 @@ std::tuple<Tensor, Tensor> sort_stable_kernel(const Tensor &self, int64_t dim, b
         check(kf_sort(static_cast<int>(self.dtype()), keys.data_ptr(), values.data_ptr(), static_cast<int64_t *>(positions.data_ptr()), nseg, n,
                       descending ? 1 : 0, ws.ptr, need, kStream));
     }
-    // back to self's dim order (views; contiguous() materialises them like the reference's copy back)
-    return std::make_tuple(values.permute(inverse).contiguous(), positions.permute(inverse).contiguous());
+    if (direct) return std::make_tuple(values, positions);
+    Tensor values_out = empty_like(self), positions_out = empty(self.sizes(), ScalarType::Long, self.device());   // back to self's own order
+    values_out.copy_(values);
+    positions_out.copy_(positions);
+    return std::make_tuple(values_out, positions_out);
 }
 
 std::tuple<Tensor, Tensor> topk_with_sort(const Tensor &self, int64_t k, int64_t dim, bool largest) {

@@ -343,8 +343,10 @@ std::tuple<Tensor, Tensor> sort(const Tensor &self, int64_t dim, bool descending
         keys = empty_strided(self.sizes(), dense_strides_dim_last(self, dim), self.dtype(), self.device());
         keys.copy_(self);
     }
-    Tensor values = empty_strided(keys.sizes(), keys.strides(), keys.dtype(), keys.device());
-    Tensor indices = empty_strided(keys.sizes(), keys.strides(), ScalarType::Long, keys.device());
+    // (direct: fresh row-major outputs as the reference's empty_like / empty, sort_ops_kernel.cu:583-585 - not self's own strides, whose extent-1 dims may carry
+    //  anything: a later in-place operation on the result is refused or not by those strides; tests/test_gpu_host_diff_fuzz.py found the difference)
+    Tensor values = direct ? empty_like(keys) : empty_strided(keys.sizes(), keys.strides(), keys.dtype(), keys.device());
+    Tensor indices = direct ? empty(keys.sizes(), ScalarType::Long, keys.device()) : empty_strided(keys.sizes(), keys.strides(), ScalarType::Long, keys.device());
     if (numel > 0) {
         const int64_t nseg = numel / nsort;
         const int dt = code(self.dtype());
