@@ -30,11 +30,18 @@ def make_program(seed, steps=28):
     rng = np.random.default_rng(seed)
     prog, shadow = [], []   # shadow[i] = dict(shape=..., kind='f'|'i', h=bool, contig=bool)
 
+    big = rng.random() < 0.12    # one program in eight works on LARGE extents: the vectorised / tall / wide / multi-block plans of the kernels behind the same geometry
+
     def rand_shape():
         nd = int(rng.integers(1, 5))
-        shape = [int(rng.choice([1, 2, 3, 4, 5, 7, 8, 16, 33, 70])) for _ in range(nd)]
-        while int(np.prod(shape)) > 150_000:      # (small tensors: the programs test geometry, not bandwidth)
-            shape[int(np.argmax(shape))] //= 2
+        if big:
+            shape = [int(rng.choice([1, 2, 3, 16, 100, 257, 1024, 4099])) for _ in range(nd)]
+            cap = 3_000_000
+        else:
+            shape = [int(rng.choice([1, 2, 3, 4, 5, 7, 8, 16, 33, 70])) for _ in range(nd)]
+            cap = 150_000                     # (small tensors: most programs test geometry, not bandwidth)
+        while int(np.prod(shape)) > cap:
+            shape[int(np.argmax(shape))] = max(1, shape[int(np.argmax(shape))] // 2)
         return tuple(shape)
 
     def new(shape=None, dt=None):
@@ -113,7 +120,7 @@ def make_program(seed, steps=28):
                     shp[d] = 1
             drop = int(rng.integers(0, nd)) if rng.random() < 0.3 else 0
             shp = shp[drop:]
-            if op == "binary" and rng.random() < 0.3 and nd < 4:     # ... or the fresh one is the larger
+            if op == "binary" and rng.random() < 0.3 and nd < 4 and not big:     # ... or the fresh one is the larger
                 shp = [int(rng.choice([2, 3, 5]))] + list(s["shape"])
             dt = str(rng.choice(FLOATS + INTS))
             if s["h"]:
