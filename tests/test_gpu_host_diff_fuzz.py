@@ -64,8 +64,8 @@ def make_program(seed, steps=28):
     new()
     for _ in range(steps):
         op = rng.choice(["permute", "getitem", "contiguous", "view", "binary", "scalar", "inplace", "inplace_scalar", "reduce", "moments", "convert", "cat", "split",
-                         "fill", "new", "sort", "topk", "iput", "gemm", "attn", "autograd"],
-                        p=[.07, .11, .05, .05, .14, .05, .09, .04, .09, .04, .05, .04, .03, .02, .03, .03, .02, .02, .01, .01, .01])
+                         "fill", "new", "sort", "topk", "iput", "gemm", "attn", "autograd", "invalid"],
+                        p=[.07, .11, .05, .05, .13, .05, .09, .04, .09, .04, .05, .04, .03, .02, .03, .03, .02, .02, .01, .01, .01, .01])
         i = int(rng.integers(0, len(shadow)))
         s = shadow[i]
         nd = len(s["shape"])
@@ -266,6 +266,35 @@ def make_program(seed, steps=28):
             for r in req:
                 if r:
                     push(shp, "f", False, True)
+        elif op == "invalid":
+            # a call the API must REFUSE (CHECK_FAIL in the reference): both hosts raise, nothing changes. Only refusals the reference makes with a check are drawn -
+            # not the ones it leaves to chance (an out-of-range select index reads past the tensor there; sum(dim) with dim > rank is ACCEPTED there - it reads the
+            # zero padding of its shape array - and refused here: 89 of 89 such calls in a 3000-program run, the only disagreement among the invalid calls)
+            what = str(rng.choice(["permute_dup", "permute_count", "view_numel", "binary_shape", "cat_shape", "inplace_grow", "view_two_neg"]))
+            if what == "permute_dup" and nd >= 2:
+                prog.append(("bad", "permute", i, [0] * nd))
+            elif what == "permute_count":
+                prog.append(("bad", "permute", i, list(range(nd + 1))))
+            elif what == "view_numel" and s["contig"]:
+                prog.append(("bad", "view", i, [int(np.prod(s["shape"])) + 1]))
+            elif what == "view_two_neg" and s["contig"]:
+                prog.append(("bad", "view", i, [-1, -1]))
+            elif what == "binary_shape":
+                shp = list(s["shape"])
+                shp[-1] = shp[-1] + 1 if shp[-1] > 1 else 2
+                if shp[-1] != s["shape"][-1] and s["shape"][-1] != 1:
+                    j = new(tuple(shp), "f4")
+                    prog.append(("bad", "binary", i, j))
+            elif what == "cat_shape" and nd >= 2:
+                shp = list(s["shape"])
+                shp[0] += 1
+                j = new(tuple(shp), {"f": "f4", "i": "q"}[s["kind"]])
+                if not s["h"]:
+                    prog.append(("bad", "cat", [i, j], nd - 1))
+            elif what == "inplace_grow" and any(x == 1 for x in s["shape"]):
+                shp = [3 if x == 1 else x for x in s["shape"]]
+                j = new(tuple(shp), "f4")
+                prog.append(("bad", "inplace", i, j))
         elif op == "fill":
             prog.append(("fill", i, float(rng.choice([0, 1, -2, 3]))))
     return prog
@@ -288,7 +317,7 @@ def run(kf, prog):
 
     for ins in prog:
         made = {"new": 1, "permute": 1, "getitem": 1, "contiguous": 1, "view": 1, "binary": 1, "scalar": 1, "reduce": 1, "moments": 2, "convert": 1, "cat": 1,
-                "split": 2, "inplace": 0, "inplace_scalar": 0, "fill": 0, "sort": 2, "topk": 2, "iput": 0, "gemm": 1, "attn": 0}.get(str(ins[0]))
+                "split": 2, "inplace": 0, "inplace_scalar": 0, "fill": 0, "sort": 2, "topk": 2, "iput": 0, "gemm": 1, "attn": 0, "bad": 0}.get(str(ins[0]))
         if made is None:
             made = sum(ins[2])   # autograd: one gradient per leaf that requires one
         try:
@@ -329,6 +358,21 @@ def run(kf, prog):
                 assert len(out) == 2
             elif k == "fill":
                 ts[ins[1]].fill_(ins[2])
+                out = []
+            elif k == "bad":
+                if ins[1] == "permute":
+                    ts[ins[2]].permute(*ins[3])
+                elif ins[1] == "view":
+                    ts[ins[2]].view(*ins[3])
+                elif ins[1] == "binary":
+                    ts[ins[2]] + ts[ins[3]]
+                elif ins[1] == "cat":
+                    kf.cat([ts[p] for p in ins[2]], ins[3])
+                elif ins[1] == "reduce":
+                    ts[ins[2]].sum(ins[3])
+                elif ins[1] == "inplace":
+                    t = ts[ins[2]]
+                    t += ts[ins[3]]
                 out = []
             elif k == "sort":
                 out = list(ts[ins[1]].sort(ins[2], ins[3]))
@@ -475,6 +519,8 @@ def test_random_programs_give_the_same_bits_on_both_hosts():
         assert where == "R", f"the child died (exit {res.returncode}) at seed {seed} while {'THIS host' if where == 'M' else 'the harness'} was running: {res.stderr[-1500:]}"
         lost.append(seed)
         first = seed + 1
+    if diffs and os.environ.get("KF_DIFF_FUZZ_LOG"):
+        Path(os.environ["KF_DIFF_FUZZ_LOG"]).write_text("\n".join(diffs) + "\n")
     assert not diffs, f"{len(diffs)} of {total} programs disagree; the first: {diffs[0]}"
     assert len(lost) <= max(1, total // 50), f"the reference host died on {len(lost)} of {total} programs: {lost}"
     assert done + len(lost) == total, (done, lost, total)
