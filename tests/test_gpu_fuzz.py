@@ -207,3 +207,17 @@ def test_abi_stress_slice():
     root = Path(__file__).resolve().parent.parent
     r = subprocess.run([sys.executable, str(root / "tools" / "scratch" / "stress_abi.py"), str(600 + SEED), "20"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "all agree" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("script,seconds,says", [("stress_abi2.py", 12, "all agree, every guard byte intact"), ("stress_attn.py", 15, "all within the bounds"),
+                                                 ("stress_attn_strided.py", 10, "bit-identical to the contiguous entries"), ("stress_gemm_grouped.py", 12, "bit-identical to kf_gemm alone")])
+def test_round6_stress_slices(script, seconds, says):
+    """Seeded slices of the round's other randomised stresses (their long runs are in profiles/r06_stress_*.txt): norms with leading dimensions + gather / scatter-add + fused
+    GEMM tails with guard bytes; ragged attention forward + backward against the f64 oracle's bounds; attention operands in random strided layouts against the contiguous entries, bit for
+    bit; grouped GEMM launches (the one-grid backward pair among them) against kf_gemm alone, bit for bit."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "tools" / "scratch" / script), str(900 + SEED), str(seconds)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and says in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
