@@ -487,7 +487,7 @@ def child_main(first, last):
 
 
 def test_random_programs_give_the_same_bits_on_both_hosts():
-    """KF_DIFF_FUZZ_SEEDS programs (default 200) through both hosts in a CHILD process. The reference's host half reads uninitialised and freed memory on some of these
+    """KF_DIFF_FUZZ_SEEDS programs (default 1000) through both hosts in a CHILD process. The reference's host half reads uninitialised and freed memory on some of these
     programs (with MALLOC_PERTURB_ set it dies inside the first fifty, alone, whatever the operations; this host runs 8000 of them under MALLOC_CHECK_=3 +
     MALLOC_PERTURB_ - tools/scratch/diff_fuzz_one_host.py, profiles/r06_host_diff_fuzz.txt), and once, with 8000 collected test items, it took the whole pytest process
     with it. So: a child that dies while the REFERENCE host is running costs that one program (at most 2 % of them may go that way) and a fresh child continues behind it;
@@ -495,7 +495,7 @@ def test_random_programs_give_the_same_bits_on_both_hosts():
     import subprocess
     if not list(REFDIR.glob("kfunca*.so")):
         pytest.skip("oracle/_ref/kfunca*.so not built (python oracle/build_ref_host.py, build container only)")
-    total = int(os.environ.get("KF_DIFF_FUZZ_SEEDS", "200"))
+    total = int(os.environ.get("KF_DIFF_FUZZ_SEEDS", "1000"))
     first, done, lost, diffs = 0, 0, [], []
     while first < total:
         res = subprocess.run([sys.executable, str(Path(__file__).resolve()), str(first), str(total)], capture_output=True, text=True, timeout=1800,
