@@ -434,8 +434,9 @@ static double item_as_double(const Tensor &t, const std::vector<int64_t> &idx) {
 }
 
 static void print_rec(std::ostream &os, const Tensor &t, std::vector<int64_t> &idx, int d) {
-    if (d == t.dim()) {
-        os << std::fixed << std::showpos << std::setprecision(5) << item_as_double(t, idx) << std::noshowpos;
+    if (d == t.dim()) { // an element, as the reference streams its accumulate type: integers as integers, floats with five decimals, always signed
+        if (is_floating_type(t.dtype())) os << std::fixed << std::showpos << std::setprecision(5) << item_as_double(t, idx) << std::noshowpos;
+        else os << std::showpos << (int64_t)item_as_double(t, idx) << std::noshowpos;
         return;
     }
     if (d > 0) os << "\n";
@@ -447,11 +448,17 @@ static void print_rec(std::ostream &os, const Tensor &t, std::vector<int64_t> &i
         print_rec(os, t, idx, d + 1);
         idx.pop_back();
     }
-    if (t.shape(d) > 12) os << ", ...";
+    if (t.shape(d) > 12) { // the thirteenth and later entries of a dim: an ellipsis, on a line of its own for an outer dim
+        os << ", ";
+        if (d < t.dim() - 1) os << "\n" << std::string(2 * (d + 2), ' ');
+        os << "...";
+    }
     if (d < t.dim() - 1) os << "\n" << std::string(2 * (d + 1), ' ');
     os << "]";
 }
 
+// The reference writes "shape=[2,3,\b]" - a trailing comma and a backspace, which a terminal shows as "[2,3]" and a log file does not; this host writes what the
+// terminal shows. Everything else of the text is the reference's, byte for byte (tests/test_gpu_host_diff_fuzz.py compares the two with that one substitution).
 std::ostream &operator<<(std::ostream &os, const Tensor &t) {
     if (!t.defined()) return os << "Tensor(Undefined)";
     os << "tensor(shape=[";
@@ -461,7 +468,7 @@ std::ostream &operator<<(std::ostream &os, const Tensor &t) {
     os << "], storage_offset=" << t.storage_offset() << ", dtype=" << t.dtype() << ", numel=" << t.numel() << ", dim=" << t.dim()
        << ", device=" << t.device() << ") {\n";
     std::vector<int64_t> idx;
-    if (t.numel() > 0) print_rec(os, t, idx, 0);
+    print_rec(os, t, idx, 0);
     return os << "\n}";
 }
 

@@ -413,7 +413,10 @@ def run(kf, prog):
             dt = str(c.dtype())
             if "Half" in dt or "BFloat16" in dt or "half" in dt.lower() or "bf" in dt.lower():
                 c = c.float()          # (16-bit values are exactly representable: the float image carries the same bits)
-            finals.append((dt, tuple(c.sizes()), c.numpy()))
+            # the text of the tensor ITSELF (not of its contiguous copy): shape, STRIDES, storage offset, dtype and the first twelve entries of every dim, as print(t) shows
+            # them - small tensors only (every printed element is a device-to-host copy)
+            rep = repr(t).replace(",\x08]", "]") if t.numel() <= 150 else None
+            finals.append((dt, tuple(c.sizes()), c.numpy(), rep))
         except Exception as e:  # noqa: BLE001
             finals.append(("raised", type(e).__name__))
     return status, finals, side
@@ -463,6 +466,7 @@ def compare(ref_mod, mine_mod, seed, mark=lambda s: None):
             continue
         assert a[1] == b[1], (n, a[1], b[1])
         assert a[2].dtype == b[2].dtype and a[2].shape == b[2].shape, (n, a[2].dtype, b[2].dtype, a[2].shape, b[2].shape)
+        assert a[3] == b[3], f"tensor {n}: print(t) differs (made by {origin(prog, n)}):\n{a[3]}\n--- this host:\n{b[3]}"
         if not np.array_equal(a[2].view(np.uint8), b[2].view(np.uint8)):
             bad = np.argwhere(a[2] != b[2])
             i = tuple(bad[0]) if len(bad) else ()
