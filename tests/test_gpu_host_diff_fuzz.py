@@ -409,16 +409,27 @@ def run(kf, prog):
             finals.append(None)
             continue
         try:
-            c = t.contiguous()
-            dt = str(c.dtype())
-            if "Half" in dt or "BFloat16" in dt or "half" in dt.lower() or "bf" in dt.lower():
-                c = c.float()          # (16-bit values are exactly representable: the float image carries the same bits)
-            # the text of the tensor ITSELF (not of its contiguous copy): shape, STRIDES, storage offset, dtype and the first twelve entries of every dim, as print(t) shows
-            # them - small tensors only (every printed element is a device-to-host copy)
+            dt = str(t.dtype())
+            # the text of the tensor ITSELF: shape, STRIDES, storage offset, dtype and the first twelve entries of every dim, as print(t) shows them - small tensors only
+            # (every printed element is a device-to-host copy)
             rep = repr(t).replace(",\x08]", "]") if t.numel() <= 150 else None
-            finals.append((dt, tuple(c.sizes()), c.numpy(), rep))
+            # who shares what: the number of tensors on this tensor's storage and on its implementation object (test_tensor.py:70-84) - equal counts on both hosts mean the
+            # same aliasing structure (which results are views of which, what contiguous() / a conversion to the own type / split hand back) - and item() of the first element
+            first = t.item([0] * t.dim()) if t.numel() > 0 and "half" not in dt.lower() and "bf" not in dt.lower() else None
+            finals.append([dt, tuple(t.sizes()), None, rep, (t.storage_ref_count(), t.impl_ref_count(), t.numel(), t.dim(), first)])
         except Exception as e:  # noqa: BLE001
             finals.append(("raised", type(e).__name__))
+    for k, t in enumerate(ts):      # (the values last: contiguous() makes copies, which would count as sharers above)
+        if t is None or finals[k][0] == "raised":
+            continue
+        try:
+            c = t.contiguous()
+            if "half" in finals[k][0].lower() or "bf" in finals[k][0].lower():
+                c = c.float()          # (16-bit values are exactly representable: the float image carries the same bits)
+            finals[k][2] = c.numpy()
+            del c
+        except Exception as e:  # noqa: BLE001
+            finals[k] = ("raised", type(e).__name__)
     return status, finals, side
 
 
@@ -466,6 +477,7 @@ def compare(ref_mod, mine_mod, seed, mark=lambda s: None):
             continue
         assert a[1] == b[1], (n, a[1], b[1])
         assert a[2].dtype == b[2].dtype and a[2].shape == b[2].shape, (n, a[2].dtype, b[2].dtype, a[2].shape, b[2].shape)
+        assert a[4][:4] == b[4][:4] and (a[4][4] == b[4][4] or a[4][4] != a[4][4]), f"tensor {n}: (storage_ref_count, impl_ref_count, numel, dim, item(0...)) {a[4]} on the reference host, {b[4]} on this one (made by {origin(prog, n)})"
         assert a[3] == b[3], f"tensor {n}: print(t) differs (made by {origin(prog, n)}):\n{a[3]}\n--- this host:\n{b[3]}"
         if not np.array_equal(a[2].view(np.uint8), b[2].view(np.uint8)):
             bad = np.argwhere(a[2] != b[2])
