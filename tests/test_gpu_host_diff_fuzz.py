@@ -506,7 +506,7 @@ def test_random_programs_give_the_same_bits_on_both_hosts():
     """KF_DIFF_FUZZ_SEEDS programs (default 1000) through both hosts in a CHILD process. The reference's host half reads uninitialised and freed memory on some of these
     programs (with MALLOC_PERTURB_ set it dies inside the first fifty, alone, whatever the operations; this host runs 8000 of them under MALLOC_CHECK_=3 +
     MALLOC_PERTURB_ - tools/scratch/diff_fuzz_one_host.py, profiles/r06_host_diff_fuzz.txt), and once, with 8000 collected test items, it took the whole pytest process
-    with it. So: a child that dies while the REFERENCE host is running costs that one program (at most 2 % of them may go that way) and a fresh child continues behind it;
+    with it. So: a child that dies while the REFERENCE host is running costs that one program (at most 5 % of them may go that way) and a fresh child continues behind it;
     a child that dies while THIS host runs, or any disagreement, fails the test."""
     import subprocess
     if not list(REFDIR.glob("kfunca*.so")):
@@ -538,7 +538,7 @@ def test_random_programs_give_the_same_bits_on_both_hosts():
     if diffs and os.environ.get("KF_DIFF_FUZZ_LOG"):
         Path(os.environ["KF_DIFF_FUZZ_LOG"]).write_text("\n".join(diffs) + "\n")
     assert not diffs, f"{len(diffs)} of {total} programs disagree; the first: {diffs[0]}"
-    assert len(lost) <= max(1, total // 50), f"the reference host died on {len(lost)} of {total} programs: {lost}"
+    assert len(lost) <= max(2, total // 20), f"the reference host died on {len(lost)} of {total} programs: {lost}"
     assert done + len(lost) == total, (done, lost, total)
     print(f"{done} of {total} random programs: same bits and same refusals on both hosts; the reference host died on {len(lost)}: {lost}")
 
