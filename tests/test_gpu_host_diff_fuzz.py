@@ -64,8 +64,8 @@ def make_program(seed, steps=28):
     new()
     for _ in range(steps):
         op = rng.choice(["permute", "getitem", "contiguous", "view", "binary", "scalar", "inplace", "inplace_scalar", "reduce", "moments", "convert", "cat", "split",
-                         "fill", "new", "sort", "topk", "iput", "gemm", "attn", "autograd", "invalid"],
-                        p=[.07, .11, .05, .05, .13, .05, .09, .04, .09, .04, .05, .04, .03, .02, .03, .03, .02, .02, .01, .01, .01, .01])
+                         "fill", "new", "sort", "topk", "iput", "gemm", "attn", "autograd", "invalid", "handle", "zeros"],
+                        p=[.07, .11, .05, .05, .12, .05, .09, .04, .08, .04, .05, .04, .03, .02, .03, .03, .02, .02, .01, .01, .01, .01, .01, .01])
         i = int(rng.integers(0, len(shadow)))
         s = shadow[i]
         nd = len(s["shape"])
@@ -295,6 +295,15 @@ def make_program(seed, steps=28):
                 shp = [3 if x == 1 else x for x in s["shape"]]
                 j = new(tuple(shp), "f4")
                 prog.append(("bad", "inplace", i, j))
+        elif op == "handle":
+            # copy.copy / copy.deepcopy: BOTH hand back another handle on the same implementation object in the reference (register.cpp:89-90; test_tensor.py:70-84)
+            prog.append(("handle", i, bool(rng.integers(0, 2))))
+            shadow.append(dict(s))
+        elif op == "zeros":
+            shp = rand_shape()
+            dtn = str(rng.choice(["float", "double", "int", "long", "half", "bfloat16"]))
+            prog.append(("zeros", list(shp), dtn, bool(rng.integers(0, 2))))
+            push(shp, "i" if dtn in ("int", "long") else "f", dtn if dtn in ("half", "bfloat16") else False, True)
         elif op == "fill":
             prog.append(("fill", i, float(rng.choice([0, 1, -2, 3]))))
     return prog
@@ -317,7 +326,7 @@ def run(kf, prog):
 
     for ins in prog:
         made = {"new": 1, "permute": 1, "getitem": 1, "contiguous": 1, "view": 1, "binary": 1, "scalar": 1, "reduce": 1, "moments": 2, "convert": 1, "cat": 1,
-                "split": 2, "inplace": 0, "inplace_scalar": 0, "fill": 0, "sort": 2, "topk": 2, "iput": 0, "gemm": 1, "attn": 0, "bad": 0}.get(str(ins[0]))
+                "split": 2, "inplace": 0, "inplace_scalar": 0, "fill": 0, "sort": 2, "topk": 2, "iput": 0, "gemm": 1, "attn": 0, "bad": 0, "handle": 1, "zeros": 1}.get(str(ins[0]))
         if made is None:
             made = sum(ins[2])   # autograd: one gradient per leaf that requires one
         try:
@@ -359,6 +368,12 @@ def run(kf, prog):
             elif k == "fill":
                 ts[ins[1]].fill_(ins[2])
                 out = []
+            elif k == "handle":
+                import copy
+                out = [copy.deepcopy(ts[ins[1]]) if ins[2] else copy.copy(ts[ins[1]])]
+            elif k == "zeros":
+                z = kf.zeros(ins[1], getattr(kf, ins[2]), 0)
+                out = [kf.empty_like(z).fill_(0.0) + z if ins[3] and ins[2] in ("float", "double") else z]   # (empty_like: its shape and dtype; its bytes are whatever the allocator had)
             elif k == "bad":
                 if ins[1] == "permute":
                     ts[ins[2]].permute(*ins[3])
@@ -440,7 +455,7 @@ def origin_args(ins):
 def origin(prog, n):
     """The instruction that made tensor n (for the failure message)."""
     made = {"new": 1, "permute": 1, "getitem": 1, "contiguous": 1, "view": 1, "binary": 1, "scalar": 1, "reduce": 1, "moments": 2, "convert": 1, "cat": 1, "split": 2,
-            "sort": 2, "topk": 2, "gemm": 1}
+            "sort": 2, "topk": 2, "gemm": 1, "handle": 1, "zeros": 1}
     k = 0
     for ins in prog:
         m = sum(ins[2]) if str(ins[0]) == "autograd" else made.get(str(ins[0]), 0)

@@ -12,7 +12,7 @@ import kfunca_amd as MINE  # noqa: E402
 from tests import test_gpu_host_diff_fuzz as F  # noqa: E402
 
 MADE = {"new": 1, "permute": 1, "getitem": 1, "contiguous": 1, "view": 1, "binary": 1, "scalar": 1, "reduce": 1, "moments": 2, "convert": 1, "cat": 1, "split": 2,
-        "sort": 2, "topk": 2, "gemm": 1}
+        "sort": 2, "topk": 2, "gemm": 1, "handle": 1, "zeros": 1}
 def makers(prog):
     out, k = {}, 0
     for n, ins in enumerate(prog):
