@@ -433,10 +433,23 @@ static double item_as_double(const Tensor &t, const std::vector<int64_t> &idx) {
     }
 }
 
+static int64_t item_as_int64(const Tensor &t, const std::vector<int64_t> &idx) { // the integer types, exactly (a double holds 53 bits)
+    any_t raw = t.item(idx);
+    switch (t.dtype()) {
+    case ScalarType::Bool: return *reinterpret_cast<uint8_t *>(raw.val) != 0;
+    case ScalarType::Byte: return *reinterpret_cast<uint8_t *>(raw.val);
+    case ScalarType::Char: return *reinterpret_cast<int8_t *>(raw.val);
+    case ScalarType::Short: return *reinterpret_cast<int16_t *>(raw.val);
+    case ScalarType::Int: return *reinterpret_cast<int32_t *>(raw.val);
+    case ScalarType::Long: return *reinterpret_cast<int64_t *>(raw.val);
+    default: return 0;
+    }
+}
+
 static void print_rec(std::ostream &os, const Tensor &t, std::vector<int64_t> &idx, int d) {
     if (d == t.dim()) { // an element, as the reference streams its accumulate type: integers as integers, floats with five decimals, always signed
         if (is_floating_type(t.dtype())) os << std::fixed << std::showpos << std::setprecision(5) << item_as_double(t, idx) << std::noshowpos;
-        else os << std::showpos << (int64_t)item_as_double(t, idx) << std::noshowpos;
+        else os << std::showpos << item_as_int64(t, idx) << std::noshowpos;
         return;
     }
     if (d > 0) os << "\n";
